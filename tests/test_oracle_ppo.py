@@ -1,0 +1,51 @@
+"""Oracle PPO-Lagrangian update vs golden vectors recorded from the unmodified reference.
+
+Same torch CPU ops in the same order => agreement to rounding of BLAS blocking only.
+Tolerances: per-step stats 2e-5 abs+rel, parameters 2e-6 abs (fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import oracle_cfg_and_data, ppo_case
+from oracle.pid import rescaling_factor
+from oracle.ppo_lag import PPOLagOracle, split_chunks
+
+CASES = ["tiny", "c1", "c2", "earlystop", "dualclip"]
+
+
+def test_split_chunks_matches_tianshou_semantics():
+    # 292 rows, size 64: 3 full chunks then 64+36 merged
+    ch = split_chunks(292, 64, np.arange(292))
+    assert [len(c) for c in ch] == [64, 64, 64, 100]
+    assert [len(c) for c in split_chunks(256, 64, None)] == [64] * 4
+    assert [len(c) for c in split_chunks(10, 64, None)] == [10]
+    assert [len(c) for c in split_chunks(100, 64, None, merge_last=False)] == [64, 36]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_process_fn(name):
+    torch.set_num_threads(4)
+    cfg, g = ppo_case(name)
+    ocfg, data = oracle_cfg_and_data(cfg, g)
+    o = PPOLagOracle(ocfg)
+    o.set_params(g["theta0"])
+    pb = o.process(data)
+    for k in ("values", "rets", "advs", "logp_old"):
+        np.testing.assert_allclose(pb[k].numpy(), g[k], rtol=1e-5, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_full_update(name):
+    torch.set_num_threads(4)
+    cfg, g = ppo_case(name)
+    ocfg, data = oracle_cfg_and_data(cfg, g)
+    o = PPOLagOracle(ocfg)
+    o.set_params(g["theta0"])
+    lag = g["lagrangian"]
+    pb, stats, stopped = o.update(data, lag, rescaling_factor(lag), cfg["batch_size"],
+                                  cfg["repeat"], perms=g["perms"])
+    assert stats.shape == g["stats"].shape
+    assert o.gradient_steps == int(g["gradient_steps"])
+    assert (stopped >= 0) == bool(g["early_stop_msgs"])
+    np.testing.assert_allclose(stats, g["stats"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(o.get_params(), g["theta_final"], rtol=0, atol=2e-6)
