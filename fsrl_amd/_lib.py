@@ -1,0 +1,91 @@
+"""ctypes binding of libfsrl_hip.so (C ABI: include/fsrl_hip.h).  Fails loudly if absent."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfsrl_hip.so")
+
+FSRL_OK, FSRL_EINVAL, FSRL_ENOMEM, FSRL_EHIP, FSRL_ESTATE = 0, -22, -12, -5, -1
+PPO_NSTATS = 11
+ALGO_PPO_LAG, ALGO_TRPO_LAG, ALGO_CPO, ALGO_SAC_LAG = 0, 1, 2, 3
+
+
+class Config(C.Structure):
+    """struct fsrl_config (include/fsrl_hip.h)"""
+    _fields_ = [("algo", C.c_int32), ("obs_dim", C.c_int32), ("act_dim", C.c_int32),
+                ("hidden", C.c_int32), ("n_critics", C.c_int32), ("env_num", C.c_int32),
+                ("buffer_size", C.c_int64), ("max_action", C.c_float), ("gamma", C.c_double),
+                ("gae_lambda", C.c_double), ("eps_clip", C.c_float), ("dual_clip", C.c_float),
+                ("vf_coef", C.c_float), ("max_grad_norm", C.c_float), ("target_kl", C.c_float),
+                ("norm_adv", C.c_int32), ("use_lagrangian", C.c_int32), ("lr", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float)]
+
+
+_P = C.POINTER
+_f, _d, _u8, _i32, _i64 = _P(C.c_float), _P(C.c_double), _P(C.c_uint8), _P(C.c_int32), _P(C.c_int64)
+_ctx = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/fsrl_hip.h declares
+SIGNATURES = {
+    "fsrl_last_error": (C.c_char_p, []),
+    "fsrl_config_default": (None, [_P(Config)]),
+    "fsrl_ctx_create": (C.c_int, [C.c_int, _P(Config), _P(_ctx)]),
+    "fsrl_ctx_destroy": (C.c_int, [_ctx]),
+    "fsrl_sync": (C.c_int, [_ctx]),
+    "fsrl_param_count": (C.c_int64, [_ctx]),
+    "fsrl_params_set": (C.c_int, [_ctx, _f, C.c_int64]),
+    "fsrl_params_get": (C.c_int, [_ctx, _f, C.c_int64]),
+    "fsrl_grads_get": (C.c_int, [_ctx, _f, C.c_int64]),
+    "fsrl_optim_reset": (C.c_int, [_ctx]),
+    "fsrl_store_push": (C.c_int, [_ctx, _i32, C.c_int32, _f, _f, _d, _d, _u8, _u8, _f, _i64, _d, _i32, _i64]),
+    "fsrl_store_reset": (C.c_int, [_ctx, C.c_int]),
+    "fsrl_store_len": (C.c_int64, [_ctx]),
+    "fsrl_store_sample0": (C.c_int, [_ctx, _i64, C.c_int64, _i64]),
+    "fsrl_actor_forward": (C.c_int, [_ctx, _f, C.c_int32, _f, _f]),
+    "fsrl_ppo_begin": (C.c_int, [_ctx, _d, C.c_double, C.c_int32, _i64]),
+    "fsrl_ppo_pass": (C.c_int, [_ctx, _i64, C.c_uint64, _i32]),
+    "fsrl_ppo_end": (C.c_int, [_ctx, _f, C.c_int64, _i64]),
+    "fsrl_ppo_update": (C.c_int, [_ctx, _d, C.c_double, C.c_int32, C.c_int32, _i64, C.c_uint64, _f,
+                                  C.c_int64, _i64, _i32]),
+    "fsrl_batch_get": (C.c_int, [_ctx, C.c_char_p, _f, C.c_int64]),
+    "fsrl_gae_return": (C.c_int, [_ctx, _f, _f, _d, _u8, C.c_int64, C.c_double, C.c_double, _d]),
+    "fsrl_set_profiling": (C.c_int, [_ctx, C.c_int]),
+    "fsrl_last_timing": (C.c_int, [_ctx, _d, C.c_int32]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raise (never fall back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with fsrl_amd/csrc/build.sh (hipcc, gfx950). "
+            "fsrl_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and the header drifted apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class FsrlHipError(RuntimeError):
+    pass
+
+
+def check(rc):
+    """Map C status codes to the exception types the reference raises for the same fault
+    (assert -> AssertionError for argument violations; RuntimeError otherwise)."""
+    if rc == FSRL_OK:
+        return
+    msg = load().fsrl_last_error().decode("utf-8", "replace")
+    if rc == FSRL_EINVAL:
+        raise AssertionError(msg)
+    if rc == FSRL_ENOMEM:
+        raise MemoryError(msg)
+    raise FsrlHipError(f"[{rc}] {msg}")

@@ -1,0 +1,77 @@
+// common.hpp -- shared types for libfsrl_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fsrl_hip.h"
+
+#define FSRL_MAX_NETS (1 + FSRL_MAX_CRITICS)
+#define FSRL_TILE_M 16      // rows of one MFMA M-tile (v_mfma_f32_16x16x4_f32)
+#define FSRL_DOW 32         // floats per row of the dout side buffer: [0,16) dout, [16,32) dsigma
+#define FSRL_MAX_OBS 128
+#define FSRL_MAX_ACT 16
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Offsets (in floats) of one network inside the flat parameter / gradient / Adam vectors.
+struct NetOff {
+    int sigma;  // -1 for critics
+    int W1, b1, W2, b2, W3, b3;
+    int out;    // output width of the head (Da for the actor, 1 for a V critic)
+    int begin, end;  // [begin,end) slice of the flat vector owned by this net
+};
+
+struct ModelDesc {
+    int Do, Da, H, n_nets;  // n_nets = 1 + n_critics ; net 0 = actor
+    NetOff net[FSRL_MAX_NETS];
+};
+
+// Scalars of one PPO minibatch step that the kernels need (passed by value).
+struct PpoStepArgs {
+    int mb_start;   // offset of this minibatch inside the pass permutation
+    int mb_size;    // rows in this minibatch (B, or up to 2B-1 for the merged last one)
+    int step;       // global step index inside the update (row of the stats table)
+    int mb_index;   // index into the per-minibatch advantage statistics of this pass
+    int last_in_pass;
+    int first_in_pass;
+    int iters_in_pass;
+    int pass;       // index of the pass inside the update (for the KL early-stop gate)
+    float rescale;  // 1/(sum(lambda)+1)
+    float lam[FSRL_MAX_CRITICS];  // lambda_i for cost critic i (index 0 = first cost)
+    float eps_clip, dual_clip, vf_coef, max_action, max_grad_norm, target_kl;
+    int norm_adv, use_lagrangian;
+    // Adam
+    float lr, beta1, beta2, adam_eps;
+    float one_minus_b1, one_minus_b2;  // (float)(1.0 - (double)beta), torch's lerp/addcmul scalars
+    double kl_thresh;  // 1.5 * target_kl in float64 (python float in the reference)
+    float step_size;   // lr / (1 - beta1^t)          (host float64 -> f32, like torch)
+    float bc2_sqrt;    // sqrt(1 - beta2^t)
+};
+
+// Device-resident control block (one per context).
+struct CtrlBlock {
+    int stopped_after;   // passes with index > stopped_after are skipped (INT_MAX = none)
+    int pad;
+    double kl_sum;       // sum of per-minibatch approx-KL of the current pass (python float sum)
+    float last_grad_norm;
+    float pad2;
+};
+
+__device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
+    // D[16x16] += A[16x4] * B[4x16]; lane l: a = A[l&15][l>>4], b = B[l>>4][l&15];
+    // c[r] = D[4*(l>>4)+r][l&15]
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

@@ -1,0 +1,874 @@
+// fsrl_hip.hip -- C ABI of libfsrl_hip.so (see include/fsrl_hip.h).  gfx950 only.
+//
+// Host side: context, parameter plumbing, the HIP-resident transition store (pinned staging +
+// hipMemcpyAsync on a side stream), and the launch sequences of the policy update.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels_misc.hpp"
+#include "kernels_mlp.hpp"
+
+// ------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return fail(FSRL_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+#define CHECK_ARG(cond, ...) \
+    do { if (!(cond)) return fail(FSRL_EINVAL, __VA_ARGS__); } while (0)
+
+extern "C" const char* fsrl_last_error(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------------------ context
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct TensorMap { int api_off, dev_off, n; };   // one parameter tensor: flat API offset -> device
+
+struct EnvBook {           // tianshou ReplayBuffer bookkeeping of one sub-buffer (host side)
+    int64_t index = 0, size = 0, last_index = 0;
+    double ep_rew = 0.0;
+    int32_t ep_len = 0;
+    int64_t ep_idx = 0;
+};
+
+struct Staging {           // pinned host staging + its device mirror (one of two)
+    int* slot = nullptr; float* obs = nullptr; float* obs_next = nullptr; float* act = nullptr;
+    double* rew = nullptr; double* cost = nullptr; uint8_t* flags = nullptr;
+    int* d_slot = nullptr; float* d_obs = nullptr; float* d_obs_next = nullptr; float* d_act = nullptr;
+    double* d_rew = nullptr; double* d_cost = nullptr; uint8_t* d_flags = nullptr;
+    int count = 0;
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+};
+
+struct fsrl_ctx {
+    fsrl_config cfg{};
+    int device = 0;
+    hipStream_t compute = nullptr, side = nullptr;
+    ModelDesc md{};
+    std::vector<TensorMap> tmap;
+    int64_t n_api = 0;     // flat parameter count (API)
+    int n_dev = 0;         // padded device parameter count
+    float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr;
+    int64_t adam_t = 0;
+    CtrlBlock* ctrl = nullptr;
+    CtrlBlock* h_ctrl = nullptr;  // pinned
+
+    // store
+    int64_t sub_size = 0, maxsize = 0;
+    std::vector<EnvBook> env;
+    std::vector<uint8_t> h_flags;      // host mirror of (terminated|truncated<<1) per slot
+    StorePtrs st{};
+    static constexpr int STAGE_CAP = 4096;
+    Staging stage[2];
+    int cur_stage = 0;
+    hipEvent_t store_ready = nullptr;
+
+    // batch (sample(0) order)
+    BatchPtrs b{};
+    int* d_indices = nullptr; uint8_t* d_end = nullptr; int* d_seg = nullptr;
+    int* h_indices = nullptr; uint8_t* h_end = nullptr; int* h_seg = nullptr;  // pinned
+    float *values = nullptr, *vnext = nullptr, *advs = nullptr, *rets = nullptr, *logp_old = nullptr;
+    int64_t N = 0;
+    bool batch_ready = false;
+
+    // ppo working set
+    int batch_size = 0, mbp_max = 0, n_tiles_max = 0;
+    float *A1 = nullptr, *A2 = nullptr, *D1 = nullptr, *D2 = nullptr, *DO = nullptr, *XB = nullptr;
+    float *statp = nullptr, *gsq_part = nullptr, *mbstats = nullptr;
+    int *d_perm = nullptr, *h_perm = nullptr;            // [N] (pinned host)
+    int *d_mbstart = nullptr, *d_mbsize = nullptr, *h_mbplan = nullptr;  // h_mbplan pinned [2*cap]
+    size_t mb_cap = 0;
+    std::vector<int> mb_start, mb_size;
+    float* d_stats = nullptr; int64_t stats_cap = 0;     // [steps][11]
+    int64_t n_steps = 0;
+    int pass_index = 0;
+    double lagr[FSRL_MAX_CRITICS] = {0, 0, 0, 0};
+    double rescaling = 1.0;
+    bool in_update = false;
+
+    // scratch for the small host-pointer APIs
+    void* scratch = nullptr; size_t scratch_bytes = 0;
+
+    // timing
+    bool profiling = false;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
+    std::vector<hipEvent_t> k_ev;     // pairs around the fwd/bwd kernel (profiling mode)
+    size_t k_ev_used = 0;
+    double t_process_ms = 0, t_learn_ms = 0, t_fwdbwd_ms = 0;
+    int64_t n_fwdbwd = 0;
+    uint64_t rng[4] = {0x9E3779B97F4A7C15ull, 0xBF58476D1CE4E5B9ull, 0x94D049BB133111EBull, 1};
+};
+
+static int ensure_scratch(fsrl_ctx* c, size_t bytes) {
+    if (c->scratch_bytes >= bytes) return 0;
+    if (c->scratch) HIPCHK(hipFree(c->scratch));
+    c->scratch = nullptr; c->scratch_bytes = 0;
+    HIPCHK(hipMalloc(&c->scratch, bytes));
+    c->scratch_bytes = bytes;
+    return 0;
+}
+
+extern "C" void fsrl_config_default(fsrl_config* c) {
+    // defaults of PPOLagAgent.__init__ (fsrl/agent/ppo_lag_agent.py:82-116)
+    memset(c, 0, sizeof(*c));
+    c->algo = FSRL_ALGO_PPO_LAG;
+    c->obs_dim = 8; c->act_dim = 2; c->hidden = 128; c->n_critics = 2;
+    c->env_num = 20; c->buffer_size = 100000; c->max_action = 1.0f;
+    c->gamma = 0.99; c->gae_lambda = 0.95; c->eps_clip = 0.2f; c->dual_clip = 0.0f;
+    c->vf_coef = 0.25f; c->max_grad_norm = 0.0f; c->target_kl = 0.02f;
+    c->norm_adv = 1; c->use_lagrangian = 1;
+    c->lr = 5e-4f; c->beta1 = 0.9f; c->beta2 = 0.999f; c->adam_eps = 1e-8f;
+}
+
+static void build_layout(fsrl_ctx* c) {
+    const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim, H = c->cfg.hidden;
+    ModelDesc& md = c->md;
+    md.Do = Do; md.Da = Da; md.H = H; md.n_nets = 1 + c->cfg.n_critics;
+    int api = 0, dev = 0;
+    auto add = [&](int n) {
+        TensorMap t{api, dev, n};
+        c->tmap.push_back(t);
+        api += n;
+        dev = round_up(dev + n, 64);  // every tensor starts 256-byte aligned on the device
+        return t.dev_off;
+    };
+    for (int net = 0; net < md.n_nets; ++net) {
+        NetOff& no = md.net[net];
+        no.begin = dev;
+        const int out = (net == 0) ? Da : 1;
+        no.out = out;
+        no.sigma = (net == 0) ? add(Da) : -1;
+        no.W1 = add(H * Do); no.b1 = add(H);
+        no.W2 = add(H * H);  no.b2 = add(H);
+        no.W3 = add(out * H); no.b3 = add(out);
+        no.end = dev;
+    }
+    c->n_api = api;
+    c->n_dev = round_up(dev, 256);
+}
+
+extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    void* dptrs[] = {c->P, c->M, c->V, c->G, c->ctrl, c->st.obs, c->st.obs_next, c->st.act, c->st.rew,
+                     c->st.cost, c->st.flags, c->b.obs, c->b.obs_next, c->b.act, c->b.rew, c->b.cost,
+                     c->b.flags, c->d_indices, c->d_end, c->d_seg, c->values, c->vnext, c->advs,
+                     c->rets, c->logp_old, c->A1, c->A2, c->D1, c->D2, c->DO, c->XB, c->statp,
+                     c->gsq_part, c->mbstats, c->d_perm, c->d_mbstart, c->d_mbsize, c->d_stats,
+                     c->scratch};
+    for (void* p : dptrs) if (p) (void)hipFree(p);
+    void* hptrs[] = {c->h_ctrl, c->h_indices, c->h_end, c->h_seg, c->h_perm, c->h_mbplan};
+    for (void* p : hptrs) if (p) (void)hipHostFree(p);
+    for (auto& s : c->stage) {
+        void* hp[] = {s.slot, s.obs, s.obs_next, s.act, s.rew, s.cost, s.flags};
+        for (void* p : hp) if (p) (void)hipHostFree(p);
+        void* dp[] = {s.d_slot, s.d_obs, s.d_obs_next, s.d_act, s.d_rew, s.d_cost, s.d_flags};
+        for (void* p : dp) if (p) (void)hipFree(p);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    for (hipEvent_t e : {c->store_ready, c->ev_a, c->ev_b, c->ev_c}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->k_ev) (void)hipEventDestroy(e);
+    if (c->compute) (void)hipStreamDestroy(c->compute);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    delete c;
+    return 0;
+}
+
+extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx** out) {
+    CHECK_ARG(cfg && out, "null argument");
+    CHECK_ARG(cfg->algo == FSRL_ALGO_PPO_LAG, "algo %d not built in this library version", cfg->algo);
+    CHECK_ARG(cfg->obs_dim >= 1 && cfg->obs_dim <= FSRL_MAX_OBS, "obs_dim must be in [1,%d]", FSRL_MAX_OBS);
+    CHECK_ARG(cfg->act_dim >= 1 && cfg->act_dim <= FSRL_MAX_ACT, "act_dim must be in [1,%d]", FSRL_MAX_ACT);
+    CHECK_ARG(cfg->hidden == 64 || cfg->hidden == 128 || cfg->hidden == 256,
+              "hidden must be 64, 128 or 256 (two equal hidden layers)");
+    CHECK_ARG(cfg->n_critics >= 1 && cfg->n_critics <= 2,
+              "n_critics must be 1 or 2 (reward [+ one cost], get_metrics base_policy.py:377-382)");
+    CHECK_ARG(cfg->env_num >= 1 && cfg->buffer_size >= cfg->env_num, "bad env_num/buffer_size");
+    CHECK_ARG(cfg->gamma >= 0.0 && cfg->gamma <= 1.0, "discount factor should be in [0, 1].");
+    CHECK_ARG(cfg->gae_lambda >= 0.0 && cfg->gae_lambda <= 1.0, "GAE lambda should be in [0, 1].");
+    CHECK_ARG(cfg->dual_clip == 0.0f || cfg->dual_clip > 1.0f,
+              "Dual-clip PPO parameter should greater than 1.0.");
+    CHECK_ARG(cfg->buffer_size + cfg->env_num < (int64_t)INT_MAX / 2, "buffer too large for 32-bit slot ids");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    CHECK_ARG(device_id >= 0 && device_id < ndev, "device %d not present (%d devices)", device_id, ndev);
+    HIPCHK(hipSetDevice(device_id));
+    fsrl_ctx* c = new fsrl_ctx();
+    c->cfg = *cfg;
+    c->device = device_id;
+    build_layout(c);
+#define TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { fail(FSRL_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); fsrl_ctx_destroy(c); return FSRL_EHIP; } } while (0)
+    TRY(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
+    TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    const size_t pb = (size_t)c->n_dev * sizeof(float);
+    TRY(hipMalloc(&c->P, pb)); TRY(hipMalloc(&c->M, pb)); TRY(hipMalloc(&c->V, pb)); TRY(hipMalloc(&c->G, pb));
+    TRY(hipMemset(c->P, 0, pb)); TRY(hipMemset(c->M, 0, pb)); TRY(hipMemset(c->V, 0, pb)); TRY(hipMemset(c->G, 0, pb));
+    TRY(hipMalloc(&c->ctrl, sizeof(CtrlBlock)));
+    TRY(hipHostMalloc(&c->h_ctrl, sizeof(CtrlBlock)));
+    // store: n sub-buffers of ceil(total/n) rows (tianshou VectorReplayBuffer)
+    c->sub_size = (cfg->buffer_size + cfg->env_num - 1) / cfg->env_num;
+    c->maxsize = c->sub_size * cfg->env_num;
+    c->env.resize(cfg->env_num);
+    c->h_flags.assign((size_t)c->maxsize, 0);
+    const size_t ms = (size_t)c->maxsize;
+    const int Do = cfg->obs_dim, Da = cfg->act_dim;
+    TRY(hipMalloc(&c->st.obs, ms * Do * 4)); TRY(hipMalloc(&c->st.obs_next, ms * Do * 4));
+    TRY(hipMalloc(&c->st.act, ms * Da * 4)); TRY(hipMalloc(&c->st.rew, ms * 8));
+    TRY(hipMalloc(&c->st.cost, ms * 8)); TRY(hipMalloc(&c->st.flags, ms));
+    TRY(hipMalloc(&c->b.obs, ms * Do * 4)); TRY(hipMalloc(&c->b.obs_next, ms * Do * 4));
+    TRY(hipMalloc(&c->b.act, ms * Da * 4)); TRY(hipMalloc(&c->b.rew, ms * 8));
+    TRY(hipMalloc(&c->b.cost, ms * 8)); TRY(hipMalloc(&c->b.flags, ms));
+    TRY(hipMalloc(&c->d_indices, ms * 4)); TRY(hipMalloc(&c->d_end, ms)); TRY(hipMalloc(&c->d_seg, (ms + 2) * 4));
+    TRY(hipHostMalloc(&c->h_indices, ms * 4)); TRY(hipHostMalloc(&c->h_end, ms)); TRY(hipHostMalloc(&c->h_seg, (ms + 2) * 4));
+    const int C = cfg->n_critics;
+    TRY(hipMalloc(&c->values, ms * C * 4)); TRY(hipMalloc(&c->vnext, ms * C * 4));
+    TRY(hipMalloc(&c->advs, ms * C * 4)); TRY(hipMalloc(&c->rets, ms * C * 4));
+    TRY(hipMalloc(&c->logp_old, ms * 4));
+    TRY(hipMalloc(&c->d_perm, ms * 4)); TRY(hipHostMalloc(&c->h_perm, ms * 4));
+    for (auto& s : c->stage) {
+        const size_t k = fsrl_ctx::STAGE_CAP;
+        TRY(hipHostMalloc(&s.slot, k * 4)); TRY(hipHostMalloc(&s.obs, k * Do * 4));
+        TRY(hipHostMalloc(&s.obs_next, k * Do * 4)); TRY(hipHostMalloc(&s.act, k * Da * 4));
+        TRY(hipHostMalloc(&s.rew, k * 8)); TRY(hipHostMalloc(&s.cost, k * 8)); TRY(hipHostMalloc(&s.flags, k));
+        TRY(hipMalloc(&s.d_slot, k * 4)); TRY(hipMalloc(&s.d_obs, k * Do * 4));
+        TRY(hipMalloc(&s.d_obs_next, k * Do * 4)); TRY(hipMalloc(&s.d_act, k * Da * 4));
+        TRY(hipMalloc(&s.d_rew, k * 8)); TRY(hipMalloc(&s.d_cost, k * 8)); TRY(hipMalloc(&s.d_flags, k));
+        TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    TRY(hipEventCreateWithFlags(&c->store_ready, hipEventDisableTiming));
+    TRY(hipEventCreate(&c->ev_a)); TRY(hipEventCreate(&c->ev_b)); TRY(hipEventCreate(&c->ev_c));
+    CtrlBlock init{INT_MAX, 0, 0.0, 0.0f, 0.0f};
+    TRY(hipMemcpy(c->ctrl, &init, sizeof(init), hipMemcpyHostToDevice));
+#undef TRY
+    *out = c;
+    return 0;
+}
+
+extern "C" int fsrl_sync(fsrl_ctx* c) {
+    CHECK_ARG(c, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->side));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ parameters
+extern "C" int64_t fsrl_param_count(const fsrl_ctx* c) { return c ? c->n_api : 0; }
+
+static int copy_flat(fsrl_ctx* c, float* dev, float* host_out, const float* host_in, int64_t n) {
+    CHECK_ARG(n == c->n_api, "expected %lld parameters, got %lld", (long long)c->n_api, (long long)n);
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<float> tmp((size_t)c->n_dev, 0.0f);
+    if (host_in) {
+        for (const TensorMap& t : c->tmap) memcpy(&tmp[t.dev_off], host_in + t.api_off, (size_t)t.n * 4);
+        HIPCHK(hipStreamSynchronize(c->compute));
+        HIPCHK(hipMemcpy(dev, tmp.data(), (size_t)c->n_dev * 4, hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(hipStreamSynchronize(c->compute));
+        HIPCHK(hipMemcpy(tmp.data(), dev, (size_t)c->n_dev * 4, hipMemcpyDeviceToHost));
+        for (const TensorMap& t : c->tmap) memcpy(host_out + t.api_off, &tmp[t.dev_off], (size_t)t.n * 4);
+    }
+    return 0;
+}
+
+extern "C" int fsrl_params_set(fsrl_ctx* c, const float* flat, int64_t n) {
+    CHECK_ARG(c && flat, "null argument");
+    return copy_flat(c, c->P, nullptr, flat, n);
+}
+extern "C" int fsrl_params_get(fsrl_ctx* c, float* flat, int64_t n) {
+    CHECK_ARG(c && flat, "null argument");
+    return copy_flat(c, c->P, flat, nullptr, n);
+}
+extern "C" int fsrl_grads_get(fsrl_ctx* c, float* flat, int64_t n) {
+    CHECK_ARG(c && flat, "null argument");
+    return copy_flat(c, c->G, flat, nullptr, n);
+}
+extern "C" int fsrl_optim_reset(fsrl_ctx* c) {
+    CHECK_ARG(c, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    HIPCHK(hipMemset(c->M, 0, (size_t)c->n_dev * 4));
+    HIPCHK(hipMemset(c->V, 0, (size_t)c->n_dev * 4));
+    c->adam_t = 0;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ store
+static int flush_stage(fsrl_ctx* c) {
+    Staging& s = c->stage[c->cur_stage];
+    if (s.count == 0) return 0;
+    const int k = s.count, Do = c->cfg.obs_dim, Da = c->cfg.act_dim;
+    HIPCHK(hipMemcpyAsync(s.d_slot, s.slot, (size_t)k * 4, hipMemcpyHostToDevice, c->side));
+    HIPCHK(hipMemcpyAsync(s.d_obs, s.obs, (size_t)k * Do * 4, hipMemcpyHostToDevice, c->side));
+    HIPCHK(hipMemcpyAsync(s.d_obs_next, s.obs_next, (size_t)k * Do * 4, hipMemcpyHostToDevice, c->side));
+    HIPCHK(hipMemcpyAsync(s.d_act, s.act, (size_t)k * Da * 4, hipMemcpyHostToDevice, c->side));
+    HIPCHK(hipMemcpyAsync(s.d_rew, s.rew, (size_t)k * 8, hipMemcpyHostToDevice, c->side));
+    HIPCHK(hipMemcpyAsync(s.d_cost, s.cost, (size_t)k * 8, hipMemcpyHostToDevice, c->side));
+    HIPCHK(hipMemcpyAsync(s.d_flags, s.flags, (size_t)k, hipMemcpyHostToDevice, c->side));
+    const int per = 2 * Do + Da + 1;
+    const int blocks = std::min(1024, (k * per + 255) / 256);
+    hipLaunchKernelGGL(store_scatter_kernel, dim3(blocks), dim3(256), 0, c->side, c->st, s.d_slot, s.d_obs,
+                       s.d_obs_next, s.d_act, s.d_rew, s.d_cost, s.d_flags, k, Do, Da);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s.done, c->side));
+    s.in_flight = true;
+    s.count = 0;
+    c->cur_stage ^= 1;
+    Staging& nx = c->stage[c->cur_stage];
+    if (nx.in_flight) {  // the other buffer's copies must have left pinned memory before reuse
+        HIPCHK(hipEventSynchronize(nx.done));
+        nx.in_flight = false;
+    }
+    return 0;
+}
+
+extern "C" int fsrl_store_push(fsrl_ctx* c, const int32_t* env_ids, int32_t k, const float* obs,
+                               const float* act, const double* rew, const double* cost,
+                               const uint8_t* terminated, const uint8_t* truncated,
+                               const float* obs_next, int64_t* ptr_out, double* ep_rew_out,
+                               int32_t* ep_len_out, int64_t* ep_idx_out) {
+    CHECK_ARG(c && env_ids && obs && act && rew && terminated && truncated && obs_next, "null argument");
+    CHECK_ARG(k >= 0 && k <= c->cfg.env_num, "k=%d rows but %d sub-buffers", k, c->cfg.env_num);
+    HIPCHK(hipSetDevice(c->device));
+    const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim;
+    for (int j = 0; j < k; ++j) {
+        const int e = env_ids[j];
+        CHECK_ARG(e >= 0 && e < c->cfg.env_num, "buffer id %d out of range", e);
+        if (c->stage[c->cur_stage].count == fsrl_ctx::STAGE_CAP) {
+            int rc = flush_stage(c);
+            if (rc) return rc;
+        }
+        Staging& s = c->stage[c->cur_stage];
+        EnvBook& eb = c->env[e];
+        const int64_t ptr = eb.index;
+        const int64_t gptr = ptr + (int64_t)e * c->sub_size;
+        const int i = s.count++;
+        s.slot[i] = (int)gptr;
+        memcpy(s.obs + (size_t)i * Do, obs + (size_t)j * Do, (size_t)Do * 4);
+        memcpy(s.obs_next + (size_t)i * Do, obs_next + (size_t)j * Do, (size_t)Do * 4);
+        memcpy(s.act + (size_t)i * Da, act + (size_t)j * Da, (size_t)Da * 4);
+        s.rew[i] = rew[j];
+        s.cost[i] = cost ? cost[j] : 0.0;
+        const uint8_t fl = (uint8_t)((terminated[j] ? 1 : 0) | (truncated[j] ? 2 : 0));
+        s.flags[i] = fl;
+        c->h_flags[(size_t)gptr] = fl;
+        // ReplayBuffer.add bookkeeping (ptr, ep_rew, ep_len, ep_idx)
+        eb.last_index = ptr;
+        eb.size = std::min(eb.size + 1, c->sub_size);
+        eb.index = (eb.index + 1) % c->sub_size;
+        eb.ep_rew += rew[j];
+        eb.ep_len += 1;
+        const bool done = fl != 0;
+        if (ptr_out) ptr_out[j] = gptr;
+        if (done) {
+            if (ep_rew_out) ep_rew_out[j] = eb.ep_rew;
+            if (ep_len_out) ep_len_out[j] = eb.ep_len;
+            if (ep_idx_out) ep_idx_out[j] = eb.ep_idx + (int64_t)e * c->sub_size;
+            eb.ep_rew = 0.0; eb.ep_len = 0; eb.ep_idx = eb.index;
+        } else {
+            if (ep_rew_out) ep_rew_out[j] = 0.0;
+            if (ep_len_out) ep_len_out[j] = 0;
+            if (ep_idx_out) ep_idx_out[j] = eb.ep_idx + (int64_t)e * c->sub_size;
+        }
+    }
+    return 0;
+}
+
+extern "C" int fsrl_store_reset(fsrl_ctx* c, int keep_statistics) {
+    CHECK_ARG(c, "null ctx");
+    (void)keep_statistics;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = flush_stage(c);   // rows already staged still land (then become unreachable)
+    if (rc) return rc;
+    for (EnvBook& e : c->env) e = EnvBook();
+    c->batch_ready = false;
+    return 0;
+}
+
+extern "C" int64_t fsrl_store_len(const fsrl_ctx* c) {
+    int64_t n = 0;
+    if (c) for (const EnvBook& e : c->env) n += e.size;
+    return n;
+}
+
+// sample_indices(0): concat over sub-buffers of [index, size) ++ [0, index)  (+offset)
+static int64_t sample0(const fsrl_ctx* c, int* idx, uint8_t* endf) {
+    int64_t n = 0;
+    for (int e = 0; e < c->cfg.env_num; ++e) {
+        const EnvBook& eb = c->env[e];
+        const int64_t off = (int64_t)e * c->sub_size;
+        const int64_t first = n;
+        for (int64_t i = eb.index; i < eb.size; ++i) idx[n++] = (int)(off + i);
+        for (int64_t i = 0; i < eb.index; ++i) idx[n++] = (int)(off + i);
+        if (endf) {
+            for (int64_t r = first; r < n; ++r) endf[r] = c->h_flags[(size_t)idx[r]] != 0;
+            // unfinished_index(): the last written row of a sub-buffer is always the final row
+            // of its sample(0) range; if it is not done the GAE scan must still stop there
+            if (n > first) endf[n - 1] = 1;
+        }
+    }
+    return n;
+}
+
+extern "C" int fsrl_store_sample0(fsrl_ctx* c, int64_t* out, int64_t cap, int64_t* n_out) {
+    CHECK_ARG(c && n_out, "null argument");
+    const int64_t n = sample0(c, c->h_indices, nullptr);
+    *n_out = n;
+    if (out) {
+        CHECK_ARG(cap >= n, "indices_out too small (%lld < %lld)", (long long)cap, (long long)n);
+        for (int64_t i = 0; i < n; ++i) out[i] = c->h_indices[i];
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ launch helpers
+template <typename F>
+static int dispatch_H(int H, F&& f) {
+    switch (H) {
+        case 64: return f(std::integral_constant<int, 64>());
+        case 128: return f(std::integral_constant<int, 128>());
+        case 256: return f(std::integral_constant<int, 256>());
+    }
+    return fail(FSRL_EINVAL, "unsupported hidden width %d", H);
+}
+
+static int launch_infer(fsrl_ctx* c, const InferArgs& ia, int jobs_y, hipStream_t s) {
+    const int tiles = (ia.N + 15) / 16;
+    if (tiles == 0) return 0;
+    return dispatch_H(c->cfg.hidden, [&](auto hc) {
+        constexpr int H = decltype(hc)::value;
+        hipLaunchKernelGGL(mlp_infer_kernel<H>, dim3(tiles, jobs_y), dim3(256), 0, s, c->P, c->md, ia);
+        HIPCHK(hipGetLastError());
+        return 0;
+    });
+}
+
+// ------------------------------------------------------------------------------ actor forward
+extern "C" int fsrl_actor_forward(fsrl_ctx* c, const float* obs, int32_t k, float* mu_out,
+                                  float* sigma_out) {
+    CHECK_ARG(c && obs && mu_out, "null argument");
+    CHECK_ARG(k >= 0, "negative row count");
+    HIPCHK(hipSetDevice(c->device));
+    const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim;
+    if (k > 0) {
+        const size_t ob = (size_t)k * Do * 4, mb = (size_t)k * Da * 4;
+        int rc = ensure_scratch(c, ob + mb + 256);
+        if (rc) return rc;
+        float* d_obs = (float*)c->scratch;
+        float* d_mu = (float*)((char*)c->scratch + (ob + 255) / 256 * 256);
+        HIPCHK(hipMemcpyAsync(d_obs, obs, ob, hipMemcpyHostToDevice, c->compute));
+        InferArgs ia{};
+        ia.obs = d_obs; ia.obs_next = d_obs; ia.act = nullptr; ia.flags = nullptr; ia.values = nullptr;
+        ia.vnext = nullptr; ia.logp_old = nullptr; ia.mu_out = d_mu; ia.N = k; ia.C = 0;
+        ia.max_action = c->cfg.max_action;
+        rc = launch_infer(c, ia, 1, c->compute);   // job 0 == 2*C == actor
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(mu_out, d_mu, mb, hipMemcpyDeviceToHost, c->compute));
+        HIPCHK(hipStreamSynchronize(c->compute));
+    }
+    if (sigma_out) {
+        std::vector<float> sp((size_t)Da);
+        HIPCHK(hipMemcpy(sp.data(), c->P + c->md.net[0].sigma, (size_t)Da * 4, hipMemcpyDeviceToHost));
+        for (int r = 0; r < k; ++r)
+            for (int d = 0; d < Da; ++d) sigma_out[(size_t)r * Da + d] = expf(sp[d]);
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ GAE (standalone)
+extern "C" int fsrl_gae_return(fsrl_ctx* c, const float* v, const float* v_next, const double* rew,
+                               const uint8_t* end_flag, int64_t n, double gamma, double gae_lambda,
+                               double* adv_out) {
+    CHECK_ARG(c && adv_out, "null argument");
+    CHECK_ARG(n >= 0 && n < INT_MAX / 4, "bad n");
+    CHECK_ARG(gae_lambda >= 0.0 && gae_lambda <= 1.0, "GAE lambda should be in [0, 1].");
+    if (n == 0) return 0;
+    CHECK_ARG(v && v_next && rew && end_flag, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    // segments: cut after every end_flag (disc = 0 there, so the scan restarts)
+    std::vector<int> seg{0};
+    std::vector<uint8_t> fl((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        fl[(size_t)i] = end_flag[i] ? 4 : 0;
+        if (end_flag[i] && i + 1 < n) seg.push_back((int)i + 1);
+    }
+    seg.push_back((int)n);
+    const int nseg = (int)seg.size() - 1;
+    const size_t N = (size_t)n;
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_v = 0, o_vn = o_v + al(N * 4), o_rew = o_vn + al(N * 4), o_fl = o_rew + al(N * 8),
+                 o_seg = o_fl + al(N), o_adv = o_seg + al(seg.size() * 4), o_ret = o_adv + al(N * 4),
+                 o_a64 = o_ret + al(N * 4), total = o_a64 + al(N * 8);
+    int rc = ensure_scratch(c, total);
+    if (rc) return rc;
+    char* base = (char*)c->scratch;
+    hipStream_t s = c->compute;
+    HIPCHK(hipMemcpyAsync(base + o_v, v, N * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(base + o_vn, v_next, N * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(base + o_rew, rew, N * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(base + o_fl, fl.data(), N, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(base + o_seg, seg.data(), seg.size() * 4, hipMemcpyHostToDevice, s));
+    GaeArgs ga{};
+    ga.values = (float*)(base + o_v); ga.vnext = (float*)(base + o_vn); ga.rew = (double*)(base + o_rew);
+    ga.cost = ga.rew; ga.flags = (uint8_t*)(base + o_fl); ga.seg_start = (int*)(base + o_seg);
+    ga.advs = (float*)(base + o_adv); ga.rets = (float*)(base + o_ret); ga.adv64 = (double*)(base + o_a64);
+    ga.N = (int)n; ga.gamma = gamma; ga.gl = gamma * gae_lambda;
+    hipLaunchKernelGGL(gae_kernel, dim3(nseg, 1), dim3(64), 0, s, ga);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(adv_out, base + o_a64, N * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ PPO-Lagrangian
+static void split_plan(int n, int B, std::vector<int>& st, std::vector<int>& sz) {
+    // tianshou Batch.split(size, merge_last=True): the remainder is merged into the last chunk
+    st.clear(); sz.clear();
+    const bool merge = (n % B) > 0;
+    for (int i = 0; i < n; i += B) {
+        if (merge && i + 2 * B >= n) { st.push_back(i); sz.push_back(n - i); break; }
+        st.push_back(i); sz.push_back(std::min(B, n - i));
+    }
+}
+
+static int ensure_ppo_buffers(fsrl_ctx* c, int B) {
+    const int mbp = round_up(2 * B, 16);
+    if (mbp <= c->mbp_max) return 0;
+    HIPCHK(hipStreamSynchronize(c->compute));
+    for (float** p : {&c->A1, &c->A2, &c->D1, &c->D2, &c->DO, &c->XB, &c->statp, &c->gsq_part})
+        if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
+    const int H = c->cfg.hidden, nn = c->md.n_nets;
+    const size_t act = (size_t)nn * mbp * H * 4;
+    HIPCHK(hipMalloc(&c->A1, act)); HIPCHK(hipMalloc(&c->A2, act));
+    HIPCHK(hipMalloc(&c->D1, act)); HIPCHK(hipMalloc(&c->D2, act));
+    HIPCHK(hipMalloc(&c->DO, (size_t)nn * mbp * FSRL_DOW * 4));
+    HIPCHK(hipMalloc(&c->XB, (size_t)mbp * c->cfg.obs_dim * 4));
+    HIPCHK(hipMalloc(&c->statp, (size_t)(mbp / 16) * nn * 4 * 4));
+    const int pb = (H / 32) * (H / 32) + H / 64;
+    HIPCHK(hipMalloc(&c->gsq_part, (size_t)nn * pb * 4));
+    c->mbp_max = mbp;
+    c->n_tiles_max = mbp / 16;
+    return 0;
+}
+
+extern "C" int fsrl_ppo_begin(fsrl_ctx* c, const double* lagrangians, double rescaling,
+                              int32_t batch_size, int64_t* n_out) {
+    CHECK_ARG(c, "null ctx");
+    CHECK_ARG(batch_size >= 1, "batch_size must be >= 1");
+    CHECK_ARG(!c->in_update, "fsrl_ppo_begin called twice without fsrl_ppo_end");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = flush_stage(c);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->store_ready, c->side));
+    HIPCHK(hipStreamWaitEvent(c->compute, c->store_ready, 0));   // join side stream -> compute
+    const int C = c->cfg.n_critics;
+    for (int i = 0; i < FSRL_MAX_CRITICS; ++i) c->lagr[i] = 0.0;
+    if (c->cfg.use_lagrangian && C > 1) {
+        CHECK_ARG(lagrangians, "lags and values length must be equal");
+        for (int i = 0; i < C - 1; ++i) c->lagr[i] = lagrangians[i];
+    }
+    c->rescaling = rescaling;
+    c->batch_size = batch_size;
+    // ---- batch, indices = buffer.sample(0)
+    const int64_t n = sample0(c, c->h_indices, c->h_end);
+    c->N = n;
+    if (n_out) *n_out = n;
+    c->n_steps = 0;
+    c->pass_index = 0;
+    c->in_update = true;
+    c->t_fwdbwd_ms = 0; c->n_fwdbwd = 0; c->k_ev_used = 0;
+    CtrlBlock init{INT_MAX, 0, 0.0, 0.0f, 0.0f};
+    *c->h_ctrl = init;
+    hipStream_t s = c->compute;
+    HIPCHK(hipMemcpyAsync(c->ctrl, c->h_ctrl, sizeof(CtrlBlock), hipMemcpyHostToDevice, s));
+    if (n == 0) { c->batch_ready = true; return 0; }
+    // episode segments for the GAE scan
+    int nseg = 0;
+    c->h_seg[nseg++] = 0;
+    for (int64_t i = 0; i + 1 < n; ++i) if (c->h_end[i]) c->h_seg[nseg++] = (int)i + 1;
+    c->h_seg[nseg] = (int)n;
+    HIPCHK(hipEventRecord(c->ev_a, s));
+    HIPCHK(hipMemcpyAsync(c->d_indices, c->h_indices, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_end, c->h_end, (size_t)n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_seg, c->h_seg, (size_t)(nseg + 1) * 4, hipMemcpyHostToDevice, s));
+    const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim;
+    {
+        const size_t work = (size_t)n * (2 * Do + Da + 1);
+        const int blocks = (int)std::min<size_t>(2048, (work + 255) / 256);
+        hipLaunchKernelGGL(batch_gather_kernel, dim3(blocks), dim3(256), 0, s, c->st, c->b, c->d_indices,
+                           c->d_end, (int)n, Do, Da);
+        HIPCHK(hipGetLastError());
+    }
+    // ---- process_fn: V_i(obs), V_i(obs_next)*~terminated, logp_old, then float64 GAE per critic
+    InferArgs ia{};
+    ia.obs = c->b.obs; ia.obs_next = c->b.obs_next; ia.act = c->b.act; ia.flags = c->b.flags;
+    ia.values = c->values; ia.vnext = c->vnext; ia.logp_old = c->logp_old; ia.mu_out = nullptr;
+    ia.N = (int)n; ia.C = C; ia.max_action = c->cfg.max_action;
+    rc = launch_infer(c, ia, 2 * C + 1, s);
+    if (rc) return rc;
+    GaeArgs ga{};
+    ga.values = c->values; ga.vnext = c->vnext; ga.rew = c->b.rew; ga.cost = c->b.cost; ga.flags = c->b.flags;
+    ga.seg_start = c->d_seg; ga.advs = c->advs; ga.rets = c->rets; ga.adv64 = nullptr; ga.N = (int)n;
+    ga.gamma = c->cfg.gamma; ga.gl = c->cfg.gamma * c->cfg.gae_lambda;
+    hipLaunchKernelGGL(gae_kernel, dim3(nseg, C), dim3(64), 0, s, ga);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev_b, s));
+    // ---- minibatch plan of every pass (same for all passes)
+    split_plan((int)n, batch_size, c->mb_start, c->mb_size);
+    rc = ensure_ppo_buffers(c, batch_size);
+    if (rc) return rc;
+    const size_t nmb = c->mb_start.size();
+    if (nmb > c->mb_cap) {
+        HIPCHK(hipStreamSynchronize(s));
+        if (c->d_mbstart) HIPCHK(hipFree(c->d_mbstart));
+        if (c->d_mbsize) HIPCHK(hipFree(c->d_mbsize));
+        if (c->mbstats) HIPCHK(hipFree(c->mbstats));
+        if (c->h_mbplan) HIPCHK(hipHostFree(c->h_mbplan));
+        c->d_mbstart = c->d_mbsize = nullptr; c->mbstats = nullptr; c->h_mbplan = nullptr;
+        const size_t cap = nmb * 2;
+        HIPCHK(hipMalloc(&c->d_mbstart, cap * 4)); HIPCHK(hipMalloc(&c->d_mbsize, cap * 4));
+        HIPCHK(hipMalloc(&c->mbstats, cap * FSRL_MAX_CRITICS * 2 * 4));
+        HIPCHK(hipHostMalloc(&c->h_mbplan, cap * 2 * 4));
+        c->mb_cap = cap;
+    }
+    memcpy(c->h_mbplan, c->mb_start.data(), nmb * 4);
+    memcpy(c->h_mbplan + c->mb_cap, c->mb_size.data(), nmb * 4);
+    HIPCHK(hipMemcpyAsync(c->d_mbstart, c->h_mbplan, nmb * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_mbsize, c->h_mbplan + c->mb_cap, nmb * 4, hipMemcpyHostToDevice, s));
+    c->batch_ready = true;
+    return 0;
+}
+
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static uint64_t xoshiro_next(uint64_t* s) {
+    const uint64_t result = rotl64(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl64(s[3], 45);
+    return result;
+}
+
+static int ensure_stats(fsrl_ctx* c, int64_t steps) {
+    if (steps <= c->stats_cap) return 0;
+    int64_t cap = std::max<int64_t>(steps, c->stats_cap * 2);
+    cap = std::max<int64_t>(cap, 1024);
+    float* nw = nullptr;
+    HIPCHK(hipMalloc(&nw, (size_t)cap * FSRL_PPO_NSTATS * 4));
+    if (c->d_stats) {
+        HIPCHK(hipStreamSynchronize(c->compute));
+        HIPCHK(hipMemcpy(nw, c->d_stats, (size_t)c->stats_cap * FSRL_PPO_NSTATS * 4, hipMemcpyDeviceToDevice));
+        HIPCHK(hipFree(c->d_stats));
+    }
+    c->d_stats = nw;
+    c->stats_cap = cap;
+    return 0;
+}
+
+extern "C" int fsrl_ppo_pass(fsrl_ctx* c, const int64_t* perm, uint64_t seed, int32_t* stopped_out) {
+    CHECK_ARG(c, "null ctx");
+    if (!c->in_update || !c->batch_ready) return fail(FSRL_ESTATE, "fsrl_ppo_pass before fsrl_ppo_begin");
+    HIPCHK(hipSetDevice(c->device));
+    if (stopped_out) *stopped_out = 0;
+    const int n = (int)c->N;
+    if (n == 0) return 0;
+    hipStream_t s = c->compute;
+    const int C = c->cfg.n_critics, H = c->cfg.hidden, nn = c->md.n_nets;
+    // ---- permutation of this pass (np.random.permutation on the caller side, or our own)
+    HIPCHK(hipStreamSynchronize(s));   // h_perm (pinned) may still be in flight from the last pass
+    if (perm) {
+        for (int i = 0; i < n; ++i) {
+            CHECK_ARG(perm[i] >= 0 && perm[i] < n, "perm[%d]=%lld out of range", i, (long long)perm[i]);
+            c->h_perm[i] = (int)perm[i];
+        }
+    } else {
+        if (seed) { c->rng[0] ^= seed; c->rng[1] += seed * 0x9E3779B97F4A7C15ull; }
+        for (int i = 0; i < n; ++i) c->h_perm[i] = i;
+        for (int i = n - 1; i > 0; --i) {
+            const int j = (int)(xoshiro_next(c->rng) % (uint64_t)(i + 1));
+            std::swap(c->h_perm[i], c->h_perm[j]);
+        }
+    }
+    const int nmb = (int)c->mb_start.size();
+    int rc = ensure_stats(c, c->n_steps + nmb);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->d_perm, c->h_perm, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (c->cfg.norm_adv) {
+        hipLaunchKernelGGL(advstats_kernel, dim3(nmb, C), dim3(256), 0, s, c->advs, c->d_perm, c->d_mbstart,
+                           c->d_mbsize, n, C, c->mbstats);
+        HIPCHK(hipGetLastError());
+    }
+    PpoBatchPtrs bp{};
+    bp.obs = c->b.obs; bp.act = c->b.act; bp.advs = c->advs; bp.rets = c->rets; bp.logp_old = c->logp_old;
+    bp.perm = c->d_perm; bp.mbstats = c->mbstats; bp.A1 = c->A1; bp.A2 = c->A2; bp.D1 = c->D1; bp.D2 = c->D2;
+    bp.DO = c->DO; bp.XB = c->XB; bp.statp = c->statp; bp.ctrl = c->ctrl; bp.mbp_max = c->mbp_max; bp.N = n;
+    WgradPtrs wp{};
+    wp.A1 = c->A1; wp.A2 = c->A2; wp.D1 = c->D1; wp.D2 = c->D2; wp.DO = c->DO; wp.XB = c->XB; wp.grad = c->G;
+    wp.gsq_part = c->gsq_part; wp.ctrl = c->ctrl; wp.mbp_max = c->mbp_max;
+    const int pb = (H / 32) * (H / 32) + H / 64;
+    const int nparts = nn * pb;
+
+    PpoStepArgs sa{};
+    sa.rescale = (float)c->rescaling;
+    for (int i = 0; i < FSRL_MAX_CRITICS; ++i) sa.lam[i] = (float)c->lagr[i];
+    sa.eps_clip = c->cfg.eps_clip; sa.dual_clip = c->cfg.dual_clip; sa.vf_coef = c->cfg.vf_coef;
+    sa.max_action = c->cfg.max_action; sa.max_grad_norm = c->cfg.max_grad_norm; sa.target_kl = c->cfg.target_kl;
+    sa.norm_adv = c->cfg.norm_adv; sa.use_lagrangian = c->cfg.use_lagrangian;
+    sa.lr = c->cfg.lr; sa.beta1 = c->cfg.beta1; sa.beta2 = c->cfg.beta2; sa.adam_eps = c->cfg.adam_eps;
+    sa.one_minus_b1 = (float)(1.0 - (double)c->cfg.beta1);
+    sa.one_minus_b2 = (float)(1.0 - (double)c->cfg.beta2);
+    sa.kl_thresh = 1.5 * (double)c->cfg.target_kl;
+    sa.pass = c->pass_index;
+    sa.iters_in_pass = nmb;
+
+    for (int mb = 0; mb < nmb; ++mb) {
+        sa.mb_start = c->mb_start[mb]; sa.mb_size = c->mb_size[mb]; sa.mb_index = mb;
+        sa.step = (int)c->n_steps + mb;
+        sa.first_in_pass = (mb == 0); sa.last_in_pass = (mb == nmb - 1);
+        c->adam_t += 1;
+        const double bc1 = 1.0 - std::pow((double)c->cfg.beta1, (double)c->adam_t);
+        const double bc2 = 1.0 - std::pow((double)c->cfg.beta2, (double)c->adam_t);
+        sa.step_size = (float)((double)c->cfg.lr / bc1);
+        sa.bc2_sqrt = (float)std::sqrt(bc2);
+        const int tiles = (sa.mb_size + 15) / 16;
+        const bool prof = c->profiling;
+        if (prof) {
+            while (c->k_ev.size() < c->k_ev_used + 2) {
+                hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->k_ev.push_back(e);
+            }
+            HIPCHK(hipEventRecord(c->k_ev[c->k_ev_used], s));
+        }
+        rc = dispatch_H(H, [&](auto hc) {
+            constexpr int HH = decltype(hc)::value;
+            hipLaunchKernelGGL(ppo_fwd_bwd_kernel<HH>, dim3(tiles, nn), dim3(256), 0, s, c->P, c->md, bp, sa);
+            return 0;
+        });
+        if (rc) return rc;
+        if (prof) { HIPCHK(hipEventRecord(c->k_ev[c->k_ev_used + 1], s)); c->k_ev_used += 2; }
+        hipLaunchKernelGGL(ppo_stats_kernel, dim3(1), dim3(64), 0, s, c->P, c->md, c->statp, tiles, sa, c->ctrl,
+                           c->d_stats);
+        rc = dispatch_H(H, [&](auto hc) {
+            constexpr int HH = decltype(hc)::value;
+            hipLaunchKernelGGL(ppo_wgrad_kernel<HH>, dim3(nparts), dim3(256), 0, s, c->md, wp, tiles * 16,
+                               sa.pass);
+            return 0;
+        });
+        if (rc) return rc;
+        hipLaunchKernelGGL(adam_clip_kernel, dim3(c->n_dev / 256), dim3(256), 0, s, c->P, c->M, c->V, c->G,
+                           c->gsq_part, nparts, c->n_dev, sa, c->ctrl);
+        HIPCHK(hipGetLastError());
+    }
+    c->n_steps += nmb;
+    c->pass_index += 1;
+    // ---- pass-level KL early stop: one small readback per pass (the reference's `break`)
+    if (c->cfg.target_kl > 0.0f) {
+        HIPCHK(hipMemcpyAsync(c->h_ctrl, c->ctrl, sizeof(CtrlBlock), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (c->h_ctrl->stopped_after != INT_MAX) {
+            if (stopped_out) *stopped_out = 1;
+        }
+    }
+    return 0;
+}
+
+extern "C" int fsrl_ppo_end(fsrl_ctx* c, float* stats_out, int64_t cap_steps, int64_t* n_steps_out) {
+    CHECK_ARG(c, "null ctx");
+    if (!c->in_update) return fail(FSRL_ESTATE, "fsrl_ppo_end without fsrl_ppo_begin");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->compute;
+    HIPCHK(hipEventRecord(c->ev_c, s));
+    if (stats_out && c->n_steps > 0) {
+        CHECK_ARG(cap_steps >= c->n_steps, "stats_out holds %lld steps, need %lld", (long long)cap_steps,
+                  (long long)c->n_steps);
+        HIPCHK(hipMemcpyAsync(stats_out, c->d_stats, (size_t)c->n_steps * FSRL_PPO_NSTATS * 4,
+                              hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    if (n_steps_out) *n_steps_out = c->n_steps;
+    c->in_update = false;
+    if (c->N > 0) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) c->t_process_ms = ms;
+        if (hipEventElapsedTime(&ms, c->ev_b, c->ev_c) == hipSuccess) c->t_learn_ms = ms;
+        double tot = 0;
+        for (size_t i = 0; i + 1 < c->k_ev_used; i += 2) {
+            if (hipEventElapsedTime(&ms, c->k_ev[i], c->k_ev[i + 1]) == hipSuccess) tot += ms;
+        }
+        c->t_fwdbwd_ms = tot;
+        c->n_fwdbwd = (int64_t)(c->k_ev_used / 2);
+    }
+    return 0;
+}
+
+extern "C" int fsrl_ppo_update(fsrl_ctx* c, const double* lagrangians, double rescaling,
+                               int32_t batch_size, int32_t repeat, const int64_t* perms, uint64_t seed,
+                               float* stats_out, int64_t cap_steps, int64_t* n_steps_out,
+                               int32_t* stopped_pass_out) {
+    CHECK_ARG(c, "null ctx");
+    CHECK_ARG(repeat >= 0, "repeat must be >= 0");
+    int64_t n = 0;
+    int rc = fsrl_ppo_begin(c, lagrangians, rescaling, batch_size, &n);
+    if (rc) return rc;
+    if (stopped_pass_out) *stopped_pass_out = -1;
+    for (int k = 0; k < repeat; ++k) {
+        int32_t stopped = 0;
+        rc = fsrl_ppo_pass(c, perms ? perms + (size_t)k * n : nullptr, seed ? seed + k : 0, &stopped);
+        if (rc) { c->in_update = false; return rc; }
+        if (stopped) { if (stopped_pass_out) *stopped_pass_out = k; break; }
+    }
+    return fsrl_ppo_end(c, stats_out, cap_steps, n_steps_out);
+}
+
+extern "C" int fsrl_batch_get(fsrl_ctx* c, const char* which, float* out, int64_t cap) {
+    CHECK_ARG(c && which && out, "null argument");
+    if (!c->batch_ready) return fail(FSRL_ESTATE, "no batch: call fsrl_ppo_begin first");
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t n = c->N;
+    const int C = c->cfg.n_critics;
+    const float* src = nullptr;
+    int cols = C;
+    if (!strcmp(which, "values")) src = c->values;
+    else if (!strcmp(which, "rets")) src = c->rets;
+    else if (!strcmp(which, "advs")) src = c->advs;
+    else if (!strcmp(which, "vnext")) src = c->vnext;
+    else if (!strcmp(which, "logp_old")) { src = c->logp_old; cols = 1; }
+    else return fail(FSRL_EINVAL, "unknown batch field '%s'", which);
+    CHECK_ARG(cap >= n * cols, "out too small");
+    HIPCHK(hipStreamSynchronize(c->compute));
+    std::vector<float> tmp((size_t)n * cols);
+    if (n) HIPCHK(hipMemcpy(tmp.data(), src, (size_t)n * cols * 4, hipMemcpyDeviceToHost));
+    // device layout is [C][N]; the reference stacks on the last axis: [N][C]
+    for (int64_t r = 0; r < n; ++r)
+        for (int k = 0; k < cols; ++k) out[r * cols + k] = tmp[(size_t)k * n + r];
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ timing
+extern "C" int fsrl_set_profiling(fsrl_ctx* c, int enable) {
+    CHECK_ARG(c, "null ctx");
+    c->profiling = enable != 0;
+    return 0;
+}
+extern "C" int fsrl_last_timing(fsrl_ctx* c, double* out, int32_t n) {
+    CHECK_ARG(c && out && n >= 4, "need room for 4 doubles");
+    out[0] = c->t_process_ms; out[1] = c->t_learn_ms; out[2] = c->t_fwdbwd_ms; out[3] = (double)c->n_fwdbwd;
+    return 0;
+}

@@ -1,0 +1,256 @@
+// kernels_misc.hpp -- the HBM-bound / scalar parts of the update: store scatter + gather,
+// float64 GAE scan, per-minibatch advantage statistics, stats finalisation, grad-clip + Adam.
+#pragma once
+#include "common.hpp"
+
+// ---------------------------------------------------------------- store: staged rows -> slots
+// Rows arrive packed (SoA) in a device staging area after one hipMemcpyAsync per array on
+// the side stream; this kernel scatters them to their per-env sub-buffer slots
+// (tianshou VectorReplayBuffer.add, as used at fsrl/data/fast_collector.py:333-335).
+struct StorePtrs {
+    float* obs;       // [maxsize][Do]
+    float* obs_next;  // [maxsize][Do]
+    float* act;       // [maxsize][Da]
+    double* rew;      // [maxsize]
+    double* cost;     // [maxsize]
+    uint8_t* flags;   // [maxsize] bit0 terminated, bit1 truncated
+};
+
+__global__ void store_scatter_kernel(StorePtrs st, const int* __restrict__ slot,
+                                     const float* __restrict__ obs, const float* __restrict__ obs_next,
+                                     const float* __restrict__ act, const double* __restrict__ rew,
+                                     const double* __restrict__ cost, const uint8_t* __restrict__ flags,
+                                     int k, int Do, int Da) {
+    const int per = 2 * Do + Da + 1;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < k * per; e += gridDim.x * blockDim.x) {
+        const int row = e / per, f = e - row * per;
+        const size_t dst = (size_t)slot[row];
+        if (f < Do) st.obs[dst * Do + f] = obs[(size_t)row * Do + f];
+        else if (f < 2 * Do) st.obs_next[dst * Do + (f - Do)] = obs_next[(size_t)row * Do + (f - Do)];
+        else if (f < 2 * Do + Da) st.act[dst * Da + (f - 2 * Do)] = act[(size_t)row * Da + (f - 2 * Do)];
+        else { st.rew[dst] = rew[row]; st.cost[dst] = cost[row]; st.flags[dst] = flags[row]; }
+    }
+}
+
+// ---------------------------------------------------------------- batch = buffer.sample(0)
+// Gather the store rows `indices` (env-major, chronological) into contiguous batch arrays;
+// bit2 of the batch flags = end_flag (done | unfinished tail, base_policy.py:409-411),
+// supplied by the host which owns the episode bookkeeping.
+struct BatchPtrs {
+    float* obs; float* obs_next; float* act; double* rew; double* cost; uint8_t* flags;
+};
+
+__global__ void batch_gather_kernel(StorePtrs st, BatchPtrs b, const int* __restrict__ indices,
+                                    const uint8_t* __restrict__ end_flag, int n, int Do, int Da) {
+    const int per = 2 * Do + Da + 1;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)n * per;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(e / per), f = (int)(e - (size_t)row * per);
+        const size_t src = (size_t)indices[row];
+        if (f < Do) b.obs[(size_t)row * Do + f] = st.obs[src * Do + f];
+        else if (f < 2 * Do) b.obs_next[(size_t)row * Do + (f - Do)] = st.obs_next[src * Do + (f - Do)];
+        else if (f < 2 * Do + Da) b.act[(size_t)row * Da + (f - 2 * Do)] = st.act[src * Da + (f - 2 * Do)];
+        else {
+            b.rew[row] = st.rew[src];
+            b.cost[row] = st.cost[src];
+            b.flags[row] = (uint8_t)((st.flags[src] & 3) | (end_flag[row] ? 4 : 0));
+        }
+    }
+}
+
+// ---------------------------------------------------------------- GAE(lambda), float64
+// gae_return (fsrl/policy/base_policy.py:524-540).  The recurrence g_i = delta_i + disc_i*g_{i+1}
+// is evaluated strictly sequentially inside one wave per episode segment (segments end where
+// end_flag is set, where disc = 0 cuts the dependence), with the multiply and the add rounded
+// separately -- bit-identical to the reference's scan.  Loads are coalesced 64 at a time.
+struct GaeArgs {
+    const float* values;   // [C][N]
+    const float* vnext;    // [C][N]  already * ~terminated
+    const double* rew;     // [N]
+    const double* cost;    // [N]
+    const uint8_t* flags;  // [N] bit2 = end_flag
+    const int* seg_start;  // [n_seg+1]
+    float* advs;           // [C][N] float32 (to_torch_as, base_policy.py:445-446)
+    float* rets;           // [C][N]
+    double* adv64;         // optional [C][N]
+    int N;
+    double gamma, gl;      // gl = gamma*lambda
+};
+
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void gae_kernel(const GaeArgs a) {
+#pragma clang fp contract(off)
+    const int seg = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+    const int s = a.seg_start[seg], e = a.seg_start[seg + 1];
+    const float* __restrict__ v = a.values + (size_t)c * a.N;
+    const float* __restrict__ vn = a.vnext + (size_t)c * a.N;
+    const double* __restrict__ met = (c == 0) ? a.rew : a.cost;
+    double g = 0.0;
+    for (int base = e - 64; base > s - 64; base -= 64) {
+        const int idx = base + lane;
+        const bool ok = idx >= s;
+        double delta = 0.0, disc = 0.0, vv = 0.0;
+        if (ok) {
+            vv = (double)v[idx];
+            const double t0 = (double)vn[idx] * a.gamma;
+            const double t1 = met[idx] + t0;
+            delta = t1 - vv;
+            disc = (1.0 - ((a.flags[idx] & 4) ? 1.0 : 0.0)) * a.gl;
+        }
+        double res = 0.0;
+#pragma unroll
+        for (int t = 63; t >= 0; --t) {
+            const double dt = readlane_f64(delta, t);
+            const double ct = readlane_f64(disc, t);
+            const double prod = ct * g;
+            g = dt + prod;
+            if (lane == t) res = g;
+        }
+        if (ok) {
+            const size_t o = (size_t)c * a.N + idx;
+            a.advs[o] = (float)res;
+            const double ret = res + vv;
+            a.rets[o] = (float)ret;
+            if (a.adv64) a.adv64[o] = res;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- per-minibatch adv stats
+// mean and unbiased std of each critic's advantages over the rows of every minibatch of a
+// pass (the reference normalises the minibatch copy, ppo_lag.py:178-182).  float64 accumulate.
+__global__ __launch_bounds__(256) void advstats_kernel(const float* __restrict__ advs,
+                                                      const int* __restrict__ perm,
+                                                      const int* __restrict__ mb_start,
+                                                      const int* __restrict__ mb_size, int N, int C,
+                                                      float* __restrict__ out) {
+    __shared__ double sh[4];
+    __shared__ double mean_s;
+    const int mb = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+    const int st = mb_start[mb], n = mb_size[mb];
+    const float* __restrict__ a = advs + (size_t)c * N;
+    double s = 0.0;
+    for (int m = tid; m < n; m += 256) s += (double)a[perm[st + m]];
+    s = wave_sum_d(s);
+    if ((tid & 63) == 0) sh[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) mean_s = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (double)n;
+    __syncthreads();
+    const double mean = mean_s;
+    double q = 0.0;
+    for (int m = tid; m < n; m += 256) {
+        const double d = (double)a[perm[st + m]] - mean;
+        q += d * d;
+    }
+    q = wave_sum_d(q);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = q;
+    __syncthreads();
+    if (tid == 0) {
+        const double var = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (double)(n - 1);
+        out[((size_t)mb * C + c) * 2 + 0] = (float)mean;
+        out[((size_t)mb * C + c) * 2 + 1] = (float)sqrt(var);
+    }
+}
+
+// ---------------------------------------------------------------- logged stats of one step
+// Runs as one extra single-wave launch after the fwd/bwd kernel (parameters still pre-update,
+// like the reference which builds `dist` before optim.step, ppo_lag.py:225-247).
+__global__ __launch_bounds__(64) void ppo_stats_kernel(const float* __restrict__ P,
+                                                      const ModelDesc md,
+                                                      const float* __restrict__ statp, int n_tiles,
+                                                      const PpoStepArgs sa, CtrlBlock* ctrl,
+                                                      float* __restrict__ stats) {
+    if (sa.pass > ctrl->stopped_after) return;
+    const int lane = threadIdx.x;
+    const int nn = md.n_nets, C = nn - 1;
+    // sums over tiles, fixed order: lane handles (net, field) pairs
+    float mine = 0.0f;
+    if (lane < nn * 4) {
+        const int net = lane >> 2, f = lane & 3;
+        for (int t = 0; t < n_tiles; ++t) mine += statp[((size_t)t * nn + net) * 4 + f];
+    }
+    const float invB = 1.0f / (float)sa.mb_size;
+    const float term = __shfl(mine, 0, 64), safety = __shfl(mine, 1, 64), kls = __shfl(mine, 2, 64);
+    float vf[FSRL_MAX_CRITICS];
+#pragma unroll
+    for (int c = 0; c < FSRL_MAX_CRITICS; ++c) vf[c] = __shfl(mine, 4 * (c + 1), 64) * invB;
+    if (lane == 0) {
+        float ent = 0.0f;
+        for (int d = 0; d < md.Da; ++d) ent += 1.4189385332046727f + logf(expf(P[md.net[0].sigma + d]));
+        const float actor_rew = -term * invB;
+        const float actor_safety = sa.use_lagrangian ? safety * invB : 0.0f;
+        const float actor_total = sa.rescale * (actor_rew + actor_safety);
+        const float kl = kls * invB;
+        float vf_total = 0.0f;
+#pragma unroll
+        for (int c = 0; c < FSRL_MAX_CRITICS; ++c)
+            if (c < C) vf_total += vf[c];
+        float* o = stats + (size_t)sa.step * FSRL_PPO_NSTATS;
+        o[0] = sa.rescale;
+        o[1] = (sa.use_lagrangian && C > 1) ? sa.lam[0] : 0.0f;
+        o[2] = actor_safety;
+        o[3] = actor_rew;
+        o[4] = actor_total;
+        o[5] = kl;
+        o[6] = vf[0];
+        o[7] = (C > 1) ? vf[1] : 0.0f;
+        o[8] = vf_total;
+        o[9] = actor_total + sa.vf_coef * vf_total;
+        o[10] = ent;
+        const double ks = (sa.first_in_pass ? 0.0 : ctrl->kl_sum) + (double)kl;
+        ctrl->kl_sum = ks;
+    }
+}
+
+// ---------------------------------------------------------------- grad clip + Adam
+// clip_grad_norm_(max_norm) then torch.optim.Adam single-tensor update, same operation order
+// as torch (lerp_ / mul_+addcmul_ / sqrt / div / add_(eps) / addcdiv_), ppo_lag.py:235-241.
+__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ P, float* __restrict__ M,
+                                                       float* __restrict__ V,
+                                                       const float* __restrict__ G,
+                                                       const float* __restrict__ gsq_part, int nparts,
+                                                       int n, const PpoStepArgs sa,
+                                                       CtrlBlock* ctrl) {
+    __shared__ double sh[4];
+    __shared__ float coef_s;
+    if (sa.pass > ctrl->stopped_after) return;
+    const int tid = threadIdx.x;
+    float coef = 1.0f;
+    if (sa.max_grad_norm > 0.0f) {
+        double s = 0.0;
+        for (int i = tid; i < nparts; i += 256) s += (double)gsq_part[i];
+        s = wave_sum_d(s);
+        if ((tid & 63) == 0) sh[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) {
+            const float norm = sqrtf((float)((sh[0] + sh[1]) + (sh[2] + sh[3])));
+            coef_s = fminf(sa.max_grad_norm / (norm + 1e-6f), 1.0f);
+            if (blockIdx.x == 0) ctrl->last_grad_norm = norm;
+        }
+        __syncthreads();
+        coef = coef_s;
+    }
+    const int i = blockIdx.x * 256 + tid;
+    if (i < n) {
+        const float g = G[i] * coef;
+        float m = M[i], v = V[i];
+        m = m + sa.one_minus_b1 * (g - m);
+        v = v * sa.beta2;
+        v = v + (sa.one_minus_b2 * g) * g;
+        const float denom = sqrtf(v) / sa.bc2_sqrt + sa.adam_eps;
+        M[i] = m;
+        V[i] = v;
+        P[i] = P[i] + (-sa.step_size * m) / denom;
+    }
+    // pass-level KL early stop (ppo_lag.py:251-255); only after the last minibatch of a pass
+    if (sa.last_in_pass && blockIdx.x == 0 && tid == 0 && sa.target_kl > 0.0f) {
+        const double mean_kl = ctrl->kl_sum / ((double)sa.iters_in_pass + 1e-7);
+        if (mean_kl > sa.kl_thresh) ctrl->stopped_after = sa.pass;
+    }
+}

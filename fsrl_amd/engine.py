@@ -1,0 +1,208 @@
+"""numpy-facing wrapper of one libfsrl_hip context (one per GPU / per agent).
+
+This is plumbing: every method forwards to one C-ABI entry point of include/fsrl_hip.h.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+_f32p, _f64p = C.POINTER(C.c_float), C.POINTER(C.c_double)
+_u8p, _i32p, _i64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+@dataclass
+class EngineConfig:
+    """Mirror of struct fsrl_config; defaults = PPOLagAgent defaults (ppo_lag_agent.py:82-116)."""
+    obs_dim: int = 8
+    act_dim: int = 2
+    hidden: int = 128
+    n_critics: int = 2
+    env_num: int = 20
+    buffer_size: int = 100000
+    max_action: float = 1.0
+    gamma: float = 0.99
+    gae_lambda: float = 0.95
+    eps_clip: float = 0.2
+    dual_clip: Optional[float] = None
+    vf_coef: float = 0.25
+    max_grad_norm: Optional[float] = None
+    target_kl: float = 0.02
+    norm_adv: bool = True
+    use_lagrangian: bool = True
+    lr: float = 5e-4
+    beta1: float = 0.9
+    beta2: float = 0.999
+    adam_eps: float = 1e-8
+    algo: int = _lib.ALGO_PPO_LAG
+
+    def to_c(self):
+        c = _lib.Config()
+        c.algo, c.obs_dim, c.act_dim, c.hidden = self.algo, self.obs_dim, self.act_dim, self.hidden
+        c.n_critics, c.env_num, c.buffer_size = self.n_critics, self.env_num, self.buffer_size
+        c.max_action, c.gamma, c.gae_lambda = self.max_action, self.gamma, self.gae_lambda
+        c.eps_clip, c.dual_clip = self.eps_clip, (self.dual_clip or 0.0)
+        c.vf_coef, c.max_grad_norm = self.vf_coef, (self.max_grad_norm or 0.0)
+        tk = self.target_kl
+        c.target_kl = 0.0 if (tk is None or not np.isfinite(tk) or tk >= 1e8) else tk
+        c.norm_adv, c.use_lagrangian = int(self.norm_adv), int(self.use_lagrangian)
+        c.lr, c.beta1, c.beta2, c.adam_eps = self.lr, self.beta1, self.beta2, self.adam_eps
+        return c
+
+
+class Engine:
+    def __init__(self, cfg: EngineConfig, device: int = 0):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self._ctx = C.c_void_p()
+        ccfg = cfg.to_c()
+        _lib.check(self.lib.fsrl_ctx_create(int(device), C.byref(ccfg), C.byref(self._ctx)))
+        self.n_params = int(self.lib.fsrl_param_count(self._ctx))
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self.lib.fsrl_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _lib.check(self.lib.fsrl_sync(self._ctx))
+
+    # ---------------------------------------------------------------- parameters
+    def set_params(self, flat):
+        flat = np.ascontiguousarray(flat, np.float32)
+        _lib.check(self.lib.fsrl_params_set(self._ctx, _ptr(flat, _f32p), flat.size))
+
+    def get_params(self):
+        out = np.empty(self.n_params, np.float32)
+        _lib.check(self.lib.fsrl_params_get(self._ctx, _ptr(out, _f32p), out.size))
+        return out
+
+    def get_grads(self):
+        out = np.empty(self.n_params, np.float32)
+        _lib.check(self.lib.fsrl_grads_get(self._ctx, _ptr(out, _f32p), out.size))
+        return out
+
+    def optim_reset(self):
+        _lib.check(self.lib.fsrl_optim_reset(self._ctx))
+
+    # ---------------------------------------------------------------- store
+    def push(self, env_ids, obs, act, rew, cost, terminated, truncated, obs_next):
+        env_ids = np.ascontiguousarray(env_ids, np.int32)
+        k = env_ids.size
+        obs = np.ascontiguousarray(obs, np.float32).reshape(k, -1)
+        obs_next = np.ascontiguousarray(obs_next, np.float32).reshape(k, -1)
+        act = np.ascontiguousarray(act, np.float32).reshape(k, -1)
+        assert obs.shape[1] == self.cfg.obs_dim and act.shape[1] == self.cfg.act_dim
+        rew = np.ascontiguousarray(rew, np.float64)
+        cost = np.ascontiguousarray(cost, np.float64) if cost is not None else None
+        term = np.ascontiguousarray(terminated).astype(np.uint8)
+        trunc = np.ascontiguousarray(truncated).astype(np.uint8)
+        ptr = np.empty(k, np.int64); ep_rew = np.empty(k, np.float64)
+        ep_len = np.empty(k, np.int32); ep_idx = np.empty(k, np.int64)
+        _lib.check(self.lib.fsrl_store_push(self._ctx, _ptr(env_ids, _i32p), k, _ptr(obs, _f32p),
+                                            _ptr(act, _f32p), _ptr(rew, _f64p), _ptr(cost, _f64p),
+                                            _ptr(term, _u8p), _ptr(trunc, _u8p), _ptr(obs_next, _f32p),
+                                            _ptr(ptr, _i64p), _ptr(ep_rew, _f64p), _ptr(ep_len, _i32p),
+                                            _ptr(ep_idx, _i64p)))
+        return ptr, ep_rew, ep_len, ep_idx
+
+    def reset_store(self, keep_statistics=False):
+        _lib.check(self.lib.fsrl_store_reset(self._ctx, int(keep_statistics)))
+
+    def __len__(self):
+        return int(self.lib.fsrl_store_len(self._ctx))
+
+    def sample0(self):
+        n = C.c_int64()
+        cap = len(self)
+        out = np.empty(max(cap, 1), np.int64)
+        _lib.check(self.lib.fsrl_store_sample0(self._ctx, _ptr(out, _i64p), out.size, C.byref(n)))
+        return out[:n.value]
+
+    # ---------------------------------------------------------------- inference
+    def actor_forward(self, obs):
+        obs = np.ascontiguousarray(obs, np.float32).reshape(-1, self.cfg.obs_dim)
+        k = obs.shape[0]
+        mu = np.empty((k, self.cfg.act_dim), np.float32)
+        sigma = np.empty((k, self.cfg.act_dim), np.float32)
+        _lib.check(self.lib.fsrl_actor_forward(self._ctx, _ptr(obs, _f32p), k, _ptr(mu, _f32p),
+                                               _ptr(sigma, _f32p)))
+        return mu, sigma
+
+    # ---------------------------------------------------------------- PPO-Lagrangian
+    def ppo_begin(self, lagrangians: Sequence[float], rescaling: float, batch_size: int) -> int:
+        lag = np.ascontiguousarray(lagrangians, np.float64).reshape(-1)
+        n = C.c_int64()
+        _lib.check(self.lib.fsrl_ppo_begin(self._ctx, _ptr(lag, _f64p) if lag.size else None,
+                                           float(rescaling), int(batch_size), C.byref(n)))
+        self._n = n.value
+        return n.value
+
+    def ppo_pass(self, perm=None, seed: int = 0) -> bool:
+        stopped = C.c_int32()
+        if perm is not None:
+            perm = np.ascontiguousarray(perm, np.int64)
+            assert perm.size == self._n, "permutation length != batch length"
+        _lib.check(self.lib.fsrl_ppo_pass(self._ctx, _ptr(perm, _i64p), int(seed), C.byref(stopped)))
+        return bool(stopped.value)
+
+    def ppo_end(self):
+        n = C.c_int64()
+        _lib.check(self.lib.fsrl_ppo_end(self._ctx, None, 0, C.byref(n)))  # count only: not allowed
+        return n.value
+
+    def ppo_end_stats(self, max_steps: int):
+        n = C.c_int64()
+        out = np.empty((max(max_steps, 1), _lib.PPO_NSTATS), np.float32)
+        _lib.check(self.lib.fsrl_ppo_end(self._ctx, _ptr(out, _f32p), out.shape[0], C.byref(n)))
+        return out[:n.value]
+
+    def ppo_update(self, lagrangians, rescaling, batch_size, repeat, perms=None, seed=0):
+        """-> (stats [steps, 11] float32, stopped_pass or -1)."""
+        n = self.ppo_begin(lagrangians, rescaling, batch_size)
+        stopped_pass = -1
+        steps_per_pass = max(1, -(-n // max(batch_size, 1)))
+        for k in range(repeat):
+            if self.ppo_pass(None if perms is None else perms[k], seed + k if seed else 0):
+                stopped_pass = k
+                break
+        stats = self.ppo_end_stats(steps_per_pass * max(repeat, 1))
+        return stats, stopped_pass
+
+    def batch_get(self, which: str):
+        n = self._n
+        cols = 1 if which == "logp_old" else self.cfg.n_critics
+        out = np.empty((n, cols), np.float32)
+        _lib.check(self.lib.fsrl_batch_get(self._ctx, which.encode(), _ptr(out, _f32p), out.size))
+        return out[:, 0] if which == "logp_old" else out
+
+    def gae_return(self, v, v_next, rew, end_flag, gamma, gae_lambda):
+        v = np.ascontiguousarray(v, np.float32); v_next = np.ascontiguousarray(v_next, np.float32)
+        rew = np.ascontiguousarray(rew, np.float64)
+        end = np.ascontiguousarray(end_flag).astype(np.uint8)
+        out = np.empty(rew.size, np.float64)
+        _lib.check(self.lib.fsrl_gae_return(self._ctx, _ptr(v, _f32p), _ptr(v_next, _f32p),
+                                            _ptr(rew, _f64p), _ptr(end, _u8p), rew.size, float(gamma),
+                                            float(gae_lambda), _ptr(out, _f64p)))
+        return out
+
+    def set_profiling(self, on: bool):
+        _lib.check(self.lib.fsrl_set_profiling(self._ctx, int(on)))
+
+    def last_timing(self):
+        out = np.zeros(4, np.float64)
+        _lib.check(self.lib.fsrl_last_timing(self._ctx, _ptr(out, _f64p), 4))
+        return dict(process_ms=out[0], learn_ms=out[1], fwdbwd_ms=out[2], fwdbwd_launches=int(out[3]))
