@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py -- policy-updates/s of the PPO-Lagrangian update path on MI355X.
+
+A "step" = ONE full `policy.update()` (BasePolicy.update, fsrl/policy/base_policy.py:332-355):
+buffer.sample(0) -> process_fn (V(obs), V(obs_next), float64 GAE x2, logp_old) -> learn
+(repeat=4 passes x 78 minibatches of 256 = 312 fwd/bwd/clip/Adam steps) over a HBM-resident
+20 000-row on-policy buffer, SafetyCarCircle-v0 shape (obs 8, act 2), 256x256 MLPs
+(BASELINE.json configs[1]).  Synthetic data, random-init (orthogonal)
+weights.  KL early stop is disabled for throughput (target_kl = inf), like BASELINE.md says.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one independent agent (seed = rank) per GPU, no data-path collective ("weak" scaling);
+RCCL is used only for the barrier and the max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+OBS, ACT, HID, NROWS, ENVS, EPLEN, BATCH, REPEAT = 8, 2, 256, 20000, 20, 250, 256, 4
+F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix = vector peak
+
+
+def make_inputs(seed):
+    """SURVEY 8(d) synthetic store: 20 envs x 1000 rows, end_flag every 250 (N = 20 000)."""
+    rng = np.random.default_rng(seed)
+    T = NROWS // ENVS
+    obs = rng.standard_normal((T + 1, ENVS, OBS)).astype(np.float32)
+    act = (0.3 * rng.standard_normal((T, ENVS, ACT))).astype(np.float32)
+    rew = rng.normal(0.5, 0.5, (T, ENVS))
+    cost = (rng.random((T, ENVS)) < 0.1).astype(np.float64)
+    trunc = np.zeros((T, ENVS), bool)
+    trunc[EPLEN - 1::EPLEN] = True
+    term = np.zeros((T, ENVS), bool)
+    return obs, act, rew, cost, term, trunc
+
+
+def orthogonal_theta(seed, n_params_check=None):
+    """PPOLagAgent init (ppo_lag_agent.py:147-153): orthogonal W, zero b, sigma_param = -0.5."""
+    import torch
+    torch.manual_seed(seed)
+    parts = []
+
+    def lin(o, i):
+        w = torch.empty(o, i)
+        torch.nn.init.orthogonal_(w)
+        return [w.reshape(-1), torch.zeros(o)]
+
+    parts.append(torch.full((ACT, ), -0.5))
+    parts += lin(HID, OBS) + lin(HID, HID) + lin(ACT, HID)
+    for _ in range(2):
+        parts += lin(HID, OBS) + lin(HID, HID) + lin(1, HID)
+    theta = torch.cat(parts).numpy()
+    assert n_params_check is None or theta.size == n_params_check
+    return theta
+
+
+def flops_fwdbwd_launch(rows):
+    """Algorithmic FLOPs of ONE ppo_fwd_bwd_kernel launch (DESIGN.md 'Roofline'):
+    forward of the 3 nets (2*(Do*H + H*H + H*out) per row and net) + activation backward
+    (dz2 = dout W3, dz1 = dz2 W2: 2*(H*out + H*H)); weight gradients are the other kernel."""
+    per_row = 0
+    for out in (ACT, 1, 1):
+        per_row += 2 * (OBS * HID + HID * HID + HID * out) + 2 * (HID * out + HID * HID)
+    return per_row * rows
+
+
+def cpu_baseline(theta, inputs, seconds=12.0):
+    """The oracle (torch CPU fp32 port of the reference update) timed on the host cores,
+    on a bounded sample: whole updates of the SAME workload until `seconds` elapsed."""
+    import torch
+    from oracle.ppo_lag import OnPolicyData, PPOLagConfig, PPOLagOracle
+    threads = 4  # reference default `thread=4` (fsrl/config/ppol_cfg.py:11)
+    torch.set_num_threads(threads)
+    obs, act, rew, cost, term, trunc = inputs
+    em = lambda a: np.concatenate([a[:, e] for e in range(ENVS)])
+    data = OnPolicyData(obs=em(obs[:-1]), act=em(act), rew=em(rew), cost=em(cost), terminated=em(term),
+                        truncated=em(trunc), obs_next=em(obs[1:]), end_flag=em(term | trunc))
+    o = PPOLagOracle(PPOLagConfig(obs_dim=OBS, act_dim=ACT, hidden=(HID, HID), max_grad_norm=0.5,
+                                  target_kl=1e9))
+    o.set_params(theta)
+    rng = np.random.default_rng(0)
+    lag = np.array([0.75])
+    n, t0 = 0, time.perf_counter()
+    while True:
+        perms = [rng.permutation(NROWS) for _ in range(REPEAT)]
+        o.update(data, lag, 1.0 / 1.75, BATCH, REPEAT, perms=perms)
+        n += 1
+        if time.perf_counter() - t0 > seconds or n >= 12:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "updates/s", "cores": threads, "kind": "port",
+            "sample": f"{n} full updates (312 grad steps each) of the same 20k-row workload, "
+                      f"torch CPU fp32, {threads} threads of {os.cpu_count()} host cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from fsrl_amd.engine import Engine, EngineConfig
+    seed = rank
+    eng = Engine(EngineConfig(obs_dim=OBS, act_dim=ACT, hidden=HID, env_num=ENVS, buffer_size=100000,
+                              max_grad_norm=0.5, target_kl=None), device=local_rank)
+    theta = orthogonal_theta(seed, eng.n_params)
+    eng.set_params(theta)
+    inputs = make_inputs(seed)
+    obs, act, rew, cost, term, trunc = inputs
+    ids = np.arange(ENVS)
+    for t in range(NROWS // ENVS):   # fill the HBM-resident store (not timed)
+        eng.push(ids, obs[t], act[t], rew[t], cost[t], term[t], trunc[t], obs[t + 1])
+    eng.sync()
+    assert len(eng) == NROWS
+    lag, resc = np.array([0.75]), 1.0 / 1.75
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        eng.sync()
+        torch.cuda.synchronize()
+
+    def one_update(k):
+        stats, _ = eng.ppo_update(lag, resc, BATCH, REPEAT, perms=None, seed=1000 * seed + k + 1)
+        return stats
+
+    for k in range(args.warmup):
+        one_update(k)
+    # ---- timed region: exactly K updates, un-instrumented
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        stats = one_update(args.warmup + k)
+    barrier()
+    dt = time.perf_counter() - t0
+    grad_steps = stats.shape[0]
+    assert np.isfinite(stats).all()
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    # ---- roofline of the dominant kernel: HIP events around every ppo_fwd_bwd_kernel launch on
+    #      the library's compute stream, over K more updates of the same workload
+    eng.set_profiling(True)
+    k_ms, k_n, learn_ms, proc_ms = 0.0, 0, 0.0, 0.0
+    prof_steps = max(1, min(args.steps, 5))
+    for k in range(prof_steps):
+        one_update(10_000 + k)
+        tm = eng.last_timing()
+        k_ms += tm["fwdbwd_ms"]; k_n += tm["fwdbwd_launches"]
+        learn_ms += tm["learn_ms"]; proc_ms += tm["process_ms"]
+    eng.set_profiling(False)
+    avg_launch_s = (k_ms / max(k_n, 1)) * 1e-3
+    # rows per launch: 77 launches of 256 rows + 1 of 288 per pass
+    rows_avg = NROWS / (grad_steps / REPEAT)
+    achieved = flops_fwdbwd_launch(rows_avg) / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+
+    if rank == 0:
+        ups = args.steps / dt
+        out = {
+            "metric": "policy-updates/sec (PPO-Lagrangian update(), SafetyCarCircle-v0 shape, 256x256 MLP, 20k-step buffer)",
+            "value": ups * world, "unit": "updates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: PPO-Lag update, obs 8 / act 2, 256x256, N=20000 rows "
+                                   "(20 envs x 1000, 250-step episodes), batch 256, repeat 4, grad-clip 0.5, "
+                                   "KL early stop off", "seeds_per_gpu": 1, "parallelism": f"independent agents x{world}"},
+            "grad_steps_per_update": int(grad_steps),
+            "grad_steps_per_s": ups * grad_steps * world,
+            "buffer_rows_per_s": ups * NROWS * world,
+            "phase_ms": {"process_fn": proc_ms / prof_steps, "learn": learn_ms / prof_steps},
+            "roofline": {"bound": "mfma", "kernel": "ppo_fwd_bwd_kernel<256>", "achieved": achieved,
+                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_us": avg_launch_s * 1e6, "launches_timed": int(k_n),
+                         "flops_per_launch": flops_fwdbwd_launch(rows_avg)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(theta, inputs)
+            out["speedup_vs_cpu_port"] = out["value"] / world / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,223 @@
+"""GPU parity tests of the HIP PPO-Lagrangian path (through the C ABI) against
+ (a) the golden vectors recorded from the unmodified reference, and
+ (b) the CPU oracle on seeded inputs.
+
+Tolerances (fp32 path; DESIGN.md "Parity"): process_fn products 5e-6 * scale, per-minibatch
+logged stats 2e-5 abs + 2e-5 rel, parameters after a full update 2e-6 abs; GAE scan and the
+store index semantics are bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_npz, oracle_cfg_and_data, ppo_case
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["tiny", "dualclip", "earlystop", "c1", "c2"]
+
+
+def _engine(cfg, **over):
+    from fsrl_amd.engine import Engine, EngineConfig
+    ec = EngineConfig(obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"], hidden=cfg["hidden"][0],
+                      n_critics=2, env_num=cfg["env_num"], buffer_size=100000,
+                      max_action=cfg["max_action"], gamma=cfg["gamma"], gae_lambda=cfg["gae_lambda"],
+                      eps_clip=cfg["eps_clip"], dual_clip=cfg["dual_clip"], vf_coef=cfg["vf_coef"],
+                      max_grad_norm=cfg["max_grad_norm"], target_kl=cfg["target_kl"],
+                      norm_adv=cfg["advantage_normalization"], use_lagrangian=cfg["use_lagrangian"],
+                      lr=cfg["lr"])
+    for k, v in over.items():
+        setattr(ec, k, v)
+    return Engine(ec)
+
+
+def _push_golden(eng, g):
+    """Lock-step replay like FastCollector (fsrl/data/fast_collector.py:333)."""
+    rows = g["env_rows"]
+    off = np.concatenate([[0], np.cumsum(rows)])
+    out = []
+    for t in range(rows.max()):
+        ids = [e for e in range(len(rows)) if t < rows[e]]
+        sel = np.array([off[e] + t for e in ids])
+        out.append((ids, eng.push(ids, g["buf_obs"][sel], g["buf_act"][sel], g["buf_rew"][sel],
+                                  g["buf_cost"][sel], g["buf_terminated"][sel],
+                                  g["buf_truncated"][sel], g["buf_obs_next"][sel])))
+    return out
+
+
+def _rescale(lag):
+    return 1.0 / (float(np.sum(lag)) + 1.0)
+
+
+@pytest.mark.parametrize("n", [1, 7, 300, 2048, 20000])
+def test_gae_scan_bit_exact(n):
+    g = load_npz("gae_cases.npz")
+    cfg, _ = ppo_case("tiny")
+    eng = _engine(cfg)
+    for gamma, lam in ((0.99, 0.95), (1.0, 1.0), (0.9, 0.0)):
+        got = eng.gae_return(g[f"n{n}_v"], g[f"n{n}_vn"], g[f"n{n}_rew"], g[f"n{n}_end"], gamma, lam)
+        assert np.array_equal(got, g[f"n{n}_g{gamma}_l{lam}_adv"])
+    assert eng.gae_return(np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0),
+                          np.zeros(0, bool), 0.99, 0.95).shape == (0, )
+    eng.close()
+
+
+def test_gae_full_size_matches_oracle_and_linearity():
+    """BASELINE size (20k rows x 300-step episodes): oracle equality + linearity in rew."""
+    from oracle.scans import gae_return_c
+    rng = np.random.default_rng(7)
+    n = 20100
+    v = rng.standard_normal(n).astype(np.float32); vn = rng.standard_normal(n).astype(np.float32)
+    r1, r2 = rng.normal(0.5, 0.5, n), rng.normal(0, 1, n)
+    end = np.zeros(n, bool); end[299::300] = True; end[-1] = True
+    cfg, _ = ppo_case("tiny")
+    eng = _engine(cfg)
+    a1 = eng.gae_return(v, vn, r1, end, 0.99, 0.95)
+    assert np.array_equal(a1, gae_return_c(v, vn, r1, end, 0.99, 0.95))
+    z = np.zeros(n, np.float32)
+    a2 = eng.gae_return(z, z, r2, end, 0.99, 0.95)
+    a12 = eng.gae_return(v, vn, r1 + r2, end, 0.99, 0.95)
+    np.testing.assert_allclose(a12, a1 + a2, rtol=0, atol=1e-11)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_store_semantics(name):
+    """VectorReplayBuffer.add / sample_indices(0) / len / reset, bit-exact index semantics."""
+    cfg, g = ppo_case(name)
+    eng = _engine(cfg)
+    pushed = _push_golden(eng, g)
+    assert len(eng) == len(g["indices"])
+    assert np.array_equal(eng.sample0(), g["indices"])
+    # add() return values: ptr = slot, episode stats only on done rows
+    sub = -(-100000 // cfg["env_num"])
+    rows = g["env_rows"]; off = np.concatenate([[0], np.cumsum(rows)])
+    ep_r = np.zeros(len(rows)); ep_l = np.zeros(len(rows), int)
+    for t, (ids, (ptr, ep_rew, ep_len, ep_idx)) in enumerate(pushed):
+        for j, e in enumerate(ids):
+            assert ptr[j] == e * sub + t
+            ep_r[e] += g["buf_rew"][off[e] + t]; ep_l[e] += 1
+            done = g["buf_terminated"][off[e] + t] or g["buf_truncated"][off[e] + t]
+            if done:
+                assert ep_len[j] == ep_l[e] and ep_rew[j] == ep_r[e]
+                ep_r[e] = 0.0; ep_l[e] = 0
+            else:
+                assert ep_len[j] == 0 and ep_rew[j] == 0.0
+    eng.reset_store()
+    assert len(eng) == 0 and eng.sample0().size == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_process_fn_vs_golden(name):
+    cfg, g = ppo_case(name)
+    eng = _engine(cfg)
+    eng.set_params(g["theta0"])
+    assert np.array_equal(eng.get_params(), g["theta0"])
+    _push_golden(eng, g)
+    lag = g["lagrangian"]
+    n = eng.ppo_begin(lag, _rescale(lag), cfg["batch_size"])
+    assert n == len(g["indices"])
+    for k in ("values", "rets", "advs", "logp_old"):
+        scale = max(1.0, float(np.abs(g[k]).max()))
+        np.testing.assert_allclose(eng.batch_get(k), g[k], rtol=0, atol=5e-6 * scale, err_msg=k)
+    eng.ppo_end()
+    eng.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_minibatch_gradient_vs_autograd(name):
+    """lr = 0 keeps theta fixed, so the gradient left in the engine after one pass is the last
+    minibatch's, at theta0; compare with torch autograd of the oracle loss."""
+    from oracle.ppo_lag import PPOLagOracle, split_chunks
+    cfg, g = ppo_case(name)
+    eng = _engine(cfg, lr=0.0, target_kl=None)
+    eng.set_params(g["theta0"])
+    _push_golden(eng, g)
+    lag = g["lagrangian"]
+    eng.ppo_begin(lag, _rescale(lag), cfg["batch_size"])
+    eng.ppo_pass(g["perms"][0])
+    eng.ppo_end()
+    grads = eng.get_grads()
+    assert np.array_equal(eng.get_params(), g["theta0"])
+    ocfg, data = oracle_cfg_and_data(cfg, g)
+    o = PPOLagOracle(ocfg); o.set_params(g["theta0"])
+    pb = o.process(data)
+    chunk = split_chunks(len(data), cfg["batch_size"], g["perms"][0])[-1]
+    loss, _, _ = o._minibatch_losses(pb, chunk, lag, _rescale(lag))
+    o.optim.zero_grad(); loss.backward()
+    og = torch.cat([t.grad.reshape(-1) for t in o._leaves]).numpy()
+    np.testing.assert_allclose(grads, og, rtol=1e-4, atol=2e-6 * max(1.0, float(np.abs(og).max())))
+    eng.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_full_update_vs_golden(name):
+    cfg, g = ppo_case(name)
+    eng = _engine(cfg)
+    eng.set_params(g["theta0"])
+    _push_golden(eng, g)
+    lag = g["lagrangian"]
+    stats, stopped = eng.ppo_update(lag, _rescale(lag), cfg["batch_size"], cfg["repeat"], perms=g["perms"])
+    assert stats.shape == g["stats"].shape
+    assert (stopped >= 0) == bool(g["early_stop_msgs"])
+    np.testing.assert_allclose(stats, g["stats"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(eng.get_params(), g["theta_final"], rtol=0, atol=2e-6)
+    eng.close()
+
+
+def test_update_is_deterministic_and_idempotent_setup():
+    """Same inputs twice => bit-identical parameters and stats (fixed reduction orders)."""
+    cfg, g = ppo_case("c1")
+    outs = []
+    for _ in range(2):
+        eng = _engine(cfg)
+        eng.set_params(g["theta0"]); _push_golden(eng, g)
+        lag = g["lagrangian"]
+        stats, _ = eng.ppo_update(lag, _rescale(lag), cfg["batch_size"], cfg["repeat"], perms=g["perms"])
+        outs.append((stats.copy(), eng.get_params()))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_full_size_update_vs_oracle():
+    """BASELINE configs[1] shape (obs 8, act 2, 256x256, 20 100 rows = 67 episodes x 300,
+    B 256, repeat 1 to keep the CPU oracle in seconds): stats and parameters vs the oracle."""
+    from oracle.ppo_lag import OnPolicyData, PPOLagConfig, PPOLagOracle
+    from fsrl_amd.engine import Engine, EngineConfig
+    rng = np.random.default_rng(11)
+    env_num, ep, n_ep = 20, 300, 67
+    eng = Engine(EngineConfig(obs_dim=8, act_dim=2, hidden=256, env_num=env_num, max_grad_norm=0.5,
+                              target_kl=None))
+    ocfg = PPOLagConfig(obs_dim=8, act_dim=2, hidden=(256, 256), max_grad_norm=0.5, target_kl=1e9)
+    o = PPOLagOracle(ocfg)
+    torch.manual_seed(5)
+    theta = (0.1 * torch.randn(o.n_params)).numpy()
+    o.set_params(theta); eng.set_params(theta)
+    # episodes round-robin over envs, pushed env-major (one env at a time is also legal)
+    per_env = [n_ep // env_num + (1 if e < n_ep % env_num else 0) for e in range(env_num)]
+    cols = {k: [] for k in ("obs", "act", "rew", "cost", "term", "trunc", "obs_next")}
+    for e in range(env_num):
+        T = per_env[e] * ep
+        obs = rng.standard_normal((T + 1, 8)).astype(np.float32)
+        act = (0.3 * rng.standard_normal((T, 2))).astype(np.float32)
+        rew = rng.normal(0.5, 0.5, T); cost = (rng.random(T) < 0.1).astype(np.float64)
+        trunc = np.zeros(T, bool); trunc[ep - 1::ep] = True
+        term = np.zeros(T, bool)
+        for t in range(T):
+            eng.push([e], obs[t:t + 1], act[t:t + 1], rew[t:t + 1], cost[t:t + 1], term[t:t + 1],
+                     trunc[t:t + 1], obs[t + 1:t + 2])
+        for k, v in zip(cols, (obs[:-1], act, rew, cost, term, trunc, obs[1:])):
+            cols[k].append(v)
+    cat = {k: np.concatenate(v) for k, v in cols.items()}
+    data = OnPolicyData(obs=cat["obs"], act=cat["act"], rew=cat["rew"], cost=cat["cost"],
+                        terminated=cat["term"], truncated=cat["trunc"], obs_next=cat["obs_next"],
+                        end_flag=cat["term"] | cat["trunc"])
+    lag = np.array([0.75]); perm = rng.permutation(len(data))
+    torch.set_num_threads(4)
+    pb, ostats, _ = o.update(data, lag, _rescale(lag), 256, 1, perms=[perm])
+    stats, _ = eng.ppo_update(lag, _rescale(lag), 256, 1, perms=[perm])
+    assert stats.shape == ostats.shape == (78, 11)
+    np.testing.assert_allclose(eng.batch_get("advs"), pb["advs"].numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(stats, ostats, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(eng.get_params(), o.get_params(), rtol=0, atol=1e-5)
+    eng.close()
