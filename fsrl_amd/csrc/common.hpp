@@ -10,6 +10,12 @@
 #define FSRL_DOW 32         // floats per row of the dout side buffer: [0,16) dout, [16,32) dsigma
 #define FSRL_MAX_OBS 128
 #define FSRL_MAX_ACT 16
+#define FSRL_W1_LDS 16      // W1 is staged to LDS when obs_dim <= 16
+// per-row loss inputs of the permuted pass batch: act[16] | logp_old | adv_n[4] | ret[4] | pad
+#define FSRL_RD 32
+#define FSRL_RD_LOGP 16
+#define FSRL_RD_ADV 17
+#define FSRL_RD_RET 21
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -47,6 +53,7 @@ struct PpoStepArgs {
     double kl_thresh;  // 1.5 * target_kl in float64 (python float in the reference)
     float step_size;   // lr / (1 - beta1^t)          (host float64 -> f32, like torch)
     float bc2_sqrt;    // sqrt(1 - beta2^t)
+    int dbg_phase;     // 0 = normal; >0: timing experiments only (env FSRL_DBG_PHASE), results invalid
 };
 
 // Device-resident control block (one per context).

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -93,8 +94,9 @@ struct fsrl_ctx {
 
     // ppo working set
     int batch_size = 0, mbp_max = 0, n_tiles_max = 0;
-    float *A1 = nullptr, *A2 = nullptr, *D1 = nullptr, *D2 = nullptr, *DO = nullptr, *XB = nullptr;
-    float *statp = nullptr, *gsq_part = nullptr, *mbstats = nullptr;
+    float *A1 = nullptr, *A2 = nullptr, *D1 = nullptr, *D2 = nullptr, *DO = nullptr;
+    float *obs_p = nullptr, *rd_p = nullptr;   // pass-ordered batch (+32 pad rows)
+    float *statp = nullptr, *gsq_part = nullptr;
     int *d_perm = nullptr, *h_perm = nullptr;            // [N] (pinned host)
     int *d_mbstart = nullptr, *d_mbsize = nullptr, *h_mbplan = nullptr;  // h_mbplan pinned [2*cap]
     size_t mb_cap = 0;
@@ -164,7 +166,7 @@ static void build_layout(fsrl_ctx* c) {
         no.end = dev;
     }
     c->n_api = api;
-    c->n_dev = round_up(dev, 256);
+    c->n_dev = round_up(dev, 1024);
 }
 
 extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
@@ -174,8 +176,8 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
     void* dptrs[] = {c->P, c->M, c->V, c->G, c->ctrl, c->st.obs, c->st.obs_next, c->st.act, c->st.rew,
                      c->st.cost, c->st.flags, c->b.obs, c->b.obs_next, c->b.act, c->b.rew, c->b.cost,
                      c->b.flags, c->d_indices, c->d_end, c->d_seg, c->values, c->vnext, c->advs,
-                     c->rets, c->logp_old, c->A1, c->A2, c->D1, c->D2, c->DO, c->XB, c->statp,
-                     c->gsq_part, c->mbstats, c->d_perm, c->d_mbstart, c->d_mbsize, c->d_stats,
+                     c->rets, c->logp_old, c->A1, c->A2, c->D1, c->D2, c->DO, c->obs_p, c->rd_p, c->statp,
+                     c->gsq_part, c->d_perm, c->d_mbstart, c->d_mbsize, c->d_stats,
                      c->scratch};
     for (void* p : dptrs) if (p) (void)hipFree(p);
     void* hptrs[] = {c->h_ctrl, c->h_indices, c->h_end, c->h_seg, c->h_perm, c->h_mbplan};
@@ -246,6 +248,8 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     TRY(hipMalloc(&c->advs, ms * C * 4)); TRY(hipMalloc(&c->rets, ms * C * 4));
     TRY(hipMalloc(&c->logp_old, ms * 4));
     TRY(hipMalloc(&c->d_perm, ms * 4)); TRY(hipHostMalloc(&c->h_perm, ms * 4));
+    TRY(hipMalloc(&c->obs_p, (ms + 32) * Do * 4)); TRY(hipMemset(c->obs_p, 0, (ms + 32) * Do * 4));
+    TRY(hipMalloc(&c->rd_p, (ms + 32) * FSRL_RD * 4)); TRY(hipMemset(c->rd_p, 0, (ms + 32) * FSRL_RD * 4));
     for (auto& s : c->stage) {
         const size_t k = fsrl_ctx::STAGE_CAP;
         TRY(hipHostMalloc(&s.slot, k * 4)); TRY(hipHostMalloc(&s.obs, k * Do * 4));
@@ -458,7 +462,7 @@ static int launch_infer(fsrl_ctx* c, const InferArgs& ia, int jobs_y, hipStream_
     if (tiles == 0) return 0;
     return dispatch_H(c->cfg.hidden, [&](auto hc) {
         constexpr int H = decltype(hc)::value;
-        hipLaunchKernelGGL(mlp_infer_kernel<H>, dim3(tiles, jobs_y), dim3(256), 0, s, c->P, c->md, ia);
+        hipLaunchKernelGGL(mlp_infer_kernel<H>, dim3(tiles, jobs_y), dim3(4 * H), 0, s, c->P, c->md, ia);
         HIPCHK(hipGetLastError());
         return 0;
     });
@@ -556,17 +560,16 @@ static int ensure_ppo_buffers(fsrl_ctx* c, int B) {
     const int mbp = round_up(2 * B, 16);
     if (mbp <= c->mbp_max) return 0;
     HIPCHK(hipStreamSynchronize(c->compute));
-    for (float** p : {&c->A1, &c->A2, &c->D1, &c->D2, &c->DO, &c->XB, &c->statp, &c->gsq_part})
+    for (float** p : {&c->A1, &c->A2, &c->D1, &c->D2, &c->DO, &c->statp, &c->gsq_part})
         if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
     const int H = c->cfg.hidden, nn = c->md.n_nets;
     const size_t act = (size_t)nn * mbp * H * 4;
     HIPCHK(hipMalloc(&c->A1, act)); HIPCHK(hipMalloc(&c->A2, act));
     HIPCHK(hipMalloc(&c->D1, act)); HIPCHK(hipMalloc(&c->D2, act));
     HIPCHK(hipMalloc(&c->DO, (size_t)nn * mbp * FSRL_DOW * 4));
-    HIPCHK(hipMalloc(&c->XB, (size_t)mbp * c->cfg.obs_dim * 4));
     HIPCHK(hipMalloc(&c->statp, (size_t)(mbp / 16) * nn * 4 * 4));
-    const int pb = (H / 32) * (H / 32) + H / 64;
-    HIPCHK(hipMalloc(&c->gsq_part, (size_t)nn * pb * 4));
+    const int pb = (H / 32) * (H / 32) + H / 32;
+    HIPCHK(hipMalloc(&c->gsq_part, (size_t)(nn * pb + 1) * 4));
     c->mbp_max = mbp;
     c->n_tiles_max = mbp / 16;
     return 0;
@@ -643,12 +646,10 @@ extern "C" int fsrl_ppo_begin(fsrl_ctx* c, const double* lagrangians, double res
         HIPCHK(hipStreamSynchronize(s));
         if (c->d_mbstart) HIPCHK(hipFree(c->d_mbstart));
         if (c->d_mbsize) HIPCHK(hipFree(c->d_mbsize));
-        if (c->mbstats) HIPCHK(hipFree(c->mbstats));
         if (c->h_mbplan) HIPCHK(hipHostFree(c->h_mbplan));
-        c->d_mbstart = c->d_mbsize = nullptr; c->mbstats = nullptr; c->h_mbplan = nullptr;
+        c->d_mbstart = c->d_mbsize = nullptr; c->h_mbplan = nullptr;
         const size_t cap = nmb * 2;
         HIPCHK(hipMalloc(&c->d_mbstart, cap * 4)); HIPCHK(hipMalloc(&c->d_mbsize, cap * 4));
-        HIPCHK(hipMalloc(&c->mbstats, cap * FSRL_MAX_CRITICS * 2 * 4));
         HIPCHK(hipHostMalloc(&c->h_mbplan, cap * 2 * 4));
         c->mb_cap = cap;
     }
@@ -711,20 +712,24 @@ extern "C" int fsrl_ppo_pass(fsrl_ctx* c, const int64_t* perm, uint64_t seed, in
     int rc = ensure_stats(c, c->n_steps + nmb);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->d_perm, c->h_perm, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    if (c->cfg.norm_adv) {
-        hipLaunchKernelGGL(advstats_kernel, dim3(nmb, C), dim3(256), 0, s, c->advs, c->d_perm, c->d_mbstart,
-                           c->d_mbsize, n, C, c->mbstats);
+    {
+        PrepArgs pa{};
+        pa.obs = c->b.obs; pa.act = c->b.act; pa.advs = c->advs; pa.rets = c->rets; pa.logp_old = c->logp_old;
+        pa.perm = c->d_perm; pa.mb_start = c->d_mbstart; pa.mb_size = c->d_mbsize; pa.obs_p = c->obs_p;
+        pa.rd_p = c->rd_p; pa.N = n; pa.C = C; pa.Do = c->cfg.obs_dim; pa.Da = c->cfg.act_dim;
+        pa.norm_adv = c->cfg.norm_adv;
+        hipLaunchKernelGGL(ppo_prepare_pass_kernel, dim3(nmb), dim3(256), 0, s, pa);
         HIPCHK(hipGetLastError());
     }
     PpoBatchPtrs bp{};
-    bp.obs = c->b.obs; bp.act = c->b.act; bp.advs = c->advs; bp.rets = c->rets; bp.logp_old = c->logp_old;
-    bp.perm = c->d_perm; bp.mbstats = c->mbstats; bp.A1 = c->A1; bp.A2 = c->A2; bp.D1 = c->D1; bp.D2 = c->D2;
-    bp.DO = c->DO; bp.XB = c->XB; bp.statp = c->statp; bp.ctrl = c->ctrl; bp.mbp_max = c->mbp_max; bp.N = n;
+    bp.obs_p = c->obs_p; bp.rd_p = c->rd_p; bp.A1 = c->A1; bp.A2 = c->A2; bp.D1 = c->D1; bp.D2 = c->D2;
+    bp.DO = c->DO; bp.statp = c->statp; bp.mbp_max = c->mbp_max;
     WgradPtrs wp{};
-    wp.A1 = c->A1; wp.A2 = c->A2; wp.D1 = c->D1; wp.D2 = c->D2; wp.DO = c->DO; wp.XB = c->XB; wp.grad = c->G;
+    wp.A1 = c->A1; wp.A2 = c->A2; wp.D1 = c->D1; wp.D2 = c->D2; wp.DO = c->DO; wp.X = c->obs_p; wp.grad = c->G;
     wp.gsq_part = c->gsq_part; wp.ctrl = c->ctrl; wp.mbp_max = c->mbp_max;
-    const int pb = (H / 32) * (H / 32) + H / 64;
-    const int nparts = nn * pb;
+    wp.P = c->P; wp.statp = c->statp; wp.stats = c->d_stats;
+    const int pb = (H / 32) * (H / 32) + H / 32;
+    const int nparts = nn * pb + 1;   // + the stats block
 
     PpoStepArgs sa{};
     sa.rescale = (float)c->rescaling;
@@ -737,6 +742,7 @@ extern "C" int fsrl_ppo_pass(fsrl_ctx* c, const int64_t* perm, uint64_t seed, in
     sa.one_minus_b2 = (float)(1.0 - (double)c->cfg.beta2);
     sa.kl_thresh = 1.5 * (double)c->cfg.target_kl;
     sa.pass = c->pass_index;
+    { const char* e = getenv("FSRL_DBG_PHASE"); sa.dbg_phase = e ? atoi(e) : 0; }
     sa.iters_in_pass = nmb;
 
     for (int mb = 0; mb < nmb; ++mb) {
@@ -749,6 +755,7 @@ extern "C" int fsrl_ppo_pass(fsrl_ctx* c, const int64_t* perm, uint64_t seed, in
         sa.step_size = (float)((double)c->cfg.lr / bc1);
         sa.bc2_sqrt = (float)std::sqrt(bc2);
         const int tiles = (sa.mb_size + 15) / 16;
+        wp.X = c->obs_p + (size_t)sa.mb_start * c->cfg.obs_dim;
         const bool prof = c->profiling;
         if (prof) {
             while (c->k_ev.size() < c->k_ev_used + 2) {
@@ -758,21 +765,18 @@ extern "C" int fsrl_ppo_pass(fsrl_ctx* c, const int64_t* perm, uint64_t seed, in
         }
         rc = dispatch_H(H, [&](auto hc) {
             constexpr int HH = decltype(hc)::value;
-            hipLaunchKernelGGL(ppo_fwd_bwd_kernel<HH>, dim3(tiles, nn), dim3(256), 0, s, c->P, c->md, bp, sa);
+            hipLaunchKernelGGL(ppo_fwd_bwd_kernel<HH>, dim3(tiles, nn), dim3(4 * HH), 0, s, c->P, c->md, bp, sa);
             return 0;
         });
         if (rc) return rc;
         if (prof) { HIPCHK(hipEventRecord(c->k_ev[c->k_ev_used + 1], s)); c->k_ev_used += 2; }
-        hipLaunchKernelGGL(ppo_stats_kernel, dim3(1), dim3(64), 0, s, c->P, c->md, c->statp, tiles, sa, c->ctrl,
-                           c->d_stats);
         rc = dispatch_H(H, [&](auto hc) {
             constexpr int HH = decltype(hc)::value;
-            hipLaunchKernelGGL(ppo_wgrad_kernel<HH>, dim3(nparts), dim3(256), 0, s, c->md, wp, tiles * 16,
-                               sa.pass);
+            hipLaunchKernelGGL(ppo_wgrad_kernel<HH>, dim3(nparts), dim3(1024), 0, s, c->md, wp, tiles * 16, sa);
             return 0;
         });
         if (rc) return rc;
-        hipLaunchKernelGGL(adam_clip_kernel, dim3(c->n_dev / 256), dim3(256), 0, s, c->P, c->M, c->V, c->G,
+        hipLaunchKernelGGL(adam_clip_kernel, dim3(c->n_dev / 1024), dim3(256), 0, s, c->P, c->M, c->V, c->G,
                            c->gsq_part, nparts, c->n_dev, sa, c->ctrl);
         HIPCHK(hipGetLastError());
     }

@@ -121,90 +121,72 @@ __global__ __launch_bounds__(64) void gae_kernel(const GaeArgs a) {
     }
 }
 
-// ---------------------------------------------------------------- per-minibatch adv stats
-// mean and unbiased std of each critic's advantages over the rows of every minibatch of a
-// pass (the reference normalises the minibatch copy, ppo_lag.py:178-182).  float64 accumulate.
-__global__ __launch_bounds__(256) void advstats_kernel(const float* __restrict__ advs,
-                                                      const int* __restrict__ perm,
-                                                      const int* __restrict__ mb_start,
-                                                      const int* __restrict__ mb_size, int N, int C,
-                                                      float* __restrict__ out) {
+// ---------------------------------------------------------------- per-pass batch preparation
+// One block per minibatch of the pass: (1) mean and unbiased std of each critic's advantages
+// over the minibatch rows (the reference normalises the minibatch copy every pass,
+// ppo_lag.py:178-182; float64 accumulate), (2) the minibatch's rows permuted into pass order:
+// obs_p[pos] and the per-row loss inputs rd_p[pos] = act | logp_old | adv_n[c] | ret[c].
+// After this the fused step kernel reads contiguous, coalesced tiles with no index chase.
+struct PrepArgs {
+    const float* obs; const float* act; const float* advs; const float* rets; const float* logp_old;
+    const int* perm; const int* mb_start; const int* mb_size;
+    float* obs_p; float* rd_p;
+    int N, C, Do, Da, norm_adv;
+};
+
+__global__ __launch_bounds__(256) void ppo_prepare_pass_kernel(const PrepArgs a) {
     __shared__ double sh[4];
     __shared__ double mean_s;
-    const int mb = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
-    const int st = mb_start[mb], n = mb_size[mb];
-    const float* __restrict__ a = advs + (size_t)c * N;
-    double s = 0.0;
-    for (int m = tid; m < n; m += 256) s += (double)a[perm[st + m]];
-    s = wave_sum_d(s);
-    if ((tid & 63) == 0) sh[tid >> 6] = s;
-    __syncthreads();
-    if (tid == 0) mean_s = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (double)n;
-    __syncthreads();
-    const double mean = mean_s;
-    double q = 0.0;
-    for (int m = tid; m < n; m += 256) {
-        const double d = (double)a[perm[st + m]] - mean;
-        q += d * d;
+    __shared__ float mean_f[FSRL_MAX_CRITICS], sd_f[FSRL_MAX_CRITICS];
+    const int mb = blockIdx.x, tid = threadIdx.x;
+    const int st = a.mb_start[mb], n = a.mb_size[mb];
+    if (a.norm_adv) {
+        for (int c = 0; c < a.C; ++c) {
+            const float* __restrict__ adv = a.advs + (size_t)c * a.N;
+            double s = 0.0;
+            for (int m = tid; m < n; m += 256) s += (double)adv[a.perm[st + m]];
+            s = wave_sum_d(s);
+            __syncthreads();
+            if ((tid & 63) == 0) sh[tid >> 6] = s;
+            __syncthreads();
+            if (tid == 0) mean_s = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (double)n;
+            __syncthreads();
+            const double mean = mean_s;
+            double q = 0.0;
+            for (int m = tid; m < n; m += 256) {
+                const double d = (double)adv[a.perm[st + m]] - mean;
+                q += d * d;
+            }
+            q = wave_sum_d(q);
+            __syncthreads();
+            if ((tid & 63) == 0) sh[tid >> 6] = q;
+            __syncthreads();
+            if (tid == 0) {
+                const double var = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (double)(n - 1);
+                mean_f[c] = (float)mean;
+                sd_f[c] = (float)sqrt(var);
+            }
+        }
+        __syncthreads();
     }
-    q = wave_sum_d(q);
-    __syncthreads();
-    if ((tid & 63) == 0) sh[tid >> 6] = q;
-    __syncthreads();
-    if (tid == 0) {
-        const double var = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (double)(n - 1);
-        out[((size_t)mb * C + c) * 2 + 0] = (float)mean;
-        out[((size_t)mb * C + c) * 2 + 1] = (float)sqrt(var);
+    for (int e = tid; e < n * FSRL_RD; e += 256) {
+        const int m = e / FSRL_RD, f = e - m * FSRL_RD;
+        const int r = a.perm[st + m];
+        float v = 0.0f;
+        if (f < a.Da) v = a.act[(size_t)r * a.Da + f];
+        else if (f == FSRL_RD_LOGP) v = a.logp_old[r];
+        else if (f >= FSRL_RD_ADV && f < FSRL_RD_ADV + a.C) {
+            const int c = f - FSRL_RD_ADV;
+            v = a.advs[(size_t)c * a.N + r];
+            if (a.norm_adv) v = (v - mean_f[c]) / sd_f[c];
+        } else if (f >= FSRL_RD_RET && f < FSRL_RD_RET + a.C) {
+            v = a.rets[(size_t)(f - FSRL_RD_RET) * a.N + r];
+        }
+        a.rd_p[(size_t)(st + m) * FSRL_RD + f] = v;
     }
-}
-
-// ---------------------------------------------------------------- logged stats of one step
-// Runs as one extra single-wave launch after the fwd/bwd kernel (parameters still pre-update,
-// like the reference which builds `dist` before optim.step, ppo_lag.py:225-247).
-__global__ __launch_bounds__(64) void ppo_stats_kernel(const float* __restrict__ P,
-                                                      const ModelDesc md,
-                                                      const float* __restrict__ statp, int n_tiles,
-                                                      const PpoStepArgs sa, CtrlBlock* ctrl,
-                                                      float* __restrict__ stats) {
-    if (sa.pass > ctrl->stopped_after) return;
-    const int lane = threadIdx.x;
-    const int nn = md.n_nets, C = nn - 1;
-    // sums over tiles, fixed order: lane handles (net, field) pairs
-    float mine = 0.0f;
-    if (lane < nn * 4) {
-        const int net = lane >> 2, f = lane & 3;
-        for (int t = 0; t < n_tiles; ++t) mine += statp[((size_t)t * nn + net) * 4 + f];
-    }
-    const float invB = 1.0f / (float)sa.mb_size;
-    const float term = __shfl(mine, 0, 64), safety = __shfl(mine, 1, 64), kls = __shfl(mine, 2, 64);
-    float vf[FSRL_MAX_CRITICS];
-#pragma unroll
-    for (int c = 0; c < FSRL_MAX_CRITICS; ++c) vf[c] = __shfl(mine, 4 * (c + 1), 64) * invB;
-    if (lane == 0) {
-        float ent = 0.0f;
-        for (int d = 0; d < md.Da; ++d) ent += 1.4189385332046727f + logf(expf(P[md.net[0].sigma + d]));
-        const float actor_rew = -term * invB;
-        const float actor_safety = sa.use_lagrangian ? safety * invB : 0.0f;
-        const float actor_total = sa.rescale * (actor_rew + actor_safety);
-        const float kl = kls * invB;
-        float vf_total = 0.0f;
-#pragma unroll
-        for (int c = 0; c < FSRL_MAX_CRITICS; ++c)
-            if (c < C) vf_total += vf[c];
-        float* o = stats + (size_t)sa.step * FSRL_PPO_NSTATS;
-        o[0] = sa.rescale;
-        o[1] = (sa.use_lagrangian && C > 1) ? sa.lam[0] : 0.0f;
-        o[2] = actor_safety;
-        o[3] = actor_rew;
-        o[4] = actor_total;
-        o[5] = kl;
-        o[6] = vf[0];
-        o[7] = (C > 1) ? vf[1] : 0.0f;
-        o[8] = vf_total;
-        o[9] = actor_total + sa.vf_coef * vf_total;
-        o[10] = ent;
-        const double ks = (sa.first_in_pass ? 0.0 : ctrl->kl_sum) + (double)kl;
-        ctrl->kl_sum = ks;
+    for (int e = tid; e < n * a.Do; e += 256) {
+        const int m = e / a.Do, k = e - m * a.Do;
+        a.obs_p[(size_t)(st + m) * a.Do + k] = a.obs[(size_t)a.perm[st + m] * a.Do + k];
     }
 }
 
@@ -219,12 +201,18 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ P, f
                                                        CtrlBlock* ctrl) {
     __shared__ double sh[4];
     __shared__ float coef_s;
-    if (sa.pass > ctrl->stopped_after) return;
     const int tid = threadIdx.x;
+    const int i4 = (blockIdx.x * 256 + tid) * 4;   // n is a multiple of 1024: float4 per thread
+    // issue every load of this thread first (one cold round trip), then reduce the norm
+    f32x4 g = {0, 0, 0, 0}, m = g, v = g, p = g;
+    if (i4 < n) {
+        g = *reinterpret_cast<const f32x4*>(G + i4); m = *reinterpret_cast<const f32x4*>(M + i4);
+        v = *reinterpret_cast<const f32x4*>(V + i4); p = *reinterpret_cast<const f32x4*>(P + i4);
+    }
     float coef = 1.0f;
     if (sa.max_grad_norm > 0.0f) {
         double s = 0.0;
-        for (int i = tid; i < nparts; i += 256) s += (double)gsq_part[i];
+        for (int k = tid; k < nparts; k += 256) s += (double)gsq_part[k];
         s = wave_sum_d(s);
         if ((tid & 63) == 0) sh[tid >> 6] = s;
         __syncthreads();
@@ -236,17 +224,21 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ P, f
         __syncthreads();
         coef = coef_s;
     }
-    const int i = blockIdx.x * 256 + tid;
-    if (i < n) {
-        const float g = G[i] * coef;
-        float m = M[i], v = V[i];
-        m = m + sa.one_minus_b1 * (g - m);
-        v = v * sa.beta2;
-        v = v + (sa.one_minus_b2 * g) * g;
-        const float denom = sqrtf(v) / sa.bc2_sqrt + sa.adam_eps;
-        M[i] = m;
-        V[i] = v;
-        P[i] = P[i] + (-sa.step_size * m) / denom;
+    if (i4 < n) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = g[e] * coef;
+            float me = m[e], ve = v[e];
+            me = me + sa.one_minus_b1 * (ge - me);
+            ve = ve * sa.beta2;
+            ve = ve + (sa.one_minus_b2 * ge) * ge;
+            const float denom = sqrtf(ve) / sa.bc2_sqrt + sa.adam_eps;
+            m[e] = me; v[e] = ve;
+            p[e] = p[e] + (-sa.step_size * me) / denom;
+        }
+        *reinterpret_cast<f32x4*>(M + i4) = m;
+        *reinterpret_cast<f32x4*>(V + i4) = v;
+        *reinterpret_cast<f32x4*>(P + i4) = p;
     }
     // pass-level KL early stop (ppo_lag.py:251-255); only after the last minibatch of a pass
     if (sa.last_in_pass && blockIdx.x == 0 && tid == 0 && sa.target_kl > 0.0f) {

@@ -5,13 +5,18 @@
 // Linear(out);  actor: mu = max_action*tanh(out), sigma = exp(sigma_param);  critic: V = out.
 //
 // Work decomposition (DESIGN.md "Kernels"):
-//   * one workgroup (4 waves) owns ONE 16-row M-tile of ONE network and runs the whole
-//     forward, the loss head and the activation backward for it (ppo_fwd_bwd_kernel).  The two
-//     H x H GEMMs run on v_mfma_f32_16x16x4_f32 (exact fp32); the weight operand is streamed
-//     straight from L2 into VGPRs (it is used by exactly one wave once per tile, so an LDS
+//   * one workgroup owns ONE 16-row M-tile of ONE network and runs the whole forward, the loss
+//     head and the activation backward for it (ppo_fwd_bwd_kernel).  The workgroup has 4*H
+//     threads = H/16 waves, ONE 16-wide N-tile per wave, so that every wave's slice of W2
+//     (H/16 float4 per lane) is requested from L2 in a single burst at kernel entry: after a
+//     kernel boundary the caches are cold and a dependent load round trip costs ~1 us, which
+//     is what bounded the first version of this kernel -- not the MFMA pipe.
+//     The two H x H GEMMs run on v_mfma_f32_16x16x4_f32 (exact fp32); the weight operand goes
+//     L2 -> VGPR directly (each element is used by exactly one wave once per tile; an LDS
 //     round trip would be pure overhead), the activation operand comes from LDS as b128.
 //   * weight gradients are a second kernel (ppo_wgrad_kernel): 32x32 output tiles per
-//     workgroup with split-K over the 4 waves, so no per-tile partial gradients ever reach HBM.
+//     workgroup with 16-way split-K over the waves (again: all loads of a wave in one burst),
+//     so no per-tile partial gradients ever reach HBM.
 #pragma once
 #include "common.hpp"
 
@@ -24,101 +29,151 @@ struct TileSmem {
     float d2[16 * LD];                // dL/dz2 (after ReLU mask)
     float out[16 * FSRL_MAX_ACT];     // head pre-activation [i][o]
     float dout[16 * FSRL_DOW];        // [i][0..16) dL/dout, [i][16..32) dL/dsigma_param rows
-    int rowidx[16];
+    float rd[16 * FSRL_RD];           // per-row loss inputs (act, logp_old, adv_n, ret)
+    float st[16 * 4];                 // per-row partial stats
+    // small parameters staged once per tile (one burst at kernel entry)
+    float w3[FSRL_MAX_ACT * H];
+    float b1[H], b2[H], b3[FSRL_MAX_ACT], sig[FSRL_MAX_ACT];
+    float w1[H * FSRL_W1_LDS];        // W1 rows when Do <= FSRL_W1_LDS (else read from L2)
+};
+
+template <int H>
+struct TileGeom {
+    static constexpr int NT = 4 * H;      // threads per workgroup
+    static constexpr int WAVES = H / 16;  // one 16-wide N tile per wave
+};
+
+// W2 slice of one wave for the forward GEMM: lane (li = lane&15, q = lane>>4) holds
+// W2[n0+li][16*kc + 4q .. +3] for every kc.  Issued as one burst (H/16 x 16-byte loads).
+template <int H>
+struct FwdW2Frag {
+    f32x4 b[H / 16];
+    __device__ __forceinline__ void load(const float* __restrict__ W2, int wave, int lane) {
+        const int li = lane & 15, q = lane >> 4;
+        const float* row = W2 + (size_t)(wave * 16 + li) * H + 4 * q;
+#pragma unroll
+        for (int kc = 0; kc < H / 16; ++kc) b[kc] = *reinterpret_cast<const f32x4*>(row + 16 * kc);
+    }
+};
+
+// Prologue: the small parameters and this tile's inputs are loaded into registers first
+// (issue()), the W2 burst is issued behind them, and only then are the registers written to
+// LDS (commit()).  VMEM returns in issue order, so commit() waits for the small loads only and
+// the 256 KB W2 burst keeps streaming in underneath layer 1.
+// `x` points at the tile's first row (rows are contiguous), n_valid rows exist.
+template <int H>
+struct TileStage {
+    static constexpr int NT = TileGeom<H>::NT;
+    static constexpr int NX = (16 * FSRL_MAX_OBS + NT - 1) / NT;   // obs elements per thread
+    static constexpr int NR = (16 * FSRL_RD + NT - 1) / NT;        // row-data elements per thread
+    float xv[NX], w3v[4], w1v[4], rdv[NR], b1v, b2v, b3v, sgv;
+
+    __device__ __forceinline__ void issue(const float* __restrict__ P, const NetOff no, const int Do,
+                                          const int Da, const float* __restrict__ x,
+                                          const float* __restrict__ rd, const int n_valid,
+                                          const int tid) {
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int e = tid + u * NT;
+            xv[u] = (e < 16 * Do && e / Do < n_valid) ? x[e] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + u * NT;
+            w3v[u] = (e < no.out * H) ? P[no.W3 + e] : 0.0f;
+            w1v[u] = (Do <= FSRL_W1_LDS && e < H * Do) ? P[no.W1 + e] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int e = tid + u * NT;
+            rdv[u] = (rd != nullptr && e < 16 * FSRL_RD && e / FSRL_RD < n_valid) ? rd[e] : 0.0f;
+        }
+        b1v = (tid < H) ? P[no.b1 + tid] : 0.0f;
+        b2v = (tid < H) ? P[no.b2 + tid] : 0.0f;
+        b3v = (tid < no.out) ? P[no.b3 + tid] : 0.0f;
+        sgv = (no.sigma >= 0 && tid < Da) ? P[no.sigma + tid] : 0.0f;
+    }
+
+    __device__ __forceinline__ void commit(TileSmem<H>& sm, const NetOff no, const int Do,
+                                           const int tid) const {
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int e = tid + u * NT;
+            if (e < 16 * Do) { const int i = e / Do, k = e - i * Do; sm.xT[k * 16 + i] = xv[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + u * NT;
+            if (e < no.out * H) sm.w3[e] = w3v[u];
+            if (Do <= FSRL_W1_LDS && e < H * Do) sm.w1[e] = w1v[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int e = tid + u * NT;
+            if (e < 16 * FSRL_RD) sm.rd[e] = rdv[u];
+        }
+        if (tid < H) { sm.b1[tid] = b1v; sm.b2[tid] = b2v; }
+        if (tid < FSRL_MAX_ACT) { sm.b3[tid] = b3v; sm.sig[tid] = sgv; }
+    }
 };
 
 // ---------------------------------------------------------------- forward of one 16-row tile
-// Pre: sm.xT filled and __syncthreads() done.  Post: sm.h1, sm.h2, sm.out valid (synced).
+// Pre: sm.xT filled + __syncthreads() done; wf holds this wave's W2 slice (may still be in
+// flight).  Post: sm.h1, sm.h2, sm.out valid (synced).
 template <int H>
 __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __restrict__ P,
-                                             const NetOff no, const int Do, const int tid) {
+                                             const NetOff no, const int Do, const int tid,
+                                             const FwdW2Frag<H>& wf) {
     constexpr int LD = TileSmem<H>::LD;
-    constexpr int NTW = H / 64;  // 16-wide N tiles per wave
+    constexpr int WAVES = TileGeom<H>::WAVES;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
 
-    // ---- layer 1 (K = Do is tiny: plain FMA, one output column per thread)
-    for (int j = tid; j < H; j += 256) {
-        float acc[16];
-        const float b = P[no.b1 + j];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = b;
-        const float* __restrict__ w = P + no.W1 + (size_t)j * Do;
+    // ---- layer 1 (K = Do is tiny: plain FMA); thread = (column j, group of 4 rows)
+    {
+        const int j = tid % H, rg = tid / H;
+        const float b = sm.b1[j];
+        float acc[4] = {b, b, b, b};
+        const float* __restrict__ w = (Do <= FSRL_W1_LDS) ? &sm.w1[j * Do] : P + no.W1 + (size_t)j * Do;
         for (int k = 0; k < Do; ++k) {
             const float wk = w[k];
-            const f32x4* xr = reinterpret_cast<const f32x4*>(&sm.xT[k * 16]);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(&sm.xT[k * 16 + 4 * rg]);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const f32x4 x = xr[v];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[4 * v + e] = fmaf(x[e], wk, acc[4 * v + e]);
-            }
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(x[e], wk, acc[e]);
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sm.h1[i * LD + j] = fmaxf(acc[i], 0.0f);
+        for (int e = 0; e < 4; ++e) sm.h1[(4 * rg + e) * LD + j] = fmaxf(acc[e], 0.0f);
     }
     __syncthreads();
 
     // ---- layer 2: h2[16,H] = relu(h1[16,H] @ W2^T + b2) on MFMA 16x16x4 (fp32)
     {
-        f32x4 acc[NTW];
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* __restrict__ W2 = P + no.W2;
-        const int n0 = wave * NTW * 16;
-        // lane (li,q) feeds k-slot q; over 4 MFMAs it covers k = kc+4q+{0..3} (one float4)
-        const float* __restrict__ wrow[NTW];
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) wrow[t] = W2 + (size_t)(n0 + t * 16 + li) * H + 4 * q;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* arow = &sm.h1[li * LD + 4 * q];
-#pragma unroll 4
-        for (int kc = 0; kc < H; kc += 16) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + kc);
-            f32x4 b[NTW];
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) b[t] = *reinterpret_cast<const f32x4*>(wrow[t] + kc);
+        for (int kc = 0; kc < H / 16; ++kc) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * kc);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[t] = mfma_16x16x4(a[s], b[t][s], acc[t]);
-            }
+            for (int s = 0; s < 4; ++s) acc = mfma_16x16x4(a[s], wf.b[kc][s], acc);
         }
+        const int j = wave * 16 + li;
+        const float bias = sm.b2[j];
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const int j = n0 + t * 16 + li;
-            const float bias = P[no.b2 + j];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sm.h2[(4 * q + r) * LD + j] = fmaxf(acc[t][r] + bias, 0.0f);
-        }
+        for (int r = 0; r < 4; ++r) sm.h2[(4 * q + r) * LD + j] = fmaxf(acc[r] + bias, 0.0f);
     }
     __syncthreads();
 
-    // ---- head (out <= 16): 16 lanes per row, shuffle-reduce
-    {
-        const int i = tid >> 4, p = tid & 15;
+    // ---- head (out <= 16): one wave per row, 64-lane shuffle reduce
+    for (int i = wave; i < 16; i += WAVES) {
         for (int o = 0; o < no.out; ++o) {
-            const float* __restrict__ w3 = P + no.W3 + (size_t)o * H;
+            const float* w3 = &sm.w3[o * H];
             float s = 0.0f;
-#pragma unroll 4
-            for (int k = p; k < H; k += 16) s = fmaf(sm.h2[i * LD + k], w3[k], s);
-            s += __shfl_xor(s, 8, 64);
-            s += __shfl_xor(s, 4, 64);
-            s += __shfl_xor(s, 2, 64);
-            s += __shfl_xor(s, 1, 64);
-            if (p == 0) sm.out[i * FSRL_MAX_ACT + o] = s + P[no.b3 + o];
+#pragma unroll
+            for (int k = lane; k < H; k += 64) s = fmaf(sm.h2[i * LD + k], w3[k], s);
+            s = wave_sum(s);
+            if (lane == 0) sm.out[i * FSRL_MAX_ACT + o] = s + sm.b3[o];
         }
     }
     __syncthreads();
-}
-
-// load 16 gathered observation rows (transposed) into LDS
-template <int H>
-__device__ __forceinline__ void tile_load_x(TileSmem<H>& sm, const float* __restrict__ obs,
-                                            const int Do, const int tid) {
-    for (int e = tid; e < 16 * Do; e += 256) {
-        const int i = e / Do, k = e - i * Do;
-        const int r = sm.rowidx[i];
-        sm.xT[k * 16 + i] = (r >= 0) ? obs[(size_t)r * Do + k] : 0.0f;
-    }
 }
 
 // ---------------------------------------------------------------- process_fn inference
@@ -141,8 +196,8 @@ struct InferArgs {
 #define LOG_SQRT_2PI 0.9189385332046727f
 
 template <int H>
-__global__ __launch_bounds__(256) void mlp_infer_kernel(const float* __restrict__ P,
-                                                       const ModelDesc md, const InferArgs a) {
+__global__ __launch_bounds__(4 * H) void mlp_infer_kernel(const float* __restrict__ P,
+                                                         const ModelDesc md, const InferArgs a) {
     __shared__ TileSmem<H> sm;
     const int tid = threadIdx.x;
     const int row0 = blockIdx.x * 16;
@@ -152,13 +207,17 @@ __global__ __launch_bounds__(256) void mlp_infer_kernel(const float* __restrict_
     const int net = is_actor ? 0 : 1 + (C > 0 ? job % C : 0);
     const bool use_next = (!is_actor) && job >= C;
     const NetOff no = md.net[net];
-    if (tid < 16) sm.rowidx[tid] = (row0 + tid < a.N) ? row0 + tid : -1;
+    const int n_valid = min(16, a.N - row0);
+    TileStage<H> stg;
+    stg.issue(P, no, md.Do, md.Da, (use_next ? a.obs_next : a.obs) + (size_t)row0 * md.Do, nullptr,
+              n_valid, tid);
+    FwdW2Frag<H> wf;
+    wf.load(P + no.W2, tid >> 6, tid & 63);
+    stg.commit(sm, no, md.Do, tid);
     __syncthreads();
-    tile_load_x(sm, use_next ? a.obs_next : a.obs, md.Do, tid);
-    __syncthreads();
-    tile_forward<H>(sm, P, no, md.Do, tid);
-    if (tid < 16 && sm.rowidx[tid] >= 0) {
-        const int r = sm.rowidx[tid];
+    tile_forward<H>(sm, P, no, md.Do, tid, wf);
+    if (tid < n_valid) {
+        const int r = row0 + tid;
         if (!is_actor) {
             float v = sm.out[tid * FSRL_MAX_ACT];
             const int c = (C > 0) ? job % C : 0;
@@ -172,7 +231,7 @@ __global__ __launch_bounds__(256) void mlp_infer_kernel(const float* __restrict_
             float logp = 0.0f;
             for (int d = 0; d < md.Da; ++d) {
                 const float mu = a.max_action * tanhf(sm.out[tid * FSRL_MAX_ACT + d]);
-                const float sig = expf(P[no.sigma + d]);
+                const float sig = expf(sm.sig[d]);
                 if (a.mu_out) a.mu_out[(size_t)r * md.Da + d] = mu;
                 if (a.act) {
                     const float diff = a.act[(size_t)r * md.Da + d] - mu;
@@ -185,273 +244,333 @@ __global__ __launch_bounds__(256) void mlp_infer_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------- fused fwd + loss + bwd
-// One PPO minibatch step, activation side.  grid = (ceil(mb/16), n_nets).
+// One PPO minibatch step, activation side.  grid = (ceil(mb/16), n_nets), block = 4*H.
 // Implements, for its 16 rows: PPOLagrangian.policy_loss / critics_loss gradients
 // (fsrl/policy/ppo_lag.py:152-212, lagrangian_base.py:145-166) analytically.
 struct PpoBatchPtrs {
-    const float* obs;        // [N][Do]  batch in sample(0) order
-    const float* act;        // [N][Da]
-    const float* advs;       // [C][N]
-    const float* rets;       // [C][N]
-    const float* logp_old;   // [N]
-    const int* perm;         // [N] permutation of this pass
-    const float* mbstats;    // [n_mb][C][2] = (mean, 1/std) of advs per minibatch of this pass
+    // the pass's batch, already permuted into minibatch order by ppo_prepare_pass_kernel
+    const float* obs_p;      // [N + pad][Do]
+    const float* rd_p;       // [N + pad][FSRL_RD]  act | logp_old | adv_n[c] | ret[c]
     // per-net activation side buffers, row = position inside the minibatch
     float* A1;               // [n_nets][mbp_max][H]   relu(z1)
     float* A2;               // [n_nets][mbp_max][H]   relu(z2)
     float* D1;               // [n_nets][mbp_max][H]   dL/dz1
     float* D2;               // [n_nets][mbp_max][H]   dL/dz2
     float* DO;               // [n_nets][mbp_max][FSRL_DOW]
-    float* XB;               // [mbp_max][Do]          gathered obs rows
     float* statp;            // [n_tiles_max][n_nets][4] partial sums of the logged stats
-    const CtrlBlock* ctrl;
     int mbp_max;
-    int N;
 };
 
 template <int H>
-__global__ __launch_bounds__(256) void ppo_fwd_bwd_kernel(const float* __restrict__ P,
-                                                         const ModelDesc md,
-                                                         const PpoBatchPtrs bp,
-                                                         const PpoStepArgs sa) {
+__global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restrict__ P,
+                                                           const ModelDesc md,
+                                                           const PpoBatchPtrs bp,
+                                                           const PpoStepArgs sa) {
     __shared__ TileSmem<H> sm;
     constexpr int LD = TileSmem<H>::LD;
-    constexpr int NTW = H / 64;
-    if (sa.pass > bp.ctrl->stopped_after) return;
+    constexpr int NT = TileGeom<H>::NT;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
     const int tile = blockIdx.x, net = blockIdx.y;
     const int row0 = tile * 16;
     const NetOff no = md.net[net];
     const int Do = md.Do, Da = md.Da, C = md.n_nets - 1;
+    const int n_valid = min(16, sa.mb_size - row0);
+    const size_t grow0 = (size_t)sa.mb_start + row0;   // first row of the tile in pass order
 
-    if (tid < 16) {
-        const int m = row0 + tid;
-        sm.rowidx[tid] = (m < sa.mb_size) ? bp.perm[sa.mb_start + m] : -1;
-    }
+    // ---- prologue: ONE burst of independent loads (W2 slice, obs tile, row data, small
+    //      parameters); nothing below waits on a second cold round trip.
+    TileStage<H> stg;
+    stg.issue(P, no, Do, Da, bp.obs_p + grow0 * Do, bp.rd_p + grow0 * FSRL_RD, n_valid, tid);
+    FwdW2Frag<H> wf;
+    wf.load(P + no.W2, wave, lane);
+    for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
+    stg.commit(sm, no, Do, tid);
+    if (sa.dbg_phase == 9) return;                      // launch + address setup only
     __syncthreads();
-    tile_load_x(sm, bp.obs, Do, tid);
-    __syncthreads();
-    tile_forward<H>(sm, P, no, Do, tid);
-
-    // ---- loss head: dL/dout per row + partial sums of the logged statistics
-    for (int e = tid; e < 16 * FSRL_DOW; e += 256) sm.dout[e] = 0.0f;
-    __syncthreads();
-    if (tid < 16) {
-        const int i = tid;
-        const int r = sm.rowidx[i];
-        const float invB = 1.0f / (float)sa.mb_size;
-        float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;
-        if (r >= 0) {
-            if (net == 0) {
-                float logp = 0.0f;
-                for (int d = 0; d < Da; ++d) {
-                    const float mu_d = sa.max_action * tanhf(sm.out[i * FSRL_MAX_ACT + d]);
-                    const float sig = expf(P[no.sigma + d]);
-                    const float df = bp.act[(size_t)r * Da + d] - mu_d;
-                    logp += -(df * df) / (2.0f * sig * sig) - logf(sig) - LOG_SQRT_2PI;
-                }
-                const float lpo = bp.logp_old[r];
-                const float ratio = expf(logp - lpo);
-                // advantages, normalised per minibatch copy (ppo_lag.py:178-182)
-                float adv[FSRL_MAX_CRITICS];
-#pragma unroll
-                for (int c = 0; c < FSRL_MAX_CRITICS; ++c) {
-                    float av = 0.0f;
-                    if (c < C) {
-                        av = bp.advs[(size_t)c * bp.N + r];
-                        if (sa.norm_adv) {
-                            const float mean = bp.mbstats[(sa.mb_index * C + c) * 2 + 0];
-                            const float sd = bp.mbstats[(sa.mb_index * C + c) * 2 + 1];
-                            av = (av - mean) / sd;
-                        }
-                    }
-                    adv[c] = av;
-                }
-                const float ar = adv[0];
-                const float s1 = ratio * ar;
-                const float rc = fminf(fmaxf(ratio, 1.0f - sa.eps_clip), 1.0f + sa.eps_clip);
-                const float s2 = rc * ar;
-                const bool inrange = (ratio >= 1.0f - sa.eps_clip) && (ratio <= 1.0f + sa.eps_clip);
-                // d min(s1,s2)/d ratio with torch's tie rule (equal => gradient shared)
-                float g_c1 = inrange ? ar : (s1 < s2 ? ar : (s1 == s2 ? 0.5f * ar : 0.0f));
-                float term = fminf(s1, s2);
-                float g_term = g_c1;
-                if (sa.dual_clip > 0.0f) {
-                    const float c1 = term;
-                    const float lim = sa.dual_clip * ar;
-                    const float c2 = fmaxf(c1, lim);
-                    if (ar < 0.0f) {
-                        term = c2;
-                        g_term = (c1 > lim) ? g_c1 : (c1 == lim ? 0.5f * g_c1 : 0.0f);
-                    }
-                }
-                float dL_dratio = -g_term * invB;
-                float safety_sum = 0.0f;
-                if (sa.use_lagrangian) {
-#pragma unroll
-                    for (int c = 1; c < FSRL_MAX_CRITICS; ++c) {
-                        if (c < C) {
-                            dL_dratio += sa.lam[c - 1] * adv[c] * invB;
-                            safety_sum += ratio * adv[c] * sa.lam[c - 1];
-                        }
-                    }
-                }
-                const float dL_dlogp = sa.rescale * dL_dratio * ratio;
-                for (int d = 0; d < Da; ++d) {
-                    const float th = tanhf(sm.out[i * FSRL_MAX_ACT + d]);
-                    const float sig = expf(P[no.sigma + d]);
-                    const float var = sig * sig;
-                    const float df = bp.act[(size_t)r * Da + d] - sa.max_action * th;
-                    sm.dout[i * FSRL_DOW + d] =
-                        dL_dlogp * (df / var) * sa.max_action * (1.0f - th * th);
-                    sm.dout[i * FSRL_DOW + 16 + d] = dL_dlogp * (df * df / var - 1.0f);
-                }
-                st0 = term;          // sum of min(surr1,surr2) (-> loss/actor_rew)
-                st1 = safety_sum;    // sum of ratio*A_c*lambda  (-> loss/actor_safety)
-                st2 = lpo - logp;    // approx KL
-            } else {
-                const int c = net - 1;
-                const float v = sm.out[i * FSRL_MAX_ACT];
-                const float d = bp.rets[(size_t)c * bp.N + r] - v;
-                sm.dout[i * FSRL_DOW] = -2.0f * sa.vf_coef * d * invB;
-                st0 = d * d;
-            }
-        }
-        // 16-lane reduce (lanes 0..15 of wave 0)
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            st0 += __shfl_xor(st0, o, 64);
-            st1 += __shfl_xor(st1, o, 64);
-            st2 += __shfl_xor(st2, o, 64);
-        }
-        if (i == 0) {
-            float* sp = bp.statp + ((size_t)tile * md.n_nets + net) * 4;
-            sp[0] = st0; sp[1] = st1; sp[2] = st2; sp[3] = st3;
-        }
-    }
-    __syncthreads();
-
-    // ---- dL/dz2 = (dout @ W3) * relu'(z2)
-    for (int k = tid; k < H; k += 256) {
-        float g[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) g[i] = 0.0f;
-        for (int o = 0; o < no.out; ++o) {
-            const float w = P[no.W3 + (size_t)o * H + k];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) g[i] = fmaf(sm.dout[i * FSRL_DOW + o], w, g[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sm.d2[i * LD + k] = (sm.h2[i * LD + k] > 0.0f) ? g[i] : 0.0f;
-    }
-    __syncthreads();
-
-    // ---- dL/dz1 = (dz2 @ W2) * relu'(z1) on MFMA; result goes straight to HBM/L2
+    if (sa.dbg_phase == 1) { if (wf.b[0][0] == 123.f && sm.xT[tid] == 1.f) bp.statp[0] = 1.f; return; }
+    tile_forward<H>(sm, P, no, Do, tid, wf);
+    if (sa.dbg_phase == 4) { if (sm.out[tid & 15] == 123.f) bp.statp[0] = 1.f; return; }
     const size_t nb = (size_t)net * bp.mbp_max;
+    {   // spill relu(z1), relu(z2) for the weight-gradient kernel now: the stores retire while
+        // the loss head and the backward GEMM run (coalesced float4)
+        float* __restrict__ A1 = bp.A1 + (nb + row0) * H;
+        float* __restrict__ A2 = bp.A2 + (nb + row0) * H;
+        constexpr int H4 = H / 4;
+        for (int e = tid; e < 16 * H4; e += NT) {
+            const int i = e / H4, c4 = e - i * H4;
+            *reinterpret_cast<f32x4*>(&A1[(size_t)i * H + 4 * c4]) =
+                *reinterpret_cast<const f32x4*>(&sm.h1[i * LD + 4 * c4]);
+            *reinterpret_cast<f32x4*>(&A2[(size_t)i * H + 4 * c4]) =
+                *reinterpret_cast<const f32x4*>(&sm.h2[i * LD + 4 * c4]);
+        }
+    }
+
+    // W2 slice for the backward GEMM dz1 = dz2 @ W2 (column block of this wave): issued now
+    // (L2-warm after the forward burst), consumed after the loss head.
+    float wb[H / 16][4];
     {
-        f32x4 acc[NTW];
+        const float* __restrict__ W2c = P + no.W2 + wave * 16 + li;
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // MFMA t owns the interleaved columns col0 + t, col0 = wave*16*NTW + NTW*li
-        const int col0 = wave * 16 * NTW + NTW * li;
-        const float* __restrict__ W2c = P + no.W2 + col0;
-        const float* arow = &sm.d2[li * LD + 4 * q];
-#pragma unroll 2
-        for (int jc = 0; jc < H; jc += 16) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + jc);
-            float b[4][NTW];
+        for (int jc = 0; jc < H / 16; ++jc) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float* src = W2c + (size_t)(jc + 4 * q + s) * H;
-                if constexpr (NTW == 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(src);
-                    b[s][0] = v[0]; b[s][1] = v[1]; b[s][2] = v[2]; b[s][3] = v[3];
-                } else if constexpr (NTW == 2) {
-                    const f32x2 v = *reinterpret_cast<const f32x2*>(src);
-                    b[s][0] = v[0]; b[s][1] = v[1];
-                } else {
-                    b[s][0] = *src;
+            for (int s = 0; s < 4; ++s) wb[jc][s] = W2c[(size_t)(16 * jc + 4 * q + s) * H];
+        }
+    }
+
+    if (sa.dbg_phase == 5) { if (wb[0][0] == 123.f) bp.statp[0] = 1.f; return; }
+    // ---- loss head: thread (row i = tid>>4, dim d = tid&15), 16-lane shuffles per row
+    if (tid < 256) {
+        const int i = tid >> 4, d = tid & 15;
+        const bool valid = i < n_valid;
+        const float* rd = &sm.rd[i * FSRL_RD];
+        const float invB = 1.0f / (float)sa.mb_size;
+        float st0 = 0.f, st1 = 0.f, st2 = 0.f;
+        if (net == 0) {
+            float th = 0.f, var = 1.f, df = 0.f, lp = 0.f;
+            if (d < Da) {
+                th = tanhf(sm.out[i * FSRL_MAX_ACT + d]);
+                const float sig = expf(sm.sig[d]);
+                var = sig * sig;
+                df = rd[d] - sa.max_action * th;
+                lp = -(df * df) / (2.0f * var) - logf(sig) - LOG_SQRT_2PI;
+            }
+            // sum over the action dims in ascending order (Independent(Normal).log_prob)
+            float logp = 0.0f;
+            for (int dd = 0; dd < Da; ++dd) logp += __shfl(lp, (lane & 48) + dd, 64);
+            const float lpo = rd[FSRL_RD_LOGP];
+            const float ratio = expf(logp - lpo);
+            const float ar = rd[FSRL_RD_ADV];
+            const float s1 = ratio * ar;
+            const float rc = fminf(fmaxf(ratio, 1.0f - sa.eps_clip), 1.0f + sa.eps_clip);
+            const float s2 = rc * ar;
+            const bool inrange = (ratio >= 1.0f - sa.eps_clip) && (ratio <= 1.0f + sa.eps_clip);
+            // d min(s1,s2)/d ratio with torch's tie rule (equal => gradient shared)
+            const float g_c1 = inrange ? ar : (s1 < s2 ? ar : (s1 == s2 ? 0.5f * ar : 0.0f));
+            float term = fminf(s1, s2);
+            float g_term = g_c1;
+            if (sa.dual_clip > 0.0f) {
+                const float c1 = term;
+                const float lim = sa.dual_clip * ar;
+                if (ar < 0.0f) {
+                    term = fmaxf(c1, lim);
+                    g_term = (c1 > lim) ? g_c1 : (c1 == lim ? 0.5f * g_c1 : 0.0f);
                 }
             }
+            float dL_dratio = -g_term * invB;
+            float safety_sum = 0.0f;
+            if (sa.use_lagrangian) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[t] = mfma_16x16x4(a[s], b[s][t], acc[t]);
+                for (int c = 1; c < FSRL_MAX_CRITICS; ++c) {
+                    if (c < C) {
+                        const float ac = rd[FSRL_RD_ADV + c];
+                        dL_dratio += sa.lam[c - 1] * ac * invB;
+                        safety_sum += ratio * ac * sa.lam[c - 1];
+                    }
+                }
+            }
+            const float dL_dlogp = sa.rescale * dL_dratio * ratio;
+            if (valid && d < Da) {
+                sm.dout[i * FSRL_DOW + d] = dL_dlogp * (df / var) * sa.max_action * (1.0f - th * th);
+                sm.dout[i * FSRL_DOW + 16 + d] = dL_dlogp * (df * df / var - 1.0f);
+            }
+            if (valid) { st0 = term; st1 = safety_sum; st2 = lpo - logp; }
+        } else {
+            const int c = net - 1;
+            const float v = sm.out[i * FSRL_MAX_ACT];
+            const float dd = rd[FSRL_RD_RET + c] - v;
+            if (valid) {
+                if (d == 0) sm.dout[i * FSRL_DOW] = -2.0f * sa.vf_coef * dd * invB;
+                st0 = dd * dd;
             }
         }
+        if (d == 0) { sm.st[i * 4 + 0] = st0; sm.st[i * 4 + 1] = st1; sm.st[i * 4 + 2] = st2; }
+    }
+    __syncthreads();
+    if (tid < 4) {   // rows summed in ascending order (fixed => deterministic)
+        float t = 0.0f;
+        if (tid < 3)
+            for (int i = 0; i < 16; ++i) t += sm.st[i * 4 + tid];
+        bp.statp[((size_t)tile * md.n_nets + net) * 4 + tid] = t;
+    }
+
+    if (sa.dbg_phase == 6) { if (wb[0][0] == 123.f) bp.statp[1] = 1.f; return; }
+    // ---- dL/dz2 = (dout @ W3) * relu'(z2); thread = (column k, group of 4 rows)
+    {
+        const int k = tid % H, rg = tid / H;
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int o = 0; o < no.out; ++o) {
+            const float w = sm.w3[o * H + k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = fmaf(sm.dout[(4 * rg + e) * FSRL_DOW + o], w, g[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * rg + e;
+            sm.d2[i * LD + k] = (sm.h2[i * LD + k] > 0.0f) ? g[e] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    {   // dz2 and dout tiles -> side buffers (retire under the backward GEMM)
+        float* __restrict__ D2 = bp.D2 + (nb + row0) * H;
+        constexpr int H4 = H / 4;
+        for (int e = tid; e < 16 * H4; e += NT) {
+            const int i = e / H4, c4 = e - i * H4;
+            *reinterpret_cast<f32x4*>(&D2[(size_t)i * H + 4 * c4]) =
+                *reinterpret_cast<const f32x4*>(&sm.d2[i * LD + 4 * c4]);
+        }
+        float* __restrict__ DOb = bp.DO + (nb + row0) * FSRL_DOW;
+        for (int e = tid; e < 16 * FSRL_DOW; e += NT) DOb[e] = sm.dout[e];
+    }
+    // ---- dL/dz1 = (dz2 @ W2) * relu'(z1) on MFMA; result goes straight to L2/HBM
+    {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = &sm.d2[li * LD + 4 * q];
+#pragma unroll
+        for (int jc = 0; jc < H / 16; ++jc) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * jc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma_16x16x4(a[s], wb[jc][s], acc);
+        }
+        if (sa.dbg_phase == 7) { if (acc[0] == 123.f) bp.statp[1] = 1.f; return; }
         float* __restrict__ D1 = bp.D1 + (nb + row0) * H;
+        const int col = wave * 16 + li;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * q + r;
-            float v[NTW];
-#pragma unroll
-            for (int t = 0; t < NTW; ++t)
-                v[t] = (sm.h1[i * LD + col0 + t] > 0.0f) ? acc[t][r] : 0.0f;
-            float* dst = D1 + (size_t)i * H + col0;
-            if constexpr (NTW == 4) {
-                *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-            } else if constexpr (NTW == 2) {
-                *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
-            } else {
-                *dst = v[0];
-            }
+            D1[(size_t)i * H + col] = (sm.h1[i * LD + col] > 0.0f) ? acc[r] : 0.0f;
         }
     }
 
-    // ---- spill the tile's activations for the weight-gradient kernel (coalesced float4)
-    {
-        float* __restrict__ A1 = bp.A1 + (nb + row0) * H;
-        float* __restrict__ A2 = bp.A2 + (nb + row0) * H;
-        float* __restrict__ D2 = bp.D2 + (nb + row0) * H;
-        constexpr int H4 = H / 4;
-        for (int e = tid; e < 16 * H4; e += 256) {
-            const int i = e / H4, c4 = e - i * H4;
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&sm.h1[i * LD + 4 * c4]);
-            const f32x4 v2 = *reinterpret_cast<const f32x4*>(&sm.h2[i * LD + 4 * c4]);
-            const f32x4 v3 = *reinterpret_cast<const f32x4*>(&sm.d2[i * LD + 4 * c4]);
-            *reinterpret_cast<f32x4*>(&A1[(size_t)i * H + 4 * c4]) = v1;
-            *reinterpret_cast<f32x4*>(&A2[(size_t)i * H + 4 * c4]) = v2;
-            *reinterpret_cast<f32x4*>(&D2[(size_t)i * H + 4 * c4]) = v3;
-        }
-        float* __restrict__ DOb = bp.DO + (nb + row0) * FSRL_DOW;
-        for (int e = tid; e < 16 * FSRL_DOW; e += 256) DOb[e] = sm.dout[e];
-        if (net == 0) {
-            float* __restrict__ XB = bp.XB + (size_t)row0 * Do;
-            for (int e = tid; e < 16 * Do; e += 256) {
-                const int i = e / Do, k = e - i * Do;
-                XB[e] = sm.xT[k * 16 + i];
-            }
-        }
-    }
 }
 
 // ---------------------------------------------------------------- weight gradients
-// grid.x = n_nets * (NT2 + NA): NT2 = (H/32)^2 MFMA tile blocks (dW2) + NA = H/64 aux blocks
-// (dW1, db1, db2, dW3, db3, dsigma) per network.  Each block also emits the sum of squares
-// of the gradient entries it produced (for clip_grad_norm_, ppo_lag.py:237-240).
+// block = 1024 threads (16 waves).  grid.x = n_nets * (NT2 + NA) + 1:
+//   NT2 = (H/32)^2 MFMA tile blocks (dW2, 32x32 outputs, 16-way split-K over the waves)
+//   NA  = H/32 aux blocks (dW1, dW3, db1, db2 of 32 columns; also MFMA, 16-way split-K)
+//   +1  = the block that finalises the logged statistics of this step and reduces the
+//         column sums of the dout side buffer (db3, dsigma) of every network.
+// Every block emits the sum of squares of the gradient entries it produced
+// (clip_grad_norm_, ppo_lag.py:237-240).
 struct WgradPtrs {
     const float* A1; const float* A2; const float* D1; const float* D2; const float* DO;
-    const float* XB;
+    const float* X;    // obs_p + mb_start*Do : the minibatch's observation rows
     float* grad;       // flat, same layout as the parameters
     float* gsq_part;   // [gridDim.x]
-    const CtrlBlock* ctrl;
+    CtrlBlock* ctrl;
+    const float* P;    // parameters (entropy of the logged stats)
+    const float* statp;
+    float* stats;      // [steps][FSRL_PPO_NSTATS]
     int mbp_max;
 };
 
+#define WG_MAXU 8      // k-steps per wave in the tile role: mbp/4/16 <= 8  (mbp <= 512)
+#define AUX_MAXU 32    // rows per thread in the aux role:   mbp/16   <= 32
+
+// Logged statistics of one minibatch step (parameters are still pre-update here, like the
+// reference which builds `dist` before optim.step, ppo_lag.py:225-247).
+__device__ __forceinline__ void ppo_stats_finalize(const ModelDesc& md, const WgradPtrs& wp,
+                                                   const PpoStepArgs& sa, int n_tiles, int lane) {
+    const int nn = md.n_nets, C = nn - 1;
+    // lane = (tile group g = lane>>4, field slot f = lane&15 -> (net, field)); every lane issues
+    // all of its loads at once (<= 8 tiles), then the 4 groups are combined in a fixed order
+    float mine = 0.0f;
+    {
+        const int g = lane >> 4, fs = lane & 15;
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = g + 4 * u;
+            v[u] = (fs < nn * 4 && t < n_tiles) ? wp.statp[(size_t)t * nn * 4 + fs] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mine += v[u];
+        mine += __shfl_xor(mine, 16, 64);
+        mine += __shfl_xor(mine, 32, 64);
+    }
+    const float invB = 1.0f / (float)sa.mb_size;
+    const float term = __shfl(mine, 0, 64), safety = __shfl(mine, 1, 64), kls = __shfl(mine, 2, 64);
+    float vf[FSRL_MAX_CRITICS];
+#pragma unroll
+    for (int c = 0; c < FSRL_MAX_CRITICS; ++c) vf[c] = __shfl(mine, 4 * (c + 1), 64) * invB;
+    if (lane == 0) {
+        float ent = 0.0f;
+        for (int d = 0; d < md.Da; ++d)
+            ent += 1.4189385332046727f + logf(expf(wp.P[md.net[0].sigma + d]));
+        const float actor_rew = -term * invB;
+        const float actor_safety = sa.use_lagrangian ? safety * invB : 0.0f;
+        const float actor_total = sa.rescale * (actor_rew + actor_safety);
+        const float kl = kls * invB;
+        float vf_total = 0.0f;
+#pragma unroll
+        for (int c = 0; c < FSRL_MAX_CRITICS; ++c)
+            if (c < C) vf_total += vf[c];
+        float* o = wp.stats + (size_t)sa.step * FSRL_PPO_NSTATS;
+        o[0] = sa.rescale;
+        o[1] = (sa.use_lagrangian && C > 1) ? sa.lam[0] : 0.0f;
+        o[2] = actor_safety;
+        o[3] = actor_rew;
+        o[4] = actor_total;
+        o[5] = kl;
+        o[6] = vf[0];
+        o[7] = (C > 1) ? vf[1] : 0.0f;
+        o[8] = vf_total;
+        o[9] = actor_total + sa.vf_coef * vf_total;
+        o[10] = ent;
+        wp.ctrl->kl_sum = (sa.first_in_pass ? 0.0 : wp.ctrl->kl_sum) + (double)kl;
+    }
+}
+
 template <int H>
-__global__ __launch_bounds__(256) void ppo_wgrad_kernel(const ModelDesc md, const WgradPtrs wp,
-                                                       const int mbp, const int pass) {
+__global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, const WgradPtrs wp,
+                                                        const int mbp, const PpoStepArgs sa) {
     constexpr int TPD = H / 32;          // tiles per dimension
     constexpr int NT2 = TPD * TPD;
-    constexpr int NA = H / 64;
+    constexpr int NA = H / 32;
     constexpr int PB = NT2 + NA;
-    __shared__ float red[256 * 20];      // split-K partials of the 4 waves / aux reduce scratch
-    __shared__ float xs[64 * 16];        // aux: 64-row x 16-col chunk of XB
-    __shared__ float dos[64 * FSRL_DOW];
-    __shared__ float wsum[4];
-    if (pass > wp.ctrl->stopped_after) return;
+    __shared__ float red[1024 * 9];      // 8 split-K partial slots of a 32x32 tile / aux reduce scratch
+    __shared__ float wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (sa.dbg_phase == 20) return;
+    if ((int)blockIdx.x == md.n_nets * PB) {  // the stats block
+        if (sa.dbg_phase == 21 || sa.dbg_phase == 22) return;
+        if (wave == 0) ppo_stats_finalize(md, wp, sa, mbp >> 4, lane);
+        // db3[o] / dsigma[d] = column sums of DO over the minibatch rows, for every network:
+        // thread (col = tid & 31, row phase = tid >> 5); all loads of a thread in one burst
+        float sqs = 0.0f;
+        for (int net = 0; net < md.n_nets; ++net) {
+            const NetOff no = md.net[net];
+            const float* __restrict__ DOn = wp.DO + (size_t)net * wp.mbp_max * FSRL_DOW;
+            const int col = tid & 31, php = tid >> 5;
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = php + 32 * u;
+                v[u] = (r < mbp) ? DOn[(size_t)r * FSRL_DOW + col] : 0.0f;
+            }
+            float t = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t += v[u];
+            __syncthreads();
+            red[php * 33 + col] = t;
+            __syncthreads();
+            if (tid < 32) {
+                float tot = 0.0f;
+#pragma unroll
+                for (int p2 = 0; p2 < 32; ++p2) tot += red[p2 * 33 + tid];
+                if (tid < no.out) { wp.grad[no.b3 + tid] = tot; sqs = fmaf(tot, tot, sqs); }
+                if (no.sigma >= 0 && tid >= 16 && tid < 16 + md.Da) {
+                    wp.grad[no.sigma + tid - 16] = tot; sqs = fmaf(tot, tot, sqs);
+                }
+            }
+        }
+        if (wave == 0) {
+            sqs = wave_sum(sqs);
+            if (lane == 0) wp.gsq_part[blockIdx.x] = sqs;
+        }
+        return;
+    }
     const int net = blockIdx.x / PB, rb = blockIdx.x % PB;
     const NetOff no = md.net[net];
     const size_t nb = (size_t)net * wp.mbp_max;
@@ -462,138 +581,202 @@ __global__ __launch_bounds__(256) void ppo_wgrad_kernel(const ModelDesc md, cons
     const float* __restrict__ DOb = wp.DO + nb * FSRL_DOW;
     float sq = 0.0f;
 
+    if (sa.dbg_phase == 23) return;
+    if (sa.dbg_phase == 21 && rb >= NT2) return;
+    if (sa.dbg_phase == 22 && rb < NT2) return;
     if (rb < NT2) {
-        // ---- dW2[j][k] = sum_r D2[r][j] * A1[r][k], 32x32 tile, split-K over waves
+        // ---- dW2[j][k] = sum_r D2[r][j] * A1[r][k]; wave w takes k-steps s = w, w+16, ...
         const int tj = rb / TPD, tk = rb % TPD;
         const int c = lane & 15, q = lane >> 4;
-        f32x4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
         const float* __restrict__ pa = D2 + tj * 32 + 2 * c;
         const float* __restrict__ pb = A1 + tk * 32 + 2 * c;
         const int KS = mbp >> 2;
-#pragma unroll 4
-        for (int s = wave; s < KS; s += 4) {
-            const size_t r = (size_t)(4 * s + q) * H;
-            const f32x2 a = *reinterpret_cast<const f32x2*>(pa + r);
-            const f32x2 b = *reinterpret_cast<const f32x2*>(pb + r);
-            acc00 = mfma_16x16x4(a[0], b[0], acc00);
-            acc01 = mfma_16x16x4(a[0], b[1], acc01);
-            acc10 = mfma_16x16x4(a[1], b[0], acc10);
-            acc11 = mfma_16x16x4(a[1], b[1], acc11);
-        }
-        // acc_tu[r]: j_local = 2*(4q+r)+t, k_local = 2c+u
-        float* myred = red + wave * (32 * 33);
+        f32x2 a[WG_MAXU], b[WG_MAXU];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int jl = 2 * (4 * q + r);
-            myred[(jl + 0) * 33 + 2 * c + 0] = acc00[r];
-            myred[(jl + 0) * 33 + 2 * c + 1] = acc01[r];
-            myred[(jl + 1) * 33 + 2 * c + 0] = acc10[r];
-            myred[(jl + 1) * 33 + 2 * c + 1] = acc11[r];
+        for (int u = 0; u < WG_MAXU; ++u) {
+            const int s = wave + 16 * u;
+            if (s < KS) {
+                const size_t r = (size_t)(4 * s + q) * H;
+                a[u] = *reinterpret_cast<const f32x2*>(pa + r);
+                b[u] = *reinterpret_cast<const f32x2*>(pb + r);
+            } else {
+                a[u] = f32x2{0.f, 0.f};
+                b[u] = f32x2{0.f, 0.f};
+            }
+        }
+        f32x4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < WG_MAXU; ++u) {
+            if (wave + 16 * u < KS) {   // wave-uniform
+                acc00 = mfma_16x16x4(a[u][0], b[u][0], acc00);
+                acc01 = mfma_16x16x4(a[u][0], b[u][1], acc01);
+                acc10 = mfma_16x16x4(a[u][1], b[u][0], acc10);
+                acc11 = mfma_16x16x4(a[u][1], b[u][1], acc11);
+            }
+        }
+        // acc_tu[r]: j_local = 2*(4q+r)+t, k_local = 2c+u.  Two rounds: waves 0-7 store their
+        // partial tile, then waves 8-15 add theirs into the same slot (fixed order).
+        float* myred = red + (wave & 7) * (32 * 33);
+        if (wave < 8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jl = 2 * (4 * q + r);
+                myred[(jl + 0) * 33 + 2 * c + 0] = acc00[r];
+                myred[(jl + 0) * 33 + 2 * c + 1] = acc01[r];
+                myred[(jl + 1) * 33 + 2 * c + 0] = acc10[r];
+                myred[(jl + 1) * 33 + 2 * c + 1] = acc11[r];
+            }
         }
         __syncthreads();
-        float* __restrict__ g = wp.grad + no.W2;
+        if (wave >= 8) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int e = tid + 256 * m;
-            const int jl = e >> 5, kl = e & 31;
-            const float v = red[jl * 33 + kl] + red[(32 * 33) + jl * 33 + kl] +
-                            red[2 * (32 * 33) + jl * 33 + kl] + red[3 * (32 * 33) + jl * 33 + kl];
-            g[(size_t)(tj * 32 + jl) * H + tk * 32 + kl] = v;
-            sq = fmaf(v, v, sq);
+            for (int r = 0; r < 4; ++r) {
+                const int jl = 2 * (4 * q + r);
+                myred[(jl + 0) * 33 + 2 * c + 0] += acc00[r];
+                myred[(jl + 0) * 33 + 2 * c + 1] += acc01[r];
+                myred[(jl + 1) * 33 + 2 * c + 0] += acc10[r];
+                myred[(jl + 1) * 33 + 2 * c + 1] += acc11[r];
+            }
+        }
+        __syncthreads();
+        {
+            const int jl = tid >> 5, kl = tid & 31;   // 1024 threads = 32x32 outputs
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[w * (32 * 33) + jl * 33 + kl];
+            wp.grad[no.W2 + (size_t)(tj * 32 + jl) * H + tk * 32 + kl] = v;
+            sq = v * v;
         }
     } else {
-        // ---- aux: column j of this 64-wide chunk; rows split over the 4 waves
-        const int ch = rb - NT2;
-        const int cidx = tid & 63, ph = tid >> 6;
-        const int j = ch * 64 + cidx;
+        // ---- aux: 32 columns j0..j0+31 of this network; same 16-way split-K MFMA structure as
+        // the dW2 tiles:   dW1[j][k]  = sum_r D1[r][j] * X[r][k]      (A = D1, B = x row)
+        //                  dW3[o][j]  = sum_r A2[r][j] * DO[r][o]     (A = A2, B = dout row)
+        //                  db1[j], db2[j] = column sums of D1, D2     (register sums of A)
+        // (v1 did this with VALU + LDS broadcasts on 12 blocks and took 16 us.)
+        const int j0 = (rb - NT2) * 32;
+        const int c = lane & 15, q = lane >> 4;
         const int Do = md.Do, out = no.out;
-        float db1 = 0.f, db2 = 0.f;
-        float dw3[FSRL_MAX_ACT];
-#pragma unroll
-        for (int o = 0; o < FSRL_MAX_ACT; ++o) dw3[o] = 0.f;
-        float dsum = 0.f;  // chunk 0, lanes < 32: column sums of DO (db3 / dsigma)
+        const int KS = mbp >> 2;
+        const float* __restrict__ X = wp.X;
         for (int k0 = 0; k0 < Do; k0 += 16) {
-            const int kn = min(16, Do - k0);
-            float dw1[16];
+            const bool first = (k0 == 0);
+            f32x4 ax0 = {0, 0, 0, 0}, ax1 = {0, 0, 0, 0}, ad0 = {0, 0, 0, 0}, ad1 = {0, 0, 0, 0};
+            f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+            for (int ub = 0; ub < WG_MAXU; ub += 4) {       // 4 k-steps per burst (64 rows / wave set)
+                if (wave + 16 * ub >= KS) break;            // wave-uniform
+                f32x2 a1[4], a2[4], a3[4];
+                float bx[4], bd[4];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) dw1[k] = 0.f;
-            for (int r0 = 0; r0 < mbp; r0 += 64) {
-                const int rn = min(64, mbp - r0);
-                __syncthreads();
-                for (int e = tid; e < rn * kn; e += 256) {
-                    const int rr = e / kn, k = e - rr * kn;
-                    xs[rr * 16 + k] = wp.XB[(size_t)(r0 + rr) * Do + k0 + k];
+                for (int u = 0; u < 4; ++u) {               // one burst of independent loads
+                    const int sidx = wave + 16 * (ub + u);
+                    a1[u] = f32x2{0.f, 0.f}; a2[u] = f32x2{0.f, 0.f}; a3[u] = f32x2{0.f, 0.f};
+                    bx[u] = 0.f; bd[u] = 0.f;
+                    if (sidx < KS) {
+                        const size_t r = (size_t)(4 * sidx + q);
+                        a1[u] = *reinterpret_cast<const f32x2*>(D1 + r * H + j0 + 2 * c);
+                        if (k0 + c < Do) bx[u] = X[r * Do + k0 + c];
+                        if (first) {
+                            a2[u] = *reinterpret_cast<const f32x2*>(A2 + r * H + j0 + 2 * c);
+                            a3[u] = *reinterpret_cast<const f32x2*>(D2 + r * H + j0 + 2 * c);
+                            bd[u] = DOb[r * FSRL_DOW + c];
+                        }
+                    }
                 }
-                if (k0 == 0)
-                    for (int e = tid; e < rn * FSRL_DOW; e += 256) dos[e] = DOb[(size_t)r0 * FSRL_DOW + e];
-                __syncthreads();
-                for (int rr = ph; rr < rn; rr += 4) {
-                    const size_t r = (size_t)(r0 + rr) * H + j;
-                    const float d1 = D1[r];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        if (k < kn) dw1[k] = fmaf(d1, xs[rr * 16 + k], dw1[k]);
-                    if (k0 == 0) {
-                        db1 += d1;
-                        db2 += D2[r];
-                        const float a2 = A2[r];
-#pragma unroll
-                        for (int o = 0; o < FSRL_MAX_ACT; ++o)
-                            if (o < out) dw3[o] = fmaf(dos[rr * FSRL_DOW + o], a2, dw3[o]);
-                        if (ch == 0 && cidx < FSRL_DOW) dsum += dos[rr * FSRL_DOW + cidx];
+                for (int u = 0; u < 4; ++u) {               // zero operands beyond KS add nothing
+                    ax0 = mfma_16x16x4(a1[u][0], bx[u], ax0);
+                    ax1 = mfma_16x16x4(a1[u][1], bx[u], ax1);
+                    if (first) {
+                        ad0 = mfma_16x16x4(a2[u][0], bd[u], ad0);
+                        ad1 = mfma_16x16x4(a2[u][1], bd[u], ad1);
+                        s1 += a1[u];
+                        s2 += a3[u];
                     }
                 }
             }
-            // reduce dW1 chunk over the 4 row phases and write
-            __syncthreads();
+            // bias sums: add the 4 k-slots (q) of the wave; lanes q==0 then hold columns 2c, 2c+1
+            if (first) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) red[(ph * 64 + cidx) * 17 + k] = dw1[k];
-            __syncthreads();
-            if (ph == 0) {
-                for (int k = 0; k < kn; ++k) {
-                    const float v = red[cidx * 17 + k] + red[(64 + cidx) * 17 + k] +
-                                    red[(128 + cidx) * 17 + k] + red[(192 + cidx) * 17 + k];
-                    wp.grad[no.W1 + (size_t)j * Do + k0 + k] = v;
-                    sq = fmaf(v, v, sq);
+                for (int t = 0; t < 2; ++t) {
+                    s1[t] += __shfl_xor(s1[t], 16, 64); s1[t] += __shfl_xor(s1[t], 32, 64);
+                    s2[t] += __shfl_xor(s2[t], 16, 64); s2[t] += __shfl_xor(s2[t], 32, 64);
                 }
             }
-        }
-        // reduce the k0==0 quantities: db1, db2, dw3[out], dsum  -> layout [ph][cidx][20]
-        __syncthreads();
-        {
-            float* rr_ = red + (ph * 64 + cidx) * 20;
-            rr_[0] = db1; rr_[1] = db2; rr_[2] = dsum;
+            // slot layout (1088 floats): [0,512) dW1 tile [32 j][16 k], [512,1024) dW3^T tile
+            // [32 j][16 o], [1024,1056) db1[32], [1056,1088) db2[32].  Two rounds over 8 slots.
+            float* slot = red + (wave & 7) * 1088;
+            __syncthreads();
 #pragma unroll
-            for (int o = 0; o < FSRL_MAX_ACT; ++o)
-                if (o < out) rr_[3 + o] = dw3[o];
-        }
-        __syncthreads();
-        if (ph == 0) {
-            auto tot = [&](int f) {
-                return red[cidx * 20 + f] + red[(64 + cidx) * 20 + f] + red[(128 + cidx) * 20 + f] +
-                       red[(192 + cidx) * 20 + f];
-            };
-            float v = tot(0);
-            wp.grad[no.b1 + j] = v; sq = fmaf(v, v, sq);
-            v = tot(1);
-            wp.grad[no.b2 + j] = v; sq = fmaf(v, v, sq);
-            for (int o = 0; o < out; ++o) {
-                v = tot(3 + o);
-                wp.grad[no.W3 + (size_t)o * H + j] = v; sq = fmaf(v, v, sq);
+            for (int round = 0; round < 2; ++round) {
+                if ((wave >> 3) == round) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int jl = 2 * (4 * q + r);
+                        if (round == 0) {
+                            slot[(jl + 0) * 16 + c] = ax0[r];
+                            slot[(jl + 1) * 16 + c] = ax1[r];
+                            if (first) {
+                                slot[512 + (jl + 0) * 16 + c] = ad0[r];
+                                slot[512 + (jl + 1) * 16 + c] = ad1[r];
+                            }
+                        } else {
+                            slot[(jl + 0) * 16 + c] += ax0[r];
+                            slot[(jl + 1) * 16 + c] += ax1[r];
+                            if (first) {
+                                slot[512 + (jl + 0) * 16 + c] += ad0[r];
+                                slot[512 + (jl + 1) * 16 + c] += ad1[r];
+                            }
+                        }
+                    }
+                    if (first && q == 0) {
+                        if (round == 0) {
+                            slot[1024 + 2 * c] = s1[0]; slot[1024 + 2 * c + 1] = s1[1];
+                            slot[1056 + 2 * c] = s2[0]; slot[1056 + 2 * c + 1] = s2[1];
+                        } else {
+                            slot[1024 + 2 * c] += s1[0]; slot[1024 + 2 * c + 1] += s1[1];
+                            slot[1056 + 2 * c] += s2[0]; slot[1056 + 2 * c + 1] += s2[1];
+                        }
+                    }
+                }
+                __syncthreads();
             }
-            if (ch == 0 && cidx < FSRL_DOW) {
-                v = tot(2);
-                if (cidx < out) { wp.grad[no.b3 + cidx] = v; sq = fmaf(v, v, sq); }
-                if (no.sigma >= 0 && cidx >= 16 && cidx < 16 + md.Da) {
-                    wp.grad[no.sigma + cidx - 16] = v; sq = fmaf(v, v, sq);
+            // final: threads [0,512) dW1, [512,1024) dW3^T (+ the first 64 of them the biases)
+            {
+                const int e = tid & 511;
+                float v = 0.0f;
+                const int off = (tid < 512) ? e : 512 + e;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += red[w * 1088 + off];
+                const int jl = e >> 4, kk = e & 15;
+                if (tid < 512) {
+                    if (k0 + kk < Do) {
+                        wp.grad[no.W1 + (size_t)(j0 + jl) * Do + k0 + kk] = v;
+                        sq = fmaf(v, v, sq);
+                    }
+                } else if (first && kk < out) {
+                    wp.grad[no.W3 + (size_t)kk * H + j0 + jl] = v;
+                    sq = fmaf(v, v, sq);
+                }
+                if (first && tid < 64) {
+                    float bsum = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) bsum += red[w * 1088 + 1024 + tid];
+                    if (tid < 32) wp.grad[no.b1 + j0 + tid] = bsum;
+                    else wp.grad[no.b2 + j0 + tid - 32] = bsum;
+                    sq = fmaf(bsum, bsum, sq);
                 }
             }
         }
     }
-    // ---- block sum of squares (deterministic order)
+    // ---- block sum of squares (fixed order => deterministic)
     sq = wave_sum(sq);
     __syncthreads();
     if (lane == 0) wsum[wave] = sq;
     __syncthreads();
-    if (tid == 0) wp.gsq_part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (tid == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += wsum[w];
+        wp.gsq_part[blockIdx.x] = t;
+    }
 }

@@ -84,8 +84,11 @@ def split_chunks(n, size, perm=None, merge_last=True):
 
 
 class PPOLagOracle:
-    def __init__(self, cfg: PPOLagConfig):
+    def __init__(self, cfg: PPOLagConfig, dtype=torch.float32):
+        """dtype=torch.float64 gives an "exact arithmetic" yardstick: the tests bound the HIP
+        path's distance to it by the fp32 oracle's own distance (same algorithm, same inputs)."""
         self.cfg = cfg
+        self.dtype = dtype
         self.specs = layout.onpolicy_specs(cfg.obs_dim, cfg.act_dim, cfg.hidden, cfg.n_critics)
         self.n_params = sum(layout.spec_size(s) for s in self.specs)
         self.nets: List[dict] = []
@@ -95,7 +98,7 @@ class PPOLagOracle:
 
     # ------------------------------------------------------------------ params
     def set_params(self, flat):
-        flat = torch.as_tensor(np.asarray(flat, np.float32)).clone()
+        flat = torch.as_tensor(np.asarray(flat, np.float32)).clone().to(self.dtype)
         assert flat.numel() == self.n_params
         self.nets, self._leaves, off = [], [], 0
         for spec in self.specs:
@@ -107,7 +110,7 @@ class PPOLagOracle:
                                       eps=self.cfg.adam_eps)
 
     def get_params(self):
-        return torch.cat([t.detach().reshape(-1) for t in self._leaves]).numpy().copy()
+        return torch.cat([t.detach().reshape(-1) for t in self._leaves]).to(torch.float32).numpy().copy()
 
     # ------------------------------------------------------------------ nets
     @staticmethod
@@ -129,8 +132,9 @@ class PPOLagOracle:
     def process(self, data: OnPolicyData):
         """GAE for every critic + old log-prob.  Returns dict of torch f32 tensors."""
         cfg = self.cfg
-        obs = torch.as_tensor(data.obs, dtype=torch.float32)
-        obs_next = torch.as_tensor(data.obs_next, dtype=torch.float32)
+        dt = self.dtype
+        obs = torch.as_tensor(data.obs, dtype=dt)
+        obs_next = torch.as_tensor(data.obs_next, dtype=dt)
         metrics = [np.asarray(data.rew, np.float64), np.asarray(data.cost).astype(np.float64)]
         value_mask = ~np.asarray(data.terminated, bool)
         values, rets, advs = [], [], []
@@ -138,13 +142,18 @@ class PPOLagOracle:
             for i in range(cfg.n_critics):
                 v = self.value(i, obs)
                 vn = self.value(i, obs_next).numpy() * value_mask  # f32 * bool -> f32
-                adv = gae_return_c(v.numpy(), vn, metrics[i], data.end_flag, cfg.gamma,
-                                   cfg.gae_lambda)
+                if dt == torch.float32:
+                    adv = gae_return_c(v.numpy(), vn, metrics[i], data.end_flag, cfg.gamma,
+                                       cfg.gae_lambda)
+                else:  # yardstick mode: keep the critic values in float64
+                    from .scans import gae_return_np
+                    adv = gae_return_np(v.numpy(), vn, metrics[i], data.end_flag, cfg.gamma,
+                                        cfg.gae_lambda)
                 ret = adv + v.numpy()  # f64 + f32 -> f64
                 values.append(v)
-                rets.append(torch.from_numpy(ret).to(torch.float32))
-                advs.append(torch.from_numpy(adv).to(torch.float32))
-            act = torch.as_tensor(data.act, dtype=torch.float32)
+                rets.append(torch.from_numpy(ret).to(dt))
+                advs.append(torch.from_numpy(adv).to(dt))
+            act = torch.as_tensor(data.act, dtype=dt)
             logp_old = self.actor_dist(obs).log_prob(act)
         return dict(obs=obs, act=act, values=torch.stack(values, -1), rets=torch.stack(rets, -1),
                     advs=torch.stack(advs, -1), logp_old=logp_old)
@@ -158,7 +167,7 @@ class PPOLagOracle:
         rets, logp_old = pb["rets"][idx_t], pb["logp_old"][idx_t]
         dist = self.actor_dist(obs)
         logp = dist.log_prob(act)
-        ratio = (logp - logp_old).exp().float()
+        ratio = (logp - logp_old).exp().to(self.dtype)
         ratio = ratio.reshape(ratio.size(0), -1).transpose(0, 1)  # (1, B) quirk, ppo_lag.py:177
         if cfg.advantage_normalization:
             for i in range(cfg.n_critics):

@@ -39,7 +39,7 @@ def _p(a, t):
 def gae_return_np(v, v_next, rew, end_flag, gamma, gae_lambda):
     """Sequential float64 reverse scan (numba typing: f32 inputs are promoted to f64
     before the multiply by gamma)."""
-    v = np.asarray(v).astype(np.float64)
+    v = np.asarray(v).astype(np.float64)  # (float64 inputs are accepted: yardstick mode)
     v_next = np.asarray(v_next).astype(np.float64)
     rew = np.asarray(rew, np.float64)
     delta = rew + v_next * np.float64(gamma) - v
