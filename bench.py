@@ -143,6 +143,11 @@ def main():
         torch.cuda.synchronize()
 
     def one_update(k):
+        # every timed update is the same workload: orthogonal-init weights, fresh Adam state
+        # (re-training 20x on ONE synthetic buffer with the KL stop off would diverge to inf;
+        # the restore -- a 0.8 MB H2D copy and two memsets -- stays inside the timed region)
+        eng.set_params(theta)
+        eng.optim_reset()
         stats, _ = eng.ppo_update(lag, resc, BATCH, REPEAT, perms=None, seed=1000 * seed + k + 1)
         return stats
 

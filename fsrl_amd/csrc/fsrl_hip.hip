@@ -758,18 +758,24 @@ extern "C" int fsrl_ppo_pass(fsrl_ctx* c, const int64_t* perm, uint64_t seed, in
         wp.X = c->obs_p + (size_t)sa.mb_start * c->cfg.obs_dim;
         const bool prof = c->profiling;
         if (prof) {
-            while (c->k_ev.size() < c->k_ev_used + 2) {
+            while (c->k_ev.size() < c->k_ev_used + 3) {
                 hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->k_ev.push_back(e);
             }
             HIPCHK(hipEventRecord(c->k_ev[c->k_ev_used], s));
         }
         rc = dispatch_H(H, [&](auto hc) {
             constexpr int HH = decltype(hc)::value;
-            hipLaunchKernelGGL(ppo_fwd_bwd_kernel<HH>, dim3(tiles, nn), dim3(4 * HH), 0, s, c->P, c->md, bp, sa);
+            hipLaunchKernelGGL(ppo_fwd_bwd_kernel<HH>, dim3(tiles * nn), dim3(4 * HH), 0, s, c->P, c->md, bp, sa);
             return 0;
         });
         if (rc) return rc;
-        if (prof) { HIPCHK(hipEventRecord(c->k_ev[c->k_ev_used + 1], s)); c->k_ev_used += 2; }
+        if (prof) {
+            // e0 | kernel | e1 | e2 : (e2 - e1) is the cost of an empty event bracket on this
+            // stream, subtracted from (e1 - e0) so the figure agrees with rocprof's kernel time
+            HIPCHK(hipEventRecord(c->k_ev[c->k_ev_used + 1], s));
+            HIPCHK(hipEventRecord(c->k_ev[c->k_ev_used + 2], s));
+            c->k_ev_used += 3;
+        }
         rc = dispatch_H(H, [&](auto hc) {
             constexpr int HH = decltype(hc)::value;
             hipLaunchKernelGGL(ppo_wgrad_kernel<HH>, dim3(nparts), dim3(1024), 0, s, c->md, wp, tiles * 16, sa);
@@ -813,11 +819,14 @@ extern "C" int fsrl_ppo_end(fsrl_ctx* c, float* stats_out, int64_t cap_steps, in
         if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) c->t_process_ms = ms;
         if (hipEventElapsedTime(&ms, c->ev_b, c->ev_c) == hipSuccess) c->t_learn_ms = ms;
         double tot = 0;
-        for (size_t i = 0; i + 1 < c->k_ev_used; i += 2) {
-            if (hipEventElapsedTime(&ms, c->k_ev[i], c->k_ev[i + 1]) == hipSuccess) tot += ms;
+        for (size_t i = 0; i + 2 < c->k_ev_used; i += 3) {
+            float a = 0, b = 0;
+            if (hipEventElapsedTime(&a, c->k_ev[i], c->k_ev[i + 1]) == hipSuccess &&
+                hipEventElapsedTime(&b, c->k_ev[i + 1], c->k_ev[i + 2]) == hipSuccess)
+                tot += (double)a - (double)b;
         }
         c->t_fwdbwd_ms = tot;
-        c->n_fwdbwd = (int64_t)(c->k_ev_used / 2);
+        c->n_fwdbwd = (int64_t)(c->k_ev_used / 3);
     }
     return 0;
 }

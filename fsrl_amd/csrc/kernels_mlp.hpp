@@ -244,7 +244,8 @@ __global__ __launch_bounds__(4 * H) void mlp_infer_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------- fused fwd + loss + bwd
-// One PPO minibatch step, activation side.  grid = (ceil(mb/16), n_nets), block = 4*H.
+// One PPO minibatch step, activation side.  1-D grid of 8*slots blocks mapped to
+// (network, 16-row tile) by xcd_assign(); block = 4*H threads.
 // Implements, for its 16 rows: PPOLagrangian.policy_loss / critics_loss gradients
 // (fsrl/policy/ppo_lag.py:152-212, lagrangian_base.py:145-166) analytically.
 struct PpoBatchPtrs {
@@ -271,7 +272,10 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
     constexpr int NT = TileGeom<H>::NT;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
-    const int tile = blockIdx.x, net = blockIdx.y;
+    // block id = tile + n_tiles*net: consecutive tiles of one network land on different XCDs
+    // (grouping a network's tiles on few XCDs was measured 25% slower: same-line contention)
+    const int n_tiles = (sa.mb_size + 15) >> 4;
+    const int tile = blockIdx.x % n_tiles, net = blockIdx.x / n_tiles;
     const int row0 = tile * 16;
     const NetOff no = md.net[net];
     const int Do = md.Do, Da = md.Da, C = md.n_nets - 1;
@@ -280,12 +284,29 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
 
     // ---- prologue: ONE burst of independent loads (W2 slice, obs tile, row data, small
     //      parameters); nothing below waits on a second cold round trip.
+    if (sa.dbg_phase == 10) return;                     // pure launch floor of this kernel
     TileStage<H> stg;
     stg.issue(P, no, Do, Da, bp.obs_p + grow0 * Do, bp.rd_p + grow0 * FSRL_RD, n_valid, tid);
+    if (sa.dbg_phase == 13) { asm volatile("" ::"v"(stg.b1v), "v"(stg.xv[0])); return; }
     FwdW2Frag<H> wf;
+    if (sa.dbg_phase == 14) {                           // a quarter of the W2 burst
+        const float* row = P + no.W2 + (size_t)(wave * 16 + li) * H + 4 * q;
+#pragma unroll
+        for (int kc = 0; kc < H / 64; ++kc) wf.b[kc] = *reinterpret_cast<const f32x4*>(row + 16 * kc);
+        asm volatile("" ::"v"(stg.b1v), "v"(wf.b[0]), "v"(wf.b[H / 64 - 1]));
+        return;
+    }
     wf.load(P + no.W2, wave, lane);
     for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
+    if (sa.dbg_phase == 11) {                           // loads issued, nobody waits for them
+        asm volatile("" ::"v"(stg.b1v), "v"(wf.b[0]));
+        return;
+    }
     stg.commit(sm, no, Do, tid);
+    if (sa.dbg_phase == 12) {                           // + small loads landed, W2 not awaited
+        asm volatile("" ::"v"(wf.b[0]));
+        return;
+    }
     if (sa.dbg_phase == 9) return;                      // launch + address setup only
     __syncthreads();
     if (sa.dbg_phase == 1) { if (wf.b[0][0] == 123.f && sm.xT[tid] == 1.f) bp.statp[0] = 1.f; return; }
