@@ -1,0 +1,122 @@
+"""Episode-count-exact vectorised rollout collection on the host CPUs.
+
+Behaviour of fsrl/data/fast_collector.py:192-408 (policy forward under no_grad -> exploration
+noise -> map_action -> env.step(ids) -> cost from info -> buffer.add -> per-env reset, surplus
+envs dropped so exactly n_episode episodes are collected, statistics dict), written against
+numpy dicts instead of tianshou Batches.  The buffer is the HIP-resident store proxy, so every
+vector step costs one staged push (no device sync)."""
+import time
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch
+
+from fsrl_amd.data.batch import Batch
+
+
+class FastCollector:
+    def __init__(self, policy, env, buffer=None, preprocess_fn=None, exploration_noise: bool = False):
+        self.env = env
+        self.env_num = len(env)
+        self.policy = policy
+        self.buffer = buffer
+        self.preprocess_fn = preprocess_fn
+        self.exploration_noise = exploration_noise
+        self._action_space = env.action_space
+        if buffer is not None:
+            assert buffer.buffer_num >= self.env_num
+        self.reset(False)
+
+    # ------------------------------------------------------------------ resets
+    def reset(self, reset_buffer: bool = True, gym_reset_kwargs: Optional[Dict[str, Any]] = None) -> None:
+        self.reset_env(gym_reset_kwargs)
+        if reset_buffer:
+            self.reset_buffer()
+        self.reset_stat()
+
+    def reset_stat(self) -> None:
+        self.collect_step, self.collect_episode, self.collect_time = 0, 0, 0.0
+
+    def reset_buffer(self, keep_statistics: bool = False) -> None:
+        if self.buffer is not None:
+            self.buffer.reset(keep_statistics=keep_statistics)
+
+    def reset_env(self, gym_reset_kwargs: Optional[Dict[str, Any]] = None) -> None:
+        obs, info = self.env.reset(**(gym_reset_kwargs or {}))
+        self._obs = np.asarray(obs)
+
+    # ------------------------------------------------------------------ collect
+    def collect(self, n_episode: int = 1, random: bool = False, render: bool = False,
+                no_grad: bool = True, gym_reset_kwargs: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
+        if n_episode is None:
+            raise TypeError("Please specify n_episode in FastCollector.collect().")
+        assert n_episode > 0
+        ready = np.arange(min(self.env_num, n_episode))
+        obs = self._obs[:len(ready)]
+        t0 = time.time()
+        step_count, total_cost, episode_count = 0, 0.0, 0
+        term_count, trunc_count = 0, 0
+        ep_rews, ep_lens = [], []
+        while True:
+            data = Batch(obs=obs, info={})
+            if random:
+                act = np.stack([self._action_space.sample() for _ in ready])
+                act = self.policy.map_action_inverse(act)
+            else:
+                with torch.no_grad():
+                    result = self.policy(data, None)
+                act = np.asarray(result.act.numpy() if torch.is_tensor(result.act) else result.act)
+                if self.exploration_noise:
+                    act = self.policy.exploration_noise(act, data)
+            obs_next, rew, terminated, truncated, info = self.env.step(self.policy.map_action(act), ready)
+            terminated, truncated = np.asarray(terminated, bool), np.asarray(truncated, bool)
+            done = terminated | truncated
+            cost = np.asarray(info.get("cost", np.zeros(len(ready))), np.float64) if isinstance(info, dict) \
+                else np.array([i.get("cost", 0.0) for i in info], np.float64)
+            total_cost += float(cost.sum())
+            step_count += len(ready)
+            if self.buffer is not None:
+                ptr, ep_rew, ep_len, ep_idx = self.buffer.add(
+                    Batch(obs=obs, act=act, rew=np.asarray(rew, np.float64), cost=cost,
+                          terminated=terminated, truncated=truncated, obs_next=obs_next), buffer_ids=ready)
+            else:
+                ep_rew, ep_len = self._track_episodes(ready, rew, done)
+            obs = np.asarray(obs_next).copy()
+            if done.any():
+                local = np.where(done)[0]
+                episode_count += len(local)
+                ep_lens.append(np.asarray(ep_len)[local])
+                ep_rews.append(np.asarray(ep_rew)[local])
+                term_count += int(terminated.sum())
+                trunc_count += int(truncated.sum())
+                obs_reset, _ = self.env.reset(ready[local], **(gym_reset_kwargs or {}))
+                obs[local] = obs_reset
+                surplus = len(ready) - (n_episode - episode_count)
+                if surplus > 0:  # drop finished envs that are no longer needed (unbiased tail)
+                    mask = np.ones(len(ready), bool)
+                    mask[local[:surplus]] = False
+                    ready, obs = ready[mask], obs[mask]
+            if episode_count >= n_episode:
+                break
+        self.collect_step += step_count
+        self.collect_episode += episode_count
+        self.collect_time += max(time.time() - t0, 1e-9)
+        self.reset_env()
+        rews, lens = np.concatenate(ep_rews), np.concatenate(ep_lens)
+        done_count = term_count + trunc_count
+        return {"n/ep": episode_count, "n/st": step_count, "rew": float(rews.mean()),
+                "len": float(lens.mean()), "total_cost": total_cost,
+                "cost": total_cost / episode_count, "truncated": trunc_count / done_count,
+                "terminated": term_count / done_count}
+
+    # episode bookkeeping when no buffer is attached (evaluation)
+    def _track_episodes(self, ready, rew, done):
+        if not hasattr(self, "_acc_rew") or len(self._acc_rew) != self.env_num:
+            self._acc_rew, self._acc_len = np.zeros(self.env_num), np.zeros(self.env_num, int)
+        self._acc_rew[ready] += np.asarray(rew, np.float64)
+        self._acc_len[ready] += 1
+        ep_rew, ep_len = np.zeros(len(ready)), np.zeros(len(ready), int)
+        d = np.where(done)[0]
+        ep_rew[d], ep_len[d] = self._acc_rew[ready[d]], self._acc_len[ready[d]]
+        self._acc_rew[ready[d]], self._acc_len[ready[d]] = 0.0, 0
+        return ep_rew, ep_len

@@ -1,0 +1,129 @@
+"""BasePolicy: the contract trainer and collector rely on (fsrl/policy/base_policy.py:86-355),
+with `update()` delegated to the HIP engine by the concrete policies.
+
+The actor / critic `nn.Module`s are kept as the HOST MIRROR of the device parameters: they give
+`state_dict()` the reference's exact key names and serve collector-time inference on the CPU;
+`_push_params()` / `_pull_params()` move the flat vector across the C ABI."""
+from abc import ABC, abstractmethod
+from typing import Any, List, Optional, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from fsrl_amd.data.batch import Batch
+from fsrl_amd.utils.logger import BaseLogger, DummyLogger
+from fsrl_amd.utils.net import ActorCritic
+
+
+class BasePolicy(ABC, nn.Module):
+    def __init__(self, actor: nn.Module, critics: Union[nn.Module, List[nn.Module]], dist_fn=None,
+                 logger: BaseLogger = None, gamma: float = 0.99, max_batchsize: Optional[int] = 99999,
+                 reward_normalization: bool = False, deterministic_eval: bool = True,
+                 action_scaling: bool = True, action_bound_method: str = "clip",
+                 observation_space=None, action_space=None, lr_scheduler=None) -> None:
+        super().__init__()
+        self.actor = actor
+        if isinstance(critics, nn.Module):
+            self.critics = nn.ModuleList([critics])
+        elif isinstance(critics, (list, tuple)):
+            self.critics = nn.ModuleList(critics)
+        else:
+            raise TypeError("critics should not be %s" % (type(critics)))
+        self.critics_num = len(self.critics)
+        self.dist_fn = dist_fn
+        self.logger = logger if logger is not None else DummyLogger()
+        assert 0.0 <= gamma <= 1.0, "discount factor should be in [0, 1]."
+        assert not reward_normalization, "reward_normalization is not built in the HIP path (off in every config)"
+        self._gamma = gamma
+        self._deterministic_eval = deterministic_eval
+        self._max_batchsize = max_batchsize
+        self._actor_critic = ActorCritic(self.actor, self.critics)
+        self.observation_space = observation_space
+        self.action_space = action_space
+        self.action_type = "continuous"
+        self.updating = False
+        self.action_scaling = action_scaling
+        assert action_bound_method in ("", "clip", "tanh")
+        self.action_bound_method = action_bound_method
+        self.lr_scheduler = lr_scheduler
+        self.gradient_steps = 0
+        self.engine = None  # set by the concrete policy
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _flat_params(self) -> np.ndarray:
+        return torch.cat([p.detach().reshape(-1) for p in self._actor_critic.parameters()]).numpy().astype(np.float32)
+
+    def _push_params(self) -> None:
+        self.engine.set_params(self._flat_params())
+
+    def _pull_params(self) -> None:
+        flat = torch.from_numpy(self.engine.get_params())
+        off = 0
+        with torch.no_grad():
+            for p in self._actor_critic.parameters():
+                n = p.numel()
+                p.copy_(flat[off:off + n].view_as(p))
+                off += n
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        out = super().load_state_dict(state_dict, strict=strict)
+        if self.engine is not None:
+            self._push_params()
+        return out
+
+    # ------------------------------------------------------------------ acting
+    def forward(self, batch: Batch, state=None, **kwargs: Any) -> Batch:
+        logits, hidden = self.actor(batch.obs, state=state)
+        dist = self.dist_fn(*logits) if isinstance(logits, tuple) else self.dist_fn(logits)
+        if self._deterministic_eval and not self.training:
+            act = logits[0]
+        else:
+            act = dist.sample()
+        return Batch(logits=logits, act=act, state=hidden, dist=dist)
+
+    def pre_update_fn(self, **kwarg: Any) -> Any:
+        pass
+
+    def post_update_fn(self, **kwarg: Any) -> Any:
+        pass
+
+    def exploration_noise(self, act, batch):
+        return act
+
+    def map_action(self, act):
+        """Bound to [-1, 1] then scale to the env's action range (base_policy.py:226-256)."""
+        if self.action_space is not None and isinstance(act, np.ndarray):
+            if self.action_bound_method == "clip":
+                act = np.clip(act, -1.0, 1.0)
+            elif self.action_bound_method == "tanh":
+                act = np.tanh(act)
+            if self.action_scaling:
+                assert np.min(act) >= -1.0 and np.max(act) <= 1.0, \
+                    "action scaling only accepts raw action range = [-1, 1]"
+                low, high = self.action_space.low, self.action_space.high
+                act = low + (high - low) * (act + 1.0) / 2.0
+        return act
+
+    def map_action_inverse(self, act):
+        act = np.asarray(act)
+        if self.action_space is not None:
+            if self.action_scaling:
+                low, high = self.action_space.low, self.action_space.high
+                scale = (high - low).copy()
+                eps = np.finfo(np.float32).eps.item()
+                scale[scale < eps] += eps
+                act = (act - low) * 2.0 / scale - 1.0
+            if self.action_bound_method == "tanh":
+                act = (np.log(1.0 + act) - np.log(1.0 - act)) / 2.0
+        return act
+
+    # ------------------------------------------------------------------ update
+    @abstractmethod
+    def learn(self, batch, **kwargs: Any):
+        """Concrete policies run the whole update on the device in `update()`; `learn` is kept
+        for interface parity and is not called by the trainers here."""
+
+    @abstractmethod
+    def update(self, sample_size: int, buffer, **kwargs: Any):
+        pass

@@ -1,0 +1,96 @@
+"""PPOLagrangian over the HIP engine.  Same constructor arguments and logger keys as
+fsrl/policy/ppo_lag.py:16-257; `update()` = process_fn + learn on the MI355X through
+`fsrl_ppo_begin / fsrl_ppo_pass / fsrl_ppo_end` (include/fsrl_hip.h)."""
+from typing import Any, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from fsrl_amd.engine import Engine, EngineConfig
+from fsrl_amd.policy.lagrangian_base import LagrangianPolicy
+
+PPO_STAT_KEYS = ("loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss/actor_rew",
+                 "loss/actor_total", "loss/kl", "loss/vf0", "loss/vf1", "loss/vf_total", "loss/total",
+                 "loss/entropy")
+
+
+class PPOLagrangian(LagrangianPolicy):
+    def __init__(self, actor: nn.Module, critics: Union[nn.Module, List[nn.Module]],
+                 optim: torch.optim.Optimizer, dist_fn, logger=None,
+                 # PPO specific arguments
+                 target_kl: float = 0.02, vf_coef: float = 0.25, max_grad_norm: Optional[float] = None,
+                 gae_lambda: float = 0.95, eps_clip: float = 0.2, dual_clip: Optional[float] = None,
+                 value_clip: bool = False, advantage_normalization: bool = True,
+                 recompute_advantage: bool = False,
+                 # Lagrangian specific arguments
+                 use_lagrangian: bool = True, lagrangian_pid: Tuple = (0.05, 0.0005, 0.1),
+                 cost_limit: Union[List, float] = np.inf, rescaling: bool = True,
+                 # Base policy common arguments
+                 gamma: float = 0.99, max_batchsize: int = 99999, reward_normalization: bool = False,
+                 deterministic_eval: bool = True, action_scaling: bool = True,
+                 action_bound_method: str = "clip", observation_space=None, action_space=None,
+                 lr_scheduler=None,
+                 # engine placement (not in the reference: which GPU, how many env sub-buffers)
+                 device: Union[int, str] = 0, env_num: int = 1, buffer_size: int = 100000) -> None:
+        super().__init__(actor, critics, dist_fn, logger, use_lagrangian, lagrangian_pid, cost_limit,
+                         rescaling, gamma, max_batchsize, reward_normalization, deterministic_eval,
+                         action_scaling, action_bound_method, observation_space, action_space, lr_scheduler)
+        assert dual_clip is None or dual_clip > 1.0, "Dual-clip PPO parameter should greater than 1.0."
+        assert not value_clip, "value clip is available only when `reward_normalization` is True"
+        assert not recompute_advantage, "recompute_advantage is not built in the HIP path"
+        assert 0.0 <= gae_lambda <= 1.0, "GAE lambda should be in [0, 1]."
+        self.optim = optim
+        self._lambda, self._weight_vf, self._grad_norm = gae_lambda, vf_coef, max_grad_norm
+        self._target_kl, self._eps_clip, self._dual_clip = target_kl, eps_clip, dual_clip
+        self._norm_adv = advantage_normalization
+        # ---- derive the engine geometry from the host networks
+        w1 = actor.preprocess.model.model[0].weight
+        hidden, obs_dim = w1.shape
+        act_dim = actor.mu.model[0].weight.shape[0]
+        g = optim.param_groups[0]
+        dev = int(str(device).split(":")[-1]) if not isinstance(device, int) and ":" in str(device) else \
+            (device if isinstance(device, int) else 0)
+        self.engine = Engine(EngineConfig(
+            obs_dim=int(obs_dim), act_dim=int(act_dim), hidden=int(hidden), n_critics=self.critics_num,
+            env_num=int(env_num), buffer_size=int(buffer_size), max_action=float(getattr(actor, "_max", 1.0)),
+            gamma=gamma, gae_lambda=gae_lambda, eps_clip=eps_clip, dual_clip=dual_clip, vf_coef=vf_coef,
+            max_grad_norm=max_grad_norm, target_kl=target_kl, norm_adv=advantage_normalization,
+            use_lagrangian=use_lagrangian, lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1],
+            adam_eps=g["eps"]), device=dev)
+        self._push_params()
+
+    def learn(self, batch, **kwargs: Any):
+        raise NotImplementedError("the HIP path runs process_fn + learn inside update()")
+
+    def update(self, sample_size: int, buffer, batch_size: int = 256, repeat: int = 4, **kwargs: Any):
+        if buffer is None:
+            return {}
+        assert sample_size == 0, "on-policy update consumes the whole buffer (sample_size=0)"
+        assert getattr(buffer, "engine", None) is self.engine, \
+            "PPOLagrangian.update needs the HipVectorReplayBuffer bound to this policy's engine"
+        self.updating = True
+        lags, rescaling = self.lagrangians_and_rescaling() if self.use_lagrangian else ([], 1.0)
+        eng = self.engine
+        n = eng.ppo_begin(lags, rescaling, batch_size)          # buffer.sample(0) + process_fn
+        stopped_at = -1
+        for step in range(repeat):                               # ppo_lag.py:217
+            perm = np.random.permutation(n) if n > 0 else None   # Batch.split(shuffle=True)
+            if eng.ppo_pass(perm):
+                stopped_at = step
+                self.logger.print("Early stop at step %d due to reaching max kl." % step)
+                break
+        steps_per_pass = max(1, -(-n // max(batch_size, 1)))
+        stats = eng.ppo_end_stats(steps_per_pass * max(repeat, 1))
+        for row in stats:                                        # one row per optimiser step
+            d = dict(zip(PPO_STAT_KEYS, (float(v) for v in row)))
+            total, entropy = d.pop("loss/total"), d.pop("loss/entropy")
+            self.logger.store(**d)
+            self.logger.store(total=total, entropy=entropy, tab="loss")
+        self.gradient_steps += len(stats)
+        self.logger.store(gradient_steps=self.gradient_steps, tab="update")
+        self._pull_params()                                      # host mirror for acting / checkpoints
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+        self.updating = False
+        return {"gradient_steps": len(stats), "early_stop_pass": stopped_at}

@@ -1,0 +1,103 @@
+"""GPU tests of the drop-in surface: fsrl_amd.policy / agent / trainer / data over the engine."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import ppo_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _policy_from_case(cfg, g, logger=None):
+    from torch.distributions import Independent, Normal
+    from fsrl_amd.env import Box
+    from fsrl_amd.policy import PPOLagrangian
+    from fsrl_amd.utils.net import ActorCritic, ActorProb, Critic, Net
+    h, Do, Da = tuple(cfg["hidden"]), cfg["obs_dim"], cfg["act_dim"]
+    actor = ActorProb(Net((Do, ), hidden_sizes=h), (Da, ), max_action=cfg["max_action"])
+    critics = [Critic(Net((Do, ), hidden_sizes=h)) for _ in range(2)]
+    ac = ActorCritic(actor, critics)
+    flat, off = torch.from_numpy(g["theta0"]), 0
+    with torch.no_grad():
+        for p in ac.parameters():
+            p.copy_(flat[off:off + p.numel()].view_as(p)); off += p.numel()
+    optim = torch.optim.Adam(ac.parameters(), lr=cfg["lr"])
+    return PPOLagrangian(actor, critics, optim, lambda *l: Independent(Normal(*l), 1), logger=logger,
+                         target_kl=cfg["target_kl"], vf_coef=cfg["vf_coef"],
+                         max_grad_norm=cfg["max_grad_norm"], gae_lambda=cfg["gae_lambda"],
+                         eps_clip=cfg["eps_clip"], dual_clip=cfg["dual_clip"],
+                         advantage_normalization=cfg["advantage_normalization"],
+                         use_lagrangian=cfg["use_lagrangian"], cost_limit=cfg["cost_limit"],
+                         gamma=cfg["gamma"], observation_space=Box(-np.inf, np.inf, (Do, )),
+                         action_space=Box(-1, 1, (Da, )), device=0, env_num=cfg["env_num"])
+
+
+class _Capture:
+    def __init__(self):
+        self.rows, self.msgs = [], []
+
+    def store(self, tab=None, **kw):
+        self.rows.append({(tab + "/" + k if tab else k): v for k, v in kw.items()})
+
+    def print(self, msg, *a):
+        self.msgs.append(msg)
+
+
+@pytest.mark.parametrize("name", ["tiny", "c1", "earlystop"])
+def test_policy_update_through_facade_matches_reference(name):
+    """Same call sequence as OnpolicyTrainer.policy_update_fn, numpy RNG seeded like the golden
+    generator: the facade draws the SAME permutations as the reference's Batch.split."""
+    import random
+    from fsrl_amd.data import Batch, HipVectorReplayBuffer
+    cfg, g = ppo_case(name)
+    log = _Capture()
+    pol = _policy_from_case(cfg, g, log)
+    pol.train()
+    buf = HipVectorReplayBuffer(pol.engine, 100000, cfg["env_num"])
+    rows = g["env_rows"]; off = np.concatenate([[0], np.cumsum(rows)])
+    for t in range(rows.max()):
+        ids = np.array([e for e in range(len(rows)) if t < rows[e]])
+        sel = np.array([off[e] + t for e in ids])
+        buf.add(Batch(obs=g["buf_obs"][sel], act=g["buf_act"][sel], rew=g["buf_rew"][sel],
+                      info={"cost": g["buf_cost"][sel]}, terminated=g["buf_terminated"][sel],
+                      truncated=g["buf_truncated"][sel], obs_next=g["buf_obs_next"][sel]), buffer_ids=ids)
+    pol.pre_update_fn(stats_train={"cost": cfg["cost_stat"]})
+    assert pol.lag_optims[0].get_lag() == g["lagrangian"][0]
+    seed = cfg["seed"] + 7
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    out = pol.update(0, buf, batch_size=cfg["batch_size"], repeat=cfg["repeat"])
+    assert out["gradient_steps"] == int(g["gradient_steps"]) == pol.gradient_steps
+    assert (out["early_stop_pass"] >= 0) == bool(g["early_stop_msgs"]) == bool(log.msgs)
+    keys = [str(k) for k in g["stats_keys"]]
+    rows_ = [r for r in log.rows if "update/gradient_steps" not in r]
+    got = np.array([[{**rows_[i], **rows_[i + 1]}[k] for k in keys] for i in range(0, len(rows_), 2)])
+    np.testing.assert_allclose(got, g["stats"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(pol._flat_params(), g["theta_final"], rtol=0, atol=2e-6)
+    # checkpoint round trip under the reference's key names
+    sd = pol.state_dict()
+    pol2 = _policy_from_case(cfg, g)
+    pol2.load_state_dict(sd)
+    assert np.array_equal(pol2.engine.get_params(), pol.engine.get_params())
+    assert pol2.lag_optims[0].get_lag() == pol.lag_optims[0].get_lag()
+
+
+def test_agent_learn_end_to_end_on_synthetic_env(tmp_path):
+    from fsrl_amd.agent import PPOLagAgent
+    from fsrl_amd.env import SyntheticSafetyVectorEnv
+    from fsrl_amd.utils import BaseLogger
+    train = SyntheticSafetyVectorEnv(env_num=4, episode_len=50, seed=1)
+    test = SyntheticSafetyVectorEnv(env_num=2, episode_len=50, seed=2)
+    agent = PPOLagAgent(train, BaseLogger(str(tmp_path), name="t"), cost_limit=10, device="cuda:0", seed=3,
+                        hidden_sizes=(64, 64), max_grad_norm=0.5, training_num=4)
+    theta0 = agent.policy.engine.get_params()
+    ep, stat, info = agent.learn(train, test, epoch=2, episode_per_collect=4, step_per_epoch=400,
+                                 repeat_per_collect=2, batch_size=64, testing_num=2, verbose=False)
+    assert ep == 2 and info["train_speed"] > 0 and info["policy_update_time"] > 0
+    assert "loss/kl" in stat and "train/reward" in stat and "test/cost" in stat
+    assert np.isfinite(list(stat.values())).all()
+    theta1 = agent.policy.engine.get_params()
+    assert np.abs(theta1 - theta0).max() > 1e-4                      # it learned something
+    assert np.array_equal(agent.policy._flat_params(), theta1)      # host mirror in sync
+    rew, length, cost = agent.evaluate(test, eval_episodes=2)
+    assert length == 50.0 and np.isfinite(rew) and cost >= 0
+    assert (tmp_path / "t" / "checkpoint" / "model.pt").exists()
