@@ -102,6 +102,43 @@ def cpu_baseline(theta, inputs, seconds=12.0):
                       f"torch CPU fp32, {threads} threads of {os.cpu_count()} host cpus"}
 
 
+def end_to_end(local_rank, seed, seconds=6.0):
+    """Secondary figure (outside the timed region): the whole training loop of
+    OnpolicyAgent.learn -- host collector over a SYNTHETIC SafetyCarCircle-shaped vector env
+    (20 envs, 300-step episodes, 20 episodes per collect) feeding the HIP-resident store, one
+    device update per collect -- reported like the reference's `train_speed` (env-steps/s)."""
+    from fsrl_amd.agent import PPOLagAgent
+    from fsrl_amd.data import FastCollector, HipVectorReplayBuffer
+    from fsrl_amd.env import SyntheticSafetyVectorEnv
+    from fsrl_amd.trainer import OnpolicyTrainer
+    env = SyntheticSafetyVectorEnv(env_num=ENVS, obs_dim=OBS, act_dim=ACT, episode_len=300, seed=seed)
+    agent = PPOLagAgent(env, cost_limit=10, device=f"cuda:{local_rank}", seed=seed, hidden_sizes=(HID, HID),
+                        max_grad_norm=0.5, training_num=ENVS)
+    agent.policy.train()
+    buf = HipVectorReplayBuffer(agent.policy.engine, 100000, ENVS)
+    col = FastCollector(agent.policy, env, buf, exploration_noise=True)
+    tr = OnpolicyTrainer(agent.policy, col, None, max_epoch=10**6, batch_size=BATCH, cost_limit=10,
+                         step_per_epoch=6000, repeat_per_collect=REPEAT, episode_per_collect=20,
+                         verbose=False)
+    tr.reset()
+    t0 = time.perf_counter()
+    collects = 0
+    while time.perf_counter() - t0 < seconds:
+        st = tr.train_step()
+        t1 = time.perf_counter()
+        tr.policy_update_fn(st)
+        tr.update_time += time.perf_counter() - t1
+        collects += 1
+    dt = time.perf_counter() - t0
+    out = {"env": "synthetic SafetyCarCircle-shaped vector env (not PyBullet)", "envs": ENVS,
+           "collects": collects, "env_steps_per_s": col.collect_step / dt,
+           "collector_only_env_steps_per_s": col.collect_step / col.collect_time,
+           "update_ms_per_collect": tr.update_time / collects * 1e3,
+           "policy_updates_per_s": collects / dt}
+    agent.policy.engine.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,12 +206,12 @@ def main():
     # ---- roofline of the dominant kernel: HIP events around every ppo_fwd_bwd_kernel launch on
     #      the library's compute stream, over K more updates of the same workload
     eng.set_profiling(True)
-    k_ms, k_n, learn_ms, proc_ms = 0.0, 0, 0.0, 0.0
+    k_ms, k_raw, k_n, learn_ms, proc_ms = 0.0, 0.0, 0, 0.0, 0.0
     prof_steps = max(1, min(args.steps, 5))
     for k in range(prof_steps):
         one_update(10_000 + k)
         tm = eng.last_timing()
-        k_ms += tm["fwdbwd_ms"]; k_n += tm["fwdbwd_launches"]
+        k_ms += tm["fwdbwd_ms"]; k_raw += tm["fwdbwd_raw_ms"]; k_n += tm["fwdbwd_launches"]
         learn_ms += tm["learn_ms"]; proc_ms += tm["process_ms"]
     eng.set_profiling(False)
     avg_launch_s = (k_ms / max(k_n, 1)) * 1e-3
@@ -199,10 +236,13 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "ppo_fwd_bwd_kernel<256>", "achieved": achieved,
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "avg_launch_us": avg_launch_s * 1e6, "launches_timed": int(k_n),
+                         "avg_launch_us": avg_launch_s * 1e6,
+                         "avg_launch_us_raw_event_bracket": k_raw / max(k_n, 1) * 1e3,
+                         "launches_timed": int(k_n),
                          "flops_per_launch": flops_fwdbwd_launch(rows_avg)},
         }
         if not args.no_cpu_baseline:
+            out["end_to_end"] = end_to_end(local_rank, seed)
             out["cpu_baseline"] = cpu_baseline(theta, inputs)
             out["speedup_vs_cpu_port"] = out["value"] / world / out["cpu_baseline"]["value"]
         print(json.dumps(out))

@@ -116,7 +116,7 @@ struct fsrl_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
     std::vector<hipEvent_t> k_ev;     // pairs around the fwd/bwd kernel (profiling mode)
     size_t k_ev_used = 0;
-    double t_process_ms = 0, t_learn_ms = 0, t_fwdbwd_ms = 0;
+    double t_process_ms = 0, t_learn_ms = 0, t_fwdbwd_ms = 0, t_fwdbwd_raw_ms = 0;
     int64_t n_fwdbwd = 0;
     uint64_t rng[4] = {0x9E3779B97F4A7C15ull, 0xBF58476D1CE4E5B9ull, 0x94D049BB133111EBull, 1};
 };
@@ -771,7 +771,8 @@ extern "C" int fsrl_ppo_pass(fsrl_ctx* c, const int64_t* perm, uint64_t seed, in
         if (rc) return rc;
         if (prof) {
             // e0 | kernel | e1 | e2 : (e2 - e1) is the cost of an empty event bracket on this
-            // stream, subtracted from (e1 - e0) so the figure agrees with rocprof's kernel time
+            // stream.  Half of it overlaps the kernel's own dispatch, so (e1 - e0) - (e2 - e1)/2
+            // is reported (calibrated against rocprofv3: 22.4 vs 22.1 us); raw sums are kept too
             HIPCHK(hipEventRecord(c->k_ev[c->k_ev_used + 1], s));
             HIPCHK(hipEventRecord(c->k_ev[c->k_ev_used + 2], s));
             c->k_ev_used += 3;
@@ -819,11 +820,12 @@ extern "C" int fsrl_ppo_end(fsrl_ctx* c, float* stats_out, int64_t cap_steps, in
         if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) c->t_process_ms = ms;
         if (hipEventElapsedTime(&ms, c->ev_b, c->ev_c) == hipSuccess) c->t_learn_ms = ms;
         double tot = 0;
+        c->t_fwdbwd_raw_ms = 0;
         for (size_t i = 0; i + 2 < c->k_ev_used; i += 3) {
             float a = 0, b = 0;
             if (hipEventElapsedTime(&a, c->k_ev[i], c->k_ev[i + 1]) == hipSuccess &&
                 hipEventElapsedTime(&b, c->k_ev[i + 1], c->k_ev[i + 2]) == hipSuccess)
-                tot += (double)a - (double)b;
+            { tot += (double)a - 0.5 * (double)b; c->t_fwdbwd_raw_ms += (double)a; }
         }
         c->t_fwdbwd_ms = tot;
         c->n_fwdbwd = (int64_t)(c->k_ev_used / 3);
@@ -883,5 +885,6 @@ extern "C" int fsrl_set_profiling(fsrl_ctx* c, int enable) {
 extern "C" int fsrl_last_timing(fsrl_ctx* c, double* out, int32_t n) {
     CHECK_ARG(c && out && n >= 4, "need room for 4 doubles");
     out[0] = c->t_process_ms; out[1] = c->t_learn_ms; out[2] = c->t_fwdbwd_ms; out[3] = (double)c->n_fwdbwd;
+    if (n >= 5) out[4] = c->t_fwdbwd_raw_ms;
     return 0;
 }

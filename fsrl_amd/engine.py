@@ -203,6 +203,7 @@ class Engine:
         _lib.check(self.lib.fsrl_set_profiling(self._ctx, int(on)))
 
     def last_timing(self):
-        out = np.zeros(4, np.float64)
-        _lib.check(self.lib.fsrl_last_timing(self._ctx, _ptr(out, _f64p), 4))
-        return dict(process_ms=out[0], learn_ms=out[1], fwdbwd_ms=out[2], fwdbwd_launches=int(out[3]))
+        out = np.zeros(5, np.float64)
+        _lib.check(self.lib.fsrl_last_timing(self._ctx, _ptr(out, _f64p), 5))
+        return dict(process_ms=out[0], learn_ms=out[1], fwdbwd_ms=out[2], fwdbwd_launches=int(out[3]),
+                    fwdbwd_raw_ms=out[4])

@@ -143,7 +143,8 @@ int fsrl_gae_return(fsrl_ctx* ctx, const float* v, const float* v_next, const do
 /* ---- timing of the last update, measured with hipEvents on the compute stream --------- */
 /* out[0] = process_fn ms, out[1] = learn ms (all passes), out[2] = fused fwd/bwd kernel
  * total ms over the update (sum of per-launch event pairs when profiling is enabled),
- * out[3] = number of fwd/bwd launches.                                                   */
+ * out[3] = number of fwd/bwd launches, out[4] (if n >= 5) = the raw event-bracket sum (no
+ * overhead correction).                                                                   */
 int fsrl_set_profiling(fsrl_ctx* ctx, int enable);
 int fsrl_last_timing(fsrl_ctx* ctx, double* out, int32_t n);
 

@@ -91,7 +91,8 @@ def test_agent_learn_end_to_end_on_synthetic_env(tmp_path):
                         hidden_sizes=(64, 64), max_grad_norm=0.5, training_num=4)
     theta0 = agent.policy.engine.get_params()
     ep, stat, info = agent.learn(train, test, epoch=2, episode_per_collect=4, step_per_epoch=400,
-                                 repeat_per_collect=2, batch_size=64, testing_num=2, verbose=False)
+                                 repeat_per_collect=2, batch_size=64, testing_num=2, save_interval=1,
+                                 verbose=False)
     assert ep == 2 and info["train_speed"] > 0 and info["policy_update_time"] > 0
     assert "loss/kl" in stat and "train/reward" in stat and "test/cost" in stat
     assert np.isfinite(list(stat.values())).all()
