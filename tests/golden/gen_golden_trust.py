@@ -1,0 +1,231 @@
+#!/usr/bin/env python
+"""Golden vectors G5 (CPO) and G6 (TRPO-Lagrangian) from the UNMODIFIED reference
+(fsrl/policy/cpo.py, fsrl/policy/trpo_lag.py), build container only.  Same rules as
+gen_golden.py: inputs and outputs are recorded, no reference source is copied.
+
+    python tests/golden/gen_golden_trust.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+from fsrl.policy import CPO, TRPOLagrangian  # noqa: E402
+from fsrl.utils.net.common import ActorCritic  # noqa: E402
+from torch import nn  # noqa: E402
+from torch.distributions import Independent, Normal  # noqa: E402
+
+from gen_golden import CaptureLogger, fill_buffer, flat_params, seed_all  # noqa: E402
+from ref_shim import ActorProb, Critic, Net, _Box  # noqa: E402
+
+
+def build_nets(obs_dim, act_dim, hidden, seed):
+    seed_all(seed)
+    actor = ActorProb(Net((obs_dim, ), hidden_sizes=hidden), (act_dim, ), max_action=1.0)
+    critic = [Critic(Net((obs_dim, ), hidden_sizes=hidden)) for _ in range(2)]
+    torch.nn.init.constant_(actor.sigma_param, -0.5)
+    ac = ActorCritic(actor, critic)
+    for m in ac.modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.orthogonal_(m.weight)
+            torch.nn.init.zeros_(m.bias)
+    return actor, critic, ac
+
+
+def dist(*logits):
+    return Independent(Normal(*logits), 1)
+
+
+class PermRecorder:
+    """Records the np.random.permutation draws of Batch.split (the full batch is shuffled)."""
+
+    def __enter__(self):
+        self.perms, self._orig = [], np.random.permutation
+
+        def rec(n):
+            p = self._orig(n)
+            self.perms.append(np.asarray(p).copy())
+            return p
+
+        np.random.permutation = rec
+        return self
+
+    def __exit__(self, *a):
+        np.random.permutation = self._orig
+
+
+def record_batch(out, buf):
+    batch, indices = buf.sample(0)
+    out["indices"] = indices
+    for k in ("obs", "act", "rew", "terminated", "truncated", "obs_next"):
+        out["buf_" + k] = getattr(batch, k)
+    out["buf_cost"] = batch.info.cost
+    out["unfinished_index"] = buf.unfinished_index()
+    out["env_rows"] = np.array([len(b) for b in buf.buffers])
+
+
+def gen_cpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cost_stat, cost_limit,
+            lr=1e-3, perturb_actor=0.0, **kw):
+    """cost_stat / cost_limit steer the optim_case; perturb_actor moves theta away from the
+    theta that produced mean_old (exercises the exact-Hessian path on the very first call)."""
+    actor, critic, ac = build_nets(obs_dim, act_dim, hidden, seed)
+    optim = torch.optim.Adam(nn.ModuleList(critic).parameters(), lr=lr)
+    logger = CaptureLogger()
+    policy = CPO(actor, critic, optim, dist, logger=logger, cost_limit=cost_limit,
+                 observation_space=_Box(-np.inf, np.inf, (obs_dim, )),
+                 action_space=_Box(-1, 1, (act_dim, )), **kw)
+    policy.train()
+    buf = fill_buffer(np.random.default_rng(seed + 1000), env_num, ep_lens, obs_dim, act_dim)
+    out = {"theta0": flat_params(ac)}
+    record_batch(out, buf)
+    policy.pre_update_fn(stats_train={"cost": cost_stat})
+    # capture internals of every policy_loss call by wrapping the policy's own methods
+    cap = {"cg": []}
+    orig_cg = policy._conjugate_gradients
+
+    def cg(g, fkg, *a, **k):
+        x = orig_cg(g, fkg, *a, **k)
+        cap["cg"].append(x.detach().numpy().copy())
+        return x
+
+    policy._conjugate_gradients = cg
+    batch, indices = buf.sample(0)
+    pbatch = policy.process_fn(batch, buf, indices)
+    out["advs_norm"] = pbatch.advs.numpy().copy()
+    out["rets"] = pbatch.rets.numpy().copy()
+    out["logp_old"] = pbatch.logp_old.numpy().copy()
+    out["mean_old"] = pbatch.mean_old.numpy().copy()
+    out["std_old"] = pbatch.std_old.numpy().copy()
+    if perturb_actor:
+        g = torch.Generator().manual_seed(seed + 5)
+        with torch.no_grad():
+            for p in actor.parameters():
+                p.add_(perturb_actor * torch.randn(p.shape, generator=g))
+        out["theta0_perturbed"] = flat_params(ac)
+        # one stand-alone policy_loss on the processed batch (theta != theta_old)
+        for _ in range(policy._optim_critic_iters):
+            policy.critics_loss(pbatch)
+        _, st = policy.policy_loss(pbatch)
+        out["pl_stats_keys"] = np.array(list(st.keys()))
+        out["pl_stats"] = np.array([float(st[k]) for k in st], np.float64)
+        out["pl_H_inv_g"] = cap["cg"][0]
+        if len(cap["cg"]) > 1:
+            out["pl_H_inv_b"] = cap["cg"][1]
+        out["theta_after_pl"] = flat_params(ac)
+    else:
+        with PermRecorder() as pr:
+            policy.update(0, buf, batch_size=99999, repeat=repeat)
+        out["perms"] = np.stack(pr.perms)
+        rows = [r for r in logger.rows if "update/gradient_steps" not in r]
+        assert len(rows) == 2 * repeat
+        keys_a = [k for k in rows[0].keys()]
+        keys_c = [k for k in rows[1].keys()]
+        out["stats_actor_keys"] = np.array(keys_a)
+        out["stats_critic_keys"] = np.array(keys_c)
+        out["stats_actor"] = np.array([[rows[2 * i][k] for k in keys_a] for i in range(repeat)])
+        out["stats_critic"] = np.array([[rows[2 * i + 1][k] for k in keys_c] for i in range(repeat)])
+        out["H_inv_g_first"] = cap["cg"][0]
+        out["theta_final"] = flat_params(ac)
+    cfg = dict(obs_dim=obs_dim, act_dim=act_dim, hidden=list(hidden), env_num=env_num, repeat=repeat,
+               seed=seed, cost_stat=cost_stat, cost_limit=cost_limit, lr=lr, max_action=1.0,
+               perturb_actor=perturb_actor)
+    defaults = dict(target_kl=0.01, backtrack_coeff=0.8, damping_coeff=0.1, max_backtracks=10,
+                    optim_critic_iters=20, l2_reg=0.001, gae_lambda=0.95, advantage_normalization=True,
+                    gamma=0.99)
+    cfg.update(kw)
+    for k, v in defaults.items():
+        cfg.setdefault(k, v)
+    out["cfg_json"] = np.array(json.dumps(cfg))
+    np.savez_compressed(os.path.join(HERE, f"cpo_{name}.npz"), **out)
+    if perturb_actor:
+        print(f"G5 cpo_{name}.npz  N={len(indices)} policy_loss case={int(st['loss/optim_case'])} "
+              f"step={st['loss/step_size']:.4f} kl={st['loss/kl']:.3e}")
+    else:
+        ic = keys_a.index("loss/optim_case"); isz = keys_a.index("loss/step_size")
+        print(f"G5 cpo_{name}.npz  N={len(indices)} cases={out['stats_actor'][:, ic]} "
+              f"steps={np.round(out['stats_actor'][:, isz], 4)}")
+
+
+def gen_trpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cost_stat, cost_limit,
+             lr=5e-4, **kw):
+    actor, critic, ac = build_nets(obs_dim, act_dim, hidden, seed)
+    optim = torch.optim.Adam(ac.parameters(), lr=lr)
+    logger = CaptureLogger()
+    policy = TRPOLagrangian(actor, critic, optim, dist, logger=logger, cost_limit=cost_limit,
+                            observation_space=_Box(-np.inf, np.inf, (obs_dim, )),
+                            action_space=_Box(-1, 1, (act_dim, )), **kw)
+    policy.train()
+    buf = fill_buffer(np.random.default_rng(seed + 1000), env_num, ep_lens, obs_dim, act_dim)
+    out = {"theta0": flat_params(ac)}
+    record_batch(out, buf)
+    policy.pre_update_fn(stats_train={"cost": cost_stat})
+    out["lagrangian"] = np.array([o.get_lag() for o in policy.lag_optims], np.float64)
+    cap = {"cg": []}
+    orig_cg = policy._conjugate_gradients
+
+    def cg(g, fkg, *a, **k):
+        x = orig_cg(g, fkg, *a, **k)
+        cap["cg"].append(x.detach().numpy().copy())
+        return x
+
+    policy._conjugate_gradients = cg
+    with PermRecorder() as pr:
+        policy.update(0, buf, batch_size=99999, repeat=repeat)
+    out["perms"] = np.stack(pr.perms)
+    rows = [r for r in logger.rows if "update/gradient_steps" not in r]
+    assert len(rows) == 3 * repeat
+    keys = []
+    for r in rows[:3]:
+        keys += list(r.keys())
+    out["stats_keys"] = np.array(keys)
+    out["stats"] = np.array([[{**rows[3 * i], **rows[3 * i + 1], **rows[3 * i + 2]}[k] for k in keys]
+                             for i in range(repeat)])
+    out["cg_first"] = cap["cg"][0]
+    out["theta_final"] = flat_params(ac)
+    out["gradient_steps"] = np.array(policy.gradient_steps)
+    out["msgs"] = np.array(len(logger.msgs))
+    cfg = dict(obs_dim=obs_dim, act_dim=act_dim, hidden=list(hidden), env_num=env_num, repeat=repeat,
+               seed=seed, cost_stat=cost_stat, cost_limit=cost_limit, lr=lr, max_action=1.0)
+    defaults = dict(target_kl=0.001, backtrack_coeff=0.8, max_backtracks=10, optim_critic_iters=5,
+                    gae_lambda=0.95, advantage_normalization=True, gamma=0.99,
+                    lagrangian_pid=(0.05, 0.0005, 0.1), rescaling=True, use_lagrangian=True)
+    cfg.update(kw)
+    for k, v in defaults.items():
+        cfg.setdefault(k, v)
+    out["cfg_json"] = np.array(json.dumps(cfg))
+    np.savez_compressed(os.path.join(HERE, f"trpo_{name}.npz"), **out)
+    ik = keys.index("loss/step_size")
+    print(f"G6 trpo_{name}.npz N={len(out['indices'])} step_sizes={np.round(out['stats'][:, ik], 5)} "
+          f"msgs={len(logger.msgs)}")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    eps = [[100, 100], [100, -60], [120, 80]]
+    # cost far above the limit (c > 0): infeasible / recovery branches
+    gen_cpo("infeasible", 8, 2, (64, 64), 3, eps, repeat=2, seed=10, cost_stat=25.0, cost_limit=10.0,
+            optim_critic_iters=5, max_backtracks=10)
+    # cost below the limit: feasible branches (cases 2-4)
+    gen_cpo("feasible", 8, 2, (64, 64), 3, eps, repeat=2, seed=11, cost_stat=3.0, cost_limit=10.0,
+            optim_critic_iters=5, max_backtracks=10)
+    gen_cpo("edge", 8, 2, (64, 64), 3, eps, repeat=3, seed=12, cost_stat=9.9, cost_limit=10.0,
+            optim_critic_iters=3, max_backtracks=25)
+    # |c| tiny => the safety boundary intersects the trust region (B >= 0): cases 1 and 2
+    gen_cpo("case1", 8, 2, (64, 64), 3, eps, repeat=2, seed=14, cost_stat=10.002, cost_limit=10.0,
+            optim_critic_iters=3, max_backtracks=12)
+    gen_cpo("case2", 8, 2, (64, 64), 3, eps, repeat=2, seed=15, cost_stat=9.998, cost_limit=10.0,
+            optim_critic_iters=3, max_backtracks=12)
+    # 128x128, obs 12 / act 3, actor perturbed away from theta_old: exact Hessian != Fisher
+    gen_cpo("perturbed", 12, 3, (128, 128), 2, [[150, 150], [150, -90]], repeat=1, seed=13,
+            cost_stat=14.0, cost_limit=10.0, optim_critic_iters=4, max_backtracks=15, perturb_actor=0.02)
+    gen_trpo("small", 8, 2, (64, 64), 3, eps, repeat=2, seed=20, cost_stat=25.0, cost_limit=10.0,
+             optim_critic_iters=5)
+    gen_trpo("c1", 8, 2, (128, 128), 4, [[300], [300], [300], [-150]], repeat=2, seed=21, cost_stat=4.0,
+             cost_limit=10.0, optim_critic_iters=5, target_kl=0.01)
