@@ -21,6 +21,16 @@ class Config(C.Structure):
                 ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float)]
 
 
+class TrConfig(C.Structure):
+    """struct fsrl_tr_config (include/fsrl_hip.h)"""
+    _fields_ = [("target_kl", C.c_float), ("backtrack_coeff", C.c_float), ("damping", C.c_float),
+                ("l2_reg", C.c_float), ("critic_lr", C.c_float), ("max_backtracks", C.c_int32),
+                ("optim_critic_iters", C.c_int32), ("cg_iters", C.c_int32), ("norm_adv", C.c_int32),
+                ("cost_limit", C.c_double)]
+
+
+CPO_NSTATS, TRPO_NSTATS = 17, 11
+
 _P = C.POINTER
 _f, _d, _u8, _i32, _i64 = _P(C.c_float), _P(C.c_double), _P(C.c_uint8), _P(C.c_int32), _P(C.c_int64)
 _ctx = C.c_void_p
@@ -49,6 +59,13 @@ SIGNATURES = {
                                   C.c_int64, _i64, _i32]),
     "fsrl_batch_get": (C.c_int, [_ctx, C.c_char_p, _f, C.c_int64]),
     "fsrl_gae_return": (C.c_int, [_ctx, _f, _f, _d, _u8, C.c_int64, C.c_double, C.c_double, _d]),
+    "fsrl_tr_begin": (C.c_int, [_ctx, _P(TrConfig), _i64]),
+    "fsrl_cpo_learn": (C.c_int, [_ctx, C.c_double, C.c_int32, _f]),
+    "fsrl_trpo_learn": (C.c_int, [_ctx, _d, C.c_double, C.c_int32, _f]),
+    "fsrl_actor_param_count": (C.c_int64, [_ctx]),
+    "fsrl_tr_grad": (C.c_int, [_ctx, C.c_int32, _f, C.c_int64]),
+    "fsrl_tr_hvp": (C.c_int, [_ctx, _f, _f, C.c_int64]),
+    "fsrl_tr_eval": (C.c_int, [_ctx, _d]),
     "fsrl_set_profiling": (C.c_int, [_ctx, C.c_int]),
     "fsrl_last_timing": (C.c_int, [_ctx, _d, C.c_int32]),
 }

@@ -11,11 +11,13 @@
 #define FSRL_MAX_OBS 128
 #define FSRL_MAX_ACT 16
 #define FSRL_W1_LDS 16      // W1 is staged to LDS when obs_dim <= 16
-// per-row loss inputs of the permuted pass batch: act[16] | logp_old | adv_n[4] | ret[4] | pad
-#define FSRL_RD 32
+// per-row loss inputs: act[16] | logp_old | adv_n[4] | ret[4] | pad | mean_old[16] | std_old[16]
+#define FSRL_RD 64
 #define FSRL_RD_LOGP 16
 #define FSRL_RD_ADV 17
 #define FSRL_RD_RET 21
+#define FSRL_RD_MEAN 32
+#define FSRL_RD_STD 48
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

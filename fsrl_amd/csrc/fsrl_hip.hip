@@ -15,6 +15,7 @@
 
 #include "kernels_misc.hpp"
 #include "kernels_mlp.hpp"
+#include "kernels_fb.hpp"
 
 // ------------------------------------------------------------------------------ errors
 static thread_local std::string g_err;
@@ -119,7 +120,9 @@ struct fsrl_ctx {
     double t_process_ms = 0, t_learn_ms = 0, t_fwdbwd_ms = 0, t_fwdbwd_raw_ms = 0;
     int64_t n_fwdbwd = 0;
     uint64_t rng[4] = {0x9E3779B97F4A7C15ull, 0xBF58476D1CE4E5B9ull, 0x94D049BB133111EBull, 1};
+    struct TrState* tr = nullptr;   // trust-region (CPO / TRPO-Lag) working set, owned
 };
+static void tr_free(fsrl_ctx* c);
 
 static int ensure_scratch(fsrl_ctx* c, size_t bytes) {
     if (c->scratch_bytes >= bytes) return 0;
@@ -173,6 +176,7 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    tr_free(c);
     void* dptrs[] = {c->P, c->M, c->V, c->G, c->ctrl, c->st.obs, c->st.obs_next, c->st.act, c->st.rew,
                      c->st.cost, c->st.flags, c->b.obs, c->b.obs_next, c->b.act, c->b.rew, c->b.cost,
                      c->b.flags, c->d_indices, c->d_end, c->d_seg, c->values, c->vnext, c->advs,
@@ -886,5 +890,499 @@ extern "C" int fsrl_last_timing(fsrl_ctx* c, double* out, int32_t n) {
     CHECK_ARG(c && out && n >= 4, "need room for 4 doubles");
     out[0] = c->t_process_ms; out[1] = c->t_learn_ms; out[2] = c->t_fwdbwd_ms; out[3] = (double)c->n_fwdbwd;
     if (n >= 5) out[4] = c->t_fwdbwd_raw_ms;
+    return 0;
+}
+
+// ====================================================================================== trust region
+// CPO / TRPO-Lagrangian: full-batch primitives on the device, the (tiny) flat-vector algebra of
+// conjugate gradients, the dual solve and the line search on the host in float32.
+struct TrState {
+    fsrl_tr_config cfg{};
+    bool ready = false;
+    int rows_pad = 0, n_tiles = 0;
+    float *A1 = nullptr, *A2 = nullptr, *D1 = nullptr, *D2 = nullptr, *DO = nullptr;      // [nets][rows_pad]
+    float *RA1 = nullptr, *RA2 = nullptr, *RD1 = nullptr, *RD2 = nullptr, *RDO = nullptr;  // [rows_pad]
+    float *statp = nullptr, *mu_old = nullptr, *Vdev = nullptr, *Out = nullptr, *rd = nullptr;
+    double* d_scal = nullptr;
+    size_t cap_rows = 0;
+    int64_t critic_t = 0;     // Adam step count of the critic optimiser
+    int na = 0;               // flat actor parameter count (API order)
+};
+static TrState* tr_of(fsrl_ctx* c) {
+    if (!c->tr) {
+        c->tr = new TrState();
+        for (int i = 0; i < 7; ++i) c->tr->na += c->tmap[i].n;   // the actor's 7 tensors
+    }
+    return c->tr;
+}
+
+static void tr_free(fsrl_ctx* c) {
+    TrState* t = c->tr;
+    if (!t) return;
+    for (float* p : {t->A1, t->A2, t->D1, t->D2, t->DO, t->RA1, t->RA2, t->RD1, t->RD2, t->RDO, t->statp,
+                     t->mu_old, t->Vdev, t->Out, t->rd})
+        if (p) (void)hipFree(p);
+    if (t->d_scal) (void)hipFree(t->d_scal);
+    delete t;
+    c->tr = nullptr;
+}
+
+extern "C" int64_t fsrl_actor_param_count(const fsrl_ctx* c) {
+    if (!c) return 0;
+    int64_t n = 0;
+    for (int i = 0; i < 7; ++i) n += c->tmap[i].n;
+    return n;
+}
+
+static int tr_alloc(fsrl_ctx* c, TrState* t, int64_t n) {
+    const int tiles = (int)((n + 15) / 16);
+    t->n_tiles = tiles; t->rows_pad = tiles * 16;
+    if ((size_t)t->rows_pad <= t->cap_rows) return 0;
+    HIPCHK(hipStreamSynchronize(c->compute));
+    for (float** p : {&t->A1, &t->A2, &t->D1, &t->D2, &t->DO, &t->RA1, &t->RA2, &t->RD1, &t->RD2, &t->RDO,
+                      &t->statp, &t->mu_old, &t->rd})
+        if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
+    const size_t rows = (size_t)t->rows_pad + 64, H = c->cfg.hidden, nn = c->md.n_nets;
+    HIPCHK(hipMalloc(&t->A1, nn * rows * H * 4)); HIPCHK(hipMalloc(&t->A2, nn * rows * H * 4));
+    HIPCHK(hipMalloc(&t->D1, nn * rows * H * 4)); HIPCHK(hipMalloc(&t->D2, nn * rows * H * 4));
+    HIPCHK(hipMalloc(&t->DO, nn * rows * FSRL_DOW * 4));
+    HIPCHK(hipMalloc(&t->RA1, rows * H * 4)); HIPCHK(hipMalloc(&t->RA2, rows * H * 4));
+    HIPCHK(hipMalloc(&t->RD1, rows * H * 4)); HIPCHK(hipMalloc(&t->RD2, rows * H * 4));
+    HIPCHK(hipMalloc(&t->RDO, rows * FSRL_DOW * 4));
+    HIPCHK(hipMalloc(&t->statp, (size_t)(tiles + 4) * nn * FB_NSTAT * 4));
+    HIPCHK(hipMalloc(&t->mu_old, rows * c->cfg.act_dim * 4));
+    HIPCHK(hipMalloc(&t->rd, rows * FSRL_RD * 4));
+    if (!t->Vdev) {
+        HIPCHK(hipMalloc(&t->Vdev, (size_t)c->n_dev * 4)); HIPCHK(hipMalloc(&t->Out, (size_t)c->n_dev * 4));
+        HIPCHK(hipMemset(t->Vdev, 0, (size_t)c->n_dev * 4)); HIPCHK(hipMemset(t->Out, 0, (size_t)c->n_dev * 4));
+        HIPCHK(hipMalloc(&t->d_scal, 64 * sizeof(double)));
+    }
+    t->cap_rows = (size_t)t->rows_pad;
+    return 0;
+}
+
+// flat ACTOR vector (API order) <-> device-layout vector
+static int actor_to_dev(fsrl_ctx* c, const float* host, float* dev) {
+    std::vector<float> tmp((size_t)c->md.net[0].end, 0.0f);
+    for (int i = 0; i < 7; ++i) memcpy(&tmp[c->tmap[i].dev_off], host + c->tmap[i].api_off, (size_t)c->tmap[i].n * 4);
+    HIPCHK(hipStreamSynchronize(c->compute));
+    HIPCHK(hipMemcpy(dev, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+static int actor_from_dev(fsrl_ctx* c, const float* dev, float* host) {
+    std::vector<float> tmp((size_t)c->md.net[0].end);
+    HIPCHK(hipStreamSynchronize(c->compute));
+    HIPCHK(hipMemcpy(tmp.data(), dev, tmp.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 7; ++i) memcpy(host + c->tmap[i].api_off, &tmp[c->tmap[i].dev_off], (size_t)c->tmap[i].n * 4);
+    return 0;
+}
+
+static int tr_refresh_old(fsrl_ctx* c, TrState* t) {
+    // mean_old / std_old := current policy (TRPO recomputes old_dist at theta, trpo_lag.py:189-190)
+    InferArgs ia{};
+    ia.obs = c->b.obs; ia.obs_next = c->b.obs; ia.act = c->b.act; ia.flags = c->b.flags; ia.values = nullptr;
+    ia.vnext = nullptr; ia.logp_old = nullptr; ia.mu_out = t->mu_old; ia.N = (int)c->N; ia.C = 0;
+    ia.max_action = c->cfg.max_action;
+    int rc = launch_infer(c, ia, 1, c->compute);
+    if (rc) return rc;
+    FbRowArgs ra{};
+    ra.act = c->b.act; ra.advs = c->advs; ra.rets = c->rets; ra.logp_old = c->logp_old; ra.mean_old = t->mu_old;
+    ra.sigma = c->P + c->md.net[0].sigma; ra.rd = t->rd; ra.N = (int)c->N; ra.C = c->cfg.n_critics; ra.Da = c->cfg.act_dim;
+    hipLaunchKernelGGL(fb_rowdata_kernel, dim3(512), dim3(256), 0, c->compute, ra);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int fsrl_tr_begin(fsrl_ctx* c, const fsrl_tr_config* cfg, int64_t* n_out) {
+    CHECK_ARG(c && cfg, "null argument");
+    CHECK_ARG(c->cfg.n_critics == 2, "CPO / TRPO-Lag need a reward and one cost critic");
+    TrState* t = tr_of(c);
+    t->cfg = *cfg;
+    // reuse the PPO begin for sample(0) + V(obs), V(obs_next), GAE, logp_old (batch_size irrelevant)
+    double zero = 0.0;
+    int64_t n = 0;
+    int rc = fsrl_ppo_begin(c, &zero, 1.0, 1 << 20, &n);
+    if (rc) return rc;
+    c->in_update = false;
+    if (n_out) *n_out = n;
+    t->ready = false;
+    if (n == 0) return 0;
+    rc = tr_alloc(c, t, n);
+    if (rc) return rc;
+    if (cfg->norm_adv) {
+        hipLaunchKernelGGL(fb_advnorm_kernel, dim3(c->cfg.n_critics), dim3(1024), 0, c->compute, c->advs, (int)n);
+        HIPCHK(hipGetLastError());
+    }
+    rc = tr_refresh_old(c, t);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->compute));
+    t->ready = true;
+    return 0;
+}
+
+static int tr_stats(fsrl_ctx* c, TrState* t, int ny, double* out) {
+    hipLaunchKernelGGL(fb_reduce_stats_kernel, dim3(ny * FB_NSTAT), dim3(256), 0, c->compute, t->statp, t->n_tiles,
+                       ny, t->d_scal);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, t->d_scal, (size_t)ny * FB_NSTAT * sizeof(double), hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    return 0;
+}
+
+static int tr_tile(fsrl_ctx* c, TrState* t, int mode, int net0, int ny, float cr, float cc) {
+    FbArgs a{};
+    a.obs = c->b.obs; a.rd = t->rd; a.A1 = t->A1; a.A2 = t->A2; a.D1 = t->D1; a.D2 = t->D2; a.DO = t->DO;
+    a.statp = t->statp; a.N = (int)c->N; a.rows_pad = t->rows_pad; a.mode = mode; a.net0 = net0; a.cr = cr; a.cc = cc;
+    a.max_action = c->cfg.max_action;
+    return dispatch_H(c->cfg.hidden, [&](auto hc) {
+        constexpr int H = decltype(hc)::value;
+        hipLaunchKernelGGL(fb_tile_kernel<H>, dim3(t->n_tiles, ny), dim3(4 * H), 0, c->compute, c->P, c->md, a);
+        HIPCHK(hipGetLastError());
+        return 0;
+    });
+}
+
+static int tr_wgrad_plain(fsrl_ctx* c, TrState* t, int net0, int ny, float* out) {
+    FbWgradArgs wa{};
+    const size_t H = c->cfg.hidden;
+    for (int y = 0; y < ny; ++y) {
+        const size_t nb = (size_t)y * t->rows_pad;
+        FbWgradNet& wn = wa.nets[y];
+        wn.w2_ya = t->D2 + nb * H; wn.w2_xa = t->A1 + nb * H; wn.w2_yb = nullptr; wn.w2_xb = nullptr;
+        wn.w1_y = t->D1 + nb * H;
+        wn.w3_xa = t->A2 + nb * H; wn.w3_ya = t->DO + nb * FSRL_DOW; wn.w3_xb = nullptr; wn.w3_yb = nullptr;
+        wn.b1_src = t->D1 + nb * H; wn.b2_src = t->D2 + nb * H; wn.do_src = t->DO + nb * FSRL_DOW;
+        wn.net = net0 + y;
+    }
+    wa.obs = c->b.obs; wa.out = out; wa.rows = t->rows_pad; wa.N = (int)c->N;
+    return dispatch_H(c->cfg.hidden, [&](auto hc) {
+        constexpr int HH = decltype(hc)::value;
+        constexpr int NB = (HH / 32) * (HH / 32) + HH / 32 + 1;
+        hipLaunchKernelGGL(fb_wgrad_kernel<HH>, dim3(NB, ny), dim3(1024), 0, c->compute, c->md, wa);
+        HIPCHK(hipGetLastError());
+        return 0;
+    });
+}
+
+// gradient of a scalar actor objective; returns the flat ACTOR gradient and the 8 batch means
+static int tr_actor_grad(fsrl_ctx* c, TrState* t, int mode, float cr, float cc, float* g_out, double* means8) {
+    int rc = tr_tile(c, t, mode, 0, 1, cr, cc);
+    if (rc) return rc;
+    rc = tr_wgrad_plain(c, t, 0, 1, t->Out);
+    if (rc) return rc;
+    if (means8) {
+        rc = tr_stats(c, t, 1, means8);
+        if (rc) return rc;
+        for (int k = 0; k < FB_NSTAT; ++k) means8[k] /= (double)c->N;
+    }
+    return actor_from_dev(c, t->Out, g_out);
+}
+
+static int tr_eval_means(fsrl_ctx* c, TrState* t, double* means8) {
+    int rc = tr_tile(c, t, FB_MODE_EVAL, 0, 1, 0.f, 0.f);
+    if (rc) return rc;
+    rc = tr_stats(c, t, 1, means8);
+    if (rc) return rc;
+    for (int k = 0; k < FB_NSTAT; ++k) means8[k] /= (double)c->N;
+    return 0;
+}
+
+static int tr_hvp(fsrl_ctx* c, TrState* t, const float* v, float* out) {
+    int rc = actor_to_dev(c, v, t->Vdev);
+    if (rc) return rc;
+    HvpArgs ha{};
+    ha.obs = c->b.obs; ha.rd = t->rd; ha.V = t->Vdev; ha.A1 = t->A1; ha.RA1 = t->RA1; ha.A2 = t->A2; ha.RA2 = t->RA2;
+    ha.D2 = t->D2; ha.RD2 = t->RD2; ha.RD1 = t->RD1; ha.DO = t->DO; ha.RDO = t->RDO; ha.N = (int)c->N;
+    ha.rows_pad = t->rows_pad; ha.max_action = c->cfg.max_action;
+    rc = dispatch_H(c->cfg.hidden, [&](auto hc) {
+        constexpr int H = decltype(hc)::value;
+        hipLaunchKernelGGL(fb_hvp_tile_kernel<H>, dim3(t->n_tiles), dim3(4 * H), 0, c->compute, c->P, c->md, ha);
+        HIPCHK(hipGetLastError());
+        return 0;
+    });
+    if (rc) return rc;
+    FbWgradArgs wa{};
+    FbWgradNet& wn = wa.nets[0];
+    wn.w2_ya = t->RD2; wn.w2_xa = t->A1; wn.w2_yb = t->D2; wn.w2_xb = t->RA1;     // R{dW2} = R{dz2}^T h1 + dz2^T R{h1}
+    wn.w1_y = t->RD1;                                                             // R{dW1} = R{dz1}^T x
+    wn.w3_xa = t->A2; wn.w3_ya = t->RDO; wn.w3_xb = t->RA2; wn.w3_yb = t->DO;     // R{dW3} = R{dout}^T h2 + dout^T R{h2}
+    wn.b1_src = t->RD1; wn.b2_src = t->RD2; wn.do_src = t->RDO; wn.net = 0;
+    wa.obs = c->b.obs; wa.out = t->Out; wa.rows = t->rows_pad; wa.N = (int)c->N;
+    rc = dispatch_H(c->cfg.hidden, [&](auto hc) {
+        constexpr int HH = decltype(hc)::value;
+        constexpr int NB = (HH / 32) * (HH / 32) + HH / 32 + 1;
+        hipLaunchKernelGGL(fb_wgrad_kernel<HH>, dim3(NB, 1), dim3(1024), 0, c->compute, c->md, wa);
+        HIPCHK(hipGetLastError());
+        return 0;
+    });
+    if (rc) return rc;
+    return actor_from_dev(c, t->Out, out);
+}
+
+extern "C" int fsrl_tr_grad(fsrl_ctx* c, int32_t which, float* out, int64_t n) {
+    CHECK_ARG(c && out, "null argument");
+    TrState* t = tr_of(c);
+    if (!t->ready) return fail(FSRL_ESTATE, "fsrl_tr_grad before fsrl_tr_begin");
+    CHECK_ARG(n == t->na, "expected %d actor parameters", t->na);
+    HIPCHK(hipSetDevice(c->device));
+    if (which == 0) return tr_actor_grad(c, t, FB_MODE_SUR, 1.0f, 0.0f, out, nullptr);
+    if (which == 1) return tr_actor_grad(c, t, FB_MODE_SUR, 0.0f, -1.0f, out, nullptr);
+    if (which == 2) return tr_actor_grad(c, t, FB_MODE_KL, 0.0f, 0.0f, out, nullptr);
+    return fail(FSRL_EINVAL, "which must be 0, 1 or 2");
+}
+extern "C" int fsrl_tr_hvp(fsrl_ctx* c, const float* v, float* out, int64_t n) {
+    CHECK_ARG(c && v && out, "null argument");
+    TrState* t = tr_of(c);
+    if (!t->ready) return fail(FSRL_ESTATE, "fsrl_tr_hvp before fsrl_tr_begin");
+    CHECK_ARG(n == t->na, "expected %d actor parameters", t->na);
+    HIPCHK(hipSetDevice(c->device));
+    return tr_hvp(c, t, v, out);
+}
+extern "C" int fsrl_tr_eval(fsrl_ctx* c, double* stats8) {
+    CHECK_ARG(c && stats8, "null argument");
+    TrState* t = tr_of(c);
+    if (!t->ready) return fail(FSRL_ESTATE, "fsrl_tr_eval before fsrl_tr_begin");
+    HIPCHK(hipSetDevice(c->device));
+    return tr_eval_means(c, t, stats8);
+}
+
+// ---- host float32 vector algebra (sizes ~7e4: microseconds)
+static float vdot(const std::vector<float>& a, const std::vector<float>& b) {
+    float s = 0.0f;
+    for (size_t i = 0; i < a.size(); ++i) s += a[i] * b[i];
+    return s;
+}
+
+// x = H^-1 g by conjugate gradients with damped HVPs (cpo.py:184-204 / trpo_lag.py:261-283)
+static int tr_cg(fsrl_ctx* c, TrState* t, const std::vector<float>& g, float damping, int nsteps, float tol,
+                 std::vector<float>& x) {
+    const size_t n = g.size();
+    x.assign(n, 0.0f);
+    std::vector<float> r = g, p = g, z(n);
+    float rs_old = vdot(r, r);
+    for (int it = 0; it < nsteps; ++it) {
+        int rc = tr_hvp(c, t, p.data(), z.data());
+        if (rc) return rc;
+        for (size_t i = 0; i < n; ++i) z[i] += p[i] * damping;
+        const float alpha = rs_old / vdot(p, z);
+        for (size_t i = 0; i < n; ++i) { x[i] += alpha * p[i]; r[i] -= alpha * z[i]; }
+        const float rs_new = vdot(r, r);
+        if (rs_new < tol) break;
+        const float beta = rs_new / rs_old;
+        for (size_t i = 0; i < n; ++i) p[i] = r[i] + beta * p[i];
+        rs_old = rs_new;
+    }
+    return 0;
+}
+
+static int tr_mvp(fsrl_ctx* c, TrState* t, const std::vector<float>& v, float damping, std::vector<float>& out) {
+    out.resize(v.size());
+    int rc = tr_hvp(c, t, v.data(), out.data());
+    if (rc) return rc;
+    for (size_t i = 0; i < v.size(); ++i) out[i] += v[i] * damping;
+    return 0;
+}
+
+static int actor_get(fsrl_ctx* c, std::vector<float>& th) {
+    th.resize((size_t)fsrl_actor_param_count(c));
+    return actor_from_dev(c, c->P, th.data());
+}
+static int actor_set(fsrl_ctx* c, const std::vector<float>& th) { return actor_to_dev(c, th.data(), c->P); }
+
+// critic regression: `iters` Adam steps on all critics (full batch).  vf_out[C] = last step's losses.
+static int tr_critic_steps(fsrl_ctx* c, TrState* t, int iters, float l2, float* vf_out) {
+    const int C = c->cfg.n_critics;
+    const int begin = c->md.net[1].begin, end = c->md.net[C].end;
+    for (int it = 0; it < iters; ++it) {
+        int rc = tr_tile(c, t, FB_MODE_VF, 1, C, 0.f, 0.f);
+        if (rc) return rc;
+        rc = tr_wgrad_plain(c, t, 1, C, c->G);
+        if (rc) return rc;
+        if (it == iters - 1) {
+            double st[FSRL_MAX_CRITICS * FB_NSTAT];
+            rc = tr_stats(c, t, C, st);
+            if (rc) return rc;
+            for (int k = 0; k < C; ++k) {
+                float vf = (float)(st[k * FB_NSTAT] / (double)c->N);
+                if (l2 > 0.0f) {   // + l2 * sum(theta^2) over the critic's parameters, pre-update
+                    hipLaunchKernelGGL(sumsq_range_kernel, dim3(1), dim3(256), 0, c->compute, c->P,
+                                       c->md.net[1 + k].begin, c->md.net[1 + k].end, t->d_scal + 40);
+                    double ss = 0;
+                    HIPCHK(hipMemcpyAsync(&ss, t->d_scal + 40, sizeof(double), hipMemcpyDeviceToHost, c->compute));
+                    HIPCHK(hipStreamSynchronize(c->compute));
+                    vf += (float)ss * l2;
+                }
+                vf_out[k] = vf;
+            }
+        }
+        t->critic_t += 1;
+        const double b1 = c->cfg.beta1, b2 = c->cfg.beta2;
+        const double bc1 = 1.0 - std::pow(b1, (double)t->critic_t), bc2 = 1.0 - std::pow(b2, (double)t->critic_t);
+        hipLaunchKernelGGL(adam_range_kernel, dim3((end - begin + 255) / 256), dim3(256), 0, c->compute, c->P, c->M,
+                           c->V, c->G, begin, end, l2, (float)(1.0 - b1), c->cfg.beta2, (float)(1.0 - b2),
+                           (float)((double)t->cfg.critic_lr / bc1), (float)std::sqrt(bc2), c->cfg.adam_eps);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
+static float actor_entropy(fsrl_ctx* c, const std::vector<float>& th) {
+    float e = 0.0f;   // sum_d (0.5 + 0.5 log(2 pi) + log sigma_d); sigma_param is the first tensor
+    for (int d = 0; d < c->cfg.act_dim; ++d) e += 1.4189385332046727f + std::log(std::exp(th[d]));
+    return e;
+}
+
+extern "C" int fsrl_cpo_learn(fsrl_ctx* c, double ave_cost_return, int32_t repeat, float* stats_out) {
+    CHECK_ARG(c && stats_out, "null argument");
+    TrState* t = tr_of(c);
+    if (!t->ready) return fail(FSRL_ESTATE, "fsrl_cpo_learn before fsrl_tr_begin");
+    HIPCHK(hipSetDevice(c->device));
+    const fsrl_tr_config& k = t->cfg;
+    const float EPS = 1e-8f, delta = k.target_kl;
+    const size_t n = (size_t)t->na;
+    for (int rep = 0; rep < repeat; ++rep) {
+        float* st = stats_out + (size_t)rep * FSRL_CPO_NSTATS;
+        int rc = tr_critic_steps(c, t, k.optim_critic_iters, k.l2_reg, st + 14);
+        if (rc) return rc;
+        st[16] = st[14] + st[15];
+        // ---- objective, cost surrogate, KL and their gradients (cpo.py:238-254)
+        std::vector<float> g(n), b(n), theta0;
+        double m[FB_NSTAT];
+        rc = tr_actor_grad(c, t, FB_MODE_SUR, 1.0f, 0.0f, g.data(), m);
+        if (rc) return rc;
+        rc = tr_actor_grad(c, t, FB_MODE_SUR, 0.0f, -1.0f, b.data(), nullptr);
+        if (rc) return rc;
+        rc = actor_get(c, theta0);
+        if (rc) return rc;
+        const float objective = (float)m[0];
+        const float cost_sur = ((float)ave_cost_return + (float)m[1]) - (float)m[5];
+        const float kl = (float)m[2];
+        const float ent = actor_entropy(c, theta0);
+        std::vector<float> Hg, Hb, approx_g, approx_b;
+        rc = tr_cg(c, t, g, k.damping, k.cg_iters, 1e-8f, Hg);
+        if (rc) return rc;
+        rc = tr_mvp(c, t, Hg, k.damping, approx_g);
+        if (rc) return rc;
+        const float c_value = cost_sur - (float)k.cost_limit;
+        float s_q, s_r = 0.f, s_s = 0.f, A = 0.f, B = 0.f;
+        int ocase;
+        if (vdot(b, b) <= EPS && c_value < 0) {
+            Hb.assign(n, 0.0f);
+            s_q = vdot(approx_g, Hg);
+            ocase = 4;
+        } else {
+            rc = tr_cg(c, t, b, k.damping, k.cg_iters, 1e-8f, Hb);
+            if (rc) return rc;
+            rc = tr_mvp(c, t, Hb, k.damping, approx_b);
+            if (rc) return rc;
+            s_q = vdot(approx_g, Hg); s_r = vdot(approx_g, Hb); s_s = vdot(approx_b, Hb);
+            A = s_q - s_r * s_r / s_s;
+            B = 2.0f * delta - c_value * c_value / s_s;
+            if (c_value < 0 && B < 0) ocase = 3;
+            else if (c_value < 0 && B >= 0) ocase = 2;
+            else if (c_value >= 0 && B >= 0) ocase = 1;
+            else ocase = 0;
+        }
+        float lam, nu;
+        if (ocase == 3 || ocase == 4) {
+            lam = std::sqrt(s_q / (2.0f * delta));
+            nu = 0.0f;
+        } else if (ocase == 1 || ocase == 2) {
+            const float rc_ = s_r / c_value, inf = INFINITY;
+            float LA[2] = {0.0f, rc_}, LB[2] = {rc_, inf};
+            if (!(c_value < 0)) { std::swap(LA[0], LB[0]); std::swap(LA[1], LB[1]); }
+            auto proj = [](float x, const float* L) { return std::max(L[0], std::min(L[1], x)); };
+            const float lam_a = proj(std::sqrt(A / B), LA), lam_b = proj(std::sqrt(s_q / (2.0f * delta)), LB);
+            auto f_a = [&](float l) { return -0.5f * (A / (l + EPS) + B * l) - s_r * c_value / (s_s + EPS); };
+            auto f_b = [&](float l) { return -0.5f * (s_q / (l + EPS) + 2.0f * delta * l); };
+            lam = (f_a(lam_a) >= f_b(lam_b)) ? lam_a : lam_b;
+            nu = std::max(0.0f, lam * c_value - s_r) / (s_s + EPS);
+        } else {
+            nu = std::sqrt(2.0f * delta / (s_s + EPS));
+            lam = 0.0f;
+        }
+        // ---- line search (cpo.py:306-333); on failure the LAST tried theta stays in place
+        std::vector<float> dir(n);
+        for (size_t i = 0; i < n; ++i)
+            dir[i] = (ocase > 0) ? (1.0f / (lam + EPS)) * (Hg[i] + nu * Hb[i]) : nu * Hb[i];
+        const float nrm = std::sqrt(vdot(dir, dir));
+        for (size_t i = 0; i < n; ++i) dir[i] /= nrm;
+        double beta = 1.0;
+        if (!std::isnan(lam)) {
+            std::vector<float> th(n);
+            for (int bt = 0; bt < k.max_backtracks; ++bt) {
+                const float bf = (float)beta;
+                for (size_t i = 0; i < n; ++i) th[i] = bf * dir[i] + theta0[i];
+                rc = actor_set(c, th);
+                if (rc) return rc;
+                double e8[FB_NSTAT];
+                rc = tr_eval_means(c, t, e8);
+                if (rc) return rc;
+                const float new_kl = (float)e8[2], new_obj = (float)e8[0];
+                const float new_cs = ((float)ave_cost_return + (float)e8[1]) - (float)e8[5];
+                const bool ok = ((double)new_kl <= (double)delta) && (ocase > 1 ? new_obj > objective : true) &&
+                                ((double)(new_cs - cost_sur) <= std::max(-(double)c_value, 0.0));
+                if (ok) break;
+                beta *= (double)k.backtrack_coeff;
+            }
+        }
+        st[0] = kl; st[1] = ent; st[2] = objective; st[3] = cost_sur; st[4] = A; st[5] = B; st[6] = c_value;
+        st[7] = s_q; st[8] = s_r; st[9] = s_s; st[10] = lam; st[11] = nu; st[12] = (float)ocase; st[13] = (float)beta;
+    }
+    return 0;
+}
+
+extern "C" int fsrl_trpo_learn(fsrl_ctx* c, const double* lagrangians, double rescaling, int32_t repeat,
+                               float* stats_out) {
+    CHECK_ARG(c && stats_out, "null argument");
+    TrState* t = tr_of(c);
+    if (!t->ready) return fail(FSRL_ESTATE, "fsrl_trpo_learn before fsrl_tr_begin");
+    HIPCHK(hipSetDevice(c->device));
+    const fsrl_tr_config& k = t->cfg;
+    const size_t n = (size_t)t->na;
+    const float lam0 = (c->cfg.use_lagrangian && lagrangians) ? (float)lagrangians[0] : 0.0f;
+    const float resc = (float)rescaling, delta = k.target_kl;
+    for (int rep = 0; rep < repeat; ++rep) {
+        float* st = stats_out + (size_t)rep * FSRL_TRPO_NSTATS;
+        int rc = tr_refresh_old(c, t);     // old_dist = pi_theta (detached), trpo_lag.py:189-190
+        if (rc) return rc;
+        std::vector<float> g(n), theta0, x, dir(n), Hd;
+        double m[FB_NSTAT];
+        // loss_actor = rescaling * ( -mean(ratio A_r) + lambda * mean(ratio A_c) )
+        rc = tr_actor_grad(c, t, FB_MODE_SUR, -resc, resc * lam0, g.data(), m);
+        if (rc) return rc;
+        rc = actor_get(c, theta0);
+        if (rc) return rc;
+        const float loss_rew = -(float)m[0];
+        const float loss_safety = c->cfg.use_lagrangian ? (float)m[1] * lam0 : 0.0f;
+        const float loss_actor = resc * (loss_rew + loss_safety);
+        const float ent = actor_entropy(c, theta0);
+        rc = tr_cg(c, t, g, k.damping, k.cg_iters, 1e-10f, x);
+        if (rc) return rc;
+        for (size_t i = 0; i < n; ++i) dir[i] = -x[i];
+        rc = tr_mvp(c, t, dir, k.damping, Hd);
+        if (rc) return rc;
+        float step = std::sqrt(2.0f * delta / vdot(dir, Hd));
+        float kl = 0.0f;
+        std::vector<float> th(n);
+        for (int i = 0; i < k.max_backtracks; ++i) {
+            for (size_t j = 0; j < n; ++j) th[j] = theta0[j] + step * dir[j];
+            rc = actor_set(c, th);
+            if (rc) return rc;
+            double e8[FB_NSTAT];
+            rc = tr_eval_means(c, t, e8);
+            if (rc) return rc;
+            kl = (float)e8[2];
+            const float loss_new = resc * (-(float)e8[0] + (c->cfg.use_lagrangian ? (float)e8[1] * lam0 : 0.0f));
+            if ((double)kl < (double)delta && loss_new < loss_actor) break;
+            else if (i < k.max_backtracks - 1) step *= k.backtrack_coeff;
+            else step = 0.0f;   // total failure: the last tried parameters stay (trpo_lag.py:225-227)
+        }
+        float vf[FSRL_MAX_CRITICS] = {0, 0, 0, 0};
+        rc = tr_critic_steps(c, t, k.optim_critic_iters, 0.0f, vf);
+        if (rc) return rc;
+        st[0] = resc; st[1] = lam0; st[2] = loss_safety; st[3] = loss_rew; st[4] = loss_actor;
+        st[5] = vf[0]; st[6] = vf[1]; st[7] = vf[0] + vf[1]; st[8] = kl; st[9] = step; st[10] = ent;
+    }
     return 0;
 }

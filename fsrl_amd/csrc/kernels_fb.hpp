@@ -1,0 +1,735 @@
+// kernels_fb.hpp -- full-batch kernels of the trust-region updates (CPO, TRPO-Lagrangian):
+// surrogate / KL / critic-regression gradients, line-search evaluation, and the exact
+// Hessian-vector product of the mean KL by an analytic R-op through the tanh-mean MLP.
+//
+// Reference: fsrl/policy/cpo.py:147-162 (critics_loss), :177-182 (_MVP), :234-254 (objective,
+// cost surrogate, kl and their flat gradients), :306-333 (line-search evaluations);
+// fsrl/policy/trpo_lag.py:148-171, :189-213, :234-239, :253-259.
+//
+// Same tile decomposition as the PPO step kernel (one workgroup = one 16-row tile of one
+// network, 4*H threads, MFMA 16x16x4 fp32), but rows are the whole batch in store order, the
+// grid is ceil(N/16) tiles, and the weight-gradient kernel loops over all N rows.
+#pragma once
+#include "kernels_mlp.hpp"
+
+#define FB_MODE_VF 0     // critics: d/dtheta mean((ret - V)^2)
+#define FB_MODE_SUR 1    // actor: d/dtheta mean((cr*A_r + cc*A_c) * ratio)
+#define FB_MODE_KL 2     // actor: d/dtheta mean KL(N(mu_old, sigma_old) || N(mu, sigma))
+#define FB_MODE_EVAL 3   // actor: statistics only (line search), nothing stored
+#define FB_NSTAT 8
+
+struct FbArgs {
+    const float* obs;     // [N][Do]  batch, store order
+    const float* rd;      // [N][FSRL_RD] act | logp_old | adv_n | ret | mean_old | std_old
+    float* A1; float* A2; float* D1; float* D2; float* DO;   // [nets][n_rows_pad][...]
+    float* statp;         // [n_tiles][nets][FB_NSTAT]
+    int N, rows_pad;      // rows_pad = n_tiles*16 (stride of the side buffers per net)
+    int mode, net0;       // first network handled (0 = actor, 1 = first critic)
+    float cr, cc;         // surrogate coefficients (FB_MODE_SUR)
+    float max_action;
+};
+
+// ------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict__ P,
+                                                       const ModelDesc md, const FbArgs a) {
+    __shared__ TileSmem<H> sm;
+    constexpr int LD = TileSmem<H>::LD;
+    constexpr int NT = TileGeom<H>::NT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.x, net = a.net0 + blockIdx.y;
+    const int row0 = tile * 16;
+    const NetOff no = md.net[net];
+    const int Do = md.Do, Da = md.Da;
+    const int n_valid = min(16, a.N - row0);
+    const float invN = 1.0f / (float)a.N;
+
+    TileStage<H> stg;
+    stg.issue(P, no, Do, Da, a.obs + (size_t)row0 * Do, a.rd + (size_t)row0 * FSRL_RD, n_valid, tid);
+    FwdW2Frag<H> wf;
+    wf.load(P + no.W2, wave, lane);
+    for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
+    stg.commit(sm, no, Do, tid);
+    __syncthreads();
+    tile_forward<H>(sm, P, no, Do, tid, wf);
+    const bool backward = (a.mode != FB_MODE_EVAL);
+
+    float wb[H / 16][4];
+    if (backward) {
+        const float* __restrict__ W2c = P + no.W2 + wave * 16 + li;
+#pragma unroll
+        for (int jc = 0; jc < H / 16; ++jc) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wb[jc][s] = W2c[(size_t)(16 * jc + 4 * q + s) * H];
+        }
+    }
+
+    // ---- head: thread (row i = tid>>4, dim d = tid&15)
+    if (tid < 256) {
+        const int i = tid >> 4, d = tid & 15;
+        const bool valid = i < n_valid;
+        const float* rd = &sm.rd[i * FSRL_RD];
+        float st[FB_NSTAT];
+#pragma unroll
+        for (int k = 0; k < FB_NSTAT; ++k) st[k] = 0.0f;
+        if (net == 0) {
+            float th = 0.f, var = 1.f, df = 0.f, lp = 0.f, klp = 0.f, dmu = 0.f, so2 = 0.f;
+            if (d < Da) {
+                th = tanhf(sm.out[i * FSRL_MAX_ACT + d]);
+                const float sig = expf(sm.sig[d]);
+                var = sig * sig;
+                const float mu = a.max_action * th;
+                df = rd[d] - mu;
+                lp = -(df * df) / (2.0f * var) - logf(sig) - LOG_SQRT_2PI;
+                // KL(old || new), torch.distributions.kl._kl_normal_normal
+                const float so = rd[FSRL_RD_STD + d];
+                dmu = mu - rd[FSRL_RD_MEAN + d];
+                so2 = so * so;
+                const float var_ratio = (so / sig) * (so / sig);
+                const float t1 = (dmu / sig) * (dmu / sig);
+                klp = 0.5f * (var_ratio + t1 - 1.0f - logf(var_ratio));
+            }
+            float logp = 0.0f, klrow = 0.0f;
+            for (int dd = 0; dd < Da; ++dd) {
+                logp += __shfl(lp, (lane & 48) + dd, 64);
+                klrow += __shfl(klp, (lane & 48) + dd, 64);
+            }
+            const float lpo = rd[FSRL_RD_LOGP];
+            const float ratio = expf(logp - lpo);
+            const float ar = rd[FSRL_RD_ADV], ac = rd[FSRL_RD_ADV + 1];
+            if (valid && d < Da) {
+                if (a.mode == FB_MODE_SUR) {
+                    const float dL_dlogp = (a.cr * ar + a.cc * ac) * ratio * invN;
+                    sm.dout[i * FSRL_DOW + d] = dL_dlogp * (df / var) * a.max_action * (1.0f - th * th);
+                    sm.dout[i * FSRL_DOW + 16 + d] = dL_dlogp * (df * df / var - 1.0f);
+                } else if (a.mode == FB_MODE_KL) {
+                    sm.dout[i * FSRL_DOW + d] = (dmu / var) * invN * a.max_action * (1.0f - th * th);
+                    sm.dout[i * FSRL_DOW + 16 + d] = (1.0f - (so2 + dmu * dmu) / var) * invN;
+                }
+            }
+            if (valid) {
+                st[0] = ratio * ar; st[1] = ratio * ac; st[2] = klrow; st[3] = lpo - logp;
+                st[4] = ar; st[5] = ac;
+            }
+        } else {
+            const int c = net - 1;
+            const float dd = rd[FSRL_RD_RET + c] - sm.out[i * FSRL_MAX_ACT];
+            if (valid) {
+                if (d == 0) sm.dout[i * FSRL_DOW] = -2.0f * dd * invN;
+                st[0] = dd * dd;
+            }
+        }
+        if (d == 0) {
+#pragma unroll
+            for (int k = 0; k < FB_NSTAT; ++k) sm.w1[i * FB_NSTAT + k] = st[k];   // w1 is free now
+        }
+    }
+    __syncthreads();
+    if (tid < FB_NSTAT) {   // rows summed in ascending order (fixed => deterministic)
+        float t = 0.0f;
+        for (int i = 0; i < 16; ++i) t += sm.w1[i * FB_NSTAT + tid];
+        a.statp[((size_t)tile * gridDim.y + blockIdx.y) * FB_NSTAT + tid] = t;
+    }
+    if (!backward) return;
+
+    const size_t nb = (size_t)blockIdx.y * a.rows_pad;
+    {   // spill relu(z1), relu(z2)
+        float* __restrict__ A1 = a.A1 + (nb + row0) * H;
+        float* __restrict__ A2 = a.A2 + (nb + row0) * H;
+        constexpr int H4 = H / 4;
+        for (int e = tid; e < 16 * H4; e += NT) {
+            const int i = e / H4, c4 = e - i * H4;
+            *reinterpret_cast<f32x4*>(&A1[(size_t)i * H + 4 * c4]) =
+                *reinterpret_cast<const f32x4*>(&sm.h1[i * LD + 4 * c4]);
+            *reinterpret_cast<f32x4*>(&A2[(size_t)i * H + 4 * c4]) =
+                *reinterpret_cast<const f32x4*>(&sm.h2[i * LD + 4 * c4]);
+        }
+    }
+    {   // dz2 = (dout @ W3) * relu'(z2)
+        const int k = tid % H, rg = tid / H;
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int o = 0; o < no.out; ++o) {
+            const float w = sm.w3[o * H + k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = fmaf(sm.dout[(4 * rg + e) * FSRL_DOW + o], w, g[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * rg + e;
+            sm.d2[i * LD + k] = (sm.h2[i * LD + k] > 0.0f) ? g[e] : 0.0f;
+        }
+    }
+    __syncthreads();
+    {
+        float* __restrict__ D2 = a.D2 + (nb + row0) * H;
+        constexpr int H4 = H / 4;
+        for (int e = tid; e < 16 * H4; e += NT) {
+            const int i = e / H4, c4 = e - i * H4;
+            *reinterpret_cast<f32x4*>(&D2[(size_t)i * H + 4 * c4]) =
+                *reinterpret_cast<const f32x4*>(&sm.d2[i * LD + 4 * c4]);
+        }
+        float* __restrict__ DOb = a.DO + (nb + row0) * FSRL_DOW;
+        for (int e = tid; e < 16 * FSRL_DOW; e += NT) DOb[e] = sm.dout[e];
+    }
+    {   // dz1 = (dz2 @ W2) * relu'(z1)
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = &sm.d2[li * LD + 4 * q];
+#pragma unroll
+        for (int jc = 0; jc < H / 16; ++jc) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * jc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma_16x16x4(av[s], wb[jc][s], acc);
+        }
+        float* __restrict__ D1 = a.D1 + (nb + row0) * H;
+        const int col = wave * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * q + r;
+            D1[(size_t)i * H + col] = (sm.h1[i * LD + col] > 0.0f) ? acc[r] : 0.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Hessian-vector product of KLbar(theta) = mean_r KL(N(mu_old, sigma_old) || N(mu_theta, sigma_theta))
+// along the tangent V (same layout as the actor parameters), activation side.  R{.} denotes the
+// directional derivative along V (Pearlmutter).  Forward: z1,h1,z2,h2,out and R{h1},R{h2},R{out};
+// head: dout = dKLbar/dout, R{dout};  backward: dz2, R{dz2}, R{dz1}.  The weight-side products
+// (R{dW} = R{d}^T a + d^T R{a}) are done by fb_wgrad_kernel with two operand pairs.
+struct HvpArgs {
+    const float* obs; const float* rd;
+    const float* V;          // tangent, parameter layout (device offsets of net 0)
+    float* A1; float* RA1; float* A2; float* RA2; float* D2; float* RD2; float* RD1;
+    float* DO; float* RDO;   // [rows_pad][FSRL_DOW]
+    int N, rows_pad;
+    float max_action;
+};
+
+template <int H>
+struct HvpSmem {
+    static constexpr int LD = H + 4;
+    float xT[FSRL_MAX_OBS * 16];
+    float h1[16 * LD], rh1[16 * LD], h2[16 * LD], rh2[16 * LD], d2[16 * LD], rd2[16 * LD];
+    float out[16 * FSRL_MAX_ACT], rout[16 * FSRL_MAX_ACT];
+    float dout[16 * FSRL_DOW], rdout[16 * FSRL_DOW];
+    float rd[16 * FSRL_RD];
+};
+
+// acc += A[16 x H](LDS, leading dim LD) @ Wrows^T where lane (li,q) of wave w holds row
+// (w*16+li) of W, columns 16*kc + 4q..+3 (the FwdW2Frag layout)
+template <int H>
+__device__ __forceinline__ f32x4 mma_rows(const float* A, const FwdW2Frag<H>& wf, int li, int q, f32x4 acc) {
+    constexpr int LD = H + 4;
+    const float* arow = A + li * LD + 4 * q;
+#pragma unroll
+    for (int kc = 0; kc < H / 16; ++kc) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * kc);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma_16x16x4(av[s], wf.b[kc][s], acc);
+    }
+    return acc;
+}
+
+// acc += A[16 x H](LDS) @ W[:, wave's 16 columns]   (column-slice layout of the backward GEMM)
+template <int H>
+__device__ __forceinline__ f32x4 mma_cols(const float* A, const float* __restrict__ W, int wave, int li,
+                                          int q, f32x4 acc) {
+    constexpr int LD = H + 4;
+    const float* __restrict__ Wc = W + wave * 16 + li;
+    float wb[H / 16][4];
+#pragma unroll
+    for (int jc = 0; jc < H / 16; ++jc) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wb[jc][s] = Wc[(size_t)(16 * jc + 4 * q + s) * H];
+    }
+    const float* arow = A + li * LD + 4 * q;
+#pragma unroll
+    for (int jc = 0; jc < H / 16; ++jc) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * jc);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma_16x16x4(av[s], wb[jc][s], acc);
+    }
+    return acc;
+}
+
+template <int H>
+__global__ __launch_bounds__(4 * H) void fb_hvp_tile_kernel(const float* __restrict__ P,
+                                                           const ModelDesc md, const HvpArgs a) {
+    __shared__ HvpSmem<H> sm;
+    constexpr int LD = HvpSmem<H>::LD;
+    constexpr int NT = 4 * H;
+    constexpr int WAVES = H / 16;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * 16;
+    const NetOff no = md.net[0];
+    const float* __restrict__ V = a.V;
+    const int Do = md.Do, Da = md.Da;
+    const int n_valid = min(16, a.N - row0);
+    const float invN = 1.0f / (float)a.N;
+
+    for (int e = tid; e < 16 * Do; e += NT) {
+        const int i = e / Do, k = e - i * Do;
+        sm.xT[k * 16 + i] = (i < n_valid) ? a.obs[(size_t)row0 * Do + e] : 0.0f;
+    }
+    for (int e = tid; e < 16 * FSRL_RD; e += NT)
+        sm.rd[e] = (e / FSRL_RD < n_valid) ? a.rd[(size_t)row0 * FSRL_RD + e] : 0.0f;
+    for (int e = tid; e < 16 * FSRL_DOW; e += NT) { sm.dout[e] = 0.0f; sm.rdout[e] = 0.0f; }
+    FwdW2Frag<H> wf;
+    wf.load(P + no.W2, wave, lane);
+    __syncthreads();
+
+    // ---- layer 1 and its tangent; thread = (column j, 4 rows)
+    {
+        const int j = tid % H, rg = tid / H;
+        const float b = P[no.b1 + j], vb = V[no.b1 + j];
+        float acc[4] = {b, b, b, b}, racc[4] = {vb, vb, vb, vb};
+        const float* __restrict__ w = P + no.W1 + (size_t)j * Do;
+        const float* __restrict__ vw = V + no.W1 + (size_t)j * Do;
+        for (int k = 0; k < Do; ++k) {
+            const float wk = w[k], vk = vw[k];
+            const f32x4 x = *reinterpret_cast<const f32x4*>(&sm.xT[k * 16 + 4 * rg]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] = fmaf(x[e], wk, acc[e]); racc[e] = fmaf(x[e], vk, racc[e]); }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool on = acc[e] > 0.0f;
+            sm.h1[(4 * rg + e) * LD + j] = on ? acc[e] : 0.0f;
+            sm.rh1[(4 * rg + e) * LD + j] = on ? racc[e] : 0.0f;
+        }
+    }
+    __syncthreads();
+    // ---- layer 2:  z2 = W2 h1 + b2 ; R{z2} = W2 R{h1} + V2 h1 + vb2
+    {
+        f32x4 z = {0, 0, 0, 0}, rz = {0, 0, 0, 0};
+        z = mma_rows<H>(sm.h1, wf, li, q, z);
+        rz = mma_rows<H>(sm.rh1, wf, li, q, rz);
+        wf.load(V + no.W2, wave, lane);
+        rz = mma_rows<H>(sm.h1, wf, li, q, rz);
+        const int j = wave * 16 + li;
+        const float bias = P[no.b2 + j], vbias = V[no.b2 + j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float zz = z[r] + bias;
+            const bool on = zz > 0.0f;
+            sm.h2[(4 * q + r) * LD + j] = on ? zz : 0.0f;
+            sm.rh2[(4 * q + r) * LD + j] = on ? rz[r] + vbias : 0.0f;
+        }
+    }
+    __syncthreads();
+    // ---- head pre-activations: out = W3 h2 + b3 ; R{out} = W3 R{h2} + V3 h2 + vb3
+    for (int i = wave; i < 16; i += WAVES) {
+        for (int o = 0; o < Da; ++o) {
+            const float* __restrict__ w3 = P + no.W3 + (size_t)o * H;
+            const float* __restrict__ v3 = V + no.W3 + (size_t)o * H;
+            float s = 0.0f, rs = 0.0f;
+#pragma unroll
+            for (int k = lane; k < H; k += 64) {
+                const float h = sm.h2[i * LD + k];
+                s = fmaf(h, w3[k], s);
+                rs = fmaf(sm.rh2[i * LD + k], w3[k], rs);
+                rs = fmaf(h, v3[k], rs);
+            }
+            s = wave_sum(s);
+            rs = wave_sum(rs);
+            if (lane == 0) {
+                sm.out[i * FSRL_MAX_ACT + o] = s + P[no.b3 + o];
+                sm.rout[i * FSRL_MAX_ACT + o] = rs + V[no.b3 + o];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- KL head (per row, per action dim): dout, R{dout}, and the sigma_param rows
+    if (tid < 256) {
+        const int i = tid >> 4, d = tid & 15;
+        if (i < n_valid && d < Da) {
+            const float t = tanhf(sm.out[i * FSRL_MAX_ACT + d]);
+            const float ro = sm.rout[i * FSRL_MAX_ACT + d];
+            const float sp = P[no.sigma + d], rls = V[no.sigma + d];   // R{log sigma} = v_sigma
+            const float sig = expf(sp), var = sig * sig;
+            const float dt = a.max_action * (1.0f - t * t);            // dmu/dout
+            const float rmu = dt * ro;
+            const float dmu = a.max_action * t - sm.rd[i * FSRL_RD + FSRL_RD_MEAN + d];
+            const float so = sm.rd[i * FSRL_RD + FSRL_RD_STD + d], so2 = so * so;
+            const float gmu = dmu / var;                                // dKL/dmu
+            const float rgmu = rmu / var - 2.0f * gmu * rls;
+            const float rgls = -2.0f * dmu * rmu / var + 2.0f * (so2 + dmu * dmu) / var * rls;
+            const float rdt = a.max_action * (-2.0f * t) * (1.0f - t * t) * ro;   // R{dmu/dout}
+            sm.dout[i * FSRL_DOW + d] = invN * gmu * dt;
+            sm.rdout[i * FSRL_DOW + d] = invN * (rgmu * dt + gmu * rdt);
+            sm.dout[i * FSRL_DOW + 16 + d] = invN * (1.0f - (so2 + dmu * dmu) / var);
+            sm.rdout[i * FSRL_DOW + 16 + d] = invN * rgls;
+        }
+    }
+    __syncthreads();
+    // ---- dz2 = relu'(z2) (dout W3) ; R{dz2} = relu'(z2) (R{dout} W3 + dout V3)
+    {
+        const int k = tid % H, rg = tid / H;
+        float g[4] = {0, 0, 0, 0}, rg_[4] = {0, 0, 0, 0};
+        for (int o = 0; o < Da; ++o) {
+            const float w = P[no.W3 + (size_t)o * H + k], v = V[no.W3 + (size_t)o * H + k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dd = sm.dout[(4 * rg + e) * FSRL_DOW + o];
+                g[e] = fmaf(dd, w, g[e]);
+                rg_[e] = fmaf(sm.rdout[(4 * rg + e) * FSRL_DOW + o], w, rg_[e]);
+                rg_[e] = fmaf(dd, v, rg_[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * rg + e;
+            const bool on = sm.h2[i * LD + k] > 0.0f;
+            sm.d2[i * LD + k] = on ? g[e] : 0.0f;
+            sm.rd2[i * LD + k] = on ? rg_[e] : 0.0f;
+        }
+    }
+    __syncthreads();
+    // ---- R{dz1} = relu'(z1) (R{dz2} W2 + dz2 V2)
+    {
+        f32x4 acc = {0, 0, 0, 0};
+        acc = mma_cols<H>(sm.rd2, P + no.W2, wave, li, q, acc);
+        acc = mma_cols<H>(sm.d2, V + no.W2, wave, li, q, acc);
+        float* __restrict__ RD1 = a.RD1 + (size_t)row0 * H;
+        const int col = wave * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * q + r;
+            RD1[(size_t)i * H + col] = (sm.h1[i * LD + col] > 0.0f) ? acc[r] : 0.0f;
+        }
+    }
+    // ---- spill the operands of the weight-side products
+    {
+        constexpr int H4 = H / 4;
+        const size_t base = (size_t)row0 * H;
+        for (int e = tid; e < 16 * H4; e += NT) {
+            const int i = e / H4, c4 = e - i * H4;
+            const size_t o = base + (size_t)i * H + 4 * c4;
+            const int l = i * LD + 4 * c4;
+            *reinterpret_cast<f32x4*>(a.A1 + o) = *reinterpret_cast<const f32x4*>(&sm.h1[l]);
+            *reinterpret_cast<f32x4*>(a.RA1 + o) = *reinterpret_cast<const f32x4*>(&sm.rh1[l]);
+            *reinterpret_cast<f32x4*>(a.A2 + o) = *reinterpret_cast<const f32x4*>(&sm.h2[l]);
+            *reinterpret_cast<f32x4*>(a.RA2 + o) = *reinterpret_cast<const f32x4*>(&sm.rh2[l]);
+            *reinterpret_cast<f32x4*>(a.D2 + o) = *reinterpret_cast<const f32x4*>(&sm.d2[l]);
+            *reinterpret_cast<f32x4*>(a.RD2 + o) = *reinterpret_cast<const f32x4*>(&sm.rd2[l]);
+        }
+        for (int e = tid; e < 16 * FSRL_DOW; e += NT) {
+            a.DO[(size_t)row0 * FSRL_DOW + e] = sm.dout[e];
+            a.RDO[(size_t)row0 * FSRL_DOW + e] = sm.rdout[e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight-side reduction over ALL rows of the batch, one network per grid.y.  Every product is
+//   out[j][k] = sum_r ( Ya[r][j] * Xa[r][k]  +  Yb[r][j] * Xb[r][k] )      (pair b optional)
+// grid.x = NT2 (dW2 32x32 tiles) + NA (32-column aux blocks: dW1, dW3^T, db1, db2) + 1 (db3, dsigma)
+struct FbWgradNet {
+    const float* w2_ya; const float* w2_xa; const float* w2_yb; const float* w2_xb;   // [rows][H]
+    const float* w1_y;                           // [rows][H]   (x = observations)
+    const float* w3_xa; const float* w3_ya;      // A2-like [rows][H], DO-like [rows][DOW]
+    const float* w3_xb; const float* w3_yb;      // optional second pair
+    const float* b1_src; const float* b2_src;    // column sums -> db1, db2
+    const float* do_src;                         // column sums -> db3 / dsigma
+    int net;                                     // which network's slice of `out` is written
+};
+struct FbWgradArgs {
+    FbWgradNet nets[FSRL_MAX_NETS];
+    const float* obs;    // [N][Do]
+    float* out;          // flat, parameter layout
+    int rows;            // padded row count (multiple of 16; rows beyond N hold zeros in Y)
+    int N;
+};
+
+template <int H>
+__global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, const FbWgradArgs wa) {
+    constexpr int TPD = H / 32;
+    constexpr int NT2 = TPD * TPD;
+    constexpr int NA = H / 32;
+    __shared__ float red[1024 * 9];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const FbWgradNet wn = wa.nets[blockIdx.y];
+    const NetOff no = md.net[wn.net];
+    const int rb = blockIdx.x;
+    const int KS = wa.rows >> 2;            // k-steps of 4 rows
+    const int c = lane & 15, q = lane >> 4;
+    const int Do = md.Do, out = no.out;
+
+    if (rb < NT2) {
+        const int tj = rb / TPD, tk = rb % TPD;
+        f32x4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+        for (int s0 = wave; s0 < KS; s0 += 16 * 8) {       // bursts of 8 k-steps per wave
+            f32x2 ya[8], xa[8], yb[8], xb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = s0 + 16 * u;
+                ya[u] = xa[u] = yb[u] = xb[u] = f32x2{0.f, 0.f};
+                if (s < KS) {
+                    const size_t r = (size_t)(4 * s + q) * H;
+                    ya[u] = *reinterpret_cast<const f32x2*>(wn.w2_ya + r + tj * 32 + 2 * c);
+                    xa[u] = *reinterpret_cast<const f32x2*>(wn.w2_xa + r + tk * 32 + 2 * c);
+                    if (wn.w2_yb) {
+                        yb[u] = *reinterpret_cast<const f32x2*>(wn.w2_yb + r + tj * 32 + 2 * c);
+                        xb[u] = *reinterpret_cast<const f32x2*>(wn.w2_xb + r + tk * 32 + 2 * c);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc00 = mfma_16x16x4(ya[u][0], xa[u][0], acc00);
+                acc01 = mfma_16x16x4(ya[u][0], xa[u][1], acc01);
+                acc10 = mfma_16x16x4(ya[u][1], xa[u][0], acc10);
+                acc11 = mfma_16x16x4(ya[u][1], xa[u][1], acc11);
+                if (wn.w2_yb) {
+                    acc00 = mfma_16x16x4(yb[u][0], xb[u][0], acc00);
+                    acc01 = mfma_16x16x4(yb[u][0], xb[u][1], acc01);
+                    acc10 = mfma_16x16x4(yb[u][1], xb[u][0], acc10);
+                    acc11 = mfma_16x16x4(yb[u][1], xb[u][1], acc11);
+                }
+            }
+        }
+        float* myred = red + (wave & 7) * (32 * 33);
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            if ((wave >> 3) == round) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jl = 2 * (4 * q + r);
+                    float* p00 = &myred[(jl + 0) * 33 + 2 * c];
+                    float* p10 = &myred[(jl + 1) * 33 + 2 * c];
+                    if (round == 0) { p00[0] = acc00[r]; p00[1] = acc01[r]; p10[0] = acc10[r]; p10[1] = acc11[r]; }
+                    else { p00[0] += acc00[r]; p00[1] += acc01[r]; p10[0] += acc10[r]; p10[1] += acc11[r]; }
+                }
+            }
+            __syncthreads();
+        }
+        const int jl = tid >> 5, kl = tid & 31;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[w * (32 * 33) + jl * 33 + kl];
+        wa.out[no.W2 + (size_t)(tj * 32 + jl) * H + tk * 32 + kl] = v;
+    } else if (rb < NT2 + NA) {
+        const int j0 = (rb - NT2) * 32;
+        for (int k0 = 0; k0 < Do; k0 += 16) {
+            const bool first = (k0 == 0);
+            f32x4 ax0 = {0, 0, 0, 0}, ax1 = {0, 0, 0, 0}, ad0 = {0, 0, 0, 0}, ad1 = {0, 0, 0, 0};
+            f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+            for (int sb = wave; sb < KS; sb += 16 * 4) {
+                f32x2 y1[4], xa3[4], xb3[4], b1v[4], b2v[4];
+                float bx[4], bda[4], bdb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int s = sb + 16 * u;
+                    y1[u] = xa3[u] = xb3[u] = b1v[u] = b2v[u] = f32x2{0.f, 0.f};
+                    bx[u] = bda[u] = bdb[u] = 0.f;
+                    if (s < KS) {
+                        const size_t r = (size_t)(4 * s + q);
+                        y1[u] = *reinterpret_cast<const f32x2*>(wn.w1_y + r * H + j0 + 2 * c);
+                        if (k0 + c < Do && r < (size_t)wa.N) bx[u] = wa.obs[r * Do + k0 + c];
+                        if (first) {
+                            xa3[u] = *reinterpret_cast<const f32x2*>(wn.w3_xa + r * H + j0 + 2 * c);
+                            bda[u] = wn.w3_ya[r * FSRL_DOW + c];
+                            if (wn.w3_xb) {
+                                xb3[u] = *reinterpret_cast<const f32x2*>(wn.w3_xb + r * H + j0 + 2 * c);
+                                bdb[u] = wn.w3_yb[r * FSRL_DOW + c];
+                            }
+                            b1v[u] = *reinterpret_cast<const f32x2*>(wn.b1_src + r * H + j0 + 2 * c);
+                            b2v[u] = *reinterpret_cast<const f32x2*>(wn.b2_src + r * H + j0 + 2 * c);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    ax0 = mfma_16x16x4(y1[u][0], bx[u], ax0);
+                    ax1 = mfma_16x16x4(y1[u][1], bx[u], ax1);
+                    if (first) {
+                        ad0 = mfma_16x16x4(xa3[u][0], bda[u], ad0);
+                        ad1 = mfma_16x16x4(xa3[u][1], bda[u], ad1);
+                        if (wn.w3_xb) {
+                            ad0 = mfma_16x16x4(xb3[u][0], bdb[u], ad0);
+                            ad1 = mfma_16x16x4(xb3[u][1], bdb[u], ad1);
+                        }
+                        s1 += b1v[u];
+                        s2 += b2v[u];
+                    }
+                }
+            }
+            if (first) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    s1[t] += __shfl_xor(s1[t], 16, 64); s1[t] += __shfl_xor(s1[t], 32, 64);
+                    s2[t] += __shfl_xor(s2[t], 16, 64); s2[t] += __shfl_xor(s2[t], 32, 64);
+                }
+            }
+            float* slot = red + (wave & 7) * 1088;
+            __syncthreads();
+#pragma unroll
+            for (int round = 0; round < 2; ++round) {
+                if ((wave >> 3) == round) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int jl = 2 * (4 * q + r);
+                        if (round == 0) {
+                            slot[(jl + 0) * 16 + c] = ax0[r]; slot[(jl + 1) * 16 + c] = ax1[r];
+                            slot[512 + (jl + 0) * 16 + c] = ad0[r]; slot[512 + (jl + 1) * 16 + c] = ad1[r];
+                        } else {
+                            slot[(jl + 0) * 16 + c] += ax0[r]; slot[(jl + 1) * 16 + c] += ax1[r];
+                            slot[512 + (jl + 0) * 16 + c] += ad0[r]; slot[512 + (jl + 1) * 16 + c] += ad1[r];
+                        }
+                    }
+                    if (q == 0) {
+                        if (round == 0) {
+                            slot[1024 + 2 * c] = s1[0]; slot[1024 + 2 * c + 1] = s1[1];
+                            slot[1056 + 2 * c] = s2[0]; slot[1056 + 2 * c + 1] = s2[1];
+                        } else {
+                            slot[1024 + 2 * c] += s1[0]; slot[1024 + 2 * c + 1] += s1[1];
+                            slot[1056 + 2 * c] += s2[0]; slot[1056 + 2 * c + 1] += s2[1];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            const int e = tid & 511;
+            float v = 0.0f;
+            const int off = (tid < 512) ? e : 512 + e;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[w * 1088 + off];
+            const int jl = e >> 4, kk = e & 15;
+            if (tid < 512) {
+                if (k0 + kk < Do) wa.out[no.W1 + (size_t)(j0 + jl) * Do + k0 + kk] = v;
+            } else if (first && kk < out) {
+                wa.out[no.W3 + (size_t)kk * H + j0 + jl] = v;
+            }
+            if (first && tid < 64) {
+                float bsum = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) bsum += red[w * 1088 + 1024 + tid];
+                if (tid < 32) wa.out[no.b1 + j0 + tid] = bsum;
+                else wa.out[no.b2 + j0 + tid - 32] = bsum;
+            }
+            __syncthreads();
+        }
+    } else {
+        // db3[o] / dsigma[d]: column sums of the dout-like buffer over all rows
+        const int col = tid & 31, php = tid >> 5;
+        float t = 0.0f;
+        for (int r0 = php; r0 < wa.rows; r0 += 32 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + 32 * u;
+                v[u] = (r < wa.rows) ? wn.do_src[(size_t)r * FSRL_DOW + col] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        red[php * 33 + col] = t;
+        __syncthreads();
+        if (tid < 32) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int p2 = 0; p2 < 32; ++p2) tot += red[p2 * 33 + tid];
+            if (tid < out) wa.out[no.b3 + tid] = tot;
+            if (no.sigma >= 0 && tid >= 16 && tid < 16 + md.Da) wa.out[no.sigma + tid - 16] = tot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// sum the per-tile statistics: statp[n_tiles][ny][FB_NSTAT] -> out[ny][FB_NSTAT] (float64)
+__global__ __launch_bounds__(256) void fb_reduce_stats_kernel(const float* __restrict__ statp, int n_tiles,
+                                                             int ny, double* __restrict__ out) {
+    __shared__ double sh[4];
+    const int slot = blockIdx.x;          // (y, field)
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int t = tid; t < n_tiles; t += 256) s += (double)statp[(size_t)t * ny * FB_NSTAT + slot];
+    s = wave_sum_d(s);
+    if ((tid & 63) == 0) sh[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) out[slot] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// full-batch advantage normalisation (CPO cpo.py:127-131, TRPO trpo_lag.py:129-133): per critic
+// (a - mean) / std with the unbiased std, float64 accumulate.  grid = C blocks of 1024 threads.
+__global__ __launch_bounds__(1024) void fb_advnorm_kernel(float* __restrict__ advs, int N) {
+    __shared__ double sh[16];
+    __shared__ double mean_s, sd_s;
+    float* a = advs + (size_t)blockIdx.x * N;
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int i = tid; i < N; i += 1024) s += (double)a[i];
+    s = wave_sum_d(s);
+    if ((tid & 63) == 0) sh[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) { double t = 0; for (int w = 0; w < 16; ++w) t += sh[w]; mean_s = t / (double)N; }
+    __syncthreads();
+    const double mean = mean_s;
+    double qv = 0.0;
+    for (int i = tid; i < N; i += 1024) { const double d = (double)a[i] - mean; qv += d * d; }
+    qv = wave_sum_d(qv);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = qv;
+    __syncthreads();
+    if (tid == 0) { double t = 0; for (int w = 0; w < 16; ++w) t += sh[w]; sd_s = sqrt(t / (double)(N - 1)); }
+    __syncthreads();
+    const float mf = (float)mean_s, sf = (float)sd_s;
+    for (int i = tid; i < N; i += 1024) a[i] = (a[i] - mf) / sf;
+}
+
+// row data in store order for the full-batch kernels (identity permutation)
+struct FbRowArgs {
+    const float* act; const float* advs; const float* rets; const float* logp_old;
+    const float* mean_old;   // [N][Da] (may be null: filled later by fb_tile EVAL? no: by infer)
+    const float* sigma;      // sigma_param[Da] at process time (std_old = exp)
+    float* rd;
+    int N, C, Da;
+};
+__global__ void fb_rowdata_kernel(const FbRowArgs a) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < a.N * FSRL_RD; e += gridDim.x * blockDim.x) {
+        const int r = e / FSRL_RD, f = e - r * FSRL_RD;
+        float v = 0.0f;
+        if (f < a.Da) v = a.act[(size_t)r * a.Da + f];
+        else if (f == FSRL_RD_LOGP) v = a.logp_old[r];
+        else if (f >= FSRL_RD_ADV && f < FSRL_RD_ADV + a.C) v = a.advs[(size_t)(f - FSRL_RD_ADV) * a.N + r];
+        else if (f >= FSRL_RD_RET && f < FSRL_RD_RET + a.C) v = a.rets[(size_t)(f - FSRL_RD_RET) * a.N + r];
+        else if (f >= FSRL_RD_MEAN && f < FSRL_RD_MEAN + a.Da) v = a.mean_old[(size_t)r * a.Da + f - FSRL_RD_MEAN];
+        else if (f >= FSRL_RD_STD && f < FSRL_RD_STD + a.Da) v = expf(a.sigma[f - FSRL_RD_STD]);
+        a.rd[e] = v;
+    }
+}
+
+// Adam on a parameter range with optional L2 term (CPO critics: loss += l2 * sum(theta^2)),
+// and the per-network sum of squares of the PRE-update parameters (for the logged vf loss).
+__global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ P, float* __restrict__ M,
+                                                        float* __restrict__ V, const float* __restrict__ G,
+                                                        int begin, int end, float l2, float one_minus_b1,
+                                                        float beta2, float one_minus_b2, float step_size,
+                                                        float bc2_sqrt, float eps) {
+    const int i = begin + blockIdx.x * 256 + threadIdx.x;
+    if (i < end) {
+        const float p = P[i];
+        const float g = G[i] + 2.0f * l2 * p;
+        float m = M[i], v = V[i];
+        m = m + one_minus_b1 * (g - m);
+        v = v * beta2;
+        v = v + (one_minus_b2 * g) * g;
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        M[i] = m; V[i] = v;
+        P[i] = p + (-step_size * m) / denom;
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_range_kernel(const float* __restrict__ P, int begin, int end,
+                                                         double* __restrict__ out) {
+    __shared__ double sh[4];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int i = begin + tid; i < end; i += 256) s += (double)P[i] * (double)P[i];
+    s = wave_sum_d(s);
+    if ((tid & 63) == 0) sh[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) out[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}

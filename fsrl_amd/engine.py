@@ -199,6 +199,50 @@ class Engine:
                                             float(gae_lambda), _ptr(out, _f64p)))
         return out
 
+    # ---------------------------------------------------------------- CPO / TRPO-Lagrangian
+    def tr_begin(self, target_kl=0.01, backtrack_coeff=0.8, damping=0.1, l2_reg=0.0, critic_lr=1e-3,
+                 max_backtracks=10, optim_critic_iters=10, cg_iters=10, norm_adv=True,
+                 cost_limit=float("inf")) -> int:
+        cfg = _lib.TrConfig(target_kl, backtrack_coeff, damping, l2_reg, critic_lr, max_backtracks,
+                            optim_critic_iters, cg_iters, int(norm_adv),
+                            cost_limit if np.isfinite(cost_limit) else 1e300)
+        n = C.c_int64()
+        _lib.check(self.lib.fsrl_tr_begin(self._ctx, C.byref(cfg), C.byref(n)))
+        self._n = n.value
+        return n.value
+
+    @property
+    def n_actor_params(self) -> int:
+        return int(self.lib.fsrl_actor_param_count(self._ctx))
+
+    def tr_grad(self, which: int):
+        out = np.empty(self.n_actor_params, np.float32)
+        _lib.check(self.lib.fsrl_tr_grad(self._ctx, int(which), _ptr(out, _f32p), out.size))
+        return out
+
+    def tr_hvp(self, v):
+        v = np.ascontiguousarray(v, np.float32)
+        out = np.empty_like(v)
+        _lib.check(self.lib.fsrl_tr_hvp(self._ctx, _ptr(v, _f32p), _ptr(out, _f32p), v.size))
+        return out
+
+    def tr_eval(self):
+        out = np.zeros(8, np.float64)
+        _lib.check(self.lib.fsrl_tr_eval(self._ctx, _ptr(out, _f64p)))
+        return out
+
+    def cpo_learn(self, ave_cost_return: float, repeat: int):
+        out = np.empty((repeat, _lib.CPO_NSTATS), np.float32)
+        _lib.check(self.lib.fsrl_cpo_learn(self._ctx, float(ave_cost_return), int(repeat), _ptr(out, _f32p)))
+        return out
+
+    def trpo_learn(self, lagrangians, rescaling: float, repeat: int):
+        lag = np.ascontiguousarray(lagrangians, np.float64).reshape(-1)
+        out = np.empty((repeat, _lib.TRPO_NSTATS), np.float32)
+        _lib.check(self.lib.fsrl_trpo_learn(self._ctx, _ptr(lag, _f64p) if lag.size else None,
+                                            float(rescaling), int(repeat), _ptr(out, _f32p)))
+        return out
+
     def set_profiling(self, on: bool):
         _lib.check(self.lib.fsrl_set_profiling(self._ctx, int(on)))
 

@@ -140,6 +140,47 @@ int fsrl_gae_return(fsrl_ctx* ctx, const float* v, const float* v_next, const do
                     const uint8_t* end_flag, int64_t n, double gamma, double gae_lambda,
                     double* adv_out);
 
+/* ---- trust-region policy updates: CPO (fsrl/policy/cpo.py) and TRPO-Lagrangian
+ *      (fsrl/policy/trpo_lag.py).  Same context / store / parameter layout as PPO-Lag;
+ *      full batch (the reference runs them with batch_size = 99999).                       */
+typedef struct fsrl_tr_config {
+    float target_kl;            /* delta: 0.01 (CPO), 0.001 (TRPO-Lag)                       */
+    float backtrack_coeff;      /* 0.8                                                       */
+    float damping;              /* 0.1  (cpo.py:182 damping_coeff, trpo_lag.py:115)          */
+    float l2_reg;               /* CPO critics: + l2_reg * sum(theta^2)   (cpo.py:155-156)   */
+    float critic_lr;            /* Adam over the critic parameters                           */
+    int32_t max_backtracks;     /* 10 (agent default) / 100 (cpo_cfg.py:17)                  */
+    int32_t optim_critic_iters; /* critic Adam steps per repeat                              */
+    int32_t cg_iters;           /* 10                                                        */
+    int32_t norm_adv;           /* full-batch advantage normalisation                        */
+    double cost_limit;          /* CPO                                                       */
+} fsrl_tr_config;
+
+#define FSRL_CPO_NSTATS 17  /* kl, entropy, rew_loss, cost_loss, optim_A, optim_B, optim_C, optim_Q,
+                               optim_R, optim_S, optim_lam, optim_nu, optim_case, step_size
+                               (cpo.py:335-350) then vf0, vf1, vf_total (cpo.py:160-161)     */
+#define FSRL_TRPO_NSTATS 11 /* rescaling, lagrangian, actor_safety, actor_rew, actor_total, vf0,
+                               vf1, vf_total, kl, step_size, entropy (trpo_lag.py:140-171,241-249) */
+
+/* begin: buffer.sample(0) + process_fn (cpo.py:123-145 / trpo_lag.py:117-134): GAE, full-batch
+ * advantage normalisation, logp_old, mean_old / std_old.                                      */
+int fsrl_tr_begin(fsrl_ctx* ctx, const fsrl_tr_config* cfg, int64_t* n_out);
+/* CPO.learn (cpo.py:353-370): `repeat` x { optim_critic_iters critic steps ; policy_loss }.
+ * ave_cost_return = stats_train["cost"] (cpo.py:112-113).  stats_out: [repeat][FSRL_CPO_NSTATS]. */
+int fsrl_cpo_learn(fsrl_ctx* ctx, double ave_cost_return, int32_t repeat, float* stats_out);
+/* TRPOLagrangian.learn (trpo_lag.py:173-251).  stats_out: [repeat][FSRL_TRPO_NSTATS].          */
+int fsrl_trpo_learn(fsrl_ctx* ctx, const double* lagrangians, double rescaling, int32_t repeat,
+                    float* stats_out);
+/* building blocks, exposed for the parity tests (all on the batch of the last fsrl_tr_begin):
+ * which = 0: grad of mean(ratio*A_r)   1: grad of -mean(ratio*A_c)   2: grad of mean KL(old||new)
+ * out: flat ACTOR parameter vector (sigma_param, W1, b1, W2, b2, W3, b3).                      */
+int64_t fsrl_actor_param_count(const fsrl_ctx* ctx);
+int fsrl_tr_grad(fsrl_ctx* ctx, int32_t which, float* out, int64_t n);
+/* out = H v (no damping), H = Hessian of mean KL(N(mean_old,std_old) || pi_theta) at the current theta */
+int fsrl_tr_hvp(fsrl_ctx* ctx, const float* v, float* out, int64_t n);
+/* stats8: mean(ratio*A_r), mean(ratio*A_c), mean KL, mean(logp_old - logp), mean A_r, mean A_c, 0, 0 */
+int fsrl_tr_eval(fsrl_ctx* ctx, double* stats8);
+
 /* ---- timing of the last update, measured with hipEvents on the compute stream --------- */
 /* out[0] = process_fn ms, out[1] = learn ms (all passes), out[2] = fused fwd/bwd kernel
  * total ms over the update (sum of per-launch event pairs when profiling is enabled),

@@ -1,0 +1,144 @@
+"""GPU parity of the trust-region path (CPO, TRPO-Lagrangian) through the C ABI:
+gradients and Hessian-vector products against torch autograd (double backward) of the oracle,
+full learn() against the golden vectors recorded from the unmodified reference.
+
+Tolerances: single gradients / HVPs 2e-5 of the vector's max-norm (fp32, different summation
+order); anything downstream of conjugate gradients is compared at 2e-2 relative: the reference
+itself moves by ~1e-3 in Q/R/S when the (mathematically irrelevant) row order of its shuffled
+full batch changes -- fp32 CG on the damped Hessian amplifies summation-order noise."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import end_flag_of, load_npz
+from test_oracle_trust import _data, cpo_cfg, trpo_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(cfg, **over):
+    from fsrl_amd.engine import Engine, EngineConfig
+    ec = EngineConfig(obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"], hidden=cfg["hidden"][0], n_critics=2,
+                      env_num=cfg["env_num"], gamma=cfg["gamma"], gae_lambda=cfg["gae_lambda"],
+                      max_action=cfg["max_action"], lr=cfg["lr"], target_kl=None)
+    for k, v in over.items():
+        setattr(ec, k, v)
+    return Engine(ec)
+
+
+def _push(eng, g):
+    rows = g["env_rows"]
+    off = np.concatenate([[0], np.cumsum(rows)])
+    for t in range(rows.max()):
+        ids = [e for e in range(len(rows)) if t < rows[e]]
+        sel = np.array([off[e] + t for e in ids])
+        eng.push(ids, g["buf_obs"][sel], g["buf_act"][sel], g["buf_rew"][sel], g["buf_cost"][sel],
+                 g["buf_terminated"][sel], g["buf_truncated"][sel], g["buf_obs_next"][sel])
+
+
+def _close(a, b, rel):
+    scale = max(float(np.abs(b).max()), 1e-12)
+    assert float(np.abs(np.asarray(a) - np.asarray(b)).max()) <= rel * scale, \
+        (float(np.abs(np.asarray(a) - np.asarray(b)).max()), scale)
+
+
+@pytest.mark.parametrize("name,perturbed", [("infeasible", False), ("perturbed", True)])
+def test_gradients_and_hvp_vs_autograd(name, perturbed):
+    from oracle.trust_region import CPOOracle
+    from torch.distributions import Independent, Normal, kl_divergence
+    g = load_npz(f"cpo_{name}.npz")
+    cfg = json.loads(str(g["cfg_json"]))
+    o = CPOOracle(cpo_cfg(cfg)); o.set_params(g["theta0"])
+    pb = o.process(_data(g))
+    eng = _engine(cfg); eng.set_params(g["theta0"]); _push(eng, g)
+    n = eng.tr_begin(target_kl=cfg["target_kl"], norm_adv=True, cost_limit=cfg["cost_limit"])
+    assert n == len(g["indices"])
+    np.testing.assert_allclose(eng.batch_get("advs"), g["advs_norm"], rtol=0, atol=2e-5)
+    if perturbed:                         # theta != theta_old: exact Hessian, not the Fisher matrix
+        o.set_params(g["theta0_perturbed"]); eng.set_params(g["theta0_perturbed"])
+    dist = o.actor_dist(pb["obs"])
+    logp = dist.log_prob(pb["act"])
+    ratio = torch.exp(logp - pb["logp_old"])
+    obj = torch.mean(ratio * pb["advs"][..., 0])
+    csur = torch.mean(ratio * pb["advs"][..., 1])
+    kl = kl_divergence(Independent(Normal(pb["mean_old"], pb["std_old"]), 1), dist).mean()
+    og = o.flat_grad(obj, retain_graph=True).numpy()
+    ob = o.flat_grad(-csur, retain_graph=True).numpy()
+    klg = o.flat_grad(kl, create_graph=True)
+    _close(eng.tr_grad(0), og, 2e-5)
+    _close(eng.tr_grad(1), ob, 2e-5)
+    if perturbed:
+        _close(eng.tr_grad(2), klg.detach().numpy(), 2e-5)
+    else:
+        assert np.abs(eng.tr_grad(2)).max() < 1e-7      # KL gradient vanishes at theta_old
+    ev = eng.tr_eval()
+    np.testing.assert_allclose(ev[:3], [obj.item(), csur.item(), kl.item()], rtol=1e-4, atol=1e-6)
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        v = rng.standard_normal(og.size).astype(np.float32)
+        hv = o.flat_grad(torch.dot(klg, torch.from_numpy(v)), retain_graph=True).numpy()
+        _close(eng.tr_hvp(v), hv, 5e-5)
+    eng.close()
+
+
+CPO_KEYS = ["loss/kl", "loss/entropy", "loss/rew_loss", "loss/cost_loss", "loss/optim_A", "loss/optim_B",
+            "loss/optim_C", "loss/optim_Q", "loss/optim_R", "loss/optim_S", "loss/optim_lam",
+            "loss/optim_nu", "loss/optim_case", "loss/step_size", "loss/vf0", "loss/vf1", "loss/vf_total"]
+
+
+@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2"])
+def test_cpo_learn_vs_golden(name):
+    g = load_npz(f"cpo_{name}.npz")
+    cfg = json.loads(str(g["cfg_json"]))
+    eng = _engine(cfg); eng.set_params(g["theta0"]); _push(eng, g)
+    eng.tr_begin(target_kl=cfg["target_kl"], backtrack_coeff=cfg["backtrack_coeff"],
+                 damping=cfg["damping_coeff"], l2_reg=cfg["l2_reg"], critic_lr=cfg["lr"],
+                 max_backtracks=cfg["max_backtracks"], optim_critic_iters=cfg["optim_critic_iters"],
+                 norm_adv=cfg["advantage_normalization"], cost_limit=cfg["cost_limit"])
+    stats = eng.cpo_learn(cfg["cost_stat"], cfg["repeat"])
+    ka = [str(k) for k in g["stats_actor_keys"]]; kc = [str(k) for k in g["stats_critic_keys"]]
+    want = np.concatenate([g["stats_actor"][:, [ka.index(k) for k in CPO_KEYS[:14]]],
+                           g["stats_critic"][:, [kc.index(k) for k in CPO_KEYS[14:]]]], 1)
+    ci, si = CPO_KEYS.index("loss/optim_case"), CPO_KEYS.index("loss/step_size")
+    assert np.array_equal(stats[:, ci], want[:, ci])                  # same branch of the dual solve
+    np.testing.assert_allclose(stats[0, si], want[0, si], rtol=1e-6)  # same number of backtracks
+    # later repeats start from a theta that already differs at the 1e-3 level (CG noise): the
+    # accept/reject test of the line search may flip by one backtrack at its boundary
+    ratio = stats[1:, si] / want[1:, si]
+    assert np.all((ratio > 0.79) & (ratio < 1.26)), (stats[:, si], want[:, si])
+    # first repeat: everything downstream of CG at 2e-2; critic losses tight
+    for j, k in enumerate(CPO_KEYS):
+        tol = 2e-5 if k.startswith("loss/vf") or k in ("loss/entropy", "loss/cost_loss", "loss/optim_C") else 2e-2
+        scale = max(abs(want[0, j]), 1e-3)
+        assert abs(stats[0, j] - want[0, j]) <= tol * scale + 1e-6, (k, stats[0, j], want[0, j])
+    th = eng.get_params()
+    assert np.abs(th - g["theta_final"]).max() <= 5e-3 and np.abs(th - g["theta_final"]).mean() <= 2e-4
+    eng.close()
+
+
+TRPO_KEYS = ["loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss/actor_rew", "loss/actor_total",
+             "loss/vf0", "loss/vf1", "loss/vf_total", "loss/kl", "loss/step_size", "loss/entropy"]
+
+
+@pytest.mark.parametrize("name", ["small", "c1"])
+def test_trpo_learn_vs_golden(name):
+    g = load_npz(f"trpo_{name}.npz")
+    cfg = json.loads(str(g["cfg_json"]))
+    eng = _engine(cfg, use_lagrangian=cfg["use_lagrangian"]); eng.set_params(g["theta0"]); _push(eng, g)
+    eng.tr_begin(target_kl=cfg["target_kl"], backtrack_coeff=cfg["backtrack_coeff"], damping=0.1,
+                 l2_reg=0.0, critic_lr=cfg["lr"], max_backtracks=cfg["max_backtracks"],
+                 optim_critic_iters=cfg["optim_critic_iters"], norm_adv=cfg["advantage_normalization"])
+    lag = g["lagrangian"]
+    stats = eng.trpo_learn(lag, 1.0 / (lag.sum() + 1.0), cfg["repeat"])
+    keys = [str(k) for k in g["stats_keys"]]
+    want = g["stats"][:, [keys.index(k) for k in TRPO_KEYS]]
+    for j, k in enumerate(TRPO_KEYS):
+        tol = 2e-2 if k in ("loss/kl", "loss/step_size") else 2e-4
+        scale = max(abs(want[0, j]), 1e-3)
+        assert abs(stats[0, j] - want[0, j]) <= tol * scale + 1e-6, (k, stats[0], want[0])
+    np.testing.assert_allclose(stats, want, rtol=5e-2, atol=2e-3)
+    th = eng.get_params()
+    assert np.abs(th - g["theta_final"]).max() <= 5e-3 and np.abs(th - g["theta_final"]).mean() <= 2e-4
+    eng.close()
