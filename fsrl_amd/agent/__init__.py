@@ -1,4 +1,5 @@
 from fsrl_amd.agent.base_agent import BaseAgent, OnpolicyAgent
 from fsrl_amd.agent.ppo_lag_agent import PPOLagAgent
+from fsrl_amd.agent.trust_agents import CPOAgent, TRPOLagAgent
 
-__all__ = ["BaseAgent", "OnpolicyAgent", "PPOLagAgent"]
+__all__ = ["BaseAgent", "OnpolicyAgent", "PPOLagAgent", "CPOAgent", "TRPOLagAgent"]

@@ -2,5 +2,7 @@
 from fsrl_amd.policy.base_policy import BasePolicy
 from fsrl_amd.policy.lagrangian_base import LagrangianPolicy
 from fsrl_amd.policy.ppo_lag import PPOLagrangian
+from fsrl_amd.policy.trpo_lag import TRPOLagrangian
+from fsrl_amd.policy.cpo import CPO
 
-__all__ = ["BasePolicy", "LagrangianPolicy", "PPOLagrangian"]
+__all__ = ["BasePolicy", "LagrangianPolicy", "PPOLagrangian", "TRPOLagrangian", "CPO"]

@@ -50,6 +50,24 @@ class BasePolicy(ABC, nn.Module):
         self.gradient_steps = 0
         self.engine = None  # set by the concrete policy
 
+    # ------------------------------------------------------------------ engine
+    def _make_engine(self, device, env_num, buffer_size, optim=None, **cfg_over):
+        """Create the HIP context with the geometry of the host networks."""
+        from fsrl_amd.engine import Engine, EngineConfig
+        w1 = self.actor.preprocess.model.model[0].weight
+        hidden, obs_dim = w1.shape
+        act_dim = self.actor.mu.model[0].weight.shape[0]
+        dev = device if isinstance(device, int) else (int(str(device).split(":")[-1]) if ":" in str(device) else 0)
+        kw = dict(obs_dim=int(obs_dim), act_dim=int(act_dim), hidden=int(hidden), n_critics=self.critics_num,
+                  env_num=int(env_num), buffer_size=int(buffer_size),
+                  max_action=float(getattr(self.actor, "_max", 1.0)), gamma=self._gamma)
+        if optim is not None:
+            g = optim.param_groups[0]
+            kw.update(lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], adam_eps=g["eps"])
+        kw.update(cfg_over)
+        self.engine = Engine(EngineConfig(**kw), device=dev)
+        self._push_params()
+
     # ------------------------------------------------------------------ parameter plumbing
     def _flat_params(self) -> np.ndarray:
         return torch.cat([p.detach().reshape(-1) for p in self._actor_critic.parameters()]).numpy().astype(np.float32)

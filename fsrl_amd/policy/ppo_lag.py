@@ -7,7 +7,6 @@ import numpy as np
 import torch
 from torch import nn
 
-from fsrl_amd.engine import Engine, EngineConfig
 from fsrl_amd.policy.lagrangian_base import LagrangianPolicy
 
 PPO_STAT_KEYS = ("loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss/actor_rew",
@@ -44,21 +43,10 @@ class PPOLagrangian(LagrangianPolicy):
         self._lambda, self._weight_vf, self._grad_norm = gae_lambda, vf_coef, max_grad_norm
         self._target_kl, self._eps_clip, self._dual_clip = target_kl, eps_clip, dual_clip
         self._norm_adv = advantage_normalization
-        # ---- derive the engine geometry from the host networks
-        w1 = actor.preprocess.model.model[0].weight
-        hidden, obs_dim = w1.shape
-        act_dim = actor.mu.model[0].weight.shape[0]
-        g = optim.param_groups[0]
-        dev = int(str(device).split(":")[-1]) if not isinstance(device, int) and ":" in str(device) else \
-            (device if isinstance(device, int) else 0)
-        self.engine = Engine(EngineConfig(
-            obs_dim=int(obs_dim), act_dim=int(act_dim), hidden=int(hidden), n_critics=self.critics_num,
-            env_num=int(env_num), buffer_size=int(buffer_size), max_action=float(getattr(actor, "_max", 1.0)),
-            gamma=gamma, gae_lambda=gae_lambda, eps_clip=eps_clip, dual_clip=dual_clip, vf_coef=vf_coef,
-            max_grad_norm=max_grad_norm, target_kl=target_kl, norm_adv=advantage_normalization,
-            use_lagrangian=use_lagrangian, lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1],
-            adam_eps=g["eps"]), device=dev)
-        self._push_params()
+        self._make_engine(device, env_num, buffer_size, optim, gae_lambda=gae_lambda, eps_clip=eps_clip,
+                          dual_clip=dual_clip, vf_coef=vf_coef, max_grad_norm=max_grad_norm,
+                          target_kl=target_kl, norm_adv=advantage_normalization,
+                          use_lagrangian=use_lagrangian)
 
     def learn(self, batch, **kwargs: Any):
         raise NotImplementedError("the HIP path runs process_fn + learn inside update()")

@@ -1,0 +1,72 @@
+"""TRPOLagrangian over the HIP engine: constructor arguments and logger keys of
+fsrl/policy/trpo_lag.py:16-301.  `update()` = process_fn + `repeat` x { natural-gradient step by
+CG with Fisher-vector products (damping 0.1), step = sqrt(2 delta / d'Hd), backtracking line
+search ; optim_critic_iters critic Adam steps } through `fsrl_tr_begin` / `fsrl_trpo_learn`."""
+from typing import Any, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from fsrl_amd.policy.lagrangian_base import LagrangianPolicy
+
+TRPO_KEYS = ("loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss/actor_rew", "loss/actor_total",
+             "loss/vf0", "loss/vf1", "loss/vf_total", "loss/kl", "loss/step_size", "loss/entropy")
+
+
+class TRPOLagrangian(LagrangianPolicy):
+    def __init__(self, actor: nn.Module, critics: Union[nn.Module, List[nn.Module]],
+                 optim: torch.optim.Optimizer, dist_fn, logger=None,
+                 # TRPO specific arguments
+                 target_kl: float = 0.001, backtrack_coeff: float = 0.8, max_backtracks: int = 10,
+                 optim_critic_iters: int = 5, gae_lambda: float = 0.95,
+                 advantage_normalization: bool = True,
+                 # Lagrangian specific arguments
+                 use_lagrangian: bool = True, lagrangian_pid: Tuple = (0.05, 0.0005, 0.1),
+                 cost_limit: Union[List, float] = np.inf, rescaling: bool = True,
+                 # Base policy common arguments
+                 gamma: float = 0.99, max_batchsize: int = 99999, reward_normalization: bool = False,
+                 deterministic_eval: bool = True, action_scaling: bool = True,
+                 action_bound_method: str = "clip", observation_space=None, action_space=None,
+                 lr_scheduler=None, device: Union[int, str] = 0, env_num: int = 1,
+                 buffer_size: int = 100000) -> None:
+        super().__init__(actor, critics, dist_fn, logger, use_lagrangian, lagrangian_pid, cost_limit,
+                         rescaling, gamma, max_batchsize, reward_normalization, deterministic_eval,
+                         action_scaling, action_bound_method, observation_space, action_space, lr_scheduler)
+        assert self.critics_num == 2, "the HIP path supports one cost constraint"
+        self.optim = optim
+        self._lambda, self._norm_adv = gae_lambda, advantage_normalization
+        self._max_backtracks, self._delta = max_backtracks, target_kl
+        self._backtrack_coeff, self._optim_critic_iters = backtrack_coeff, optim_critic_iters
+        self._damping = 0.1
+        self._make_engine(device, env_num, buffer_size, optim, gae_lambda=gae_lambda, target_kl=None,
+                          use_lagrangian=use_lagrangian)
+
+    def learn(self, batch, **kwargs: Any):
+        raise NotImplementedError("the HIP path runs process_fn + learn inside update()")
+
+    def update(self, sample_size: int, buffer, batch_size: int = 99999, repeat: int = 4, **kwargs: Any):
+        if buffer is None:
+            return {}
+        assert sample_size == 0 and getattr(buffer, "engine", None) is self.engine
+        self.updating = True
+        eng = self.engine
+        g = self.optim.param_groups[0]
+        n = eng.tr_begin(target_kl=self._delta, backtrack_coeff=self._backtrack_coeff, damping=self._damping,
+                         l2_reg=0.0, critic_lr=g["lr"], max_backtracks=self._max_backtracks,
+                         optim_critic_iters=self._optim_critic_iters, cg_iters=10, norm_adv=self._norm_adv)
+        assert n <= batch_size, "TRPO-Lag on the HIP path is full-batch (reference default batch_size=99999)"
+        lags, rescaling = self.lagrangians_and_rescaling() if self.use_lagrangian else ([], 1.0)
+        stats = eng.trpo_learn(lags, rescaling, repeat) if n > 0 else np.zeros((0, 11), np.float32)
+        for row in stats:
+            d = dict(zip(TRPO_KEYS, (float(v) for v in row)))
+            kl, step, ent = d.pop("loss/kl"), d.pop("loss/step_size"), d.pop("loss/entropy")
+            self.gradient_steps += self._optim_critic_iters
+            self.logger.store(**d)
+            self.logger.store(kl=kl, step_size=step, entropy=ent, tab="loss")
+        self.logger.store(gradient_steps=self.gradient_steps, tab="update")
+        self._pull_params()
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+        self.updating = False
+        return {"gradient_steps": len(stats)}

@@ -102,3 +102,22 @@ def test_agent_learn_end_to_end_on_synthetic_env(tmp_path):
     rew, length, cost = agent.evaluate(test, eval_episodes=2)
     assert length == 50.0 and np.isfinite(rew) and cost >= 0
     assert (tmp_path / "t" / "checkpoint" / "model.pt").exists()
+
+
+@pytest.mark.parametrize("kind", ["cpo", "trpo"])
+def test_trust_region_agents_learn_end_to_end(kind, tmp_path):
+    from fsrl_amd.agent import CPOAgent, TRPOLagAgent
+    from fsrl_amd.env import SyntheticSafetyVectorEnv
+    from fsrl_amd.utils import BaseLogger
+    train = SyntheticSafetyVectorEnv(env_num=4, episode_len=50, seed=1)
+    Agent = CPOAgent if kind == "cpo" else TRPOLagAgent
+    agent = Agent(train, BaseLogger(str(tmp_path), name="t"), cost_limit=10, device="cuda:0", seed=3,
+                  hidden_sizes=(64, 64), optim_critic_iters=3, training_num=4)
+    theta0 = agent.policy.engine.get_params()
+    ep, stat, info = agent.learn(train, None, epoch=2, episode_per_collect=4, step_per_epoch=400,
+                                 repeat_per_collect=2, batch_size=99999, verbose=False)
+    assert ep == 2 and np.isfinite(list(stat.values())).all()
+    assert "loss/step_size" in stat and "loss/vf_total" in stat and "loss/kl" in stat
+    assert ("loss/optim_case" in stat) == (kind == "cpo")
+    theta1 = agent.policy.engine.get_params()
+    assert np.abs(theta1 - theta0).max() > 1e-5 and np.array_equal(agent.policy._flat_params(), theta1)

@@ -1,0 +1,97 @@
+#!/usr/bin/env python
+"""Secondary benchmarks: BASELINE.json configs[2] (CPO, SafetyPointGoal shape: obs 60, act 2,
+256x256, N = 20 000 full batch, CG 10) and TRPO-Lagrangian on the configs[1] shape.  One JSON
+line each; the CPU figure is the oracle (torch fp32, 4 threads) on the same inputs."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fsrl_amd.engine import Engine, EngineConfig  # noqa: E402
+from oracle.ppo_lag import OnPolicyData  # noqa: E402
+from oracle.trust_region import CPOConfig, CPOOracle, TRPOConfig, TRPOLagOracle  # noqa: E402
+
+
+def inputs(rng, envs, T, obs_dim, act_dim, ep):
+    obs = rng.standard_normal((T + 1, envs, obs_dim)).astype(np.float32)
+    act = (0.3 * rng.standard_normal((T, envs, act_dim))).astype(np.float32)
+    rew = rng.normal(0.5, 0.5, (T, envs)); cost = (rng.random((T, envs)) < 0.1).astype(np.float64)
+    trunc = np.zeros((T, envs), bool); trunc[ep - 1::ep] = True
+    return obs, act, rew, cost, np.zeros((T, envs), bool), trunc
+
+
+def orth_theta(o, seed):
+    torch.manual_seed(seed)
+    parts = []
+    for spec in o.specs:
+        for name, shape in spec.items():
+            if name == "sigma_param":
+                parts.append(torch.full(shape, -0.5).reshape(-1))
+            elif name.startswith("W"):
+                w = torch.empty(shape); torch.nn.init.orthogonal_(w); parts.append(w.reshape(-1))
+            else:
+                parts.append(torch.zeros(shape).reshape(-1))
+    return torch.cat(parts).numpy()
+
+
+def run(kind, obs_dim, act_dim, hid, envs=20, T=1000, ep=1000, repeat=4, cpu_repeat=1):
+    rng = np.random.default_rng(0)
+    obs, act, rew, cost, term, trunc = inputs(rng, envs, T, obs_dim, act_dim, ep)
+    eng = Engine(EngineConfig(obs_dim=obs_dim, act_dim=act_dim, hidden=hid, env_num=envs, target_kl=None,
+                              lr=1e-3 if kind == "cpo" else 5e-4))
+    if kind == "cpo":
+        ocfg = CPOConfig(obs_dim=obs_dim, act_dim=act_dim, hidden=(hid, hid), optim_critic_iters=10,
+                         max_backtracks=10, cost_limit=10.0)
+        o = CPOOracle(ocfg)
+    else:
+        ocfg = TRPOConfig(obs_dim=obs_dim, act_dim=act_dim, hidden=(hid, hid), optim_critic_iters=20)
+        o = TRPOLagOracle(ocfg)
+    theta = orth_theta(o, 0)
+    ids = np.arange(envs)
+    for t in range(T):
+        eng.push(ids, obs[t], act[t], rew[t], cost[t], term[t], trunc[t], obs[t + 1])
+    eng.sync()
+
+    def device_update():
+        eng.set_params(theta)
+        if kind == "cpo":
+            eng.tr_begin(target_kl=0.01, l2_reg=0.001, critic_lr=1e-3, max_backtracks=10, optim_critic_iters=10,
+                         cost_limit=10.0)
+            return eng.cpo_learn(25.0, repeat)
+        eng.tr_begin(target_kl=0.001, critic_lr=5e-4, max_backtracks=10, optim_critic_iters=20)
+        return eng.trpo_learn([0.75], 1 / 1.75, repeat)
+
+    device_update()
+    t0 = time.perf_counter(); n = 3
+    for _ in range(n):
+        stats = device_update()
+    dt = (time.perf_counter() - t0) / n
+    em = lambda a: np.concatenate([a[:, e] for e in range(envs)])
+    data = OnPolicyData(obs=em(obs[:-1]), act=em(act), rew=em(rew), cost=em(cost), terminated=em(term),
+                        truncated=em(trunc), obs_next=em(obs[1:]), end_flag=em(term | trunc))
+    torch.set_num_threads(4)
+    o.set_params(theta)
+    t0 = time.perf_counter()
+    if kind == "cpo":
+        _, rows = o.update(data, 25.0, cpu_repeat)
+        ostat = rows[0][0]
+    else:
+        _, rows = o.update(data, [0.75], 1 / 1.75, cpu_repeat)
+        ostat = rows[0][0]
+    cdt = (time.perf_counter() - t0) / cpu_repeat * repeat
+    print(json.dumps({"bench": kind, "obs": obs_dim, "act": act_dim, "hidden": hid, "N": envs * T,
+                      "repeat": repeat, "hip_ms_per_update": dt * 1e3, "hip_updates_per_s": 1 / dt,
+                      "cpu_oracle_ms_per_update_4thr": cdt * 1e3, "speedup": cdt / dt,
+                      "hip_first_repeat": [float(x) for x in stats[0]],
+                      "oracle_first_repeat": {k: float(v) for k, v in ostat.items()}}))
+    eng.close()
+
+
+if __name__ == "__main__":
+    run("cpo", 60, 2, 256)
+    run("trpo", 8, 2, 256, ep=250)
