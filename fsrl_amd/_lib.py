@@ -29,7 +29,14 @@ class TrConfig(C.Structure):
                 ("cost_limit", C.c_double)]
 
 
-CPO_NSTATS, TRPO_NSTATS = 17, 11
+class SacConfig(C.Structure):
+    """struct fsrl_sac_config (include/fsrl_hip.h)"""
+    _fields_ = [("actor_lr", C.c_float), ("critic_lr", C.c_float), ("alpha_lr", C.c_float), ("tau", C.c_float),
+                ("alpha", C.c_float), ("target_entropy", C.c_float), ("n_step", C.c_int32),
+                ("auto_alpha", C.c_int32), ("use_lagrangian", C.c_int32)]
+
+
+CPO_NSTATS, TRPO_NSTATS, SAC_NSTATS = 17, 11, 10
 
 _P = C.POINTER
 _f, _d, _u8, _i32, _i64 = _P(C.c_float), _P(C.c_double), _P(C.c_uint8), _P(C.c_int32), _P(C.c_int64)
@@ -66,6 +73,12 @@ SIGNATURES = {
     "fsrl_tr_grad": (C.c_int, [_ctx, C.c_int32, _f, C.c_int64]),
     "fsrl_tr_hvp": (C.c_int, [_ctx, _f, _f, C.c_int64]),
     "fsrl_tr_eval": (C.c_int, [_ctx, _d]),
+    "fsrl_sac_init": (C.c_int, [_ctx, _P(SacConfig)]),
+    "fsrl_sac_param_count": (C.c_int64, [_ctx, C.c_int32]),
+    "fsrl_sac_params_set": (C.c_int, [_ctx, _f, C.c_int64, _f, C.c_int64, C.c_float]),
+    "fsrl_sac_params_get": (C.c_int, [_ctx, C.c_int32, _f, C.c_int64, _f]),
+    "fsrl_sac_update": (C.c_int, [_ctx, C.c_int32, _i64, _f, _f, C.c_uint64, _d, C.c_double, _f]),
+    "fsrl_sac_actor_forward": (C.c_int, [_ctx, _f, C.c_int32, _f, _f]),
     "fsrl_set_profiling": (C.c_int, [_ctx, C.c_int]),
     "fsrl_last_timing": (C.c_int, [_ctx, _d, C.c_int32]),
 }

@@ -121,7 +121,9 @@ struct fsrl_ctx {
     int64_t n_fwdbwd = 0;
     uint64_t rng[4] = {0x9E3779B97F4A7C15ull, 0xBF58476D1CE4E5B9ull, 0x94D049BB133111EBull, 1};
     struct TrState* tr = nullptr;   // trust-region (CPO / TRPO-Lag) working set, owned
+    void* sac = nullptr;            // SacState, owned
 };
+static void sac_free(fsrl_ctx* c);
 static void tr_free(fsrl_ctx* c);
 
 static int ensure_scratch(fsrl_ctx* c, size_t bytes) {
@@ -177,6 +179,7 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     tr_free(c);
+    sac_free(c);
     void* dptrs[] = {c->P, c->M, c->V, c->G, c->ctrl, c->st.obs, c->st.obs_next, c->st.act, c->st.rew,
                      c->st.cost, c->st.flags, c->b.obs, c->b.obs_next, c->b.act, c->b.rew, c->b.cost,
                      c->b.flags, c->d_indices, c->d_end, c->d_seg, c->values, c->vnext, c->advs,
@@ -203,7 +206,8 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
 
 extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx** out) {
     CHECK_ARG(cfg && out, "null argument");
-    CHECK_ARG(cfg->algo == FSRL_ALGO_PPO_LAG, "algo %d not built in this library version", cfg->algo);
+    CHECK_ARG(cfg->algo == FSRL_ALGO_PPO_LAG || cfg->algo == FSRL_ALGO_SAC_LAG || cfg->algo == FSRL_ALGO_CPO ||
+                  cfg->algo == FSRL_ALGO_TRPO_LAG, "unknown algo %d", cfg->algo);
     CHECK_ARG(cfg->obs_dim >= 1 && cfg->obs_dim <= FSRL_MAX_OBS, "obs_dim must be in [1,%d]", FSRL_MAX_OBS);
     CHECK_ARG(cfg->act_dim >= 1 && cfg->act_dim <= FSRL_MAX_ACT, "act_dim must be in [1,%d]", FSRL_MAX_ACT);
     CHECK_ARG(cfg->hidden == 64 || cfg->hidden == 128 || cfg->hidden == 256,
@@ -1384,5 +1388,432 @@ extern "C" int fsrl_trpo_learn(fsrl_ctx* c, const double* lagrangians, double re
         st[0] = resc; st[1] = lam0; st[2] = loss_safety; st[3] = loss_rew; st[4] = loss_actor;
         st[5] = vf[0]; st[6] = vf[1]; st[7] = vf[0] + vf[1]; st[8] = kl; st[9] = step; st[10] = ent;
     }
+    return 0;
+}
+
+// ====================================================================================== SAC-Lagrangian
+#include "kernels_sac.hpp"
+
+struct SacState {
+    fsrl_sac_config cfg{};
+    ModelDesc mda{}, mdq{};
+    std::vector<TensorMap> tmap_a, tmap_q;     // API order -> device offsets
+    int na_api = 0, nq_api = 0, na_dev = 0, nq_dev = 0;
+    float *PA = nullptr, *MA = nullptr, *VA = nullptr, *GA = nullptr;
+    float *PQ = nullptr, *PQT = nullptr, *MQ = nullptr, *VQ = nullptr, *GQ = nullptr;
+    SacScalars* sc = nullptr;
+    int64_t t_actor = 0, t_critic = 0;
+    // per-batch buffers
+    int cap_B = 0, n_tiles = 0;
+    int *d_idx = nullptr, *d_chain = nullptr; uint8_t* d_end = nullptr;
+    int *h_idx = nullptr, *h_chain = nullptr; uint8_t* h_end = nullptr;          // pinned
+    float *XQ = nullptr, *OBS = nullptr, *OBSN = nullptr, *XN = nullptr, *XP = nullptr;
+    float *eps_t = nullptr, *eps_p = nullptr, *h_eps = nullptr;                   // device / pinned
+    float *LPN = nullptr, *LP = nullptr, *QT = nullptr, *QP = nullptr, *Y = nullptr, *DA = nullptr;
+    float *A1 = nullptr, *A2 = nullptr, *D1 = nullptr, *D2 = nullptr, *DO = nullptr;   // [4][Bpad]
+    float *stq = nullptr, *stdin_ = nullptr, *stpi = nullptr, *d_stats = nullptr;
+    uint64_t rng[4] = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 7};
+};
+
+static SacState* sac_of(fsrl_ctx* c) { return reinterpret_cast<SacState*>(c->sac); }
+
+static void sac_layout(fsrl_ctx* c, SacState* s) {
+    const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim, H = c->cfg.hidden, Din = Do + Da;
+    // ---- actor: device W3 = [Wmu ; Wsig], b3 = [bmu ; bsig]
+    {
+        ModelDesc& md = s->mda;
+        md.Do = Do; md.Da = Da; md.H = H; md.n_nets = 1;
+        int dev = 0, api = 0;
+        auto place = [&](int n) { int o = dev; dev = round_up(dev + n, 64); return o; };
+        NetOff& no = md.net[0];
+        no.sigma = -1; no.out = 2 * Da; no.begin = 0;
+        no.W1 = place(H * Do); no.b1 = place(H); no.W2 = place(H * H); no.b2 = place(H);
+        no.W3 = place(2 * Da * H); no.b3 = place(2 * Da);
+        no.end = dev;
+        auto add = [&](int dev_off, int n) { s->tmap_a.push_back(TensorMap{api, dev_off, n}); api += n; };
+        add(no.W1, H * Do); add(no.b1, H); add(no.W2, H * H); add(no.b2, H);
+        add(no.W3, Da * H); add(no.b3, Da);                       // mu head
+        add(no.W3 + Da * H, Da * H); add(no.b3 + Da, Da);         // sigma head
+        s->na_api = api; s->na_dev = round_up(dev, 1024);
+    }
+    // ---- four Q-nets: device order Qr1, Qr2, Qc1, Qc2 ; API order per DoubleCritic: pre1 pre2 last1 last2
+    {
+        ModelDesc& md = s->mdq;
+        md.Do = Din; md.Da = Da; md.H = H; md.n_nets = 4;
+        int dev = 0;
+        auto place = [&](int n) { int o = dev; dev = round_up(dev + n, 64); return o; };
+        for (int n = 0; n < 4; ++n) {
+            NetOff& no = md.net[n];
+            no.sigma = -1; no.out = 1; no.begin = dev;
+            no.W1 = place(H * Din); no.b1 = place(H); no.W2 = place(H * H); no.b2 = place(H);
+            no.W3 = place(H); no.b3 = place(1);
+            no.end = dev;
+        }
+        int api = 0;
+        auto add = [&](int dev_off, int n) { s->tmap_q.push_back(TensorMap{api, dev_off, n}); api += n; };
+        for (int i = 0; i < 2; ++i) {
+            for (int j = 0; j < 2; ++j) {
+                const NetOff& no = md.net[2 * i + j];
+                add(no.W1, H * Din); add(no.b1, H); add(no.W2, H * H); add(no.b2, H);
+            }
+            for (int j = 0; j < 2; ++j) { const NetOff& no = md.net[2 * i + j]; add(no.W3, H); add(no.b3, 1); }
+        }
+        s->nq_api = api; s->nq_dev = round_up(dev, 1024);
+    }
+}
+
+extern "C" int fsrl_sac_init(fsrl_ctx* c, const fsrl_sac_config* cfg) {
+    CHECK_ARG(c && cfg, "null argument");
+    CHECK_ARG(c->cfg.algo == FSRL_ALGO_SAC_LAG, "context was not created with FSRL_ALGO_SAC_LAG");
+    CHECK_ARG(c->cfg.act_dim <= 8, "SAC actor needs 2*act_dim <= 16 head outputs");
+    CHECK_ARG(c->cfg.obs_dim + c->cfg.act_dim <= FSRL_MAX_OBS, "obs_dim + act_dim too large");
+    CHECK_ARG(cfg->n_step >= 1 && cfg->n_step <= 8, "n_step must be in [1, 8]");
+    CHECK_ARG(cfg->tau >= 0.0f && cfg->tau <= 1.0f, "tau should be in [0, 1]");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->sac) sac_free(c);
+    SacState* s = new SacState();
+    c->sac = s;
+    s->cfg = *cfg;
+    sac_layout(c, s);
+    const size_t ab = (size_t)s->na_dev * 4, qb = (size_t)s->nq_dev * 4;
+    for (float** p : {&s->PA, &s->MA, &s->VA, &s->GA}) { HIPCHK(hipMalloc(p, ab)); HIPCHK(hipMemset(*p, 0, ab)); }
+    for (float** p : {&s->PQ, &s->PQT, &s->MQ, &s->VQ, &s->GQ}) { HIPCHK(hipMalloc(p, qb)); HIPCHK(hipMemset(*p, 0, qb)); }
+    HIPCHK(hipMalloc(&s->sc, sizeof(SacScalars)));
+    SacScalars init{cfg->auto_alpha ? 1.0f : cfg->alpha, 0.0f, 0.0f, 0.0f, 0, 0};
+    HIPCHK(hipMemcpy(s->sc, &init, sizeof(init), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&s->d_stats, FSRL_SAC_NSTATS_K * 4));
+    return 0;
+}
+
+static void sac_free(fsrl_ctx* c) {
+    SacState* s = sac_of(c);
+    if (!s) return;
+    for (void* p : {(void*)s->PA, (void*)s->MA, (void*)s->VA, (void*)s->GA, (void*)s->PQ, (void*)s->PQT, (void*)s->MQ,
+                    (void*)s->VQ, (void*)s->GQ, (void*)s->sc, (void*)s->d_idx, (void*)s->d_chain, (void*)s->d_end,
+                    (void*)s->XQ, (void*)s->OBS, (void*)s->OBSN, (void*)s->XN, (void*)s->XP, (void*)s->eps_t,
+                    (void*)s->eps_p, (void*)s->LPN, (void*)s->LP, (void*)s->QT, (void*)s->QP, (void*)s->Y,
+                    (void*)s->DA, (void*)s->A1, (void*)s->A2, (void*)s->D1, (void*)s->D2, (void*)s->DO,
+                    (void*)s->stq, (void*)s->stdin_, (void*)s->stpi, (void*)s->d_stats})
+        if (p) (void)hipFree(p);
+    for (void* p : {(void*)s->h_idx, (void*)s->h_chain, (void*)s->h_end, (void*)s->h_eps})
+        if (p) (void)hipHostFree(p);
+    delete s;
+    c->sac = nullptr;
+}
+
+extern "C" int64_t fsrl_sac_param_count(const fsrl_ctx* c, int32_t which) {
+    if (!c || !c->sac) return 0;
+    const SacState* s = reinterpret_cast<const SacState*>(c->sac);
+    return which == 0 ? s->na_api : s->nq_api;
+}
+
+static int sac_copy(fsrl_ctx* c, const std::vector<TensorMap>& tm, int n_dev, float* dev, const float* in, float* out) {
+    std::vector<float> tmp((size_t)n_dev, 0.0f);
+    HIPCHK(hipStreamSynchronize(c->compute));
+    if (in) {
+        for (const TensorMap& t : tm) memcpy(&tmp[t.dev_off], in + t.api_off, (size_t)t.n * 4);
+        HIPCHK(hipMemcpy(dev, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(hipMemcpy(tmp.data(), dev, tmp.size() * 4, hipMemcpyDeviceToHost));
+        for (const TensorMap& t : tm) memcpy(out + t.api_off, &tmp[t.dev_off], (size_t)t.n * 4);
+    }
+    return 0;
+}
+
+extern "C" int fsrl_sac_params_set(fsrl_ctx* c, const float* actor, int64_t na, const float* critics, int64_t nc,
+                                   float log_alpha) {
+    CHECK_ARG(c && actor && critics, "null argument");
+    SacState* s = sac_of(c);
+    if (!s) return fail(FSRL_ESTATE, "fsrl_sac_init first");
+    CHECK_ARG(na == s->na_api && nc == s->nq_api, "expected %d actor / %d critic parameters", s->na_api, s->nq_api);
+    HIPCHK(hipSetDevice(c->device));
+    int rc = sac_copy(c, s->tmap_a, s->na_dev, s->PA, actor, nullptr);
+    if (rc) return rc;
+    rc = sac_copy(c, s->tmap_q, s->nq_dev, s->PQ, critics, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(s->PQT, s->PQ, (size_t)s->nq_dev * 4, hipMemcpyDeviceToDevice));   // critics_old = deepcopy
+    for (float* p : {s->MA, s->VA}) HIPCHK(hipMemset(p, 0, (size_t)s->na_dev * 4));
+    for (float* p : {s->MQ, s->VQ}) HIPCHK(hipMemset(p, 0, (size_t)s->nq_dev * 4));
+    s->t_actor = s->t_critic = 0;
+    SacScalars init{s->cfg.auto_alpha ? std::exp(log_alpha) : s->cfg.alpha, log_alpha, 0.0f, 0.0f, 0, 0};
+    HIPCHK(hipMemcpy(s->sc, &init, sizeof(init), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int fsrl_sac_params_get(fsrl_ctx* c, int32_t which, float* out, int64_t n, float* alpha_out) {
+    CHECK_ARG(c && out, "null argument");
+    SacState* s = sac_of(c);
+    if (!s) return fail(FSRL_ESTATE, "fsrl_sac_init first");
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if (which == 0) { CHECK_ARG(n == s->na_api, "bad size"); rc = sac_copy(c, s->tmap_a, s->na_dev, s->PA, nullptr, out); }
+    else { CHECK_ARG(n == s->nq_api, "bad size"); rc = sac_copy(c, s->tmap_q, s->nq_dev, which == 1 ? s->PQ : s->PQT, nullptr, out); }
+    if (rc) return rc;
+    if (alpha_out) {
+        SacScalars sc;
+        HIPCHK(hipMemcpy(&sc, s->sc, sizeof(sc), hipMemcpyDeviceToHost));
+        *alpha_out = s->cfg.auto_alpha ? sc.alpha : s->cfg.alpha;
+    }
+    return 0;
+}
+
+static int sac_alloc_batch(fsrl_ctx* c, SacState* s, int B) {
+    s->n_tiles = (B + 15) / 16;
+    if (B <= s->cap_B) return 0;
+    HIPCHK(hipStreamSynchronize(c->compute));
+    const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim, Din = Do + Da, H = c->cfg.hidden, ns = s->cfg.n_step;
+    const size_t Bp = (size_t)s->n_tiles * 16 + 64;
+    auto re = [&](auto** p, size_t bytes) -> int {
+        if (*p) HIPCHK(hipFree(*p));
+        *p = nullptr;
+        HIPCHK(hipMalloc(p, bytes));
+        HIPCHK(hipMemset(*p, 0, bytes));
+        return 0;
+    };
+    auto reh = [&](auto** p, size_t bytes) -> int {
+        if (*p) HIPCHK(hipHostFree(*p));
+        *p = nullptr;
+        HIPCHK(hipHostMalloc(p, bytes));
+        return 0;
+    };
+    int rc = 0;
+    rc |= re(&s->d_idx, Bp * 4); rc |= re(&s->d_chain, Bp * ns * 4); rc |= re(&s->d_end, Bp * ns);
+    rc |= reh(&s->h_idx, Bp * 4); rc |= reh(&s->h_chain, Bp * ns * 4); rc |= reh(&s->h_end, Bp * ns);
+    rc |= reh(&s->h_eps, Bp * Da * 4 * 2);
+    rc |= re(&s->XQ, Bp * Din * 4); rc |= re(&s->XN, Bp * Din * 4); rc |= re(&s->XP, Bp * Din * 4);
+    rc |= re(&s->OBS, Bp * Do * 4); rc |= re(&s->OBSN, Bp * Do * 4);
+    rc |= re(&s->eps_t, Bp * Da * 4); rc |= re(&s->eps_p, Bp * Da * 4);
+    rc |= re(&s->LPN, Bp * 4); rc |= re(&s->LP, Bp * 4); rc |= re(&s->QT, 4 * Bp * 4); rc |= re(&s->QP, 4 * Bp * 4);
+    rc |= re(&s->Y, 2 * Bp * 4); rc |= re(&s->DA, 4 * Bp * Da * 4);
+    rc |= re(&s->A1, 4 * Bp * H * 4); rc |= re(&s->A2, 4 * Bp * H * 4); rc |= re(&s->D1, 4 * Bp * H * 4);
+    rc |= re(&s->D2, 4 * Bp * H * 4); rc |= re(&s->DO, 4 * Bp * FSRL_DOW * 4);
+    rc |= re(&s->stq, (size_t)(s->n_tiles + 4) * 4 * FB_NSTAT * 4); rc |= re(&s->stdin_, (size_t)(s->n_tiles + 4) * 4 * FB_NSTAT * 4);
+    rc |= re(&s->stpi, (size_t)(s->n_tiles + 4) * FB_NSTAT * 4);
+    if (rc) return FSRL_EHIP;
+    s->cap_B = B;
+    return 0;
+}
+
+// tianshou ReplayBuffer.next inside the owning sub-buffer
+static inline int64_t store_next(const fsrl_ctx* c, int64_t idx) {
+    const int64_t e = idx / c->sub_size, local = idx % c->sub_size;
+    const EnvBook& eb = c->env[(size_t)e];
+    const bool end = c->h_flags[(size_t)idx] != 0 || local == eb.last_index;
+    if (end || eb.size == 0) return idx;
+    return e * c->sub_size + (local + 1) % eb.size;
+}
+static inline bool store_end_flag(const fsrl_ctx* c, int64_t idx) {
+    if (c->h_flags[(size_t)idx] != 0) return true;
+    const int64_t e = idx / c->sub_size, local = idx % c->sub_size;
+    const EnvBook& eb = c->env[(size_t)e];
+    return eb.size > 0 && local == (eb.index - 1 + eb.size) % eb.size;   // unfinished tail
+}
+
+static double xo_uniform(uint64_t* st) { return (double)(xoshiro_next(st) >> 11) * (1.0 / 9007199254740992.0); }
+static float xo_normal(uint64_t* st) {
+    double u1 = xo_uniform(st), u2 = xo_uniform(st);
+    if (u1 < 1e-300) u1 = 1e-300;
+    return (float)(std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2));
+}
+
+static int sac_q_launch(fsrl_ctx* c, SacState* s, const float* params, const float* X, int mode, float cr, float cc,
+                        float* statp, int B) {
+    FbArgs a{};
+    a.obs = X; a.rd = nullptr; a.A1 = s->A1; a.A2 = s->A2; a.D1 = s->D1; a.D2 = s->D2; a.DO = s->DO; a.statp = statp;
+    a.N = B; a.rows_pad = s->n_tiles * 16; a.mode = mode; a.net0 = 0; a.cr = cr; a.cc = cc; a.max_action = 1.0f;
+    a.tgt = s->Y; a.qout = (mode == FB_MODE_Q_FWD && params == s->PQT) ? s->QT : s->QP; a.qin = s->QP; a.da_out = s->DA;
+    a.act_cols = c->cfg.act_dim;
+    return dispatch_H(c->cfg.hidden, [&](auto hc) {
+        constexpr int H = decltype(hc)::value;
+        hipLaunchKernelGGL(fb_tile_kernel<H>, dim3(s->n_tiles, 4), dim3(4 * H), 0, c->compute, params, s->mdq, a);
+        HIPCHK(hipGetLastError());
+        return 0;
+    });
+}
+
+static int sac_wgrad(fsrl_ctx* c, SacState* s, const ModelDesc& md, int ny, const float* X, float* out, int B) {
+    FbWgradArgs wa{};
+    const size_t H = c->cfg.hidden, rp = (size_t)s->n_tiles * 16;
+    for (int y = 0; y < ny; ++y) {
+        FbWgradNet& wn = wa.nets[y];
+        const size_t nb = (size_t)y * rp;
+        wn.w2_ya = s->D2 + nb * H; wn.w2_xa = s->A1 + nb * H; wn.w2_yb = nullptr; wn.w2_xb = nullptr;
+        wn.w1_y = s->D1 + nb * H; wn.w3_xa = s->A2 + nb * H; wn.w3_ya = s->DO + nb * FSRL_DOW;
+        wn.w3_xb = nullptr; wn.w3_yb = nullptr; wn.b1_src = s->D1 + nb * H; wn.b2_src = s->D2 + nb * H;
+        wn.do_src = s->DO + nb * FSRL_DOW; wn.net = y;
+    }
+    wa.obs = X; wa.out = out; wa.rows = (int)rp; wa.N = B;
+    return dispatch_H(c->cfg.hidden, [&](auto hc) {
+        constexpr int HH = decltype(hc)::value;
+        constexpr int NB = (HH / 32) * (HH / 32) + HH / 32 + 1;
+        hipLaunchKernelGGL(fb_wgrad_kernel<HH>, dim3(NB, ny), dim3(1024), 0, c->compute, md, wa);
+        HIPCHK(hipGetLastError());
+        return 0;
+    });
+}
+
+static void adam_launch(fsrl_ctx* c, float* P, float* M, float* V, const float* G, int n, float lr, int64_t t) {
+    const double b1 = c->cfg.beta1, b2 = c->cfg.beta2;
+    const double bc1 = 1.0 - std::pow(b1, (double)t), bc2 = 1.0 - std::pow(b2, (double)t);
+    hipLaunchKernelGGL(adam_range_kernel, dim3((n + 255) / 256), dim3(256), 0, c->compute, P, M, V, G, 0, n, 0.0f,
+                       (float)(1.0 - b1), c->cfg.beta2, (float)(1.0 - b2), (float)((double)lr / bc1),
+                       (float)std::sqrt(bc2), c->cfg.adam_eps);
+}
+
+extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, const float* eps_target,
+                               const float* eps_pi, uint64_t seed, const double* lagrangians, double rescaling,
+                               float* stats_out) {
+    CHECK_ARG(c, "null ctx");
+    SacState* s = sac_of(c);
+    if (!s) return fail(FSRL_ESTATE, "fsrl_sac_init first");
+    CHECK_ARG(B >= 1, "batch_size must be >= 1");
+    const int64_t stored = fsrl_store_len(c);
+    CHECK_ARG(stored > 0, "empty replay store");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = flush_stage(c);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->store_ready, c->side));
+    HIPCHK(hipStreamWaitEvent(c->compute, c->store_ready, 0));
+    rc = sac_alloc_batch(c, s, B);
+    if (rc) return rc;
+    hipStream_t st = c->compute;
+    HIPCHK(hipStreamSynchronize(st));          // pinned staging of the previous update has landed
+    const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim, ns = s->cfg.n_step;
+    if (seed) { s->rng[0] ^= seed; s->rng[1] += seed * 0x9E3779B97F4A7C15ull; }
+    // ---- indices: given (parity) or uniform over the stored rows (perf)
+    for (int b = 0; b < B; ++b) {
+        int64_t idx;
+        if (indices) {
+            idx = indices[b];
+            CHECK_ARG(idx >= 0 && idx < c->maxsize, "index %lld out of range", (long long)idx);
+        } else {
+            int64_t k = (int64_t)(xo_uniform(s->rng) * (double)stored);
+            if (k >= stored) k = stored - 1;
+            int e = 0;
+            while (k >= c->env[(size_t)e].size) { k -= c->env[(size_t)e].size; ++e; }
+            idx = (int64_t)e * c->sub_size + k;
+        }
+        s->h_idx[b] = (int)idx;
+        int64_t cur = idx;
+        for (int n = 0; n < ns; ++n) {          // indices[n] = buffer.next(indices[n-1])
+            if (n > 0) cur = store_next(c, cur);
+            s->h_chain[(size_t)n * B + b] = (int)cur;
+            s->h_end[(size_t)n * B + b] = store_end_flag(c, cur) ? 1 : 0;
+        }
+    }
+    float* he_t = s->h_eps; float* he_p = s->h_eps + (size_t)B * Da;
+    for (size_t i = 0; i < (size_t)B * Da; ++i) {
+        he_t[i] = eps_target ? eps_target[i] : xo_normal(s->rng);
+        he_p[i] = eps_pi ? eps_pi[i] : xo_normal(s->rng);
+    }
+    HIPCHK(hipMemcpyAsync(s->d_idx, s->h_idx, (size_t)B * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->d_chain, s->h_chain, (size_t)B * ns * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->d_end, s->h_end, (size_t)B * ns, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->eps_t, he_t, (size_t)B * Da * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->eps_p, he_p, (size_t)B * Da * 4, hipMemcpyHostToDevice, st));
+    const float lam = (s->cfg.use_lagrangian && lagrangians) ? (float)lagrangians[0] : 0.0f;
+    const float resc = (float)rescaling;
+    // ---- gather
+    SacGatherArgs ga{};
+    ga.st = c->st; ga.idx = s->d_idx; ga.term = s->d_chain + (size_t)(ns - 1) * B; ga.XQ = s->XQ; ga.OBS = s->OBS;
+    ga.OBSN = s->OBSN; ga.XN = s->XN; ga.XP = s->XP; ga.B = B; ga.Do = Do; ga.Da = Da;
+    hipLaunchKernelGGL(sac_gather_kernel, dim3(std::min(1024, (B * (Do + Da) + 255) / 256)), dim3(256), 0, st, ga);
+    HIPCHK(hipGetLastError());
+    // ---- target: a', log pi' at s_{t+n}; target Q-nets; float64 n-step return
+    auto actor_launch = [&](const float* obs, const float* eps, float* X, float* lp, int mode) {
+        SacActorArgs aa{};
+        aa.obs = obs; aa.eps = eps; aa.X = X; aa.lp_out = lp; aa.DA = s->DA; aa.sc = s->sc; aa.A1 = s->A1; aa.A2 = s->A2;
+        aa.D1 = s->D1; aa.D2 = s->D2; aa.DO = s->DO; aa.statp = s->stpi; aa.B = B; aa.mode = mode; aa.rescale = resc;
+        aa.auto_alpha = s->cfg.auto_alpha; aa.alpha_fixed = s->cfg.alpha;
+        return dispatch_H(c->cfg.hidden, [&](auto hc) {
+            constexpr int H = decltype(hc)::value;
+            hipLaunchKernelGGL(sac_actor_tile_kernel<H>, dim3(s->n_tiles), dim3(4 * H), 0, st, s->PA, s->mda, aa);
+            HIPCHK(hipGetLastError());
+            return 0;
+        });
+    };
+    rc = actor_launch(s->OBSN, s->eps_t, s->XN, s->LPN, SAC_A_FWD);
+    if (rc) return rc;
+    rc = sac_q_launch(c, s, s->PQT, s->XN, FB_MODE_Q_FWD, 0.f, 0.f, s->stq, B);
+    if (rc) return rc;
+    SacNstepArgs na{};
+    na.QT = s->QT; na.lpn = s->LPN; na.chain = s->d_chain; na.endbits = s->d_end; na.rew = c->st.rew; na.cost = c->st.cost;
+    na.flags = c->st.flags; na.sc = s->sc; na.Y = s->Y; na.B = B; na.n_step = ns; na.gamma = c->cfg.gamma;
+    na.auto_alpha = s->cfg.auto_alpha; na.alpha_fixed = s->cfg.alpha;
+    hipLaunchKernelGGL(sac_nstep_kernel, dim3((B + 255) / 256), dim3(256), 0, st, na);
+    HIPCHK(hipGetLastError());
+    // ---- critic step (all four Q-nets, one Adam)
+    rc = sac_q_launch(c, s, s->PQ, s->XQ, FB_MODE_Q_TRAIN, 0.f, 0.f, s->stq, B);
+    if (rc) return rc;
+    rc = sac_wgrad(c, s, s->mdq, 4, s->XQ, s->GQ, B);
+    if (rc) return rc;
+    s->t_critic += 1;
+    adam_launch(c, s->PQ, s->MQ, s->VQ, s->GQ, s->nq_dev, s->cfg.critic_lr, s->t_critic);
+    // ---- actor step: a ~ pi(s), Q(s, a) with the UPDATED critics, dL/da, actor backward
+    rc = actor_launch(s->OBS, s->eps_p, s->XP, s->LP, SAC_A_FWD);
+    if (rc) return rc;
+    rc = sac_q_launch(c, s, s->PQ, s->XP, FB_MODE_Q_FWD, 0.f, 0.f, s->stdin_, B);
+    if (rc) return rc;
+    rc = sac_q_launch(c, s, s->PQ, s->XP, FB_MODE_Q_DIN, -resc, s->cfg.use_lagrangian ? resc * lam : 0.0f, s->stdin_, B);
+    if (rc) return rc;
+    rc = actor_launch(s->OBS, s->eps_p, s->XP, s->LP, SAC_A_BWD);
+    if (rc) return rc;
+    rc = sac_wgrad(c, s, s->mda, 1, s->OBS, s->GA, B);
+    if (rc) return rc;
+    s->t_actor += 1;
+    adam_launch(c, s->PA, s->MA, s->VA, s->GA, s->na_dev, s->cfg.actor_lr, s->t_actor);
+    // ---- alpha step + logged stats, then Polyak
+    SacFinalArgs fa{};
+    fa.statp_q = s->stq; fa.statp_din = s->stdin_; fa.statp_pi = s->stpi; fa.sc = s->sc; fa.stats = s->d_stats;
+    fa.n_tiles = s->n_tiles; fa.B = B; fa.rescale = resc; fa.lam = lam; fa.target_entropy = s->cfg.target_entropy;
+    fa.alpha_lr = s->cfg.alpha_lr; fa.beta1 = c->cfg.beta1; fa.beta2 = c->cfg.beta2; fa.adam_eps = c->cfg.adam_eps;
+    fa.alpha_fixed = s->cfg.alpha; fa.auto_alpha = s->cfg.auto_alpha; fa.use_lagrangian = s->cfg.use_lagrangian;
+    hipLaunchKernelGGL(sac_finalize_kernel, dim3(1), dim3(64), 0, st, fa);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(polyak_kernel, dim3(256), dim3(256), 0, st, s->PQT, s->PQ, s->nq_dev, s->cfg.tau,
+                       (float)(1.0 - (double)s->cfg.tau));
+    HIPCHK(hipGetLastError());
+    if (stats_out) {
+        HIPCHK(hipMemcpyAsync(stats_out, s->d_stats, FSRL_SAC_NSTATS_K * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+extern "C" int fsrl_sac_actor_forward(fsrl_ctx* c, const float* obs, int32_t k, float* mu_out, float* sigma_out) {
+    CHECK_ARG(c && obs && mu_out && sigma_out, "null argument");
+    SacState* s = sac_of(c);
+    if (!s) return fail(FSRL_ESTATE, "fsrl_sac_init first");
+    if (k <= 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    // run the actor tile kernel with eps = 0: the action columns then hold tanh(mu); mu / sigma are
+    // recovered on the host from a second tiny pass would cost more than the host MLP -- the
+    // collector-time actor therefore stays on the host mirror (fsrl_amd/policy); this entry point
+    // returns the device parameters' mu and sigma through mlp_infer_kernel's head outputs.
+    const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim;
+    const size_t ob = (size_t)k * Do * 4, ub = (size_t)k * 2 * Da * 4;
+    int rc = ensure_scratch(c, ob + ub + 512);
+    if (rc) return rc;
+    float* d_obs = (float*)c->scratch;
+    float* d_out = (float*)((char*)c->scratch + (ob + 255) / 256 * 256);
+    HIPCHK(hipMemcpyAsync(d_obs, obs, ob, hipMemcpyHostToDevice, c->compute));
+    InferArgs ia{};
+    ia.obs = d_obs; ia.obs_next = d_obs; ia.N = k; ia.C = 0; ia.max_action = 1.0f; ia.raw_out = d_out; ia.raw_cols = 2 * Da;
+    rc = dispatch_H(c->cfg.hidden, [&](auto hc) {
+        constexpr int H = decltype(hc)::value;
+        hipLaunchKernelGGL(mlp_infer_kernel<H>, dim3((k + 15) / 16, 1), dim3(4 * H), 0, c->compute, s->PA, s->mda, ia);
+        HIPCHK(hipGetLastError());
+        return 0;
+    });
+    if (rc) return rc;
+    std::vector<float> raw((size_t)k * 2 * Da);
+    HIPCHK(hipMemcpyAsync(raw.data(), d_out, ub, hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    for (int r = 0; r < k; ++r)
+        for (int d = 0; d < Da; ++d) {
+            mu_out[(size_t)r * Da + d] = raw[(size_t)r * 2 * Da + d];
+            const float l = std::min(std::max(raw[(size_t)r * 2 * Da + Da + d], -20.0f), 2.0f);
+            sigma_out[(size_t)r * Da + d] = std::exp(l);
+        }
     return 0;
 }

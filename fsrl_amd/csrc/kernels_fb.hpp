@@ -16,6 +16,9 @@
 #define FB_MODE_SUR 1    // actor: d/dtheta mean((cr*A_r + cc*A_c) * ratio)
 #define FB_MODE_KL 2     // actor: d/dtheta mean KL(N(mu_old, sigma_old) || N(mu, sigma))
 #define FB_MODE_EVAL 3   // actor: statistics only (line search), nothing stored
+#define FB_MODE_Q_TRAIN 4 // SAC Q-nets: d/dtheta mean((Q - y_i)^2), i = net >> 1 ; also writes Q
+#define FB_MODE_Q_FWD 5   // SAC Q-nets: forward only, writes Q
+#define FB_MODE_Q_DIN 6   // SAC Q-nets: backward to the action input with min-routing coefficients
 #define FB_NSTAT 8
 
 struct FbArgs {
@@ -25,9 +28,75 @@ struct FbArgs {
     float* statp;         // [n_tiles][nets][FB_NSTAT]
     int N, rows_pad;      // rows_pad = n_tiles*16 (stride of the side buffers per net)
     int mode, net0;       // first network handled (0 = actor, 1 = first critic)
-    float cr, cc;         // surrogate coefficients (FB_MODE_SUR)
+    float cr, cc;         // surrogate coefficients (FB_MODE_SUR); Q_DIN: cr = dL/dQr scale, cc = dL/dQc scale
     float max_action;
+    // SAC Q-net modes
+    const float* tgt;     // [2][N] regression targets y_i           (Q_TRAIN)
+    float* qout;          // [nets][N] Q values written              (Q_TRAIN, Q_FWD)
+    const float* qin;     // [nets][N] Q values of all nets          (Q_DIN: min routing)
+    float* da_out;        // [nets][N][act_cols] dL/da contributions (Q_DIN)
+    int act_cols;         // number of action columns at the end of x
 };
+
+// Activation backward of one tile given sm.dout: spills relu(z1), relu(z2), dz2, dout, dz1 for the
+// weight-gradient kernel.  wb = this wave's column slice of W2 (lane (li,q): W2[16jc+4q+s][16w+li]).
+// keep_dz1: also leave dz1 in sm.d2 (used for input gradients).  Always leaves dz1 in sm.d2 when
+// `FB_MODE_Q_DIN` callers ask for it via the trailing flag == true or read it after a barrier.
+template <int H>
+__device__ __forceinline__ void tile_backward(TileSmem<H>& sm, const NetOff no, const float (&wb)[H / 16][4],
+                                              float* __restrict__ A1, float* __restrict__ A2,
+                                              float* __restrict__ D1, float* __restrict__ D2,
+                                              float* __restrict__ DOb, const int tid, const bool) {
+    constexpr int LD = TileSmem<H>::LD;
+    constexpr int NT = TileGeom<H>::NT;
+    constexpr int H4 = H / 4;
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+    for (int e = tid; e < 16 * H4; e += NT) {
+        const int i = e / H4, c4 = e - i * H4;
+        *reinterpret_cast<f32x4*>(&A1[(size_t)i * H + 4 * c4]) = *reinterpret_cast<const f32x4*>(&sm.h1[i * LD + 4 * c4]);
+        *reinterpret_cast<f32x4*>(&A2[(size_t)i * H + 4 * c4]) = *reinterpret_cast<const f32x4*>(&sm.h2[i * LD + 4 * c4]);
+    }
+    {   // dz2 = (dout @ W3) * relu'(z2)
+        const int k = tid % H, rg = tid / H;
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int o = 0; o < no.out; ++o) {
+            const float w = sm.w3[o * H + k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = fmaf(sm.dout[(4 * rg + e) * FSRL_DOW + o], w, g[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * rg + e;
+            sm.d2[i * LD + k] = (sm.h2[i * LD + k] > 0.0f) ? g[e] : 0.0f;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 16 * H4; e += NT) {
+        const int i = e / H4, c4 = e - i * H4;
+        *reinterpret_cast<f32x4*>(&D2[(size_t)i * H + 4 * c4]) = *reinterpret_cast<const f32x4*>(&sm.d2[i * LD + 4 * c4]);
+    }
+    for (int e = tid; e < 16 * FSRL_DOW; e += NT) DOb[e] = sm.dout[e];
+    // dz1 = (dz2 @ W2) * relu'(z1)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* arow = &sm.d2[li * LD + 4 * q];
+#pragma unroll
+    for (int jc = 0; jc < H / 16; ++jc) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * jc);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma_16x16x4(av[s], wb[jc][s], acc);
+    }
+    const int col = wave * 16 + li;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * q + r;
+        v[r] = (sm.h1[i * LD + col] > 0.0f) ? acc[r] : 0.0f;
+        D1[(size_t)i * H + col] = v[r];
+    }
+    __syncthreads();          // every wave is done reading dz2 from sm.d2
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sm.d2[(4 * q + r) * LD + col] = v[r];   // dz1, for input gradients
+}
 
 // ------------------------------------------------------------------------------------------
 template <int H>
@@ -53,7 +122,7 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
     stg.commit(sm, no, Do, tid);
     __syncthreads();
     tile_forward<H>(sm, P, no, Do, tid, wf);
-    const bool backward = (a.mode != FB_MODE_EVAL);
+    const bool backward = (a.mode != FB_MODE_EVAL && a.mode != FB_MODE_Q_FWD);
 
     float wb[H / 16][4];
     if (backward) {
@@ -73,7 +142,7 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
         float st[FB_NSTAT];
 #pragma unroll
         for (int k = 0; k < FB_NSTAT; ++k) st[k] = 0.0f;
-        if (net == 0) {
+        if (net == 0 && a.mode < FB_MODE_Q_TRAIN) {
             float th = 0.f, var = 1.f, df = 0.f, lp = 0.f, klp = 0.f, dmu = 0.f, so2 = 0.f;
             if (d < Da) {
                 th = tanhf(sm.out[i * FSRL_MAX_ACT + d]);
@@ -112,6 +181,24 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
                 st[0] = ratio * ar; st[1] = ratio * ac; st[2] = klrow; st[3] = lpo - logp;
                 st[4] = ar; st[5] = ac;
             }
+        } else if (a.mode >= FB_MODE_Q_TRAIN) {
+            const float qv = sm.out[i * FSRL_MAX_ACT];
+            const int r = row0 + i;
+            if (valid && d == 0) {
+                if (a.mode == FB_MODE_Q_TRAIN) {
+                    const float td = qv - a.tgt[(size_t)(net >> 1) * a.N + r];
+                    sm.dout[i * FSRL_DOW] = 2.0f * td * invN;
+                    st[0] = td * td;
+                    a.qout[(size_t)net * a.N + r] = qv;
+                } else if (a.mode == FB_MODE_Q_FWD) {
+                    a.qout[(size_t)net * a.N + r] = qv;
+                } else {   // Q_DIN: d min(Q1,Q2)/dQ_this with torch's tie rule, times the loss scale
+                    const float mine = a.qin[(size_t)net * a.N + r], other = a.qin[(size_t)(net ^ 1) * a.N + r];
+                    const float w = (mine < other) ? 1.0f : (mine == other ? 0.5f : 0.0f);
+                    sm.dout[i * FSRL_DOW] = w * ((net >> 1) == 0 ? a.cr : a.cc) * invN;
+                    st[0] = fminf(mine, other);
+                }
+            }
         } else {
             const int c = net - 1;
             const float dd = rd[FSRL_RD_RET + c] - sm.out[i * FSRL_MAX_ACT];
@@ -134,59 +221,18 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
     if (!backward) return;
 
     const size_t nb = (size_t)blockIdx.y * a.rows_pad;
-    {   // spill relu(z1), relu(z2)
-        float* __restrict__ A1 = a.A1 + (nb + row0) * H;
-        float* __restrict__ A2 = a.A2 + (nb + row0) * H;
-        constexpr int H4 = H / 4;
-        for (int e = tid; e < 16 * H4; e += NT) {
-            const int i = e / H4, c4 = e - i * H4;
-            *reinterpret_cast<f32x4*>(&A1[(size_t)i * H + 4 * c4]) =
-                *reinterpret_cast<const f32x4*>(&sm.h1[i * LD + 4 * c4]);
-            *reinterpret_cast<f32x4*>(&A2[(size_t)i * H + 4 * c4]) =
-                *reinterpret_cast<const f32x4*>(&sm.h2[i * LD + 4 * c4]);
-        }
-    }
-    {   // dz2 = (dout @ W3) * relu'(z2)
-        const int k = tid % H, rg = tid / H;
-        float g[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int o = 0; o < no.out; ++o) {
-            const float w = sm.w3[o * H + k];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = fmaf(sm.dout[(4 * rg + e) * FSRL_DOW + o], w, g[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = 4 * rg + e;
-            sm.d2[i * LD + k] = (sm.h2[i * LD + k] > 0.0f) ? g[e] : 0.0f;
-        }
-    }
-    __syncthreads();
-    {
-        float* __restrict__ D2 = a.D2 + (nb + row0) * H;
-        constexpr int H4 = H / 4;
-        for (int e = tid; e < 16 * H4; e += NT) {
-            const int i = e / H4, c4 = e - i * H4;
-            *reinterpret_cast<f32x4*>(&D2[(size_t)i * H + 4 * c4]) =
-                *reinterpret_cast<const f32x4*>(&sm.d2[i * LD + 4 * c4]);
-        }
-        float* __restrict__ DOb = a.DO + (nb + row0) * FSRL_DOW;
-        for (int e = tid; e < 16 * FSRL_DOW; e += NT) DOb[e] = sm.dout[e];
-    }
-    {   // dz1 = (dz2 @ W2) * relu'(z1)
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* arow = &sm.d2[li * LD + 4 * q];
-#pragma unroll
-        for (int jc = 0; jc < H / 16; ++jc) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * jc);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc = mfma_16x16x4(av[s], wb[jc][s], acc);
-        }
-        float* __restrict__ D1 = a.D1 + (nb + row0) * H;
-        const int col = wave * 16 + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 4 * q + r;
-            D1[(size_t)i * H + col] = (sm.h1[i * LD + col] > 0.0f) ? acc[r] : 0.0f;
+    tile_backward<H>(sm, no, wb, a.A1 + (nb + row0) * H, a.A2 + (nb + row0) * H, a.D1 + (nb + row0) * H,
+                     a.D2 + (nb + row0) * H, a.DO + (nb + row0) * FSRL_DOW, tid, false);
+    if (a.mode == FB_MODE_Q_DIN) {
+        // input gradient w.r.t. the action columns of x = concat(obs, act):
+        //   da[i][k] = sum_j dz1[i][j] * W1[j][Do_obs + k]       (dz1 left in sm.d2 by tile_backward)
+        __syncthreads();
+        const int Dact = a.act_cols, Dobs = Do - Dact;
+        for (int e = tid; e < 16 * Dact; e += NT) {
+            const int i = e / Dact, kk = e - i * Dact;
+            float s_ = 0.0f;
+            for (int j = 0; j < H; ++j) s_ = fmaf(sm.d2[i * LD + j], P[no.W1 + (size_t)j * Do + Dobs + kk], s_);
+            if (i < n_valid) a.da_out[((size_t)blockIdx.y * a.N + row0 + i) * Dact + kk] = s_;
         }
     }
 }

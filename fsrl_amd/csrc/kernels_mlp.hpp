@@ -191,6 +191,8 @@ struct InferArgs {
     float* mu_out;          // optional [N][Da] (actor_forward API)  may be null
     int N, C;
     float max_action;
+    float* raw_out;         // optional [N][raw_cols] raw head outputs (SAC actor: mu | log sigma)
+    int raw_cols;
 };
 
 #define LOG_SQRT_2PI 0.9189385332046727f
@@ -216,6 +218,13 @@ __global__ __launch_bounds__(4 * H) void mlp_infer_kernel(const float* __restric
     stg.commit(sm, no, md.Do, tid);
     __syncthreads();
     tile_forward<H>(sm, P, no, md.Do, tid, wf);
+    if (a.raw_out) {
+        for (int e = tid; e < n_valid * a.raw_cols; e += TileGeom<H>::NT) {
+            const int i = e / a.raw_cols, o = e - i * a.raw_cols;
+            a.raw_out[(size_t)(row0 + i) * a.raw_cols + o] = sm.out[i * FSRL_MAX_ACT + o];
+        }
+        return;
+    }
     if (tid < n_valid) {
         const int r = row0 + tid;
         if (!is_actor) {

@@ -1,0 +1,242 @@
+// kernels_sac.hpp -- SAC-Lagrangian update kernels (fsrl/policy/sac_lag.py:136-269,
+// fsrl/policy/base_policy.py:453-512,543-567).  The Q-networks run through fb_tile_kernel's
+// Q modes (kernels_fb.hpp); this file holds the replay gather, the tanh-Gaussian actor tile, the
+// float64 n-step target, the scalar bookkeeping (alpha, logged stats) and the Polyak update.
+#pragma once
+#include "kernels_fb.hpp"
+
+#define SAC_LOG_SIG_MIN (-20.0f)
+#define SAC_LOG_SIG_MAX (2.0f)
+#define SAC_F32_EPS 1.1920928955078125e-07f   // np.finfo(np.float32).eps  (sac_lag.py:118)
+#define FSRL_SAC_NSTATS_K 10
+
+// ---- replay gather: rows `idx` (sampled) and `term` (n-step terminal) of the store
+struct SacGatherArgs {
+    StorePtrs st;
+    const int* idx; const int* term;
+    float* XQ;      // [B][Do+Da] concat(obs, act)               (critic update)
+    float* OBS;     // [B][Do]
+    float* OBSN;    // [B][Do]   obs_next at the terminal index
+    float* XN;      // [B][Do+Da] obs part of concat(obs_next_T, a')
+    float* XP;      // [B][Do+Da] obs part of concat(obs, a_pi)
+    int B, Do, Da;
+};
+__global__ void sac_gather_kernel(const SacGatherArgs a) {
+    const int Din = a.Do + a.Da;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < a.B * Din; e += gridDim.x * blockDim.x) {
+        const int r = e / Din, f = e - r * Din;
+        const size_t s = (size_t)a.idx[r], t = (size_t)a.term[r];
+        if (f < a.Do) {
+            const float o = a.st.obs[s * a.Do + f], on = a.st.obs_next[t * a.Do + f];
+            a.XQ[e] = o; a.XP[e] = o; a.XN[e] = on;
+            a.OBS[(size_t)r * a.Do + f] = o; a.OBSN[(size_t)r * a.Do + f] = on;
+        } else {
+            a.XQ[e] = a.st.act[s * a.Da + (f - a.Do)];
+        }
+    }
+}
+
+// ---- scalars that live on the device between updates
+struct SacScalars {
+    float alpha, log_alpha;         // temperature
+    float m, v;                     // Adam moments of log_alpha
+    int t;                          // Adam step count of log_alpha
+    int pad;
+};
+
+// ---- actor tile: a = tanh(mu + sigma*eps), log pi with the tanh correction; optional backward
+#define SAC_A_FWD 0      // write action into X[:, Do:], log pi into lp_out
+#define SAC_A_BWD 1      // forward again + gradient of rescale*(alpha*mean(log pi) + <dL/da, a>)
+struct SacActorArgs {
+    const float* obs;    // [B][Do]
+    const float* eps;    // [B][Da] standard-normal draws (rsample)
+    float* X;            // [B][Do+Da]: action columns written in FWD
+    float* lp_out;       // [B]
+    const float* DA;     // [4][B][Da] dL/da from the Q-nets (BWD)
+    const SacScalars* sc;
+    float* A1; float* A2; float* D1; float* D2; float* DO;   // side buffers (BWD)
+    float* statp;        // [n_tiles][FB_NSTAT]  st[0] = sum log pi
+    int B, mode;
+    float rescale;       // lagrangian rescaling 1/(sum(lambda)+1)
+    int auto_alpha; float alpha_fixed;
+};
+
+template <int H>
+__global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __restrict__ P,
+                                                              const ModelDesc md, const SacActorArgs a) {
+    __shared__ TileSmem<H> sm;
+    constexpr int NT = TileGeom<H>::NT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * 16;
+    const NetOff no = md.net[0];
+    const int Do = md.Do, Da = md.Da;
+    const int n_valid = min(16, a.B - row0);
+    const float invB = 1.0f / (float)a.B;
+
+    TileStage<H> stg;
+    stg.issue(P, no, Do, 0, a.obs + (size_t)row0 * Do, nullptr, n_valid, tid);
+    FwdW2Frag<H> wf;
+    wf.load(P + no.W2, wave, lane);
+    for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
+    stg.commit(sm, no, Do, tid);
+    __syncthreads();
+    tile_forward<H>(sm, P, no, Do, tid, wf);     // sm.out[i][0..Da) = mu, [Da..2Da) = raw log sigma
+
+    float wb[H / 16][4];
+    if (a.mode == SAC_A_BWD) {
+        const float* __restrict__ W2c = P + no.W2 + wave * 16 + li;
+#pragma unroll
+        for (int jc = 0; jc < H / 16; ++jc) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wb[jc][s] = W2c[(size_t)(16 * jc + 4 * q + s) * H];
+        }
+    }
+    const float alpha = a.auto_alpha ? a.sc->alpha : a.alpha_fixed;
+    if (tid < 256) {
+        const int i = tid >> 4, d = tid & 15;
+        const int r = row0 + i;
+        const bool valid = i < n_valid;
+        float lpd = 0.0f, act = 0.0f, sig = 1.0f, ep = 0.0f, one_m = 1.0f, pass = 0.0f;
+        if (valid && d < Da) {
+            const float mu = sm.out[i * FSRL_MAX_ACT + d];
+            const float lraw = sm.out[i * FSRL_MAX_ACT + Da + d];
+            pass = (lraw >= SAC_LOG_SIG_MIN && lraw <= SAC_LOG_SIG_MAX) ? 1.0f : 0.0f;
+            sig = expf(fminf(fmaxf(lraw, SAC_LOG_SIG_MIN), SAC_LOG_SIG_MAX));
+            ep = a.eps[(size_t)r * Da + d];
+            const float u = mu + ep * sig;
+            const float dv = u - mu;
+            act = tanhf(u);
+            one_m = 1.0f - act * act;
+            lpd = (-(dv * dv) / (2.0f * (sig * sig)) - logf(sig) - LOG_SQRT_2PI) - logf(one_m + SAC_F32_EPS);
+        }
+        // log pi = sum_d Normal.log_prob  -  sum_d log(1 - a^2 + eps): two separate sums in the
+        // reference; summed per dim here (difference: fp32 rounding only)
+        float logp = 0.0f;
+        for (int dd = 0; dd < Da; ++dd) logp += __shfl(lpd, (lane & 48) + dd, 64);
+        if (a.mode == SAC_A_FWD) {
+            if (valid && d < Da) a.X[(size_t)r * (Do + Da) + Do + d] = act;
+            if (valid && d == 0) a.lp_out[r] = logp;
+        } else if (valid && d < Da) {
+            float ga = 0.0f;   // dL/da_d summed over the four Q-nets (already scaled)
+#pragma unroll
+            for (int n4 = 0; n4 < 4; ++n4) ga += a.DA[((size_t)n4 * a.B + r) * Da + d];
+            const float c = a.rescale * alpha * invB;                 // weight of log pi in the loss
+            const float sq = 2.0f * act * one_m / (one_m + SAC_F32_EPS);   // d(-log(1-a^2+eps))/du
+            const float dLdu = c * sq + ga * one_m;                   // (+-(u-mu)/sigma^2 cancel)
+            sm.dout[i * FSRL_DOW + d] = dLdu;                         // d/dmu
+            sm.dout[i * FSRL_DOW + Da + d] = (dLdu * ep * sig - c) * pass;   // d/d(raw log sigma)
+        }
+        if (d == 0) sm.w1[i * FB_NSTAT] = valid ? logp : 0.0f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.0f;
+        for (int i = 0; i < 16; ++i) t += sm.w1[i * FB_NSTAT];
+        a.statp[(size_t)blockIdx.x * FB_NSTAT] = t;
+    }
+    if (a.mode != SAC_A_BWD) return;
+    tile_backward<H>(sm, no, wb, a.A1 + (size_t)row0 * H, a.A2 + (size_t)row0 * H, a.D1 + (size_t)row0 * H,
+                     a.D2 + (size_t)row0 * H, a.DO + (size_t)row0 * FSRL_DOW, tid, false);
+}
+
+// ---- n-step target (float64), base_policy.py:453-512 + nstep_return :543-567
+struct SacNstepArgs {
+    const float* QT;        // [4][B] target-net Q(s', a')
+    const float* lpn;       // [B] log pi(a'|s')
+    const int* chain;       // [n_step][B] index chain (host: buffer.next)
+    const uint8_t* endbits; // [n_step][B] end_flag (done | unfinished) at each chain element
+    const double* rew; const double* cost; const uint8_t* flags;   // store columns
+    const SacScalars* sc;
+    float* Y;               // [2][B]
+    int B, n_step;
+    double gamma;
+    int auto_alpha; float alpha_fixed;
+};
+__global__ void sac_nstep_kernel(const SacNstepArgs a) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const float alpha = a.auto_alpha ? a.sc->alpha : a.alpha_fixed;
+    double gpow = 1.0;
+    int gammas = a.n_step;
+    double ret_r = 0.0, ret_c = 0.0;
+    for (int n = a.n_step - 1; n >= 0; --n) {
+        const int now = a.chain[(size_t)n * a.B + b];
+        if (a.endbits[(size_t)n * a.B + b]) { gammas = n + 1; ret_r = 0.0; ret_c = 0.0; }
+        const double tr = a.gamma * ret_r, tc = a.gamma * ret_c;
+        ret_r = a.rew[now] + tr;
+        ret_c = a.cost[now] + tc;
+    }
+    for (int i = 0; i < gammas; ++i) gpow = gpow * a.gamma;          // gamma_buffer[gammas]
+    const int terminal = a.chain[(size_t)(a.n_step - 1) * a.B + b];
+    const bool term = (a.flags[terminal] & 1) != 0;
+    const float lp = alpha * a.lpn[b];
+    for (int i = 0; i < 2; ++i) {
+        float tq = fminf(a.QT[(size_t)(2 * i) * a.B + b], a.QT[(size_t)(2 * i + 1) * a.B + b]) - lp;
+        if (term) tq = 0.0f;
+        const double prod = (double)tq * gpow;
+        const double y = prod + (i == 0 ? ret_r : ret_c);
+        a.Y[(size_t)i * a.B + b] = (float)y;
+    }
+}
+
+// ---- scalar bookkeeping of one update: logged stats, alpha loss + Adam on log_alpha
+struct SacFinalArgs {
+    const float* statp_q;    // [n_tiles][4][FB_NSTAT]   st0 = sum td^2            (critic launch)
+    const float* statp_din;  // [n_tiles][4][FB_NSTAT]   st0 = sum min(Q1,Q2)      (actor-step Q launch)
+    const float* statp_pi;   // [n_tiles][FB_NSTAT]      st0 = sum log pi
+    SacScalars* sc;
+    float* stats;            // [FSRL_SAC_NSTATS_K]
+    int n_tiles, B;
+    float rescale, lam, target_entropy, alpha_lr, beta1, beta2, adam_eps, alpha_fixed;
+    int auto_alpha, use_lagrangian;
+};
+__global__ __launch_bounds__(64) void sac_finalize_kernel(const SacFinalArgs a) {
+    const int lane = threadIdx.x;
+    // lanes 0..3: td^2 of net l ; 4..7: min-Q sums of net l-4 ; 8: log pi
+    double s = 0.0;
+    for (int t = 0; t < a.n_tiles; ++t) {
+        if (lane < 4) s += (double)a.statp_q[((size_t)t * 4 + lane) * FB_NSTAT];
+        else if (lane < 8) s += (double)a.statp_din[((size_t)t * 4 + (lane - 4)) * FB_NSTAT];
+        else if (lane == 8) s += (double)a.statp_pi[(size_t)t * FB_NSTAT];
+    }
+    const float v = (float)(s / (double)a.B);
+    const float q_r1 = __shfl(v, 0, 64), q_r2 = __shfl(v, 1, 64), q_c1 = __shfl(v, 2, 64), q_c2 = __shfl(v, 3, 64);
+    const float minqr = __shfl(v, 4, 64), minqc = __shfl(v, 6, 64), mlogp = __shfl(v, 8, 64);
+    if (lane == 0) {
+        SacScalars sc = *a.sc;
+        const float alpha = a.auto_alpha ? sc.alpha : a.alpha_fixed;
+        const float q0 = q_r1 + q_r2, q1 = q_c1 + q_c2;
+        const float actor_rew = alpha * mlogp - minqr;
+        const float actor_safety = a.use_lagrangian ? minqc * a.lam : 0.0f;
+        const float actor_total = a.rescale * (actor_rew + actor_safety);
+        float alpha_loss = 0.0f, alpha_value = alpha;
+        if (a.auto_alpha) {
+            const float lpm = mlogp + a.target_entropy;
+            alpha_loss = -(sc.log_alpha * lpm);
+            const float g = -lpm;                                   // d alpha_loss / d log_alpha
+            sc.t += 1;
+            sc.m = sc.m + (float)(1.0 - (double)a.beta1) * (g - sc.m);
+            sc.v = sc.v * a.beta2;
+            sc.v = sc.v + ((float)(1.0 - (double)a.beta2) * g) * g;
+            const double bc1 = 1.0 - pow((double)a.beta1, (double)sc.t), bc2 = 1.0 - pow((double)a.beta2, (double)sc.t);
+            const float step_size = (float)((double)a.alpha_lr / bc1);
+            const float denom = sqrtf(sc.v) / (float)sqrt(bc2) + a.adam_eps;
+            sc.log_alpha = sc.log_alpha + (-step_size * sc.m) / denom;
+            sc.alpha = expf(sc.log_alpha);
+            alpha_value = sc.alpha;
+            *a.sc = sc;
+        }
+        float* o = a.stats;
+        o[0] = a.rescale; o[1] = a.lam; o[2] = actor_safety; o[3] = alpha_loss; o[4] = alpha_value;
+        o[5] = actor_rew; o[6] = actor_total; o[7] = q0; o[8] = q1; o[9] = q0 + q1;
+    }
+}
+
+// target <- tau * source + (1 - tau) * target      (BasePolicy.soft_update, base_policy.py:220-224)
+__global__ void polyak_kernel(float* __restrict__ tgt, const float* __restrict__ src, int n, float tau,
+                              float one_minus_tau) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        tgt[i] = tau * src[i] + one_minus_tau * tgt[i];
+}

@@ -243,6 +243,49 @@ class Engine:
                                             float(rescaling), int(repeat), _ptr(out, _f32p)))
         return out
 
+    # ---------------------------------------------------------------- SAC-Lagrangian
+    def sac_init(self, actor_lr=5e-4, critic_lr=1e-3, alpha_lr=3e-4, tau=0.05, alpha=0.005,
+                 target_entropy=None, n_step=2, auto_alpha=True, use_lagrangian=True):
+        te = -float(self.cfg.act_dim) if target_entropy is None else float(target_entropy)
+        cfg = _lib.SacConfig(actor_lr, critic_lr, alpha_lr, tau, alpha, te, int(n_step), int(auto_alpha),
+                             int(use_lagrangian))
+        _lib.check(self.lib.fsrl_sac_init(self._ctx, C.byref(cfg)))
+        self.n_sac_actor = int(self.lib.fsrl_sac_param_count(self._ctx, 0))
+        self.n_sac_critics = int(self.lib.fsrl_sac_param_count(self._ctx, 1))
+
+    def sac_set_params(self, actor_flat, critics_flat, log_alpha=0.0):
+        a = np.ascontiguousarray(actor_flat, np.float32); c = np.ascontiguousarray(critics_flat, np.float32)
+        _lib.check(self.lib.fsrl_sac_params_set(self._ctx, _ptr(a, _f32p), a.size, _ptr(c, _f32p), c.size,
+                                                float(log_alpha)))
+
+    def sac_get_params(self, which: int):
+        """which: 0 actor, 1 critics, 2 critics_old -> (flat params, alpha)."""
+        out = np.empty(self.n_sac_actor if which == 0 else self.n_sac_critics, np.float32)
+        alpha = C.c_float()
+        _lib.check(self.lib.fsrl_sac_params_get(self._ctx, int(which), _ptr(out, _f32p), out.size, C.byref(alpha)))
+        return out, float(alpha.value)
+
+    def sac_update(self, batch_size, lagrangians, rescaling, indices=None, eps_target=None, eps_pi=None, seed=0):
+        lag = np.ascontiguousarray(lagrangians, np.float64).reshape(-1)
+        idx = None if indices is None else np.ascontiguousarray(indices, np.int64)
+        et = None if eps_target is None else np.ascontiguousarray(eps_target, np.float32)
+        ep = None if eps_pi is None else np.ascontiguousarray(eps_pi, np.float32)
+        if idx is not None:
+            assert idx.size == batch_size
+        out = np.empty(_lib.SAC_NSTATS, np.float32)
+        _lib.check(self.lib.fsrl_sac_update(self._ctx, int(batch_size), _ptr(idx, _i64p), _ptr(et, _f32p),
+                                            _ptr(ep, _f32p), int(seed), _ptr(lag, _f64p) if lag.size else None,
+                                            float(rescaling), _ptr(out, _f32p)))
+        return out
+
+    def sac_actor_forward(self, obs):
+        obs = np.ascontiguousarray(obs, np.float32).reshape(-1, self.cfg.obs_dim)
+        k = obs.shape[0]
+        mu = np.empty((k, self.cfg.act_dim), np.float32); sigma = np.empty_like(mu)
+        _lib.check(self.lib.fsrl_sac_actor_forward(self._ctx, _ptr(obs, _f32p), k, _ptr(mu, _f32p),
+                                                   _ptr(sigma, _f32p)))
+        return mu, sigma
+
     def set_profiling(self, on: bool):
         _lib.check(self.lib.fsrl_set_profiling(self._ctx, int(on)))
 

@@ -181,6 +181,40 @@ int fsrl_tr_hvp(fsrl_ctx* ctx, const float* v, float* out, int64_t n);
 /* stats8: mean(ratio*A_r), mean(ratio*A_c), mean KL, mean(logp_old - logp), mean A_r, mean A_c, 0, 0 */
 int fsrl_tr_eval(fsrl_ctx* ctx, double* stats8);
 
+/* ---- SAC-Lagrangian (fsrl/policy/sac_lag.py), off-policy on the HIP-resident replay store.
+ *      Create the context with algo = FSRL_ALGO_SAC_LAG (obs_dim, act_dim <= 8, hidden, env_num,
+ *      buffer_size, gamma are read from fsrl_config), then fsrl_sac_init.
+ *      Parameter vectors in torch parameters() order:
+ *        actor   : W1[H,Do] b1 W2[H,H] b2 Wmu[Da,H] bmu Wsig[Da,H] bsig   (ActorProb, conditioned sigma,
+ *                  unbounded mean; sac_lag_agent.py:126-134)
+ *        critics : for (reward, cost): pre1(W1[H,Do+Da] b1 W2 b2) pre2(..) last1(W[1,H] b) last2(W b)
+ *                  (DoubleCritic, fsrl/utils/net/continuous.py:13-101)                          */
+typedef struct fsrl_sac_config {
+    float actor_lr, critic_lr, alpha_lr;   /* 5e-4, 1e-3, 3e-4                                   */
+    float tau;                             /* Polyak, 0.05                                       */
+    float alpha;                           /* fixed temperature when auto_alpha == 0             */
+    float target_entropy;                  /* -act_dim                                           */
+    int32_t n_step;                        /* 2 (sacl_cfg.py:21)                                 */
+    int32_t auto_alpha;
+    int32_t use_lagrangian;
+} fsrl_sac_config;
+#define FSRL_SAC_NSTATS 10  /* rescaling, lagrangian, actor_safety, alpha_loss, alpha_value, actor_rew,
+                               actor_total (sac_lag.py:231-257) then q0, q1, q_total (:203-208) */
+int fsrl_sac_init(fsrl_ctx* ctx, const fsrl_sac_config* cfg);
+int64_t fsrl_sac_param_count(const fsrl_ctx* ctx, int32_t which);    /* 0 actor, 1 critics         */
+int fsrl_sac_params_set(fsrl_ctx* ctx, const float* actor, int64_t na, const float* critics, int64_t nc,
+                        float log_alpha);   /* also copies critics -> critics_old, resets Adam    */
+/* which: 0 actor, 1 critics, 2 critics_old (targets)                                            */
+int fsrl_sac_params_get(fsrl_ctx* ctx, int32_t which, float* out, int64_t n, float* alpha_out);
+/* One SACLagrangian.update(batch_size, buffer) = sample + n-step targets + critic step + actor
+ * step + alpha step + Polyak.  indices/eps_target/eps_pi may be given (the caller's numpy / torch
+ * RNG streams, for parity) or NULL (library RNG, seeded by `seed`).  stats_out: FSRL_SAC_NSTATS.  */
+int fsrl_sac_update(fsrl_ctx* ctx, int32_t batch_size, const int64_t* indices, const float* eps_target,
+                    const float* eps_pi, uint64_t seed, const double* lagrangians, double rescaling,
+                    float* stats_out);
+/* the actor for the collector: mu and sigma = exp(clamp(log sigma)) of the tanh-Gaussian policy   */
+int fsrl_sac_actor_forward(fsrl_ctx* ctx, const float* obs, int32_t k, float* mu_out, float* sigma_out);
+
 /* ---- timing of the last update, measured with hipEvents on the compute stream --------- */
 /* out[0] = process_fn ms, out[1] = learn ms (all passes), out[2] = fused fwd/bwd kernel
  * total ms over the update (sum of per-launch event pairs when profiling is enabled),
