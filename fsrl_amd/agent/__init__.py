@@ -1,5 +1,6 @@
 from fsrl_amd.agent.base_agent import BaseAgent, OnpolicyAgent
 from fsrl_amd.agent.ppo_lag_agent import PPOLagAgent
 from fsrl_amd.agent.trust_agents import CPOAgent, TRPOLagAgent
+from fsrl_amd.agent.sac_lag_agent import OffpolicyAgent, SACLagAgent
 
-__all__ = ["BaseAgent", "OnpolicyAgent", "PPOLagAgent", "CPOAgent", "TRPOLagAgent"]
+__all__ = ["BaseAgent", "OnpolicyAgent", "PPOLagAgent", "CPOAgent", "TRPOLagAgent", "OffpolicyAgent", "SACLagAgent"]

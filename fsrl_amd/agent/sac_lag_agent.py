@@ -1,0 +1,107 @@
+"""SACLagAgent + the off-policy learn loop: keyword arguments and defaults of
+fsrl/agent/sac_lag_agent.py:75-203 and fsrl/agent/base_agent.py:108-209."""
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from fsrl_amd.agent.base_agent import BaseAgent
+from fsrl_amd.data import FastCollector, HipVectorReplayBuffer
+from fsrl_amd.policy.sac_lag import SACLagrangian
+from fsrl_amd.trainer.offpolicy import OffpolicyTrainer
+from fsrl_amd.utils.exp_util import seed_all
+from fsrl_amd.utils.logger import DummyLogger
+from fsrl_amd.utils.net import ActorCritic, ActorProb, DoubleCritic, Net
+
+
+class OffpolicyAgent(BaseAgent):
+    name = "OffpolicyAgent"
+
+    def __init__(self) -> None:
+        pass
+
+    def learn(self, train_envs, test_envs=None, epoch: int = 300, episode_per_collect: int = 5,
+              step_per_epoch: int = 3000, update_per_step: float = 0.1, buffer_size: int = 100000,
+              testing_num: int = 2, batch_size: int = 256, reward_threshold: float = 450,
+              save_interval: int = 4, resume: bool = False, save_ckpt: bool = True, verbose: bool = True,
+              show_progress: bool = True):
+        assert self.policy is not None, "The policy is not initialized"
+        self.policy.train()
+        eng = self.policy.engine
+        assert eng.cfg.env_num >= len(train_envs)
+        buffer = HipVectorReplayBuffer(eng, buffer_size, len(train_envs))
+        train_collector = FastCollector(self.policy, train_envs, buffer, exploration_noise=True)
+        test_collector = FastCollector(self.policy, test_envs) if test_envs is not None else None
+
+        def stop_fn(reward, cost):
+            return reward > reward_threshold and cost < self.cost_limit
+
+        if save_ckpt:
+            self.logger.setup_checkpoint_fn(lambda: {"model": self.state_dict})
+        trainer = OffpolicyTrainer(policy=self.policy, train_collector=train_collector,
+                                   test_collector=test_collector, max_epoch=epoch, batch_size=batch_size,
+                                   cost_limit=self.cost_limit, step_per_epoch=step_per_epoch,
+                                   update_per_step=update_per_step, episode_per_test=testing_num,
+                                   episode_per_collect=episode_per_collect, stop_fn=stop_fn,
+                                   logger=self.logger, resume_from_log=resume,
+                                   save_model_interval=save_interval, verbose=verbose,
+                                   show_progress=show_progress)
+        ep, stat, info = 0, {}, {}
+        for ep, stat, info in trainer:
+            self.logger.store(tab="train", cost_limit=self.cost_limit)
+            if verbose:
+                print(f"Epoch: {ep}", info)
+        return ep, stat, info
+
+
+class SACLagAgent(OffpolicyAgent):
+    name = "SACLagAgent"
+
+    def __init__(self, env, logger=None, cost_limit: float = 10, device: str = "cuda:0", thread: int = 4,
+                 seed: int = 10, actor_lr: float = 5e-4, critic_lr: float = 1e-3,
+                 hidden_sizes: Tuple[int, ...] = (128, 128), auto_alpha: bool = True, alpha_lr: float = 3e-4,
+                 alpha: float = 0.002, tau: float = 0.05, n_step: int = 2, use_lagrangian: bool = True,
+                 lagrangian_pid: Tuple[float, ...] = (0.05, 0.0005, 0.1), rescaling: bool = True,
+                 gamma: float = 0.99, conditioned_sigma: bool = True, unbounded: bool = True,
+                 last_layer_scale: bool = False, deterministic_eval: bool = False, action_scaling: bool = True,
+                 action_bound_method: str = "clip", lr_scheduler=None, training_num: int = 10,
+                 buffer_size: int = 100000) -> None:
+        super().__init__()
+        self.logger = logger if logger is not None else DummyLogger()
+        self.cost_limit = cost_limit
+        assert np.isscalar(cost_limit) and conditioned_sigma and unbounded, \
+            "the HIP SAC path: one cost, state-conditioned sigma, unbounded mean (the reference defaults)"
+        seed_all(seed)
+        torch.set_num_threads(thread)
+        state_shape, action_shape = env.observation_space.shape, env.action_space.shape
+        actor = ActorProb(Net(state_shape, hidden_sizes=hidden_sizes), action_shape,
+                          max_action=float(env.action_space.high[0]), conditioned_sigma=True, unbounded=True)
+        actor_optim = torch.optim.Adam(actor.parameters(), lr=actor_lr)
+        critics = [DoubleCritic(Net(state_shape, action_shape, hidden_sizes=hidden_sizes, concat=True),
+                                Net(state_shape, action_shape, hidden_sizes=hidden_sizes, concat=True))
+                   for _ in range(2)]
+        critic_optim = torch.optim.Adam(nn.ModuleList(critics).parameters(), lr=critic_lr)
+        for m in ActorCritic(actor, critics).modules():
+            if isinstance(m, torch.nn.Linear):
+                torch.nn.init.orthogonal_(m.weight)
+                torch.nn.init.zeros_(m.bias)
+        if last_layer_scale:
+            for m in actor.mu.modules():
+                if isinstance(m, torch.nn.Linear):
+                    torch.nn.init.zeros_(m.bias)
+                    m.weight.data.copy_(0.01 * m.weight.data)
+        if auto_alpha:
+            target_entropy = -float(np.prod(env.action_space.shape))
+            log_alpha = torch.zeros(1, requires_grad=True)
+            alpha = (target_entropy, log_alpha, torch.optim.Adam([log_alpha], lr=alpha_lr))
+        self.policy = SACLagrangian(actor=actor, critics=critics, actor_optim=actor_optim,
+                                    critic_optim=critic_optim, logger=self.logger, alpha=alpha, tau=tau,
+                                    gamma=gamma, exploration_noise=None, n_step=n_step,
+                                    use_lagrangian=use_lagrangian, lagrangian_pid=lagrangian_pid,
+                                    cost_limit=cost_limit, rescaling=rescaling, reward_normalization=False,
+                                    deterministic_eval=deterministic_eval, action_scaling=action_scaling,
+                                    action_bound_method=action_bound_method,
+                                    observation_space=env.observation_space, action_space=env.action_space,
+                                    lr_scheduler=lr_scheduler, device=device, env_num=training_num,
+                                    buffer_size=buffer_size)

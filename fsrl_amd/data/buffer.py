@@ -13,6 +13,8 @@ class HipVectorReplayBuffer:
         self.buffer_num = engine.cfg.env_num if buffer_num is None else buffer_num
         assert self.buffer_num <= engine.cfg.env_num, "more sub-buffers requested than the engine has"
         self.maxsize = engine.cfg.buffer_size
+        self._sub = -(-engine.cfg.buffer_size // engine.cfg.env_num)      # rows per sub-buffer
+        self._sizes = np.zeros(engine.cfg.env_num, np.int64)             # host mirror of the fill levels
 
     def add(self, batch, buffer_ids=None):
         ids = np.arange(len(batch.rew)) if buffer_ids is None else np.asarray(buffer_ids)
@@ -22,15 +24,28 @@ class HipVectorReplayBuffer:
             cost = info.get("cost", None) if hasattr(info, "get") else None
         if cost is None:
             cost = np.zeros(len(ids))
+        for e in ids:
+            self._sizes[e] = min(self._sizes[e] + 1, self._sub)
         return self.engine.push(ids, batch.obs, batch.act, batch.rew, cost, batch.terminated,
                                 batch.truncated, batch.obs_next)
 
     def reset(self, keep_statistics: bool = False) -> None:
+        self._sizes[:] = 0
         self.engine.reset_store(keep_statistics)
 
     def __len__(self) -> int:
         return len(self.engine)
 
     def sample_indices(self, batch_size: int):
-        assert batch_size == 0, "only the on-policy sample(0) order is exposed in this round"
-        return self.engine.sample0()
+        """tianshou-0.5 ReplayBufferManager.sample_indices: batch_size == 0 -> every row, env-major
+        and chronological; > 0 -> sub-buffers drawn proportionally to their fill with the numpy
+        global RNG, then uniform rows inside each (np.random.choice), concatenated in buffer order."""
+        if batch_size == 0:
+            return self.engine.sample0()
+        if batch_size < 0:
+            return np.array([], int)
+        lengths = self._sizes[:self.buffer_num]
+        pick = np.random.choice(self.buffer_num, batch_size, p=lengths / lengths.sum())
+        counts = np.bincount(pick, minlength=self.buffer_num)
+        return np.concatenate([np.random.choice(int(lengths[e]), int(counts[e])) + e * self._sub
+                               for e in range(self.buffer_num)]).astype(np.int64)

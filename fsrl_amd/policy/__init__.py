@@ -4,5 +4,6 @@ from fsrl_amd.policy.lagrangian_base import LagrangianPolicy
 from fsrl_amd.policy.ppo_lag import PPOLagrangian
 from fsrl_amd.policy.trpo_lag import TRPOLagrangian
 from fsrl_amd.policy.cpo import CPO
+from fsrl_amd.policy.sac_lag import SACLagrangian
 
-__all__ = ["BasePolicy", "LagrangianPolicy", "PPOLagrangian", "TRPOLagrangian", "CPO"]
+__all__ = ["BasePolicy", "LagrangianPolicy", "PPOLagrangian", "TRPOLagrangian", "CPO", "SACLagrangian"]

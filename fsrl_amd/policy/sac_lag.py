@@ -1,0 +1,150 @@
+"""SACLagrangian over the HIP engine: constructor arguments and logger keys of
+fsrl/policy/sac_lag.py:16-277.  `update(batch_size, buffer)` = sample + n-step soft targets +
+critic step + actor step + alpha step + Polyak on the MI355X through `fsrl_sac_update`; the
+sampled indices (numpy RNG, tianshou's sub-buffer-proportional rule) and the two rsample noise
+draws (torch RNG) are produced here so the random streams match the reference's."""
+from copy import deepcopy
+from typing import Any, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from torch import nn
+from torch.distributions import Independent, Normal
+
+from fsrl_amd import _lib
+from fsrl_amd.data.batch import Batch
+from fsrl_amd.engine import Engine, EngineConfig
+from fsrl_amd.policy.lagrangian_base import LagrangianPolicy
+
+SAC_KEYS = ("loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss/alpha_loss", "loss/alpha_value",
+            "loss/actor_rew", "loss/actor_total", "loss/q0", "loss/q1", "loss/q_total")
+
+
+class SACLagrangian(LagrangianPolicy):
+    def __init__(self, actor: nn.Module, critics: Union[nn.Module, List[nn.Module]], actor_optim, critic_optim,
+                 logger=None, alpha=0.005, tau: float = 0.05, exploration_noise=None, n_step: int = 2,
+                 use_lagrangian: bool = True, lagrangian_pid: Tuple = (0.05, 0.0005, 0.1),
+                 cost_limit: Union[List, float] = np.inf, rescaling: bool = True, gamma: float = 0.99,
+                 reward_normalization: bool = False, deterministic_eval: bool = True,
+                 action_scaling: bool = True, action_bound_method: str = "clip", observation_space=None,
+                 action_space=None, lr_scheduler=None, device: Union[int, str] = 0, env_num: int = 1,
+                 buffer_size: int = 100000) -> None:
+        super().__init__(actor, critics, None, logger, use_lagrangian, lagrangian_pid, cost_limit, rescaling,
+                         gamma, 10000, reward_normalization, deterministic_eval, action_scaling,
+                         action_bound_method, observation_space, action_space, lr_scheduler)
+        assert self.critics_num == 2, "the HIP path supports one cost constraint (reward + cost double critics)"
+        assert 0.0 <= tau <= 1.0, "tau should be in [0, 1]"
+        self.actor_optim, self.critics_optim = actor_optim, critic_optim
+        self.critics_old = deepcopy(self.critics)
+        self.critics_old.eval()
+        self.tau, self._n_step, self._noise = tau, n_step, exploration_noise
+        self._is_auto_alpha = isinstance(alpha, tuple)
+        if self._is_auto_alpha:
+            self._target_entropy, self._log_alpha, self._alpha_optim = alpha
+            assert alpha[1].shape == torch.Size([1]) and alpha[1].requires_grad
+            self._alpha = self._log_alpha.detach().exp()
+            alpha_lr, alpha_fixed = self._alpha_optim.param_groups[0]["lr"], 0.0
+        else:
+            self._alpha, self._target_entropy, alpha_lr, alpha_fixed = alpha, None, 3e-4, float(alpha)
+        self.__eps = np.finfo(np.float32).eps.item()
+        w1 = actor.preprocess.model.model[0].weight
+        hidden, obs_dim = w1.shape
+        act_dim = actor.mu.model[0].weight.shape[0]
+        dev = device if isinstance(device, int) else (int(str(device).split(":")[-1]) if ":" in str(device) else 0)
+        self.engine = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=int(obs_dim), act_dim=int(act_dim),
+                                          hidden=int(hidden), n_critics=2, env_num=int(env_num),
+                                          buffer_size=int(buffer_size), gamma=gamma, target_kl=None),
+                             device=dev)
+        self.engine.sac_init(actor_lr=actor_optim.param_groups[0]["lr"],
+                             critic_lr=critic_optim.param_groups[0]["lr"], alpha_lr=alpha_lr, tau=tau,
+                             alpha=alpha_fixed, target_entropy=self._target_entropy, n_step=n_step,
+                             auto_alpha=self._is_auto_alpha, use_lagrangian=use_lagrangian)
+        self._push_params()
+        self._dirty = False
+
+    # ------------------------------------------------------------------ parameter plumbing
+    @staticmethod
+    def _flat(mods):
+        return torch.cat([p.detach().reshape(-1) for m in mods for p in m.parameters()]).numpy().astype(np.float32)
+
+    @staticmethod
+    def _unflat(mods, flat):
+        flat, off = torch.from_numpy(flat), 0
+        with torch.no_grad():
+            for m in mods:
+                for p in m.parameters():
+                    p.copy_(flat[off:off + p.numel()].view_as(p))
+                    off += p.numel()
+
+    def _push_params(self) -> None:
+        la = float(self._log_alpha.detach()) if self._is_auto_alpha else 0.0
+        self.engine.sac_set_params(self._flat([self.actor]), self._flat(list(self.critics)), la)
+
+    def _pull_params(self, everything: bool = False) -> None:
+        th, alpha = self.engine.sac_get_params(0)
+        self._unflat([self.actor], th)
+        if self._is_auto_alpha:
+            self._alpha = torch.tensor([alpha])
+            with torch.no_grad():
+                self._log_alpha.fill_(float(np.log(alpha)))
+        if everything:
+            self._unflat(list(self.critics), self.engine.sac_get_params(1)[0])
+            self._unflat(list(self.critics_old), self.engine.sac_get_params(2)[0])
+        self._dirty = False
+
+    def state_dict(self, *args, **kwargs):
+        if getattr(self, "_dirty", False):
+            self._pull_params(everything=True)
+        return super().state_dict(*args, **kwargs)
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        self.actor.train(mode)
+        self.critics.train(mode)
+        return self
+
+    # ------------------------------------------------------------------ acting (host mirror)
+    def forward(self, batch: Batch, state=None, input: str = "obs", **kwargs: Any) -> Batch:
+        if self._dirty:
+            self._pull_params()
+        logits, hidden = self.actor(batch[input], state=state)
+        dist = Independent(Normal(*logits), 1)
+        act = logits[0] if (self._deterministic_eval and not self.training) else dist.rsample()
+        log_prob = dist.log_prob(act).unsqueeze(-1)
+        squashed = torch.tanh(act)
+        log_prob = log_prob - torch.log((1 - squashed.pow(2)) + self.__eps).sum(-1, keepdim=True)
+        return Batch(logits=logits, act=squashed, state=hidden, dist=dist, log_prob=log_prob)
+
+    def exploration_noise(self, act, batch):
+        if self._noise is None:
+            return act
+        return act + self._noise(act.shape) if isinstance(act, np.ndarray) else act
+
+    def learn(self, batch, **kwargs: Any):
+        raise NotImplementedError("the HIP path runs process_fn + learn inside update()")
+
+    def update(self, sample_size: int, buffer, **kwargs: Any):
+        if buffer is None:
+            return {}
+        assert getattr(buffer, "engine", None) is self.engine
+        self.updating = True
+        B, Da = int(sample_size), self.engine.cfg.act_dim
+        indices = buffer.sample_indices(B)                               # numpy RNG, tianshou rule
+        eps_t = torch.normal(torch.zeros(B, Da), torch.ones(B, Da)).numpy()   # rsample at s_{t+n}
+        eps_p = torch.normal(torch.zeros(B, Da), torch.ones(B, Da)).numpy()   # rsample at s_t
+        lags, rescaling = self.lagrangians_and_rescaling() if self.use_lagrangian else ([], 1.0)
+        st = self.engine.sac_update(B, lags, rescaling, indices=indices, eps_target=eps_t, eps_pi=eps_p)
+        d = dict(zip(SAC_KEYS, (float(v) for v in st)))
+        if not self._is_auto_alpha:
+            d.pop("loss/alpha_loss"); d.pop("loss/alpha_value")
+        if not self.use_lagrangian:
+            d.pop("loss/lagrangian"); d.pop("loss/actor_safety")
+        qs = {k: d.pop(k) for k in ("loss/q0", "loss/q1", "loss/q_total")}
+        self.logger.store(**d)
+        self.logger.store(**qs)
+        self.gradient_steps += 1
+        self._dirty = True
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+        self.updating = False
+        return {}

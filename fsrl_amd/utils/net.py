@@ -29,22 +29,32 @@ class MLP(nn.Module):
 
 
 class Net(nn.Module):
-    def __init__(self, state_shape, hidden_sizes: Sequence[int] = (), device="cpu"):
+    def __init__(self, state_shape, action_shape=0, hidden_sizes: Sequence[int] = (), device="cpu",
+                 concat: bool = False):
         super().__init__()
-        self.model = MLP(int(np.prod(state_shape)), 0, hidden_sizes)
+        in_dim = int(np.prod(state_shape)) + (int(np.prod(action_shape)) if concat else 0)
+        self.model = MLP(in_dim, 0, hidden_sizes)
         self.output_dim = self.model.output_dim
 
     def forward(self, obs, state=None, info={}):
         return self.model(obs), state
 
 
+SIGMA_MIN, SIGMA_MAX = -20, 2
+
+
 class ActorProb(nn.Module):
-    def __init__(self, preprocess_net, action_shape, max_action=1.0, device="cpu", unbounded=False):
+    def __init__(self, preprocess_net, action_shape, max_action=1.0, device="cpu", unbounded=False,
+                 conditioned_sigma=False):
         super().__init__()
         self.preprocess = preprocess_net
         self.output_dim = int(np.prod(action_shape))
         self.mu = MLP(preprocess_net.output_dim, self.output_dim)
-        self.sigma_param = nn.Parameter(torch.zeros(self.output_dim, 1))
+        self._c_sigma = conditioned_sigma
+        if conditioned_sigma:
+            self.sigma = MLP(preprocess_net.output_dim, self.output_dim)
+        else:
+            self.sigma_param = nn.Parameter(torch.zeros(self.output_dim, 1))
         self._max = max_action
         self._unbounded = unbounded
 
@@ -53,8 +63,33 @@ class ActorProb(nn.Module):
         mu = self.mu(logits)
         if not self._unbounded:
             mu = self._max * torch.tanh(mu)
-        sigma = (self.sigma_param.view(1, -1) + torch.zeros_like(mu)).exp()
+        if self._c_sigma:
+            sigma = torch.clamp(self.sigma(logits), min=SIGMA_MIN, max=SIGMA_MAX).exp()
+        else:
+            sigma = (self.sigma_param.view(1, -1) + torch.zeros_like(mu)).exp()
         return (mu, sigma), state
+
+
+class DoubleCritic(nn.Module):
+    """Two Q MLPs on concat(obs, act) (fsrl/utils/net/continuous.py:13-101): same attribute names
+    (preprocess1/2, last1/2) so the state_dict keys match the reference."""
+
+    def __init__(self, preprocess_net1, preprocess_net2, device="cpu"):
+        super().__init__()
+        from copy import deepcopy
+        self.preprocess1, self.preprocess2 = preprocess_net1, preprocess_net2
+        self.last1 = MLP(preprocess_net1.output_dim, 1)
+        self.last2 = deepcopy(self.last1)
+
+    def forward(self, obs, act=None, info={}):
+        obs = torch.as_tensor(obs, dtype=torch.float32).flatten(1)
+        if act is not None:
+            obs = torch.cat([obs, torch.as_tensor(act, dtype=torch.float32).flatten(1)], dim=1)
+        return [self.last1(self.preprocess1(obs)[0]), self.last2(self.preprocess2(obs)[0])]
+
+    def predict(self, obs, act=None, info={}):
+        q = self(obs, act, info)
+        return torch.min(q[0], q[1]), q
 
 
 class Critic(nn.Module):

@@ -121,3 +121,65 @@ def test_trust_region_agents_learn_end_to_end(kind, tmp_path):
     assert ("loss/optim_case" in stat) == (kind == "cpo")
     theta1 = agent.policy.engine.get_params()
     assert np.abs(theta1 - theta0).max() > 1e-5 and np.array_equal(agent.policy._flat_params(), theta1)
+
+
+def test_sac_policy_update_through_facade_matches_reference():
+    """The facade reproduces the reference's random streams: numpy RNG for buffer.sample (tianshou's
+    sub-buffer-proportional rule), torch RNG for the two rsample draws."""
+    import json, random
+    from fsrl_amd.data import Batch, HipVectorReplayBuffer
+    from fsrl_amd.env import Box
+    from fsrl_amd.policy import SACLagrangian
+    from fsrl_amd.utils.net import ActorProb, DoubleCritic, Net
+    from helpers import load_npz
+    g = load_npz("sac_small.npz"); cfg = json.loads(str(g["cfg_json"]))
+    Do, Da, h = cfg["obs_dim"], cfg["act_dim"], tuple(cfg["hidden"])
+    actor = ActorProb(Net((Do, ), hidden_sizes=h), (Da, ), conditioned_sigma=True, unbounded=True)
+    critics = [DoubleCritic(Net((Do, ), (Da, ), hidden_sizes=h, concat=True),
+                            Net((Do, ), (Da, ), hidden_sizes=h, concat=True)) for _ in range(2)]
+    SACLagrangian._unflat([actor], g["theta_actor0"]); SACLagrangian._unflat(critics, g["theta_critics0"])
+    log_alpha = torch.zeros(1, requires_grad=True)
+    alpha = (-float(Da), log_alpha, torch.optim.Adam([log_alpha], lr=cfg["alpha_lr"]))
+    log = _Capture()
+    pol = SACLagrangian(actor, critics, torch.optim.Adam(actor.parameters(), lr=cfg["actor_lr"]),
+                        torch.optim.Adam(torch.nn.ModuleList(critics).parameters(), lr=cfg["critic_lr"]),
+                        logger=log, alpha=alpha, tau=cfg["tau"], n_step=cfg["n_step"], cost_limit=cfg["cost_limit"],
+                        gamma=cfg["gamma"], observation_space=Box(-np.inf, np.inf, (Do, )),
+                        action_space=Box(-1, 1, (Da, )), device=0, env_num=cfg["env_num"])
+    pol.train()
+    buf = HipVectorReplayBuffer(pol.engine, cfg["buffer_size"], cfg["env_num"])
+    rows = g["env_rows"]; off = np.concatenate([[0], np.cumsum(rows)])
+    for t in range(rows.max()):
+        ids = np.array([e for e in range(len(rows)) if t < rows[e]])
+        sel = np.array([off[e] + t for e in ids])
+        buf.add(Batch(obs=g["st_obs"][sel], act=g["st_act"][sel], rew=g["st_rew"][sel],
+                      info={"cost": g["st_cost"][sel]}, terminated=g["st_terminated"][sel],
+                      truncated=g["st_truncated"][sel], obs_next=g["st_obs_next"][sel]), buffer_ids=ids)
+    pol.pre_update_fn(stats_train={"cost": cfg["cost_stat"]})
+    seed = cfg["seed"] + 7
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    ka = [str(k) for k in g["stats_actor_keys"]]; kc = [str(k) for k in g["stats_critic_keys"]]
+    for u in range(cfg["n_updates"]):
+        pol.update(cfg["batch_size"], buf)
+        ra, rc = log.rows[2 * u], log.rows[2 * u + 1]
+        np.testing.assert_allclose([ra[k] for k in ka], g["stats_actor"][u], rtol=5e-5, atol=5e-6)
+        np.testing.assert_allclose([rc[k] for k in kc], g["stats_critic"][u], rtol=5e-5, atol=5e-6)
+    sd = pol.state_dict()
+    assert "critics_old.0.preprocess1.model.model.0.weight" in sd and "actor.sigma.model.0.weight" in sd
+    d = np.abs(SACLagrangian._flat([pol.actor]) - g["theta_actor_final"])
+    assert np.quantile(d, 0.99) <= 5e-6 and d.max() <= 5e-4
+
+
+def test_sac_agent_learns_end_to_end(tmp_path):
+    from fsrl_amd.agent import SACLagAgent
+    from fsrl_amd.env import SyntheticSafetyVectorEnv
+    from fsrl_amd.utils import BaseLogger
+    train = SyntheticSafetyVectorEnv(env_num=4, episode_len=40, seed=1)
+    agent = SACLagAgent(train, BaseLogger(str(tmp_path), name="s"), cost_limit=10, device="cuda:0", seed=3,
+                        hidden_sizes=(64, 64), training_num=4, buffer_size=4000)
+    a0, _ = agent.policy.engine.sac_get_params(0)
+    ep, stat, info = agent.learn(train, None, epoch=2, episode_per_collect=4, step_per_epoch=320,
+                                 update_per_step=0.2, batch_size=64, verbose=False)
+    assert ep == 2 and np.isfinite(list(stat.values())).all() and "loss/q_total" in stat and "loss/alpha_value" in stat
+    a1, alpha = agent.policy.engine.sac_get_params(0)
+    assert np.abs(a1 - a0).max() > 1e-4 and 0 < alpha < 1.0
