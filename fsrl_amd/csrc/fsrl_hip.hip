@@ -120,6 +120,10 @@ struct fsrl_ctx {
     double t_process_ms = 0, t_learn_ms = 0, t_fwdbwd_ms = 0, t_fwdbwd_raw_ms = 0;
     int64_t n_fwdbwd = 0;
     uint64_t rng[4] = {0x9E3779B97F4A7C15ull, 0xBF58476D1CE4E5B9ull, 0x94D049BB133111EBull, 1};
+    // split-K partial gradients of fb_wgrad_kernel, one buffer per parameter layout (keyed by its
+    // padded size) so that the never-written inter-tensor padding stays zero
+    struct Parts { int stride = 0; float* p = nullptr; size_t floats = 0; } parts[3];
+    float* wg_parts = nullptr;      // the buffer the last wgrad_launch wrote
     struct TrState* tr = nullptr;   // trust-region (CPO / TRPO-Lag) working set, owned
     void* sac = nullptr;            // SacState, owned
 };
@@ -133,6 +137,49 @@ static int ensure_scratch(fsrl_ctx* c, size_t bytes) {
     HIPCHK(hipMalloc(&c->scratch, bytes));
     c->scratch_bytes = bytes;
     return 0;
+}
+
+// ---- split-K launch of fb_wgrad_kernel.  Rows are cut into <= 24 splits of >= 256 rows; every split
+//      writes a partial gradient at parts + z * stride, summed later in z order.
+struct WgradPlan { int nsplit, ks_per_split; };
+static WgradPlan wgrad_plan(int rows) {
+    const int KS = rows >> 2;
+    int n = std::max(1, std::min((rows + 255) / 256, 24));
+    const int per = round_up((KS + n - 1) / n, 16);
+    n = (KS + per - 1) / per;
+    return WgradPlan{std::max(n, 1), per};
+}
+static int ensure_parts(fsrl_ctx* c, int stride, int nsplit) {
+    fsrl_ctx::Parts* slot = nullptr;
+    for (auto& pp : c->parts)
+        if (pp.stride == stride || pp.stride == 0) { slot = &pp; break; }
+    if (!slot) return fail(FSRL_ESTATE, "no free split-K buffer slot");
+    const size_t floats = (size_t)stride * nsplit;
+    if (slot->floats < floats) {
+        HIPCHK(hipStreamSynchronize(c->compute));
+        if (slot->p) HIPCHK(hipFree(slot->p));
+        slot->p = nullptr; slot->floats = 0; slot->stride = stride;
+        HIPCHK(hipMalloc(&slot->p, floats * 4));
+        HIPCHK(hipMemsetAsync(slot->p, 0, floats * 4, c->compute));
+        slot->floats = floats;
+    }
+    c->wg_parts = slot->p;
+    return 0;
+}
+template <bool PAIR2>
+static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int ny, int stride, int* nsplit) {
+    const WgradPlan pl = wgrad_plan(wa.rows);
+    int rc = ensure_parts(c, stride, pl.nsplit);
+    if (rc) return rc;
+    wa.out = c->wg_parts; wa.ks_per_split = pl.ks_per_split; wa.split_stride = stride;
+    *nsplit = pl.nsplit;
+    return dispatch_H(c->cfg.hidden, [&](auto hc) {
+        constexpr int HH = decltype(hc)::value;
+        constexpr int NB = (HH / 32) * (HH / 32) + HH / 32 + 1;
+        hipLaunchKernelGGL((fb_wgrad_kernel<HH, PAIR2>), dim3(NB, ny, pl.nsplit), dim3(1024), 0, c->compute, md, wa);
+        HIPCHK(hipGetLastError());
+        return 0;
+    });
 }
 
 extern "C" void fsrl_config_default(fsrl_config* c) {
@@ -187,6 +234,7 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
                      c->gsq_part, c->d_perm, c->d_mbstart, c->d_mbsize, c->d_stats,
                      c->scratch};
     for (void* p : dptrs) if (p) (void)hipFree(p);
+    for (auto& pp : c->parts) if (pp.p) (void)hipFree(pp.p);
     void* hptrs[] = {c->h_ctrl, c->h_indices, c->h_end, c->h_seg, c->h_perm, c->h_mbplan};
     for (void* p : hptrs) if (p) (void)hipHostFree(p);
     for (auto& s : c->stage) {
@@ -233,7 +281,7 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     const size_t pb = (size_t)c->n_dev * sizeof(float);
     TRY(hipMalloc(&c->P, pb)); TRY(hipMalloc(&c->M, pb)); TRY(hipMalloc(&c->V, pb)); TRY(hipMalloc(&c->G, pb));
-    TRY(hipMemset(c->P, 0, pb)); TRY(hipMemset(c->M, 0, pb)); TRY(hipMemset(c->V, 0, pb)); TRY(hipMemset(c->G, 0, pb));
+    TRY(hipMemsetAsync(c->P, 0, pb, c->compute)); TRY(hipMemsetAsync(c->M, 0, pb, c->compute)); TRY(hipMemsetAsync(c->V, 0, pb, c->compute)); TRY(hipMemsetAsync(c->G, 0, pb, c->compute));
     TRY(hipMalloc(&c->ctrl, sizeof(CtrlBlock)));
     TRY(hipHostMalloc(&c->h_ctrl, sizeof(CtrlBlock)));
     // store: n sub-buffers of ceil(total/n) rows (tianshou VectorReplayBuffer)
@@ -256,8 +304,9 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     TRY(hipMalloc(&c->advs, ms * C * 4)); TRY(hipMalloc(&c->rets, ms * C * 4));
     TRY(hipMalloc(&c->logp_old, ms * 4));
     TRY(hipMalloc(&c->d_perm, ms * 4)); TRY(hipHostMalloc(&c->h_perm, ms * 4));
-    TRY(hipMalloc(&c->obs_p, (ms + 32) * Do * 4)); TRY(hipMemset(c->obs_p, 0, (ms + 32) * Do * 4));
-    TRY(hipMalloc(&c->rd_p, (ms + 32) * FSRL_RD * 4)); TRY(hipMemset(c->rd_p, 0, (ms + 32) * FSRL_RD * 4));
+    TRY(hipMalloc(&c->obs_p, (ms + 32) * Do * 4)); TRY(hipMemsetAsync(c->obs_p, 0, (ms + 32) * Do * 4, c->compute));
+    TRY(hipMalloc(&c->rd_p, (ms + 32) * FSRL_RD * 4)); TRY(hipMemsetAsync(c->rd_p, 0, (ms + 32) * FSRL_RD * 4, c->compute));
+    TRY(hipStreamSynchronize(c->compute));     // zero fills have landed before any other stream touches them
     for (auto& s : c->stage) {
         const size_t k = fsrl_ctx::STAGE_CAP;
         TRY(hipHostMalloc(&s.slot, k * 4)); TRY(hipHostMalloc(&s.obs, k * Do * 4));
@@ -320,8 +369,9 @@ extern "C" int fsrl_optim_reset(fsrl_ctx* c) {
     CHECK_ARG(c, "null ctx");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->compute));
-    HIPCHK(hipMemset(c->M, 0, (size_t)c->n_dev * 4));
-    HIPCHK(hipMemset(c->V, 0, (size_t)c->n_dev * 4));
+    HIPCHK(hipMemsetAsync(c->M, 0, (size_t)c->n_dev * 4, c->compute));
+    HIPCHK(hipMemsetAsync(c->V, 0, (size_t)c->n_dev * 4, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
     c->adam_t = 0;
     return 0;
 }
@@ -958,7 +1008,8 @@ static int tr_alloc(fsrl_ctx* c, TrState* t, int64_t n) {
     HIPCHK(hipMalloc(&t->rd, rows * FSRL_RD * 4));
     if (!t->Vdev) {
         HIPCHK(hipMalloc(&t->Vdev, (size_t)c->n_dev * 4)); HIPCHK(hipMalloc(&t->Out, (size_t)c->n_dev * 4));
-        HIPCHK(hipMemset(t->Vdev, 0, (size_t)c->n_dev * 4)); HIPCHK(hipMemset(t->Out, 0, (size_t)c->n_dev * 4));
+        HIPCHK(hipMemsetAsync(t->Vdev, 0, (size_t)c->n_dev * 4, c->compute)); HIPCHK(hipMemsetAsync(t->Out, 0, (size_t)c->n_dev * 4, c->compute));
+        HIPCHK(hipStreamSynchronize(c->compute));
         HIPCHK(hipMalloc(&t->d_scal, 64 * sizeof(double)));
     }
     t->cap_rows = (size_t)t->rows_pad;
@@ -1058,14 +1109,15 @@ static int tr_wgrad_plain(fsrl_ctx* c, TrState* t, int net0, int ny, float* out)
         wn.b1_src = t->D1 + nb * H; wn.b2_src = t->D2 + nb * H; wn.do_src = t->DO + nb * FSRL_DOW;
         wn.net = net0 + y;
     }
-    wa.obs = c->b.obs; wa.out = out; wa.rows = t->rows_pad; wa.N = (int)c->N;
-    return dispatch_H(c->cfg.hidden, [&](auto hc) {
-        constexpr int HH = decltype(hc)::value;
-        constexpr int NB = (HH / 32) * (HH / 32) + HH / 32 + 1;
-        hipLaunchKernelGGL(fb_wgrad_kernel<HH>, dim3(NB, ny), dim3(1024), 0, c->compute, c->md, wa);
-        HIPCHK(hipGetLastError());
-        return 0;
-    });
+    wa.obs = c->b.obs; wa.rows = t->rows_pad; wa.N = (int)c->N;
+    int nsplit = 1;
+    int rc = wgrad_launch<false>(c, c->md, wa, ny, c->n_dev, &nsplit);
+    if (rc) return rc;
+    const int begin = c->md.net[net0].begin, end = c->md.net[net0 + ny - 1].end;
+    hipLaunchKernelGGL(fb_sum_parts_kernel, dim3((end - begin + 255) / 256), dim3(256), 0, c->compute, out, c->wg_parts,
+                       begin, end, nsplit, c->n_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // gradient of a scalar actor objective; returns the flat ACTOR gradient and the 8 batch means
@@ -1111,15 +1163,13 @@ static int tr_hvp(fsrl_ctx* c, TrState* t, const float* v, float* out) {
     wn.w1_y = t->RD1;                                                             // R{dW1} = R{dz1}^T x
     wn.w3_xa = t->A2; wn.w3_ya = t->RDO; wn.w3_xb = t->RA2; wn.w3_yb = t->DO;     // R{dW3} = R{dout}^T h2 + dout^T R{h2}
     wn.b1_src = t->RD1; wn.b2_src = t->RD2; wn.do_src = t->RDO; wn.net = 0;
-    wa.obs = c->b.obs; wa.out = t->Out; wa.rows = t->rows_pad; wa.N = (int)c->N;
-    rc = dispatch_H(c->cfg.hidden, [&](auto hc) {
-        constexpr int HH = decltype(hc)::value;
-        constexpr int NB = (HH / 32) * (HH / 32) + HH / 32 + 1;
-        hipLaunchKernelGGL(fb_wgrad_kernel<HH>, dim3(NB, 1), dim3(1024), 0, c->compute, c->md, wa);
-        HIPCHK(hipGetLastError());
-        return 0;
-    });
+    wa.obs = c->b.obs; wa.rows = t->rows_pad; wa.N = (int)c->N;
+    int nsplit = 1;
+    rc = wgrad_launch<true>(c, c->md, wa, 1, c->n_dev, &nsplit);
     if (rc) return rc;
+    hipLaunchKernelGGL(fb_sum_parts_kernel, dim3((c->md.net[0].end - c->md.net[0].begin + 255) / 256), dim3(256), 0,
+                       c->compute, t->Out, c->wg_parts, c->md.net[0].begin, c->md.net[0].end, nsplit, c->n_dev);
+    HIPCHK(hipGetLastError());
     return actor_from_dev(c, t->Out, out);
 }
 
@@ -1224,7 +1274,7 @@ static int tr_critic_steps(fsrl_ctx* c, TrState* t, int iters, float l2, float* 
         const double bc1 = 1.0 - std::pow(b1, (double)t->critic_t), bc2 = 1.0 - std::pow(b2, (double)t->critic_t);
         hipLaunchKernelGGL(adam_range_kernel, dim3((end - begin + 255) / 256), dim3(256), 0, c->compute, c->P, c->M,
                            c->V, c->G, begin, end, l2, (float)(1.0 - b1), c->cfg.beta2, (float)(1.0 - b2),
-                           (float)((double)t->cfg.critic_lr / bc1), (float)std::sqrt(bc2), c->cfg.adam_eps);
+                           (float)((double)t->cfg.critic_lr / bc1), (float)std::sqrt(bc2), c->cfg.adam_eps, 1, 0);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -1476,8 +1526,9 @@ extern "C" int fsrl_sac_init(fsrl_ctx* c, const fsrl_sac_config* cfg) {
     s->cfg = *cfg;
     sac_layout(c, s);
     const size_t ab = (size_t)s->na_dev * 4, qb = (size_t)s->nq_dev * 4;
-    for (float** p : {&s->PA, &s->MA, &s->VA, &s->GA}) { HIPCHK(hipMalloc(p, ab)); HIPCHK(hipMemset(*p, 0, ab)); }
-    for (float** p : {&s->PQ, &s->PQT, &s->MQ, &s->VQ, &s->GQ}) { HIPCHK(hipMalloc(p, qb)); HIPCHK(hipMemset(*p, 0, qb)); }
+    for (float** p : {&s->PA, &s->MA, &s->VA, &s->GA}) { HIPCHK(hipMalloc(p, ab)); HIPCHK(hipMemsetAsync(*p, 0, ab, c->compute)); }
+    for (float** p : {&s->PQ, &s->PQT, &s->MQ, &s->VQ, &s->GQ}) { HIPCHK(hipMalloc(p, qb)); HIPCHK(hipMemsetAsync(*p, 0, qb, c->compute)); }
+    HIPCHK(hipStreamSynchronize(c->compute));
     HIPCHK(hipMalloc(&s->sc, sizeof(SacScalars)));
     SacScalars init{cfg->auto_alpha ? 1.0f : cfg->alpha, 0.0f, 0.0f, 0.0f, 0, 0};
     HIPCHK(hipMemcpy(s->sc, &init, sizeof(init), hipMemcpyHostToDevice));
@@ -1532,8 +1583,9 @@ extern "C" int fsrl_sac_params_set(fsrl_ctx* c, const float* actor, int64_t na, 
     rc = sac_copy(c, s->tmap_q, s->nq_dev, s->PQ, critics, nullptr);
     if (rc) return rc;
     HIPCHK(hipMemcpy(s->PQT, s->PQ, (size_t)s->nq_dev * 4, hipMemcpyDeviceToDevice));   // critics_old = deepcopy
-    for (float* p : {s->MA, s->VA}) HIPCHK(hipMemset(p, 0, (size_t)s->na_dev * 4));
-    for (float* p : {s->MQ, s->VQ}) HIPCHK(hipMemset(p, 0, (size_t)s->nq_dev * 4));
+    for (float* p : {s->MA, s->VA}) HIPCHK(hipMemsetAsync(p, 0, (size_t)s->na_dev * 4, c->compute));
+    for (float* p : {s->MQ, s->VQ}) HIPCHK(hipMemsetAsync(p, 0, (size_t)s->nq_dev * 4, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
     s->t_actor = s->t_critic = 0;
     SacScalars init{s->cfg.auto_alpha ? std::exp(log_alpha) : s->cfg.alpha, log_alpha, 0.0f, 0.0f, 0, 0};
     HIPCHK(hipMemcpy(s->sc, &init, sizeof(init), hipMemcpyHostToDevice));
@@ -1567,7 +1619,7 @@ static int sac_alloc_batch(fsrl_ctx* c, SacState* s, int B) {
         if (*p) HIPCHK(hipFree(*p));
         *p = nullptr;
         HIPCHK(hipMalloc(p, bytes));
-        HIPCHK(hipMemset(*p, 0, bytes));
+        HIPCHK(hipMemsetAsync(*p, 0, bytes, c->compute));
         return 0;
     };
     auto reh = [&](auto** p, size_t bytes) -> int {
@@ -1631,7 +1683,8 @@ static int sac_q_launch(fsrl_ctx* c, SacState* s, const float* params, const flo
     });
 }
 
-static int sac_wgrad(fsrl_ctx* c, SacState* s, const ModelDesc& md, int ny, const float* X, float* out, int B) {
+// weight gradients of `ny` networks of `md` as split-K partials in c->wg_parts (stride = n_dev)
+static int sac_wgrad(fsrl_ctx* c, SacState* s, const ModelDesc& md, int ny, const float* X, int n_dev, int B, int* nsplit) {
     FbWgradArgs wa{};
     const size_t H = c->cfg.hidden, rp = (size_t)s->n_tiles * 16;
     for (int y = 0; y < ny; ++y) {
@@ -1642,22 +1695,18 @@ static int sac_wgrad(fsrl_ctx* c, SacState* s, const ModelDesc& md, int ny, cons
         wn.w3_xb = nullptr; wn.w3_yb = nullptr; wn.b1_src = s->D1 + nb * H; wn.b2_src = s->D2 + nb * H;
         wn.do_src = s->DO + nb * FSRL_DOW; wn.net = y;
     }
-    wa.obs = X; wa.out = out; wa.rows = (int)rp; wa.N = B;
-    return dispatch_H(c->cfg.hidden, [&](auto hc) {
-        constexpr int HH = decltype(hc)::value;
-        constexpr int NB = (HH / 32) * (HH / 32) + HH / 32 + 1;
-        hipLaunchKernelGGL(fb_wgrad_kernel<HH>, dim3(NB, ny), dim3(1024), 0, c->compute, md, wa);
-        HIPCHK(hipGetLastError());
-        return 0;
-    });
+    wa.obs = X; wa.rows = (int)rp; wa.N = B;
+    return wgrad_launch<false>(c, md, wa, ny, n_dev, nsplit);
 }
 
-static void adam_launch(fsrl_ctx* c, float* P, float* M, float* V, const float* G, int n, float lr, int64_t t) {
+// Adam with the gradient read as the z-ordered sum of `nparts` split-K partials
+static void adam_launch(fsrl_ctx* c, float* P, float* M, float* V, const float* G, int n, float lr, int64_t t,
+                        int nparts, int stride) {
     const double b1 = c->cfg.beta1, b2 = c->cfg.beta2;
     const double bc1 = 1.0 - std::pow(b1, (double)t), bc2 = 1.0 - std::pow(b2, (double)t);
     hipLaunchKernelGGL(adam_range_kernel, dim3((n + 255) / 256), dim3(256), 0, c->compute, P, M, V, G, 0, n, 0.0f,
                        (float)(1.0 - b1), c->cfg.beta2, (float)(1.0 - b2), (float)((double)lr / bc1),
-                       (float)std::sqrt(bc2), c->cfg.adam_eps);
+                       (float)std::sqrt(bc2), c->cfg.adam_eps, nparts, stride);
 }
 
 extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, const float* eps_target,
@@ -1745,10 +1794,11 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     // ---- critic step (all four Q-nets, one Adam)
     rc = sac_q_launch(c, s, s->PQ, s->XQ, FB_MODE_Q_TRAIN, 0.f, 0.f, s->stq, B);
     if (rc) return rc;
-    rc = sac_wgrad(c, s, s->mdq, 4, s->XQ, s->GQ, B);
+    int nsplit = 1;
+    rc = sac_wgrad(c, s, s->mdq, 4, s->XQ, s->nq_dev, B, &nsplit);
     if (rc) return rc;
     s->t_critic += 1;
-    adam_launch(c, s->PQ, s->MQ, s->VQ, s->GQ, s->nq_dev, s->cfg.critic_lr, s->t_critic);
+    adam_launch(c, s->PQ, s->MQ, s->VQ, c->wg_parts, s->nq_dev, s->cfg.critic_lr, s->t_critic, nsplit, s->nq_dev);
     // ---- actor step: a ~ pi(s), Q(s, a) with the UPDATED critics, dL/da, actor backward
     rc = actor_launch(s->OBS, s->eps_p, s->XP, s->LP, SAC_A_FWD);
     if (rc) return rc;
@@ -1758,10 +1808,10 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     if (rc) return rc;
     rc = actor_launch(s->OBS, s->eps_p, s->XP, s->LP, SAC_A_BWD);
     if (rc) return rc;
-    rc = sac_wgrad(c, s, s->mda, 1, s->OBS, s->GA, B);
+    rc = sac_wgrad(c, s, s->mda, 1, s->OBS, s->na_dev, B, &nsplit);
     if (rc) return rc;
     s->t_actor += 1;
-    adam_launch(c, s->PA, s->MA, s->VA, s->GA, s->na_dev, s->cfg.actor_lr, s->t_actor);
+    adam_launch(c, s->PA, s->MA, s->VA, c->wg_parts, s->na_dev, s->cfg.actor_lr, s->t_actor, nsplit, s->na_dev);
     // ---- alpha step + logged stats, then Polyak
     SacFinalArgs fa{};
     fa.statp_q = s->stq; fa.statp_din = s->stdin_; fa.statp_pi = s->stpi; fa.sc = s->sc; fa.stats = s->d_stats;

@@ -484,51 +484,60 @@ struct FbWgradNet {
 struct FbWgradArgs {
     FbWgradNet nets[FSRL_MAX_NETS];
     const float* obs;    // [N][Do]
-    float* out;          // flat, parameter layout
+    float* out;          // flat, parameter layout; split z writes its partial at out + z * split_stride
     int rows;            // padded row count (multiple of 16; rows beyond N hold zeros in Y)
     int N;
+    int ks_per_split;    // k-steps (4 rows each) per blockIdx.z
+    int split_stride;    // floats between the partial gradients of consecutive splits
 };
 
-template <int H>
+// Weight-side products over a row range.  grid = (NT2 + NA + 1, ny, nsplit): blockIdx.z owns the rows
+// [4*z*ks_per_split, 4*(z+1)*ks_per_split) and writes a PARTIAL gradient; the consumer
+// (fb_sum_parts_kernel or adam_range_kernel's nparts) adds the partials in z order, so the result
+// does not depend on scheduling.  PAIR2: second operand pair (R-op products of the HVP).
+template <int H, bool PAIR2>
 __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, const FbWgradArgs wa) {
     constexpr int TPD = H / 32;
     constexpr int NT2 = TPD * TPD;
     constexpr int NA = H / 32;
+    constexpr int BU = 4;                   // k-steps per load burst
     __shared__ float red[1024 * 9];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FbWgradNet wn = wa.nets[blockIdx.y];
     const NetOff no = md.net[wn.net];
     const int rb = blockIdx.x;
-    const int KS = wa.rows >> 2;            // k-steps of 4 rows
+    const int KS0 = blockIdx.z * wa.ks_per_split;
+    const int KS = min(wa.rows >> 2, KS0 + wa.ks_per_split);     // this split's k-step range [KS0, KS)
+    float* __restrict__ gout = wa.out + (size_t)blockIdx.z * wa.split_stride;
     const int c = lane & 15, q = lane >> 4;
     const int Do = md.Do, out = no.out;
 
     if (rb < NT2) {
         const int tj = rb / TPD, tk = rb % TPD;
         f32x4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
-        for (int s0 = wave; s0 < KS; s0 += 16 * 8) {       // bursts of 8 k-steps per wave
-            f32x2 ya[8], xa[8], yb[8], xb[8];
+        for (int s0 = KS0 + wave; s0 < KS; s0 += 16 * BU) {       // bursts of BU k-steps per wave
+            f32x2 ya[BU], xa[BU], yb[BU], xb[BU];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < BU; ++u) {
                 const int s = s0 + 16 * u;
                 ya[u] = xa[u] = yb[u] = xb[u] = f32x2{0.f, 0.f};
                 if (s < KS) {
                     const size_t r = (size_t)(4 * s + q) * H;
                     ya[u] = *reinterpret_cast<const f32x2*>(wn.w2_ya + r + tj * 32 + 2 * c);
                     xa[u] = *reinterpret_cast<const f32x2*>(wn.w2_xa + r + tk * 32 + 2 * c);
-                    if (wn.w2_yb) {
+                    if constexpr (PAIR2) {
                         yb[u] = *reinterpret_cast<const f32x2*>(wn.w2_yb + r + tj * 32 + 2 * c);
                         xb[u] = *reinterpret_cast<const f32x2*>(wn.w2_xb + r + tk * 32 + 2 * c);
                     }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < BU; ++u) {
                 acc00 = mfma_16x16x4(ya[u][0], xa[u][0], acc00);
                 acc01 = mfma_16x16x4(ya[u][0], xa[u][1], acc01);
                 acc10 = mfma_16x16x4(ya[u][1], xa[u][0], acc10);
                 acc11 = mfma_16x16x4(ya[u][1], xa[u][1], acc11);
-                if (wn.w2_yb) {
+                if constexpr (PAIR2) {
                     acc00 = mfma_16x16x4(yb[u][0], xb[u][0], acc00);
                     acc01 = mfma_16x16x4(yb[u][0], xb[u][1], acc01);
                     acc10 = mfma_16x16x4(yb[u][1], xb[u][0], acc10);
@@ -555,14 +564,14 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
         float v = 0.0f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) v += red[w * (32 * 33) + jl * 33 + kl];
-        wa.out[no.W2 + (size_t)(tj * 32 + jl) * H + tk * 32 + kl] = v;
+        gout[no.W2 + (size_t)(tj * 32 + jl) * H + tk * 32 + kl] = v;
     } else if (rb < NT2 + NA) {
         const int j0 = (rb - NT2) * 32;
         for (int k0 = 0; k0 < Do; k0 += 16) {
             const bool first = (k0 == 0);
             f32x4 ax0 = {0, 0, 0, 0}, ax1 = {0, 0, 0, 0}, ad0 = {0, 0, 0, 0}, ad1 = {0, 0, 0, 0};
             f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
-            for (int sb = wave; sb < KS; sb += 16 * 4) {
+            for (int sb = KS0 + wave; sb < KS; sb += 16 * 4) {
                 f32x2 y1[4], xa3[4], xb3[4], b1v[4], b2v[4];
                 float bx[4], bda[4], bdb[4];
 #pragma unroll
@@ -577,7 +586,7 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
                         if (first) {
                             xa3[u] = *reinterpret_cast<const f32x2*>(wn.w3_xa + r * H + j0 + 2 * c);
                             bda[u] = wn.w3_ya[r * FSRL_DOW + c];
-                            if (wn.w3_xb) {
+                            if constexpr (PAIR2) {
                                 xb3[u] = *reinterpret_cast<const f32x2*>(wn.w3_xb + r * H + j0 + 2 * c);
                                 bdb[u] = wn.w3_yb[r * FSRL_DOW + c];
                             }
@@ -593,7 +602,7 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
                     if (first) {
                         ad0 = mfma_16x16x4(xa3[u][0], bda[u], ad0);
                         ad1 = mfma_16x16x4(xa3[u][1], bda[u], ad1);
-                        if (wn.w3_xb) {
+                        if constexpr (PAIR2) {
                             ad0 = mfma_16x16x4(xb3[u][0], bdb[u], ad0);
                             ad1 = mfma_16x16x4(xb3[u][1], bdb[u], ad1);
                         }
@@ -644,16 +653,16 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
             for (int w = 0; w < 8; ++w) v += red[w * 1088 + off];
             const int jl = e >> 4, kk = e & 15;
             if (tid < 512) {
-                if (k0 + kk < Do) wa.out[no.W1 + (size_t)(j0 + jl) * Do + k0 + kk] = v;
+                if (k0 + kk < Do) gout[no.W1 + (size_t)(j0 + jl) * Do + k0 + kk] = v;
             } else if (first && kk < out) {
-                wa.out[no.W3 + (size_t)kk * H + j0 + jl] = v;
+                gout[no.W3 + (size_t)kk * H + j0 + jl] = v;
             }
             if (first && tid < 64) {
                 float bsum = 0.0f;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) bsum += red[w * 1088 + 1024 + tid];
-                if (tid < 32) wa.out[no.b1 + j0 + tid] = bsum;
-                else wa.out[no.b2 + j0 + tid - 32] = bsum;
+                if (tid < 32) gout[no.b1 + j0 + tid] = bsum;
+                else gout[no.b2 + j0 + tid - 32] = bsum;
             }
             __syncthreads();
         }
@@ -661,12 +670,13 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
         // db3[o] / dsigma[d]: column sums of the dout-like buffer over all rows
         const int col = tid & 31, php = tid >> 5;
         float t = 0.0f;
-        for (int r0 = php; r0 < wa.rows; r0 += 32 * 8) {
+        const int rend = 4 * KS;
+        for (int r0 = 4 * KS0 + php; r0 < rend; r0 += 32 * 8) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int r = r0 + 32 * u;
-                v[u] = (r < wa.rows) ? wn.do_src[(size_t)r * FSRL_DOW + col] : 0.0f;
+                v[u] = (r < rend) ? wn.do_src[(size_t)r * FSRL_DOW + col] : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) t += v[u];
@@ -677,10 +687,20 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
             float tot = 0.0f;
 #pragma unroll
             for (int p2 = 0; p2 < 32; ++p2) tot += red[p2 * 33 + tid];
-            if (tid < out) wa.out[no.b3 + tid] = tot;
-            if (no.sigma >= 0 && tid >= 16 && tid < 16 + md.Da) wa.out[no.sigma + tid - 16] = tot;
+            if (tid < out) gout[no.b3 + tid] = tot;
+            if (no.sigma >= 0 && tid >= 16 && tid < 16 + md.Da) gout[no.sigma + tid - 16] = tot;
         }
     }
+}
+
+// out[i] = sum_z parts[z * stride + i], z ascending (fixed order), i in [begin, end)
+__global__ __launch_bounds__(256) void fb_sum_parts_kernel(float* __restrict__ out, const float* __restrict__ parts,
+                                                          int begin, int end, int nparts, int stride) {
+    const int i = begin + blockIdx.x * 256 + threadIdx.x;
+    if (i >= end) return;
+    float v = parts[i];
+    for (int z = 1; z < nparts; ++z) v += parts[(size_t)z * stride + i];
+    out[i] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -753,11 +773,13 @@ __global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ P, 
                                                         float* __restrict__ V, const float* __restrict__ G,
                                                         int begin, int end, float l2, float one_minus_b1,
                                                         float beta2, float one_minus_b2, float step_size,
-                                                        float bc2_sqrt, float eps) {
+                                                        float bc2_sqrt, float eps, int nparts, int stride) {
     const int i = begin + blockIdx.x * 256 + threadIdx.x;
     if (i < end) {
         const float p = P[i];
-        const float g = G[i] + 2.0f * l2 * p;
+        float gs = G[i];                                   // split-K partials of fb_wgrad_kernel, z order
+        for (int z = 1; z < nparts; ++z) gs += G[(size_t)z * stride + i];
+        const float g = gs + 2.0f * l2 * p;
         float m = M[i], v = V[i];
         m = m + one_minus_b1 * (g - m);
         v = v * beta2;

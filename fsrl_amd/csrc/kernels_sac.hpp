@@ -194,16 +194,24 @@ struct SacFinalArgs {
 };
 __global__ __launch_bounds__(64) void sac_finalize_kernel(const SacFinalArgs a) {
     const int lane = threadIdx.x;
-    // lanes 0..3: td^2 of net l ; 4..7: min-Q sums of net l-4 ; 8: log pi
-    double s = 0.0;
-    for (int t = 0; t < a.n_tiles; ++t) {
-        if (lane < 4) s += (double)a.statp_q[((size_t)t * 4 + lane) * FB_NSTAT];
-        else if (lane < 8) s += (double)a.statp_din[((size_t)t * 4 + (lane - 4)) * FB_NSTAT];
-        else if (lane == 8) s += (double)a.statp_pi[(size_t)t * FB_NSTAT];
+    // nine sums over the tiles (4 x td^2, 4 x min-Q, log pi): lanes stride the tiles, then a fixed
+    // xor-tree adds the lanes (float64, order independent of scheduling)
+    double s9[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s9[k] = 0.0;
+    for (int t = lane; t < a.n_tiles; t += 64) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s9[k] += (double)a.statp_q[((size_t)t * 4 + k) * FB_NSTAT];
+            s9[4 + k] += (double)a.statp_din[((size_t)t * 4 + k) * FB_NSTAT];
+        }
+        s9[8] += (double)a.statp_pi[(size_t)t * FB_NSTAT];
     }
-    const float v = (float)(s / (double)a.B);
-    const float q_r1 = __shfl(v, 0, 64), q_r2 = __shfl(v, 1, 64), q_c1 = __shfl(v, 2, 64), q_c2 = __shfl(v, 3, 64);
-    const float minqr = __shfl(v, 4, 64), minqc = __shfl(v, 6, 64), mlogp = __shfl(v, 8, 64);
+    float m9[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m9[k] = (float)(wave_sum_d(s9[k]) / (double)a.B);
+    const float q_r1 = m9[0], q_r2 = m9[1], q_c1 = m9[2], q_c2 = m9[3];
+    const float minqr = m9[4], minqc = m9[6], mlogp = m9[8];
     if (lane == 0) {
         SacScalars sc = *a.sc;
         const float alpha = a.auto_alpha ? sc.alpha : a.alpha_fixed;
