@@ -66,7 +66,7 @@ class SACLagAgent(OffpolicyAgent):
                  gamma: float = 0.99, conditioned_sigma: bool = True, unbounded: bool = True,
                  last_layer_scale: bool = False, deterministic_eval: bool = False, action_scaling: bool = True,
                  action_bound_method: str = "clip", lr_scheduler=None, training_num: int = 10,
-                 buffer_size: int = 100000) -> None:
+                 buffer_size: int = 100000, reference_rng: bool = False) -> None:
         super().__init__()
         self.logger = logger if logger is not None else DummyLogger()
         self.cost_limit = cost_limit
@@ -104,4 +104,4 @@ class SACLagAgent(OffpolicyAgent):
                                     action_bound_method=action_bound_method,
                                     observation_space=env.observation_space, action_space=env.action_space,
                                     lr_scheduler=lr_scheduler, device=device, env_num=training_num,
-                                    buffer_size=buffer_size)
+                                    buffer_size=buffer_size, reference_rng=reference_rng, seed=seed)

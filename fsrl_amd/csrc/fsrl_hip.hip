@@ -124,6 +124,7 @@ struct fsrl_ctx {
     // padded size) so that the never-written inter-tensor padding stays zero
     struct Parts { int stride = 0; float* p = nullptr; size_t floats = 0; } parts[3];
     float* wg_parts = nullptr;      // the buffer the last wgrad_launch wrote
+    uint64_t store_version = 1;     // bumped by every push / reset (device copies of the bookkeeping)
     struct TrState* tr = nullptr;   // trust-region (CPO / TRPO-Lag) working set, owned
     void* sac = nullptr;            // SacState, owned
 };
@@ -413,6 +414,7 @@ extern "C" int fsrl_store_push(fsrl_ctx* c, const int32_t* env_ids, int32_t k, c
     CHECK_ARG(c && env_ids && obs && act && rew && terminated && truncated && obs_next, "null argument");
     CHECK_ARG(k >= 0 && k <= c->cfg.env_num, "k=%d rows but %d sub-buffers", k, c->cfg.env_num);
     HIPCHK(hipSetDevice(c->device));
+    c->store_version += 1;
     const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim;
     for (int j = 0; j < k; ++j) {
         const int e = env_ids[j];
@@ -465,6 +467,7 @@ extern "C" int fsrl_store_reset(fsrl_ctx* c, int keep_statistics) {
     if (rc) return rc;
     for (EnvBook& e : c->env) e = EnvBook();
     c->batch_ready = false;
+    c->store_version += 1;
     return 0;
 }
 
@@ -1461,9 +1464,15 @@ struct SacState {
     float *eps_t = nullptr, *eps_p = nullptr, *h_eps = nullptr;                   // device / pinned
     float *LPN = nullptr, *LP = nullptr, *QT = nullptr, *QP = nullptr, *Y = nullptr, *DA = nullptr;
     float *A1 = nullptr, *A2 = nullptr, *D1 = nullptr, *D2 = nullptr, *DO = nullptr;   // [4][Bpad]
-    float *stq = nullptr, *stdin_ = nullptr, *stpi = nullptr, *d_stats = nullptr;
-    uint64_t rng[4] = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 7};
+    float *stq = nullptr, *stdin_ = nullptr, *stpi = nullptr;
+    float* d_stats = nullptr;                 // ring [SAC_RING][FSRL_SAC_NSTATS]: one row per update
+    int64_t n_updates = 0, n_drained = 0;
+    uint64_t key = 0x243F6A8885A308D3ull;     // Philox key of the library-RNG mode
+    SacBook* d_book = nullptr; SacBook* h_book = nullptr;      // device / pinned sub-buffer bookkeeping
+    uint64_t book_version = 0;
+    int last_B = 0;
 };
+static constexpr int SAC_RING = 4096;
 
 static SacState* sac_of(fsrl_ctx* c) { return reinterpret_cast<SacState*>(c->sac); }
 
@@ -1532,7 +1541,9 @@ extern "C" int fsrl_sac_init(fsrl_ctx* c, const fsrl_sac_config* cfg) {
     HIPCHK(hipMalloc(&s->sc, sizeof(SacScalars)));
     SacScalars init{cfg->auto_alpha ? 1.0f : cfg->alpha, 0.0f, 0.0f, 0.0f, 0, 0};
     HIPCHK(hipMemcpy(s->sc, &init, sizeof(init), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&s->d_stats, FSRL_SAC_NSTATS_K * 4));
+    HIPCHK(hipMalloc(&s->d_stats, (size_t)SAC_RING * FSRL_SAC_NSTATS_K * 4));
+    HIPCHK(hipMalloc(&s->d_book, (size_t)c->cfg.env_num * sizeof(SacBook)));
+    HIPCHK(hipHostMalloc(&s->h_book, (size_t)c->cfg.env_num * sizeof(SacBook)));
     return 0;
 }
 
@@ -1544,9 +1555,9 @@ static void sac_free(fsrl_ctx* c) {
                     (void*)s->XQ, (void*)s->OBS, (void*)s->OBSN, (void*)s->XN, (void*)s->XP, (void*)s->eps_t,
                     (void*)s->eps_p, (void*)s->LPN, (void*)s->LP, (void*)s->QT, (void*)s->QP, (void*)s->Y,
                     (void*)s->DA, (void*)s->A1, (void*)s->A2, (void*)s->D1, (void*)s->D2, (void*)s->DO,
-                    (void*)s->stq, (void*)s->stdin_, (void*)s->stpi, (void*)s->d_stats})
+                    (void*)s->stq, (void*)s->stdin_, (void*)s->stpi, (void*)s->d_stats, (void*)s->d_book})
         if (p) (void)hipFree(p);
-    for (void* p : {(void*)s->h_idx, (void*)s->h_chain, (void*)s->h_end, (void*)s->h_eps})
+    for (void* p : {(void*)s->h_idx, (void*)s->h_chain, (void*)s->h_end, (void*)s->h_eps, (void*)s->h_book})
         if (p) (void)hipHostFree(p);
     delete s;
     c->sac = nullptr;
@@ -1661,13 +1672,6 @@ static inline bool store_end_flag(const fsrl_ctx* c, int64_t idx) {
     return eb.size > 0 && local == (eb.index - 1 + eb.size) % eb.size;   // unfinished tail
 }
 
-static double xo_uniform(uint64_t* st) { return (double)(xoshiro_next(st) >> 11) * (1.0 / 9007199254740992.0); }
-static float xo_normal(uint64_t* st) {
-    double u1 = xo_uniform(st), u2 = xo_uniform(st);
-    if (u1 < 1e-300) u1 = 1e-300;
-    return (float)(std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2));
-}
-
 static int sac_q_launch(fsrl_ctx* c, SacState* s, const float* params, const float* X, int mode, float cr, float cc,
                         float* statp, int B) {
     FbArgs a{};
@@ -1726,40 +1730,52 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     rc = sac_alloc_batch(c, s, B);
     if (rc) return rc;
     hipStream_t st = c->compute;
-    HIPCHK(hipStreamSynchronize(st));          // pinned staging of the previous update has landed
     const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim, ns = s->cfg.n_step;
-    if (seed) { s->rng[0] ^= seed; s->rng[1] += seed * 0x9E3779B97F4A7C15ull; }
-    // ---- indices: given (parity) or uniform over the stored rows (perf)
-    for (int b = 0; b < B; ++b) {
-        int64_t idx;
-        if (indices) {
-            idx = indices[b];
+    CHECK_ARG((indices != nullptr) == (eps_target != nullptr) && (indices != nullptr) == (eps_pi != nullptr),
+              "indices, eps_target and eps_pi are given together (caller RNG) or all NULL (library RNG)");
+    if (seed) s->key = seed * 0x9E3779B97F4A7C15ull + 0x243F6A8885A308D3ull;
+    if (indices) {
+        // ---- caller-provided sample (parity mode): index chains on the host, staged through pinned memory
+        HIPCHK(hipStreamSynchronize(st));      // pinned staging of the previous update has landed
+        for (int b = 0; b < B; ++b) {
+            const int64_t idx = indices[b];
             CHECK_ARG(idx >= 0 && idx < c->maxsize, "index %lld out of range", (long long)idx);
-        } else {
-            int64_t k = (int64_t)(xo_uniform(s->rng) * (double)stored);
-            if (k >= stored) k = stored - 1;
-            int e = 0;
-            while (k >= c->env[(size_t)e].size) { k -= c->env[(size_t)e].size; ++e; }
-            idx = (int64_t)e * c->sub_size + k;
+            s->h_idx[b] = (int)idx;
+            int64_t cur = idx;
+            for (int n = 0; n < ns; ++n) {      // indices[n] = buffer.next(indices[n-1])
+                if (n > 0) cur = store_next(c, cur);
+                s->h_chain[(size_t)n * B + b] = (int)cur;
+                s->h_end[(size_t)n * B + b] = store_end_flag(c, cur) ? 1 : 0;
+            }
         }
-        s->h_idx[b] = (int)idx;
-        int64_t cur = idx;
-        for (int n = 0; n < ns; ++n) {          // indices[n] = buffer.next(indices[n-1])
-            if (n > 0) cur = store_next(c, cur);
-            s->h_chain[(size_t)n * B + b] = (int)cur;
-            s->h_end[(size_t)n * B + b] = store_end_flag(c, cur) ? 1 : 0;
+        float* he_t = s->h_eps; float* he_p = s->h_eps + (size_t)B * Da;
+        memcpy(he_t, eps_target, (size_t)B * Da * 4);
+        memcpy(he_p, eps_pi, (size_t)B * Da * 4);
+        HIPCHK(hipMemcpyAsync(s->d_idx, s->h_idx, (size_t)B * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->d_chain, s->h_chain, (size_t)B * ns * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->d_end, s->h_end, (size_t)B * ns, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->eps_t, he_t, (size_t)B * Da * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->eps_p, he_p, (size_t)B * Da * 4, hipMemcpyHostToDevice, st));
+    } else {
+        // ---- library RNG: everything on the device, nothing to wait for
+        if (s->book_version != c->store_version) {     // the store changed since the last upload
+            HIPCHK(hipStreamSynchronize(st));           // h_book may still be in flight
+            for (int e = 0; e < c->cfg.env_num; ++e) {
+                const EnvBook& eb = c->env[(size_t)e];
+                s->h_book[e] = SacBook{(int)eb.size, (int)eb.index, (int)eb.last_index, 0};
+            }
+            HIPCHK(hipMemcpyAsync(s->d_book, s->h_book, (size_t)c->cfg.env_num * sizeof(SacBook), hipMemcpyHostToDevice, st));
+            s->book_version = c->store_version;
         }
+        SacSampleArgs sa{};
+        sa.book = s->d_book; sa.flags = c->st.flags; sa.idx = s->d_idx; sa.chain = s->d_chain; sa.endbits = s->d_end;
+        sa.eps_t = s->eps_t; sa.eps_p = s->eps_p; sa.env_num = c->cfg.env_num; sa.sub_size = (int)c->sub_size; sa.B = B;
+        sa.n_step = ns; sa.Da = Da; sa.stored = (unsigned long long)stored; sa.key = s->key;
+        sa.counter = (unsigned long long)s->n_updates;
+        hipLaunchKernelGGL(sac_sample_kernel, dim3((B + 255) / 256), dim3(256), 0, st, sa);
+        HIPCHK(hipGetLastError());
     }
-    float* he_t = s->h_eps; float* he_p = s->h_eps + (size_t)B * Da;
-    for (size_t i = 0; i < (size_t)B * Da; ++i) {
-        he_t[i] = eps_target ? eps_target[i] : xo_normal(s->rng);
-        he_p[i] = eps_pi ? eps_pi[i] : xo_normal(s->rng);
-    }
-    HIPCHK(hipMemcpyAsync(s->d_idx, s->h_idx, (size_t)B * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(s->d_chain, s->h_chain, (size_t)B * ns * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(s->d_end, s->h_end, (size_t)B * ns, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(s->eps_t, he_t, (size_t)B * Da * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(s->eps_p, he_p, (size_t)B * Da * 4, hipMemcpyHostToDevice, st));
+    s->last_B = B;
     const float lam = (s->cfg.use_lagrangian && lagrangians) ? (float)lagrangians[0] : 0.0f;
     const float resc = (float)rescaling;
     // ---- gather
@@ -1814,7 +1830,8 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     adam_launch(c, s->PA, s->MA, s->VA, c->wg_parts, s->na_dev, s->cfg.actor_lr, s->t_actor, nsplit, s->na_dev);
     // ---- alpha step + logged stats, then Polyak
     SacFinalArgs fa{};
-    fa.statp_q = s->stq; fa.statp_din = s->stdin_; fa.statp_pi = s->stpi; fa.sc = s->sc; fa.stats = s->d_stats;
+    float* stats_row = s->d_stats + (size_t)(s->n_updates % SAC_RING) * FSRL_SAC_NSTATS_K;
+    fa.statp_q = s->stq; fa.statp_din = s->stdin_; fa.statp_pi = s->stpi; fa.sc = s->sc; fa.stats = stats_row;
     fa.n_tiles = s->n_tiles; fa.B = B; fa.rescale = resc; fa.lam = lam; fa.target_entropy = s->cfg.target_entropy;
     fa.alpha_lr = s->cfg.alpha_lr; fa.beta1 = c->cfg.beta1; fa.beta2 = c->cfg.beta2; fa.adam_eps = c->cfg.adam_eps;
     fa.alpha_fixed = s->cfg.alpha; fa.auto_alpha = s->cfg.auto_alpha; fa.use_lagrangian = s->cfg.use_lagrangian;
@@ -1823,10 +1840,50 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     hipLaunchKernelGGL(polyak_kernel, dim3(256), dim3(256), 0, st, s->PQT, s->PQ, s->nq_dev, s->cfg.tau,
                        (float)(1.0 - (double)s->cfg.tau));
     HIPCHK(hipGetLastError());
-    if (stats_out) {
-        HIPCHK(hipMemcpyAsync(stats_out, s->d_stats, FSRL_SAC_NSTATS_K * 4, hipMemcpyDeviceToHost, st));
+    s->n_updates += 1;
+    if (stats_out) {                           // synchronous: this update's row (and mark it drained)
+        HIPCHK(hipMemcpyAsync(stats_out, stats_row, FSRL_SAC_NSTATS_K * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        s->n_drained = s->n_updates;
     }
+    return 0;
+}
+
+// Rows of logged statistics of the updates issued with stats_out == NULL since the last drain
+// (oldest first; at most SAC_RING = 4096 are kept).  Returns the number of rows written, < 0 on error.
+extern "C" int64_t fsrl_sac_stats_drain(fsrl_ctx* c, float* out, int64_t max_rows) {
+    CHECK_ARG(c && out && max_rows >= 0, "bad argument");
+    SacState* s = sac_of(c);
+    if (!s) return fail(FSRL_ESTATE, "fsrl_sac_init first");
+    HIPCHK(hipSetDevice(c->device));
+    int64_t first = std::max(s->n_drained, s->n_updates - SAC_RING);
+    int64_t n = std::min(s->n_updates - first, max_rows);
+    for (int64_t i = 0; i < n;) {              // at most two contiguous pieces of the ring
+        const int64_t slot = (first + i) % SAC_RING;
+        const int64_t run = std::min(n - i, (int64_t)SAC_RING - slot);
+        HIPCHK(hipMemcpyAsync(out + i * FSRL_SAC_NSTATS_K, s->d_stats + slot * FSRL_SAC_NSTATS_K,
+                              (size_t)run * FSRL_SAC_NSTATS_K * 4, hipMemcpyDeviceToHost, c->compute));
+        i += run;
+    }
+    HIPCHK(hipStreamSynchronize(c->compute));
+    s->n_drained = first + n;
+    return n;
+}
+
+// The sample the last fsrl_sac_update used (either RNG mode): store indices and both N(0,1) blocks.
+extern "C" int fsrl_sac_last_sample(fsrl_ctx* c, int64_t* indices, float* eps_target, float* eps_pi, int32_t B) {
+    CHECK_ARG(c && indices && eps_target && eps_pi, "null argument");
+    SacState* s = sac_of(c);
+    if (!s) return fail(FSRL_ESTATE, "fsrl_sac_init first");
+    CHECK_ARG(B == s->last_B && B > 0, "last update used batch_size %d", s->last_B);
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<int> idx((size_t)B);
+    const size_t eb = (size_t)B * c->cfg.act_dim * 4;
+    HIPCHK(hipMemcpyAsync(idx.data(), s->d_idx, (size_t)B * 4, hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipMemcpyAsync(eps_target, s->eps_t, eb, hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipMemcpyAsync(eps_pi, s->eps_p, eb, hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    for (int b = 0; b < B; ++b) indices[b] = idx[(size_t)b];
     return 0;
 }
 

@@ -36,6 +36,67 @@ __global__ void sac_gather_kernel(const SacGatherArgs a) {
     }
 }
 
+// ---- device-side sampling (library RNG mode): uniform rows of the store, their n-step chains
+//      (tianshou ReplayBuffer.next / unfinished_index) and the two rsample N(0,1) blocks.
+//      Philox4x32-10 counter RNG: counter = (row, draw, update lo, update hi), key = seed.
+struct SacBook { int size, index, last_index, pad; };     // one sub-buffer's bookkeeping
+struct SacSampleArgs {
+    const SacBook* book; const uint8_t* flags;
+    int* idx; int* chain; uint8_t* endbits; float* eps_t; float* eps_p;
+    int env_num, sub_size, B, n_step, Da;
+    unsigned long long stored, key, counter;
+};
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        c[0] = hi1 ^ c[1] ^ k0; c[1] = lo1; c[2] = hi0 ^ c[3] ^ k1; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);              // [0, 1)
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincospif(2.0f * u2, &sn, &cs);
+    n0 = rad * cs; n1 = rad * sn;
+}
+__global__ __launch_bounds__(256) void sac_sample_kernel(const SacSampleArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const uint32_t k0 = (uint32_t)a.key, k1 = (uint32_t)(a.key >> 32);
+    uint32_t c[4] = {(uint32_t)b, 0u, (uint32_t)a.counter, (uint32_t)(a.counter >> 32)};
+    philox4x32_10(c, k0, k1);
+    unsigned long long k = ((unsigned long long)c[0] * a.stored) >> 32;    // uniform over the stored rows
+    int e = 0;
+    while (e < a.env_num - 1 && k >= (unsigned long long)a.book[e].size) { k -= a.book[e].size; ++e; }
+    int cur = e * a.sub_size + (int)k;
+    a.idx[b] = cur;
+    for (int n = 0; n < a.n_step; ++n) {
+        const int env = cur / a.sub_size, local = cur - env * a.sub_size;
+        const SacBook bk = a.book[env];
+        if (n > 0) {                                   // indices[n] = buffer.next(indices[n-1])
+            const bool end = a.flags[cur] != 0 || local == bk.last_index;
+            if (!end && bk.size > 0) cur = env * a.sub_size + (local + 1) % bk.size;
+        }
+        const int loc2 = cur - env * a.sub_size;
+        a.chain[(size_t)n * a.B + b] = cur;
+        a.endbits[(size_t)n * a.B + b] =
+            (a.flags[cur] != 0 || (bk.size > 0 && loc2 == (bk.index - 1 + bk.size) % bk.size)) ? 1 : 0;
+    }
+    for (int d0 = 0; d0 < a.Da; d0 += 2) {             // 4 normals per Philox block: 2 for each stream
+        uint32_t r[4] = {(uint32_t)b, 1u + (uint32_t)(d0 >> 1), (uint32_t)a.counter, (uint32_t)(a.counter >> 32)};
+        philox4x32_10(r, k0, k1);
+        float t0, t1, p0, p1;
+        box_muller(r[0], r[1], t0, t1);
+        box_muller(r[2], r[3], p0, p1);
+        a.eps_t[(size_t)b * a.Da + d0] = t0; a.eps_p[(size_t)b * a.Da + d0] = p0;
+        if (d0 + 1 < a.Da) { a.eps_t[(size_t)b * a.Da + d0 + 1] = t1; a.eps_p[(size_t)b * a.Da + d0 + 1] = p1; }
+    }
+}
+
 // ---- scalars that live on the device between updates
 struct SacScalars {
     float alpha, log_alpha;         // temperature

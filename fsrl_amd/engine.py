@@ -265,18 +265,36 @@ class Engine:
         _lib.check(self.lib.fsrl_sac_params_get(self._ctx, int(which), _ptr(out, _f32p), out.size, C.byref(alpha)))
         return out, float(alpha.value)
 
-    def sac_update(self, batch_size, lagrangians, rescaling, indices=None, eps_target=None, eps_pi=None, seed=0):
+    def sac_update(self, batch_size, lagrangians, rescaling, indices=None, eps_target=None, eps_pi=None, seed=0,
+                   sync=True):
+        """One SAC-Lag update.  indices/eps_* given together = caller RNG (parity); all None = device
+        RNG.  sync=False only enqueues the work: the statistics row is fetched later by sac_drain()."""
         lag = np.ascontiguousarray(lagrangians, np.float64).reshape(-1)
         idx = None if indices is None else np.ascontiguousarray(indices, np.int64)
         et = None if eps_target is None else np.ascontiguousarray(eps_target, np.float32)
         ep = None if eps_pi is None else np.ascontiguousarray(eps_pi, np.float32)
         if idx is not None:
             assert idx.size == batch_size
-        out = np.empty(_lib.SAC_NSTATS, np.float32)
+        out = np.empty(_lib.SAC_NSTATS, np.float32) if sync else None
         _lib.check(self.lib.fsrl_sac_update(self._ctx, int(batch_size), _ptr(idx, _i64p), _ptr(et, _f32p),
                                             _ptr(ep, _f32p), int(seed), _ptr(lag, _f64p) if lag.size else None,
                                             float(rescaling), _ptr(out, _f32p)))
         return out
+
+    def sac_drain(self, max_rows=4096):
+        """Statistics rows [n, SAC_NSTATS] of the sync=False updates since the last drain."""
+        out = np.empty((int(max_rows), _lib.SAC_NSTATS), np.float32)
+        n = int(self.lib.fsrl_sac_stats_drain(self._ctx, _ptr(out, _f32p), int(max_rows)))
+        if n < 0:
+            _lib.check(n)
+        return out[:n]
+
+    def sac_last_sample(self, batch_size):
+        idx = np.empty(int(batch_size), np.int64)
+        et = np.empty((int(batch_size), self.cfg.act_dim), np.float32); ep = np.empty_like(et)
+        _lib.check(self.lib.fsrl_sac_last_sample(self._ctx, _ptr(idx, _i64p), _ptr(et, _f32p), _ptr(ep, _f32p),
+                                                 int(batch_size)))
+        return idx, et, ep
 
     def sac_actor_forward(self, obs):
         obs = np.ascontiguousarray(obs, np.float32).reshape(-1, self.cfg.obs_dim)

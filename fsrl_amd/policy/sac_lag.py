@@ -28,7 +28,7 @@ class SACLagrangian(LagrangianPolicy):
                  reward_normalization: bool = False, deterministic_eval: bool = True,
                  action_scaling: bool = True, action_bound_method: str = "clip", observation_space=None,
                  action_space=None, lr_scheduler=None, device: Union[int, str] = 0, env_num: int = 1,
-                 buffer_size: int = 100000) -> None:
+                 buffer_size: int = 100000, reference_rng: bool = False, seed: int = 0) -> None:
         super().__init__(actor, critics, None, logger, use_lagrangian, lagrangian_pid, cost_limit, rescaling,
                          gamma, 10000, reward_normalization, deterministic_eval, action_scaling,
                          action_bound_method, observation_space, action_space, lr_scheduler)
@@ -61,6 +61,11 @@ class SACLagrangian(LagrangianPolicy):
                              auto_alpha=self._is_auto_alpha, use_lagrangian=use_lagrangian)
         self._push_params()
         self._dirty = False
+        # reference_rng=True: buffer.sample through numpy's and rsample through torch's global RNG,
+        # exactly the streams the reference consumes (bit-comparable runs; one host round trip per
+        # update).  False (default): sampling and noise on the device, updates only enqueue work
+        # and the logged statistics are drained after the last update of a collect step.
+        self._reference_rng, self._seed, self._pending = reference_rng, int(seed), 0
 
     # ------------------------------------------------------------------ parameter plumbing
     @staticmethod
@@ -93,6 +98,8 @@ class SACLagrangian(LagrangianPolicy):
         self._dirty = False
 
     def state_dict(self, *args, **kwargs):
+        if getattr(self, "_pending", 0):
+            self._drain()
         if getattr(self, "_dirty", False):
             self._pull_params(everything=True)
         return super().state_dict(*args, **kwargs)
@@ -120,6 +127,26 @@ class SACLagrangian(LagrangianPolicy):
             return act
         return act + self._noise(act.shape) if isinstance(act, np.ndarray) else act
 
+    def _log_rows(self, rows) -> None:
+        for st in rows:
+            d = dict(zip(SAC_KEYS, (float(v) for v in st)))
+            if not self._is_auto_alpha:
+                d.pop("loss/alpha_loss"); d.pop("loss/alpha_value")
+            if not self.use_lagrangian:
+                d.pop("loss/lagrangian"); d.pop("loss/actor_safety")
+            qs = {k: d.pop(k) for k in ("loss/q0", "loss/q1", "loss/q_total")}
+            self.logger.store(**d)
+            self.logger.store(**qs)
+
+    def _drain(self) -> None:
+        if self._pending:
+            self._log_rows(self.engine.sac_drain())
+            self._pending = 0
+
+    def post_update_fn(self, **kwarg: Any) -> None:
+        self._drain()
+        super().post_update_fn(**kwarg)
+
     def learn(self, batch, **kwargs: Any):
         raise NotImplementedError("the HIP path runs process_fn + learn inside update()")
 
@@ -129,19 +156,19 @@ class SACLagrangian(LagrangianPolicy):
         assert getattr(buffer, "engine", None) is self.engine
         self.updating = True
         B, Da = int(sample_size), self.engine.cfg.act_dim
-        indices = buffer.sample_indices(B)                               # numpy RNG, tianshou rule
-        eps_t = torch.normal(torch.zeros(B, Da), torch.ones(B, Da)).numpy()   # rsample at s_{t+n}
-        eps_p = torch.normal(torch.zeros(B, Da), torch.ones(B, Da)).numpy()   # rsample at s_t
         lags, rescaling = self.lagrangians_and_rescaling() if self.use_lagrangian else ([], 1.0)
-        st = self.engine.sac_update(B, lags, rescaling, indices=indices, eps_target=eps_t, eps_pi=eps_p)
-        d = dict(zip(SAC_KEYS, (float(v) for v in st)))
-        if not self._is_auto_alpha:
-            d.pop("loss/alpha_loss"); d.pop("loss/alpha_value")
-        if not self.use_lagrangian:
-            d.pop("loss/lagrangian"); d.pop("loss/actor_safety")
-        qs = {k: d.pop(k) for k in ("loss/q0", "loss/q1", "loss/q_total")}
-        self.logger.store(**d)
-        self.logger.store(**qs)
+        if self._reference_rng:
+            indices = buffer.sample_indices(B)                               # numpy RNG, tianshou rule
+            eps_t = torch.normal(torch.zeros(B, Da), torch.ones(B, Da)).numpy()   # rsample at s_{t+n}
+            eps_p = torch.normal(torch.zeros(B, Da), torch.ones(B, Da)).numpy()   # rsample at s_t
+            st = self.engine.sac_update(B, lags, rescaling, indices=indices, eps_target=eps_t, eps_pi=eps_p)
+            self._log_rows(st[None])
+        else:
+            seed = self._seed + 1 if self.gradient_steps == 0 else 0     # key the Philox stream once
+            self.engine.sac_update(B, lags, rescaling, seed=seed, sync=False)
+            self._pending += 1
+            if self._pending >= 2048:
+                self._drain()
         self.gradient_steps += 1
         self._dirty = True
         if self.lr_scheduler is not None:

@@ -207,11 +207,21 @@ int fsrl_sac_params_set(fsrl_ctx* ctx, const float* actor, int64_t na, const flo
 /* which: 0 actor, 1 critics, 2 critics_old (targets)                                            */
 int fsrl_sac_params_get(fsrl_ctx* ctx, int32_t which, float* out, int64_t n, float* alpha_out);
 /* One SACLagrangian.update(batch_size, buffer) = sample + n-step targets + critic step + actor
- * step + alpha step + Polyak.  indices/eps_target/eps_pi may be given (the caller's numpy / torch
- * RNG streams, for parity) or NULL (library RNG, seeded by `seed`).  stats_out: FSRL_SAC_NSTATS.  */
+ * step + alpha step + Polyak (sac_lag.py:185-269, base_policy.py:356-395,453-512).
+ * Sampling: indices / eps_target / eps_pi are given TOGETHER (the caller's numpy / torch RNG
+ * streams -- parity mode) or are all NULL (library RNG on the device: Philox4x32-10 keyed by
+ * `seed` (0 = keep the current key), uniform over the stored rows -- nothing is staged from the host).
+ * stats_out: FSRL_SAC_NSTATS floats, synchronous; NULL = the call only enqueues work and the row is
+ * kept in a device ring for fsrl_sac_stats_drain.                                                  */
 int fsrl_sac_update(fsrl_ctx* ctx, int32_t batch_size, const int64_t* indices, const float* eps_target,
                     const float* eps_pi, uint64_t seed, const double* lagrangians, double rescaling,
                     float* stats_out);
+/* Statistics rows of the updates issued with stats_out == NULL since the last drain, oldest first
+ * (the ring keeps the newest 4096).  Returns the number of rows written (>= 0) or an error code.   */
+int64_t fsrl_sac_stats_drain(fsrl_ctx* ctx, float* out, int64_t max_rows);
+/* The sample the last fsrl_sac_update used, either mode (tests: library-RNG updates can be replayed
+ * through the caller-RNG arguments).                                                              */
+int fsrl_sac_last_sample(fsrl_ctx* ctx, int64_t* indices, float* eps_target, float* eps_pi, int32_t batch_size);
 /* the actor for the collector: mu and sigma = exp(clamp(log sigma)) of the tanh-Gaussian policy   */
 int fsrl_sac_actor_forward(fsrl_ctx* ctx, const float* obs, int32_t k, float* mu_out, float* sigma_out);
 

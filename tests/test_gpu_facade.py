@@ -145,7 +145,7 @@ def test_sac_policy_update_through_facade_matches_reference():
                         torch.optim.Adam(torch.nn.ModuleList(critics).parameters(), lr=cfg["critic_lr"]),
                         logger=log, alpha=alpha, tau=cfg["tau"], n_step=cfg["n_step"], cost_limit=cfg["cost_limit"],
                         gamma=cfg["gamma"], observation_space=Box(-np.inf, np.inf, (Do, )),
-                        action_space=Box(-1, 1, (Da, )), device=0, env_num=cfg["env_num"])
+                        action_space=Box(-1, 1, (Da, )), device=0, env_num=cfg["env_num"], reference_rng=True)
     pol.train()
     buf = HipVectorReplayBuffer(pol.engine, cfg["buffer_size"], cfg["env_num"])
     rows = g["env_rows"]; off = np.concatenate([[0], np.cumsum(rows)])

@@ -75,3 +75,46 @@ def test_sac_perf_mode_runs_and_is_finite():
     mu, sigma = eng.sac_actor_forward(g["st_obs"][:37])
     assert mu.shape == (37, cfg["act_dim"]) and (sigma > 0).all() and np.isfinite(mu).all()
     eng.close()
+
+
+def test_device_sampling_replays_through_caller_rng_and_is_well_distributed():
+    """Library-RNG mode (Philox on the device): (1) the sample it drew, fed back through the
+    caller-RNG arguments into a twin context, gives bit-identical statistics and parameters -- the two
+    modes share every kernel after sampling, including the n-step chains / end flags computed on the
+    device vs the host; (2) rows are uniform over the stored rows; noise is N(0,1)."""
+    g, cfg, ocfg, store, index = sac_setup("c4")
+    dev, twin = _engine(cfg, g), _engine(cfg, g)
+    B = 512
+    valid = np.concatenate([e * (cfg["buffer_size"] // cfg["env_num"]) + np.arange(r)
+                            for e, r in enumerate(g["env_rows"])])
+    all_idx, all_eps = [], []
+    for u in range(12):
+        dev.sac_update(B, [0.5], 1 / 1.5, seed=11 if u == 0 else 0, sync=False)
+        idx, et, ep = dev.sac_last_sample(B)
+        assert np.isin(idx, valid).all()
+        st_twin = twin.sac_update(B, [0.5], 1 / 1.5, indices=idx, eps_target=et, eps_pi=ep)
+        all_idx.append(idx); all_eps += [et, ep]
+        if u == 0:
+            first = (idx.copy(), et.copy())
+    rows = dev.sac_drain()
+    assert rows.shape == (12, len(SAC_KEYS)) and np.array_equal(rows[-1], st_twin)
+    assert dev.sac_drain().shape[0] == 0
+    for which in (0, 1, 2):
+        assert np.array_equal(dev.sac_get_params(which)[0], twin.sac_get_params(which)[0])
+    idx = np.concatenate(all_idx); eps = np.concatenate([e.ravel() for e in all_eps])
+    assert not np.array_equal(all_idx[0], all_idx[1])
+    # uniform over stored rows: per-env share within 5 sigma of the binomial expectation
+    share = g["env_rows"] / g["env_rows"].sum()
+    sub = cfg["buffer_size"] // cfg["env_num"]
+    cnt = np.bincount(idx // sub, minlength=cfg["env_num"])
+    assert (np.abs(cnt - idx.size * share) <= 5 * np.sqrt(idx.size * share * (1 - share)) + 1).all()
+    n = eps.size
+    assert abs(eps.mean()) < 5 / np.sqrt(n) and abs(eps.var() - 1) < 5 * np.sqrt(2 / n)
+    assert abs((eps**4).mean() - 3) < 0.2 and abs((eps**3).mean()) < 0.1 and np.abs(eps).max() < 7
+    # same key + same update counter -> same sample
+    again = _engine(cfg, g)
+    again.sac_update(B, [0.5], 1 / 1.5, seed=11, sync=False)
+    i2, e2, _ = again.sac_last_sample(B)
+    assert np.array_equal(i2, first[0]) and np.array_equal(e2, first[1])
+    for e in (dev, twin, again):
+        e.close()
