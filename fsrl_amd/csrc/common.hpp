@@ -26,6 +26,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct NetOff {
     int sigma;  // -1 for critics
     int W1, b1, W2, b2, W3, b3;
+    int W2f;    // forward-fragment mirror of W2 (same values, wave-contiguous order), beyond the main vector
     int out;    // output width of the head (Da for the actor, 1 for a V critic)
     int begin, end;  // [begin,end) slice of the flat vector owned by this net
 };
@@ -34,6 +35,25 @@ struct ModelDesc {
     int Do, Da, H, n_nets;  // n_nets = 1 + n_critics ; net 0 = actor
     NetOff net[FSRL_MAX_NETS];
 };
+
+// ---- forward-fragment mirror of W2.  The forward GEMM wants, per wave w and k-chunk kc, lane
+// (li, q) to hold W2[16w + li][16kc + 4q .. +3].  Read from the row-major matrix that is 16 rows
+// x 64 B per instruction (1 KB stride): measured 5.9 us for the 256 KB burst, against 0.9 us when the
+// same bytes are 1 KB-contiguous per instruction (tools/ubench/ingest.hip).  So every network keeps a
+// second copy of W2 in exactly that order; whoever writes W2 (Adam, Polyak, host uploads) writes
+// the mirror too.  The backward GEMM and everything else keep using the row-major matrix.
+__host__ __device__ __forceinline__ int w2f_index(int H, int n, int k) {
+    return ((((n >> 4) * (H >> 4) + (k >> 4)) * 64) + ((k >> 2) & 3) * 16 + (n & 15)) * 4 + (k & 3);
+}
+// mirror position of main-vector element i, or -1 when i is not inside a W2 tensor
+__device__ __forceinline__ int w2f_mirror_of(const ModelDesc& md, int i) {
+    const int HH = md.H * md.H;
+    for (int net = 0; net < md.n_nets; ++net) {
+        const int o = i - md.net[net].W2;
+        if ((unsigned)o < (unsigned)HH) return md.net[net].W2f + w2f_index(md.H, o / md.H, o % md.H);
+    }
+    return -1;
+}
 
 // Scalars of one PPO minibatch step that the kernels need (passed by value).
 struct PpoStepArgs {

@@ -69,7 +69,8 @@ struct fsrl_ctx {
     ModelDesc md{};
     std::vector<TensorMap> tmap;
     int64_t n_api = 0;     // flat parameter count (API)
-    int n_dev = 0;         // padded device parameter count
+    int n_dev = 0;         // padded device parameter count (main vector: what Adam / clip / copies see)
+    int n_alloc = 0;       // n_dev + the forward-fragment mirrors of every W2 (P only)
     float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr;
     int64_t adam_t = 0;
     CtrlBlock* ctrl = nullptr;
@@ -220,6 +221,18 @@ static void build_layout(fsrl_ctx* c) {
     }
     c->n_api = api;
     c->n_dev = round_up(dev, 1024);
+    for (int net = 0; net < md.n_nets; ++net) md.net[net].W2f = c->n_dev + net * H * H;
+    c->n_alloc = c->n_dev + md.n_nets * H * H;
+}
+
+// host copy of a parameter vector in device layout: fill the W2 mirrors behind the main part
+static void fill_mirrors(const ModelDesc& md, std::vector<float>& v) {
+    const int H = md.H;
+    for (int net = 0; net < md.n_nets; ++net) {
+        const NetOff& no = md.net[net];
+        for (int n = 0; n < H; ++n)
+            for (int k = 0; k < H; ++k) v[(size_t)no.W2f + w2f_index(H, n, k)] = v[(size_t)no.W2 + (size_t)n * H + k];
+    }
 }
 
 extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
@@ -281,8 +294,9 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     TRY(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
     TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     const size_t pb = (size_t)c->n_dev * sizeof(float);
-    TRY(hipMalloc(&c->P, pb)); TRY(hipMalloc(&c->M, pb)); TRY(hipMalloc(&c->V, pb)); TRY(hipMalloc(&c->G, pb));
-    TRY(hipMemsetAsync(c->P, 0, pb, c->compute)); TRY(hipMemsetAsync(c->M, 0, pb, c->compute)); TRY(hipMemsetAsync(c->V, 0, pb, c->compute)); TRY(hipMemsetAsync(c->G, 0, pb, c->compute));
+    TRY(hipMalloc(&c->P, (size_t)c->n_alloc * sizeof(float))); TRY(hipMemsetAsync(c->P, 0, (size_t)c->n_alloc * sizeof(float), c->compute));
+    TRY(hipMalloc(&c->M, pb)); TRY(hipMalloc(&c->V, pb)); TRY(hipMalloc(&c->G, pb));
+    TRY(hipMemsetAsync(c->M, 0, pb, c->compute)); TRY(hipMemsetAsync(c->V, 0, pb, c->compute)); TRY(hipMemsetAsync(c->G, 0, pb, c->compute));
     TRY(hipMalloc(&c->ctrl, sizeof(CtrlBlock)));
     TRY(hipHostMalloc(&c->h_ctrl, sizeof(CtrlBlock)));
     // store: n sub-buffers of ceil(total/n) rows (tianshou VectorReplayBuffer)
@@ -341,11 +355,12 @@ extern "C" int64_t fsrl_param_count(const fsrl_ctx* c) { return c ? c->n_api : 0
 static int copy_flat(fsrl_ctx* c, float* dev, float* host_out, const float* host_in, int64_t n) {
     CHECK_ARG(n == c->n_api, "expected %lld parameters, got %lld", (long long)c->n_api, (long long)n);
     HIPCHK(hipSetDevice(c->device));
-    std::vector<float> tmp((size_t)c->n_dev, 0.0f);
-    if (host_in) {
+    std::vector<float> tmp((size_t)c->n_alloc, 0.0f);
+    if (host_in) {                              // only P is ever written from the host
         for (const TensorMap& t : c->tmap) memcpy(&tmp[t.dev_off], host_in + t.api_off, (size_t)t.n * 4);
+        fill_mirrors(c->md, tmp);
         HIPCHK(hipStreamSynchronize(c->compute));
-        HIPCHK(hipMemcpy(dev, tmp.data(), (size_t)c->n_dev * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dev, tmp.data(), (size_t)c->n_alloc * 4, hipMemcpyHostToDevice));
     } else {
         HIPCHK(hipStreamSynchronize(c->compute));
         HIPCHK(hipMemcpy(tmp.data(), dev, (size_t)c->n_dev * 4, hipMemcpyDeviceToHost));
@@ -845,7 +860,7 @@ extern "C" int fsrl_ppo_pass(fsrl_ctx* c, const int64_t* perm, uint64_t seed, in
         });
         if (rc) return rc;
         hipLaunchKernelGGL(adam_clip_kernel, dim3(c->n_dev / 1024), dim3(256), 0, s, c->P, c->M, c->V, c->G,
-                           c->gsq_part, nparts, c->n_dev, sa, c->ctrl);
+                           c->gsq_part, nparts, c->n_dev, sa, c->ctrl, c->md);
         HIPCHK(hipGetLastError());
     }
     c->n_steps += nmb;
@@ -1010,8 +1025,8 @@ static int tr_alloc(fsrl_ctx* c, TrState* t, int64_t n) {
     HIPCHK(hipMalloc(&t->mu_old, rows * c->cfg.act_dim * 4));
     HIPCHK(hipMalloc(&t->rd, rows * FSRL_RD * 4));
     if (!t->Vdev) {
-        HIPCHK(hipMalloc(&t->Vdev, (size_t)c->n_dev * 4)); HIPCHK(hipMalloc(&t->Out, (size_t)c->n_dev * 4));
-        HIPCHK(hipMemsetAsync(t->Vdev, 0, (size_t)c->n_dev * 4, c->compute)); HIPCHK(hipMemsetAsync(t->Out, 0, (size_t)c->n_dev * 4, c->compute));
+        HIPCHK(hipMalloc(&t->Vdev, (size_t)c->n_alloc * 4)); HIPCHK(hipMalloc(&t->Out, (size_t)c->n_dev * 4));
+        HIPCHK(hipMemsetAsync(t->Vdev, 0, (size_t)c->n_alloc * 4, c->compute)); HIPCHK(hipMemsetAsync(t->Out, 0, (size_t)c->n_dev * 4, c->compute));
         HIPCHK(hipStreamSynchronize(c->compute));
         HIPCHK(hipMalloc(&t->d_scal, 64 * sizeof(double)));
     }
@@ -1023,8 +1038,14 @@ static int tr_alloc(fsrl_ctx* c, TrState* t, int64_t n) {
 static int actor_to_dev(fsrl_ctx* c, const float* host, float* dev) {
     std::vector<float> tmp((size_t)c->md.net[0].end, 0.0f);
     for (int i = 0; i < 7; ++i) memcpy(&tmp[c->tmap[i].dev_off], host + c->tmap[i].api_off, (size_t)c->tmap[i].n * 4);
+    const int H = c->md.H;
+    const NetOff& no = c->md.net[0];
+    std::vector<float> mir((size_t)H * H);      // dev is P or a tangent vector: both carry the W2 mirror
+    for (int n = 0; n < H; ++n)
+        for (int k = 0; k < H; ++k) mir[(size_t)w2f_index(H, n, k)] = tmp[(size_t)no.W2 + (size_t)n * H + k];
     HIPCHK(hipStreamSynchronize(c->compute));
     HIPCHK(hipMemcpy(dev, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dev + no.W2f, mir.data(), mir.size() * 4, hipMemcpyHostToDevice));
     return 0;
 }
 static int actor_from_dev(fsrl_ctx* c, const float* dev, float* host) {
@@ -1277,7 +1298,7 @@ static int tr_critic_steps(fsrl_ctx* c, TrState* t, int iters, float l2, float* 
         const double bc1 = 1.0 - std::pow(b1, (double)t->critic_t), bc2 = 1.0 - std::pow(b2, (double)t->critic_t);
         hipLaunchKernelGGL(adam_range_kernel, dim3((end - begin + 255) / 256), dim3(256), 0, c->compute, c->P, c->M,
                            c->V, c->G, begin, end, l2, (float)(1.0 - b1), c->cfg.beta2, (float)(1.0 - b2),
-                           (float)((double)t->cfg.critic_lr / bc1), (float)std::sqrt(bc2), c->cfg.adam_eps, 1, 0);
+                           (float)((double)t->cfg.critic_lr / bc1), (float)std::sqrt(bc2), c->cfg.adam_eps, 1, 0, c->md);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -1494,6 +1515,7 @@ static void sac_layout(fsrl_ctx* c, SacState* s) {
         add(no.W3, Da * H); add(no.b3, Da);                       // mu head
         add(no.W3 + Da * H, Da * H); add(no.b3 + Da, Da);         // sigma head
         s->na_api = api; s->na_dev = round_up(dev, 1024);
+        no.W2f = s->na_dev;                                       // forward-fragment mirror behind the main vector
     }
     // ---- four Q-nets: device order Qr1, Qr2, Qc1, Qc2 ; API order per DoubleCritic: pre1 pre2 last1 last2
     {
@@ -1518,6 +1540,7 @@ static void sac_layout(fsrl_ctx* c, SacState* s) {
             for (int j = 0; j < 2; ++j) { const NetOff& no = md.net[2 * i + j]; add(no.W3, H); add(no.b3, 1); }
         }
         s->nq_api = api; s->nq_dev = round_up(dev, 1024);
+        for (int n = 0; n < 4; ++n) md.net[n].W2f = s->nq_dev + n * H * H;
     }
 }
 
@@ -1534,7 +1557,8 @@ extern "C" int fsrl_sac_init(fsrl_ctx* c, const fsrl_sac_config* cfg) {
     c->sac = s;
     s->cfg = *cfg;
     sac_layout(c, s);
-    const size_t ab = (size_t)s->na_dev * 4, qb = (size_t)s->nq_dev * 4;
+    const size_t HH = (size_t)c->cfg.hidden * c->cfg.hidden;
+    const size_t ab = ((size_t)s->na_dev + HH) * 4, qb = ((size_t)s->nq_dev + 4 * HH) * 4;   // + W2 mirrors (used in P only)
     for (float** p : {&s->PA, &s->MA, &s->VA, &s->GA}) { HIPCHK(hipMalloc(p, ab)); HIPCHK(hipMemsetAsync(*p, 0, ab, c->compute)); }
     for (float** p : {&s->PQ, &s->PQT, &s->MQ, &s->VQ, &s->GQ}) { HIPCHK(hipMalloc(p, qb)); HIPCHK(hipMemsetAsync(*p, 0, qb, c->compute)); }
     HIPCHK(hipStreamSynchronize(c->compute));
@@ -1569,11 +1593,14 @@ extern "C" int64_t fsrl_sac_param_count(const fsrl_ctx* c, int32_t which) {
     return which == 0 ? s->na_api : s->nq_api;
 }
 
-static int sac_copy(fsrl_ctx* c, const std::vector<TensorMap>& tm, int n_dev, float* dev, const float* in, float* out) {
-    std::vector<float> tmp((size_t)n_dev, 0.0f);
+static int sac_copy(fsrl_ctx* c, const std::vector<TensorMap>& tm, const ModelDesc& md, int n_dev, float* dev,
+                    const float* in, float* out) {
+    const size_t n_alloc = (size_t)n_dev + (size_t)md.n_nets * md.H * md.H;
+    std::vector<float> tmp(in ? n_alloc : (size_t)n_dev, 0.0f);
     HIPCHK(hipStreamSynchronize(c->compute));
     if (in) {
         for (const TensorMap& t : tm) memcpy(&tmp[t.dev_off], in + t.api_off, (size_t)t.n * 4);
+        fill_mirrors(md, tmp);
         HIPCHK(hipMemcpy(dev, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
     } else {
         HIPCHK(hipMemcpy(tmp.data(), dev, tmp.size() * 4, hipMemcpyDeviceToHost));
@@ -1589,11 +1616,12 @@ extern "C" int fsrl_sac_params_set(fsrl_ctx* c, const float* actor, int64_t na, 
     if (!s) return fail(FSRL_ESTATE, "fsrl_sac_init first");
     CHECK_ARG(na == s->na_api && nc == s->nq_api, "expected %d actor / %d critic parameters", s->na_api, s->nq_api);
     HIPCHK(hipSetDevice(c->device));
-    int rc = sac_copy(c, s->tmap_a, s->na_dev, s->PA, actor, nullptr);
+    int rc = sac_copy(c, s->tmap_a, s->mda, s->na_dev, s->PA, actor, nullptr);
     if (rc) return rc;
-    rc = sac_copy(c, s->tmap_q, s->nq_dev, s->PQ, critics, nullptr);
+    rc = sac_copy(c, s->tmap_q, s->mdq, s->nq_dev, s->PQ, critics, nullptr);
     if (rc) return rc;
-    HIPCHK(hipMemcpy(s->PQT, s->PQ, (size_t)s->nq_dev * 4, hipMemcpyDeviceToDevice));   // critics_old = deepcopy
+    HIPCHK(hipMemcpy(s->PQT, s->PQ, ((size_t)s->nq_dev + 4 * (size_t)c->cfg.hidden * c->cfg.hidden) * 4,
+                     hipMemcpyDeviceToDevice));   // critics_old = deepcopy (with the W2 mirrors)
     for (float* p : {s->MA, s->VA}) HIPCHK(hipMemsetAsync(p, 0, (size_t)s->na_dev * 4, c->compute));
     for (float* p : {s->MQ, s->VQ}) HIPCHK(hipMemsetAsync(p, 0, (size_t)s->nq_dev * 4, c->compute));
     HIPCHK(hipStreamSynchronize(c->compute));
@@ -1609,8 +1637,8 @@ extern "C" int fsrl_sac_params_get(fsrl_ctx* c, int32_t which, float* out, int64
     if (!s) return fail(FSRL_ESTATE, "fsrl_sac_init first");
     HIPCHK(hipSetDevice(c->device));
     int rc;
-    if (which == 0) { CHECK_ARG(n == s->na_api, "bad size"); rc = sac_copy(c, s->tmap_a, s->na_dev, s->PA, nullptr, out); }
-    else { CHECK_ARG(n == s->nq_api, "bad size"); rc = sac_copy(c, s->tmap_q, s->nq_dev, which == 1 ? s->PQ : s->PQT, nullptr, out); }
+    if (which == 0) { CHECK_ARG(n == s->na_api, "bad size"); rc = sac_copy(c, s->tmap_a, s->mda, s->na_dev, s->PA, nullptr, out); }
+    else { CHECK_ARG(n == s->nq_api, "bad size"); rc = sac_copy(c, s->tmap_q, s->mdq, s->nq_dev, which == 1 ? s->PQ : s->PQT, nullptr, out); }
     if (rc) return rc;
     if (alpha_out) {
         SacScalars sc;
@@ -1704,13 +1732,13 @@ static int sac_wgrad(fsrl_ctx* c, SacState* s, const ModelDesc& md, int ny, cons
 }
 
 // Adam with the gradient read as the z-ordered sum of `nparts` split-K partials
-static void adam_launch(fsrl_ctx* c, float* P, float* M, float* V, const float* G, int n, float lr, int64_t t,
-                        int nparts, int stride) {
+static void adam_launch(fsrl_ctx* c, const ModelDesc& md, float* P, float* M, float* V, const float* G, int n, float lr,
+                        int64_t t, int nparts, int stride) {
     const double b1 = c->cfg.beta1, b2 = c->cfg.beta2;
     const double bc1 = 1.0 - std::pow(b1, (double)t), bc2 = 1.0 - std::pow(b2, (double)t);
     hipLaunchKernelGGL(adam_range_kernel, dim3((n + 255) / 256), dim3(256), 0, c->compute, P, M, V, G, 0, n, 0.0f,
                        (float)(1.0 - b1), c->cfg.beta2, (float)(1.0 - b2), (float)((double)lr / bc1),
-                       (float)std::sqrt(bc2), c->cfg.adam_eps, nparts, stride);
+                       (float)std::sqrt(bc2), c->cfg.adam_eps, nparts, stride, md);
 }
 
 extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, const float* eps_target,
@@ -1814,7 +1842,7 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     rc = sac_wgrad(c, s, s->mdq, 4, s->XQ, s->nq_dev, B, &nsplit);
     if (rc) return rc;
     s->t_critic += 1;
-    adam_launch(c, s->PQ, s->MQ, s->VQ, c->wg_parts, s->nq_dev, s->cfg.critic_lr, s->t_critic, nsplit, s->nq_dev);
+    adam_launch(c, s->mdq, s->PQ, s->MQ, s->VQ, c->wg_parts, s->nq_dev, s->cfg.critic_lr, s->t_critic, nsplit, s->nq_dev);
     // ---- actor step: a ~ pi(s), Q(s, a) with the UPDATED critics, dL/da, actor backward
     rc = actor_launch(s->OBS, s->eps_p, s->XP, s->LP, SAC_A_FWD);
     if (rc) return rc;
@@ -1827,7 +1855,7 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     rc = sac_wgrad(c, s, s->mda, 1, s->OBS, s->na_dev, B, &nsplit);
     if (rc) return rc;
     s->t_actor += 1;
-    adam_launch(c, s->PA, s->MA, s->VA, c->wg_parts, s->na_dev, s->cfg.actor_lr, s->t_actor, nsplit, s->na_dev);
+    adam_launch(c, s->mda, s->PA, s->MA, s->VA, c->wg_parts, s->na_dev, s->cfg.actor_lr, s->t_actor, nsplit, s->na_dev);
     // ---- alpha step + logged stats, then Polyak
     SacFinalArgs fa{};
     float* stats_row = s->d_stats + (size_t)(s->n_updates % SAC_RING) * FSRL_SAC_NSTATS_K;
@@ -1838,7 +1866,7 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     hipLaunchKernelGGL(sac_finalize_kernel, dim3(1), dim3(64), 0, st, fa);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(polyak_kernel, dim3(256), dim3(256), 0, st, s->PQT, s->PQ, s->nq_dev, s->cfg.tau,
-                       (float)(1.0 - (double)s->cfg.tau));
+                       (float)(1.0 - (double)s->cfg.tau), s->mdq);
     HIPCHK(hipGetLastError());
     s->n_updates += 1;
     if (stats_out) {                           // synchronous: this update's row (and mark it drained)

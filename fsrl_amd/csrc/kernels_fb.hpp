@@ -117,7 +117,7 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
     TileStage<H> stg;
     stg.issue(P, no, Do, Da, a.obs + (size_t)row0 * Do, a.rd + (size_t)row0 * FSRL_RD, n_valid, tid);
     FwdW2Frag<H> wf;
-    wf.load(P + no.W2, wave, lane);
+    wf.load(P + no.W2f, wave, lane);
     for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
     stg.commit(sm, no, Do, tid);
     __syncthreads();
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(4 * H) void fb_hvp_tile_kernel(const float* __restr
         sm.rd[e] = (e / FSRL_RD < n_valid) ? a.rd[(size_t)row0 * FSRL_RD + e] : 0.0f;
     for (int e = tid; e < 16 * FSRL_DOW; e += NT) { sm.dout[e] = 0.0f; sm.rdout[e] = 0.0f; }
     FwdW2Frag<H> wf;
-    wf.load(P + no.W2, wave, lane);
+    wf.load(P + no.W2f, wave, lane);
     __syncthreads();
 
     // ---- layer 1 and its tangent; thread = (column j, 4 rows)
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(4 * H) void fb_hvp_tile_kernel(const float* __restr
         f32x4 z = {0, 0, 0, 0}, rz = {0, 0, 0, 0};
         z = mma_rows<H>(sm.h1, wf, li, q, z);
         rz = mma_rows<H>(sm.rh1, wf, li, q, rz);
-        wf.load(V + no.W2, wave, lane);
+        wf.load(V + no.W2f, wave, lane);
         rz = mma_rows<H>(sm.h1, wf, li, q, rz);
         const int j = wave * 16 + li;
         const float bias = P[no.b2 + j], vbias = V[no.b2 + j];
@@ -773,7 +773,8 @@ __global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ P, 
                                                         float* __restrict__ V, const float* __restrict__ G,
                                                         int begin, int end, float l2, float one_minus_b1,
                                                         float beta2, float one_minus_b2, float step_size,
-                                                        float bc2_sqrt, float eps, int nparts, int stride) {
+                                                        float bc2_sqrt, float eps, int nparts, int stride,
+                                                        const ModelDesc md) {
     const int i = begin + blockIdx.x * 256 + threadIdx.x;
     if (i < end) {
         const float p = P[i];
@@ -786,7 +787,10 @@ __global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ P, 
         v = v + (one_minus_b2 * g) * g;
         const float denom = sqrtf(v) / bc2_sqrt + eps;
         M[i] = m; V[i] = v;
-        P[i] = p + (-step_size * m) / denom;
+        const float pn = p + (-step_size * m) / denom;
+        P[i] = pn;
+        const int mi = w2f_mirror_of(md, i);
+        if (mi >= 0) P[mi] = pn;
     }
 }
 

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ P, f
                                                        const float* __restrict__ G,
                                                        const float* __restrict__ gsq_part, int nparts,
                                                        int n, const PpoStepArgs sa,
-                                                       CtrlBlock* ctrl) {
+                                                       CtrlBlock* ctrl, const ModelDesc md) {
     __shared__ double sh[4];
     __shared__ float coef_s;
     const int tid = threadIdx.x;
@@ -239,6 +239,8 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ P, f
         *reinterpret_cast<f32x4*>(M + i4) = m;
         *reinterpret_cast<f32x4*>(V + i4) = v;
         *reinterpret_cast<f32x4*>(P + i4) = p;
+        const int mi = w2f_mirror_of(md, i4);           // 4 consecutive k of one W2 row = one mirror float4
+        if (mi >= 0) *reinterpret_cast<f32x4*>(P + mi) = p;
     }
     // pass-level KL early stop (ppo_lag.py:251-255); only after the last minibatch of a pass
     if (sa.last_in_pass && blockIdx.x == 0 && tid == 0 && sa.target_kl > 0.0f) {

@@ -44,15 +44,15 @@ struct TileGeom {
 };
 
 // W2 slice of one wave for the forward GEMM: lane (li = lane&15, q = lane>>4) holds
-// W2[n0+li][16*kc + 4q .. +3] for every kc.  Issued as one burst (H/16 x 16-byte loads).
+// W2[n0+li][16*kc + 4q .. +3] for every kc.  Issued as one burst (H/16 x 16-byte loads) from the
+// wave-contiguous mirror (common.hpp: w2f_index): 1 KB contiguous per instruction.
 template <int H>
 struct FwdW2Frag {
     f32x4 b[H / 16];
-    __device__ __forceinline__ void load(const float* __restrict__ W2, int wave, int lane) {
-        const int li = lane & 15, q = lane >> 4;
-        const float* row = W2 + (size_t)(wave * 16 + li) * H + 4 * q;
+    __device__ __forceinline__ void load(const float* __restrict__ W2f, int wave, int lane) {
+        const float* base = W2f + ((size_t)wave * (H / 16) * 64 + lane) * 4;
 #pragma unroll
-        for (int kc = 0; kc < H / 16; ++kc) b[kc] = *reinterpret_cast<const f32x4*>(row + 16 * kc);
+        for (int kc = 0; kc < H / 16; ++kc) b[kc] = *reinterpret_cast<const f32x4*>(base + kc * 256);
     }
 };
 
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(4 * H) void mlp_infer_kernel(const float* __restric
     stg.issue(P, no, md.Do, md.Da, (use_next ? a.obs_next : a.obs) + (size_t)row0 * md.Do, nullptr,
               n_valid, tid);
     FwdW2Frag<H> wf;
-    wf.load(P + no.W2, tid >> 6, tid & 63);
+    wf.load(P + no.W2f, tid >> 6, tid & 63);
     stg.commit(sm, no, md.Do, tid);
     __syncthreads();
     tile_forward<H>(sm, P, no, md.Do, tid, wf);
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
         asm volatile("" ::"v"(stg.b1v), "v"(wf.b[0]), "v"(wf.b[H / 64 - 1]));
         return;
     }
-    wf.load(P + no.W2, wave, lane);
+    wf.load(P + no.W2f, wave, lane);
     for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
     if (sa.dbg_phase == 11) {                           // loads issued, nobody waits for them
         asm volatile("" ::"v"(stg.b1v), "v"(wf.b[0]));

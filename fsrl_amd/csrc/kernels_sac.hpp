@@ -138,7 +138,7 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
     TileStage<H> stg;
     stg.issue(P, no, Do, 0, a.obs + (size_t)row0 * Do, nullptr, n_valid, tid);
     FwdW2Frag<H> wf;
-    wf.load(P + no.W2, wave, lane);
+    wf.load(P + no.W2f, wave, lane);
     for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
     stg.commit(sm, no, Do, tid);
     __syncthreads();
@@ -305,7 +305,11 @@ __global__ __launch_bounds__(64) void sac_finalize_kernel(const SacFinalArgs a) 
 
 // target <- tau * source + (1 - tau) * target      (BasePolicy.soft_update, base_policy.py:220-224)
 __global__ void polyak_kernel(float* __restrict__ tgt, const float* __restrict__ src, int n, float tau,
-                              float one_minus_tau) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        tgt[i] = tau * src[i] + one_minus_tau * tgt[i];
+                              float one_minus_tau, const ModelDesc md) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float v = tau * src[i] + one_minus_tau * tgt[i];
+        tgt[i] = v;
+        const int mi = w2f_mirror_of(md, i);
+        if (mi >= 0) tgt[mi] = v;
+    }
 }

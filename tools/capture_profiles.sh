@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round capture, run on the GPU box through gpurun:  bash tools/capture_profiles.sh r01
+# Writes everything under gpurun_out/<tag>_*; tools/collect_profiles.py then copies the summaries to profiles/.
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+timeout 300 python bench.py --steps 20 --warmup 3 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+cd /tmp; export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_profiled.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+cd $R
+timeout 300 python tools/bench_sac.py > $O/${TAG}_bench_sac.json 2>/dev/null
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_sac -- python $R/tools/bench_sac.py --rows 200000 --updates 300 --no-cpu > /dev/null 2>&1
+cd $R
+timeout 600 python tools/bench_trust.py > $O/${TAG}_bench_trust.json 2>/dev/null
+ls $O | head -40

@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Copy the summaries of tools/capture_profiles.sh from gpurun_out/ into profiles/ (tracked) and
+reduce the PMC passes to per-launch HBM traffic of each kernel (MI355X_MICROARCH.md, HBM section:
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read ->
+doubled; WRITE_SIZE is uncalibrated and kept as reported)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(go, pattern), recursive=True)
+    return f[0] if f else None
+
+
+for src, dst in ((f"{tag}_bench.json", f"{tag}_bench.json"), (f"{tag}_bench_profiled.json", f"{tag}_bench_profiled.json"),
+                 (f"{tag}_bench_sac.json", f"{tag}_bench_sac.json"), (f"{tag}_bench_trust.json", f"{tag}_bench_trust.json")):
+    if os.path.exists(os.path.join(go, src)):
+        shutil.copy(os.path.join(go, src), os.path.join(pr, dst))
+for sub, dst in ((f"{tag}_prof_bench", f"{tag}_kernel_stats.csv"), (f"{tag}_prof_sac", f"{tag}_sac_kernel_stats.csv")):
+    f = one(f"{sub}/**/*_kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(pr, dst))
+f = one(f"{tag}_prof_bench/**/*_domain_stats.csv")
+if f:
+    shutil.copy(f, os.path.join(pr, f"{tag}_domain_stats.csv"))
+
+traffic = defaultdict(lambda: {"launches": 0, "fetch_kib": 0.0, "write_kib": 0.0})
+for sub, key in ((f"{tag}_pmc_fetch", "fetch_kib"), (f"{tag}_pmc_write", "write_kib")):
+    f = one(f"{sub}/**/*_counter_collection.csv")
+    if not f:
+        continue
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0]
+        traffic[name][key] += float(r["Counter_Value"])
+        if key == "fetch_kib":
+            traffic[name]["launches"] += 1
+out = {}
+for name, t in traffic.items():
+    n = max(t["launches"], 1)
+    wl = t["launches"] if t["launches"] else 1
+    out[name] = {"launches": t["launches"], "fetch_bytes_per_launch_reported": t["fetch_kib"] * 1024 / n,
+                 "fetch_bytes_per_launch_x2_gfx950": 2 * t["fetch_kib"] * 1024 / n,
+                 "write_bytes_per_launch_reported": t["write_kib"] * 1024 / wl,
+                 "hbm_bytes_per_launch": (2 * t["fetch_kib"] + t["write_kib"]) * 1024 / n}
+if out:
+    json.dump(out, open(os.path.join(pr, f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: round(v["hbm_bytes_per_launch"]) for k, v in out.items()}, indent=1))
