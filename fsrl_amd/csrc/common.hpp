@@ -93,6 +93,12 @@ __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+__device__ __forceinline__ f32x4 mfma_4x4x1(float a, float b, f32x4 c) {
+    // 16 independent blocks blk = l>>2:  D_blk[4x4] += A_blk[4x1] * B_blk[1x4];
+    // lane l: a = A_blk[l&3], b = B_blk[l&3]; c[r] = D_blk[r][l&3]   (checked: tools/ubench/mfma4.hip)
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -125,6 +125,7 @@ struct fsrl_ctx {
     // padded size) so that the never-written inter-tensor padding stays zero
     struct Parts { int stride = 0; float* p = nullptr; size_t floats = 0; } parts[3];
     float* wg_parts = nullptr;      // the buffer the last wgrad_launch wrote
+    int n_cus = 256;                // compute units of the device (tile-shape heuristic)
     uint64_t store_version = 1;     // bumped by every push / reset (device copies of the bookkeeping)
     struct TrState* tr = nullptr;   // trust-region (CPO / TRPO-Lag) working set, owned
     void* sac = nullptr;            // SacState, owned
@@ -286,9 +287,12 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     HIPCHK(hipGetDeviceCount(&ndev));
     CHECK_ARG(device_id >= 0 && device_id < ndev, "device %d not present (%d devices)", device_id, ndev);
     HIPCHK(hipSetDevice(device_id));
+    int n_cus_probe = 256;
+    (void)hipDeviceGetAttribute(&n_cus_probe, hipDeviceAttributeMultiprocessorCount, device_id);
     fsrl_ctx* c = new fsrl_ctx();
     c->cfg = *cfg;
     c->device = device_id;
+    c->n_cus = n_cus_probe > 0 ? n_cus_probe : 256;
     build_layout(c);
 #define TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { fail(FSRL_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); fsrl_ctx_destroy(c); return FSRL_EHIP; } } while (0)
     TRY(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
@@ -643,7 +647,7 @@ static int ensure_ppo_buffers(fsrl_ctx* c, int B) {
     HIPCHK(hipMalloc(&c->A1, act)); HIPCHK(hipMalloc(&c->A2, act));
     HIPCHK(hipMalloc(&c->D1, act)); HIPCHK(hipMalloc(&c->D2, act));
     HIPCHK(hipMalloc(&c->DO, (size_t)nn * mbp * FSRL_DOW * 4));
-    HIPCHK(hipMalloc(&c->statp, (size_t)(mbp / 16) * nn * 4 * 4));
+    HIPCHK(hipMalloc(&c->statp, (size_t)(mbp / 4) * nn * 4 * 4));      // one slot per 4-row tile
     const int pb = (H / 32) * (H / 32) + H / 32;
     HIPCHK(hipMalloc(&c->gsq_part, (size_t)(nn * pb + 1) * 4));
     c->mbp_max = mbp;
@@ -839,9 +843,14 @@ extern "C" int fsrl_ppo_pass(fsrl_ctx* c, const int64_t* perm, uint64_t seed, in
             }
             HIPCHK(hipEventRecord(c->k_ev[c->k_ev_used], s));
         }
+        // 4-row tiles (4x4x1 MFMA) when they still fit the chip in one round: four times the CUs,
+        // a quarter of the MFMA time each; 16-row tiles otherwise
+        const bool rows4 = tiles * 4 * nn <= c->n_cus && !getenv("FSRL_TILE16");
+        const int stat_tiles = rows4 ? tiles * 4 : tiles;
         rc = dispatch_H(H, [&](auto hc) {
             constexpr int HH = decltype(hc)::value;
-            hipLaunchKernelGGL(ppo_fwd_bwd_kernel<HH>, dim3(tiles * nn), dim3(4 * HH), 0, s, c->P, c->md, bp, sa);
+            if (rows4) hipLaunchKernelGGL((ppo_fwd_bwd_kernel<HH, 4>), dim3(tiles * 4 * nn), dim3(4 * HH), 0, s, c->P, c->md, bp, sa);
+            else hipLaunchKernelGGL((ppo_fwd_bwd_kernel<HH, 16>), dim3(tiles * nn), dim3(4 * HH), 0, s, c->P, c->md, bp, sa);
             return 0;
         });
         if (rc) return rc;
@@ -855,7 +864,7 @@ extern "C" int fsrl_ppo_pass(fsrl_ctx* c, const int64_t* perm, uint64_t seed, in
         }
         rc = dispatch_H(H, [&](auto hc) {
             constexpr int HH = decltype(hc)::value;
-            hipLaunchKernelGGL(ppo_wgrad_kernel<HH>, dim3(nparts), dim3(1024), 0, s, c->md, wp, tiles * 16, sa);
+            hipLaunchKernelGGL(ppo_wgrad_kernel<HH>, dim3(nparts), dim3(1024), 0, s, c->md, wp, tiles * 16, sa, stat_tiles);
             return 0;
         });
         if (rc) return rc;

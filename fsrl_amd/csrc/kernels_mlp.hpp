@@ -120,7 +120,11 @@ struct TileStage {
 // ---------------------------------------------------------------- forward of one 16-row tile
 // Pre: sm.xT filled + __syncthreads() done; wf holds this wave's W2 slice (may still be in
 // flight).  Post: sm.h1, sm.h2, sm.out valid (synced).
-template <int H>
+// R = rows of the tile: 16 (v_mfma_f32_16x16x4_f32) or 4 (v_mfma_f32_4x4x1_16B_f32: the same FLOP
+// rate with a quarter of the rows, for launches whose 16-row tiles would leave most CUs idle).  The
+// 4-row variant uses the SAME W2 fragment: the 16 blocks of the instruction are (q = k-class, 4
+// column quads), each q-class accumulates its quarter of K and the classes are added at the end.
+template <int H, int R = 16>
 __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __restrict__ P,
                                              const NetOff no, const int Do, const int tid,
                                              const FwdW2Frag<H>& wf) {
@@ -129,7 +133,7 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
 
     // ---- layer 1 (K = Do is tiny: plain FMA); thread = (column j, group of 4 rows)
-    {
+    if (R == 16 || tid < H) {
         const int j = tid % H, rg = tid / H;
         const float b = sm.b1[j];
         float acc[4] = {b, b, b, b};
@@ -145,8 +149,28 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
     }
     __syncthreads();
 
-    // ---- layer 2: h2[16,H] = relu(h1[16,H] @ W2^T + b2) on MFMA 16x16x4 (fp32)
-    {
+    // ---- layer 2: h2[R,H] = relu(h1[R,H] @ W2^T + b2) on MFMA (fp32)
+    if constexpr (R == 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = &sm.h1[(lane & 3) * LD + 4 * q];
+#pragma unroll
+        for (int kc = 0; kc < H / 16; ++kc) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * kc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma_4x4x1(a[s], wf.b[kc][s], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {            // add the four k-classes: (q0 + q1) + (q2 + q3)
+            acc[r] += __shfl_xor(acc[r], 16, 64);
+            acc[r] += __shfl_xor(acc[r], 32, 64);
+        }
+        if (q == 0) {
+            const int j = wave * 16 + li;
+            const float bias = sm.b2[j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm.h2[r * LD + j] = fmaxf(acc[r] + bias, 0.0f);
+        }
+    } else {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* arow = &sm.h1[li * LD + 4 * q];
 #pragma unroll
@@ -163,7 +187,7 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
     __syncthreads();
 
     // ---- head (out <= 16): one wave per row, 64-lane shuffle reduce
-    for (int i = wave; i < 16; i += WAVES) {
+    for (int i = wave; i < R; i += WAVES) {
         for (int o = 0; o < no.out; ++o) {
             const float* w3 = &sm.w3[o * H];
             float s = 0.0f;
@@ -271,7 +295,7 @@ struct PpoBatchPtrs {
     int mbp_max;
 };
 
-template <int H>
+template <int H, int R>
 __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restrict__ P,
                                                            const ModelDesc md,
                                                            const PpoBatchPtrs bp,
@@ -283,12 +307,14 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
     // block id = tile + n_tiles*net: consecutive tiles of one network land on different XCDs
     // (grouping a network's tiles on few XCDs was measured 25% slower: same-line contention)
-    const int n_tiles = (sa.mb_size + 15) >> 4;
+    // tiles cover round_up(mb_size, 16) rows: the weight-gradient kernel reads whole 16-row groups,
+    // rows past mb_size are written as zeros
+    const int n_tiles = ((sa.mb_size + 15) >> 4) * (16 / R);
     const int tile = blockIdx.x % n_tiles, net = blockIdx.x / n_tiles;
-    const int row0 = tile * 16;
+    const int row0 = tile * R;
     const NetOff no = md.net[net];
     const int Do = md.Do, Da = md.Da, C = md.n_nets - 1;
-    const int n_valid = min(16, sa.mb_size - row0);
+    const int n_valid = max(0, min(R, sa.mb_size - row0));
     const size_t grow0 = (size_t)sa.mb_start + row0;   // first row of the tile in pass order
 
     // ---- prologue: ONE burst of independent loads (W2 slice, obs tile, row data, small
@@ -319,7 +345,7 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
     if (sa.dbg_phase == 9) return;                      // launch + address setup only
     __syncthreads();
     if (sa.dbg_phase == 1) { if (wf.b[0][0] == 123.f && sm.xT[tid] == 1.f) bp.statp[0] = 1.f; return; }
-    tile_forward<H>(sm, P, no, Do, tid, wf);
+    tile_forward<H, R>(sm, P, no, Do, tid, wf);
     if (sa.dbg_phase == 4) { if (sm.out[tid & 15] == 123.f) bp.statp[0] = 1.f; return; }
     const size_t nb = (size_t)net * bp.mbp_max;
     {   // spill relu(z1), relu(z2) for the weight-gradient kernel now: the stores retire while
@@ -327,7 +353,7 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
         float* __restrict__ A1 = bp.A1 + (nb + row0) * H;
         float* __restrict__ A2 = bp.A2 + (nb + row0) * H;
         constexpr int H4 = H / 4;
-        for (int e = tid; e < 16 * H4; e += NT) {
+        for (int e = tid; e < R * H4; e += NT) {
             const int i = e / H4, c4 = e - i * H4;
             *reinterpret_cast<f32x4*>(&A1[(size_t)i * H + 4 * c4]) =
                 *reinterpret_cast<const f32x4*>(&sm.h1[i * LD + 4 * c4]);
@@ -350,7 +376,7 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
 
     if (sa.dbg_phase == 5) { if (wb[0][0] == 123.f) bp.statp[0] = 1.f; return; }
     // ---- loss head: thread (row i = tid>>4, dim d = tid&15), 16-lane shuffles per row
-    if (tid < 256) {
+    if (tid < 16 * R) {
         const int i = tid >> 4, d = tid & 15;
         const bool valid = i < n_valid;
         const float* rd = &sm.rd[i * FSRL_RD];
@@ -420,13 +446,13 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
     if (tid < 4) {   // rows summed in ascending order (fixed => deterministic)
         float t = 0.0f;
         if (tid < 3)
-            for (int i = 0; i < 16; ++i) t += sm.st[i * 4 + tid];
+            for (int i = 0; i < R; ++i) t += sm.st[i * 4 + tid];
         bp.statp[((size_t)tile * md.n_nets + net) * 4 + tid] = t;
     }
 
     if (sa.dbg_phase == 6) { if (wb[0][0] == 123.f) bp.statp[1] = 1.f; return; }
     // ---- dL/dz2 = (dout @ W3) * relu'(z2); thread = (column k, group of 4 rows)
-    {
+    if (R == 16 || tid < H) {
         const int k = tid % H, rg = tid / H;
         float g[4] = {0.f, 0.f, 0.f, 0.f};
         for (int o = 0; o < no.out; ++o) {
@@ -445,16 +471,37 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
     {   // dz2 and dout tiles -> side buffers (retire under the backward GEMM)
         float* __restrict__ D2 = bp.D2 + (nb + row0) * H;
         constexpr int H4 = H / 4;
-        for (int e = tid; e < 16 * H4; e += NT) {
+        for (int e = tid; e < R * H4; e += NT) {
             const int i = e / H4, c4 = e - i * H4;
             *reinterpret_cast<f32x4*>(&D2[(size_t)i * H + 4 * c4]) =
                 *reinterpret_cast<const f32x4*>(&sm.d2[i * LD + 4 * c4]);
         }
         float* __restrict__ DOb = bp.DO + (nb + row0) * FSRL_DOW;
-        for (int e = tid; e < 16 * FSRL_DOW; e += NT) DOb[e] = sm.dout[e];
+        for (int e = tid; e < R * FSRL_DOW; e += NT) DOb[e] = sm.dout[e];
     }
     // ---- dL/dz1 = (dz2 @ W2) * relu'(z1) on MFMA; result goes straight to L2/HBM
-    {
+    if constexpr (R == 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = &sm.d2[(lane & 3) * LD + 4 * q];
+#pragma unroll
+        for (int jc = 0; jc < H / 16; ++jc) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * jc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma_4x4x1(a[s], wb[jc][s], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[r] += __shfl_xor(acc[r], 16, 64);
+            acc[r] += __shfl_xor(acc[r], 32, 64);
+        }
+        if (sa.dbg_phase == 7) { if (acc[0] == 123.f) bp.statp[1] = 1.f; return; }
+        if (q == 0) {
+            float* __restrict__ D1 = bp.D1 + (nb + row0) * H;
+            const int col = wave * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) D1[(size_t)r * H + col] = (sm.h1[r * LD + col] > 0.0f) ? acc[r] : 0.0f;
+        }
+    } else {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* arow = &sm.d2[li * LD + 4 * q];
 #pragma unroll
@@ -508,14 +555,16 @@ __device__ __forceinline__ void ppo_stats_finalize(const ModelDesc& md, const Wg
     float mine = 0.0f;
     {
         const int g = lane >> 4, fs = lane & 15;
-        float v[8];
+        for (int t0 = 0; t0 < n_tiles; t0 += 32) {
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int t = g + 4 * u;
-            v[u] = (fs < nn * 4 && t < n_tiles) ? wp.statp[(size_t)t * nn * 4 + fs] : 0.0f;
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + g + 4 * u;
+                v[u] = (fs < nn * 4 && t < n_tiles) ? wp.statp[(size_t)t * nn * 4 + fs] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mine += v[u];
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) mine += v[u];
         mine += __shfl_xor(mine, 16, 64);
         mine += __shfl_xor(mine, 32, 64);
     }
@@ -554,7 +603,8 @@ __device__ __forceinline__ void ppo_stats_finalize(const ModelDesc& md, const Wg
 
 template <int H>
 __global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, const WgradPtrs wp,
-                                                        const int mbp, const PpoStepArgs sa) {
+                                                        const int mbp, const PpoStepArgs sa,
+                                                        const int n_stat_tiles) {
     constexpr int TPD = H / 32;          // tiles per dimension
     constexpr int NT2 = TPD * TPD;
     constexpr int NA = H / 32;
@@ -565,7 +615,7 @@ __global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, con
     if (sa.dbg_phase == 20) return;
     if ((int)blockIdx.x == md.n_nets * PB) {  // the stats block
         if (sa.dbg_phase == 21 || sa.dbg_phase == 22) return;
-        if (wave == 0) ppo_stats_finalize(md, wp, sa, mbp >> 4, lane);
+        if (wave == 0) ppo_stats_finalize(md, wp, sa, n_stat_tiles, lane);
         // db3[o] / dsigma[d] = column sums of DO over the minibatch rows, for every network:
         // thread (col = tid & 31, row phase = tid >> 5); all loads of a thread in one burst
         float sqs = 0.0f;
