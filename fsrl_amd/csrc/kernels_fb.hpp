@@ -228,11 +228,26 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
         //   da[i][k] = sum_j dz1[i][j] * W1[j][Do_obs + k]       (dz1 left in sm.d2 by tile_backward)
         __syncthreads();
         const int Dact = a.act_cols, Dobs = Do - Dact;
-        for (int e = tid; e < 16 * Dact; e += NT) {
-            const int i = e / Dact, kk = e - i * Dact;
+        // stage the action columns of W1 ([H][Dact]) into LDS with one coalesced burst (sm.h2 is
+        // free now), then thread (row i, column kk, j-phase jp) sums 1/8 of the j range
+        float* __restrict__ wact = sm.h2;
+        for (int e = tid; e < H * Dact; e += NT) {
+            const int j = e / Dact, kk = e - j * Dact;
+            wact[e] = P[no.W1 + (size_t)j * Do + Dobs + kk];
+        }
+        __syncthreads();
+        for (int e0 = 0; e0 < 16 * Dact * 8; e0 += NT) {
+            const int e = e0 + tid;
+            const int jp = e & 7, ik = e >> 3;
+            const int i = ik / Dact, kk = ik - i * Dact;
             float s_ = 0.0f;
-            for (int j = 0; j < H; ++j) s_ = fmaf(sm.d2[i * LD + j], P[no.W1 + (size_t)j * Do + Dobs + kk], s_);
-            if (i < n_valid) a.da_out[((size_t)blockIdx.y * a.N + row0 + i) * Dact + kk] = s_;
+            if (ik < 16 * Dact)
+                for (int j = jp; j < H; j += 8) s_ = fmaf(sm.d2[i * LD + j], wact[j * Dact + kk], s_);
+            s_ += __shfl_xor(s_, 1, 64);
+            s_ += __shfl_xor(s_, 2, 64);
+            s_ += __shfl_xor(s_, 4, 64);
+            if (jp == 0 && ik < 16 * Dact && i < n_valid)
+                a.da_out[((size_t)blockIdx.y * a.N + row0 + i) * Dact + kk] = s_;
         }
     }
 }
@@ -326,24 +341,37 @@ __global__ __launch_bounds__(4 * H) void fb_hvp_tile_kernel(const float* __restr
     wf.load(P + no.W2f, wave, lane);
     __syncthreads();
 
-    // ---- layer 1 and its tangent; thread = (column j, 4 rows)
+    // ---- layer 1 and its tangent on MFMA: the wave's 16 rows of W1 and of V1 in one load burst
     {
-        const int j = tid % H, rg = tid / H;
-        const float b = P[no.b1 + j], vb = V[no.b1 + j];
-        float acc[4] = {b, b, b, b}, racc[4] = {vb, vb, vb, vb};
-        const float* __restrict__ w = P + no.W1 + (size_t)j * Do;
-        const float* __restrict__ vw = V + no.W1 + (size_t)j * Do;
-        for (int k = 0; k < Do; ++k) {
-            const float wk = w[k], vk = vw[k];
-            const f32x4 x = *reinterpret_cast<const f32x4*>(&sm.xT[k * 16 + 4 * rg]);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, racc = {0.f, 0.f, 0.f, 0.f};
+        const float* __restrict__ wrow = P + no.W1 + (size_t)(wave * 16 + li) * Do;
+        const float* __restrict__ vrow = V + no.W1 + (size_t)(wave * 16 + li) * Do;
+        for (int k0 = 0; k0 < Do; k0 += 64) {
+            float b[16], vb_[16];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { acc[e] = fmaf(x[e], wk, acc[e]); racc[e] = fmaf(x[e], vk, racc[e]); }
+            for (int s = 0; s < 16; ++s) {
+                const int k = k0 + 4 * s + q;
+                b[s] = (k < Do) ? wrow[k] : 0.0f;
+                vb_[s] = (k < Do) ? vrow[k] : 0.0f;
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int k = k0 + 4 * s + q;
+                if (k0 + 4 * s < Do) {
+                    const float a_ = (k < Do) ? sm.xT[k * 16 + li] : 0.0f;
+                    acc = mfma_16x16x4(a_, b[s], acc);
+                    racc = mfma_16x16x4(a_, vb_[s], racc);
+                }
+            }
         }
+        const int j = wave * 16 + li;
+        const float b1 = P[no.b1 + j], vb1 = V[no.b1 + j];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool on = acc[e] > 0.0f;
-            sm.h1[(4 * rg + e) * LD + j] = on ? acc[e] : 0.0f;
-            sm.rh1[(4 * rg + e) * LD + j] = on ? racc[e] : 0.0f;
+        for (int r = 0; r < 4; ++r) {
+            const float z = acc[r] + b1;
+            const bool on = z > 0.0f;
+            sm.h1[(4 * q + r) * LD + j] = on ? z : 0.0f;
+            sm.rh1[(4 * q + r) * LD + j] = on ? racc[r] + vb1 : 0.0f;
         }
     }
     __syncthreads();

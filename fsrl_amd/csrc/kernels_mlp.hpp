@@ -132,20 +132,62 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
     constexpr int WAVES = TileGeom<H>::WAVES;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
 
-    // ---- layer 1 (K = Do is tiny: plain FMA); thread = (column j, group of 4 rows)
-    if (R == 16 || tid < H) {
-        const int j = tid % H, rg = tid / H;
-        const float b = sm.b1[j];
-        float acc[4] = {b, b, b, b};
-        const float* __restrict__ w = (Do <= FSRL_W1_LDS) ? &sm.w1[j * Do] : P + no.W1 + (size_t)j * Do;
-        for (int k = 0; k < Do; ++k) {
-            const float wk = w[k];
-            const f32x4 x = *reinterpret_cast<const f32x4*>(&sm.xT[k * 16 + 4 * rg]);
+    // ---- layer 1.  Do <= FSRL_W1_LDS: W1 sits in LDS, plain FMA, thread = (column j, group of 4
+    //      rows).  Wider inputs (SAC: obs+act = 41, SafetyPointGoal: 60): MFMA with the wave's 16 rows of
+    //      W1 fetched in ONE burst of <= 16 independent loads per 64 inputs -- a k-loop of dependent
+    //      global loads cost one L2 round trip per input (measured: 20 us of a 27 us kernel).
+    if (Do <= FSRL_W1_LDS) {
+        if (R == 16 || tid < H) {
+            const int j = tid % H, rg = tid / H;
+            const float b = sm.b1[j];
+            float acc[4] = {b, b, b, b};
+            const float* __restrict__ w = &sm.w1[j * Do];
+            for (int k = 0; k < Do; ++k) {
+                const float wk = w[k];
+                const f32x4 x = *reinterpret_cast<const f32x4*>(&sm.xT[k * 16 + 4 * rg]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = fmaf(x[e], wk, acc[e]);
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(x[e], wk, acc[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sm.h1[(4 * rg + e) * LD + j] = fmaxf(acc[e], 0.0f);
         }
+    } else {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* __restrict__ wrow = P + no.W1 + (size_t)(wave * 16 + li) * Do;
+        const int arow = (R == 4) ? (lane & 3) : li;
+        for (int k0 = 0; k0 < Do; k0 += 64) {
+            float b[16];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sm.h1[(4 * rg + e) * LD + j] = fmaxf(acc[e], 0.0f);
+            for (int s = 0; s < 16; ++s) {
+                const int k = k0 + 4 * s + q;
+                b[s] = (k < Do) ? wrow[k] : 0.0f;
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int k = k0 + 4 * s + q;
+                if (k0 + 4 * s < Do) {
+                    const float a = (k < Do) ? sm.xT[k * 16 + arow] : 0.0f;
+                    if constexpr (R == 4) acc = mfma_4x4x1(a, b[s], acc);
+                    else acc = mfma_16x16x4(a, b[s], acc);
+                }
+            }
+        }
+        const int j = wave * 16 + li;
+        const float bias = sm.b1[j];
+        if constexpr (R == 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[r] += __shfl_xor(acc[r], 16, 64);
+                acc[r] += __shfl_xor(acc[r], 32, 64);
+            }
+            if (q == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sm.h1[r * LD + j] = fmaxf(acc[r] + bias, 0.0f);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm.h1[(4 * q + r) * LD + j] = fmaxf(acc[r] + bias, 0.0f);
+        }
     }
     __syncthreads();
 
