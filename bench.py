@@ -139,6 +139,21 @@ def end_to_end(local_rank, seed, seconds=6.0):
     return out
 
 
+def pmc_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE, separate runs; tools/capture_profiles.sh + tools/collect_profiles.py apply
+    the guide's KiB unit and gfx950 x2 FETCH correction).  Counters cannot be read inside this process,
+    so the figure is the one measured when the profile was captured; None when there is none."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
+        f = os.path.join(here, "profiles", f"{tag}_pmc_traffic.json")
+        if os.path.exists(f):
+            for name, v in json.load(open(f)).items():
+                if name.startswith("void ppo_fwd_bwd_kernel<256"):
+                    return float(v["hbm_bytes_per_launch"]), f"profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc, separate pass)"
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,7 +256,10 @@ def main():
                          "launches_timed": int(k_n),
                          "flops_per_launch": flops_fwdbwd_launch(rows_avg)},
         }
-        if not args.no_cpu_baseline:
+        pmc = pmc_traffic()
+        if pmc is not None:
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc
+        if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
             out["end_to_end"] = end_to_end(local_rank, seed)
             out["cpu_baseline"] = cpu_baseline(theta, inputs)
             out["speedup_vs_cpu_port"] = out["value"] / world / out["cpu_baseline"]["value"]
