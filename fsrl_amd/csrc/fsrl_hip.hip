@@ -798,7 +798,7 @@ extern "C" int fsrl_ppo_pass(fsrl_ctx* c, const int64_t* perm, uint64_t seed, in
         pa.perm = c->d_perm; pa.mb_start = c->d_mbstart; pa.mb_size = c->d_mbsize; pa.obs_p = c->obs_p;
         pa.rd_p = c->rd_p; pa.N = n; pa.C = C; pa.Do = c->cfg.obs_dim; pa.Da = c->cfg.act_dim;
         pa.norm_adv = c->cfg.norm_adv;
-        hipLaunchKernelGGL(ppo_prepare_pass_kernel, dim3(nmb), dim3(256), 0, s, pa);
+        hipLaunchKernelGGL(ppo_prepare_pass_kernel, dim3(nmb), dim3(1024), 0, s, pa);
         HIPCHK(hipGetLastError());
     }
     PpoBatchPtrs bp{};

@@ -134,59 +134,64 @@ struct PrepArgs {
     int N, C, Do, Da, norm_adv;
 };
 
-__global__ __launch_bounds__(256) void ppo_prepare_pass_kernel(const PrepArgs a) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void ppo_prepare_pass_kernel(const PrepArgs a) {
+    constexpr int NT = 1024, NW = NT / 64;
+    __shared__ double sh[NW];
     __shared__ double mean_s;
     __shared__ float mean_f[FSRL_MAX_CRITICS], sd_f[FSRL_MAX_CRITICS];
+    __shared__ int perm_s[1024];            // this minibatch's row indices (n <= 2*batch-1; chunks of 1024)
     const int mb = blockIdx.x, tid = threadIdx.x;
     const int st = a.mb_start[mb], n = a.mb_size[mb];
+    auto block_sum = [&](double v) -> double {      // fixed order: waves 0..15
+        v = wave_sum_d(v);
+        __syncthreads();
+        if ((tid & 63) == 0) sh[tid >> 6] = v;
+        __syncthreads();
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += sh[w];
+        return t;
+    };
     if (a.norm_adv) {
         for (int c = 0; c < a.C; ++c) {
             const float* __restrict__ adv = a.advs + (size_t)c * a.N;
             double s = 0.0;
-            for (int m = tid; m < n; m += 256) s += (double)adv[a.perm[st + m]];
-            s = wave_sum_d(s);
-            __syncthreads();
-            if ((tid & 63) == 0) sh[tid >> 6] = s;
-            __syncthreads();
-            if (tid == 0) mean_s = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (double)n;
-            __syncthreads();
-            const double mean = mean_s;
+            for (int m = tid; m < n; m += NT) s += (double)adv[a.perm[st + m]];
+            const double mean = block_sum(s) / (double)n;
             double q = 0.0;
-            for (int m = tid; m < n; m += 256) {
+            for (int m = tid; m < n; m += NT) {
                 const double d = (double)adv[a.perm[st + m]] - mean;
                 q += d * d;
             }
-            q = wave_sum_d(q);
-            __syncthreads();
-            if ((tid & 63) == 0) sh[tid >> 6] = q;
-            __syncthreads();
-            if (tid == 0) {
-                const double var = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (double)(n - 1);
-                mean_f[c] = (float)mean;
-                sd_f[c] = (float)sqrt(var);
-            }
+            const double var = block_sum(q) / (double)(n - 1);
+            if (tid == 0) { mean_f[c] = (float)mean; sd_f[c] = (float)sqrt(var); }
         }
         __syncthreads();
     }
-    for (int e = tid; e < n * FSRL_RD; e += 256) {
-        const int m = e / FSRL_RD, f = e - m * FSRL_RD;
-        const int r = a.perm[st + m];
-        float v = 0.0f;
-        if (f < a.Da) v = a.act[(size_t)r * a.Da + f];
-        else if (f == FSRL_RD_LOGP) v = a.logp_old[r];
-        else if (f >= FSRL_RD_ADV && f < FSRL_RD_ADV + a.C) {
-            const int c = f - FSRL_RD_ADV;
-            v = a.advs[(size_t)c * a.N + r];
-            if (a.norm_adv) v = (v - mean_f[c]) / sd_f[c];
-        } else if (f >= FSRL_RD_RET && f < FSRL_RD_RET + a.C) {
-            v = a.rets[(size_t)(f - FSRL_RD_RET) * a.N + r];
+    for (int m0 = 0; m0 < n; m0 += 1024) {       // rows in chunks whose indices sit in LDS
+        const int nc = min(1024, n - m0);
+        __syncthreads();
+        if (tid < nc) perm_s[tid] = a.perm[st + m0 + tid];
+        __syncthreads();
+        for (int e = tid; e < nc * FSRL_RD; e += NT) {
+            const int m = e / FSRL_RD, f = e - m * FSRL_RD;
+            const int r = perm_s[m];
+            float v = 0.0f;
+            if (f < a.Da) v = a.act[(size_t)r * a.Da + f];
+            else if (f == FSRL_RD_LOGP) v = a.logp_old[r];
+            else if (f >= FSRL_RD_ADV && f < FSRL_RD_ADV + a.C) {
+                const int c = f - FSRL_RD_ADV;
+                v = a.advs[(size_t)c * a.N + r];
+                if (a.norm_adv) v = (v - mean_f[c]) / sd_f[c];
+            } else if (f >= FSRL_RD_RET && f < FSRL_RD_RET + a.C) {
+                v = a.rets[(size_t)(f - FSRL_RD_RET) * a.N + r];
+            }
+            a.rd_p[(size_t)(st + m0 + m) * FSRL_RD + f] = v;
         }
-        a.rd_p[(size_t)(st + m) * FSRL_RD + f] = v;
-    }
-    for (int e = tid; e < n * a.Do; e += 256) {
-        const int m = e / a.Do, k = e - m * a.Do;
-        a.obs_p[(size_t)(st + m) * a.Do + k] = a.obs[(size_t)a.perm[st + m] * a.Do + k];
+        for (int e = tid; e < nc * a.Do; e += NT) {
+            const int m = e / a.Do, k = e - m * a.Do;
+            a.obs_p[(size_t)(st + m0 + m) * a.Do + k] = a.obs[(size_t)perm_s[m] * a.Do + k];
+        }
     }
 }
 
