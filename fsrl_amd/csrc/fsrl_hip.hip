@@ -47,6 +47,7 @@ struct TensorMap { int api_off, dev_off, n; };   // one parameter tensor: flat A
 
 struct EnvBook {           // tianshou ReplayBuffer bookkeeping of one sub-buffer (host side)
     int64_t index = 0, size = 0, last_index = 0;
+    int64_t staged = 0;    // rows of this sub-buffer in the current staging window
     double ep_rew = 0.0;
     int32_t ep_len = 0;
     int64_t ep_idx = 0;
@@ -416,6 +417,7 @@ static int flush_stage(fsrl_ctx* c) {
     HIPCHK(hipEventRecord(s.done, c->side));
     s.in_flight = true;
     s.count = 0;
+    for (EnvBook& e : c->env) e.staged = 0;
     c->cur_stage ^= 1;
     Staging& nx = c->stage[c->cur_stage];
     if (nx.in_flight) {  // the other buffer's copies must have left pinned memory before reuse
@@ -438,12 +440,16 @@ extern "C" int fsrl_store_push(fsrl_ctx* c, const int32_t* env_ids, int32_t k, c
     for (int j = 0; j < k; ++j) {
         const int e = env_ids[j];
         CHECK_ARG(e >= 0 && e < c->cfg.env_num, "buffer id %d out of range", e);
-        if (c->stage[c->cur_stage].count == fsrl_ctx::STAGE_CAP) {
+        // flush when the window is full -- or when this sub-buffer would wrap onto a slot that is
+        // already in the window: the scatter kernel writes a window's rows in parallel, so one slot
+        // must not appear twice in it (windows themselves are ordered on the side stream)
+        if (c->stage[c->cur_stage].count == fsrl_ctx::STAGE_CAP || c->env[e].staged == c->sub_size) {
             int rc = flush_stage(c);
             if (rc) return rc;
         }
         Staging& s = c->stage[c->cur_stage];
         EnvBook& eb = c->env[e];
+        eb.staged += 1;
         const int64_t ptr = eb.index;
         const int64_t gptr = ptr + (int64_t)e * c->sub_size;
         const int i = s.count++;
@@ -776,8 +782,11 @@ extern "C" int fsrl_ppo_pass(fsrl_ctx* c, const int64_t* perm, uint64_t seed, in
     // ---- permutation of this pass (np.random.permutation on the caller side, or our own)
     HIPCHK(hipStreamSynchronize(s));   // h_perm (pinned) may still be in flight from the last pass
     if (perm) {
+        std::vector<uint8_t> seen((size_t)n, 0);
         for (int i = 0; i < n; ++i) {
             CHECK_ARG(perm[i] >= 0 && perm[i] < n, "perm[%d]=%lld out of range", i, (long long)perm[i]);
+            CHECK_ARG(!seen[(size_t)perm[i]], "perm is not a permutation: %lld appears twice", (long long)perm[i]);
+            seen[(size_t)perm[i]] = 1;
             c->h_perm[i] = (int)perm[i];
         }
     } else {
@@ -864,7 +873,8 @@ extern "C" int fsrl_ppo_pass(fsrl_ctx* c, const int64_t* perm, uint64_t seed, in
         }
         rc = dispatch_H(H, [&](auto hc) {
             constexpr int HH = decltype(hc)::value;
-            hipLaunchKernelGGL(ppo_wgrad_kernel<HH>, dim3(nparts), dim3(1024), 0, s, c->md, wp, tiles * 16, sa, stat_tiles);
+            if (tiles * 16 <= 512) hipLaunchKernelGGL((ppo_wgrad_kernel<HH, false>), dim3(nparts), dim3(1024), 0, s, c->md, wp, tiles * 16, sa, stat_tiles);
+            else hipLaunchKernelGGL((ppo_wgrad_kernel<HH, true>), dim3(nparts), dim3(1024), 0, s, c->md, wp, tiles * 16, sa, stat_tiles);
             return 0;
         });
         if (rc) return rc;

@@ -584,7 +584,7 @@ struct WgradPtrs {
     int mbp_max;
 };
 
-#define WG_MAXU 8      // k-steps per wave in the tile role: mbp/4/16 <= 8  (mbp <= 512)
+#define WG_MAXU 8      // k-steps per wave and load burst in the tile role (512 rows per burst)
 #define AUX_MAXU 32    // rows per thread in the aux role:   mbp/16   <= 32
 
 // Logged statistics of one minibatch step (parameters are still pre-update here, like the
@@ -643,10 +643,13 @@ __device__ __forceinline__ void ppo_stats_finalize(const ModelDesc& md, const Wg
     }
 }
 
-template <int H>
+// BIG = false: mbp <= 512, every role is one straight-line load burst (the common case: batch <= 256).
+// BIG = true: the same code inside a loop over 512-row chunks (merged last minibatch of batch 512: 1023).
+template <int H, bool BIG>
 __global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, const WgradPtrs wp,
                                                         const int mbp, const PpoStepArgs sa,
                                                         const int n_stat_tiles) {
+    const int CH = BIG ? (mbp + 511) / 512 : 1;      // row chunks
     constexpr int TPD = H / 32;          // tiles per dimension
     constexpr int NT2 = TPD * TPD;
     constexpr int NA = H / 32;
@@ -665,15 +668,17 @@ __global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, con
             const NetOff no = md.net[net];
             const float* __restrict__ DOn = wp.DO + (size_t)net * wp.mbp_max * FSRL_DOW;
             const int col = tid & 31, php = tid >> 5;
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int r = php + 32 * u;
-                v[u] = (r < mbp) ? DOn[(size_t)r * FSRL_DOW + col] : 0.0f;
-            }
             float t = 0.0f;
+            for (int ch = 0; ch < CH; ++ch) {
+                float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) t += v[u];
+                for (int u = 0; u < 16; ++u) {
+                    const int r = 512 * ch + php + 32 * u;
+                    v[u] = (r < mbp) ? DOn[(size_t)r * FSRL_DOW + col] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t += v[u];
+            }
             __syncthreads();
             red[php * 33 + col] = t;
             __syncthreads();
@@ -713,27 +718,30 @@ __global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, con
         const float* __restrict__ pa = D2 + tj * 32 + 2 * c;
         const float* __restrict__ pb = A1 + tk * 32 + 2 * c;
         const int KS = mbp >> 2;
-        f32x2 a[WG_MAXU], b[WG_MAXU];
-#pragma unroll
-        for (int u = 0; u < WG_MAXU; ++u) {
-            const int s = wave + 16 * u;
-            if (s < KS) {
-                const size_t r = (size_t)(4 * s + q) * H;
-                a[u] = *reinterpret_cast<const f32x2*>(pa + r);
-                b[u] = *reinterpret_cast<const f32x2*>(pb + r);
-            } else {
-                a[u] = f32x2{0.f, 0.f};
-                b[u] = f32x2{0.f, 0.f};
-            }
-        }
         f32x4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+        for (int ch = 0; ch < CH; ++ch) {
+            const int s0 = 16 * WG_MAXU * ch;
+            f32x2 a[WG_MAXU], b[WG_MAXU];
 #pragma unroll
-        for (int u = 0; u < WG_MAXU; ++u) {
-            if (wave + 16 * u < KS) {   // wave-uniform
-                acc00 = mfma_16x16x4(a[u][0], b[u][0], acc00);
-                acc01 = mfma_16x16x4(a[u][0], b[u][1], acc01);
-                acc10 = mfma_16x16x4(a[u][1], b[u][0], acc10);
-                acc11 = mfma_16x16x4(a[u][1], b[u][1], acc11);
+            for (int u = 0; u < WG_MAXU; ++u) {
+                const int s = s0 + wave + 16 * u;
+                if (s < KS) {
+                    const size_t r = (size_t)(4 * s + q) * H;
+                    a[u] = *reinterpret_cast<const f32x2*>(pa + r);
+                    b[u] = *reinterpret_cast<const f32x2*>(pb + r);
+                } else {
+                    a[u] = f32x2{0.f, 0.f};
+                    b[u] = f32x2{0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < WG_MAXU; ++u) {
+                if (s0 + wave + 16 * u < KS) {   // wave-uniform
+                    acc00 = mfma_16x16x4(a[u][0], b[u][0], acc00);
+                    acc01 = mfma_16x16x4(a[u][0], b[u][1], acc01);
+                    acc10 = mfma_16x16x4(a[u][1], b[u][0], acc10);
+                    acc11 = mfma_16x16x4(a[u][1], b[u][1], acc11);
+                }
             }
         }
         // acc_tu[r]: j_local = 2*(4q+r)+t, k_local = 2c+u.  Two rounds: waves 0-7 store their
@@ -784,13 +792,14 @@ __global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, con
             const bool first = (k0 == 0);
             f32x4 ax0 = {0, 0, 0, 0}, ax1 = {0, 0, 0, 0}, ad0 = {0, 0, 0, 0}, ad1 = {0, 0, 0, 0};
             f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+            for (int ch = 0; ch < CH; ++ch)
             for (int ub = 0; ub < WG_MAXU; ub += 4) {       // 4 k-steps per burst (64 rows / wave set)
-                if (wave + 16 * ub >= KS) break;            // wave-uniform
+                if (16 * WG_MAXU * ch + wave + 16 * ub >= KS) break;            // wave-uniform
                 f32x2 a1[4], a2[4], a3[4];
                 float bx[4], bd[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {               // one burst of independent loads
-                    const int sidx = wave + 16 * (ub + u);
+                    const int sidx = 16 * WG_MAXU * ch + wave + 16 * (ub + u);
                     a1[u] = f32x2{0.f, 0.f}; a2[u] = f32x2{0.f, 0.f}; a3[u] = f32x2{0.f, 0.f};
                     bx[u] = 0.f; bd[u] = 0.f;
                     if (sidx < KS) {

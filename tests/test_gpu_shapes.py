@@ -1,0 +1,139 @@
+"""Shape / edge-case sweep of the HIP paths against the CPU oracle on seeded synthetic inputs, plus
+the error behaviour of the C ABI on a GPU.  Covers what the golden fixtures do not: wide inputs with
+4-row tiles (layer 1 on MFMA), the maximum dimensions, a batch size above N (one minibatch), the
+merged last minibatch taking the 16-row kernel inside the same pass, ragged / single-row sub-buffers,
+and a wrapped replay store for SAC.  Tolerances as in test_gpu_ppo.py (stats 2e-5, theta 5e-6: few
+optimiser steps, so no chaotic drift yet)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _synthetic(rng, rows_per_env, Do, Da, ep):
+    cols = {k: [] for k in ("obs", "act", "rew", "cost", "term", "trunc", "obs_next")}
+    for T in rows_per_env:
+        obs = rng.standard_normal((T + 1, Do)).astype(np.float32)
+        act = (0.3 * rng.standard_normal((T, Da))).astype(np.float32)
+        rew = rng.normal(0.5, 0.5, T); cost = (rng.random(T) < 0.2).astype(np.float64)
+        trunc = np.zeros(T, bool); trunc[ep - 1::ep] = True
+        term = np.zeros(T, bool)
+        if T > 3:
+            term[T // 2] = True
+        for k, v in zip(cols, (obs[:-1], act, rew, cost, term, trunc, obs[1:])):
+            cols[k].append(v)
+    return cols
+
+
+SHAPES = [  # obs, act, hidden, rows per env, episode length, batch, repeat
+    (33, 6, 128, [300, 257, 143], 50, 64, 2),          # wide input + 4-row tiles, ragged envs
+    (128, 16, 64, [200, 200], 40, 128, 2),             # maximum obs / act dims
+    (17, 1, 256, [300, 300], 75, 256, 2),              # merged last minibatch (344 rows) -> 16-row kernel
+    (3, 2, 64, [90, 1, 35], 30, 1000, 3),              # batch > N: one minibatch; a single-row sub-buffer
+    (60, 2, 256, [520], 520, 512, 1),                  # one env, unfinished episode only, two 16-row steps
+]
+
+
+@pytest.mark.parametrize("Do,Da,H,rows,ep,B,repeat", SHAPES)
+def test_ppo_update_shape_sweep_vs_oracle(Do, Da, H, rows, ep, B, repeat):
+    from fsrl_amd.engine import Engine, EngineConfig
+    from oracle.ppo_lag import OnPolicyData, PPOLagConfig, PPOLagOracle
+    rng = np.random.default_rng(Do * 1000 + H)
+    cols = _synthetic(rng, rows, Do, Da, ep)
+    eng = Engine(EngineConfig(obs_dim=Do, act_dim=Da, hidden=H, env_num=len(rows), buffer_size=len(rows) * 1024,
+                              max_grad_norm=0.5, target_kl=None, max_action=1.5))
+    o = PPOLagOracle(PPOLagConfig(obs_dim=Do, act_dim=Da, hidden=(H, H), max_grad_norm=0.5, target_kl=1e9,
+                                  max_action=1.5))
+    torch.manual_seed(Do)
+    theta = (0.15 * torch.randn(o.n_params)).numpy()
+    o.set_params(theta); eng.set_params(theta)
+    for t in range(max(rows)):                          # lock-step, envs drop out as they run dry
+        ids = [e for e in range(len(rows)) if t < rows[e]]
+        eng.push(ids, *[np.stack([cols[k][e][t] for e in ids]) for k in ("obs", "act", "rew", "cost", "term", "trunc",
+                                                                         "obs_next")])
+    cat = {k: np.concatenate(v) for k, v in cols.items()}
+    end = cat["term"] | cat["trunc"]
+    off = np.cumsum(rows) - 1
+    end = end.copy(); end[off] = True                   # unfinished tails
+    data = OnPolicyData(obs=cat["obs"], act=cat["act"], rew=cat["rew"], cost=cat["cost"], terminated=cat["term"],
+                        truncated=cat["trunc"], obs_next=cat["obs_next"], end_flag=end)
+    N = len(data)
+    lag = np.array([0.4]); resc = 1 / 1.4
+    perms = [rng.permutation(N) for _ in range(repeat)]
+    pb, ostats, _ = o.update(data, lag, resc, B, repeat, perms=perms)
+    stats, stopped = eng.ppo_update(lag, resc, B, repeat, perms=perms)
+    assert stopped == -1 and stats.shape == np.asarray(ostats).shape
+    for k in ("advs", "rets", "values"):
+        scale = max(1.0, float(pb[k].abs().max()))
+        np.testing.assert_allclose(eng.batch_get(k), pb[k].numpy(), rtol=0, atol=5e-6 * scale, err_msg=k)
+    np.testing.assert_allclose(stats, np.asarray(ostats), rtol=3e-5, atol=3e-5)
+    d = np.abs(eng.get_params() - o.get_params())      # Adam on noise-level gradients: a handful of entries
+    assert np.quantile(d, 0.999) <= 5e-6 and d.max() <= 1e-4, (np.quantile(d, 0.999), d.max())   # may differ by ~lr*1e-2
+    eng.close()
+
+
+def test_c_abi_error_behaviour_on_gpu():
+    from fsrl_amd.engine import Engine, EngineConfig
+    eng = Engine(EngineConfig(obs_dim=4, act_dim=2, hidden=64, env_num=2, buffer_size=64))
+    # empty store: like the reference (sample(0) of an empty buffer -> empty batch -> no minibatches)
+    assert eng.ppo_begin([0.1], 1.0, 16) == 0
+    assert eng.ppo_pass(None) is False
+    assert eng.ppo_end_stats(4).shape == (0, 11)
+    with pytest.raises((AssertionError, RuntimeError)):          # pass without begin
+        eng.ppo_pass(None)
+    z = np.zeros
+    eng.push([0, 1], z((2, 4), np.float32), z((2, 2), np.float32), z(2), z(2), z(2, bool), z(2, bool), z((2, 4), np.float32))
+    with pytest.raises(AssertionError):                          # buffer id out of range
+        eng.push([2], z((1, 4), np.float32), z((1, 2), np.float32), z(1), z(1), z(1, bool), z(1, bool), z((1, 4), np.float32))
+    with pytest.raises(AssertionError):                          # non-positive batch size
+        eng.ppo_begin([0.1], 1.0, 0)
+    n = eng.ppo_begin([0.1], 1.0, 16)
+    assert n == 2
+    with pytest.raises(AssertionError):                          # not a permutation of the batch
+        eng.ppo_pass(np.array([0, 0]))
+    with pytest.raises((AssertionError, RuntimeError)):          # SAC entry point on a PPO context
+        eng.sac_init()
+    with pytest.raises(AssertionError):
+        eng.set_params(np.zeros(3, np.float32))
+    eng.close()
+
+
+def test_sac_on_a_wrapped_store_device_and_host_chains_agree():
+    """Sub-buffers overwritten 2.5 times: ReplayBuffer.next / unfinished_index across the wrap point.
+    The device sampler (chains computed in sac_sample_kernel) and the caller-RNG mode (chains computed
+    on the host) must produce bit-identical updates from the same indices."""
+    from fsrl_amd import _lib
+    from fsrl_amd.engine import Engine, EngineConfig
+    rng = np.random.default_rng(3)
+    Do, Da, E, sub = 5, 3, 3, 40
+
+    def make():
+        eng = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=Do, act_dim=Da, hidden=64, n_critics=2, env_num=E,
+                                  buffer_size=E * sub, gamma=0.97, target_kl=None))
+        eng.sac_init(n_step=3)
+        r = np.random.default_rng(0)
+        eng.sac_set_params((0.2 * r.standard_normal(eng.n_sac_actor)).astype(np.float32),
+                           (0.2 * r.standard_normal(eng.n_sac_critics)).astype(np.float32), -0.3)
+        return eng
+    dev, twin = make(), make()
+    T = 100                                                  # 2.5 x the sub-buffer
+    obs = rng.standard_normal((T + 1, E, Do)).astype(np.float32)
+    act = np.tanh(rng.standard_normal((T, E, Da))).astype(np.float32)
+    rew = rng.normal(0, 1, (T, E)); cost = (rng.random((T, E)) < 0.3).astype(np.float64)
+    term = rng.random((T, E)) < 0.05; trunc = np.zeros((T, E), bool); trunc[12::13] = True
+    for t in range(T):
+        ids = [0, 1, 2] if t % 7 else [0, 2]                 # env 1 lags: different write cursors
+        for e_ in (dev, twin):
+            e_.push(ids, obs[t, ids], act[t, ids], rew[t, ids], cost[t, ids], term[t, ids], trunc[t, ids], obs[t + 1, ids])
+    assert len(dev) == E * sub
+    for u in range(6):
+        dev.sac_update(64, [0.2], 1 / 1.2, seed=5 if u == 0 else 0, sync=False)
+        idx, et, ep = dev.sac_last_sample(64)
+        assert (idx >= 0).all() and (idx < E * sub).all()
+        st = twin.sac_update(64, [0.2], 1 / 1.2, indices=idx, eps_target=et, eps_pi=ep)
+    rows = dev.sac_drain()
+    assert np.isfinite(rows).all() and np.array_equal(rows[-1], st)
+    for which in (0, 1, 2):
+        assert np.array_equal(dev.sac_get_params(which)[0], twin.sac_get_params(which)[0])
+    dev.close(); twin.close()

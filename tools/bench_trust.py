@@ -71,6 +71,8 @@ def run(kind, obs_dim, act_dim, hid, envs=20, T=1000, ep=1000, repeat=4, cpu_rep
     for _ in range(n):
         stats = device_update()
     dt = (time.perf_counter() - t0) / n
+    if os.environ.get("FSRL_NO_CPU"):
+        print(json.dumps({"bench": kind, "hip_ms_per_update": dt * 1e3})); eng.close(); return
     em = lambda a: np.concatenate([a[:, e] for e in range(envs)])
     data = OnPolicyData(obs=em(obs[:-1]), act=em(act), rew=em(rew), cost=em(cost), terminated=em(term),
                         truncated=em(trunc), obs_next=em(obs[1:]), end_flag=em(term | trunc))
