@@ -137,3 +137,107 @@ def test_sac_on_a_wrapped_store_device_and_host_chains_agree():
     for which in (0, 1, 2):
         assert np.array_equal(dev.sac_get_params(which)[0], twin.sac_get_params(which)[0])
     dev.close(); twin.close()
+
+
+SAC_VARIANTS = [  # Do, Da, H, rows per env, batch, n_step, auto_alpha, use_lagrangian
+    (7, 3, 64, [40, 17], 100, 1, True, True),            # batch not a multiple of 16, 1-step targets
+    (20, 8, 128, [64, 64, 64], 16, 3, False, True),      # fixed temperature, maximum action width
+    (9, 2, 256, [33], 1, 2, True, False),                # batch of one row, no Lagrangian term
+    (41, 1, 64, [90, 45], 333, 2, True, True),           # batch larger than the store (sampling with replacement)
+]
+
+
+@pytest.mark.parametrize("Do,Da,H,rows,B,n_step,auto_alpha,use_lag", SAC_VARIANTS)
+def test_sac_variants_vs_oracle(Do, Da, H, rows, B, n_step, auto_alpha, use_lag):
+    from fsrl_amd import _lib
+    from fsrl_amd.engine import Engine, EngineConfig
+    from oracle.sac_lag import ReplayIndex, SACConfig, SACLagOracle
+    rng = np.random.default_rng(Do + 10 * Da)
+    E, sub = len(rows), 128
+    eng = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=Do, act_dim=Da, hidden=H, n_critics=2, env_num=E,
+                              buffer_size=E * sub, gamma=0.98, target_kl=None))
+    eng.sac_init(n_step=n_step, auto_alpha=auto_alpha, alpha=0.05, use_lagrangian=use_lag, tau=0.1)
+    o = SACLagOracle(SACConfig(obs_dim=Do, act_dim=Da, hidden=(H, H), gamma=0.98, n_step=n_step, tau=0.1, alpha=0.05,
+                               auto_alpha=auto_alpha, use_lagrangian=use_lag))
+    tha = (0.2 * rng.standard_normal(o.n_actor)).astype(np.float32)
+    thc = (0.2 * rng.standard_normal(2 * o.n_critic)).astype(np.float32)
+    o.set_params(tha, thc, -0.5); eng.sac_set_params(tha, thc, -0.5)
+    store = {k: np.zeros((E * sub, ) + s, d) for k, s, d in (("obs", (Do, ), np.float32), ("obs_next", (Do, ), np.float32),
+             ("act", (Da, ), np.float32), ("rew", (), np.float64), ("cost", (), np.float64),
+             ("terminated", (), bool), ("truncated", (), bool))}
+    for t in range(max(rows)):
+        ids = [e for e in range(E) if t < rows[e]]
+        k = len(ids)
+        row = dict(obs=rng.standard_normal((k, Do)).astype(np.float32), act=np.tanh(rng.standard_normal((k, Da))).astype(np.float32),
+                   rew=rng.normal(0, 1, k), cost=(rng.random(k) < 0.3).astype(np.float64), terminated=rng.random(k) < 0.1,
+                   truncated=np.full(k, t % 11 == 10), obs_next=rng.standard_normal((k, Do)).astype(np.float32))
+        eng.push(ids, row["obs"], row["act"], row["rew"], row["cost"], row["terminated"], row["truncated"], row["obs_next"])
+        for e, j in zip(ids, range(k)):
+            for key in store:
+                store[key][e * sub + t] = row[key][j]
+    index = ReplayIndex(rows, sub, store["terminated"] | store["truncated"])
+    valid = np.concatenate([e * sub + np.arange(r) for e, r in enumerate(rows)])
+    lag = [0.3] if use_lag else []
+    for u in range(3):
+        idx = rng.choice(valid, B)
+        et = rng.standard_normal((B, Da)).astype(np.float32); ep = rng.standard_normal((B, Da)).astype(np.float32)
+        sa, sc, _ = o.update(store, index, idx, et, ep, lag if use_lag else [0.0], 1 / 1.3)
+        st = eng.sac_update(B, lag, 1 / 1.3, indices=idx, eps_target=et, eps_pi=ep)
+        want = {**sa, **sc}
+        keys = ["loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss/alpha_loss", "loss/alpha_value",
+                "loss/actor_rew", "loss/actor_total", "loss/q0", "loss/q1", "loss/q_total"]
+        for j, kname in enumerate(keys):
+            if kname in want:
+                w = float(want[kname])
+                assert abs(st[j] - w) <= 1e-4 * abs(w) + 1e-5, (u, kname, st[j], w)
+    for got, ref in ((eng.sac_get_params(0)[0], o.actor_flat()), (eng.sac_get_params(1)[0], o.critics_flat()),
+                     (eng.sac_get_params(2)[0], o.critics_flat(old=True))):
+        d = np.abs(got - ref)      # Adam: an entry whose gradient is rounding noise moves by +-lr per step either way
+        assert np.quantile(d, 0.99) <= 5e-6 and d.max() <= 3 * 1e-3, (np.quantile(d, 0.99), d.max())
+    eng.close()
+
+
+@pytest.mark.parametrize("Do,Da,H,rows", [(5, 2, 64, [37]), (60, 2, 128, [130, 99, 20]), (12, 4, 256, [5, 3])])
+def test_trust_region_pieces_on_odd_sizes_vs_autograd(Do, Da, H, rows):
+    """Surrogate / KL gradients and the Hessian-vector product for N that is not a multiple of 16 (and as
+    small as 8 rows), wide inputs, several ragged sub-buffers."""
+    from fsrl_amd.engine import Engine, EngineConfig
+    from oracle.ppo_lag import OnPolicyData
+    from oracle.trust_region import CPOConfig, CPOOracle
+    from torch.distributions import Independent, Normal, kl_divergence
+    rng = np.random.default_rng(H + Do)
+    cols = _synthetic(rng, rows, Do, Da, 25)
+    eng = Engine(EngineConfig(obs_dim=Do, act_dim=Da, hidden=H, env_num=len(rows), buffer_size=len(rows) * 256,
+                              target_kl=None, max_action=1.0))
+    o = CPOOracle(CPOConfig(obs_dim=Do, act_dim=Da, hidden=(H, H)))
+    torch.manual_seed(H)
+    theta = (0.2 * torch.randn(o.n_params)).numpy()
+    o.set_params(theta); eng.set_params(theta)
+    for t in range(max(rows)):
+        ids = [e for e in range(len(rows)) if t < rows[e]]
+        eng.push(ids, *[np.stack([cols[k][e][t] for e in ids]) for k in ("obs", "act", "rew", "cost", "term", "trunc",
+                                                                         "obs_next")])
+    cat = {k: np.concatenate(v) for k, v in cols.items()}
+    end = (cat["term"] | cat["trunc"]).copy(); end[np.cumsum(rows) - 1] = True
+    data = OnPolicyData(obs=cat["obs"], act=cat["act"], rew=cat["rew"], cost=cat["cost"], terminated=cat["term"],
+                        truncated=cat["trunc"], obs_next=cat["obs_next"], end_flag=end)
+    pb = o.process(data)
+    assert eng.tr_begin(target_kl=0.01, norm_adv=True, cost_limit=10.0) == sum(rows)
+    theta2 = theta + (0.02 * torch.randn(o.n_params)).numpy()          # theta != theta_old: exact Hessian
+    o.set_params(theta2); eng.set_params(theta2)
+    dist = o.actor_dist(pb["obs"])
+    ratio = torch.exp(dist.log_prob(pb["act"]) - pb["logp_old"])
+    obj = torch.mean(ratio * pb["advs"][..., 0])
+    kl = kl_divergence(Independent(Normal(pb["mean_old"], pb["std_old"]), 1), dist).mean()
+    og = o.flat_grad(obj, retain_graph=True).numpy()
+    klg = o.flat_grad(kl, create_graph=True)
+
+    def close(a, b, rel):
+        scale = max(float(np.abs(b).max()), 1e-12)
+        assert float(np.abs(a - b).max()) <= rel * scale, (float(np.abs(a - b).max()), scale)
+    close(eng.tr_grad(0), og, 3e-5)
+    close(eng.tr_grad(2), klg.detach().numpy(), 3e-5)
+    v = torch.randn(klg.numel())
+    hv = o.flat_grad((klg * v).sum(), retain_graph=True).numpy()
+    close(eng.tr_hvp(v.numpy()), hv, 1e-4)
+    eng.close()
