@@ -994,6 +994,8 @@ struct TrState {
     float *A1 = nullptr, *A2 = nullptr, *D1 = nullptr, *D2 = nullptr, *DO = nullptr;      // [nets][rows_pad]
     float *RA1 = nullptr, *RA2 = nullptr, *RD1 = nullptr, *RD2 = nullptr, *RDO = nullptr;  // [rows_pad]
     float *statp = nullptr, *mu_old = nullptr, *Vdev = nullptr, *Out = nullptr, *rd = nullptr;
+    float *cg_r = nullptr, *cg_x = nullptr, *cg_g = nullptr;     // device-resident CG vectors (actor layout)
+    CgScal* cg_sc = nullptr;
     double* d_scal = nullptr;
     size_t cap_rows = 0;
     int64_t critic_t = 0;     // Adam step count of the critic optimiser
@@ -1011,8 +1013,9 @@ static void tr_free(fsrl_ctx* c) {
     TrState* t = c->tr;
     if (!t) return;
     for (float* p : {t->A1, t->A2, t->D1, t->D2, t->DO, t->RA1, t->RA2, t->RD1, t->RD2, t->RDO, t->statp,
-                     t->mu_old, t->Vdev, t->Out, t->rd})
+                     t->mu_old, t->Vdev, t->Out, t->rd, t->cg_r, t->cg_x, t->cg_g})
         if (p) (void)hipFree(p);
+    if (t->cg_sc) (void)hipFree(t->cg_sc);
     if (t->d_scal) (void)hipFree(t->d_scal);
     delete t;
     c->tr = nullptr;
@@ -1045,6 +1048,11 @@ static int tr_alloc(fsrl_ctx* c, TrState* t, int64_t n) {
     HIPCHK(hipMalloc(&t->rd, rows * FSRL_RD * 4));
     if (!t->Vdev) {
         HIPCHK(hipMalloc(&t->Vdev, (size_t)c->n_alloc * 4)); HIPCHK(hipMalloc(&t->Out, (size_t)c->n_dev * 4));
+        for (float** p : {&t->cg_r, &t->cg_x, &t->cg_g}) {
+            HIPCHK(hipMalloc(p, (size_t)c->n_dev * 4));
+            HIPCHK(hipMemsetAsync(*p, 0, (size_t)c->n_dev * 4, c->compute));
+        }
+        HIPCHK(hipMalloc(&t->cg_sc, sizeof(CgScal)));
         HIPCHK(hipMemsetAsync(t->Vdev, 0, (size_t)c->n_alloc * 4, c->compute)); HIPCHK(hipMemsetAsync(t->Out, 0, (size_t)c->n_dev * 4, c->compute));
         HIPCHK(hipStreamSynchronize(c->compute));
         HIPCHK(hipMalloc(&t->d_scal, 64 * sizeof(double)));
@@ -1186,9 +1194,9 @@ static int tr_eval_means(fsrl_ctx* c, TrState* t, double* means8) {
     return 0;
 }
 
-static int tr_hvp(fsrl_ctx* c, TrState* t, const float* v, float* out) {
-    int rc = actor_to_dev(c, v, t->Vdev);
-    if (rc) return rc;
+// H v for the tangent already in t->Vdev (main part + W2 mirror); result in t->Out (device)
+static int tr_hvp_dev(fsrl_ctx* c, TrState* t) {
+    int rc = 0;
     HvpArgs ha{};
     ha.obs = c->b.obs; ha.rd = t->rd; ha.V = t->Vdev; ha.A1 = t->A1; ha.RA1 = t->RA1; ha.A2 = t->A2; ha.RA2 = t->RA2;
     ha.D2 = t->D2; ha.RD2 = t->RD2; ha.RD1 = t->RD1; ha.DO = t->DO; ha.RDO = t->RDO; ha.N = (int)c->N;
@@ -1213,6 +1221,13 @@ static int tr_hvp(fsrl_ctx* c, TrState* t, const float* v, float* out) {
     hipLaunchKernelGGL(fb_sum_parts_kernel, dim3((c->md.net[0].end - c->md.net[0].begin + 255) / 256), dim3(256), 0,
                        c->compute, t->Out, c->wg_parts, c->md.net[0].begin, c->md.net[0].end, nsplit, c->n_dev);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+static int tr_hvp(fsrl_ctx* c, TrState* t, const float* v, float* out) {
+    int rc = actor_to_dev(c, v, t->Vdev);
+    if (rc) return rc;
+    rc = tr_hvp_dev(c, t);
+    if (rc) return rc;
     return actor_from_dev(c, t->Out, out);
 }
 
@@ -1253,23 +1268,28 @@ static float vdot(const std::vector<float>& a, const std::vector<float>& b) {
 // x = H^-1 g by conjugate gradients with damped HVPs (cpo.py:184-204 / trpo_lag.py:261-283)
 static int tr_cg(fsrl_ctx* c, TrState* t, const std::vector<float>& g, float damping, int nsteps, float tol,
                  std::vector<float>& x) {
+    // device-resident: g goes up once, x comes back once; no host synchronisation per iteration
+    // (after an early convergence the remaining steps are no-ops on the device)
     const size_t n = g.size();
     x.assign(n, 0.0f);
-    std::vector<float> r = g, p = g, z(n);
-    float rs_old = vdot(r, r);
-    for (int it = 0; it < nsteps; ++it) {
-        int rc = tr_hvp(c, t, p.data(), z.data());
-        if (rc) return rc;
-        for (size_t i = 0; i < n; ++i) z[i] += p[i] * damping;
-        const float alpha = rs_old / vdot(p, z);
-        for (size_t i = 0; i < n; ++i) { x[i] += alpha * p[i]; r[i] -= alpha * z[i]; }
-        const float rs_new = vdot(r, r);
-        if (rs_new < tol) break;
-        const float beta = rs_new / rs_old;
-        for (size_t i = 0; i < n; ++i) p[i] = r[i] + beta * p[i];
-        rs_old = rs_new;
+    const int nd = c->md.net[0].end;
+    {   // g in device layout (no mirror needed: cg_init writes p and its mirror)
+        std::vector<float> tmp((size_t)nd, 0.0f);
+        for (int i = 0; i < 7; ++i) memcpy(&tmp[c->tmap[i].dev_off], g.data() + c->tmap[i].api_off, (size_t)c->tmap[i].n * 4);
+        HIPCHK(hipStreamSynchronize(c->compute));
+        HIPCHK(hipMemcpy(t->cg_g, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
     }
-    return 0;
+    hipLaunchKernelGGL(cg_init_kernel, dim3(1), dim3(1024), 0, c->compute, t->cg_g, t->cg_r, t->Vdev, t->cg_x, t->cg_sc, nd,
+                       c->md);
+    HIPCHK(hipGetLastError());
+    for (int it = 0; it < nsteps; ++it) {
+        int rc = tr_hvp_dev(c, t);
+        if (rc) return rc;
+        hipLaunchKernelGGL(cg_step_kernel, dim3(1), dim3(1024), 0, c->compute, t->Out, t->cg_r, t->Vdev, t->cg_x, t->cg_sc, nd,
+                           damping, tol, c->md);
+        HIPCHK(hipGetLastError());
+    }
+    return actor_from_dev(c, t->cg_x, x.data());
 }
 
 static int tr_mvp(fsrl_ctx* c, TrState* t, const std::vector<float>& v, float damping, std::vector<float>& out) {

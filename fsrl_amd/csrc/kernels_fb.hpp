@@ -746,6 +746,79 @@ __global__ __launch_bounds__(256) void fb_reduce_stats_kernel(const float* __res
     if (tid == 0) out[slot] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// ---- conjugate gradients on the device (cpo.py:184-204, trpo_lag.py:261-283).  Vectors live in the
+// actor's device layout (length n = md.net[0].end, inter-tensor padding stays zero); p is the tangent
+// vector the HVP kernels read (with its W2 mirror), z arrives in `hz` from fb_sum_parts_kernel.
+// One 1024-thread block per step: both dot products and the three axpys, reductions in a fixed order.
+struct CgScal { float rs_old; int done; int iters; int pad; };
+
+__device__ __forceinline__ float cg_block_sum(float v, float* sh, int tid) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
+    __syncthreads();
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void cg_init_kernel(const float* __restrict__ g, float* __restrict__ r,
+                                                      float* __restrict__ p, float* __restrict__ x,
+                                                      CgScal* __restrict__ sc, int n, const ModelDesc md) {
+    __shared__ float sh[16];
+    const int tid = threadIdx.x;
+    float part = 0.0f;
+    for (int i = tid; i < n; i += 1024) {
+        const float gi = g[i];
+        r[i] = gi; p[i] = gi; x[i] = 0.0f;
+        const int mi = w2f_mirror_of(md, i);
+        if (mi >= 0) p[mi] = gi;
+        part = fmaf(gi, gi, part);
+    }
+    const float rs = cg_block_sum(part, sh, tid);
+    if (tid == 0) { sc->rs_old = rs; sc->done = 0; sc->iters = 0; }
+}
+
+__global__ __launch_bounds__(1024) void cg_step_kernel(float* __restrict__ hz, float* __restrict__ r,
+                                                      float* __restrict__ p, float* __restrict__ x,
+                                                      CgScal* __restrict__ sc, int n, float damping, float tol,
+                                                      const ModelDesc md) {
+    __shared__ float sh[16];
+    const int tid = threadIdx.x;
+    if (sc->done) return;                                  // converged earlier: x is final
+    const float rs_old = sc->rs_old;
+    float part = 0.0f;
+    for (int i = tid; i < n; i += 1024) {                  // z = H p + damping p ;  p.z
+        const float pi = p[i];
+        const float z = hz[i] + pi * damping;
+        hz[i] = z;
+        part = fmaf(pi, z, part);
+    }
+    const float pAp = cg_block_sum(part, sh, tid);
+    const float alpha = rs_old / pAp;
+    part = 0.0f;
+    for (int i = tid; i < n; i += 1024) {                  // x += alpha p ; r -= alpha z ; r.r
+        x[i] = x[i] + alpha * p[i];
+        const float ri = r[i] - alpha * hz[i];
+        r[i] = ri;
+        part = fmaf(ri, ri, part);
+    }
+    const float rs_new = cg_block_sum(part, sh, tid);
+    if (rs_new < tol) {
+        if (tid == 0) { sc->done = 1; sc->iters += 1; }
+        return;
+    }
+    const float beta = rs_new / rs_old;
+    for (int i = tid; i < n; i += 1024) {                  // p = r + beta p  (and its W2 mirror)
+        const float pn = r[i] + beta * p[i];
+        p[i] = pn;
+        const int mi = w2f_mirror_of(md, i);
+        if (mi >= 0) p[mi] = pn;
+    }
+    if (tid == 0) { sc->rs_old = rs_new; sc->iters += 1; }
+}
+
 // full-batch advantage normalisation (CPO cpo.py:127-131, TRPO trpo_lag.py:129-133): per critic
 // (a - mean) / std with the unbiased std, float64 accumulate.  grid = C blocks of 1024 threads.
 __global__ __launch_bounds__(1024) void fb_advnorm_kernel(float* __restrict__ advs, int N) {
