@@ -1142,7 +1142,7 @@ static int tr_tile(fsrl_ctx* c, TrState* t, int mode, int net0, int ny, float cr
     a.max_action = c->cfg.max_action;
     return dispatch_H(c->cfg.hidden, [&](auto hc) {
         constexpr int H = decltype(hc)::value;
-        hipLaunchKernelGGL(fb_tile_kernel<H>, dim3(t->n_tiles, ny), dim3(4 * H), 0, c->compute, c->P, c->md, a);
+        hipLaunchKernelGGL((fb_tile_kernel<H, 16>), dim3(t->n_tiles, ny), dim3(4 * H), 0, c->compute, c->P, c->md, a);
         HIPCHK(hipGetLastError());
         return 0;
     });
@@ -1517,7 +1517,8 @@ struct SacState {
     SacScalars* sc = nullptr;
     int64_t t_actor = 0, t_critic = 0;
     // per-batch buffers
-    int cap_B = 0, n_tiles = 0;
+    int cap_B = 0, n_tiles = 0;               // n_tiles = 16-row tiles of the batch
+    bool q_rows4 = false, a_rows4 = false;    // 4-row tile variants for the Q / actor launches
     int *d_idx = nullptr, *d_chain = nullptr; uint8_t* d_end = nullptr;
     int *h_idx = nullptr, *h_chain = nullptr; uint8_t* h_end = nullptr;          // pinned
     float *XQ = nullptr, *OBS = nullptr, *OBSN = nullptr, *XN = nullptr, *XP = nullptr;
@@ -1689,6 +1690,8 @@ extern "C" int fsrl_sac_params_get(fsrl_ctx* c, int32_t which, float* out, int64
 
 static int sac_alloc_batch(fsrl_ctx* c, SacState* s, int B) {
     s->n_tiles = (B + 15) / 16;
+    s->q_rows4 = 4 * s->n_tiles * 4 <= c->n_cus && !getenv("FSRL_TILE16");
+    s->a_rows4 = 4 * s->n_tiles <= c->n_cus && !getenv("FSRL_TILE16");
     if (B <= s->cap_B) return 0;
     HIPCHK(hipStreamSynchronize(c->compute));
     const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim, Din = Do + Da, H = c->cfg.hidden, ns = s->cfg.n_step;
@@ -1717,8 +1720,9 @@ static int sac_alloc_batch(fsrl_ctx* c, SacState* s, int B) {
     rc |= re(&s->Y, 2 * Bp * 4); rc |= re(&s->DA, 4 * Bp * Da * 4);
     rc |= re(&s->A1, 4 * Bp * H * 4); rc |= re(&s->A2, 4 * Bp * H * 4); rc |= re(&s->D1, 4 * Bp * H * 4);
     rc |= re(&s->D2, 4 * Bp * H * 4); rc |= re(&s->DO, 4 * Bp * FSRL_DOW * 4);
-    rc |= re(&s->stq, (size_t)(s->n_tiles + 4) * 4 * FB_NSTAT * 4); rc |= re(&s->stdin_, (size_t)(s->n_tiles + 4) * 4 * FB_NSTAT * 4);
-    rc |= re(&s->stpi, (size_t)(s->n_tiles + 4) * FB_NSTAT * 4);
+    // per-tile partial statistics: room for 4-row tiles (4 x the 16-row tile count)
+    rc |= re(&s->stq, (size_t)(4 * s->n_tiles + 4) * 4 * FB_NSTAT * 4); rc |= re(&s->stdin_, (size_t)(4 * s->n_tiles + 4) * 4 * FB_NSTAT * 4);
+    rc |= re(&s->stpi, (size_t)(4 * s->n_tiles + 4) * FB_NSTAT * 4);
     if (rc) return FSRL_EHIP;
     s->cap_B = B;
     return 0;
@@ -1748,7 +1752,9 @@ static int sac_q_launch(fsrl_ctx* c, SacState* s, const float* params, const flo
     a.act_cols = c->cfg.act_dim;
     return dispatch_H(c->cfg.hidden, [&](auto hc) {
         constexpr int H = decltype(hc)::value;
-        hipLaunchKernelGGL(fb_tile_kernel<H>, dim3(s->n_tiles, 4), dim3(4 * H), 0, c->compute, params, s->mdq, a);
+        // 4-row tiles while they still fit the chip in one round (batch <= 256 for the four Q-nets)
+        if (s->q_rows4) hipLaunchKernelGGL((fb_tile_kernel<H, 4>), dim3(4 * s->n_tiles, 4), dim3(4 * H), 0, c->compute, params, s->mdq, a);
+        else hipLaunchKernelGGL((fb_tile_kernel<H, 16>), dim3(s->n_tiles, 4), dim3(4 * H), 0, c->compute, params, s->mdq, a);
         HIPCHK(hipGetLastError());
         return 0;
     });
@@ -1859,7 +1865,8 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
         aa.auto_alpha = s->cfg.auto_alpha; aa.alpha_fixed = s->cfg.alpha;
         return dispatch_H(c->cfg.hidden, [&](auto hc) {
             constexpr int H = decltype(hc)::value;
-            hipLaunchKernelGGL(sac_actor_tile_kernel<H>, dim3(s->n_tiles), dim3(4 * H), 0, st, s->PA, s->mda, aa);
+            if (s->a_rows4) hipLaunchKernelGGL((sac_actor_tile_kernel<H, 4>), dim3(4 * s->n_tiles), dim3(4 * H), 0, st, s->PA, s->mda, aa);
+            else hipLaunchKernelGGL((sac_actor_tile_kernel<H, 16>), dim3(s->n_tiles), dim3(4 * H), 0, st, s->PA, s->mda, aa);
             HIPCHK(hipGetLastError());
             return 0;
         });
@@ -1899,7 +1906,7 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     SacFinalArgs fa{};
     float* stats_row = s->d_stats + (size_t)(s->n_updates % SAC_RING) * FSRL_SAC_NSTATS_K;
     fa.statp_q = s->stq; fa.statp_din = s->stdin_; fa.statp_pi = s->stpi; fa.sc = s->sc; fa.stats = stats_row;
-    fa.n_tiles = s->n_tiles; fa.B = B; fa.rescale = resc; fa.lam = lam; fa.target_entropy = s->cfg.target_entropy;
+    fa.n_tiles_q = s->q_rows4 ? 4 * s->n_tiles : s->n_tiles; fa.n_tiles_pi = s->a_rows4 ? 4 * s->n_tiles : s->n_tiles; fa.B = B; fa.rescale = resc; fa.lam = lam; fa.target_entropy = s->cfg.target_entropy;
     fa.alpha_lr = s->cfg.alpha_lr; fa.beta1 = c->cfg.beta1; fa.beta2 = c->cfg.beta2; fa.adam_eps = c->cfg.adam_eps;
     fa.alpha_fixed = s->cfg.alpha; fa.auto_alpha = s->cfg.auto_alpha; fa.use_lagrangian = s->cfg.use_lagrangian;
     hipLaunchKernelGGL(sac_finalize_kernel, dim3(1), dim3(64), 0, st, fa);

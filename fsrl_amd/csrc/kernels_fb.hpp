@@ -42,7 +42,7 @@ struct FbArgs {
 // weight-gradient kernel.  wb = this wave's column slice of W2 (lane (li,q): W2[16jc+4q+s][16w+li]).
 // keep_dz1: also leave dz1 in sm.d2 (used for input gradients).  Always leaves dz1 in sm.d2 when
 // `FB_MODE_Q_DIN` callers ask for it via the trailing flag == true or read it after a barrier.
-template <int H>
+template <int H, int R = 16>
 __device__ __forceinline__ void tile_backward(TileSmem<H>& sm, const NetOff no, const float (&wb)[H / 16][4],
                                               float* __restrict__ A1, float* __restrict__ A2,
                                               float* __restrict__ D1, float* __restrict__ D2,
@@ -51,12 +51,12 @@ __device__ __forceinline__ void tile_backward(TileSmem<H>& sm, const NetOff no, 
     constexpr int NT = TileGeom<H>::NT;
     constexpr int H4 = H / 4;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
-    for (int e = tid; e < 16 * H4; e += NT) {
+    for (int e = tid; e < R * H4; e += NT) {
         const int i = e / H4, c4 = e - i * H4;
         *reinterpret_cast<f32x4*>(&A1[(size_t)i * H + 4 * c4]) = *reinterpret_cast<const f32x4*>(&sm.h1[i * LD + 4 * c4]);
         *reinterpret_cast<f32x4*>(&A2[(size_t)i * H + 4 * c4]) = *reinterpret_cast<const f32x4*>(&sm.h2[i * LD + 4 * c4]);
     }
-    {   // dz2 = (dout @ W3) * relu'(z2)
+    if (R == 16 || tid < H) {   // dz2 = (dout @ W3) * relu'(z2)
         const int k = tid % H, rg = tid / H;
         float g[4] = {0.f, 0.f, 0.f, 0.f};
         for (int o = 0; o < no.out; ++o) {
@@ -71,35 +71,62 @@ __device__ __forceinline__ void tile_backward(TileSmem<H>& sm, const NetOff no, 
         }
     }
     __syncthreads();
-    for (int e = tid; e < 16 * H4; e += NT) {
+    for (int e = tid; e < R * H4; e += NT) {
         const int i = e / H4, c4 = e - i * H4;
         *reinterpret_cast<f32x4*>(&D2[(size_t)i * H + 4 * c4]) = *reinterpret_cast<const f32x4*>(&sm.d2[i * LD + 4 * c4]);
     }
-    for (int e = tid; e < 16 * FSRL_DOW; e += NT) DOb[e] = sm.dout[e];
+    for (int e = tid; e < R * FSRL_DOW; e += NT) DOb[e] = sm.dout[e];
     // dz1 = (dz2 @ W2) * relu'(z1)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* arow = &sm.d2[li * LD + 4 * q];
-#pragma unroll
-    for (int jc = 0; jc < H / 16; ++jc) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * jc);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = mfma_16x16x4(av[s], wb[jc][s], acc);
-    }
     const int col = wave * 16 + li;
-    float v[4];
+    if constexpr (R == 4) {
+        const float* arow = &sm.d2[(lane & 3) * LD + 4 * q];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = 4 * q + r;
-        v[r] = (sm.h1[i * LD + col] > 0.0f) ? acc[r] : 0.0f;
-        D1[(size_t)i * H + col] = v[r];
+        for (int jc = 0; jc < H / 16; ++jc) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * jc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma_4x4x1(av[s], wb[jc][s], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {            // add the four k-classes
+            acc[r] += __shfl_xor(acc[r], 16, 64);
+            acc[r] += __shfl_xor(acc[r], 32, 64);
+        }
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = (sm.h1[r * LD + col] > 0.0f) ? acc[r] : 0.0f;
+            if (q == 0) D1[(size_t)r * H + col] = v[r];
+        }
+        __syncthreads();          // every wave is done reading dz2 from sm.d2
+        if (q == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm.d2[r * LD + col] = v[r];   // dz1, for input gradients
+        }
+    } else {
+        const float* arow = &sm.d2[li * LD + 4 * q];
+#pragma unroll
+        for (int jc = 0; jc < H / 16; ++jc) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * jc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma_16x16x4(av[s], wb[jc][s], acc);
+        }
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * q + r;
+            v[r] = (sm.h1[i * LD + col] > 0.0f) ? acc[r] : 0.0f;
+            D1[(size_t)i * H + col] = v[r];
+        }
+        __syncthreads();          // every wave is done reading dz2 from sm.d2
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sm.d2[(4 * q + r) * LD + col] = v[r];   // dz1, for input gradients
     }
-    __syncthreads();          // every wave is done reading dz2 from sm.d2
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sm.d2[(4 * q + r) * LD + col] = v[r];   // dz1, for input gradients
 }
 
 // ------------------------------------------------------------------------------------------
-template <int H>
+// R = rows per tile (16, or 4 on v_mfma_f32_4x4x1 when 16-row tiles would leave most CUs idle)
+template <int H, int R>
 __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict__ P,
                                                        const ModelDesc md, const FbArgs a) {
     __shared__ TileSmem<H> sm;
@@ -108,10 +135,10 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
     const int tile = blockIdx.x, net = a.net0 + blockIdx.y;
-    const int row0 = tile * 16;
+    const int row0 = tile * R;
     const NetOff no = md.net[net];
     const int Do = md.Do, Da = md.Da;
-    const int n_valid = min(16, a.N - row0);
+    const int n_valid = max(0, min(R, a.N - row0));
     const float invN = 1.0f / (float)a.N;
 
     TileStage<H> stg;
@@ -121,7 +148,7 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
     for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
     stg.commit(sm, no, Do, tid);
     __syncthreads();
-    tile_forward<H>(sm, P, no, Do, tid, wf);
+    tile_forward<H, R>(sm, P, no, Do, tid, wf);
     const bool backward = (a.mode != FB_MODE_EVAL && a.mode != FB_MODE_Q_FWD);
 
     float wb[H / 16][4];
@@ -135,7 +162,7 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
     }
 
     // ---- head: thread (row i = tid>>4, dim d = tid&15)
-    if (tid < 256) {
+    if (tid < 16 * R) {
         const int i = tid >> 4, d = tid & 15;
         const bool valid = i < n_valid;
         const float* rd = &sm.rd[i * FSRL_RD];
@@ -215,13 +242,13 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
     __syncthreads();
     if (tid < FB_NSTAT) {   // rows summed in ascending order (fixed => deterministic)
         float t = 0.0f;
-        for (int i = 0; i < 16; ++i) t += sm.w1[i * FB_NSTAT + tid];
+        for (int i = 0; i < R; ++i) t += sm.w1[i * FB_NSTAT + tid];
         a.statp[((size_t)tile * gridDim.y + blockIdx.y) * FB_NSTAT + tid] = t;
     }
     if (!backward) return;
 
     const size_t nb = (size_t)blockIdx.y * a.rows_pad;
-    tile_backward<H>(sm, no, wb, a.A1 + (nb + row0) * H, a.A2 + (nb + row0) * H, a.D1 + (nb + row0) * H,
+    tile_backward<H, R>(sm, no, wb, a.A1 + (nb + row0) * H, a.A2 + (nb + row0) * H, a.D1 + (nb + row0) * H,
                      a.D2 + (nb + row0) * H, a.DO + (nb + row0) * FSRL_DOW, tid, false);
     if (a.mode == FB_MODE_Q_DIN) {
         // input gradient w.r.t. the action columns of x = concat(obs, act):
@@ -236,17 +263,17 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
             wact[e] = P[no.W1 + (size_t)j * Do + Dobs + kk];
         }
         __syncthreads();
-        for (int e0 = 0; e0 < 16 * Dact * 8; e0 += NT) {
+        for (int e0 = 0; e0 < R * Dact * 8; e0 += NT) {
             const int e = e0 + tid;
             const int jp = e & 7, ik = e >> 3;
             const int i = ik / Dact, kk = ik - i * Dact;
             float s_ = 0.0f;
-            if (ik < 16 * Dact)
+            if (ik < R * Dact)
                 for (int j = jp; j < H; j += 8) s_ = fmaf(sm.d2[i * LD + j], wact[j * Dact + kk], s_);
             s_ += __shfl_xor(s_, 1, 64);
             s_ += __shfl_xor(s_, 2, 64);
             s_ += __shfl_xor(s_, 4, 64);
-            if (jp == 0 && ik < 16 * Dact && i < n_valid)
+            if (jp == 0 && ik < R * Dact && i < n_valid)
                 a.da_out[((size_t)blockIdx.y * a.N + row0 + i) * Dact + kk] = s_;
         }
     }

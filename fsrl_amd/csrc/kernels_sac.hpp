@@ -122,17 +122,17 @@ struct SacActorArgs {
     int auto_alpha; float alpha_fixed;
 };
 
-template <int H>
+template <int H, int R>
 __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __restrict__ P,
                                                               const ModelDesc md, const SacActorArgs a) {
     __shared__ TileSmem<H> sm;
     constexpr int NT = TileGeom<H>::NT;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
-    const int row0 = blockIdx.x * 16;
+    const int row0 = blockIdx.x * R;
     const NetOff no = md.net[0];
     const int Do = md.Do, Da = md.Da;
-    const int n_valid = min(16, a.B - row0);
+    const int n_valid = max(0, min(R, a.B - row0));
     const float invB = 1.0f / (float)a.B;
 
     TileStage<H> stg;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
     for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
     stg.commit(sm, no, Do, tid);
     __syncthreads();
-    tile_forward<H>(sm, P, no, Do, tid, wf);     // sm.out[i][0..Da) = mu, [Da..2Da) = raw log sigma
+    tile_forward<H, R>(sm, P, no, Do, tid, wf);     // sm.out[i][0..Da) = mu, [Da..2Da) = raw log sigma
 
     float wb[H / 16][4];
     if (a.mode == SAC_A_BWD) {
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
         }
     }
     const float alpha = a.auto_alpha ? a.sc->alpha : a.alpha_fixed;
-    if (tid < 256) {
+    if (tid < 16 * R) {
         const int i = tid >> 4, d = tid & 15;
         const int r = row0 + i;
         const bool valid = i < n_valid;
@@ -193,11 +193,11 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
     __syncthreads();
     if (tid == 0) {
         float t = 0.0f;
-        for (int i = 0; i < 16; ++i) t += sm.w1[i * FB_NSTAT];
+        for (int i = 0; i < R; ++i) t += sm.w1[i * FB_NSTAT];
         a.statp[(size_t)blockIdx.x * FB_NSTAT] = t;
     }
     if (a.mode != SAC_A_BWD) return;
-    tile_backward<H>(sm, no, wb, a.A1 + (size_t)row0 * H, a.A2 + (size_t)row0 * H, a.D1 + (size_t)row0 * H,
+    tile_backward<H, R>(sm, no, wb, a.A1 + (size_t)row0 * H, a.A2 + (size_t)row0 * H, a.D1 + (size_t)row0 * H,
                      a.D2 + (size_t)row0 * H, a.DO + (size_t)row0 * FSRL_DOW, tid, false);
 }
 
@@ -249,7 +249,7 @@ struct SacFinalArgs {
     const float* statp_pi;   // [n_tiles][FB_NSTAT]      st0 = sum log pi
     SacScalars* sc;
     float* stats;            // [FSRL_SAC_NSTATS_K]
-    int n_tiles, B;
+    int n_tiles_q, n_tiles_pi, B;
     float rescale, lam, target_entropy, alpha_lr, beta1, beta2, adam_eps, alpha_fixed;
     int auto_alpha, use_lagrangian;
 };
@@ -260,14 +260,14 @@ __global__ __launch_bounds__(64) void sac_finalize_kernel(const SacFinalArgs a) 
     double s9[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) s9[k] = 0.0;
-    for (int t = lane; t < a.n_tiles; t += 64) {
+    for (int t = lane; t < a.n_tiles_q; t += 64) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             s9[k] += (double)a.statp_q[((size_t)t * 4 + k) * FB_NSTAT];
             s9[4 + k] += (double)a.statp_din[((size_t)t * 4 + k) * FB_NSTAT];
         }
-        s9[8] += (double)a.statp_pi[(size_t)t * FB_NSTAT];
     }
+    for (int t = lane; t < a.n_tiles_pi; t += 64) s9[8] += (double)a.statp_pi[(size_t)t * FB_NSTAT];
     float m9[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) m9[k] = (float)(wave_sum_d(s9[k]) / (double)a.B);
