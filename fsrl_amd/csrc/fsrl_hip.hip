@@ -1860,7 +1860,8 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     // ---- target: a', log pi' at s_{t+n}; target Q-nets; float64 n-step return
     auto actor_launch = [&](const float* obs, const float* eps, float* X, float* lp, int mode) {
         SacActorArgs aa{};
-        aa.obs = obs; aa.eps = eps; aa.X = X; aa.lp_out = lp; aa.DA = s->DA; aa.sc = s->sc; aa.A1 = s->A1; aa.A2 = s->A2;
+        aa.obs = obs; aa.eps = eps; aa.X = X; aa.lp_out = lp; aa.DA = s->DA; aa.QP = s->QP; aa.sc = s->sc; aa.A1 = s->A1; aa.A2 = s->A2;
+        aa.cr = -resc; aa.cc = s->cfg.use_lagrangian ? resc * lam : 0.0f;
         aa.D1 = s->D1; aa.D2 = s->D2; aa.DO = s->DO; aa.statp = s->stpi; aa.B = B; aa.mode = mode; aa.rescale = resc;
         aa.auto_alpha = s->cfg.auto_alpha; aa.alpha_fixed = s->cfg.alpha;
         return dispatch_H(c->cfg.hidden, [&](auto hc) {
@@ -1892,9 +1893,7 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     // ---- actor step: a ~ pi(s), Q(s, a) with the UPDATED critics, dL/da, actor backward
     rc = actor_launch(s->OBS, s->eps_p, s->XP, s->LP, SAC_A_FWD);
     if (rc) return rc;
-    rc = sac_q_launch(c, s, s->PQ, s->XP, FB_MODE_Q_FWD, 0.f, 0.f, s->stdin_, B);
-    if (rc) return rc;
-    rc = sac_q_launch(c, s, s->PQ, s->XP, FB_MODE_Q_DIN, -resc, s->cfg.use_lagrangian ? resc * lam : 0.0f, s->stdin_, B);
+    rc = sac_q_launch(c, s, s->PQ, s->XP, FB_MODE_Q_DIN, 0.f, 0.f, s->stdin_, B);   // Q values + unit-seed dQ/da
     if (rc) return rc;
     rc = actor_launch(s->OBS, s->eps_p, s->XP, s->LP, SAC_A_BWD);
     if (rc) return rc;
@@ -1905,7 +1904,7 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     // ---- alpha step + logged stats, then Polyak
     SacFinalArgs fa{};
     float* stats_row = s->d_stats + (size_t)(s->n_updates % SAC_RING) * FSRL_SAC_NSTATS_K;
-    fa.statp_q = s->stq; fa.statp_din = s->stdin_; fa.statp_pi = s->stpi; fa.sc = s->sc; fa.stats = stats_row;
+    fa.statp_q = s->stq; fa.statp_pi = s->stpi; fa.sc = s->sc; fa.stats = stats_row;
     fa.n_tiles_q = s->q_rows4 ? 4 * s->n_tiles : s->n_tiles; fa.n_tiles_pi = s->a_rows4 ? 4 * s->n_tiles : s->n_tiles; fa.B = B; fa.rescale = resc; fa.lam = lam; fa.target_entropy = s->cfg.target_entropy;
     fa.alpha_lr = s->cfg.alpha_lr; fa.beta1 = c->cfg.beta1; fa.beta2 = c->cfg.beta2; fa.adam_eps = c->cfg.adam_eps;
     fa.alpha_fixed = s->cfg.alpha; fa.auto_alpha = s->cfg.auto_alpha; fa.use_lagrangian = s->cfg.use_lagrangian;

@@ -219,11 +219,10 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
                     a.qout[(size_t)net * a.N + r] = qv;
                 } else if (a.mode == FB_MODE_Q_FWD) {
                     a.qout[(size_t)net * a.N + r] = qv;
-                } else {   // Q_DIN: d min(Q1,Q2)/dQ_this with torch's tie rule, times the loss scale
-                    const float mine = a.qin[(size_t)net * a.N + r], other = a.qin[(size_t)(net ^ 1) * a.N + r];
-                    const float w = (mine < other) ? 1.0f : (mine == other ? 0.5f : 0.0f);
-                    sm.dout[i * FSRL_DOW] = w * ((net >> 1) == 0 ? a.cr : a.cc) * invN;
-                    st[0] = fminf(mine, other);
+                } else {   // Q_DIN: dQ/dx with a unit seed; the consumer (sac_actor_tile_kernel BWD) routes
+                           // min(Q1,Q2) with torch's tie rule and applies the loss scale (backward is linear)
+                    sm.dout[i * FSRL_DOW] = 1.0f;
+                    a.qout[(size_t)net * a.N + r] = qv;
                 }
             }
         } else {

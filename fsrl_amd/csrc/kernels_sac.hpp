@@ -113,7 +113,9 @@ struct SacActorArgs {
     const float* eps;    // [B][Da] standard-normal draws (rsample)
     float* X;            // [B][Do+Da]: action columns written in FWD
     float* lp_out;       // [B]
-    const float* DA;     // [4][B][Da] dL/da from the Q-nets (BWD)
+    const float* DA;     // [4][B][Da] dQ_n/da of the four Q-nets, unit seed (BWD)
+    const float* QP;     // [4][B] Q_n(s, a_pi): min routing + the logged min-Q sums (BWD)
+    float cr, cc;        // loss weights of min(Qr1,Qr2) and min(Qc1,Qc2): -rescale, rescale*lambda
     const SacScalars* sc;
     float* A1; float* A2; float* D1; float* D2; float* DO;   // side buffers (BWD)
     float* statp;        // [n_tiles][FB_NSTAT]  st[0] = sum log pi
@@ -179,22 +181,37 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
             if (valid && d < Da) a.X[(size_t)r * (Do + Da) + Do + d] = act;
             if (valid && d == 0) a.lp_out[r] = logp;
         } else if (valid && d < Da) {
-            float ga = 0.0f;   // dL/da_d summed over the four Q-nets (already scaled)
+            // dL/da_d = sum over the two double critics of weight * d min(Q1,Q2)/da_d / B ; torch's
+            // tie rule for min: the smaller one gets the gradient, equal values share it
+            float ga = 0.0f;
 #pragma unroll
-            for (int n4 = 0; n4 < 4; ++n4) ga += a.DA[((size_t)n4 * a.B + r) * Da + d];
+            for (int pr = 0; pr < 2; ++pr) {
+                const float q1 = a.QP[(size_t)(2 * pr) * a.B + r], q2 = a.QP[(size_t)(2 * pr + 1) * a.B + r];
+                const float w1 = (q1 < q2) ? 1.0f : (q1 == q2 ? 0.5f : 0.0f), w2 = 1.0f - w1;
+                const float cw = (pr == 0 ? a.cr : a.cc) * invB;
+                ga += (w1 * cw) * a.DA[((size_t)(2 * pr) * a.B + r) * Da + d];
+                ga += (w2 * cw) * a.DA[((size_t)(2 * pr + 1) * a.B + r) * Da + d];
+            }
             const float c = a.rescale * alpha * invB;                 // weight of log pi in the loss
             const float sq = 2.0f * act * one_m / (one_m + SAC_F32_EPS);   // d(-log(1-a^2+eps))/du
             const float dLdu = c * sq + ga * one_m;                   // (+-(u-mu)/sigma^2 cancel)
             sm.dout[i * FSRL_DOW + d] = dLdu;                         // d/dmu
             sm.dout[i * FSRL_DOW + Da + d] = (dLdu * ep * sig - c) * pass;   // d/d(raw log sigma)
         }
-        if (d == 0) sm.w1[i * FB_NSTAT] = valid ? logp : 0.0f;
+        if (d == 0) {
+            sm.w1[i * FB_NSTAT] = valid ? logp : 0.0f;
+            if (a.mode == SAC_A_BWD) {       // logged actor losses: sums of min(Q1,Q2) per double critic
+                sm.w1[i * FB_NSTAT + 1] = valid ? fminf(a.QP[r], a.QP[(size_t)a.B + r]) : 0.0f;
+                sm.w1[i * FB_NSTAT + 2] = valid ? fminf(a.QP[(size_t)2 * a.B + r], a.QP[(size_t)3 * a.B + r]) : 0.0f;
+            }
+        }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < 3) {
         float t = 0.0f;
-        for (int i = 0; i < R; ++i) t += sm.w1[i * FB_NSTAT];
-        a.statp[(size_t)blockIdx.x * FB_NSTAT] = t;
+        if (tid == 0 || a.mode == SAC_A_BWD)
+            for (int i = 0; i < R; ++i) t += sm.w1[i * FB_NSTAT + tid];
+        a.statp[(size_t)blockIdx.x * FB_NSTAT + tid] = t;
     }
     if (a.mode != SAC_A_BWD) return;
     tile_backward<H, R>(sm, no, wb, a.A1 + (size_t)row0 * H, a.A2 + (size_t)row0 * H, a.D1 + (size_t)row0 * H,
@@ -245,8 +262,7 @@ __global__ void sac_nstep_kernel(const SacNstepArgs a) {
 // ---- scalar bookkeeping of one update: logged stats, alpha loss + Adam on log_alpha
 struct SacFinalArgs {
     const float* statp_q;    // [n_tiles][4][FB_NSTAT]   st0 = sum td^2            (critic launch)
-    const float* statp_din;  // [n_tiles][4][FB_NSTAT]   st0 = sum min(Q1,Q2)      (actor-step Q launch)
-    const float* statp_pi;   // [n_tiles][FB_NSTAT]      st0 = sum log pi
+    const float* statp_pi;   // [n_tiles][FB_NSTAT]      st0 = sum log pi, st1 / st2 = sum min(Q1,Q2) reward / cost
     SacScalars* sc;
     float* stats;            // [FSRL_SAC_NSTATS_K]
     int n_tiles_q, n_tiles_pi, B;
@@ -262,12 +278,13 @@ __global__ __launch_bounds__(64) void sac_finalize_kernel(const SacFinalArgs a) 
     for (int k = 0; k < 9; ++k) s9[k] = 0.0;
     for (int t = lane; t < a.n_tiles_q; t += 64) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            s9[k] += (double)a.statp_q[((size_t)t * 4 + k) * FB_NSTAT];
-            s9[4 + k] += (double)a.statp_din[((size_t)t * 4 + k) * FB_NSTAT];
-        }
+        for (int k = 0; k < 4; ++k) s9[k] += (double)a.statp_q[((size_t)t * 4 + k) * FB_NSTAT];
     }
-    for (int t = lane; t < a.n_tiles_pi; t += 64) s9[8] += (double)a.statp_pi[(size_t)t * FB_NSTAT];
+    for (int t = lane; t < a.n_tiles_pi; t += 64) {
+        s9[8] += (double)a.statp_pi[(size_t)t * FB_NSTAT];
+        s9[4] += (double)a.statp_pi[(size_t)t * FB_NSTAT + 1];     // sum min(Qr1, Qr2)
+        s9[6] += (double)a.statp_pi[(size_t)t * FB_NSTAT + 2];     // sum min(Qc1, Qc2)
+    }
     float m9[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) m9[k] = (float)(wave_sum_d(s9[k]) / (double)a.B);
