@@ -102,7 +102,7 @@ def cpu_baseline(theta, inputs, seconds=12.0):
                       f"torch CPU fp32, {threads} threads of {os.cpu_count()} host cpus"}
 
 
-def end_to_end(local_rank, seed, seconds=6.0):
+def end_to_end(local_rank, seed, seconds=6.0, device_actor=False):
     """Secondary figure (outside the timed region): the whole training loop of
     OnpolicyAgent.learn -- host collector over a SYNTHETIC SafetyCarCircle-shaped vector env
     (20 envs, 300-step episodes, 20 episodes per collect) feeding the HIP-resident store, one
@@ -116,7 +116,7 @@ def end_to_end(local_rank, seed, seconds=6.0):
                         max_grad_norm=0.5, training_num=ENVS)
     agent.policy.train()
     buf = HipVectorReplayBuffer(agent.policy.engine, 100000, ENVS)
-    col = FastCollector(agent.policy, env, buf, exploration_noise=True)
+    col = FastCollector(agent.policy, env, buf, exploration_noise=True, device_actor=device_actor)
     tr = OnpolicyTrainer(agent.policy, col, None, max_epoch=10**6, batch_size=BATCH, cost_limit=10,
                          step_per_epoch=6000, repeat_per_collect=REPEAT, episode_per_collect=20,
                          verbose=False)
@@ -131,6 +131,7 @@ def end_to_end(local_rank, seed, seconds=6.0):
         collects += 1
     dt = time.perf_counter() - t0
     out = {"env": "synthetic SafetyCarCircle-shaped vector env (not PyBullet)", "envs": ENVS,
+           "actor": "device (fsrl_actor_sample, library RNG)" if device_actor else "host mirror (torch CPU, torch RNG)",
            "collects": collects, "env_steps_per_s": col.collect_step / dt,
            "collector_only_env_steps_per_s": col.collect_step / col.collect_time,
            "update_ms_per_collect": tr.update_time / collects * 1e3,
@@ -260,7 +261,8 @@ def main():
         if pmc is not None:
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
-            out["end_to_end"] = end_to_end(local_rank, seed)
+            out["end_to_end"] = end_to_end(local_rank, seed, device_actor=True)
+            out["end_to_end_host_actor"] = end_to_end(local_rank, seed, seconds=4.0, device_actor=False)
             out["cpu_baseline"] = cpu_baseline(theta, inputs)
             out["speedup_vs_cpu_port"] = out["value"] / world / out["cpu_baseline"]["value"]
         print(json.dumps(out))

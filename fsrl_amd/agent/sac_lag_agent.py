@@ -25,13 +25,14 @@ class OffpolicyAgent(BaseAgent):
               step_per_epoch: int = 3000, update_per_step: float = 0.1, buffer_size: int = 100000,
               testing_num: int = 2, batch_size: int = 256, reward_threshold: float = 450,
               save_interval: int = 4, resume: bool = False, save_ckpt: bool = True, verbose: bool = True,
-              show_progress: bool = True):
+              show_progress: bool = True, device_actor: bool = False):
         assert self.policy is not None, "The policy is not initialized"
         self.policy.train()
         eng = self.policy.engine
         assert eng.cfg.env_num >= len(train_envs)
         buffer = HipVectorReplayBuffer(eng, buffer_size, len(train_envs))
-        train_collector = FastCollector(self.policy, train_envs, buffer, exploration_noise=True)
+        train_collector = FastCollector(self.policy, train_envs, buffer, exploration_noise=True,
+                                        device_actor=device_actor)   # True: actor + noise on the MI355X
         test_collector = FastCollector(self.policy, test_envs) if test_envs is not None else None
 
         def stop_fn(reward, cost):

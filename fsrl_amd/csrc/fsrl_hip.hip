@@ -575,13 +575,53 @@ extern "C" int fsrl_actor_forward(fsrl_ctx* c, const float* obs, int32_t k, floa
         rc = launch_infer(c, ia, 1, c->compute);   // job 0 == 2*C == actor
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(mu_out, d_mu, mb, hipMemcpyDeviceToHost, c->compute));
-        HIPCHK(hipStreamSynchronize(c->compute));
     }
+    float sp[FSRL_MAX_ACT];
+    if (sigma_out)   // same stream, one synchronisation for both copies
+        HIPCHK(hipMemcpyAsync(sp, c->P + c->md.net[0].sigma, (size_t)Da * 4, hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
     if (sigma_out) {
-        std::vector<float> sp((size_t)Da);
-        HIPCHK(hipMemcpy(sp.data(), c->P + c->md.net[0].sigma, (size_t)Da * 4, hipMemcpyDeviceToHost));
         for (int r = 0; r < k; ++r)
             for (int d = 0; d < Da; ++d) sigma_out[(size_t)r * Da + d] = expf(sp[d]);
+    }
+    return 0;
+}
+
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static uint64_t xoshiro_next(uint64_t* s) {
+    const uint64_t result = rotl64(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl64(s[3], 45);
+    return result;
+}
+
+// Collector-time action sampling (fsrl/data/fast_collector.py:283-300: policy.forward -> dist.sample()):
+// the actor runs on the device, the k x Da Gaussian draws come from the library's xoshiro256** stream.
+//   PPO / CPO / TRPO contexts: a = mu + exp(sigma_param) * eps          (ppo_lag / cpo forward: Independent(Normal))
+//   SAC contexts:              a = tanh(mu + sigma(s) * eps)             (sac_lag.py:155-183)
+// deterministic != 0 returns the mean (tanh(mean) for SAC).  Noise is NOT torch's stream: callers that
+// need the reference's random numbers keep the host mirror of the actor (fsrl_amd/policy).
+static int sac_actor_mu_sigma(fsrl_ctx* c, const float* obs, int32_t k, float* mu_out, float* sigma_out);
+extern "C" int fsrl_actor_sample(fsrl_ctx* c, const float* obs, int32_t k, int32_t deterministic, uint64_t seed,
+                                 float* act_out) {
+    CHECK_ARG(c && obs && act_out, "null argument");
+    CHECK_ARG(k >= 0, "negative row count");
+    if (k == 0) return 0;
+    const int Da = c->cfg.act_dim;
+    if (seed) { c->rng[2] ^= seed; c->rng[3] += seed * 0x9E3779B97F4A7C15ull; }
+    std::vector<float> mu((size_t)k * Da), sg((size_t)k * Da);
+    const bool sac = c->cfg.algo == FSRL_ALGO_SAC_LAG;
+    int rc = sac ? sac_actor_mu_sigma(c, obs, k, mu.data(), sg.data()) : fsrl_actor_forward(c, obs, k, mu.data(), sg.data());
+    if (rc) return rc;
+    for (size_t i = 0; i < mu.size(); ++i) {
+        float u = mu[i];
+        if (!deterministic) {
+            // Box-Muller on two 53-bit uniforms of the context's stream
+            double u1 = (double)(xoshiro_next(c->rng) >> 11) * (1.0 / 9007199254740992.0);
+            const double u2 = (double)(xoshiro_next(c->rng) >> 11) * (1.0 / 9007199254740992.0);
+            if (u1 < 1e-300) u1 = 1e-300;
+            u += sg[i] * (float)(std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2));
+        }
+        act_out[i] = sac ? std::tanh(u) : u;
     }
     return 0;
 }
@@ -747,12 +787,6 @@ extern "C" int fsrl_ppo_begin(fsrl_ctx* c, const double* lagrangians, double res
     return 0;
 }
 
-static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-static uint64_t xoshiro_next(uint64_t* s) {
-    const uint64_t result = rotl64(s[1] * 5, 7) * 9, t = s[1] << 17;
-    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl64(s[3], 45);
-    return result;
-}
 
 static int ensure_stats(fsrl_ctx* c, int64_t steps) {
     if (steps <= c->stats_cap) return 0;
@@ -1996,4 +2030,8 @@ extern "C" int fsrl_sac_actor_forward(fsrl_ctx* c, const float* obs, int32_t k, 
             sigma_out[(size_t)r * Da + d] = std::exp(l);
         }
     return 0;
+}
+
+static int sac_actor_mu_sigma(fsrl_ctx* c, const float* obs, int32_t k, float* mu_out, float* sigma_out) {
+    return fsrl_sac_actor_forward(c, obs, k, mu_out, sigma_out);
 }

@@ -29,6 +29,11 @@ class HipVectorReplayBuffer:
         return self.engine.push(ids, batch.obs, batch.act, batch.rew, cost, batch.terminated,
                                 batch.truncated, batch.obs_next)
 
+    def note_add(self, buffer_ids) -> None:
+        """Bookkeeping for rows pushed directly through the engine (FastCollector device_actor path)."""
+        for e in buffer_ids:
+            self._sizes[e] = min(self._sizes[e] + 1, self._sub)
+
     def reset(self, keep_statistics: bool = False) -> None:
         self._sizes[:] = 0
         self.engine.reset_store(keep_statistics)

@@ -15,7 +15,12 @@ from fsrl_amd.data.batch import Batch
 
 
 class FastCollector:
-    def __init__(self, policy, env, buffer=None, preprocess_fn=None, exploration_noise: bool = False):
+    def __init__(self, policy, env, buffer=None, preprocess_fn=None, exploration_noise: bool = False,
+                 device_actor: bool = False):
+        # device_actor=True: actions come from fsrl_actor_sample (actor on the MI355X, library RNG) and rows go
+        # straight to fsrl_store_push -- no torch call and no Batch objects per vector step.  False keeps the
+        # host mirror of the actor with torch's random stream (what the reference consumes).
+        self.device_actor = device_actor and getattr(policy, "engine", None) is not None
         self.env = env
         self.env_num = len(env)
         self.policy = policy
@@ -57,9 +62,14 @@ class FastCollector:
         step_count, total_cost, episode_count = 0, 0.0, 0
         term_count, trunc_count = 0, 0
         ep_rews, ep_lens = [], []
+        eng = self.policy.engine if self.device_actor else None
+        if eng is not None and hasattr(self.policy, "_drain"):
+            self.policy._drain()
         while True:
-            data = Batch(obs=obs, info={})
-            if random:
+            data = None if eng is not None and not random else Batch(obs=obs, info={})
+            if eng is not None and not random:
+                act = eng.actor_sample(obs, deterministic=self.policy._deterministic_eval and not self.policy.training)
+            elif random:
                 act = np.stack([self._action_space.sample() for _ in ready])
                 act = self.policy.map_action_inverse(act)
             else:
@@ -75,7 +85,10 @@ class FastCollector:
                 else np.array([i.get("cost", 0.0) for i in info], np.float64)
             total_cost += float(cost.sum())
             step_count += len(ready)
-            if self.buffer is not None:
+            if self.buffer is not None and eng is not None:
+                ptr, ep_rew, ep_len, ep_idx = eng.push(ready, obs, act, rew, cost, terminated, truncated, obs_next)
+                self.buffer.note_add(ready)
+            elif self.buffer is not None:
                 ptr, ep_rew, ep_len, ep_idx = self.buffer.add(
                     Batch(obs=obs, act=act, rew=np.asarray(rew, np.float64), cost=cost,
                           terminated=terminated, truncated=truncated, obs_next=obs_next), buffer_ids=ready)

@@ -142,6 +142,14 @@ class Engine:
                                                _ptr(sigma, _f32p)))
         return mu, sigma
 
+    def actor_sample(self, obs, deterministic=False, seed=0):
+        """Collector-time actions a ~ pi(.|obs): actor on the device, noise from the library RNG."""
+        obs = np.ascontiguousarray(obs, np.float32).reshape(-1, self.cfg.obs_dim)
+        act = np.empty((obs.shape[0], self.cfg.act_dim), np.float32)
+        _lib.check(self.lib.fsrl_actor_sample(self._ctx, _ptr(obs, _f32p), obs.shape[0], int(deterministic), int(seed),
+                                              _ptr(act, _f32p)))
+        return act
+
     # ---------------------------------------------------------------- PPO-Lagrangian
     def ppo_begin(self, lagrangians: Sequence[float], rescaling: float, batch_size: int) -> int:
         lag = np.ascontiguousarray(lagrangians, np.float64).reshape(-1)

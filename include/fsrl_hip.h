@@ -108,6 +108,13 @@ int fsrl_store_sample0(fsrl_ctx* ctx, int64_t* indices_out, int64_t cap, int64_t
  *      fsrl/policy/base_policy.py:178-190; sampling stays on the host RNG) ------------ */
 int fsrl_actor_forward(fsrl_ctx* ctx, const float* obs, int32_t k, float* mu_out,
                        float* sigma_out);
+/* Collector-time sampling (fsrl/data/fast_collector.py:283-300 -> policy.forward -> dist.sample()): actor on
+ * the device, k x act_dim draws from the library RNG (seed != 0 re-keys it).  On-policy contexts:
+ * a = mu + exp(sigma_param) * eps; SAC contexts: a = tanh(mu + sigma(s) * eps).  deterministic != 0: the
+ * mean.  act_out[k][act_dim] is the raw policy output (what the buffer stores; map_action stays with the
+ * caller).  Not torch's random stream -- the host mirror of the actor remains for stream-exact runs.   */
+int fsrl_actor_sample(fsrl_ctx* ctx, const float* obs, int32_t k, int32_t deterministic, uint64_t seed,
+                      float* act_out);
 
 /* ---- PPO-Lagrangian update = BasePolicy.update (base_policy.py:332-355) -------------- */
 /* begin: buffer.sample(0) + PPOLagrangian.process_fn (ppo_lag.py:134-150): gathers the

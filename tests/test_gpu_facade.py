@@ -183,3 +183,32 @@ def test_sac_agent_learns_end_to_end(tmp_path):
     assert ep == 2 and np.isfinite(list(stat.values())).all() and "loss/q_total" in stat and "loss/alpha_value" in stat
     a1, alpha = agent.policy.engine.sac_get_params(0)
     assert np.abs(a1 - a0).max() > 1e-4 and 0 < alpha < 1.0
+
+
+def test_device_actor_sampling_statistics_and_collector_path(tmp_path):
+    """fsrl_actor_sample: deterministic == the actor mean; stochastic draws have the policy's mean and
+    sigma; the collector's device_actor path trains end to end with it."""
+    from fsrl_amd.agent import PPOLagAgent, SACLagAgent
+    from fsrl_amd.env import SyntheticSafetyVectorEnv
+    from fsrl_amd.utils import BaseLogger
+    env = SyntheticSafetyVectorEnv(env_num=4, episode_len=30, seed=2)
+    agent = PPOLagAgent(env, BaseLogger(str(tmp_path), name="d"), cost_limit=10, device="cuda:0", seed=1,
+                        hidden_sizes=(64, 64), training_num=4)
+    eng = agent.policy.engine
+    obs = np.random.default_rng(0).standard_normal((3, eng.cfg.obs_dim)).astype(np.float32)
+    mu, sigma = eng.actor_forward(obs)
+    assert np.array_equal(eng.actor_sample(obs, deterministic=True), mu)
+    draws = np.stack([eng.actor_sample(obs, seed=7 if i == 0 else 0) for i in range(2000)])
+    n = draws.shape[0]
+    assert np.abs(draws.mean(0) - mu).max() < 5 * sigma.max() / np.sqrt(n)
+    assert np.abs(draws.std(0) / sigma - 1).max() < 0.1
+    ep, stat, info = agent.learn(env, None, epoch=2, episode_per_collect=4, step_per_epoch=240, repeat_per_collect=2,
+                                 batch_size=64, verbose=False, save_ckpt=False, device_actor=True)
+    assert ep == 2 and np.isfinite(list(stat.values())).all()
+    sac = SACLagAgent(env, BaseLogger(str(tmp_path), name="e"), cost_limit=10, device="cuda:0", seed=1,
+                      hidden_sizes=(64, 64), training_num=4, buffer_size=2000)
+    a = sac.policy.engine.actor_sample(obs)
+    assert a.shape == (3, sac.policy.engine.cfg.act_dim) and (np.abs(a) < 1).all()
+    ep, stat, info = sac.learn(env, None, epoch=1, episode_per_collect=4, step_per_epoch=240, update_per_step=0.2,
+                               batch_size=32, verbose=False, save_ckpt=False, device_actor=True)
+    assert ep == 1 and np.isfinite(list(stat.values())).all()
