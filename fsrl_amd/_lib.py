@@ -33,7 +33,8 @@ class SacConfig(C.Structure):
     """struct fsrl_sac_config (include/fsrl_hip.h)"""
     _fields_ = [("actor_lr", C.c_float), ("critic_lr", C.c_float), ("alpha_lr", C.c_float), ("tau", C.c_float),
                 ("alpha", C.c_float), ("target_entropy", C.c_float), ("n_step", C.c_int32),
-                ("auto_alpha", C.c_int32), ("use_lagrangian", C.c_int32)]
+                ("auto_alpha", C.c_int32), ("use_lagrangian", C.c_int32), ("deterministic", C.c_int32),
+                ("exploration_sigma", C.c_float)]
 
 
 CPO_NSTATS, TRPO_NSTATS, SAC_NSTATS = 17, 11, 10

@@ -601,6 +601,7 @@ static uint64_t xoshiro_next(uint64_t* s) {
 // deterministic != 0 returns the mean (tanh(mean) for SAC).  Noise is NOT torch's stream: callers that
 // need the reference's random numbers keep the host mirror of the actor (fsrl_amd/policy).
 static int sac_actor_mu_sigma(fsrl_ctx* c, const float* obs, int32_t k, float* mu_out, float* sigma_out);
+static bool sac_squashes(fsrl_ctx* c);
 extern "C" int fsrl_actor_sample(fsrl_ctx* c, const float* obs, int32_t k, int32_t deterministic, uint64_t seed,
                                  float* act_out) {
     CHECK_ARG(c && obs && act_out, "null argument");
@@ -621,7 +622,7 @@ extern "C" int fsrl_actor_sample(fsrl_ctx* c, const float* obs, int32_t k, int32
             if (u1 < 1e-300) u1 = 1e-300;
             u += sg[i] * (float)(std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2));
         }
-        act_out[i] = sac ? std::tanh(u) : u;
+        act_out[i] = (sac && sac_squashes(c)) ? std::tanh(u) : u;     // DDPG-Lag: mu is already max_action * tanh
     }
     return 0;
 }
@@ -1548,6 +1549,9 @@ struct SacState {
     int na_api = 0, nq_api = 0, na_dev = 0, nq_dev = 0;
     float *PA = nullptr, *MA = nullptr, *VA = nullptr, *GA = nullptr;
     float *PQ = nullptr, *PQT = nullptr, *MQ = nullptr, *VQ = nullptr, *GQ = nullptr;
+    float* PAT = nullptr;                      // target actor (DDPG-Lag mode only)
+    int n_q = 4;                               // Q-networks: 4 (two double critics) or 2 (DDPG-Lag)
+    bool ddpg = false;
     SacScalars* sc = nullptr;
     int64_t t_actor = 0, t_critic = 0;
     // per-batch buffers
@@ -1582,22 +1586,24 @@ static void sac_layout(fsrl_ctx* c, SacState* s) {
         NetOff& no = md.net[0];
         no.sigma = -1; no.out = 2 * Da; no.begin = 0;
         no.W1 = place(H * Do); no.b1 = place(H); no.W2 = place(H * H); no.b2 = place(H);
-        no.W3 = place(2 * Da * H); no.b3 = place(2 * Da);
+        const int heads = s->ddpg ? 1 : 2;                        // DDPG-Lag: the mean head only
+        no.out = heads * Da;
+        no.W3 = place(heads * Da * H); no.b3 = place(heads * Da);
         no.end = dev;
         auto add = [&](int dev_off, int n) { s->tmap_a.push_back(TensorMap{api, dev_off, n}); api += n; };
         add(no.W1, H * Do); add(no.b1, H); add(no.W2, H * H); add(no.b2, H);
         add(no.W3, Da * H); add(no.b3, Da);                       // mu head
-        add(no.W3 + Da * H, Da * H); add(no.b3 + Da, Da);         // sigma head
+        if (!s->ddpg) { add(no.W3 + Da * H, Da * H); add(no.b3 + Da, Da); }   // sigma head
         s->na_api = api; s->na_dev = round_up(dev, 1024);
         no.W2f = s->na_dev;                                       // forward-fragment mirror behind the main vector
     }
     // ---- four Q-nets: device order Qr1, Qr2, Qc1, Qc2 ; API order per DoubleCritic: pre1 pre2 last1 last2
     {
         ModelDesc& md = s->mdq;
-        md.Do = Din; md.Da = Da; md.H = H; md.n_nets = 4;
+        md.Do = Din; md.Da = Da; md.H = H; md.n_nets = s->n_q;
         int dev = 0;
         auto place = [&](int n) { int o = dev; dev = round_up(dev + n, 64); return o; };
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < s->n_q; ++n) {
             NetOff& no = md.net[n];
             no.sigma = -1; no.out = 1; no.begin = dev;
             no.W1 = place(H * Din); no.b1 = place(H); no.W2 = place(H * H); no.b2 = place(H);
@@ -1606,22 +1612,27 @@ static void sac_layout(fsrl_ctx* c, SacState* s) {
         }
         int api = 0;
         auto add = [&](int dev_off, int n) { s->tmap_q.push_back(TensorMap{api, dev_off, n}); api += n; };
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2 && !s->ddpg; ++i) {
             for (int j = 0; j < 2; ++j) {
                 const NetOff& no = md.net[2 * i + j];
                 add(no.W1, H * Din); add(no.b1, H); add(no.W2, H * H); add(no.b2, H);
             }
             for (int j = 0; j < 2; ++j) { const NetOff& no = md.net[2 * i + j]; add(no.W3, H); add(no.b3, 1); }
         }
+        for (int i = 0; i < 2 && s->ddpg; ++i) {       // tianshou Critic: preprocess MLP then the last layer
+            const NetOff& no = md.net[i];
+            add(no.W1, H * Din); add(no.b1, H); add(no.W2, H * H); add(no.b2, H); add(no.W3, H); add(no.b3, 1);
+        }
         s->nq_api = api; s->nq_dev = round_up(dev, 1024);
-        for (int n = 0; n < 4; ++n) md.net[n].W2f = s->nq_dev + n * H * H;
+        for (int n = 0; n < s->n_q; ++n) md.net[n].W2f = s->nq_dev + n * H * H;
     }
 }
 
 extern "C" int fsrl_sac_init(fsrl_ctx* c, const fsrl_sac_config* cfg) {
     CHECK_ARG(c && cfg, "null argument");
     CHECK_ARG(c->cfg.algo == FSRL_ALGO_SAC_LAG, "context was not created with FSRL_ALGO_SAC_LAG");
-    CHECK_ARG(c->cfg.act_dim <= 8, "SAC actor needs 2*act_dim <= 16 head outputs");
+    CHECK_ARG(cfg->deterministic ? c->cfg.act_dim <= 16 : c->cfg.act_dim <= 8,
+              "the actor head has at most 16 outputs (act_dim <= 8 for SAC, <= 16 for DDPG)");
     CHECK_ARG(c->cfg.obs_dim + c->cfg.act_dim <= FSRL_MAX_OBS, "obs_dim + act_dim too large");
     CHECK_ARG(cfg->n_step >= 1 && cfg->n_step <= 8, "n_step must be in [1, 8]");
     CHECK_ARG(cfg->tau >= 0.0f && cfg->tau <= 1.0f, "tau should be in [0, 1]");
@@ -1630,10 +1641,13 @@ extern "C" int fsrl_sac_init(fsrl_ctx* c, const fsrl_sac_config* cfg) {
     SacState* s = new SacState();
     c->sac = s;
     s->cfg = *cfg;
+    s->ddpg = cfg->deterministic != 0;
+    s->n_q = s->ddpg ? 2 : 4;
+    if (s->ddpg) { s->cfg.auto_alpha = 0; s->cfg.alpha = 0.0f; }      // no entropy term anywhere
     sac_layout(c, s);
     const size_t HH = (size_t)c->cfg.hidden * c->cfg.hidden;
     const size_t ab = ((size_t)s->na_dev + HH) * 4, qb = ((size_t)s->nq_dev + 4 * HH) * 4;   // + W2 mirrors (used in P only)
-    for (float** p : {&s->PA, &s->MA, &s->VA, &s->GA}) { HIPCHK(hipMalloc(p, ab)); HIPCHK(hipMemsetAsync(*p, 0, ab, c->compute)); }
+    for (float** p : {&s->PA, &s->MA, &s->VA, &s->GA, &s->PAT}) { HIPCHK(hipMalloc(p, ab)); HIPCHK(hipMemsetAsync(*p, 0, ab, c->compute)); }
     for (float** p : {&s->PQ, &s->PQT, &s->MQ, &s->VQ, &s->GQ}) { HIPCHK(hipMalloc(p, qb)); HIPCHK(hipMemsetAsync(*p, 0, qb, c->compute)); }
     HIPCHK(hipStreamSynchronize(c->compute));
     HIPCHK(hipMalloc(&s->sc, sizeof(SacScalars)));
@@ -1648,7 +1662,7 @@ extern "C" int fsrl_sac_init(fsrl_ctx* c, const fsrl_sac_config* cfg) {
 static void sac_free(fsrl_ctx* c) {
     SacState* s = sac_of(c);
     if (!s) return;
-    for (void* p : {(void*)s->PA, (void*)s->MA, (void*)s->VA, (void*)s->GA, (void*)s->PQ, (void*)s->PQT, (void*)s->MQ,
+    for (void* p : {(void*)s->PAT, (void*)s->PA, (void*)s->MA, (void*)s->VA, (void*)s->GA, (void*)s->PQ, (void*)s->PQT, (void*)s->MQ,
                     (void*)s->VQ, (void*)s->GQ, (void*)s->sc, (void*)s->d_idx, (void*)s->d_chain, (void*)s->d_end,
                     (void*)s->XQ, (void*)s->OBS, (void*)s->OBSN, (void*)s->XN, (void*)s->XP, (void*)s->eps_t,
                     (void*)s->eps_p, (void*)s->LPN, (void*)s->LP, (void*)s->QT, (void*)s->QP, (void*)s->Y,
@@ -1696,6 +1710,8 @@ extern "C" int fsrl_sac_params_set(fsrl_ctx* c, const float* actor, int64_t na, 
     if (rc) return rc;
     HIPCHK(hipMemcpy(s->PQT, s->PQ, ((size_t)s->nq_dev + 4 * (size_t)c->cfg.hidden * c->cfg.hidden) * 4,
                      hipMemcpyDeviceToDevice));   // critics_old = deepcopy (with the W2 mirrors)
+    HIPCHK(hipMemcpy(s->PAT, s->PA, ((size_t)s->na_dev + (size_t)c->cfg.hidden * c->cfg.hidden) * 4,
+                     hipMemcpyDeviceToDevice));   // actor_old = deepcopy (DDPG-Lag)
     for (float* p : {s->MA, s->VA}) HIPCHK(hipMemsetAsync(p, 0, (size_t)s->na_dev * 4, c->compute));
     for (float* p : {s->MQ, s->VQ}) HIPCHK(hipMemsetAsync(p, 0, (size_t)s->nq_dev * 4, c->compute));
     HIPCHK(hipStreamSynchronize(c->compute));
@@ -1711,7 +1727,10 @@ extern "C" int fsrl_sac_params_get(fsrl_ctx* c, int32_t which, float* out, int64
     if (!s) return fail(FSRL_ESTATE, "fsrl_sac_init first");
     HIPCHK(hipSetDevice(c->device));
     int rc;
-    if (which == 0) { CHECK_ARG(n == s->na_api, "bad size"); rc = sac_copy(c, s->tmap_a, s->mda, s->na_dev, s->PA, nullptr, out); }
+    if (which == 0 || which == 3) {
+        CHECK_ARG(n == s->na_api, "bad size");
+        rc = sac_copy(c, s->tmap_a, s->mda, s->na_dev, which == 0 ? s->PA : s->PAT, nullptr, out);
+    }
     else { CHECK_ARG(n == s->nq_api, "bad size"); rc = sac_copy(c, s->tmap_q, s->mdq, s->nq_dev, which == 1 ? s->PQ : s->PQT, nullptr, out); }
     if (rc) return rc;
     if (alpha_out) {
@@ -1724,7 +1743,7 @@ extern "C" int fsrl_sac_params_get(fsrl_ctx* c, int32_t which, float* out, int64
 
 static int sac_alloc_batch(fsrl_ctx* c, SacState* s, int B) {
     s->n_tiles = (B + 15) / 16;
-    s->q_rows4 = 4 * s->n_tiles * 4 <= c->n_cus && !getenv("FSRL_TILE16");
+    s->q_rows4 = 4 * s->n_tiles * s->n_q <= c->n_cus && !getenv("FSRL_TILE16");
     s->a_rows4 = 4 * s->n_tiles <= c->n_cus && !getenv("FSRL_TILE16");
     if (B <= s->cap_B) return 0;
     HIPCHK(hipStreamSynchronize(c->compute));
@@ -1783,12 +1802,12 @@ static int sac_q_launch(fsrl_ctx* c, SacState* s, const float* params, const flo
     a.obs = X; a.rd = nullptr; a.A1 = s->A1; a.A2 = s->A2; a.D1 = s->D1; a.D2 = s->D2; a.DO = s->DO; a.statp = statp;
     a.N = B; a.rows_pad = s->n_tiles * 16; a.mode = mode; a.net0 = 0; a.cr = cr; a.cc = cc; a.max_action = 1.0f;
     a.tgt = s->Y; a.qout = (mode == FB_MODE_Q_FWD && params == s->PQT) ? s->QT : s->QP; a.qin = s->QP; a.da_out = s->DA;
-    a.act_cols = c->cfg.act_dim;
+    a.act_cols = c->cfg.act_dim; a.pair_shift = s->ddpg ? 0 : 1;
     return dispatch_H(c->cfg.hidden, [&](auto hc) {
         constexpr int H = decltype(hc)::value;
         // 4-row tiles while they still fit the chip in one round (batch <= 256 for the four Q-nets)
-        if (s->q_rows4) hipLaunchKernelGGL((fb_tile_kernel<H, 4>), dim3(4 * s->n_tiles, 4), dim3(4 * H), 0, c->compute, params, s->mdq, a);
-        else hipLaunchKernelGGL((fb_tile_kernel<H, 16>), dim3(s->n_tiles, 4), dim3(4 * H), 0, c->compute, params, s->mdq, a);
+        if (s->q_rows4) hipLaunchKernelGGL((fb_tile_kernel<H, 4>), dim3(4 * s->n_tiles, s->n_q), dim3(4 * H), 0, c->compute, params, s->mdq, a);
+        else hipLaunchKernelGGL((fb_tile_kernel<H, 16>), dim3(s->n_tiles, s->n_q), dim3(4 * H), 0, c->compute, params, s->mdq, a);
         HIPCHK(hipGetLastError());
         return 0;
     });
@@ -1892,44 +1911,45 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     hipLaunchKernelGGL(sac_gather_kernel, dim3(std::min(1024, (B * (Do + Da) + 255) / 256)), dim3(256), 0, st, ga);
     HIPCHK(hipGetLastError());
     // ---- target: a', log pi' at s_{t+n}; target Q-nets; float64 n-step return
-    auto actor_launch = [&](const float* obs, const float* eps, float* X, float* lp, int mode) {
+    auto actor_launch = [&](const float* obs, const float* eps, float* X, float* lp, int mode, const float* PAx) {
         SacActorArgs aa{};
+        aa.deterministic = s->ddpg ? 1 : 0; aa.max_action = c->cfg.max_action;
         aa.obs = obs; aa.eps = eps; aa.X = X; aa.lp_out = lp; aa.DA = s->DA; aa.QP = s->QP; aa.sc = s->sc; aa.A1 = s->A1; aa.A2 = s->A2;
         aa.cr = -resc; aa.cc = s->cfg.use_lagrangian ? resc * lam : 0.0f;
         aa.D1 = s->D1; aa.D2 = s->D2; aa.DO = s->DO; aa.statp = s->stpi; aa.B = B; aa.mode = mode; aa.rescale = resc;
         aa.auto_alpha = s->cfg.auto_alpha; aa.alpha_fixed = s->cfg.alpha;
         return dispatch_H(c->cfg.hidden, [&](auto hc) {
             constexpr int H = decltype(hc)::value;
-            if (s->a_rows4) hipLaunchKernelGGL((sac_actor_tile_kernel<H, 4>), dim3(4 * s->n_tiles), dim3(4 * H), 0, st, s->PA, s->mda, aa);
-            else hipLaunchKernelGGL((sac_actor_tile_kernel<H, 16>), dim3(s->n_tiles), dim3(4 * H), 0, st, s->PA, s->mda, aa);
+            if (s->a_rows4) hipLaunchKernelGGL((sac_actor_tile_kernel<H, 4>), dim3(4 * s->n_tiles), dim3(4 * H), 0, st, PAx, s->mda, aa);
+            else hipLaunchKernelGGL((sac_actor_tile_kernel<H, 16>), dim3(s->n_tiles), dim3(4 * H), 0, st, PAx, s->mda, aa);
             HIPCHK(hipGetLastError());
             return 0;
         });
     };
-    rc = actor_launch(s->OBSN, s->eps_t, s->XN, s->LPN, SAC_A_FWD);
+    rc = actor_launch(s->OBSN, s->eps_t, s->XN, s->LPN, SAC_A_FWD, s->ddpg ? s->PAT : s->PA);   // DDPG: target actor
     if (rc) return rc;
     rc = sac_q_launch(c, s, s->PQT, s->XN, FB_MODE_Q_FWD, 0.f, 0.f, s->stq, B);
     if (rc) return rc;
     SacNstepArgs na{};
     na.QT = s->QT; na.lpn = s->LPN; na.chain = s->d_chain; na.endbits = s->d_end; na.rew = c->st.rew; na.cost = c->st.cost;
     na.flags = c->st.flags; na.sc = s->sc; na.Y = s->Y; na.B = B; na.n_step = ns; na.gamma = c->cfg.gamma;
-    na.auto_alpha = s->cfg.auto_alpha; na.alpha_fixed = s->cfg.alpha;
+    na.auto_alpha = s->cfg.auto_alpha; na.alpha_fixed = s->cfg.alpha; na.single = s->ddpg ? 1 : 0;
     hipLaunchKernelGGL(sac_nstep_kernel, dim3((B + 255) / 256), dim3(256), 0, st, na);
     HIPCHK(hipGetLastError());
     // ---- critic step (all four Q-nets, one Adam)
     rc = sac_q_launch(c, s, s->PQ, s->XQ, FB_MODE_Q_TRAIN, 0.f, 0.f, s->stq, B);
     if (rc) return rc;
     int nsplit = 1;
-    rc = sac_wgrad(c, s, s->mdq, 4, s->XQ, s->nq_dev, B, &nsplit);
+    rc = sac_wgrad(c, s, s->mdq, s->n_q, s->XQ, s->nq_dev, B, &nsplit);
     if (rc) return rc;
     s->t_critic += 1;
     adam_launch(c, s->mdq, s->PQ, s->MQ, s->VQ, c->wg_parts, s->nq_dev, s->cfg.critic_lr, s->t_critic, nsplit, s->nq_dev);
     // ---- actor step: a ~ pi(s), Q(s, a) with the UPDATED critics, dL/da, actor backward
-    rc = actor_launch(s->OBS, s->eps_p, s->XP, s->LP, SAC_A_FWD);
+    rc = actor_launch(s->OBS, s->eps_p, s->XP, s->LP, SAC_A_FWD, s->PA);
     if (rc) return rc;
     rc = sac_q_launch(c, s, s->PQ, s->XP, FB_MODE_Q_DIN, 0.f, 0.f, s->stdin_, B);   // Q values + unit-seed dQ/da
     if (rc) return rc;
-    rc = actor_launch(s->OBS, s->eps_p, s->XP, s->LP, SAC_A_BWD);
+    rc = actor_launch(s->OBS, s->eps_p, s->XP, s->LP, SAC_A_BWD, s->PA);
     if (rc) return rc;
     rc = sac_wgrad(c, s, s->mda, 1, s->OBS, s->na_dev, B, &nsplit);
     if (rc) return rc;
@@ -1942,11 +1962,17 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     fa.n_tiles_q = s->q_rows4 ? 4 * s->n_tiles : s->n_tiles; fa.n_tiles_pi = s->a_rows4 ? 4 * s->n_tiles : s->n_tiles; fa.B = B; fa.rescale = resc; fa.lam = lam; fa.target_entropy = s->cfg.target_entropy;
     fa.alpha_lr = s->cfg.alpha_lr; fa.beta1 = c->cfg.beta1; fa.beta2 = c->cfg.beta2; fa.adam_eps = c->cfg.adam_eps;
     fa.alpha_fixed = s->cfg.alpha; fa.auto_alpha = s->cfg.auto_alpha; fa.use_lagrangian = s->cfg.use_lagrangian;
+    fa.n_q = s->n_q;
     hipLaunchKernelGGL(sac_finalize_kernel, dim3(1), dim3(64), 0, st, fa);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(polyak_kernel, dim3(256), dim3(256), 0, st, s->PQT, s->PQ, s->nq_dev, s->cfg.tau,
                        (float)(1.0 - (double)s->cfg.tau), s->mdq);
     HIPCHK(hipGetLastError());
+    if (s->ddpg) {                              // actor_old <- tau * actor + (1 - tau) * actor_old  (ddpg_lag.py:120-123)
+        hipLaunchKernelGGL(polyak_kernel, dim3(128), dim3(256), 0, st, s->PAT, s->PA, s->na_dev, s->cfg.tau,
+                           (float)(1.0 - (double)s->cfg.tau), s->mda);
+        HIPCHK(hipGetLastError());
+    }
     s->n_updates += 1;
     if (stats_out) {                           // synchronous: this update's row (and mark it drained)
         HIPCHK(hipMemcpyAsync(stats_out, stats_row, FSRL_SAC_NSTATS_K * 4, hipMemcpyDeviceToHost, st));
@@ -2025,6 +2051,11 @@ extern "C" int fsrl_sac_actor_forward(fsrl_ctx* c, const float* obs, int32_t k, 
     HIPCHK(hipStreamSynchronize(c->compute));
     for (int r = 0; r < k; ++r)
         for (int d = 0; d < Da; ++d) {
+            if (s->ddpg) {     // deterministic actor: the action itself, and the exploration-noise std
+                mu_out[(size_t)r * Da + d] = c->cfg.max_action * std::tanh(raw[(size_t)r * 2 * Da + d]);
+                sigma_out[(size_t)r * Da + d] = s->cfg.exploration_sigma;
+                continue;
+            }
             mu_out[(size_t)r * Da + d] = raw[(size_t)r * 2 * Da + d];
             const float l = std::min(std::max(raw[(size_t)r * 2 * Da + Da + d], -20.0f), 2.0f);
             sigma_out[(size_t)r * Da + d] = std::exp(l);
@@ -2035,3 +2066,4 @@ extern "C" int fsrl_sac_actor_forward(fsrl_ctx* c, const float* obs, int32_t k, 
 static int sac_actor_mu_sigma(fsrl_ctx* c, const float* obs, int32_t k, float* mu_out, float* sigma_out) {
     return fsrl_sac_actor_forward(c, obs, k, mu_out, sigma_out);
 }
+static bool sac_squashes(fsrl_ctx* c) { SacState* s = sac_of(c); return s && !s->ddpg; }

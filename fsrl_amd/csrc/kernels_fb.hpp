@@ -36,6 +36,7 @@ struct FbArgs {
     const float* qin;     // [nets][N] Q values of all nets          (Q_DIN: min routing)
     float* da_out;        // [nets][N][act_cols] dL/da contributions (Q_DIN)
     int act_cols;         // number of action columns at the end of x
+    int pair_shift;       // Q_TRAIN target of net n is tgt[n >> pair_shift]: 1 = double critics (SAC), 0 = single (DDPG)
 };
 
 // Activation backward of one tile given sm.dout: spills relu(z1), relu(z2), dz2, dout, dz1 for the
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
             const int r = row0 + i;
             if (valid && d == 0) {
                 if (a.mode == FB_MODE_Q_TRAIN) {
-                    const float td = qv - a.tgt[(size_t)(net >> 1) * a.N + r];
+                    const float td = qv - a.tgt[(size_t)(net >> a.pair_shift) * a.N + r];
                     sm.dout[i * FSRL_DOW] = 2.0f * td * invN;
                     st[0] = td * td;
                     a.qout[(size_t)net * a.N + r] = qv;

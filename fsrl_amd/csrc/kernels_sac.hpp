@@ -116,6 +116,8 @@ struct SacActorArgs {
     const float* DA;     // [4][B][Da] dQ_n/da of the four Q-nets, unit seed (BWD)
     const float* QP;     // [4][B] Q_n(s, a_pi): min routing + the logged min-Q sums (BWD)
     float cr, cc;        // loss weights of min(Qr1,Qr2) and min(Qc1,Qc2): -rescale, rescale*lambda
+    int deterministic;   // DDPG-Lag actor: a = max_action * tanh(out), single critics, no entropy (ddpg_lag.py:189-213)
+    float max_action;
     const SacScalars* sc;
     float* A1; float* A2; float* D1; float* D2; float* DO;   // side buffers (BWD)
     float* statp;        // [n_tiles][FB_NSTAT]  st[0] = sum log pi
@@ -161,6 +163,19 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
         const int r = row0 + i;
         const bool valid = i < n_valid;
         float lpd = 0.0f, act = 0.0f, sig = 1.0f, ep = 0.0f, one_m = 1.0f, pass = 0.0f;
+        float logp = 0.0f;
+        if (a.deterministic) {
+            float th = 0.0f;
+            if (valid && d < Da) th = tanhf(sm.out[i * FSRL_MAX_ACT + d]);
+            if (a.mode == SAC_A_FWD) {
+                if (valid && d < Da) a.X[(size_t)r * (Do + Da) + Do + d] = a.max_action * th;
+            } else if (valid && d < Da) {
+                // dL/da_d = (cr * dQ_r/da_d + cc * dQ_c/da_d) / B ; a_d = max_action * tanh(out_d)
+                const float ga = (a.cr * invB) * a.DA[((size_t)0 * a.B + r) * Da + d] +
+                                 (a.cc * invB) * a.DA[((size_t)1 * a.B + r) * Da + d];
+                sm.dout[i * FSRL_DOW + d] = ga * a.max_action * (1.0f - th * th);
+            }
+        } else {
         if (valid && d < Da) {
             const float mu = sm.out[i * FSRL_MAX_ACT + d];
             const float lraw = sm.out[i * FSRL_MAX_ACT + Da + d];
@@ -175,7 +190,6 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
         }
         // log pi = sum_d Normal.log_prob  -  sum_d log(1 - a^2 + eps): two separate sums in the
         // reference; summed per dim here (difference: fp32 rounding only)
-        float logp = 0.0f;
         for (int dd = 0; dd < Da; ++dd) logp += __shfl(lpd, (lane & 48) + dd, 64);
         if (a.mode == SAC_A_FWD) {
             if (valid && d < Da) a.X[(size_t)r * (Do + Da) + Do + d] = act;
@@ -198,9 +212,13 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
             sm.dout[i * FSRL_DOW + d] = dLdu;                         // d/dmu
             sm.dout[i * FSRL_DOW + Da + d] = (dLdu * ep * sig - c) * pass;   // d/d(raw log sigma)
         }
+        }
         if (d == 0) {
             sm.w1[i * FB_NSTAT] = valid ? logp : 0.0f;
-            if (a.mode == SAC_A_BWD) {       // logged actor losses: sums of min(Q1,Q2) per double critic
+            if (a.mode == SAC_A_BWD && a.deterministic) {          // sums of Q_r, Q_c
+                sm.w1[i * FB_NSTAT + 1] = valid ? a.QP[r] : 0.0f;
+                sm.w1[i * FB_NSTAT + 2] = valid ? a.QP[(size_t)a.B + r] : 0.0f;
+            } else if (a.mode == SAC_A_BWD) {       // logged actor losses: sums of min(Q1,Q2) per double critic
                 sm.w1[i * FB_NSTAT + 1] = valid ? fminf(a.QP[r], a.QP[(size_t)a.B + r]) : 0.0f;
                 sm.w1[i * FB_NSTAT + 2] = valid ? fminf(a.QP[(size_t)2 * a.B + r], a.QP[(size_t)3 * a.B + r]) : 0.0f;
             }
@@ -230,6 +248,7 @@ struct SacNstepArgs {
     int B, n_step;
     double gamma;
     int auto_alpha; float alpha_fixed;
+    int single;             // DDPG-Lag: one target critic per metric, no entropy term (ddpg_lag.py:125-131)
 };
 __global__ void sac_nstep_kernel(const SacNstepArgs a) {
 #pragma clang fp contract(off)
@@ -249,9 +268,10 @@ __global__ void sac_nstep_kernel(const SacNstepArgs a) {
     for (int i = 0; i < gammas; ++i) gpow = gpow * a.gamma;          // gamma_buffer[gammas]
     const int terminal = a.chain[(size_t)(a.n_step - 1) * a.B + b];
     const bool term = (a.flags[terminal] & 1) != 0;
-    const float lp = alpha * a.lpn[b];
+    const float lp = a.single ? 0.0f : alpha * a.lpn[b];
     for (int i = 0; i < 2; ++i) {
-        float tq = fminf(a.QT[(size_t)(2 * i) * a.B + b], a.QT[(size_t)(2 * i + 1) * a.B + b]) - lp;
+        float tq = a.single ? a.QT[(size_t)i * a.B + b]
+                            : fminf(a.QT[(size_t)(2 * i) * a.B + b], a.QT[(size_t)(2 * i + 1) * a.B + b]) - lp;
         if (term) tq = 0.0f;
         const double prod = (double)tq * gpow;
         const double y = prod + (i == 0 ? ret_r : ret_c);
@@ -268,6 +288,7 @@ struct SacFinalArgs {
     int n_tiles_q, n_tiles_pi, B;
     float rescale, lam, target_entropy, alpha_lr, beta1, beta2, adam_eps, alpha_fixed;
     int auto_alpha, use_lagrangian;
+    int n_q;                 // Q-networks in statp_q: 4 (two double critics) or 2 (DDPG-Lag: single critics)
 };
 __global__ __launch_bounds__(64) void sac_finalize_kernel(const SacFinalArgs a) {
     const int lane = threadIdx.x;
@@ -278,7 +299,8 @@ __global__ __launch_bounds__(64) void sac_finalize_kernel(const SacFinalArgs a) 
     for (int k = 0; k < 9; ++k) s9[k] = 0.0;
     for (int t = lane; t < a.n_tiles_q; t += 64) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s9[k] += (double)a.statp_q[((size_t)t * 4 + k) * FB_NSTAT];
+        for (int k = 0; k < 4; ++k)
+            if (k < a.n_q) s9[k] += (double)a.statp_q[((size_t)t * a.n_q + k) * FB_NSTAT];
     }
     for (int t = lane; t < a.n_tiles_pi; t += 64) {
         s9[8] += (double)a.statp_pi[(size_t)t * FB_NSTAT];
@@ -288,7 +310,8 @@ __global__ __launch_bounds__(64) void sac_finalize_kernel(const SacFinalArgs a) 
     float m9[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) m9[k] = (float)(wave_sum_d(s9[k]) / (double)a.B);
-    const float q_r1 = m9[0], q_r2 = m9[1], q_c1 = m9[2], q_c2 = m9[3];
+    const bool single = a.n_q == 2;
+    const float q_r1 = m9[0], q_r2 = single ? 0.0f : m9[1], q_c1 = single ? m9[1] : m9[2], q_c2 = single ? 0.0f : m9[3];
     const float minqr = m9[4], minqc = m9[6], mlogp = m9[8];
     if (lane == 0) {
         SacScalars sc = *a.sc;

@@ -253,10 +253,12 @@ class Engine:
 
     # ---------------------------------------------------------------- SAC-Lagrangian
     def sac_init(self, actor_lr=5e-4, critic_lr=1e-3, alpha_lr=3e-4, tau=0.05, alpha=0.005,
-                 target_entropy=None, n_step=2, auto_alpha=True, use_lagrangian=True):
+                 target_entropy=None, n_step=2, auto_alpha=True, use_lagrangian=True, deterministic=False,
+                 exploration_sigma=0.1):
+        """deterministic=True selects DDPG-Lagrangian (deterministic actor + target actor, single critics)."""
         te = -float(self.cfg.act_dim) if target_entropy is None else float(target_entropy)
         cfg = _lib.SacConfig(actor_lr, critic_lr, alpha_lr, tau, alpha, te, int(n_step), int(auto_alpha),
-                             int(use_lagrangian))
+                             int(use_lagrangian), int(deterministic), float(exploration_sigma))
         _lib.check(self.lib.fsrl_sac_init(self._ctx, C.byref(cfg)))
         self.n_sac_actor = int(self.lib.fsrl_sac_param_count(self._ctx, 0))
         self.n_sac_critics = int(self.lib.fsrl_sac_param_count(self._ctx, 1))
@@ -267,8 +269,8 @@ class Engine:
                                                 float(log_alpha)))
 
     def sac_get_params(self, which: int):
-        """which: 0 actor, 1 critics, 2 critics_old -> (flat params, alpha)."""
-        out = np.empty(self.n_sac_actor if which == 0 else self.n_sac_critics, np.float32)
+        """which: 0 actor, 1 critics, 2 critics_old, 3 actor_old (DDPG-Lag) -> (flat params, alpha)."""
+        out = np.empty(self.n_sac_actor if which in (0, 3) else self.n_sac_critics, np.float32)
         alpha = C.c_float()
         _lib.check(self.lib.fsrl_sac_params_get(self._ctx, int(which), _ptr(out, _f32p), out.size, C.byref(alpha)))
         return out, float(alpha.value)

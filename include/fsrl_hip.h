@@ -204,6 +204,14 @@ typedef struct fsrl_sac_config {
     int32_t n_step;                        /* 2 (sacl_cfg.py:21)                                 */
     int32_t auto_alpha;
     int32_t use_lagrangian;
+    /* DDPG-Lagrangian (fsrl/policy/ddpg_lag.py:125-223) on the same entry points: deterministic actor
+     * a = max_action * tanh(MLP(s)) with a target copy, ONE critic per metric (tianshou Critic on
+     * concat(s, a)) with target copies, no entropy term.  Parameter vectors then are
+     *   actor: W1 b1 W2 b2 W3[Da,H] b3      critics: for (reward, cost): W1[H,Do+Da] b1 W2 b2 W3[1,H] b3
+     * fsrl_sac_params_get which = 3 returns the target actor.  exploration_sigma: std of the Gaussian
+     * exploration noise fsrl_actor_sample adds (GaussianNoise, ddpg_lag_agent.py:80,160).              */
+    int32_t deterministic;
+    float exploration_sigma;
 } fsrl_sac_config;
 #define FSRL_SAC_NSTATS 10  /* rescaling, lagrangian, actor_safety, alpha_loss, alpha_value, actor_rew,
                                actor_total (sac_lag.py:231-257) then q0, q1, q_total (:203-208) */

@@ -1,0 +1,60 @@
+"""GPU parity of the DDPG-Lagrangian update through the C ABI against the golden vectors
+recorded from the unmodified reference.  Tolerances as for SAC: stats 5e-5 rel + 5e-6 abs, parameters
+99 % within 5e-6 (Adam on noise-level gradients may move single entries by ~lr per step)."""
+import numpy as np
+import pytest
+
+from test_oracle_ddpg import ddpg_setup
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ["loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss/alpha_loss", "loss/alpha_value",
+        "loss/actor_rew", "loss/actor_total", "loss/q0", "loss/q1", "loss/q_total"]
+
+
+def _engine(cfg, g):
+    from fsrl_amd import _lib
+    from fsrl_amd.engine import Engine, EngineConfig
+    eng = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"],
+                              hidden=cfg["hidden"][0], n_critics=2, env_num=cfg["env_num"], buffer_size=cfg["buffer_size"],
+                              gamma=cfg["gamma"], max_action=cfg["max_action"], target_kl=None))
+    eng.sac_init(actor_lr=cfg["actor_lr"], critic_lr=cfg["critic_lr"], tau=cfg["tau"], n_step=cfg["n_step"],
+                 use_lagrangian=cfg["use_lagrangian"], deterministic=True)
+    eng.sac_set_params(g["theta_actor0"], g["theta_critics0"], 0.0)
+    rows = g["env_rows"]; off = np.concatenate([[0], np.cumsum(rows)])
+    for t in range(rows.max()):
+        ids = [e for e in range(len(rows)) if t < rows[e]]
+        sel = np.array([off[e] + t for e in ids])
+        eng.push(ids, g["st_obs"][sel], g["st_act"][sel], g["st_rew"][sel], g["st_cost"][sel], g["st_terminated"][sel],
+                 g["st_truncated"][sel], g["st_obs_next"][sel])
+    return eng
+
+
+@pytest.mark.parametrize("name", ["small", "scaled", "nolag"])
+def test_ddpg_updates_vs_golden(name):
+    g, cfg, ocfg, store, index = ddpg_setup(name)
+    eng = _engine(cfg, g)
+    assert np.array_equal(eng.sac_get_params(0)[0], g["theta_actor0"]) and np.array_equal(eng.sac_get_params(3)[0], g["theta_actor0"])
+    assert np.array_equal(eng.sac_get_params(1)[0], g["theta_critics0"])
+    lag = g["lagrangian"] if cfg["use_lagrangian"] else np.zeros(0)
+    resc = 1.0 / (lag.sum() + 1.0)
+    ka = [str(k) for k in g["stats_actor_keys"]]; kc = [str(k) for k in g["stats_critic_keys"]]
+    B, Da = cfg["batch_size"], cfg["act_dim"]
+    zero = np.zeros((B, Da), np.float32)
+    for u in range(cfg["n_updates"]):
+        st = eng.sac_update(B, lag, resc, indices=g["indices"][u], eps_target=zero, eps_pi=zero)
+        want = {**dict(zip(ka, g["stats_actor"][u])), **dict(zip(kc, g["stats_critic"][u]))}
+        for j, k in enumerate(KEYS):
+            if k in want:
+                assert abs(st[j] - want[k]) <= 5e-5 * abs(want[k]) + 5e-6, (u, k, st[j], want[k])
+    for which, key in ((0, "theta_actor_final"), (3, "theta_actor_old_final"), (1, "theta_critics_final"),
+                       (2, "theta_critics_old_final")):
+        d = np.abs(eng.sac_get_params(which)[0] - g[key])
+        assert np.quantile(d, 0.99) <= 5e-6 and d.max() <= 2e-3, (key, np.quantile(d, 0.99), d.max())
+    # collector-time action: deterministic = max_action * tanh(actor(s)); exploration adds N(0, 0.1^2)
+    obs = g["st_obs"][:5]
+    a_det = eng.actor_sample(obs, deterministic=True)
+    assert np.abs(a_det).max() <= cfg["max_action"] + 1e-6
+    a = np.stack([eng.actor_sample(obs, seed=3 if i == 0 else 0) for i in range(400)])
+    assert abs((a - a_det).std() - 0.1) < 0.01
+    eng.close()
