@@ -5,5 +5,6 @@ from fsrl_amd.policy.ppo_lag import PPOLagrangian
 from fsrl_amd.policy.trpo_lag import TRPOLagrangian
 from fsrl_amd.policy.cpo import CPO
 from fsrl_amd.policy.sac_lag import SACLagrangian
+from fsrl_amd.policy.ddpg_lag import DDPGLagrangian
 
-__all__ = ["BasePolicy", "LagrangianPolicy", "PPOLagrangian", "TRPOLagrangian", "CPO", "SACLagrangian"]
+__all__ = ["BasePolicy", "LagrangianPolicy", "PPOLagrangian", "TRPOLagrangian", "CPO", "SACLagrangian", "DDPGLagrangian"]

@@ -1,0 +1,131 @@
+"""DDPGLagrangian over the HIP engine: constructor arguments and logger keys of
+fsrl/policy/ddpg_lag.py:64-231.  `update(batch_size, buffer)` = sample + n-step targets
+through the target actor / target critics + critic step + actor step + Polyak of both, on the MI355X
+through `fsrl_sac_update` in its deterministic mode."""
+from copy import deepcopy
+from typing import Any, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from fsrl_amd import _lib
+from fsrl_amd.data.batch import Batch
+from fsrl_amd.engine import Engine, EngineConfig
+from fsrl_amd.policy.lagrangian_base import LagrangianPolicy
+from fsrl_amd.policy.sac_lag import SAC_KEYS, SACLagrangian
+
+_DROP = ("loss/alpha_loss", "loss/alpha_value")
+
+
+class DDPGLagrangian(LagrangianPolicy):
+    def __init__(self, actor: nn.Module, critics: Union[nn.Module, List[nn.Module]], actor_optim, critic_optim,
+                 logger=None, tau: float = 0.05, exploration_noise=None, n_step: int = 2, use_lagrangian: bool = True,
+                 lagrangian_pid: Tuple = (0.05, 0.0005, 0.1), cost_limit: Union[List, float] = np.inf,
+                 rescaling: bool = True, gamma: float = 0.99, reward_normalization: bool = False,
+                 deterministic_eval: bool = True, action_scaling: bool = True, action_bound_method: str = "clip",
+                 observation_space=None, action_space=None, lr_scheduler=None, device: Union[int, str] = 0,
+                 env_num: int = 1, buffer_size: int = 100000, reference_rng: bool = False, seed: int = 0) -> None:
+        super().__init__(actor, critics, None, logger, use_lagrangian, lagrangian_pid, cost_limit, rescaling, gamma,
+                         99999, reward_normalization, deterministic_eval, action_scaling, action_bound_method,
+                         observation_space, action_space, lr_scheduler)
+        assert self.critics_num == 2, "the HIP path supports one cost constraint (reward + cost critics)"
+        assert 0.0 <= tau <= 1.0, "tau should be in [0, 1]"
+        self.actor_old = deepcopy(self.actor)
+        self.actor_old.eval()
+        self.actor_optim, self.critics_optim = actor_optim, critic_optim
+        self.critics_old = deepcopy(self.critics)
+        self.critics_old.eval()
+        self.tau, self._noise, self._n_step = tau, exploration_noise, n_step
+        w1 = actor.preprocess.model.model[0].weight
+        hidden, obs_dim = w1.shape
+        act_dim = actor.last.model[0].weight.shape[0]
+        dev = device if isinstance(device, int) else (int(str(device).split(":")[-1]) if ":" in str(device) else 0)
+        self.engine = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=int(obs_dim), act_dim=int(act_dim),
+                                          hidden=int(hidden), n_critics=2, env_num=int(env_num),
+                                          buffer_size=int(buffer_size), gamma=gamma, max_action=float(actor._max),
+                                          target_kl=None), device=dev)
+        self.engine.sac_init(actor_lr=actor_optim.param_groups[0]["lr"], critic_lr=critic_optim.param_groups[0]["lr"],
+                             tau=tau, n_step=n_step, use_lagrangian=use_lagrangian, deterministic=True,
+                             exploration_sigma=getattr(exploration_noise, "_sigma", 0.0))
+        self.engine.sac_set_params(SACLagrangian._flat([self.actor]), SACLagrangian._flat(list(self.critics)), 0.0)
+        self._dirty, self._reference_rng, self._seed, self._pending = False, reference_rng, int(seed), 0
+
+    def set_exp_noise(self, noise) -> None:
+        self._noise = noise
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        self.actor.train(mode)
+        self.critics.train(mode)
+        return self
+
+    def _pull_params(self, everything: bool = False) -> None:
+        SACLagrangian._unflat([self.actor], self.engine.sac_get_params(0)[0])
+        if everything:
+            SACLagrangian._unflat([self.actor_old], self.engine.sac_get_params(3)[0])
+            SACLagrangian._unflat(list(self.critics), self.engine.sac_get_params(1)[0])
+            SACLagrangian._unflat(list(self.critics_old), self.engine.sac_get_params(2)[0])
+        self._dirty = False
+
+    def state_dict(self, *args, **kwargs):
+        if self._pending:
+            self._drain()
+        if self._dirty:
+            self._pull_params(everything=True)
+        return super().state_dict(*args, **kwargs)
+
+    def forward(self, batch: Batch, state=None, model: str = "actor", input: str = "obs", **kwargs: Any) -> Batch:
+        if self._dirty:
+            self._pull_params(everything=model != "actor")
+        actions, hidden = getattr(self, model)(batch[input], state=state)
+        return Batch(act=actions, state=hidden)
+
+    def exploration_noise(self, act, batch):
+        if self._noise is None:
+            return act
+        return act + self._noise(act.shape) if isinstance(act, np.ndarray) else act
+
+    def learn(self, batch, **kwargs: Any):
+        raise NotImplementedError("the HIP path runs process_fn + learn inside update()")
+
+    def _log_rows(self, rows) -> None:
+        for st in rows:
+            d = {k: float(v) for k, v in zip(SAC_KEYS, st) if k not in _DROP}
+            if not self.use_lagrangian:
+                d.pop("loss/lagrangian"); d.pop("loss/actor_safety")
+            qs = {k: d.pop(k) for k in ("loss/q0", "loss/q1", "loss/q_total")}
+            self.logger.store(**d)
+            self.logger.store(**qs)
+
+    def _drain(self) -> None:
+        if self._pending:
+            self._log_rows(self.engine.sac_drain())
+            self._pending = 0
+
+    def post_update_fn(self, **kwarg: Any) -> None:
+        self._drain()
+        super().post_update_fn(**kwarg)
+
+    def update(self, sample_size: int, buffer, **kwargs: Any):
+        if buffer is None:
+            return {}
+        assert getattr(buffer, "engine", None) is self.engine
+        self.updating = True
+        B = int(sample_size)
+        lags, rescaling = self.lagrangians_and_rescaling() if self.use_lagrangian else ([], 1.0)
+        if self._reference_rng:                       # buffer.sample through numpy's RNG, like the reference
+            zero = np.zeros((B, self.engine.cfg.act_dim), np.float32)
+            st = self.engine.sac_update(B, lags, rescaling, indices=buffer.sample_indices(B), eps_target=zero, eps_pi=zero)
+            self._log_rows(st[None])
+        else:
+            self.engine.sac_update(B, lags, rescaling, seed=self._seed + 1 if self.gradient_steps == 0 else 0, sync=False)
+            self._pending += 1
+            if self._pending >= 2048:
+                self._drain()
+        self.gradient_steps += 1
+        self._dirty = True
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+        self.updating = False
+        return {}

@@ -92,6 +92,32 @@ class DoubleCritic(nn.Module):
         return torch.min(q[0], q[1]), q
 
 
+class Actor(nn.Module):
+    """Deterministic actor max_action * tanh(MLP(obs)) (tianshou-0.5 continuous.Actor as FSRL builds it,
+    fsrl/agent/ddpg_lag_agent.py:106-107): attribute names preprocess / last like the reference's state_dict."""
+
+    def __init__(self, preprocess_net, action_shape, max_action=1.0, device="cpu"):
+        super().__init__()
+        self.preprocess = preprocess_net
+        self.output_dim = int(np.prod(action_shape))
+        self.last = MLP(preprocess_net.output_dim, self.output_dim)
+        self._max = max_action
+
+    def forward(self, obs, state=None, info={}):
+        logits, hidden = self.preprocess(obs, state)
+        return self._max * torch.tanh(self.last(logits)), hidden
+
+
+class GaussianNoise:
+    """Exploration noise N(mu, sigma^2) from numpy's global RNG (tianshou.exploration.GaussianNoise)."""
+
+    def __init__(self, mu: float = 0.0, sigma: float = 1.0):
+        self._mu, self._sigma = mu, sigma
+
+    def __call__(self, size):
+        return np.random.normal(self._mu, self._sigma, size)
+
+
 class Critic(nn.Module):
     def __init__(self, preprocess_net, device="cpu"):
         super().__init__()
