@@ -77,6 +77,7 @@ SIGNATURES = {
     "fsrl_sac_init": (C.c_int, [_ctx, _P(SacConfig)]),
     "fsrl_sac_param_count": (C.c_int64, [_ctx, C.c_int32]),
     "fsrl_sac_params_set": (C.c_int, [_ctx, _f, C.c_int64, _f, C.c_int64, C.c_float]),
+    "fsrl_sac_params_put": (C.c_int, [_ctx, C.c_int32, _f, C.c_int64]),
     "fsrl_sac_params_get": (C.c_int, [_ctx, C.c_int32, _f, C.c_int64, _f]),
     "fsrl_sac_update": (C.c_int, [_ctx, C.c_int32, _i64, _f, _f, C.c_uint64, _d, C.c_double, _f]),
     "fsrl_actor_sample": (C.c_int, [_ctx, _f, C.c_int32, C.c_int32, C.c_uint64, _f]),

@@ -1721,6 +1721,23 @@ extern "C" int fsrl_sac_params_set(fsrl_ctx* c, const float* actor, int64_t na, 
     return 0;
 }
 
+// Overwrite ONE parameter set (checkpoint load): which = 0 actor, 1 critics, 2 critics_old, 3 actor_old.
+// Unlike fsrl_sac_params_set nothing else changes (targets, Adam moments, step counts stay).
+extern "C" int fsrl_sac_params_put(fsrl_ctx* c, int32_t which, const float* in, int64_t n) {
+    CHECK_ARG(c && in, "null argument");
+    SacState* s = sac_of(c);
+    if (!s) return fail(FSRL_ESTATE, "fsrl_sac_init first");
+    CHECK_ARG(which >= 0 && which <= 3, "which must be 0..3");
+    CHECK_ARG(which != 3 || s->ddpg, "actor_old exists in the DDPG-Lagrangian mode only");
+    HIPCHK(hipSetDevice(c->device));
+    if (which == 0 || which == 3) {
+        CHECK_ARG(n == s->na_api, "expected %d actor parameters", s->na_api);
+        return sac_copy(c, s->tmap_a, s->mda, s->na_dev, which == 0 ? s->PA : s->PAT, in, nullptr);
+    }
+    CHECK_ARG(n == s->nq_api, "expected %d critic parameters", s->nq_api);
+    return sac_copy(c, s->tmap_q, s->mdq, s->nq_dev, which == 1 ? s->PQ : s->PQT, in, nullptr);
+}
+
 extern "C" int fsrl_sac_params_get(fsrl_ctx* c, int32_t which, float* out, int64_t n, float* alpha_out) {
     CHECK_ARG(c && out, "null argument");
     SacState* s = sac_of(c);

@@ -268,6 +268,11 @@ class Engine:
         _lib.check(self.lib.fsrl_sac_params_set(self._ctx, _ptr(a, _f32p), a.size, _ptr(c, _f32p), c.size,
                                                 float(log_alpha)))
 
+    def sac_put_params(self, which: int, flat):
+        """Overwrite one parameter set (0 actor, 1 critics, 2 critics_old, 3 actor_old); nothing else changes."""
+        a = np.ascontiguousarray(flat, np.float32)
+        _lib.check(self.lib.fsrl_sac_params_put(self._ctx, int(which), _ptr(a, _f32p), a.size))
+
     def sac_get_params(self, which: int):
         """which: 0 actor, 1 critics, 2 critics_old, 3 actor_old (DDPG-Lag) -> (flat params, alpha)."""
         out = np.empty(self.n_sac_actor if which in (0, 3) else self.n_sac_critics, np.float32)

@@ -75,6 +75,14 @@ class DDPGLagrangian(LagrangianPolicy):
             self._pull_params(everything=True)
         return super().state_dict(*args, **kwargs)
 
+    def load_state_dict(self, state_dict, strict: bool = True):
+        out = nn.Module.load_state_dict(self, state_dict, strict=strict)
+        if getattr(self, "engine", None) is not None:
+            for which, mods in ((0, [self.actor]), (3, [self.actor_old]), (1, list(self.critics)), (2, list(self.critics_old))):
+                self.engine.sac_put_params(which, SACLagrangian._flat(mods))
+            self._dirty = False
+        return out
+
     def forward(self, batch: Batch, state=None, model: str = "actor", input: str = "obs", **kwargs: Any) -> Batch:
         if self._dirty:
             self._pull_params(everything=model != "actor")

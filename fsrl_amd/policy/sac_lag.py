@@ -104,6 +104,15 @@ class SACLagrangian(LagrangianPolicy):
             self._pull_params(everything=True)
         return super().state_dict(*args, **kwargs)
 
+    def load_state_dict(self, state_dict, strict: bool = True):
+        out = nn.Module.load_state_dict(self, state_dict, strict=strict)
+        if getattr(self, "engine", None) is not None:            # actor, critics, targets: each set on its own
+            self.engine.sac_put_params(0, self._flat([self.actor]))
+            self.engine.sac_put_params(1, self._flat(list(self.critics)))
+            self.engine.sac_put_params(2, self._flat(list(self.critics_old)))
+            self._dirty = False
+        return out
+
     def train(self, mode: bool = True):
         self.training = mode
         self.actor.train(mode)

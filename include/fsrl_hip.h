@@ -221,6 +221,9 @@ int fsrl_sac_params_set(fsrl_ctx* ctx, const float* actor, int64_t na, const flo
                         float log_alpha);   /* also copies critics -> critics_old, resets Adam    */
 /* which: 0 actor, 1 critics, 2 critics_old (targets)                                            */
 int fsrl_sac_params_get(fsrl_ctx* ctx, int32_t which, float* out, int64_t n, float* alpha_out);
+/* Checkpoint load (policy.load_state_dict): overwrite ONE parameter set, same `which` as above; targets,
+ * Adam moments and step counts are left alone.                                                        */
+int fsrl_sac_params_put(fsrl_ctx* ctx, int32_t which, const float* in, int64_t n);
 /* One SACLagrangian.update(batch_size, buffer) = sample + n-step targets + critic step + actor
  * step + alpha step + Polyak (sac_lag.py:185-269, base_policy.py:356-395,453-512).
  * Sampling: indices / eps_target / eps_pi are given TOGETHER (the caller's numpy / torch RNG
