@@ -913,7 +913,7 @@ extern "C" int fsrl_ppo_pass(fsrl_ctx* c, const int64_t* perm, uint64_t seed, in
             return 0;
         });
         if (rc) return rc;
-        hipLaunchKernelGGL(adam_clip_kernel, dim3(c->n_dev / 1024), dim3(256), 0, s, c->P, c->M, c->V, c->G,
+        hipLaunchKernelGGL(adam_clip_kernel, dim3((c->n_dev + 4 * ADAM_NT - 1) / (4 * ADAM_NT)), dim3(ADAM_NT), 0, s, c->P, c->M, c->V, c->G,
                            c->gsq_part, nparts, c->n_dev, sa, c->ctrl, c->md);
         HIPCHK(hipGetLastError());
     }

@@ -196,18 +196,21 @@ __global__ __launch_bounds__(1024) void ppo_prepare_pass_kernel(const PrepArgs a
 }
 
 // ---------------------------------------------------------------- grad clip + Adam
+#ifndef ADAM_NT
+#define ADAM_NT 256
+#endif
 // clip_grad_norm_(max_norm) then torch.optim.Adam single-tensor update, same operation order
 // as torch (lerp_ / mul_+addcmul_ / sqrt / div / add_(eps) / addcdiv_), ppo_lag.py:235-241.
-__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ P, float* __restrict__ M,
+__global__ __launch_bounds__(ADAM_NT) void adam_clip_kernel(float* __restrict__ P, float* __restrict__ M,
                                                        float* __restrict__ V,
                                                        const float* __restrict__ G,
                                                        const float* __restrict__ gsq_part, int nparts,
                                                        int n, const PpoStepArgs sa,
                                                        CtrlBlock* ctrl, const ModelDesc md) {
-    __shared__ double sh[4];
+    __shared__ double sh[ADAM_NT / 64];
     __shared__ float coef_s;
     const int tid = threadIdx.x;
-    const int i4 = (blockIdx.x * 256 + tid) * 4;   // n is a multiple of 1024: float4 per thread
+    const int i4 = (blockIdx.x * ADAM_NT + tid) * 4;   // float4 per thread
     // issue every load of this thread first (one cold round trip), then reduce the norm
     f32x4 g = {0, 0, 0, 0}, m = g, v = g, p = g;
     if (i4 < n) {
@@ -217,12 +220,14 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ P, f
     float coef = 1.0f;
     if (sa.max_grad_norm > 0.0f) {
         double s = 0.0;
-        for (int k = tid; k < nparts; k += 256) s += (double)gsq_part[k];
+        for (int k = tid; k < nparts; k += ADAM_NT) s += (double)gsq_part[k];
         s = wave_sum_d(s);
         if ((tid & 63) == 0) sh[tid >> 6] = s;
         __syncthreads();
         if (tid == 0) {
-            const float norm = sqrtf((float)((sh[0] + sh[1]) + (sh[2] + sh[3])));
+            double tot = 0.0;
+            for (int w = 0; w < ADAM_NT / 64; ++w) tot += sh[w];
+            const float norm = sqrtf((float)tot);
             coef_s = fminf(sa.max_grad_norm / (norm + 1e-6f), 1.0f);
             if (blockIdx.x == 0) ctrl->last_grad_norm = norm;
         }
