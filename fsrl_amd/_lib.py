@@ -100,6 +100,13 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with fsrl_amd/csrc/build.sh (hipcc, gfx950). "
             "fsrl_amd has no CPU fallback.")
+    # PyTorch-ROCm ships its own HIP runtime; whichever copy initialises first owns the process.  Loading
+    # ours first leaves torch.cuda (RCCL, the bench's barriers) -- or, the other way round, this library --
+    # without a device ("no ROCm-capable device is detected").  torch first is the order that works.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI and the header drifted apart
