@@ -179,7 +179,7 @@ static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int n
     *nsplit = pl.nsplit;
     return dispatch_H(c->cfg.hidden, [&](auto hc) {
         constexpr int HH = decltype(hc)::value;
-        constexpr int NB = (HH / 32) * (HH / 32) + HH / 32 + 1;
+        constexpr int NB = (HH / 64) * (HH / 64) + HH / 32 + 1;   // 64x64 dW2 tiles + 32-column aux blocks + db3 block
         hipLaunchKernelGGL((fb_wgrad_kernel<HH, PAIR2>), dim3(NB, ny, pl.nsplit), dim3(1024), 0, c->compute, md, wa);
         HIPCHK(hipGetLastError());
         return 0;
@@ -1031,6 +1031,7 @@ struct TrState {
     float *statp = nullptr, *mu_old = nullptr, *Vdev = nullptr, *Out = nullptr, *rd = nullptr;
     float *cg_r = nullptr, *cg_x = nullptr, *cg_g = nullptr;     // device-resident CG vectors (actor layout)
     CgScal* cg_sc = nullptr;
+    float* cg_part = nullptr;                                    // [3 * CG_NB]: p.z partials | r.r partials (two halves)
     double* d_scal = nullptr;
     size_t cap_rows = 0;
     int64_t critic_t = 0;     // Adam step count of the critic optimiser
@@ -1051,6 +1052,7 @@ static void tr_free(fsrl_ctx* c) {
                      t->mu_old, t->Vdev, t->Out, t->rd, t->cg_r, t->cg_x, t->cg_g})
         if (p) (void)hipFree(p);
     if (t->cg_sc) (void)hipFree(t->cg_sc);
+    if (t->cg_part) (void)hipFree(t->cg_part);
     if (t->d_scal) (void)hipFree(t->d_scal);
     delete t;
     c->tr = nullptr;
@@ -1088,6 +1090,7 @@ static int tr_alloc(fsrl_ctx* c, TrState* t, int64_t n) {
             HIPCHK(hipMemsetAsync(*p, 0, (size_t)c->n_dev * 4, c->compute));
         }
         HIPCHK(hipMalloc(&t->cg_sc, sizeof(CgScal)));
+        HIPCHK(hipMalloc(&t->cg_part, 3 * CG_NB * sizeof(float)));
         HIPCHK(hipMemsetAsync(t->Vdev, 0, (size_t)c->n_alloc * 4, c->compute)); HIPCHK(hipMemsetAsync(t->Out, 0, (size_t)c->n_dev * 4, c->compute));
         HIPCHK(hipStreamSynchronize(c->compute));
         HIPCHK(hipMalloc(&t->d_scal, 64 * sizeof(double)));
@@ -1314,14 +1317,18 @@ static int tr_cg(fsrl_ctx* c, TrState* t, const std::vector<float>& g, float dam
         HIPCHK(hipStreamSynchronize(c->compute));
         HIPCHK(hipMemcpy(t->cg_g, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
     }
-    hipLaunchKernelGGL(cg_init_kernel, dim3(1), dim3(1024), 0, c->compute, t->cg_g, t->cg_r, t->Vdev, t->cg_x, t->cg_sc, nd,
-                       c->md);
+    float* part_pz = t->cg_part; float* part_rr = t->cg_part + CG_NB;
+    hipLaunchKernelGGL(cg_init_kernel, dim3(CG_NB), dim3(256), 0, c->compute, t->cg_g, t->cg_r, t->Vdev, t->cg_x, t->cg_sc,
+                       part_rr, nd, c->md);
     HIPCHK(hipGetLastError());
     for (int it = 0; it < nsteps; ++it) {
         int rc = tr_hvp_dev(c, t);
         if (rc) return rc;
-        hipLaunchKernelGGL(cg_step_kernel, dim3(1), dim3(1024), 0, c->compute, t->Out, t->cg_r, t->Vdev, t->cg_x, t->cg_sc, nd,
-                           damping, tol, c->md);
+        hipLaunchKernelGGL(cg_pz_kernel, dim3(CG_NB), dim3(256), 0, c->compute, t->Out, t->Vdev, t->cg_sc, part_pz, nd, damping);
+        hipLaunchKernelGGL(cg_xr_kernel, dim3(CG_NB), dim3(256), 0, c->compute, t->Out, t->cg_r, t->Vdev, t->cg_x, t->cg_sc,
+                           part_pz, part_rr, nd, it);
+        hipLaunchKernelGGL(cg_p_kernel, dim3(CG_NB), dim3(256), 0, c->compute, t->cg_r, t->Vdev, t->cg_sc, part_rr, nd, it, tol,
+                           c->md);
         HIPCHK(hipGetLastError());
     }
     return actor_from_dev(c, t->cg_x, x.data());

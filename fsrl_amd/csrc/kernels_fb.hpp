@@ -552,11 +552,12 @@ struct FbWgradArgs {
 // does not depend on scheduling.  PAIR2: second operand pair (R-op products of the HVP).
 template <int H, bool PAIR2>
 __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, const FbWgradArgs wa) {
-    constexpr int TPD = H / 32;
+    constexpr int TPD = H / 64;             // dW2 tiles of 64 x 64 outputs
     constexpr int NT2 = TPD * TPD;
     constexpr int NA = H / 32;
-    constexpr int BU = 4;                   // k-steps per load burst
-    __shared__ float red[1024 * 9];
+    constexpr int BU = 2;                   // k-steps per load burst
+    constexpr int SLOT = 64 * 65;           // one 64 x 64 partial tile (+1 column of padding)
+    __shared__ float red[4 * SLOT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FbWgradNet wn = wa.nets[blockIdx.y];
     const NetOff no = md.net[wn.net];
@@ -568,58 +569,66 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
     const int Do = md.Do, out = no.out;
 
     if (rb < NT2) {
+        // ---- dW2[j][k] += sum_r Ya[r][j] Xa[r][k] (+ Yb Xb): a 64 x 64 tile per block, 16-way split-K over
+        // the waves.  Per k-step (4 rows) a lane loads ONE float4 of each operand (256 B contiguous per
+        // row and operand) and feeds 16 MFMAs: 8 FLOP per loaded byte (32 x 32 tiles: 4 -- the kernel
+        // was L2-bandwidth bound at N = 20 000).  Lane (c, q) holds columns 4c..4c+3 of row q, so
+        // acc[t][u][r] is output (j = 4(4q+r)+t, k = 4c+u) of the tile.
         const int tj = rb / TPD, tk = rb % TPD;
-        f32x4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
-        for (int s0 = KS0 + wave; s0 < KS; s0 += 16 * BU) {       // bursts of BU k-steps per wave
-            f32x2 ya[BU], xa[BU], yb[BU], xb[BU];
+        f32x4 acc[4][4];
 #pragma unroll
-            for (int u = 0; u < BU; ++u) {
-                const int s = s0 + 16 * u;
-                ya[u] = xa[u] = yb[u] = xb[u] = f32x2{0.f, 0.f};
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s0 = KS0 + wave; s0 < KS; s0 += 16 * BU) {       // bursts of BU k-steps per wave
+            f32x4 ya[BU], xa[BU], yb[BU], xb[BU];
+#pragma unroll
+            for (int b = 0; b < BU; ++b) {
+                const int s = s0 + 16 * b;
+                ya[b] = xa[b] = yb[b] = xb[b] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (s < KS) {
                     const size_t r = (size_t)(4 * s + q) * H;
-                    ya[u] = *reinterpret_cast<const f32x2*>(wn.w2_ya + r + tj * 32 + 2 * c);
-                    xa[u] = *reinterpret_cast<const f32x2*>(wn.w2_xa + r + tk * 32 + 2 * c);
+                    ya[b] = *reinterpret_cast<const f32x4*>(wn.w2_ya + r + tj * 64 + 4 * c);
+                    xa[b] = *reinterpret_cast<const f32x4*>(wn.w2_xa + r + tk * 64 + 4 * c);
                     if constexpr (PAIR2) {
-                        yb[u] = *reinterpret_cast<const f32x2*>(wn.w2_yb + r + tj * 32 + 2 * c);
-                        xb[u] = *reinterpret_cast<const f32x2*>(wn.w2_xb + r + tk * 32 + 2 * c);
+                        yb[b] = *reinterpret_cast<const f32x4*>(wn.w2_yb + r + tj * 64 + 4 * c);
+                        xb[b] = *reinterpret_cast<const f32x4*>(wn.w2_xb + r + tk * 64 + 4 * c);
                     }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < BU; ++u) {
-                acc00 = mfma_16x16x4(ya[u][0], xa[u][0], acc00);
-                acc01 = mfma_16x16x4(ya[u][0], xa[u][1], acc01);
-                acc10 = mfma_16x16x4(ya[u][1], xa[u][0], acc10);
-                acc11 = mfma_16x16x4(ya[u][1], xa[u][1], acc11);
-                if constexpr (PAIR2) {
-                    acc00 = mfma_16x16x4(yb[u][0], xb[u][0], acc00);
-                    acc01 = mfma_16x16x4(yb[u][0], xb[u][1], acc01);
-                    acc10 = mfma_16x16x4(yb[u][1], xb[u][0], acc10);
-                    acc11 = mfma_16x16x4(yb[u][1], xb[u][1], acc11);
-                }
+            for (int b = 0; b < BU; ++b) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc[t][u] = mfma_16x16x4(ya[b][t], xa[b][u], acc[t][u]);
+                        if constexpr (PAIR2) acc[t][u] = mfma_16x16x4(yb[b][t], xb[b][u], acc[t][u]);
+                    }
             }
         }
-        float* myred = red + (wave & 7) * (32 * 33);
+        // four partial-tile slots, four rounds: waves 4k..4k+3 add into slot (wave & 3) in round k
+        float* myred = red + (wave & 3) * SLOT;
 #pragma unroll
-        for (int round = 0; round < 2; ++round) {
-            if ((wave >> 3) == round) {
+        for (int round = 0; round < 4; ++round) {
+            if ((wave >> 2) == round) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int jl = 2 * (4 * q + r);
-                    float* p00 = &myred[(jl + 0) * 33 + 2 * c];
-                    float* p10 = &myred[(jl + 1) * 33 + 2 * c];
-                    if (round == 0) { p00[0] = acc00[r]; p00[1] = acc01[r]; p10[0] = acc10[r]; p10[1] = acc11[r]; }
-                    else { p00[0] += acc00[r]; p00[1] += acc01[r]; p10[0] += acc10[r]; p10[1] += acc11[r]; }
-                }
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* p = &myred[(4 * (4 * q + r) + t) * 65 + 4 * c];
+                        if (round == 0) { p[0] = acc[t][0][r]; p[1] = acc[t][1][r]; p[2] = acc[t][2][r]; p[3] = acc[t][3][r]; }
+                        else { p[0] += acc[t][0][r]; p[1] += acc[t][1][r]; p[2] += acc[t][2][r]; p[3] += acc[t][3][r]; }
+                    }
             }
             __syncthreads();
         }
-        const int jl = tid >> 5, kl = tid & 31;
-        float v = 0.0f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) v += red[w * (32 * 33) + jl * 33 + kl];
-        gout[no.W2 + (size_t)(tj * 32 + jl) * H + tk * 32 + kl] = v;
+        for (int e0 = 0; e0 < 4096; e0 += 1024) {
+            const int e = e0 + tid, jl = e >> 6, kl = e & 63;
+            const float v = (red[jl * 65 + kl] + red[SLOT + jl * 65 + kl]) + (red[2 * SLOT + jl * 65 + kl] + red[3 * SLOT + jl * 65 + kl]);
+            gout[no.W2 + (size_t)(tj * 64 + jl) * H + tk * 64 + kl] = v;
+        }
     } else if (rb < NT2 + NA) {
         const int j0 = (rb - NT2) * 32;
         for (int k0 = 0; k0 < Do; k0 += 16) {
@@ -777,73 +786,126 @@ __global__ __launch_bounds__(256) void fb_reduce_stats_kernel(const float* __res
 // actor's device layout (length n = md.net[0].end, inter-tensor padding stays zero); p is the tangent
 // vector the HVP kernels read (with its W2 mirror), z arrives in `hz` from fb_sum_parts_kernel.
 // One 1024-thread block per step: both dot products and the three axpys, reductions in a fixed order.
-struct CgScal { float rs_old; int done; int iters; int pad; };
+struct CgScal { float rs[2]; int done; int iters; };     // rs[it & 1] = r.r entering iteration `it`
+#define CG_NB 96                                          // blocks of the CG kernels (256 threads, float4 each, grid-stride)
 
-__device__ __forceinline__ float cg_block_sum(float v, float* sh, int tid) {
+__device__ __forceinline__ float cg_block_sum256(float v, float* sh, int tid) {
     v = wave_sum(v);
     __syncthreads();
     if ((tid & 63) == 0) sh[tid >> 6] = v;
     __syncthreads();
-    float t = 0.0f;
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+// every block adds the CG_NB partials in the same fixed order (cheap, and no extra launch)
+__device__ __forceinline__ float cg_sum_parts(const float* __restrict__ part, float* sh, int tid) {
+    float v = (tid < CG_NB) ? part[tid] : 0.0f;
+    return cg_block_sum256(v, sh, tid);
+}
+
+// r = g, p = g (with the W2 mirror), x = 0 ; partial r.r
+__global__ __launch_bounds__(256) void cg_init_kernel(const float* __restrict__ g, float* __restrict__ r,
+                                                     float* __restrict__ p, float* __restrict__ x,
+                                                     CgScal* __restrict__ sc, float* __restrict__ part, int n,
+                                                     const ModelDesc md) {
+    __shared__ float sh[4];
+    const int tid = threadIdx.x;
+    float acc = 0.0f;
+    for (int i4 = (blockIdx.x * 256 + tid) * 4; i4 < n; i4 += CG_NB * 1024) {
+        const f32x4 gi = *reinterpret_cast<const f32x4*>(g + i4);
+        *reinterpret_cast<f32x4*>(r + i4) = gi;
+        *reinterpret_cast<f32x4*>(p + i4) = gi;
+        *reinterpret_cast<f32x4*>(x + i4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int mi = w2f_mirror_of(md, i4);
+        if (mi >= 0) *reinterpret_cast<f32x4*>(p + mi) = gi;
+        acc += (gi[0] * gi[0] + gi[1] * gi[1]) + (gi[2] * gi[2] + gi[3] * gi[3]);
+    }
+    const float t = cg_block_sum256(acc, sh, tid);
+    if (tid == 0) part[blockIdx.x] = t;
+    if (blockIdx.x == 0 && tid == 0) { sc->done = 0; sc->iters = 0; }
+}
+
+// z = H p + damping p (in place in hz) ; partial p.z
+__global__ __launch_bounds__(256) void cg_pz_kernel(float* __restrict__ hz, const float* __restrict__ p,
+                                                   const CgScal* __restrict__ sc, float* __restrict__ part, int n,
+                                                   float damping) {
+    __shared__ float sh[4];
+    const int tid = threadIdx.x;
+    if (sc->done) return;
+    float acc = 0.0f;
+    for (int i4 = (blockIdx.x * 256 + tid) * 4; i4 < n; i4 += CG_NB * 1024) {
+        const f32x4 pi = *reinterpret_cast<const f32x4*>(p + i4);
+        f32x4 z = *reinterpret_cast<const f32x4*>(hz + i4);
 #pragma unroll
-    for (int w = 0; w < 16; ++w) t += sh[w];
-    return t;
+        for (int e = 0; e < 4; ++e) z[e] = z[e] + pi[e] * damping;
+        *reinterpret_cast<f32x4*>(hz + i4) = z;
+        acc += (pi[0] * z[0] + pi[1] * z[1]) + (pi[2] * z[2] + pi[3] * z[3]);
+    }
+    const float t = cg_block_sum256(acc, sh, tid);
+    if (tid == 0) part[blockIdx.x] = t;
 }
 
-__global__ __launch_bounds__(1024) void cg_init_kernel(const float* __restrict__ g, float* __restrict__ r,
-                                                      float* __restrict__ p, float* __restrict__ x,
-                                                      CgScal* __restrict__ sc, int n, const ModelDesc md) {
-    __shared__ float sh[16];
+// alpha = rs_old / p.z ; x += alpha p ; r -= alpha z ; partial r.r       (rs_old = sum of part_rr when it == 0)
+__global__ __launch_bounds__(256) void cg_xr_kernel(const float* __restrict__ hz, float* __restrict__ r,
+                                                   const float* __restrict__ p, float* __restrict__ x,
+                                                   CgScal* __restrict__ sc, const float* __restrict__ part_pz,
+                                                   float* __restrict__ part_rr, int n, int it) {
+    __shared__ float sh[4];
     const int tid = threadIdx.x;
-    float part = 0.0f;
-    for (int i = tid; i < n; i += 1024) {
-        const float gi = g[i];
-        r[i] = gi; p[i] = gi; x[i] = 0.0f;
-        const int mi = w2f_mirror_of(md, i);
-        if (mi >= 0) p[mi] = gi;
-        part = fmaf(gi, gi, part);
-    }
-    const float rs = cg_block_sum(part, sh, tid);
-    if (tid == 0) { sc->rs_old = rs; sc->done = 0; sc->iters = 0; }
-}
-
-__global__ __launch_bounds__(1024) void cg_step_kernel(float* __restrict__ hz, float* __restrict__ r,
-                                                      float* __restrict__ p, float* __restrict__ x,
-                                                      CgScal* __restrict__ sc, int n, float damping, float tol,
-                                                      const ModelDesc md) {
-    __shared__ float sh[16];
-    const int tid = threadIdx.x;
-    if (sc->done) return;                                  // converged earlier: x is final
-    const float rs_old = sc->rs_old;
-    float part = 0.0f;
-    for (int i = tid; i < n; i += 1024) {                  // z = H p + damping p ;  p.z
-        const float pi = p[i];
-        const float z = hz[i] + pi * damping;
-        hz[i] = z;
-        part = fmaf(pi, z, part);
-    }
-    const float pAp = cg_block_sum(part, sh, tid);
+    if (sc->done) return;
+    float rs_old;
+    if (it == 0) rs_old = cg_sum_parts(part_rr, sh, tid);         // r.r of cg_init_kernel
+    else rs_old = sc->rs[it & 1];
+    __syncthreads();
+    const float pAp = cg_sum_parts(part_pz, sh, tid);
+    __syncthreads();
     const float alpha = rs_old / pAp;
-    part = 0.0f;
-    for (int i = tid; i < n; i += 1024) {                  // x += alpha p ; r -= alpha z ; r.r
-        x[i] = x[i] + alpha * p[i];
-        const float ri = r[i] - alpha * hz[i];
-        r[i] = ri;
-        part = fmaf(ri, ri, part);
+    float acc = 0.0f;
+    for (int i4 = (blockIdx.x * 256 + tid) * 4; i4 < n; i4 += CG_NB * 1024) {
+        const f32x4 pi = *reinterpret_cast<const f32x4*>(p + i4);
+        const f32x4 z = *reinterpret_cast<const f32x4*>(hz + i4);
+        f32x4 xi = *reinterpret_cast<const f32x4*>(x + i4), ri = *reinterpret_cast<const f32x4*>(r + i4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xi[e] = xi[e] + alpha * pi[e]; ri[e] = ri[e] - alpha * z[e]; }
+        *reinterpret_cast<f32x4*>(x + i4) = xi;
+        *reinterpret_cast<f32x4*>(r + i4) = ri;
+        acc += (ri[0] * ri[0] + ri[1] * ri[1]) + (ri[2] * ri[2] + ri[3] * ri[3]);
     }
-    const float rs_new = cg_block_sum(part, sh, tid);
-    if (rs_new < tol) {
-        if (tid == 0) { sc->done = 1; sc->iters += 1; }
+    __syncthreads();
+    const float t = cg_block_sum256(acc, sh, tid);
+    // the new partials must not overwrite part_rr while other blocks still read it at it == 0:
+    // they go to the second half of the buffer on even iterations, the first half on odd ones
+    if (tid == 0) part_rr[((it & 1) ? 0 : CG_NB) + blockIdx.x] = t;
+    if (blockIdx.x == 0 && tid == 0 && it == 0) sc->rs[0] = rs_old;
+}
+
+// rs_new = sum partials ; converged -> done ; else p = r + (rs_new / rs_old) p (with the W2 mirror)
+__global__ __launch_bounds__(256) void cg_p_kernel(const float* __restrict__ r, float* __restrict__ p,
+                                                  CgScal* __restrict__ sc, const float* __restrict__ part_rr, int n,
+                                                  int it, float tol, const ModelDesc md) {
+    __shared__ float sh[4];
+    const int tid = threadIdx.x;
+    if (sc->done) return;
+    const float rs_new = cg_sum_parts(part_rr + ((it & 1) ? 0 : CG_NB), sh, tid);
+    __syncthreads();
+    float rs_old = sc->rs[it & 1];
+    if (it == 0) rs_old = cg_sum_parts(part_rr, sh, tid);          // sc->rs[0] is written by a sibling launch's block 0 only
+    if (rs_new < tol) {                                            // every block takes the same branch
+        if (blockIdx.x == 0 && tid == 0) { sc->rs[(it + 1) & 1] = rs_new; sc->iters = it + 1; }
+        // `done` is raised by the NEXT launch's view: write it last, nobody in this launch reads it again
+        if (blockIdx.x == 0 && tid == 0) { __threadfence(); sc->done = 1; }
         return;
     }
     const float beta = rs_new / rs_old;
-    for (int i = tid; i < n; i += 1024) {                  // p = r + beta p  (and its W2 mirror)
-        const float pn = r[i] + beta * p[i];
-        p[i] = pn;
-        const int mi = w2f_mirror_of(md, i);
-        if (mi >= 0) p[mi] = pn;
+    for (int i4 = (blockIdx.x * 256 + tid) * 4; i4 < n; i4 += CG_NB * 1024) {
+        const f32x4 ri = *reinterpret_cast<const f32x4*>(r + i4);
+        f32x4 pi = *reinterpret_cast<const f32x4*>(p + i4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pi[e] = ri[e] + beta * pi[e];
+        *reinterpret_cast<f32x4*>(p + i4) = pi;
+        const int mi = w2f_mirror_of(md, i4);
+        if (mi >= 0) *reinterpret_cast<f32x4*>(p + mi) = pi;
     }
-    if (tid == 0) { sc->rs_old = rs_new; sc->iters += 1; }
+    if (blockIdx.x == 0 && tid == 0) { sc->rs[(it + 1) & 1] = rs_new; sc->iters = it + 1; }
 }
 
 // full-batch advantage normalisation (CPO cpo.py:127-131, TRPO trpo_lag.py:129-133): per critic
