@@ -176,6 +176,7 @@ static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int n
     int rc = ensure_parts(c, stride, pl.nsplit);
     if (rc) return rc;
     wa.out = c->wg_parts; wa.ks_per_split = pl.ks_per_split; wa.split_stride = stride;
+    { const char* e = getenv("FSRL_WGRAD_SKIP"); wa.dbg_skip = e ? atoi(e) : 0; }
     *nsplit = pl.nsplit;
     return dispatch_H(c->cfg.hidden, [&](auto hc) {
         constexpr int HH = decltype(hc)::value;

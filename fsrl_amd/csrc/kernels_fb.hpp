@@ -544,6 +544,7 @@ struct FbWgradArgs {
     int N;
     int ks_per_split;    // k-steps (4 rows each) per blockIdx.z
     int split_stride;    // floats between the partial gradients of consecutive splits
+    int dbg_skip;        // timing experiments: bit0 skip dW2 tiles, bit1 skip aux blocks, bit2 skip the db3 block
 };
 
 // Weight-side products over a row range.  grid = (NT2 + NA + 1, ny, nsplit): blockIdx.z owns the rows
@@ -568,6 +569,8 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
     const int c = lane & 15, q = lane >> 4;
     const int Do = md.Do, out = no.out;
 
+    if (wa.dbg_skip && ((rb < NT2 && (wa.dbg_skip & 1)) || (rb >= NT2 && rb < NT2 + NA && (wa.dbg_skip & 2)) ||
+                        (rb >= NT2 + NA && (wa.dbg_skip & 4)))) return;
     if (rb < NT2) {
         // ---- dW2[j][k] += sum_r Ya[r][j] Xa[r][k] (+ Yb Xb): a 64 x 64 tile per block, 16-way split-K over
         // the waves.  Per k-step (4 rows) a lane loads ONE float4 of each operand (256 B contiguous per
