@@ -127,6 +127,8 @@ struct fsrl_ctx {
     struct Parts { int stride = 0; float* p = nullptr; size_t floats = 0; } parts[3];
     float* wg_parts = nullptr;      // the buffer the last wgrad_launch wrote
     int n_cus = 256;                // compute units of the device (tile-shape heuristic)
+    std::vector<int> perm_tmp;      // this pass's permutation before it goes to the pinned buffer
+    hipEvent_t perm_copied = nullptr; bool perm_in_flight = false;
     uint64_t store_version = 1;     // bumped by every push / reset (device copies of the bookkeeping)
     struct TrState* tr = nullptr;   // trust-region (CPO / TRPO-Lag) working set, owned
     void* sac = nullptr;            // SacState, owned
@@ -261,7 +263,7 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
         for (void* p : dp) if (p) (void)hipFree(p);
         if (s.done) (void)hipEventDestroy(s.done);
     }
-    for (hipEvent_t e : {c->store_ready, c->ev_a, c->ev_b, c->ev_c}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {c->store_ready, c->ev_a, c->ev_b, c->ev_c, c->perm_copied}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->k_ev) (void)hipEventDestroy(e);
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -340,6 +342,7 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     }
     TRY(hipEventCreateWithFlags(&c->store_ready, hipEventDisableTiming));
     TRY(hipEventCreate(&c->ev_a)); TRY(hipEventCreate(&c->ev_b)); TRY(hipEventCreate(&c->ev_c));
+    TRY(hipEventCreateWithFlags(&c->perm_copied, hipEventDisableTiming));
     CtrlBlock init{INT_MAX, 0, 0.0, 0.0f, 0.0f};
     TRY(hipMemcpy(c->ctrl, &init, sizeof(init), hipMemcpyHostToDevice));
 #undef TRY
@@ -361,12 +364,13 @@ extern "C" int64_t fsrl_param_count(const fsrl_ctx* c) { return c ? c->n_api : 0
 static int copy_flat(fsrl_ctx* c, float* dev, float* host_out, const float* host_in, int64_t n) {
     CHECK_ARG(n == c->n_api, "expected %lld parameters, got %lld", (long long)c->n_api, (long long)n);
     HIPCHK(hipSetDevice(c->device));
-    std::vector<float> tmp((size_t)c->n_alloc, 0.0f);
+    std::vector<float> tmp((size_t)c->n_dev, 0.0f);
     if (host_in) {                              // only P is ever written from the host
         for (const TensorMap& t : c->tmap) memcpy(&tmp[t.dev_off], host_in + t.api_off, (size_t)t.n * 4);
-        fill_mirrors(c->md, tmp);
         HIPCHK(hipStreamSynchronize(c->compute));
-        HIPCHK(hipMemcpy(dev, tmp.data(), (size_t)c->n_alloc * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dev, tmp.data(), (size_t)c->n_dev * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(w2f_sync_kernel, dim3(192), dim3(256), 0, c->compute, dev, c->md);   // W2 mirrors
+        HIPCHK(hipGetLastError());
     } else {
         HIPCHK(hipStreamSynchronize(c->compute));
         HIPCHK(hipMemcpy(tmp.data(), dev, (size_t)c->n_dev * 4, hipMemcpyDeviceToHost));
@@ -815,28 +819,34 @@ extern "C" int fsrl_ppo_pass(fsrl_ctx* c, const int64_t* perm, uint64_t seed, in
     if (n == 0) return 0;
     hipStream_t s = c->compute;
     const int C = c->cfg.n_critics, H = c->cfg.hidden, nn = c->md.n_nets;
-    // ---- permutation of this pass (np.random.permutation on the caller side, or our own)
-    HIPCHK(hipStreamSynchronize(s));   // h_perm (pinned) may still be in flight from the last pass
+    // ---- permutation of this pass (np.random.permutation on the caller side, or our own), built in
+    //      pageable memory first: the GPU keeps working on the previous pass meanwhile.  Only the previous
+    //      H2D copy out of the pinned buffer has to be over (an event, not a stream drain).
+    c->perm_tmp.resize((size_t)n);
     if (perm) {
         std::vector<uint8_t> seen((size_t)n, 0);
         for (int i = 0; i < n; ++i) {
             CHECK_ARG(perm[i] >= 0 && perm[i] < n, "perm[%d]=%lld out of range", i, (long long)perm[i]);
             CHECK_ARG(!seen[(size_t)perm[i]], "perm is not a permutation: %lld appears twice", (long long)perm[i]);
             seen[(size_t)perm[i]] = 1;
-            c->h_perm[i] = (int)perm[i];
+            c->perm_tmp[(size_t)i] = (int)perm[i];
         }
     } else {
         if (seed) { c->rng[0] ^= seed; c->rng[1] += seed * 0x9E3779B97F4A7C15ull; }
-        for (int i = 0; i < n; ++i) c->h_perm[i] = i;
+        for (int i = 0; i < n; ++i) c->perm_tmp[(size_t)i] = i;
         for (int i = n - 1; i > 0; --i) {
             const int j = (int)(xoshiro_next(c->rng) % (uint64_t)(i + 1));
-            std::swap(c->h_perm[i], c->h_perm[j]);
+            std::swap(c->perm_tmp[(size_t)i], c->perm_tmp[(size_t)j]);
         }
     }
+    if (c->perm_in_flight) { HIPCHK(hipEventSynchronize(c->perm_copied)); c->perm_in_flight = false; }
+    memcpy(c->h_perm, c->perm_tmp.data(), (size_t)n * 4);
     const int nmb = (int)c->mb_start.size();
     int rc = ensure_stats(c, c->n_steps + nmb);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->d_perm, c->h_perm, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(c->perm_copied, s));
+    c->perm_in_flight = true;
     {
         PrepArgs pa{};
         pa.obs = c->b.obs; pa.act = c->b.act; pa.advs = c->advs; pa.rets = c->rets; pa.logp_old = c->logp_old;

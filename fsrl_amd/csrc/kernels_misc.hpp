@@ -196,6 +196,17 @@ __global__ __launch_bounds__(1024) void ppo_prepare_pass_kernel(const PrepArgs a
 }
 
 // ---------------------------------------------------------------- grad clip + Adam
+// rebuild the forward-fragment mirrors of every W2 from the row-major matrices (after a host upload)
+__global__ __launch_bounds__(256) void w2f_sync_kernel(float* __restrict__ P, const ModelDesc md) {
+    const int H = md.H, q4 = H * H / 4;                       // float4 groups per network
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < md.n_nets * q4; e += gridDim.x * 256) {
+        const int net = e / q4, g = e - net * q4;
+        const int n = (4 * g) / H, k = (4 * g) - n * H;       // 4 consecutive k of row n = one mirror float4
+        const f32x4 v = *reinterpret_cast<const f32x4*>(P + md.net[net].W2 + (size_t)n * H + k);
+        *reinterpret_cast<f32x4*>(P + md.net[net].W2f + w2f_index(H, n, k)) = v;
+    }
+}
+
 #ifndef ADAM_NT
 #define ADAM_NT 256
 #endif
