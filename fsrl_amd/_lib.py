@@ -7,7 +7,7 @@ LIB_PATH = os.path.join(_HERE, "libfsrl_hip.so")
 
 FSRL_OK, FSRL_EINVAL, FSRL_ENOMEM, FSRL_EHIP, FSRL_ESTATE = 0, -22, -12, -5, -1
 PPO_NSTATS = 11
-ALGO_PPO_LAG, ALGO_TRPO_LAG, ALGO_CPO, ALGO_SAC_LAG = 0, 1, 2, 3
+ALGO_PPO_LAG, ALGO_TRPO_LAG, ALGO_CPO, ALGO_SAC_LAG, ALGO_FOCOPS = 0, 1, 2, 3, 4
 
 
 class Config(C.Structure):
@@ -37,7 +37,13 @@ class SacConfig(C.Structure):
                 ("exploration_sigma", C.c_float)]
 
 
-CPO_NSTATS, TRPO_NSTATS, SAC_NSTATS = 17, 11, 10
+class FocopsConfig(C.Structure):
+    """struct fsrl_focops_config (include/fsrl_hip.h)"""
+    _fields_ = [("actor_lr", C.c_float), ("critic_lr", C.c_float), ("l2_reg", C.c_float), ("delta", C.c_float),
+                ("eta", C.c_float), ("tem_lambda", C.c_float), ("max_grad_norm", C.c_float)]
+
+
+CPO_NSTATS, TRPO_NSTATS, SAC_NSTATS, FOCOPS_NSTATS = 17, 11, 10, 8
 
 _P = C.POINTER
 _f, _d, _u8, _i32, _i64 = _P(C.c_float), _P(C.c_double), _P(C.c_uint8), _P(C.c_int32), _P(C.c_int64)
@@ -74,6 +80,8 @@ SIGNATURES = {
     "fsrl_tr_grad": (C.c_int, [_ctx, C.c_int32, _f, C.c_int64]),
     "fsrl_tr_hvp": (C.c_int, [_ctx, _f, _f, C.c_int64]),
     "fsrl_tr_eval": (C.c_int, [_ctx, _d]),
+    "fsrl_focops_init": (C.c_int, [_ctx, _P(FocopsConfig)]),
+    "fsrl_focops_set_nu": (C.c_int, [_ctx, C.c_double, C.c_double]),
     "fsrl_sac_init": (C.c_int, [_ctx, _P(SacConfig)]),
     "fsrl_sac_param_count": (C.c_int64, [_ctx, C.c_int32]),
     "fsrl_sac_params_set": (C.c_int, [_ctx, _f, C.c_int64, _f, C.c_int64, C.c_float]),

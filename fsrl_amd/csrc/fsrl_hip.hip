@@ -127,6 +127,9 @@ struct fsrl_ctx {
     struct Parts { int stride = 0; float* p = nullptr; size_t floats = 0; } parts[3];
     float* wg_parts = nullptr;      // the buffer the last wgrad_launch wrote
     int n_cus = 256;                // compute units of the device (tile-shape heuristic)
+    struct FocState* foc = nullptr; // FOCOPS working set, owned
+    float* mu_old = nullptr;        // [maxsize][Da] actor means at process time (FOCOPS)
+    float* sigma_old = nullptr;     // [FSRL_MAX_ACT] sigma_param at process time (FOCOPS)
     std::vector<int> perm_tmp;      // this pass's permutation before it goes to the pinned buffer
     hipEvent_t perm_copied = nullptr; bool perm_in_flight = false;
     uint64_t store_version = 1;     // bumped by every push / reset (device copies of the bookkeeping)
@@ -135,6 +138,8 @@ struct fsrl_ctx {
 };
 static void sac_free(fsrl_ctx* c);
 static void tr_free(fsrl_ctx* c);
+static void foc_free(fsrl_ctx* c);
+static int focops_pass(fsrl_ctx* c, int32_t* stopped_out);
 
 static int ensure_scratch(fsrl_ctx* c, size_t bytes) {
     if (c->scratch_bytes >= bytes) return 0;
@@ -246,6 +251,9 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
     (void)hipDeviceSynchronize();
     tr_free(c);
     sac_free(c);
+    foc_free(c);
+    if (c->mu_old) (void)hipFree(c->mu_old);
+    if (c->sigma_old) (void)hipFree(c->sigma_old);
     void* dptrs[] = {c->P, c->M, c->V, c->G, c->ctrl, c->st.obs, c->st.obs_next, c->st.act, c->st.rew,
                      c->st.cost, c->st.flags, c->b.obs, c->b.obs_next, c->b.act, c->b.rew, c->b.cost,
                      c->b.flags, c->d_indices, c->d_end, c->d_seg, c->values, c->vnext, c->advs,
@@ -274,7 +282,7 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
 extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx** out) {
     CHECK_ARG(cfg && out, "null argument");
     CHECK_ARG(cfg->algo == FSRL_ALGO_PPO_LAG || cfg->algo == FSRL_ALGO_SAC_LAG || cfg->algo == FSRL_ALGO_CPO ||
-                  cfg->algo == FSRL_ALGO_TRPO_LAG, "unknown algo %d", cfg->algo);
+                  cfg->algo == FSRL_ALGO_TRPO_LAG || cfg->algo == FSRL_ALGO_FOCOPS, "unknown algo %d", cfg->algo);
     CHECK_ARG(cfg->obs_dim >= 1 && cfg->obs_dim <= FSRL_MAX_OBS, "obs_dim must be in [1,%d]", FSRL_MAX_OBS);
     CHECK_ARG(cfg->act_dim >= 1 && cfg->act_dim <= FSRL_MAX_ACT, "act_dim must be in [1,%d]", FSRL_MAX_ACT);
     CHECK_ARG(cfg->hidden == 64 || cfg->hidden == 128 || cfg->hidden == 256,
@@ -759,6 +767,14 @@ extern "C" int fsrl_ppo_begin(fsrl_ctx* c, const double* lagrangians, double res
     InferArgs ia{};
     ia.obs = c->b.obs; ia.obs_next = c->b.obs_next; ia.act = c->b.act; ia.flags = c->b.flags;
     ia.values = c->values; ia.vnext = c->vnext; ia.logp_old = c->logp_old; ia.mu_out = nullptr;
+    if (c->cfg.algo == FSRL_ALGO_FOCOPS) {      // old distribution of the pass batches: means + sigma_param snapshot
+        if (!c->mu_old) {
+            HIPCHK(hipMalloc(&c->mu_old, (size_t)c->maxsize * Da * 4));
+            HIPCHK(hipMalloc(&c->sigma_old, FSRL_MAX_ACT * 4));
+        }
+        ia.mu_out = c->mu_old;
+        HIPCHK(hipMemcpyAsync(c->sigma_old, c->P + c->md.net[0].sigma, (size_t)Da * 4, hipMemcpyDeviceToDevice, s));
+    }
     ia.N = (int)n; ia.C = C; ia.max_action = c->cfg.max_action;
     rc = launch_infer(c, ia, 2 * C + 1, s);
     if (rc) return rc;
@@ -853,9 +869,11 @@ extern "C" int fsrl_ppo_pass(fsrl_ctx* c, const int64_t* perm, uint64_t seed, in
         pa.perm = c->d_perm; pa.mb_start = c->d_mbstart; pa.mb_size = c->d_mbsize; pa.obs_p = c->obs_p;
         pa.rd_p = c->rd_p; pa.N = n; pa.C = C; pa.Do = c->cfg.obs_dim; pa.Da = c->cfg.act_dim;
         pa.norm_adv = c->cfg.norm_adv;
+        pa.mean_old = (c->cfg.algo == FSRL_ALGO_FOCOPS) ? c->mu_old : nullptr; pa.sigma_old = c->sigma_old;
         hipLaunchKernelGGL(ppo_prepare_pass_kernel, dim3(nmb), dim3(1024), 0, s, pa);
         HIPCHK(hipGetLastError());
     }
+    if (c->cfg.algo == FSRL_ALGO_FOCOPS) return focops_pass(c, stopped_out);
     PpoBatchPtrs bp{};
     bp.obs_p = c->obs_p; bp.rd_p = c->rd_p; bp.A1 = c->A1; bp.A2 = c->A2; bp.D1 = c->D1; bp.D2 = c->D2;
     bp.DO = c->DO; bp.statp = c->statp; bp.mbp_max = c->mbp_max;
@@ -1554,6 +1572,141 @@ extern "C" int fsrl_trpo_learn(fsrl_ctx* c, const double* lagrangians, double re
         st[0] = resc; st[1] = lam0; st[2] = loss_safety; st[3] = loss_rew; st[4] = loss_actor;
         st[5] = vf[0]; st[6] = vf[1]; st[7] = vf[0] + vf[1]; st[8] = kl; st[9] = step; st[10] = ent;
     }
+    return 0;
+}
+
+// ====================================================================================== FOCOPS
+struct FocState {
+    fsrl_focops_config cfg{};
+    double nu = 0.0, nu_loss = 0.0;
+    int64_t t_actor = 0, t_critic = 0;
+    float *statp_vf = nullptr, *statp_pi = nullptr, *psq = nullptr, *gsq = nullptr;
+    int cap_tiles = 0, cap_psq = 0;
+};
+static void foc_free(fsrl_ctx* c) {
+    FocState* f = c->foc;
+    if (!f) return;
+    for (float* p : {f->statp_vf, f->statp_pi, f->psq, f->gsq}) if (p) (void)hipFree(p);
+    delete f;
+    c->foc = nullptr;
+}
+extern "C" int fsrl_focops_init(fsrl_ctx* c, const fsrl_focops_config* cfg) {
+    CHECK_ARG(c && cfg, "null argument");
+    CHECK_ARG(c->cfg.algo == FSRL_ALGO_FOCOPS, "context was not created with FSRL_ALGO_FOCOPS");
+    CHECK_ARG(c->cfg.n_critics == 2, "FOCOPS uses a reward and a cost critic");
+    CHECK_ARG(cfg->tem_lambda > 0.0f, "tem_lambda must be positive");
+    foc_free(c);
+    c->foc = new FocState();
+    c->foc->cfg = *cfg;
+    return 0;
+}
+extern "C" int fsrl_focops_set_nu(fsrl_ctx* c, double nu, double nu_loss) {
+    CHECK_ARG(c, "null ctx");
+    if (!c->foc) return fail(FSRL_ESTATE, "fsrl_focops_init first");
+    c->foc->nu = nu; c->foc->nu_loss = nu_loss;
+    return 0;
+}
+
+// one pass of FOCOPS minibatch steps over the batch prepared by fsrl_ppo_pass (permuted rows, per-minibatch
+// normalised advantages, old means / stds in the row data).  Per minibatch (focops.py:226-241):
+//   critics:  fb_tile(VF, 2 nets) -> fb_wgrad -> Adam per critic (+ l2, records sum(theta^2))
+//   actor:    fb_tile(FOCOPS)     -> fb_wgrad -> sum (+ ||g||^2 partials) -> clip + Adam
+//   stats row + pass KL sum (focops_finalize_kernel)
+static int focops_pass(fsrl_ctx* c, int32_t* stopped_out) {
+    FocState* f = c->foc;
+    if (!f) return fail(FSRL_ESTATE, "fsrl_focops_init first");
+    hipStream_t s = c->compute;
+    const int H = c->cfg.hidden, Do = c->cfg.obs_dim;
+    const int nmb = (int)c->mb_start.size();
+    const int max_tiles = c->mbp_max / 16;
+    const int nb_c0 = (c->md.net[1].end - c->md.net[1].begin + 255) / 256, nb_c1 = (c->md.net[2].end - c->md.net[2].begin + 255) / 256;
+    const int nb_a = (c->md.net[0].end - c->md.net[0].begin + 255) / 256;
+    if (f->cap_tiles < max_tiles || f->cap_psq < nb_c0 + nb_c1) {
+        HIPCHK(hipStreamSynchronize(s));
+        for (float** p : {&f->statp_vf, &f->statp_pi, &f->psq, &f->gsq}) { if (*p) HIPCHK(hipFree(*p)); *p = nullptr; }
+        HIPCHK(hipMalloc(&f->statp_vf, (size_t)(4 * max_tiles + 4) * 2 * FB_NSTAT * 4));
+        HIPCHK(hipMalloc(&f->statp_pi, (size_t)(4 * max_tiles + 4) * FB_NSTAT * 4));
+        HIPCHK(hipMalloc(&f->psq, (size_t)(nb_c0 + nb_c1) * 4));
+        HIPCHK(hipMalloc(&f->gsq, (size_t)nb_a * 4));
+        f->cap_tiles = max_tiles; f->cap_psq = nb_c0 + nb_c1;
+    }
+    const double b1 = c->cfg.beta1, b2 = c->cfg.beta2;
+    for (int mb = 0; mb < nmb; ++mb) {
+        const int start = c->mb_start[(size_t)mb], size = c->mb_size[(size_t)mb];
+        const int tiles = (size + 15) / 16, rows_pad = tiles * 16;
+        FbArgs a{};
+        a.obs = c->obs_p + (size_t)start * Do; a.rd = c->rd_p + (size_t)start * FSRL_RD;
+        a.A1 = c->A1; a.A2 = c->A2; a.D1 = c->D1; a.D2 = c->D2; a.DO = c->DO;
+        a.N = size; a.rows_pad = rows_pad; a.max_action = c->cfg.max_action;
+        auto tile = [&](int mode, int net0, int ny, float* statp) -> int {
+            a.mode = mode; a.net0 = net0; a.statp = statp;
+            const bool rows4 = 4 * tiles * ny <= c->n_cus;
+            return dispatch_H(H, [&](auto hc) {
+                constexpr int HH = decltype(hc)::value;
+                if (rows4) hipLaunchKernelGGL((fb_tile_kernel<HH, 4>), dim3(4 * tiles, ny), dim3(4 * HH), 0, s, c->P, c->md, a);
+                else hipLaunchKernelGGL((fb_tile_kernel<HH, 16>), dim3(tiles, ny), dim3(4 * HH), 0, s, c->P, c->md, a);
+                HIPCHK(hipGetLastError());
+                return 0;
+            });
+        };
+        auto wgrad = [&](int net0, int ny, int* nsplit) -> int {
+            FbWgradArgs wa{};
+            for (int y = 0; y < ny; ++y) {
+                const size_t nb = (size_t)y * rows_pad;
+                FbWgradNet& wn = wa.nets[y];
+                wn.w2_ya = c->D2 + nb * H; wn.w2_xa = c->A1 + nb * H; wn.w1_y = c->D1 + nb * H;
+                wn.w3_xa = c->A2 + nb * H; wn.w3_ya = c->DO + nb * FSRL_DOW;
+                wn.b1_src = c->D1 + nb * H; wn.b2_src = c->D2 + nb * H; wn.do_src = c->DO + nb * FSRL_DOW;
+                wn.net = net0 + y;
+            }
+            wa.obs = a.obs; wa.rows = rows_pad; wa.N = size;
+            return wgrad_launch<false>(c, c->md, wa, ny, c->n_dev, nsplit);
+        };
+        auto adam = [&](int net, float lr, int64_t t, float l2, const float* G, int nparts, const float* gsq, int n_gsq,
+                        float max_norm, float* psq) {
+            const int begin = c->md.net[net].begin, end = c->md.net[net].end;
+            const double bc1 = 1.0 - std::pow(b1, (double)t), bc2 = 1.0 - std::pow(b2, (double)t);
+            hipLaunchKernelGGL(adam_range_kernel, dim3((end - begin + 255) / 256), dim3(256), 0, s, c->P, c->M, c->V, G, begin, end,
+                               l2, (float)(1.0 - b1), c->cfg.beta2, (float)(1.0 - b2), (float)((double)lr / bc1),
+                               (float)std::sqrt(bc2), c->cfg.adam_eps, nparts, c->n_dev, c->md, gsq, n_gsq, max_norm, psq);
+        };
+        // ---- critics (their own optimiser; L2 inside the loss)
+        int rc = tile(FB_MODE_VF, 1, 2, f->statp_vf);
+        if (rc) return rc;
+        int nsplit = 1;
+        rc = wgrad(1, 2, &nsplit);
+        if (rc) return rc;
+        f->t_critic += 1;
+        adam(1, f->cfg.critic_lr, f->t_critic, f->cfg.l2_reg, c->wg_parts, nsplit, nullptr, 0, 0.0f, f->psq);
+        adam(2, f->cfg.critic_lr, f->t_critic, f->cfg.l2_reg, c->wg_parts, nsplit, nullptr, 0, 0.0f, f->psq + nb_c0);
+        // ---- actor
+        a.cr = 1.0f / f->cfg.tem_lambda; a.cc = (float)f->nu; a.eta = f->cfg.eta;
+        rc = tile(FB_MODE_FOCOPS, 0, 1, f->statp_pi);
+        if (rc) return rc;
+        rc = wgrad(0, 1, &nsplit);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fb_sum_parts_kernel, dim3(nb_a), dim3(256), 0, s, c->G, c->wg_parts, c->md.net[0].begin,
+                           c->md.net[0].end, nsplit, c->n_dev, f->gsq);
+        // ---- logged row, pass KL sum, pass-level early stop flag
+        FocopsFinalArgs fa{};
+        const bool rows4_vf = 4 * tiles * 2 <= c->n_cus, rows4_pi = 4 * tiles <= c->n_cus;
+        fa.statp_vf = f->statp_vf; fa.statp_pi = f->statp_pi; fa.psq0 = f->psq; fa.psq1 = f->psq + nb_c0;
+        fa.n_psq0 = nb_c0; fa.n_psq1 = nb_c1; fa.P = c->P; fa.sigma_off = c->md.net[0].sigma; fa.Da = c->cfg.act_dim;
+        fa.stats = c->d_stats + (size_t)(c->n_steps + mb) * FSRL_PPO_NSTATS; fa.ctrl = c->ctrl;
+        fa.n_tiles = rows4_vf ? 4 * tiles : tiles; fa.mb = size; fa.first_in_pass = mb == 0; fa.last_in_pass = mb == nmb - 1;
+        fa.iters_in_pass = nmb; fa.pass = (int)c->pass_index; fa.l2 = f->cfg.l2_reg; fa.nu_loss = (float)f->nu_loss;
+        fa.nu_value = (float)f->nu; fa.delta = f->cfg.delta;
+        fa.n_tiles_pi = rows4_pi ? 4 * tiles : tiles;
+        hipLaunchKernelGGL(focops_finalize_kernel, dim3(1), dim3(64), 0, s, fa);   // entropy of the PRE-update policy
+        HIPCHK(hipGetLastError());
+        f->t_actor += 1;
+        adam(0, f->cfg.actor_lr, f->t_actor, 0.0f, c->G, 1, f->gsq, nb_a, f->cfg.max_grad_norm, nullptr);
+    }
+    c->n_steps += nmb;
+    c->pass_index += 1;
+    HIPCHK(hipMemcpyAsync(c->h_ctrl, c->ctrl, sizeof(CtrlBlock), hipMemcpyDeviceToHost, s));   // the reference's `break`
+    HIPCHK(hipStreamSynchronize(s));
+    if (c->h_ctrl->stopped_after != INT_MAX && stopped_out) *stopped_out = 1;
     return 0;
 }
 

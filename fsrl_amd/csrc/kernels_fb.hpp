@@ -19,6 +19,7 @@
 #define FB_MODE_Q_TRAIN 4 // SAC Q-nets: d/dtheta mean((Q - y_i)^2), i = net >> 1 ; also writes Q
 #define FB_MODE_Q_FWD 5   // SAC Q-nets: forward only, writes Q
 #define FB_MODE_Q_DIN 6   // SAC Q-nets: backward to the action input with min-routing coefficients
+#define FB_MODE_FOCOPS 7  // actor: d/dtheta mean((KL(new||old) - cr * ratio * (A_r - cc * A_c)) * [KL <= eta])  (focops.py:179-203)
 #define FB_NSTAT 8
 
 struct FbArgs {
@@ -36,6 +37,7 @@ struct FbArgs {
     const float* qin;     // [nets][N] Q values of all nets          (Q_DIN: min routing)
     float* da_out;        // [nets][N][act_cols] dL/da contributions (Q_DIN)
     int act_cols;         // number of action columns at the end of x
+    float eta;            // FOCOPS: rows whose KL(new||old) exceeds eta drop out of the loss
     int pair_shift;       // Q_TRAIN target of net n is tgt[n >> pair_shift]: 1 = double critics (SAC), 0 = single (DDPG)
 };
 
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
     __syncthreads();
     tile_forward<H, R>(sm, P, no, Do, tid, wf);
     const bool backward = (a.mode != FB_MODE_EVAL && a.mode != FB_MODE_Q_FWD);
+    const bool qmode = a.mode >= FB_MODE_Q_TRAIN && a.mode <= FB_MODE_Q_DIN;
 
     float wb[H / 16][4];
     if (backward) {
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
         float st[FB_NSTAT];
 #pragma unroll
         for (int k = 0; k < FB_NSTAT; ++k) st[k] = 0.0f;
-        if (net == 0 && a.mode < FB_MODE_Q_TRAIN) {
+        if (net == 0 && !qmode) {
             float th = 0.f, var = 1.f, df = 0.f, lp = 0.f, klp = 0.f, dmu = 0.f, so2 = 0.f;
             if (d < Da) {
                 th = tanhf(sm.out[i * FSRL_MAX_ACT + d]);
@@ -186,6 +189,13 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
                 const float var_ratio = (so / sig) * (so / sig);
                 const float t1 = (dmu / sig) * (dmu / sig);
                 klp = 0.5f * (var_ratio + t1 - 1.0f - logf(var_ratio));
+                if (a.mode == FB_MODE_FOCOPS) {          // KL(new || old): _kl_normal_normal(p = new, q = old)
+                    const float vr = (sig / so) * (sig / so);
+                    const float t1n = (dmu / so) * (dmu / so);
+                    klp = 0.5f * (vr + t1n - 1.0f - logf(vr));
+                    so2 = vr;                             // reused below: d KL / d log sigma_new = vr - 1
+                    dmu = dmu / (so * so);                // d KL / d mu_new
+                }
             }
             float logp = 0.0f, klrow = 0.0f;
             for (int dd = 0; dd < Da; ++dd) {
@@ -203,13 +213,21 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
                 } else if (a.mode == FB_MODE_KL) {
                     sm.dout[i * FSRL_DOW + d] = (dmu / var) * invN * a.max_action * (1.0f - th * th);
                     sm.dout[i * FSRL_DOW + 16 + d] = (1.0f - (so2 + dmu * dmu) / var) * invN;
+                } else if (a.mode == FB_MODE_FOCOPS) {
+                    // loss_row = (KL - cr * ratio * (A_r - cc * A_c)) * mask ; cr = 1/lambda, cc = nu
+                    const float mask = (klrow <= a.eta) ? invN : 0.0f;
+                    const float dL_dlogp = -a.cr * (ar - a.cc * ac) * ratio;
+                    sm.dout[i * FSRL_DOW + d] = (dL_dlogp * (df / var) + dmu) * a.max_action * (1.0f - th * th) * mask;
+                    sm.dout[i * FSRL_DOW + 16 + d] = (dL_dlogp * (df * df / var - 1.0f) + (so2 - 1.0f)) * mask;
                 }
             }
             if (valid) {
                 st[0] = ratio * ar; st[1] = ratio * ac; st[2] = klrow; st[3] = lpo - logp;
                 st[4] = ar; st[5] = ac;
+                if (a.mode == FB_MODE_FOCOPS)
+                    st[0] = (klrow <= a.eta) ? (klrow - a.cr * ratio * (ar - a.cc * ac)) : 0.0f;
             }
-        } else if (a.mode >= FB_MODE_Q_TRAIN) {
+        } else if (qmode) {
             const float qv = sm.out[i * FSRL_MAX_ACT];
             const int r = row0 + i;
             if (valid && d == 0) {
@@ -762,12 +780,22 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
 
 // out[i] = sum_z parts[z * stride + i], z ascending (fixed order), i in [begin, end)
 __global__ __launch_bounds__(256) void fb_sum_parts_kernel(float* __restrict__ out, const float* __restrict__ parts,
-                                                          int begin, int end, int nparts, int stride) {
+                                                          int begin, int end, int nparts, int stride,
+                                                          float* __restrict__ gsq_part = nullptr) {
+    __shared__ float sh[4];
     const int i = begin + blockIdx.x * 256 + threadIdx.x;
-    if (i >= end) return;
-    float v = parts[i];
-    for (int z = 1; z < nparts; ++z) v += parts[(size_t)z * stride + i];
-    out[i] = v;
+    float v = 0.0f;
+    if (i < end) {
+        v = parts[i];
+        for (int z = 1; z < nparts; ++z) v += parts[(size_t)z * stride + i];
+        out[i] = v;
+    }
+    if (gsq_part) {                          // per-block sum of squares (clip_grad_norm_ of the consumer)
+        float q = wave_sum(v * v);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = q;
+        __syncthreads();
+        if (threadIdx.x == 0) gsq_part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -911,6 +939,49 @@ __global__ __launch_bounds__(256) void cg_p_kernel(const float* __restrict__ r, 
     if (blockIdx.x == 0 && tid == 0) { sc->rs[(it + 1) & 1] = rs_new; sc->iters = it + 1; }
 }
 
+// ---- FOCOPS: logged statistics of one minibatch step (focops.py:161-215, 232-241) and the pass-level KL sum
+#define FSRL_FOCOPS_NSTATS_K 8
+struct FocopsFinalArgs {
+    const float* statp_vf;   // [tiles][2][FB_NSTAT]   st0 = sum (ret - V)^2
+    const float* statp_pi;   // [tiles][1][FB_NSTAT]   st0 = sum masked loss rows, st2 = sum KL(new||old)
+    const float* psq0; const float* psq1;    // per-block sums of squares of the critics' pre-update parameters
+    int n_psq0, n_psq1;
+    const float* P; int sigma_off, Da;
+    float* stats;            // row: nu_loss, nu_value, actor_loss, kl, entropy, vf0, vf1, vf_total
+    CtrlBlock* ctrl;
+    int n_tiles, n_tiles_pi, mb, first_in_pass, last_in_pass, iters_in_pass, pass;
+    float l2, nu_loss, nu_value, delta;
+};
+__global__ __launch_bounds__(64) void focops_finalize_kernel(const FocopsFinalArgs a) {
+    const int lane = threadIdx.x;
+    double s_vf0 = 0.0, s_vf1 = 0.0, s_loss = 0.0, s_kl = 0.0, s_p0 = 0.0, s_p1 = 0.0;
+    for (int t = lane; t < a.n_tiles; t += 64) {
+        s_vf0 += (double)a.statp_vf[((size_t)t * 2 + 0) * FB_NSTAT];
+        s_vf1 += (double)a.statp_vf[((size_t)t * 2 + 1) * FB_NSTAT];
+    }
+    for (int t = lane; t < a.n_tiles_pi; t += 64) {
+        s_loss += (double)a.statp_pi[(size_t)t * FB_NSTAT];
+        s_kl += (double)a.statp_pi[(size_t)t * FB_NSTAT + 2];
+    }
+    for (int k = lane; k < a.n_psq0; k += 64) s_p0 += (double)a.psq0[k];
+    for (int k = lane; k < a.n_psq1; k += 64) s_p1 += (double)a.psq1[k];
+    s_vf0 = wave_sum_d(s_vf0); s_vf1 = wave_sum_d(s_vf1); s_loss = wave_sum_d(s_loss); s_kl = wave_sum_d(s_kl);
+    s_p0 = wave_sum_d(s_p0); s_p1 = wave_sum_d(s_p1);
+    if (lane == 0) {
+        const float invB = 1.0f / (float)a.mb;
+        float ent = 0.0f;
+        for (int d = 0; d < a.Da; ++d) ent += 1.4189385332046727f + logf(expf(a.P[a.sigma_off + d]));
+        const float vf0 = (float)s_vf0 * invB + (float)s_p0 * a.l2, vf1 = (float)s_vf1 * invB + (float)s_p1 * a.l2;
+        const float kl = (float)s_kl * invB;
+        float* o = a.stats;
+        o[0] = a.nu_loss; o[1] = a.nu_value; o[2] = (float)s_loss * invB; o[3] = kl; o[4] = ent;
+        o[5] = vf0; o[6] = vf1; o[7] = vf0 + vf1;
+        const double ksum = (a.first_in_pass ? 0.0 : a.ctrl->kl_sum) + (double)kl;
+        a.ctrl->kl_sum = ksum;
+        if (a.last_in_pass && ksum / ((double)a.iters_in_pass + 1e-7) > (double)a.delta) a.ctrl->stopped_after = a.pass;
+    }
+}
+
 // full-batch advantage normalisation (CPO cpo.py:127-131, TRPO trpo_lag.py:129-133): per critic
 // (a - mean) / std with the unbiased std, float64 accumulate.  grid = C blocks of 1024 threads.
 __global__ __launch_bounds__(1024) void fb_advnorm_kernel(float* __restrict__ advs, int N) {
@@ -967,13 +1038,30 @@ __global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ P, 
                                                         int begin, int end, float l2, float one_minus_b1,
                                                         float beta2, float one_minus_b2, float step_size,
                                                         float bc2_sqrt, float eps, int nparts, int stride,
-                                                        const ModelDesc md) {
+                                                        const ModelDesc md, const float* __restrict__ gsq_part = nullptr,
+                                                        int n_gsq = 0, float max_norm = 0.0f,
+                                                        float* __restrict__ psq_part = nullptr) {
+    __shared__ double shd[4];
+    __shared__ float coef_s, shf[4];
     const int i = begin + blockIdx.x * 256 + threadIdx.x;
+    float coef = 1.0f;
+    if (gsq_part && max_norm > 0.0f) {       // clip_grad_norm_(max_norm) over the range: same rule as adam_clip_kernel
+        double sq = 0.0;
+        for (int k = threadIdx.x; k < n_gsq; k += 256) sq += (double)gsq_part[k];
+        sq = wave_sum_d(sq);
+        if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) coef_s = fminf(max_norm / (sqrtf((float)((shd[0] + shd[1]) + (shd[2] + shd[3]))) + 1e-6f), 1.0f);
+        __syncthreads();
+        coef = coef_s;
+    }
+    float psq = 0.0f;
     if (i < end) {
         const float p = P[i];
+        psq = p * p;
         float gs = G[i];                                   // split-K partials of fb_wgrad_kernel, z order
         for (int z = 1; z < nparts; ++z) gs += G[(size_t)z * stride + i];
-        const float g = gs + 2.0f * l2 * p;
+        const float g = gs * coef + 2.0f * l2 * p;
         float m = M[i], v = V[i];
         m = m + one_minus_b1 * (g - m);
         v = v * beta2;
@@ -984,6 +1072,12 @@ __global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ P, 
         P[i] = pn;
         const int mi = w2f_mirror_of(md, i);
         if (mi >= 0) P[mi] = pn;
+    }
+    if (psq_part) {                          // per-block sum of squares of the PRE-update parameters (L2 term of the logged loss)
+        psq = wave_sum(psq);
+        if ((threadIdx.x & 63) == 0) shf[threadIdx.x >> 6] = psq;
+        __syncthreads();
+        if (threadIdx.x == 0) psq_part[blockIdx.x] = (shf[0] + shf[1]) + (shf[2] + shf[3]);
     }
 }
 

@@ -132,6 +132,8 @@ struct PrepArgs {
     const int* perm; const int* mb_start; const int* mb_size;
     float* obs_p; float* rd_p;
     int N, C, Do, Da, norm_adv;
+    const float* mean_old;   // optional [N][Da] + sigma_old[Da] (log std at process time): FOCOPS needs the old distribution
+    const float* sigma_old;
 };
 
 __global__ __launch_bounds__(1024) void ppo_prepare_pass_kernel(const PrepArgs a) {
@@ -185,6 +187,10 @@ __global__ __launch_bounds__(1024) void ppo_prepare_pass_kernel(const PrepArgs a
                 if (a.norm_adv) v = (v - mean_f[c]) / sd_f[c];
             } else if (f >= FSRL_RD_RET && f < FSRL_RD_RET + a.C) {
                 v = a.rets[(size_t)(f - FSRL_RD_RET) * a.N + r];
+            } else if (a.mean_old && f >= FSRL_RD_MEAN && f < FSRL_RD_MEAN + a.Da) {
+                v = a.mean_old[(size_t)r * a.Da + f - FSRL_RD_MEAN];
+            } else if (a.mean_old && f >= FSRL_RD_STD && f < FSRL_RD_STD + a.Da) {
+                v = expf(a.sigma_old[f - FSRL_RD_STD]);
             }
             a.rd_p[(size_t)(st + m0 + m) * FSRL_RD + f] = v;
         }

@@ -150,6 +150,18 @@ class Engine:
                                               _ptr(act, _f32p)))
         return act
 
+    # ---------------------------------------------------------------- FOCOPS (on the PPO begin / pass / end calls)
+    def focops_init(self, actor_lr=5e-4, critic_lr=1e-3, l2_reg=1e-3, delta=0.02, eta=0.02, tem_lambda=0.95,
+                    max_grad_norm=0.5):
+        cfg = _lib.FocopsConfig(actor_lr, critic_lr, l2_reg, delta, eta, tem_lambda, float(max_grad_norm or 0.0))
+        _lib.check(self.lib.fsrl_focops_init(self._ctx, C.byref(cfg)))
+
+    def focops_update(self, nu, nu_loss, batch_size, repeat, perms=None, seed=0):
+        """-> (stats [steps, 8]: nu_loss, nu_value, actor_loss, kl, entropy, vf0, vf1, vf_total; stopped pass or -1)."""
+        _lib.check(self.lib.fsrl_focops_set_nu(self._ctx, float(nu), float(nu_loss)))
+        stats, stopped = self.ppo_update([0.0], 1.0, batch_size, repeat, perms=perms, seed=seed)
+        return stats[:, :_lib.FOCOPS_NSTATS], stopped
+
     # ---------------------------------------------------------------- PPO-Lagrangian
     def ppo_begin(self, lagrangians: Sequence[float], rescaling: float, batch_size: int) -> int:
         lag = np.ascontiguousarray(lagrangians, np.float64).reshape(-1)

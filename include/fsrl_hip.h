@@ -39,6 +39,7 @@ extern "C" {
 #define FSRL_ALGO_TRPO_LAG 1
 #define FSRL_ALGO_CPO 2
 #define FSRL_ALGO_SAC_LAG 3
+#define FSRL_ALGO_FOCOPS 4
 
 #define FSRL_MAX_CRITICS 4
 #define FSRL_PPO_NSTATS 11  /* rescaling, lagrangian, actor_safety, actor_rew, actor_total,
@@ -187,6 +188,24 @@ int fsrl_tr_grad(fsrl_ctx* ctx, int32_t which, float* out, int64_t n);
 int fsrl_tr_hvp(fsrl_ctx* ctx, const float* v, float* out, int64_t n);
 /* stats8: mean(ratio*A_r), mean(ratio*A_c), mean KL, mean(logp_old - logp), mean A_r, mean A_c, 0, 0 */
 int fsrl_tr_eval(fsrl_ctx* ctx, double* stats8);
+
+/* ---- FOCOPS (fsrl/policy/focops.py:126-251), on the PPO entry points: create the context
+ *      with algo = FSRL_ALGO_FOCOPS (same networks and parameter vector as PPO-Lag), call fsrl_focops_init once,
+ *      then per update: fsrl_focops_set_nu (the host-side nu step, focops.py:154-159) -> fsrl_ppo_begin
+ *      (lagrangians / rescaling ignored) -> fsrl_ppo_pass x repeat (pass-level KL early stop against `delta`)
+ *      -> fsrl_ppo_end.  Stats rows keep FSRL_PPO_NSTATS floats; the first FSRL_FOCOPS_NSTATS are
+ *      nu_loss, nu_value, actor_loss, kl, entropy, vf0, vf1, vf_total (focops.py:158,208-213,166-176).      */
+typedef struct fsrl_focops_config {
+    float actor_lr, critic_lr;   /* two Adam optimisers: actor / both critics                              */
+    float l2_reg;                /* critics: + l2_reg * sum(theta^2)                                       */
+    float delta;                 /* pass-level mean-KL early stop                                          */
+    float eta;                   /* rows with KL(new||old) > eta leave the actor loss                      */
+    float tem_lambda;            /* temperature lambda                                                     */
+    float max_grad_norm;         /* clip_grad_norm_ over the ACTOR parameters; 0 = off                     */
+} fsrl_focops_config;
+#define FSRL_FOCOPS_NSTATS 8
+int fsrl_focops_init(fsrl_ctx* ctx, const fsrl_focops_config* cfg);
+int fsrl_focops_set_nu(fsrl_ctx* ctx, double nu, double nu_loss);
 
 /* ---- SAC-Lagrangian (fsrl/policy/sac_lag.py), off-policy on the HIP-resident replay store.
  *      Create the context with algo = FSRL_ALGO_SAC_LAG (obs_dim, act_dim <= 8, hidden, env_num,
