@@ -106,3 +106,37 @@ class TRPOLagAgent(OnpolicyAgent):
                                      observation_space=env.observation_space,
                                      action_space=env.action_space, lr_scheduler=lr_scheduler, device=device,
                                      env_num=training_num, buffer_size=buffer_size)
+
+
+class FOCOPSAgent(OnpolicyAgent):
+    """Keyword arguments and defaults of fsrl/agent/focops_agent.py:79-214."""
+    name = "FOCOPSAgent"
+
+    def __init__(self, env, logger=None, cost_limit: float = 10, device: str = "cuda:0", thread: int = 4, seed: int = 10,
+                 actor_lr: float = 5e-4, critic_lr: float = 1e-3, hidden_sizes: Tuple[int, ...] = (128, 128),
+                 unbounded: bool = False, last_layer_scale: bool = False, auto_nu: bool = True, nu: float = 0.01,
+                 nu_max: float = 2.0, nu_lr: float = 1e-2, l2_reg: float = 1e-3, delta: float = 0.02, eta: float = 0.02,
+                 tem_lambda: float = 0.95, gae_lambda: float = 0.95, max_grad_norm: Optional[float] = 0.5,
+                 advantage_normalization: bool = True, recompute_advantage: bool = False, gamma: float = 0.99,
+                 max_batchsize: int = 100000, reward_normalization: bool = False, deterministic_eval: bool = True,
+                 action_scaling: bool = True, action_bound_method: str = "clip", lr_scheduler=None, training_num: int = 20,
+                 buffer_size: int = 100000) -> None:
+        super().__init__()
+        from fsrl_amd.policy.focops import FOCOPS
+        self.logger = logger if logger is not None else DummyLogger()
+        self.cost_limit = cost_limit
+        assert np.isscalar(cost_limit) and auto_nu and not unbounded
+        seed_all(seed)
+        torch.set_num_threads(thread)
+        actor, critic, _ = _build_nets(env, hidden_sizes, last_layer_scale, 2)
+        actor_optim = torch.optim.Adam(actor.parameters(), lr=actor_lr)
+        critic_optim = torch.optim.Adam(nn.ModuleList(critic).parameters(), lr=critic_lr)
+        self.policy = FOCOPS(actor, critic, actor_optim, critic_optim, _dist, logger=self.logger, cost_limit=cost_limit,
+                             nu=(nu_max, nu_lr, torch.zeros(1)), l2_reg=l2_reg, delta=delta, eta=eta, tem_lambda=tem_lambda,
+                             gae_lambda=gae_lambda, max_grad_norm=max_grad_norm,
+                             advantage_normalization=advantage_normalization, recompute_advantage=recompute_advantage,
+                             gamma=gamma, max_batchsize=max_batchsize, reward_normalization=reward_normalization,
+                             deterministic_eval=deterministic_eval, action_scaling=action_scaling,
+                             action_bound_method=action_bound_method, observation_space=env.observation_space,
+                             action_space=env.action_space, lr_scheduler=lr_scheduler, device=device,
+                             env_num=training_num, buffer_size=buffer_size)

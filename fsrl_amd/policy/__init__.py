@@ -6,5 +6,6 @@ from fsrl_amd.policy.trpo_lag import TRPOLagrangian
 from fsrl_amd.policy.cpo import CPO
 from fsrl_amd.policy.sac_lag import SACLagrangian
 from fsrl_amd.policy.ddpg_lag import DDPGLagrangian
+from fsrl_amd.policy.focops import FOCOPS
 
-__all__ = ["BasePolicy", "LagrangianPolicy", "PPOLagrangian", "TRPOLagrangian", "CPO", "SACLagrangian", "DDPGLagrangian"]
+__all__ = ["BasePolicy", "LagrangianPolicy", "PPOLagrangian", "TRPOLagrangian", "CPO", "SACLagrangian", "DDPGLagrangian", "FOCOPS"]
