@@ -130,6 +130,7 @@ struct fsrl_ctx {
     struct FocState* foc = nullptr; // FOCOPS working set, owned
     float* mu_old = nullptr;        // [maxsize][Da] actor means at process time (FOCOPS)
     float* sigma_old = nullptr;     // [FSRL_MAX_ACT] sigma_param at process time (FOCOPS)
+    void* h_actor = nullptr; size_t h_actor_bytes = 0;   // pinned staging of fsrl_actor_forward
     std::vector<int> perm_tmp;      // this pass's permutation before it goes to the pinned buffer
     hipEvent_t perm_copied = nullptr; bool perm_in_flight = false;
     uint64_t store_version = 1;     // bumped by every push / reset (device copies of the bookkeeping)
@@ -252,6 +253,7 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
     tr_free(c);
     sac_free(c);
     foc_free(c);
+    if (c->h_actor) (void)hipHostFree(c->h_actor);
     if (c->mu_old) (void)hipFree(c->mu_old);
     if (c->sigma_old) (void)hipFree(c->sigma_old);
     void* dptrs[] = {c->P, c->M, c->V, c->G, c->ctrl, c->st.obs, c->st.obs_next, c->st.act, c->st.rew,
@@ -574,28 +576,41 @@ extern "C" int fsrl_actor_forward(fsrl_ctx* c, const float* obs, int32_t k, floa
     CHECK_ARG(k >= 0, "negative row count");
     HIPCHK(hipSetDevice(c->device));
     const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim;
+    // pinned staging [obs | mu | sigma_param]: pageable pointers would make every copy a staged, synchronous one
+    const size_t ob = (size_t)k * Do * 4, mb = (size_t)k * Da * 4;
+    const size_t need = ob + mb + FSRL_MAX_ACT * 4;
+    if (c->h_actor_bytes < need) {
+        HIPCHK(hipStreamSynchronize(c->compute));
+        if (c->h_actor) HIPCHK(hipHostFree(c->h_actor));
+        c->h_actor = nullptr; c->h_actor_bytes = 0;
+        HIPCHK(hipHostMalloc(&c->h_actor, need * 2));
+        c->h_actor_bytes = need * 2;
+    }
+    float* h_obs = (float*)c->h_actor;
+    float* h_mu = (float*)((char*)c->h_actor + ob);
+    float* h_sp = (float*)((char*)c->h_actor + ob + mb);
     if (k > 0) {
-        const size_t ob = (size_t)k * Do * 4, mb = (size_t)k * Da * 4;
         int rc = ensure_scratch(c, ob + mb + 256);
         if (rc) return rc;
         float* d_obs = (float*)c->scratch;
         float* d_mu = (float*)((char*)c->scratch + (ob + 255) / 256 * 256);
-        HIPCHK(hipMemcpyAsync(d_obs, obs, ob, hipMemcpyHostToDevice, c->compute));
+        memcpy(h_obs, obs, ob);
+        HIPCHK(hipMemcpyAsync(d_obs, h_obs, ob, hipMemcpyHostToDevice, c->compute));
         InferArgs ia{};
         ia.obs = d_obs; ia.obs_next = d_obs; ia.act = nullptr; ia.flags = nullptr; ia.values = nullptr;
         ia.vnext = nullptr; ia.logp_old = nullptr; ia.mu_out = d_mu; ia.N = k; ia.C = 0;
         ia.max_action = c->cfg.max_action;
         rc = launch_infer(c, ia, 1, c->compute);   // job 0 == 2*C == actor
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(mu_out, d_mu, mb, hipMemcpyDeviceToHost, c->compute));
+        HIPCHK(hipMemcpyAsync(h_mu, d_mu, mb, hipMemcpyDeviceToHost, c->compute));
     }
-    float sp[FSRL_MAX_ACT];
     if (sigma_out)   // same stream, one synchronisation for both copies
-        HIPCHK(hipMemcpyAsync(sp, c->P + c->md.net[0].sigma, (size_t)Da * 4, hipMemcpyDeviceToHost, c->compute));
+        HIPCHK(hipMemcpyAsync(h_sp, c->P + c->md.net[0].sigma, (size_t)Da * 4, hipMemcpyDeviceToHost, c->compute));
     HIPCHK(hipStreamSynchronize(c->compute));
+    if (k > 0) memcpy(mu_out, h_mu, mb);
     if (sigma_out) {
         for (int r = 0; r < k; ++r)
-            for (int d = 0; d < Da; ++d) sigma_out[(size_t)r * Da + d] = expf(sp[d]);
+            for (int d = 0; d < Da; ++d) sigma_out[(size_t)r * Da + d] = expf(h_sp[d]);
     }
     return 0;
 }

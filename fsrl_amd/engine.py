@@ -65,6 +65,8 @@ class Engine:
         ccfg = cfg.to_c()
         _lib.check(self.lib.fsrl_ctx_create(int(device), C.byref(ccfg), C.byref(self._ctx)))
         self.n_params = int(self.lib.fsrl_param_count(self._ctx))
+        self._act_stage = None      # cached staging arrays + ctypes pointers of the collector's hot calls
+        self._push_stage = None
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx:
@@ -100,24 +102,31 @@ class Engine:
 
     # ---------------------------------------------------------------- store
     def push(self, env_ids, obs, act, rew, cost, terminated, truncated, obs_next):
-        env_ids = np.ascontiguousarray(env_ids, np.int32)
-        k = env_ids.size
-        obs = np.ascontiguousarray(obs, np.float32).reshape(k, -1)
-        obs_next = np.ascontiguousarray(obs_next, np.float32).reshape(k, -1)
-        act = np.ascontiguousarray(act, np.float32).reshape(k, -1)
+        """VectorReplayBuffer.add for k rows -> (ptr, ep_rew, ep_len, ep_idx).  Called once per vector step:
+        inputs are copied into cached staging arrays whose ctypes pointers are built once."""
+        k = len(env_ids)
+        st = self._push_stage
+        if st is None or st["cap"] < k:
+            cap, Do, Da = max(k, self.cfg.env_num), self.cfg.obs_dim, self.cfg.act_dim
+            arr = dict(ids=np.empty(cap, np.int32), obs=np.empty((cap, Do), np.float32), act=np.empty((cap, Da), np.float32),
+                       rew=np.empty(cap, np.float64), cost=np.empty(cap, np.float64), term=np.empty(cap, np.uint8),
+                       trunc=np.empty(cap, np.uint8), nxt=np.empty((cap, Do), np.float32), ptr=np.empty(cap, np.int64),
+                       er=np.empty(cap, np.float64), el=np.empty(cap, np.int32), ei=np.empty(cap, np.int64))
+            types = dict(ids=_i32p, obs=_f32p, act=_f32p, rew=_f64p, cost=_f64p, term=_u8p, trunc=_u8p, nxt=_f32p, ptr=_i64p,
+                         er=_f64p, el=_i32p, ei=_i64p)
+            st = self._push_stage = dict(cap=cap, a=arr, p={n: _ptr(arr[n], types[n]) for n in arr})
+        a, p = st["a"], st["p"]
+        obs = np.asarray(obs, np.float32).reshape(k, -1); act = np.asarray(act, np.float32).reshape(k, -1)
         assert obs.shape[1] == self.cfg.obs_dim and act.shape[1] == self.cfg.act_dim
-        rew = np.ascontiguousarray(rew, np.float64)
-        cost = np.ascontiguousarray(cost, np.float64) if cost is not None else None
-        term = np.ascontiguousarray(terminated).astype(np.uint8)
-        trunc = np.ascontiguousarray(truncated).astype(np.uint8)
-        ptr = np.empty(k, np.int64); ep_rew = np.empty(k, np.float64)
-        ep_len = np.empty(k, np.int32); ep_idx = np.empty(k, np.int64)
-        _lib.check(self.lib.fsrl_store_push(self._ctx, _ptr(env_ids, _i32p), k, _ptr(obs, _f32p),
-                                            _ptr(act, _f32p), _ptr(rew, _f64p), _ptr(cost, _f64p),
-                                            _ptr(term, _u8p), _ptr(trunc, _u8p), _ptr(obs_next, _f32p),
-                                            _ptr(ptr, _i64p), _ptr(ep_rew, _f64p), _ptr(ep_len, _i32p),
-                                            _ptr(ep_idx, _i64p)))
-        return ptr, ep_rew, ep_len, ep_idx
+        a["ids"][:k] = env_ids; a["obs"][:k] = obs; a["act"][:k] = act; a["rew"][:k] = rew
+        a["term"][:k] = terminated; a["trunc"][:k] = truncated
+        a["nxt"][:k] = np.asarray(obs_next, np.float32).reshape(k, -1)
+        if cost is not None:
+            a["cost"][:k] = cost
+        _lib.check(self.lib.fsrl_store_push(self._ctx, p["ids"], k, p["obs"], p["act"], p["rew"],
+                                            p["cost"] if cost is not None else None, p["term"], p["trunc"], p["nxt"],
+                                            p["ptr"], p["er"], p["el"], p["ei"]))
+        return a["ptr"][:k].copy(), a["er"][:k].copy(), a["el"][:k].copy(), a["ei"][:k].copy()
 
     def reset_store(self, keep_statistics=False):
         _lib.check(self.lib.fsrl_store_reset(self._ctx, int(keep_statistics)))
@@ -143,12 +152,18 @@ class Engine:
         return mu, sigma
 
     def actor_sample(self, obs, deterministic=False, seed=0):
-        """Collector-time actions a ~ pi(.|obs): actor on the device, noise from the library RNG."""
-        obs = np.ascontiguousarray(obs, np.float32).reshape(-1, self.cfg.obs_dim)
-        act = np.empty((obs.shape[0], self.cfg.act_dim), np.float32)
-        _lib.check(self.lib.fsrl_actor_sample(self._ctx, _ptr(obs, _f32p), obs.shape[0], int(deterministic), int(seed),
-                                              _ptr(act, _f32p)))
-        return act
+        """Collector-time actions a ~ pi(.|obs): actor on the device, noise from the library RNG.
+        Hot loop of the collector: staging arrays and their ctypes pointers are cached."""
+        obs = np.asarray(obs, np.float32).reshape(-1, self.cfg.obs_dim)
+        k = obs.shape[0]
+        st = self._act_stage
+        if st is None or st[0].shape[0] < k:
+            cap = max(k, self.cfg.env_num)
+            so, sa = np.empty((cap, self.cfg.obs_dim), np.float32), np.empty((cap, self.cfg.act_dim), np.float32)
+            st = self._act_stage = (so, sa, _ptr(so, _f32p), _ptr(sa, _f32p))
+        np.copyto(st[0][:k], obs)
+        _lib.check(self.lib.fsrl_actor_sample(self._ctx, st[2], k, int(deterministic), int(seed), st[3]))
+        return st[1][:k].copy()
 
     # ---------------------------------------------------------------- FOCOPS (on the PPO begin / pass / end calls)
     def focops_init(self, actor_lr=5e-4, critic_lr=1e-3, l2_reg=1e-3, delta=0.02, eta=0.02, tem_lambda=0.95,
