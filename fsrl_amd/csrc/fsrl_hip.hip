@@ -590,22 +590,18 @@ extern "C" int fsrl_actor_forward(fsrl_ctx* c, const float* obs, int32_t k, floa
     float* h_mu = (float*)((char*)c->h_actor + ob);
     float* h_sp = (float*)((char*)c->h_actor + ob + mb);
     if (k > 0) {
-        int rc = ensure_scratch(c, ob + mb + 256);
-        if (rc) return rc;
-        float* d_obs = (float*)c->scratch;
-        float* d_mu = (float*)((char*)c->scratch + (ob + 255) / 256 * 256);
+        // zero-copy: the kernel reads the observations from, and writes mu / sigma_param to, pinned host
+        // memory (a few hundred bytes over PCIe) -- one launch and one synchronisation per vector step
         memcpy(h_obs, obs, ob);
-        HIPCHK(hipMemcpyAsync(d_obs, h_obs, ob, hipMemcpyHostToDevice, c->compute));
         InferArgs ia{};
-        ia.obs = d_obs; ia.obs_next = d_obs; ia.act = nullptr; ia.flags = nullptr; ia.values = nullptr;
-        ia.vnext = nullptr; ia.logp_old = nullptr; ia.mu_out = d_mu; ia.N = k; ia.C = 0;
-        ia.max_action = c->cfg.max_action;
-        rc = launch_infer(c, ia, 1, c->compute);   // job 0 == 2*C == actor
+        ia.obs = h_obs; ia.obs_next = h_obs; ia.act = nullptr; ia.flags = nullptr; ia.values = nullptr;
+        ia.vnext = nullptr; ia.logp_old = nullptr; ia.mu_out = h_mu; ia.N = k; ia.C = 0;
+        ia.max_action = c->cfg.max_action; ia.sigma_param_out = sigma_out ? h_sp : nullptr;
+        int rc = launch_infer(c, ia, 1, c->compute);   // job 0 == 2*C == actor
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(h_mu, d_mu, mb, hipMemcpyDeviceToHost, c->compute));
-    }
-    if (sigma_out)   // same stream, one synchronisation for both copies
+    } else if (sigma_out) {
         HIPCHK(hipMemcpyAsync(h_sp, c->P + c->md.net[0].sigma, (size_t)Da * 4, hipMemcpyDeviceToHost, c->compute));
+    }
     HIPCHK(hipStreamSynchronize(c->compute));
     if (k > 0) memcpy(mu_out, h_mu, mb);
     if (sigma_out) {

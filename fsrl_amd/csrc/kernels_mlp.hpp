@@ -259,6 +259,7 @@ struct InferArgs {
     float max_action;
     float* raw_out;         // optional [N][raw_cols] raw head outputs (SAC actor: mu | log sigma)
     int raw_cols;
+    float* sigma_param_out; // optional [Da]: the actor's sigma_param (collector: one launch, no extra copy)
 };
 
 #define LOG_SQRT_2PI 0.9189385332046727f
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(4 * H) void mlp_infer_kernel(const float* __restric
     stg.commit(sm, no, md.Do, tid);
     __syncthreads();
     tile_forward<H>(sm, P, no, md.Do, tid, wf);
+    if (a.sigma_param_out && is_actor && blockIdx.x == 0 && tid < md.Da && no.sigma >= 0) a.sigma_param_out[tid] = sm.sig[tid];
     if (a.raw_out) {
         for (int e = tid; e < n_valid * a.raw_cols; e += TileGeom<H>::NT) {
             const int i = e / a.raw_cols, o = e - i * a.raw_cols;
