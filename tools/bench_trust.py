@@ -94,6 +94,48 @@ def run(kind, obs_dim, act_dim, hid, envs=20, T=1000, ep=1000, repeat=4, cpu_rep
     eng.close()
 
 
+def run_focops(obs_dim=8, act_dim=2, hid=256, envs=20, T=1000, ep=250, batch=256, repeat=4):
+    """FOCOPS on the configs[1] shape (N = 20 000, batch 256, 4 passes = 312 minibatch steps)."""
+    from fsrl_amd import _lib
+    from oracle.focops import FOCOPSConfig, FOCOPSOracle
+    rng = np.random.default_rng(0)
+    obs, act, rew, cost, term, trunc = inputs(rng, envs, T, obs_dim, act_dim, ep)
+    eng = Engine(EngineConfig(algo=_lib.ALGO_FOCOPS, obs_dim=obs_dim, act_dim=act_dim, hidden=hid, env_num=envs, target_kl=None))
+    eng.focops_init(delta=1e9)                      # KL early stop off: every update runs all 312 steps
+    o = FOCOPSOracle(FOCOPSConfig(obs_dim=obs_dim, act_dim=act_dim, hidden=(hid, hid), delta=1e9))
+    theta = orth_theta(o, 0)
+    ids = np.arange(envs)
+    for t in range(T):
+        eng.push(ids, obs[t], act[t], rew[t], cost[t], term[t], trunc[t], obs[t + 1])
+    eng.sync()
+
+    def device_update(k):
+        eng.set_params(theta)
+        return eng.focops_update(0.1, -15.0, batch, repeat, perms=None, seed=k + 1)
+
+    device_update(0)
+    t0 = time.perf_counter(); n = 3
+    for k in range(n):
+        stats, _ = device_update(k + 1)
+    dt = (time.perf_counter() - t0) / n
+    out = {"bench": "focops", "obs": obs_dim, "act": act_dim, "hidden": hid, "N": envs * T, "batch": batch, "repeat": repeat,
+           "steps": int(stats.shape[0]), "hip_ms_per_update": dt * 1e3, "hip_us_per_step": dt * 1e6 / stats.shape[0]}
+    if not os.environ.get("FSRL_NO_CPU"):
+        em = lambda a: np.concatenate([a[:, e] for e in range(envs)])  # noqa: E731
+        data = OnPolicyData(obs=em(obs[:-1]), act=em(act), rew=em(rew), cost=em(cost), terminated=em(term),
+                            truncated=em(trunc), obs_next=em(obs[1:]), end_flag=em(term | trunc))
+        torch.set_num_threads(4)
+        o.set_params(theta, nu=0.1)
+        r2 = np.random.default_rng(1)
+        t0 = time.perf_counter()
+        o.update(data, 25.0, batch, 1, [r2.permutation(envs * T)])
+        cdt = (time.perf_counter() - t0) * repeat
+        out.update(cpu_oracle_ms_per_update_4thr=cdt * 1e3, speedup=cdt / dt)
+    print(json.dumps(out))
+    eng.close()
+
+
 if __name__ == "__main__":
     run("cpo", 60, 2, 256)
     run("trpo", 8, 2, 256, ep=250)
+    run_focops()
