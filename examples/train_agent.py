@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Train any of the HIP-backed agents the way the reference's examples/mlp/train_*_agent.py do, on the
+synthetic SafetyCarCircle-shaped vector env (this image has no safety-gymnasium / bullet-safety-gym; with them
+installed pass real vector envs exposing reset(ids) / step(act, ids) -> (obs, rew, terminated, truncated, info["cost"])).
+
+    python examples/train_agent.py --algo ppol --epoch 3
+    python examples/train_agent.py --algo sacl --epoch 2 --device-actor
+"""
+import argparse
+import os
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fsrl_amd.agent import CPOAgent, DDPGLagAgent, FOCOPSAgent, PPOLagAgent, SACLagAgent, TRPOLagAgent  # noqa: E402
+from fsrl_amd.env import SyntheticSafetyVectorEnv  # noqa: E402
+from fsrl_amd.utils import BaseLogger  # noqa: E402
+
+AGENTS = {"ppol": PPOLagAgent, "cpo": CPOAgent, "trpol": TRPOLagAgent, "focops": FOCOPSAgent, "sacl": SACLagAgent,
+          "ddpgl": DDPGLagAgent}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--algo", choices=sorted(AGENTS), default="ppol")
+    ap.add_argument("--epoch", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=20)
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--cost-limit", type=float, default=10.0)
+    ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--seed", type=int, default=10)
+    ap.add_argument("--device-actor", action="store_true", help="collector actions from fsrl_actor_sample (library RNG)")
+    a = ap.parse_args()
+    env = SyntheticSafetyVectorEnv(env_num=a.envs, obs_dim=8, act_dim=2, episode_len=300, seed=a.seed)
+    test_env = SyntheticSafetyVectorEnv(env_num=2, obs_dim=8, act_dim=2, episode_len=300, seed=a.seed + 1)
+    logger = BaseLogger(tempfile.mkdtemp(prefix="fsrl_amd_"), name=a.algo)
+    kw = dict(cost_limit=a.cost_limit, device=a.device, seed=a.seed, hidden_sizes=(a.hidden, a.hidden), training_num=a.envs)
+    agent = AGENTS[a.algo](env, logger, **kw)
+    if a.algo in ("sacl", "ddpgl"):
+        out = agent.learn(env, test_env, epoch=a.epoch, episode_per_collect=a.envs, step_per_epoch=6000, update_per_step=0.2,
+                          batch_size=256, testing_num=2, device_actor=a.device_actor, verbose=True, save_ckpt=False)
+    else:
+        out = agent.learn(env, test_env, epoch=a.epoch, episode_per_collect=a.envs, step_per_epoch=6000, repeat_per_collect=4,
+                          batch_size=256 if a.algo in ("ppol", "focops") else 99999, testing_num=2, device_actor=a.device_actor,
+                          verbose=True, save_ckpt=False)
+    print("final:", {k: round(float(v), 4) for k, v in out[1].items() if isinstance(v, (int, float))})
+    rew, length, cost = agent.evaluate(test_env, eval_episodes=2)
+    print(f"eval: reward {rew:.2f} length {length:.1f} cost {cost:.2f}")
+
+
+if __name__ == "__main__":
+    main()
