@@ -241,3 +241,36 @@ def test_trust_region_pieces_on_odd_sizes_vs_autograd(Do, Da, H, rows):
     hv = o.flat_grad((klg * v).sum(), retain_graph=True).numpy()
     close(eng.tr_hvp(v.numpy()), hv, 1e-4)
     eng.close()
+
+
+def test_one_shot_ppo_update_entry_point_matches_the_stepwise_calls():
+    """fsrl_ppo_update (begin + passes + end in one C call, caller-provided permutations) == the three-call form."""
+    import ctypes as C
+    from fsrl_amd import _lib
+    from fsrl_amd.engine import Engine, EngineConfig
+    rng = np.random.default_rng(4)
+    rows, Do, Da = [120, 77], 6, 2
+    cols = _synthetic(rng, rows, Do, Da, 40)
+    outs = []
+    for one_shot in (False, True):
+        eng = Engine(EngineConfig(obs_dim=Do, act_dim=Da, hidden=64, env_num=2, buffer_size=1024, max_grad_norm=0.5, target_kl=0.5))
+        eng.set_params((0.1 * np.random.default_rng(0).standard_normal(eng.n_params)).astype(np.float32))
+        for t in range(max(rows)):
+            ids = [e for e in range(2) if t < rows[e]]
+            eng.push(ids, *[np.stack([cols[k][e][t] for e in ids]) for k in ("obs", "act", "rew", "cost", "term", "trunc", "obs_next")])
+        N, B, repeat = sum(rows), 32, 3
+        perms = np.stack([np.random.default_rng(9 + k).permutation(N) for k in range(repeat)]).astype(np.int64)
+        lag = np.array([0.3])
+        if one_shot:
+            cap = repeat * (N // B + 1)
+            stats = np.empty((cap, _lib.PPO_NSTATS), np.float32); n = C.c_int64(); stopped = C.c_int32()
+            P = lambda a, t: a.ctypes.data_as(C.POINTER(t))  # noqa: E731
+            _lib.check(eng.lib.fsrl_ppo_update(eng._ctx, P(lag, C.c_double), 1 / 1.3, B, repeat, P(perms, C.c_int64), 0,
+                                               P(stats, C.c_float), cap, C.byref(n), C.byref(stopped)))
+            outs.append((stats[:n.value].copy(), stopped.value, eng.get_params()))
+        else:
+            stats, stopped = eng.ppo_update(lag, 1 / 1.3, B, repeat, perms=list(perms))
+            outs.append((stats.copy(), stopped, eng.get_params()))
+        eng.close()
+    assert outs[0][0].shape == outs[1][0].shape and np.array_equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1] and np.array_equal(outs[0][2], outs[1][2])
