@@ -140,6 +140,45 @@ def end_to_end(local_rank, seed, seconds=6.0, device_actor=False):
     return out
 
 
+def multi_seed(seeds=3, steps=6):
+    """Secondary figure: `seeds` independent agents on ONE GPU (one host thread + one library context each, own HIP
+    streams).  One agent's dependent kernels leave latency gaps another agent fills: aggregate updates/s."""
+    import threading
+    from fsrl_amd.engine import Engine, EngineConfig
+    agents = []
+    for s_ in range(seeds):
+        eng = Engine(EngineConfig(obs_dim=OBS, act_dim=ACT, hidden=HID, env_num=ENVS, buffer_size=100000, max_grad_norm=0.5,
+                                  target_kl=None))
+        theta = orthogonal_theta(s_, eng.n_params)
+        obs, act, rew, cost, term, trunc = make_inputs(s_)
+        ids = np.arange(ENVS)
+        for t in range(NROWS // ENVS):
+            eng.push(ids, obs[t], act[t], rew[t], cost[t], term[t], trunc[t], obs[t + 1])
+        eng.sync()
+        agents.append((eng, theta))
+    lag, resc = np.array([0.75]), 1.0 / 1.75
+
+    def work(i, n):
+        eng, theta = agents[i]
+        for k in range(n):
+            eng.set_params(theta); eng.optim_reset()
+            eng.ppo_update(lag, resc, BATCH, REPEAT, perms=None, seed=1000 * i + k + 1)
+
+    for i in range(seeds):
+        work(i, 1)
+    th = [threading.Thread(target=work, args=(i, steps)) for i in range(seeds)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    for eng, _ in agents:
+        eng.close()
+    return {"seeds_per_gpu": seeds, "value": seeds * steps / dt, "unit": "updates/s (aggregate)",
+            "note": "same configs[1] workload per agent; not the headline value (that is one agent per GPU)"}
+
+
 def pmc_traffic():
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE, separate runs; tools/capture_profiles.sh + tools/collect_profiles.py apply
@@ -263,6 +302,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
             out["end_to_end"] = end_to_end(local_rank, seed, device_actor=True)
             out["end_to_end_host_actor"] = end_to_end(local_rank, seed, seconds=4.0, device_actor=False)
+            out["multi_seed"] = multi_seed()
             out["cpu_baseline"] = cpu_baseline(theta, inputs)
             out["speedup_vs_cpu_port"] = out["value"] / world / out["cpu_baseline"]["value"]
         print(json.dumps(out))
