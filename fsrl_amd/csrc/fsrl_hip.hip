@@ -1729,8 +1729,8 @@ struct SacState {
     ModelDesc mda{}, mdq{};
     std::vector<TensorMap> tmap_a, tmap_q;     // API order -> device offsets
     int na_api = 0, nq_api = 0, na_dev = 0, nq_dev = 0;
-    float *PA = nullptr, *MA = nullptr, *VA = nullptr, *GA = nullptr;
-    float *PQ = nullptr, *PQT = nullptr, *MQ = nullptr, *VQ = nullptr, *GQ = nullptr;
+    float *PA = nullptr, *MA = nullptr, *VA = nullptr;          // gradients live in the split-K partial buffers
+    float *PQ = nullptr, *PQT = nullptr, *MQ = nullptr, *VQ = nullptr;
     float* PAT = nullptr;                      // target actor (DDPG-Lag mode only)
     int n_q = 4;                               // Q-networks: 4 (two double critics) or 2 (DDPG-Lag)
     bool ddpg = false;
@@ -1745,7 +1745,7 @@ struct SacState {
     float *eps_t = nullptr, *eps_p = nullptr, *h_eps = nullptr;                   // device / pinned
     float *LPN = nullptr, *LP = nullptr, *QT = nullptr, *QP = nullptr, *Y = nullptr, *DA = nullptr;
     float *A1 = nullptr, *A2 = nullptr, *D1 = nullptr, *D2 = nullptr, *DO = nullptr;   // [4][Bpad]
-    float *stq = nullptr, *stdin_ = nullptr, *stpi = nullptr;
+    float *stq = nullptr, *stdin_ = nullptr, *stpi = nullptr;   // stdin_: per-tile scratch of the Q_DIN launch (unused sums)
     float* d_stats = nullptr;                 // ring [SAC_RING][FSRL_SAC_NSTATS]: one row per update
     int64_t n_updates = 0, n_drained = 0;
     uint64_t key = 0x243F6A8885A308D3ull;     // Philox key of the library-RNG mode
@@ -1829,8 +1829,8 @@ extern "C" int fsrl_sac_init(fsrl_ctx* c, const fsrl_sac_config* cfg) {
     sac_layout(c, s);
     const size_t HH = (size_t)c->cfg.hidden * c->cfg.hidden;
     const size_t ab = ((size_t)s->na_dev + HH) * 4, qb = ((size_t)s->nq_dev + 4 * HH) * 4;   // + W2 mirrors (used in P only)
-    for (float** p : {&s->PA, &s->MA, &s->VA, &s->GA, &s->PAT}) { HIPCHK(hipMalloc(p, ab)); HIPCHK(hipMemsetAsync(*p, 0, ab, c->compute)); }
-    for (float** p : {&s->PQ, &s->PQT, &s->MQ, &s->VQ, &s->GQ}) { HIPCHK(hipMalloc(p, qb)); HIPCHK(hipMemsetAsync(*p, 0, qb, c->compute)); }
+    for (float** p : {&s->PA, &s->MA, &s->VA, &s->PAT}) { HIPCHK(hipMalloc(p, ab)); HIPCHK(hipMemsetAsync(*p, 0, ab, c->compute)); }
+    for (float** p : {&s->PQ, &s->PQT, &s->MQ, &s->VQ}) { HIPCHK(hipMalloc(p, qb)); HIPCHK(hipMemsetAsync(*p, 0, qb, c->compute)); }
     HIPCHK(hipStreamSynchronize(c->compute));
     HIPCHK(hipMalloc(&s->sc, sizeof(SacScalars)));
     SacScalars init{cfg->auto_alpha ? 1.0f : cfg->alpha, 0.0f, 0.0f, 0.0f, 0, 0};
@@ -1844,8 +1844,8 @@ extern "C" int fsrl_sac_init(fsrl_ctx* c, const fsrl_sac_config* cfg) {
 static void sac_free(fsrl_ctx* c) {
     SacState* s = sac_of(c);
     if (!s) return;
-    for (void* p : {(void*)s->PAT, (void*)s->PA, (void*)s->MA, (void*)s->VA, (void*)s->GA, (void*)s->PQ, (void*)s->PQT, (void*)s->MQ,
-                    (void*)s->VQ, (void*)s->GQ, (void*)s->sc, (void*)s->d_idx, (void*)s->d_chain, (void*)s->d_end,
+    for (void* p : {(void*)s->PAT, (void*)s->PA, (void*)s->MA, (void*)s->VA, (void*)s->PQ, (void*)s->PQT, (void*)s->MQ,
+                    (void*)s->VQ, (void*)s->sc, (void*)s->d_idx, (void*)s->d_chain, (void*)s->d_end,
                     (void*)s->XQ, (void*)s->OBS, (void*)s->OBSN, (void*)s->XN, (void*)s->XP, (void*)s->eps_t,
                     (void*)s->eps_p, (void*)s->LPN, (void*)s->LP, (void*)s->QT, (void*)s->QP, (void*)s->Y,
                     (void*)s->DA, (void*)s->A1, (void*)s->A2, (void*)s->D1, (void*)s->D2, (void*)s->DO,
