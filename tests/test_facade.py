@@ -130,3 +130,18 @@ def test_logger_running_means_and_keys():
     assert abs(lg.get_mean("loss/kl") - 0.2) < 1e-12 and lg.stats_mean["loss/total"] == 2.0
     lg.write(10)
     assert lg.stats_mean == {}
+
+
+def test_fast_collector_random_mode_collects_one_episode():
+    """The reference's tests/test_collector.py:24-47 (policy and random modes, exactly one episode)."""
+    from fsrl_amd.data import FastCollector
+    from fsrl_amd.env import SyntheticSafetyVectorEnv
+    env = SyntheticSafetyVectorEnv(env_num=1, episode_len=17, seed=3)
+    from torch.distributions import Independent, Normal
+    pol = _host_policy()
+    pol.dist_fn = lambda *l: Independent(Normal(*l), 1)
+    col = FastCollector(pol, env, _FakeBuffer(1))
+    st = col.collect(n_episode=1, random=True)
+    assert st["n/ep"] == 1 and st["n/st"] == 17 and st["len"] == 17.0
+    st = col.collect(n_episode=1)                     # evaluation mode of the policy: deterministic actions
+    assert st["n/ep"] == 1 and st["n/st"] == 17
