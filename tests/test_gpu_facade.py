@@ -251,3 +251,30 @@ def test_offpolicy_state_dict_keys_and_shapes_match_reference_manifest():
         assert np.array_equal(pol.engine.sac_get_params(1)[0], SACLagrangian._flat(list(pol.critics)))
         assert not np.array_equal(pol.engine.sac_get_params(1)[0], pol.engine.sac_get_params(2)[0])
         pol.engine.close()
+
+
+def test_agents_learn_the_synthetic_task_under_the_cost_constraint(tmp_path):
+    """End-to-end learning smoke test in the spirit of the reference's tests/test_all_agents.py (which trains on
+    SafetyBallRun-v0; no simulator in this image): on the synthetic vector env reward = s0*a0 - 0.1|a|^2 + 0.5 and
+    cost = [|s1| > 1] are both controllable, so training must raise the evaluation reward and push the cost
+    towards the limit (PPO-Lag, via the PID multiplier) or under it (CPO)."""
+    from fsrl_amd.agent import CPOAgent, PPOLagAgent
+    from fsrl_amd.env import SyntheticSafetyVectorEnv
+    from fsrl_amd.utils import BaseLogger
+    for name, cls, lk in (("ppol", PPOLagAgent, dict(repeat_per_collect=4, batch_size=256)),
+                          ("cpo", CPOAgent, dict(repeat_per_collect=2, batch_size=99999))):
+        env = SyntheticSafetyVectorEnv(env_num=10, episode_len=100, seed=0)
+        test = SyntheticSafetyVectorEnv(env_num=2, episode_len=100, seed=5)
+        agent = cls(env, BaseLogger(str(tmp_path), name=name), cost_limit=20, device="cuda:0", seed=1, hidden_sizes=(64, 64),
+                    training_num=10)
+        r0, _, c0 = agent.evaluate(test, eval_episodes=4)
+        agent.learn(env, None, epoch=20, episode_per_collect=10, step_per_epoch=2000, verbose=False, save_ckpt=False,
+                    device_actor=True, **lk)
+        r1, _, c1 = agent.evaluate(test, eval_episodes=4)
+        assert c0 > 30, (name, c0)                                  # the untrained policy violates the limit of 20
+        assert c1 < 0.7 * c0, (name, c0, c1)                        # the constraint bites
+        if name == "ppol":
+            assert r1 > r0 + 50, (r0, r1)                           # and reward still improves
+            assert agent.policy.lag_optims[0].get_lag() > 0
+        else:
+            assert c1 <= 20 * 1.2 and r1 > r0 - 20, (r0, r1, c1)    # CPO: feasible, reward not sacrificed
