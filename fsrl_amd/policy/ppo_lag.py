@@ -14,6 +14,19 @@ PPO_STAT_KEYS = ("loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss
                  "loss/entropy")
 
 
+def _chunk_sizes(n: int, size: int) -> List[int]:
+    """Row counts of tianshou-0.5 Batch.split(size, merge_last=True)."""
+    out, i = [], 0
+    merge_last = n % size > 0
+    while i < n:
+        if merge_last and i + 2 * size >= n:
+            out.append(n - i)
+            break
+        out.append(min(size, n - i))
+        i += size
+    return out
+
+
 class PPOLagrangian(LagrangianPolicy):
     def __init__(self, actor: nn.Module, critics: Union[nn.Module, List[nn.Module]],
                  optim: torch.optim.Optimizer, dist_fn, logger=None,
@@ -31,7 +44,8 @@ class PPOLagrangian(LagrangianPolicy):
                  action_bound_method: str = "clip", observation_space=None, action_space=None,
                  lr_scheduler=None,
                  # engine placement (not in the reference: which GPU, how many env sub-buffers)
-                 device: Union[int, str] = 0, env_num: int = 1, buffer_size: int = 100000) -> None:
+                 device: Union[int, str] = 0, env_num: int = 1, buffer_size: int = 100000,
+                 reference_rng: bool = False) -> None:
         super().__init__(actor, critics, dist_fn, logger, use_lagrangian, lagrangian_pid, cost_limit,
                          rescaling, gamma, max_batchsize, reward_normalization, deterministic_eval,
                          action_scaling, action_bound_method, observation_space, action_space, lr_scheduler)
@@ -43,6 +57,11 @@ class PPOLagrangian(LagrangianPolicy):
         self._lambda, self._weight_vf, self._grad_norm = gae_lambda, vf_coef, max_grad_norm
         self._target_kl, self._eps_clip, self._dual_clip = target_kl, eps_clip, dual_clip
         self._norm_adv = advantage_normalization
+        # reference_rng=True: also consume torch's global RNG exactly where the reference does inside update() --
+        # its forward() draws dist.sample() in training mode even when only the distribution is used
+        # (process_fn: ppo_lag.py:146-148; learn: :225 via policy_loss :175) -- so that a whole collect/update
+        # loop stays on the reference's random streams (tests/test_gpu_loop.py).  Costs ~N*Da normals per update.
+        self._reference_rng = reference_rng
         self._make_engine(device, env_num, buffer_size, optim, gae_lambda=gae_lambda, eps_clip=eps_clip,
                           dual_clip=dual_clip, vf_coef=vf_coef, max_grad_norm=max_grad_norm,
                           target_kl=target_kl, norm_adv=advantage_normalization,
@@ -50,6 +69,11 @@ class PPOLagrangian(LagrangianPolicy):
 
     def learn(self, batch, **kwargs: Any):
         raise NotImplementedError("the HIP path runs process_fn + learn inside update()")
+
+    def _burn_samples(self, sizes) -> None:
+        da = self.engine.cfg.act_dim
+        for m in sizes:                                          # Independent(Normal).sample() of an [m, Da] batch
+            torch.normal(torch.zeros(m, da), torch.ones(m, da))
 
     def update(self, sample_size: int, buffer, batch_size: int = 256, repeat: int = 4, **kwargs: Any):
         if buffer is None:
@@ -61,9 +85,14 @@ class PPOLagrangian(LagrangianPolicy):
         lags, rescaling = self.lagrangians_and_rescaling() if self.use_lagrangian else ([], 1.0)
         eng = self.engine
         n = eng.ppo_begin(lags, rescaling, batch_size)          # buffer.sample(0) + process_fn
+        burn = self._reference_rng and (self.training or not self._deterministic_eval)
+        if burn:                                                 # process_fn's forward over chunks of max_batchsize
+            self._burn_samples(_chunk_sizes(n, self._max_batchsize))
         stopped_at = -1
         for step in range(repeat):                               # ppo_lag.py:217
             perm = np.random.permutation(n) if n > 0 else None   # Batch.split(shuffle=True)
+            if burn:
+                self._burn_samples(_chunk_sizes(n, batch_size))  # one forward per minibatch
             if eng.ppo_pass(perm):
                 stopped_at = step
                 self.logger.print("Early stop at step %d due to reaching max kl." % step)

@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""Golden vectors G11: a CLOSED training loop -- collect with the policy, update, collect with the updated policy ...
+-- driven by the UNMODIFIED reference PPOLagrangian (forward / map_action / pre_update_fn / update) over the shim's
+VectorReplayBuffer, on the build-owned synthetic vector env.  Records what a learning curve is made of: per collect
+the mean episode reward / cost / length, the PID multiplier, the first and last logged minibatch rows, and the
+parameters at the end.  The rollout loop itself (n_episode = env_num, lock-step) is written here and again in
+tests/test_gpu_loop.py: what is pinned is acting + storing + updating + the PID controller across cycles.
+
+    python tests/golden/gen_golden_loop.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+from gen_golden import CaptureLogger, build_ppo, flat_params, seed_all  # noqa: E402
+from ref_shim import Batch, VectorReplayBuffer  # noqa: E402
+
+from fsrl_amd.env.synthetic import SyntheticSafetyVectorEnv  # noqa: E402  (numpy only; no engine is touched)
+
+
+def rollout(policy, env, buf, rng_unused=None):
+    """One collect of exactly env_num episodes (every env runs one episode, lock-step)."""
+    obs, _ = env.reset()
+    E = len(env)
+    ids = np.arange(E)
+    ep_rew, ep_cost, steps = np.zeros(E), np.zeros(E), 0
+    while True:
+        with torch.no_grad():
+            res = policy(Batch(obs=obs, info={}), None)
+        act = res.act.numpy()
+        obs_next, rew, term, trunc, info = env.step(policy.map_action(act), ids)
+        buf.add({"obs": obs, "act": act, "rew": rew, "terminated": term, "truncated": trunc, "done": term | trunc,
+                 "obs_next": obs_next, "info.cost": info["cost"]}, ids)
+        ep_rew += rew; ep_cost += info["cost"]; steps += E
+        obs = obs_next
+        if (term | trunc).all():
+            break
+    return dict(reward=float(ep_rew.mean()), cost=float(ep_cost.mean()), steps=steps)
+
+
+def gen(name, obs_dim, act_dim, hidden, env_num, ep_len, cycles, batch_size, repeat, seed, cost_limit, **kw):
+    logger = CaptureLogger()
+    policy, ac, _ = build_ppo(obs_dim, act_dim, hidden, seed, logger=logger, cost_limit=cost_limit, **kw)
+    policy.train()
+    env = SyntheticSafetyVectorEnv(env_num=env_num, obs_dim=obs_dim, act_dim=act_dim, episode_len=ep_len, seed=seed + 11)
+    buf = VectorReplayBuffer(env_num * ep_len * 2, env_num)
+    out = {"theta0": flat_params(ac)}
+    seed_all(seed + 7)
+    curve, first_rows, last_rows, lags, steps_per = [], [], [], [], []
+    for c in range(cycles):
+        buf.reset()
+        st = rollout(policy, env, buf)
+        policy.pre_update_fn(stats_train={"cost": st["cost"]})
+        lags.append([o.get_lag() for o in policy.lag_optims])
+        n0 = len(logger.rows)
+        policy.update(0, buf, batch_size=batch_size, repeat=repeat)
+        rows = [r for r in logger.rows[n0:] if "update/gradient_steps" not in r]
+        assert len(rows) % 3 == 0                       # actor stats, critic stats, {total, entropy} per minibatch
+        keys = list(rows[0].keys()) + list(rows[1].keys()) + list(rows[2].keys())
+        first_rows.append([{**rows[0], **rows[1], **rows[2]}[k] for k in keys])
+        last_rows.append([{**rows[-3], **rows[-2], **rows[-1]}[k] for k in keys])
+        steps_per.append(len(rows) // 3)
+        curve.append([st["reward"], st["cost"], st["steps"]])
+    out.update(curve=np.array(curve), first_rows=np.array(first_rows), last_rows=np.array(last_rows), lagrangians=np.array(lags),
+               steps_per_update=np.array(steps_per), stat_keys=np.array(keys), theta_final=flat_params(ac))
+    cfg = dict(obs_dim=obs_dim, act_dim=act_dim, hidden=list(hidden), env_num=env_num, ep_len=ep_len, cycles=cycles,
+               batch_size=batch_size, repeat=repeat, seed=seed, cost_limit=cost_limit, max_action=1.0, lr=5e-4,
+               lagrangian_pid=[0.05, 0.0005, 0.1])
+    cfg.update(kw)
+    out["cfg_json"] = np.array(json.dumps(cfg))
+    np.savez_compressed(os.path.join(HERE, f"loop_{name}.npz"), **out)
+    print(f"G11 loop_{name}.npz cycles={cycles} reward {curve[0][0]:.2f} -> {curve[-1][0]:.2f} cost {curve[0][1]:.2f} -> {curve[-1][1]:.2f} "
+          f"lag {lags[0][0]:.3f} -> {lags[-1][0]:.3f} steps/update {steps_per[0]}")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    gen("ppo", 8, 2, (64, 64), env_num=8, ep_len=60, cycles=12, batch_size=128, repeat=4, seed=70, cost_limit=8.0,
+        target_kl=0.5, max_grad_norm=0.5)

@@ -1,0 +1,94 @@
+"""Closed-loop parity: collect with the policy -> update on the MI355X -> collect with the updated policy ..., against
+the learning curve the UNMODIFIED reference PPOLagrangian produced on the same synthetic env with the same random
+streams (tests/golden/gen_golden_loop.py).  This is the results-parity target of BASELINE.md (returns, costs) in
+miniature: acting, storing, process_fn + learn and the PID multiplier across 12 collect/update cycles.
+
+Random streams: numpy's for the minibatch permutations, torch's for the sampled actions -- including the draws the
+reference's forward() wastes inside update() (PPOLagrangian(reference_rng=True) burns the same amount).
+Tolerances (observed: rewards within 1.5e-4 of values ~50, episode costs identical in every cycle, theta mean
+diff 1.4e-7): rewards 5e-3 abs, costs equal, PID multiplier 1e-5, parameters mean 2e-6 / max 2e-3."""
+import json
+import random
+
+import numpy as np
+import pytest
+import torch
+from torch.distributions import Independent, Normal
+
+from helpers import load_npz
+
+pytestmark = pytest.mark.gpu
+
+
+def _rollout(policy, env, buf):
+    from fsrl_amd.data import Batch
+    obs, _ = env.reset()
+    E = len(env)
+    ids = np.arange(E)
+    ep_rew, ep_cost, steps = np.zeros(E), np.zeros(E), 0
+    while True:
+        with torch.no_grad():
+            res = policy(Batch(obs=obs, info={}), None)
+        act = res.act.numpy()
+        obs_next, rew, term, trunc, info = env.step(policy.map_action(act), ids)
+        buf.add(Batch(obs=obs, act=act, rew=rew, info={"cost": info["cost"]}, terminated=term, truncated=trunc,
+                      obs_next=obs_next), buffer_ids=ids)
+        ep_rew += rew; ep_cost += info["cost"]; steps += E
+        obs = obs_next
+        if (term | trunc).all():
+            break
+    return dict(reward=float(ep_rew.mean()), cost=float(ep_cost.mean()), steps=steps)
+
+
+def test_closed_training_loop_tracks_the_reference_learning_curve():
+    from fsrl_amd.data import HipVectorReplayBuffer
+    from fsrl_amd.env import Box, SyntheticSafetyVectorEnv
+    from fsrl_amd.policy import PPOLagrangian
+    from fsrl_amd.utils.net import ActorProb, Critic, Net
+    g = load_npz("loop_ppo.npz"); cfg = json.loads(str(g["cfg_json"]))
+    Do, Da, h, E = cfg["obs_dim"], cfg["act_dim"], tuple(cfg["hidden"]), cfg["env_num"]
+    actor = ActorProb(Net((Do, ), hidden_sizes=h), (Da, ), max_action=1.0)
+    critics = [Critic(Net((Do, ), hidden_sizes=h)) for _ in range(2)]
+
+    class Cap:
+        def __init__(self): self.rows = []
+        def store(self, tab=None, **kw): self.rows.append({(tab + "/" + k if tab else k): float(v) for k, v in kw.items()})
+        def print(self, *a, **k): pass
+    log = Cap()
+    from fsrl_amd.utils.net import ActorCritic
+    optim = torch.optim.Adam(ActorCritic(actor, critics).parameters(), lr=cfg["lr"])
+    pol = PPOLagrangian(actor, critics, optim, lambda *l: Independent(Normal(*l), 1), logger=log, cost_limit=cfg["cost_limit"],
+                        target_kl=cfg["target_kl"], max_grad_norm=cfg["max_grad_norm"],
+                        observation_space=Box(-np.inf, np.inf, (Do, )), action_space=Box(-1, 1, (Da, )), device=0, env_num=E,
+                        buffer_size=E * cfg["ep_len"] * 2, reference_rng=True)
+    pol.engine.set_params(g["theta0"]); pol._pull_params()
+    pol.train()
+    env = SyntheticSafetyVectorEnv(env_num=E, obs_dim=Do, act_dim=Da, episode_len=cfg["ep_len"], seed=cfg["seed"] + 11)
+    buf = HipVectorReplayBuffer(pol.engine, E * cfg["ep_len"] * 2, E)
+    seed = cfg["seed"] + 7
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    keys = [str(k) for k in g["stat_keys"]]
+    curve, lags = [], []
+    for c in range(cfg["cycles"]):
+        buf.reset()
+        st = _rollout(pol, env, buf)
+        pol.pre_update_fn(stats_train={"cost": st["cost"]})
+        lags.append(pol.lag_optims[0].get_lag())
+        n0 = len(log.rows)
+        pol.update(0, buf, batch_size=cfg["batch_size"], repeat=cfg["repeat"])
+        rows = [r for r in log.rows[n0:] if "update/gradient_steps" not in r]
+        assert len(rows) // 2 == int(g["steps_per_update"][c])
+        first = {**rows[0], **rows[1]}
+        last = {**rows[-2], **rows[-1]}
+        curve.append([st["reward"], st["cost"], st["steps"]])
+        assert abs(st["reward"] - g["curve"][c][0]) <= 5e-3 and st["cost"] == g["curve"][c][1], (c, st, g["curve"][c])
+        np.testing.assert_allclose([first[k] for k in keys], g["first_rows"][c], rtol=2e-4, atol=1e-4)
+        np.testing.assert_allclose([last[k] for k in keys], g["last_rows"][c], rtol=2e-4, atol=1e-4)
+    curve, want = np.array(curve), g["curve"]
+    assert np.array_equal(curve[:, 2], want[:, 2])
+    np.testing.assert_allclose(lags, g["lagrangians"][:, 0], rtol=1e-5, atol=1e-7)
+    d = np.abs(pol.engine.get_params() - g["theta_final"])
+    assert d.mean() <= 2e-6 and d.max() <= 2e-3, (d.mean(), d.max())
+    print("closed loop: max |reward diff|", np.abs(curve[:, 0] - want[:, 0]).max(), "max |cost diff|",
+          np.abs(curve[:, 1] - want[:, 1]).max(), "theta mean/max diff", d.mean(), d.max())
+    pol.engine.close()
