@@ -83,7 +83,62 @@ def gen(name, obs_dim, act_dim, hidden, env_num, ep_len, cycles, batch_size, rep
           f"lag {lags[0][0]:.3f} -> {lags[-1][0]:.3f} steps/update {steps_per[0]}")
 
 
+def gen_sac(name, obs_dim, act_dim, hidden, env_num, ep_len, cycles, batch_size, updates_per_cycle, seed, cost_limit, n_step=2):
+    """Off-policy closed loop: the store accumulates over cycles; `updates_per_cycle` SACLagrangian.update calls after
+    every collect (fsrl/trainer/offpolicy.py:100-105)."""
+    from fsrl.policy import SACLagrangian
+    from fsrl.utils.net.common import ActorCritic
+    from fsrl.utils.net.continuous import DoubleCritic
+    from ref_shim import ActorProb, Net, _Box
+    from torch import nn
+    seed_all(seed)
+    actor = ActorProb(Net((obs_dim, ), hidden_sizes=hidden), (act_dim, ), max_action=1.0, conditioned_sigma=True, unbounded=True)
+    critics = [DoubleCritic(Net((obs_dim, ), (act_dim, ), hidden_sizes=hidden, concat=True),
+                            Net((obs_dim, ), (act_dim, ), hidden_sizes=hidden, concat=True)) for _ in range(2)]
+    for m in ActorCritic(actor, critics).modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.orthogonal_(m.weight)
+            torch.nn.init.zeros_(m.bias)
+    log_alpha = torch.zeros(1, requires_grad=True)
+    logger = CaptureLogger()
+    policy = SACLagrangian(actor=actor, critics=critics, actor_optim=torch.optim.Adam(actor.parameters(), lr=5e-4),
+                           critic_optim=torch.optim.Adam(nn.ModuleList(critics).parameters(), lr=1e-3), logger=logger,
+                           alpha=(-float(act_dim), log_alpha, torch.optim.Adam([log_alpha], lr=3e-4)), n_step=n_step,
+                           cost_limit=cost_limit, observation_space=_Box(-np.inf, np.inf, (obs_dim, )),
+                           action_space=_Box(-1, 1, (act_dim, )))
+    policy.train()
+    env = SyntheticSafetyVectorEnv(env_num=env_num, obs_dim=obs_dim, act_dim=act_dim, episode_len=ep_len, seed=seed + 11)
+    buf = VectorReplayBuffer(env_num * ep_len * cycles, env_num)           # never wraps
+    flat = lambda mods: torch.cat([p.detach().reshape(-1) for m in mods for p in m.parameters()]).numpy().copy()  # noqa: E731
+    out = {"theta_actor0": flat([actor]), "theta_critics0": flat(critics)}
+    seed_all(seed + 7)
+    curve, last_rows, lags, alphas = [], [], [], []
+    for c in range(cycles):
+        st = rollout(policy, env, buf)
+        policy.pre_update_fn(stats_train={"cost": st["cost"]})
+        lags.append([o.get_lag() for o in policy.lag_optims])
+        n0 = len(logger.rows)
+        for _ in range(updates_per_cycle):
+            policy.update(batch_size, buf)
+        rows = logger.rows[n0:]
+        keys = list(rows[-2].keys()) + list(rows[-1].keys())
+        last_rows.append([{**rows[-2], **rows[-1]}[k] for k in keys])
+        alphas.append(float(policy._alpha))
+        curve.append([st["reward"], st["cost"], st["steps"]])
+    out.update(curve=np.array(curve), last_rows=np.array(last_rows), lagrangians=np.array(lags), alphas=np.array(alphas),
+               stat_keys=np.array(keys), theta_actor_final=flat([actor]), theta_critics_final=flat(critics),
+               theta_critics_old_final=flat(list(policy.critics_old)))
+    cfg = dict(obs_dim=obs_dim, act_dim=act_dim, hidden=list(hidden), env_num=env_num, ep_len=ep_len, cycles=cycles,
+               batch_size=batch_size, updates_per_cycle=updates_per_cycle, seed=seed, cost_limit=cost_limit, n_step=n_step,
+               actor_lr=5e-4, critic_lr=1e-3, alpha_lr=3e-4, tau=0.05, gamma=0.99)
+    out["cfg_json"] = np.array(json.dumps(cfg))
+    np.savez_compressed(os.path.join(HERE, f"loop_{name}.npz"), **out)
+    print(f"G11 loop_{name}.npz cycles={cycles} reward {curve[0][0]:.2f} -> {curve[-1][0]:.2f} cost {curve[0][1]:.2f} -> {curve[-1][1]:.2f} "
+          f"alpha {alphas[0]:.4f} -> {alphas[-1]:.4f} lag {lags[0][0]:.3f} -> {lags[-1][0]:.3f}")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    gen_sac("sac", 8, 2, (64, 64), env_num=6, ep_len=50, cycles=10, batch_size=64, updates_per_cycle=30, seed=71, cost_limit=5.0)
     gen("ppo", 8, 2, (64, 64), env_num=8, ep_len=60, cycles=12, batch_size=128, repeat=4, seed=70, cost_limit=8.0,
         target_kl=0.5, max_grad_norm=0.5)
