@@ -10,6 +10,7 @@ from torch import nn
 
 from fsrl_amd import _lib
 from fsrl_amd.policy.base_policy import BasePolicy
+from fsrl_amd.policy.ppo_lag import _chunk_sizes
 
 FOCOPS_KEYS = ("loss/nu_loss", "loss/nu_value", "loss/actor_loss", "loss/kl", "loss/entropy", "loss/vf0", "loss/vf1",
                "loss/vf_total")
@@ -24,7 +25,7 @@ class FOCOPS(BasePolicy):
                  max_batchsize: int = 99999, reward_normalization: bool = False, deterministic_eval: bool = True,
                  action_scaling: bool = True, action_bound_method: str = "clip", observation_space=None,
                  action_space=None, lr_scheduler=None, device: Union[int, str] = 0, env_num: int = 1,
-                 buffer_size: int = 100000) -> None:
+                 buffer_size: int = 100000, reference_rng: bool = False) -> None:
         super().__init__(actor, critics, dist_fn, logger, gamma, max_batchsize, reward_normalization, deterministic_eval,
                          action_scaling, action_bound_method, observation_space, action_space, lr_scheduler)
         assert self.critics_num == 2, "FOCOPS uses a reward and a cost critic"
@@ -35,6 +36,7 @@ class FOCOPS(BasePolicy):
         self._nu_max, self._nu_lr, self._nu = nu
         self._is_auto_nu = True
         self._ave_cost_return = 0.0
+        self._reference_rng = reference_rng     # burn the torch draws the reference's forward() wastes in update()
         self._make_engine(device, env_num, buffer_size, actor_optim, algo=_lib.ALGO_FOCOPS, gae_lambda=gae_lambda,
                           norm_adv=advantage_normalization, target_kl=None)
         self.engine.focops_init(actor_lr=actor_optim.param_groups[0]["lr"], critic_lr=critic_optim.param_groups[0]["lr"],
@@ -60,9 +62,17 @@ class FOCOPS(BasePolicy):
         eng = self.engine
         _lib.check(eng.lib.fsrl_focops_set_nu(eng._ctx, float(self._nu), float(loss_nu)))
         n = eng.ppo_begin([0.0], 1.0, batch_size)
+        burn = self._reference_rng and (self.training or not self._deterministic_eval)
+        da = eng.cfg.act_dim
+        if burn:                                                     # process_fn: forward per chunk of max_batchsize
+            for m in _chunk_sizes(n, self._max_batchsize):
+                torch.normal(torch.zeros(m, da), torch.ones(m, da))
         stopped_at = -1
         for step in range(repeat):
             perm = np.random.permutation(n) if n > 0 else None       # Batch.split(shuffle=True)
+            if burn:                                                 # policy_loss: forward per minibatch
+                for m in _chunk_sizes(n, batch_size):
+                    torch.normal(torch.zeros(m, da), torch.ones(m, da))
             if eng.ppo_pass(perm):
                 stopped_at = step
                 self.logger.print("Early stop at step %d due to reaching max kl." % step)

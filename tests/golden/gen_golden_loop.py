@@ -28,7 +28,7 @@ from ref_shim import Batch, VectorReplayBuffer  # noqa: E402
 from fsrl_amd.env.synthetic import SyntheticSafetyVectorEnv  # noqa: E402  (numpy only; no engine is touched)
 
 
-def rollout(policy, env, buf, rng_unused=None):
+def rollout(policy, env, buf, noise=False):
     """One collect of exactly env_num episodes (every env runs one episode, lock-step)."""
     obs, _ = env.reset()
     E = len(env)
@@ -38,6 +38,8 @@ def rollout(policy, env, buf, rng_unused=None):
         with torch.no_grad():
             res = policy(Batch(obs=obs, info={}), None)
         act = res.act.numpy()
+        if noise:
+            act = policy.exploration_noise(act, None)
         obs_next, rew, term, trunc, info = env.step(policy.map_action(act), ids)
         buf.add({"obs": obs, "act": act, "rew": rew, "terminated": term, "truncated": trunc, "done": term | trunc,
                  "obs_next": obs_next, "info.cost": info["cost"]}, ids)
@@ -81,6 +83,96 @@ def gen(name, obs_dim, act_dim, hidden, env_num, ep_len, cycles, batch_size, rep
     np.savez_compressed(os.path.join(HERE, f"loop_{name}.npz"), **out)
     print(f"G11 loop_{name}.npz cycles={cycles} reward {curve[0][0]:.2f} -> {curve[-1][0]:.2f} cost {curve[0][1]:.2f} -> {curve[-1][1]:.2f} "
           f"lag {lags[0][0]:.3f} -> {lags[-1][0]:.3f} steps/update {steps_per[0]}")
+
+
+def gen_focops(name, obs_dim, act_dim, hidden, env_num, ep_len, cycles, batch_size, repeat, seed, cost_limit):
+    from fsrl.policy import FOCOPS
+    from gen_golden_trust import build_nets, dist
+    from torch import nn
+    from ref_shim import _Box
+    actor, critic, ac = build_nets(obs_dim, act_dim, hidden, seed)
+    logger = CaptureLogger()
+    policy = FOCOPS(actor, critic, torch.optim.Adam(actor.parameters(), lr=5e-4),
+                    torch.optim.Adam(nn.ModuleList(critic).parameters(), lr=1e-3), dist, logger=logger, cost_limit=cost_limit,
+                    nu=(2.0, 1e-2, torch.zeros(1)), observation_space=_Box(-np.inf, np.inf, (obs_dim, )),
+                    action_space=_Box(-1, 1, (act_dim, )))
+    policy.train()
+    env = SyntheticSafetyVectorEnv(env_num=env_num, obs_dim=obs_dim, act_dim=act_dim, episode_len=ep_len, seed=seed + 11)
+    buf = VectorReplayBuffer(env_num * ep_len * 2, env_num)
+    out = {"theta0": flat_params(ac)}
+    seed_all(seed + 7)
+    curve, last_rows, nus, steps_per = [], [], [], []
+    for c in range(cycles):
+        buf.reset()
+        st = rollout(policy, env, buf)
+        policy.pre_update_fn(stats_train={"cost": st["cost"]})
+        n0 = len(logger.rows)
+        policy.update(0, buf, batch_size=batch_size, repeat=repeat)
+        rows = [r for r in logger.rows[n0:] if "update/gradient_steps" not in r]
+        assert len(rows) % 3 == 0
+        keys = list(rows[0].keys()) + list(rows[1].keys()) + list(rows[2].keys())
+        last_rows.append([{**rows[-3], **rows[-2], **rows[-1]}[k] for k in keys])
+        steps_per.append(len(rows) // 3)
+        nus.append(float(policy._nu))
+        curve.append([st["reward"], st["cost"], st["steps"]])
+    out.update(curve=np.array(curve), last_rows=np.array(last_rows), nus=np.array(nus), steps_per_update=np.array(steps_per),
+               stat_keys=np.array(keys), theta_final=flat_params(ac))
+    cfg = dict(obs_dim=obs_dim, act_dim=act_dim, hidden=list(hidden), env_num=env_num, ep_len=ep_len, cycles=cycles,
+               batch_size=batch_size, repeat=repeat, seed=seed, cost_limit=cost_limit, actor_lr=5e-4, critic_lr=1e-3,
+               nu_max=2.0, nu_lr=1e-2)
+    out["cfg_json"] = np.array(json.dumps(cfg))
+    np.savez_compressed(os.path.join(HERE, f"loop_{name}.npz"), **out)
+    print(f"G11 loop_{name}.npz cycles={cycles} reward {curve[0][0]:.2f} -> {curve[-1][0]:.2f} cost {curve[0][1]:.2f} -> {curve[-1][1]:.2f} "
+          f"nu {nus[0]:.3f} -> {nus[-1]:.3f} steps/update {steps_per}")
+
+
+def gen_ddpg(name, obs_dim, act_dim, hidden, env_num, ep_len, cycles, batch_size, updates_per_cycle, seed, cost_limit, n_step=3):
+    from fsrl.policy import DDPGLagrangian
+    from fsrl.utils.net.common import ActorCritic
+    from ref_shim import Actor, Critic, Net, _Box
+    from torch import nn
+
+    class GaussianNoise:                      # tianshou.exploration.GaussianNoise: numpy's global RNG
+        def __init__(self, sigma): self._sigma = sigma
+        def __call__(self, size): return np.random.normal(0.0, self._sigma, size)
+    seed_all(seed)
+    actor = Actor(Net((obs_dim, ), hidden_sizes=hidden), (act_dim, ), max_action=1.0)
+    critics = [Critic(Net((obs_dim, ), (act_dim, ), hidden_sizes=hidden, concat=True)) for _ in range(2)]
+    for m in ActorCritic(actor, critics).modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.orthogonal_(m.weight)
+            torch.nn.init.zeros_(m.bias)
+    logger = CaptureLogger()
+    policy = DDPGLagrangian(actor=actor, critics=critics, actor_optim=torch.optim.Adam(actor.parameters(), lr=1e-4),
+                            critic_optim=torch.optim.Adam(nn.ModuleList(critics).parameters(), lr=1e-3), logger=logger,
+                            exploration_noise=GaussianNoise(0.1), n_step=n_step, cost_limit=cost_limit,
+                            observation_space=_Box(-np.inf, np.inf, (obs_dim, )), action_space=_Box(-1, 1, (act_dim, )))
+    policy.train()
+    env = SyntheticSafetyVectorEnv(env_num=env_num, obs_dim=obs_dim, act_dim=act_dim, episode_len=ep_len, seed=seed + 11)
+    buf = VectorReplayBuffer(env_num * ep_len * cycles, env_num)
+    flat = lambda mods: torch.cat([p.detach().reshape(-1) for m in mods for p in m.parameters()]).numpy().copy()  # noqa: E731
+    out = {"theta_actor0": flat([actor]), "theta_critics0": flat(critics)}
+    seed_all(seed + 7)
+    curve, last_rows, lags = [], [], []
+    for c in range(cycles):
+        st = rollout(policy, env, buf, noise=True)
+        policy.pre_update_fn(stats_train={"cost": st["cost"]})
+        lags.append([o.get_lag() for o in policy.lag_optims])
+        for _ in range(updates_per_cycle):
+            policy.update(batch_size, buf)
+        rows = logger.rows
+        keys = list(rows[-2].keys()) + list(rows[-1].keys())
+        last_rows.append([{**rows[-2], **rows[-1]}[k] for k in keys])
+        curve.append([st["reward"], st["cost"], st["steps"]])
+    out.update(curve=np.array(curve), last_rows=np.array(last_rows), lagrangians=np.array(lags), stat_keys=np.array(keys),
+               theta_actor_final=flat([actor]), theta_critics_final=flat(critics))
+    cfg = dict(obs_dim=obs_dim, act_dim=act_dim, hidden=list(hidden), env_num=env_num, ep_len=ep_len, cycles=cycles,
+               batch_size=batch_size, updates_per_cycle=updates_per_cycle, seed=seed, cost_limit=cost_limit, n_step=n_step,
+               actor_lr=1e-4, critic_lr=1e-3, tau=0.05, gamma=0.99, exploration_sigma=0.1)
+    out["cfg_json"] = np.array(json.dumps(cfg))
+    np.savez_compressed(os.path.join(HERE, f"loop_{name}.npz"), **out)
+    print(f"G11 loop_{name}.npz cycles={cycles} reward {curve[0][0]:.2f} -> {curve[-1][0]:.2f} cost {curve[0][1]:.2f} -> {curve[-1][1]:.2f} "
+          f"lag {lags[0][0]:.3f} -> {lags[-1][0]:.3f}")
 
 
 def gen_sac(name, obs_dim, act_dim, hidden, env_num, ep_len, cycles, batch_size, updates_per_cycle, seed, cost_limit, n_step=2):
@@ -140,5 +232,7 @@ def gen_sac(name, obs_dim, act_dim, hidden, env_num, ep_len, cycles, batch_size,
 if __name__ == "__main__":
     torch.set_num_threads(4)
     gen_sac("sac", 8, 2, (64, 64), env_num=6, ep_len=50, cycles=10, batch_size=64, updates_per_cycle=30, seed=71, cost_limit=5.0)
+    gen_focops("focops", 8, 2, (64, 64), env_num=8, ep_len=60, cycles=10, batch_size=128, repeat=4, seed=72, cost_limit=8.0)
+    gen_ddpg("ddpg", 8, 2, (64, 64), env_num=6, ep_len=50, cycles=10, batch_size=64, updates_per_cycle=30, seed=73, cost_limit=5.0)
     gen("ppo", 8, 2, (64, 64), env_num=8, ep_len=60, cycles=12, batch_size=128, repeat=4, seed=70, cost_limit=8.0,
         target_kl=0.5, max_grad_norm=0.5)

@@ -20,7 +20,7 @@ from helpers import load_npz
 pytestmark = pytest.mark.gpu
 
 
-def _rollout(policy, env, buf):
+def _rollout(policy, env, buf, noise=False):
     from fsrl_amd.data import Batch
     obs, _ = env.reset()
     E = len(env)
@@ -30,6 +30,8 @@ def _rollout(policy, env, buf):
         with torch.no_grad():
             res = policy(Batch(obs=obs, info={}), None)
         act = res.act.numpy()
+        if noise:
+            act = policy.exploration_noise(act, None)
         obs_next, rew, term, trunc, info = env.step(policy.map_action(act), ids)
         buf.add(Batch(obs=obs, act=act, rew=rew, info={"cost": info["cost"]}, terminated=term, truncated=trunc,
                       obs_next=obs_next), buffer_ids=ids)
@@ -143,5 +145,96 @@ def test_closed_offpolicy_loop_tracks_the_reference_learning_curve():
         assert abs(float(pol.engine.sac_get_params(0)[1]) - g["alphas"][c]) <= 1e-5
     d = np.abs(pol.engine.sac_get_params(0)[0] - g["theta_actor_final"])
     print("closed SAC loop: max |reward diff|", worst_r, "max |cost diff|", worst_c, "actor theta mean/max diff", d.mean(), d.max())
+    assert d.mean() <= 1e-4, (d.mean(), d.max())
+    pol.engine.close()
+
+
+class _Cap:
+    def __init__(self): self.rows = []
+    def store(self, tab=None, **kw): self.rows.append({(tab + "/" + k if tab else k): float(v) for k, v in kw.items()})
+    def print(self, *a, **k): pass
+
+
+def test_closed_focops_loop_tracks_the_reference_learning_curve():
+    """FOCOPS incl. the cycles in which the reference stops a pass early on the KL threshold."""
+    from fsrl_amd.data import HipVectorReplayBuffer
+    from fsrl_amd.env import Box, SyntheticSafetyVectorEnv
+    from fsrl_amd.policy import FOCOPS
+    from fsrl_amd.utils.net import ActorProb, Critic, Net
+    g = load_npz("loop_focops.npz"); cfg = json.loads(str(g["cfg_json"]))
+    Do, Da, h, E = cfg["obs_dim"], cfg["act_dim"], tuple(cfg["hidden"]), cfg["env_num"]
+    actor = ActorProb(Net((Do, ), hidden_sizes=h), (Da, ), max_action=1.0)
+    critics = [Critic(Net((Do, ), hidden_sizes=h)) for _ in range(2)]
+    log = _Cap()
+    pol = FOCOPS(actor, critics, torch.optim.Adam(actor.parameters(), lr=cfg["actor_lr"]),
+                 torch.optim.Adam(torch.nn.ModuleList(critics).parameters(), lr=cfg["critic_lr"]),
+                 lambda *l: Independent(Normal(*l), 1), logger=log, cost_limit=cfg["cost_limit"],
+                 nu=(cfg["nu_max"], cfg["nu_lr"], torch.zeros(1)), observation_space=Box(-np.inf, np.inf, (Do, )),
+                 action_space=Box(-1, 1, (Da, )), device=0, env_num=E, buffer_size=E * cfg["ep_len"] * 2, reference_rng=True)
+    pol.engine.set_params(g["theta0"]); pol._pull_params()
+    pol.train()
+    env = SyntheticSafetyVectorEnv(env_num=E, obs_dim=Do, act_dim=Da, episode_len=cfg["ep_len"], seed=cfg["seed"] + 11)
+    buf = HipVectorReplayBuffer(pol.engine, E * cfg["ep_len"] * 2, E)
+    seed = cfg["seed"] + 7
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    keys = [str(k) for k in g["stat_keys"]]
+    worst = 0.0
+    for c in range(cfg["cycles"]):
+        buf.reset()
+        st = _rollout(pol, env, buf)
+        pol.pre_update_fn(stats_train={"cost": st["cost"]})
+        n0 = len(log.rows)
+        pol.update(0, buf, batch_size=cfg["batch_size"], repeat=cfg["repeat"])
+        rows = [r for r in log.rows[n0:] if "update/gradient_steps" not in r]
+        assert len(rows) // 3 == int(g["steps_per_update"][c]), (c, len(rows) // 3, g["steps_per_update"][c])   # same early stops
+        last = {**rows[-3], **rows[-2], **rows[-1]}
+        worst = max(worst, abs(st["reward"] - g["curve"][c][0]))
+        assert abs(st["reward"] - g["curve"][c][0]) <= 5e-3 and st["cost"] == g["curve"][c][1], (c, st, g["curve"][c])
+        np.testing.assert_allclose([last[k] for k in keys], g["last_rows"][c], rtol=3e-4, atol=1e-4)
+        assert abs(float(pol._nu) - g["nus"][c]) <= 1e-6
+    d = np.abs(pol.engine.get_params() - g["theta_final"])
+    print("closed FOCOPS loop: max |reward diff|", worst, "theta mean/max diff", d.mean(), d.max())
+    assert d.mean() <= 2e-6 and d.max() <= 2e-3, (d.mean(), d.max())
+    pol.engine.close()
+
+
+def test_closed_ddpg_loop_tracks_the_reference_learning_curve():
+    """DDPG-Lagrangian: deterministic actor + Gaussian exploration noise from numpy's stream, 300 updates."""
+    from fsrl_amd.data import HipVectorReplayBuffer
+    from fsrl_amd.env import Box, SyntheticSafetyVectorEnv
+    from fsrl_amd.policy import DDPGLagrangian, SACLagrangian
+    from fsrl_amd.utils.net import Actor, Critic, GaussianNoise, Net
+    g = load_npz("loop_ddpg.npz"); cfg = json.loads(str(g["cfg_json"]))
+    Do, Da, h, E = cfg["obs_dim"], cfg["act_dim"], tuple(cfg["hidden"]), cfg["env_num"]
+    actor = Actor(Net((Do, ), hidden_sizes=h), (Da, ), max_action=1.0)
+    critics = [Critic(Net((Do, ), (Da, ), hidden_sizes=h, concat=True)) for _ in range(2)]
+    SACLagrangian._unflat([actor], g["theta_actor0"]); SACLagrangian._unflat(critics, g["theta_critics0"])
+    log = _Cap()
+    pol = DDPGLagrangian(actor, critics, torch.optim.Adam(actor.parameters(), lr=cfg["actor_lr"]),
+                         torch.optim.Adam(torch.nn.ModuleList(critics).parameters(), lr=cfg["critic_lr"]), logger=log,
+                         tau=cfg["tau"], exploration_noise=GaussianNoise(sigma=cfg["exploration_sigma"]), n_step=cfg["n_step"],
+                         cost_limit=cfg["cost_limit"], gamma=cfg["gamma"], observation_space=Box(-np.inf, np.inf, (Do, )),
+                         action_space=Box(-1, 1, (Da, )), device=0, env_num=E, buffer_size=E * cfg["ep_len"] * cfg["cycles"],
+                         reference_rng=True)
+    pol.train()
+    env = SyntheticSafetyVectorEnv(env_num=E, obs_dim=Do, act_dim=Da, episode_len=cfg["ep_len"], seed=cfg["seed"] + 11)
+    buf = HipVectorReplayBuffer(pol.engine, E * cfg["ep_len"] * cfg["cycles"], E)
+    seed = cfg["seed"] + 7
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    keys = [str(k) for k in g["stat_keys"]]
+    worst_r = worst_c = 0.0
+    for c in range(cfg["cycles"]):
+        st = _rollout(pol, env, buf, noise=True)
+        pol.pre_update_fn(stats_train={"cost": st["cost"]})
+        assert abs(pol.lag_optims[0].get_lag() - g["lagrangians"][c][0]) <= 1e-4 * max(1.0, g["lagrangians"][c][0])
+        for _ in range(cfg["updates_per_cycle"]):
+            pol.update(cfg["batch_size"], buf)
+        last = {**log.rows[-2], **log.rows[-1]}
+        worst_r = max(worst_r, abs(st["reward"] - g["curve"][c][0])); worst_c = max(worst_c, abs(st["cost"] - g["curve"][c][1]))
+        assert abs(st["reward"] - g["curve"][c][0]) <= 0.05 and abs(st["cost"] - g["curve"][c][1]) <= 0.5, (c, st, g["curve"][c])
+        tol = 2e-3 if c < 5 else 2e-2
+        np.testing.assert_allclose([last[k] for k in keys], g["last_rows"][c], rtol=tol, atol=tol)
+    d = np.abs(pol.engine.sac_get_params(0)[0] - g["theta_actor_final"])
+    print("closed DDPG loop: max |reward diff|", worst_r, "max |cost diff|", worst_c, "actor theta mean/max diff", d.mean(), d.max())
     assert d.mean() <= 1e-4, (d.mean(), d.max())
     pol.engine.close()
