@@ -1076,6 +1076,7 @@ struct TrState {
     size_t cap_rows = 0;
     int64_t critic_t = 0;     // Adam step count of the critic optimiser
     int na = 0;               // flat actor parameter count (API order)
+    std::vector<int32_t> ls_iters;   // line-search evaluations of every repeat of the last learn call
 };
 static TrState* tr_of(fsrl_ctx* c) {
     if (!c->tr) {
@@ -1309,6 +1310,16 @@ static int tr_hvp(fsrl_ctx* c, TrState* t, const float* v, float* out) {
     return actor_from_dev(c, t->Out, out);
 }
 
+// Line-search evaluations (policy forwards over the batch) of every repeat of the last fsrl_cpo_learn /
+// fsrl_trpo_learn call; returns how many were written.
+extern "C" int32_t fsrl_tr_linesearch_evals(fsrl_ctx* c, int32_t* out, int32_t cap) {
+    CHECK_ARG(c && out && cap >= 0, "bad argument");
+    TrState* t = tr_of(c);
+    const int32_t n = std::min<int32_t>(cap, (int32_t)t->ls_iters.size());
+    for (int32_t i = 0; i < n; ++i) out[i] = t->ls_iters[(size_t)i];
+    return n;
+}
+
 extern "C" int fsrl_tr_grad(fsrl_ctx* c, int32_t which, float* out, int64_t n) {
     CHECK_ARG(c && out, "null argument");
     TrState* t = tr_of(c);
@@ -1439,6 +1450,7 @@ extern "C" int fsrl_cpo_learn(fsrl_ctx* c, double ave_cost_return, int32_t repea
     const fsrl_tr_config& k = t->cfg;
     const float EPS = 1e-8f, delta = k.target_kl;
     const size_t n = (size_t)t->na;
+    t->ls_iters.clear();
     for (int rep = 0; rep < repeat; ++rep) {
         float* st = stats_out + (size_t)rep * FSRL_CPO_NSTATS;
         int rc = tr_critic_steps(c, t, k.optim_critic_iters, k.l2_reg, st + 14);
@@ -1507,9 +1519,11 @@ extern "C" int fsrl_cpo_learn(fsrl_ctx* c, double ave_cost_return, int32_t repea
         const float nrm = std::sqrt(vdot(dir, dir));
         for (size_t i = 0; i < n; ++i) dir[i] /= nrm;
         double beta = 1.0;
+        int evals = 0;
         if (!std::isnan(lam)) {
             std::vector<float> th(n);
             for (int bt = 0; bt < k.max_backtracks; ++bt) {
+                ++evals;
                 const float bf = (float)beta;
                 for (size_t i = 0; i < n; ++i) th[i] = bf * dir[i] + theta0[i];
                 rc = actor_set(c, th);
@@ -1527,6 +1541,7 @@ extern "C" int fsrl_cpo_learn(fsrl_ctx* c, double ave_cost_return, int32_t repea
         }
         st[0] = kl; st[1] = ent; st[2] = objective; st[3] = cost_sur; st[4] = A; st[5] = B; st[6] = c_value;
         st[7] = s_q; st[8] = s_r; st[9] = s_s; st[10] = lam; st[11] = nu; st[12] = (float)ocase; st[13] = (float)beta;
+        t->ls_iters.push_back(evals);
     }
     return 0;
 }
@@ -1541,6 +1556,7 @@ extern "C" int fsrl_trpo_learn(fsrl_ctx* c, const double* lagrangians, double re
     const size_t n = (size_t)t->na;
     const float lam0 = (c->cfg.use_lagrangian && lagrangians) ? (float)lagrangians[0] : 0.0f;
     const float resc = (float)rescaling, delta = k.target_kl;
+    t->ls_iters.clear();
     for (int rep = 0; rep < repeat; ++rep) {
         float* st = stats_out + (size_t)rep * FSRL_TRPO_NSTATS;
         int rc = tr_refresh_old(c, t);     // old_dist = pi_theta (detached), trpo_lag.py:189-190
@@ -1564,7 +1580,9 @@ extern "C" int fsrl_trpo_learn(fsrl_ctx* c, const double* lagrangians, double re
         float step = std::sqrt(2.0f * delta / vdot(dir, Hd));
         float kl = 0.0f;
         std::vector<float> th(n);
+        int evals = 0;
         for (int i = 0; i < k.max_backtracks; ++i) {
+            ++evals;
             for (size_t j = 0; j < n; ++j) th[j] = theta0[j] + step * dir[j];
             rc = actor_set(c, th);
             if (rc) return rc;
@@ -1582,6 +1600,7 @@ extern "C" int fsrl_trpo_learn(fsrl_ctx* c, const double* lagrangians, double re
         if (rc) return rc;
         st[0] = resc; st[1] = lam0; st[2] = loss_safety; st[3] = loss_rew; st[4] = loss_actor;
         st[5] = vf[0]; st[6] = vf[1]; st[7] = vf[0] + vf[1]; st[8] = kl; st[9] = step; st[10] = ent;
+        t->ls_iters.push_back(evals);
     }
     return 0;
 }

@@ -250,6 +250,11 @@ class Engine:
     def n_actor_params(self) -> int:
         return int(self.lib.fsrl_actor_param_count(self._ctx))
 
+    def tr_linesearch_evals(self, cap=64):
+        out = np.zeros(cap, np.int32)
+        n = int(self.lib.fsrl_tr_linesearch_evals(self._ctx, _ptr(out, _i32p), cap))
+        return out[:n]
+
     def tr_grad(self, which: int):
         out = np.empty(self.n_actor_params, np.float32)
         _lib.check(self.lib.fsrl_tr_grad(self._ctx, int(which), _ptr(out, _f32p), out.size))

@@ -30,12 +30,13 @@ class CPO(BasePolicy):
                  deterministic_eval: bool = True, action_scaling: bool = True,
                  action_bound_method: str = "clip", observation_space=None, action_space=None,
                  lr_scheduler=None, device: Union[int, str] = 0, env_num: int = 1,
-                 buffer_size: int = 100000) -> None:
+                 buffer_size: int = 100000, reference_rng: bool = False) -> None:
         super().__init__(actor, critics, dist_fn, logger, gamma, max_batchsize, reward_normalization,
                          deterministic_eval, action_scaling, action_bound_method, observation_space,
                          action_space, lr_scheduler)
         assert self.critics_num == 2, "CPO does not support multiple costs"
-        self.optim = optim                      # Adam over the critic parameters only (cpo_agent.py:147)
+        self.optim = optim
+        self._reference_rng = reference_rng                      # Adam over the critic parameters only (cpo_agent.py:147)
         self._cost_limit = cost_limit
         self._lambda, self._norm_adv = gae_lambda, advantage_normalization
         self._max_backtracks, self._optim_critic_iters = max_backtracks, optim_critic_iters
@@ -49,6 +50,14 @@ class CPO(BasePolicy):
 
     def update_cost_limit(self, cost_limit: float) -> None:
         self._cost_limit = cost_limit
+
+    def _burn(self, n_rows: int, forwards: int) -> None:
+        """The reference's forward() samples an action ([n, Da] normals from torch's stream) every time it is
+        called in training mode, also inside update(); reference_rng=True consumes the same amount."""
+        if self._reference_rng and (self.training or not self._deterministic_eval):
+            da = self.engine.cfg.act_dim
+            for _ in range(forwards):
+                torch.normal(torch.zeros(n_rows, da), torch.ones(n_rows, da))
 
     def learn(self, batch, **kwargs: Any):
         raise NotImplementedError("the HIP path runs process_fn + learn inside update()")
@@ -71,6 +80,8 @@ class CPO(BasePolicy):
             self.logger.store(**dict(zip(CPO_ACTOR_KEYS, (float(v) for v in row[:14]))))
             self.logger.store(**dict(zip(CPO_CRITIC_KEYS, (float(v) for v in row[14:]))))
         self.logger.store(gradient_steps=self.gradient_steps, tab="update")
+        if n > 0:   # process_fn: one forward; per repeat: 1 forward(s) + one per line-search evaluation
+            self._burn(n, 1 + 1 * len(stats) + int(eng.tr_linesearch_evals().sum()))
         self._pull_params()
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()

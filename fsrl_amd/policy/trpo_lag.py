@@ -29,18 +29,27 @@ class TRPOLagrangian(LagrangianPolicy):
                  deterministic_eval: bool = True, action_scaling: bool = True,
                  action_bound_method: str = "clip", observation_space=None, action_space=None,
                  lr_scheduler=None, device: Union[int, str] = 0, env_num: int = 1,
-                 buffer_size: int = 100000) -> None:
+                 buffer_size: int = 100000, reference_rng: bool = False) -> None:
         super().__init__(actor, critics, dist_fn, logger, use_lagrangian, lagrangian_pid, cost_limit,
                          rescaling, gamma, max_batchsize, reward_normalization, deterministic_eval,
                          action_scaling, action_bound_method, observation_space, action_space, lr_scheduler)
         assert self.critics_num == 2, "the HIP path supports one cost constraint"
         self.optim = optim
+        self._reference_rng = reference_rng
         self._lambda, self._norm_adv = gae_lambda, advantage_normalization
         self._max_backtracks, self._delta = max_backtracks, target_kl
         self._backtrack_coeff, self._optim_critic_iters = backtrack_coeff, optim_critic_iters
         self._damping = 0.1
         self._make_engine(device, env_num, buffer_size, optim, gae_lambda=gae_lambda, target_kl=None,
                           use_lagrangian=use_lagrangian)
+
+    def _burn(self, n_rows: int, forwards: int) -> None:
+        """The reference's forward() samples an action ([n, Da] normals from torch's stream) every time it is
+        called in training mode, also inside update(); reference_rng=True consumes the same amount."""
+        if self._reference_rng and (self.training or not self._deterministic_eval):
+            da = self.engine.cfg.act_dim
+            for _ in range(forwards):
+                torch.normal(torch.zeros(n_rows, da), torch.ones(n_rows, da))
 
     def learn(self, batch, **kwargs: Any):
         raise NotImplementedError("the HIP path runs process_fn + learn inside update()")
@@ -65,6 +74,8 @@ class TRPOLagrangian(LagrangianPolicy):
             self.logger.store(**d)
             self.logger.store(kl=kl, step_size=step, entropy=ent, tab="loss")
         self.logger.store(gradient_steps=self.gradient_steps, tab="update")
+        if n > 0:   # process_fn: one forward; per repeat: 2 forward(s) + one per line-search evaluation
+            self._burn(n, 1 + 2 * len(stats) + int(eng.tr_linesearch_evals().sum()))
         self._pull_params()
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()

@@ -179,6 +179,10 @@ int fsrl_cpo_learn(fsrl_ctx* ctx, double ave_cost_return, int32_t repeat, float*
 /* TRPOLagrangian.learn (trpo_lag.py:173-251).  stats_out: [repeat][FSRL_TRPO_NSTATS].          */
 int fsrl_trpo_learn(fsrl_ctx* ctx, const double* lagrangians, double rescaling, int32_t repeat,
                     float* stats_out);
+/* policy evaluations the line search of each repeat of the last learn call made (cpo.py:306-333,
+ * trpo_lag.py:205-231); returns the number written.  The reference samples an action in every one of them --
+ * callers that follow its random streams need the count.                                        */
+int32_t fsrl_tr_linesearch_evals(fsrl_ctx* ctx, int32_t* out, int32_t cap);
 /* building blocks, exposed for the parity tests (all on the batch of the last fsrl_tr_begin):
  * which = 0: grad of mean(ratio*A_r)   1: grad of -mean(ratio*A_c)   2: grad of mean KL(old||new)
  * out: flat ACTOR parameter vector (sigma_param, W1, b1, W2, b2, W3, b3).                      */

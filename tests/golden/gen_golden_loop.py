@@ -85,6 +85,49 @@ def gen(name, obs_dim, act_dim, hidden, env_num, ep_len, cycles, batch_size, rep
           f"lag {lags[0][0]:.3f} -> {lags[-1][0]:.3f} steps/update {steps_per[0]}")
 
 
+def gen_trust(kind, name, obs_dim, act_dim, hidden, env_num, ep_len, cycles, repeat, seed, cost_limit):
+    """CPO / TRPO-Lagrangian closed loop (full-batch updates, batch_size = 99999)."""
+    from fsrl.policy import CPO, TRPOLagrangian
+    from gen_golden_trust import build_nets, dist
+    from torch import nn
+    from ref_shim import _Box
+    actor, critic, ac = build_nets(obs_dim, act_dim, hidden, seed)
+    logger = CaptureLogger()
+    spaces = dict(observation_space=_Box(-np.inf, np.inf, (obs_dim, )), action_space=_Box(-1, 1, (act_dim, )))
+    if kind == "cpo":
+        policy = CPO(actor, critic, torch.optim.Adam(nn.ModuleList(critic).parameters(), lr=1e-3), dist, logger=logger,
+                     cost_limit=cost_limit, optim_critic_iters=10, **spaces)
+    else:
+        policy = TRPOLagrangian(actor, critic, torch.optim.Adam(nn.ModuleList(critic).parameters(), lr=1e-3), dist, logger=logger,
+                                cost_limit=cost_limit, optim_critic_iters=10, **spaces)
+    policy.train()
+    env = SyntheticSafetyVectorEnv(env_num=env_num, obs_dim=obs_dim, act_dim=act_dim, episode_len=ep_len, seed=seed + 11)
+    buf = VectorReplayBuffer(env_num * ep_len * 2, env_num)
+    out = {"theta0": flat_params(ac)}
+    seed_all(seed + 7)
+    curve, last_rows = [], []
+    for c in range(cycles):
+        buf.reset()
+        st = rollout(policy, env, buf)
+        policy.pre_update_fn(stats_train={"cost": st["cost"]})
+        n0 = len(logger.rows)
+        policy.update(0, buf, batch_size=99999, repeat=repeat)
+        rows = [r for r in logger.rows[n0:] if "update/gradient_steps" not in r]
+        per = len(rows) // repeat
+        keys = [k for r in rows[-per:] for k in r.keys()]
+        merged = {}
+        for r in rows[-per:]:
+            merged.update(r)
+        last_rows.append([merged[k] for k in keys])
+        curve.append([st["reward"], st["cost"], st["steps"]])
+    out.update(curve=np.array(curve), last_rows=np.array(last_rows), stat_keys=np.array(keys), theta_final=flat_params(ac))
+    cfg = dict(kind=kind, obs_dim=obs_dim, act_dim=act_dim, hidden=list(hidden), env_num=env_num, ep_len=ep_len, cycles=cycles,
+               repeat=repeat, seed=seed, cost_limit=cost_limit, lr=1e-3, optim_critic_iters=10)
+    out["cfg_json"] = np.array(json.dumps(cfg))
+    np.savez_compressed(os.path.join(HERE, f"loop_{name}.npz"), **out)
+    print(f"G11 loop_{name}.npz cycles={cycles} reward {curve[0][0]:.2f} -> {curve[-1][0]:.2f} cost {curve[0][1]:.2f} -> {curve[-1][1]:.2f} keys {keys}")
+
+
 def gen_focops(name, obs_dim, act_dim, hidden, env_num, ep_len, cycles, batch_size, repeat, seed, cost_limit):
     from fsrl.policy import FOCOPS
     from gen_golden_trust import build_nets, dist
@@ -233,6 +276,8 @@ if __name__ == "__main__":
     torch.set_num_threads(4)
     gen_sac("sac", 8, 2, (64, 64), env_num=6, ep_len=50, cycles=10, batch_size=64, updates_per_cycle=30, seed=71, cost_limit=5.0)
     gen_focops("focops", 8, 2, (64, 64), env_num=8, ep_len=60, cycles=10, batch_size=128, repeat=4, seed=72, cost_limit=8.0)
+    gen_trust("cpo", "cpo", 8, 2, (64, 64), env_num=8, ep_len=60, cycles=8, repeat=2, seed=74, cost_limit=20.0)
+    gen_trust("trpo", "trpo", 8, 2, (64, 64), env_num=8, ep_len=60, cycles=8, repeat=2, seed=75, cost_limit=20.0)
     gen_ddpg("ddpg", 8, 2, (64, 64), env_num=6, ep_len=50, cycles=10, batch_size=64, updates_per_cycle=30, seed=73, cost_limit=5.0)
     gen("ppo", 8, 2, (64, 64), env_num=8, ep_len=60, cycles=12, batch_size=128, repeat=4, seed=70, cost_limit=8.0,
         target_kl=0.5, max_grad_norm=0.5)

@@ -238,3 +238,61 @@ def test_closed_ddpg_loop_tracks_the_reference_learning_curve():
     print("closed DDPG loop: max |reward diff|", worst_r, "max |cost diff|", worst_c, "actor theta mean/max diff", d.mean(), d.max())
     assert d.mean() <= 1e-4, (d.mean(), d.max())
     pol.engine.close()
+
+
+@pytest.mark.parametrize("kind", ["cpo", "trpo"])
+def test_closed_trust_region_loop_tracks_the_reference_learning_curve(kind):
+    """CPO / TRPO-Lagrangian: full-batch updates with conjugate gradients and a line search in every cycle.  fp32 CG on
+    the damped Hessian amplifies rounding differences (conditioning note: the reference itself moves by
+    ~1e-3 in Q/R/S when its batch is merely re-ordered), so one update already leaves theta ~1e-4..1e-3 apart and a
+    stochastic closed loop turns that into percent-level differences of the episode returns within a few cycles.
+    What is asserted: the first cycle is exact (same acting, storing, random stream), the second within 5 %, and for
+    TRPO-Lag the whole curve within 10 % of its range (observed 0.2 .. 4.1 on returns of ~50).  CPO's line search
+    exhausts its backtracks in most cycles of this fixture (step 0.8^10 in the reference too): printed, not asserted."""
+    from fsrl_amd.data import HipVectorReplayBuffer
+    from fsrl_amd.env import Box, SyntheticSafetyVectorEnv
+    from fsrl_amd.policy import CPO, TRPOLagrangian
+    from fsrl_amd.utils.net import ActorProb, Critic, Net
+    g = load_npz(f"loop_{kind}.npz"); cfg = json.loads(str(g["cfg_json"]))
+    Do, Da, h, E = cfg["obs_dim"], cfg["act_dim"], tuple(cfg["hidden"]), cfg["env_num"]
+    actor = ActorProb(Net((Do, ), hidden_sizes=h), (Da, ), max_action=1.0)
+    critics = [Critic(Net((Do, ), hidden_sizes=h)) for _ in range(2)]
+    log = _Cap()
+    cls = CPO if kind == "cpo" else TRPOLagrangian
+    pol = cls(actor, critics, torch.optim.Adam(torch.nn.ModuleList(critics).parameters(), lr=cfg["lr"]),
+              lambda *l: Independent(Normal(*l), 1), logger=log, cost_limit=cfg["cost_limit"],
+              optim_critic_iters=cfg["optim_critic_iters"], observation_space=Box(-np.inf, np.inf, (Do, )),
+              action_space=Box(-1, 1, (Da, )), device=0, env_num=E, buffer_size=E * cfg["ep_len"] * 2, reference_rng=True)
+    pol.engine.set_params(g["theta0"]); pol._pull_params()
+    pol.train()
+    env = SyntheticSafetyVectorEnv(env_num=E, obs_dim=Do, act_dim=Da, episode_len=cfg["ep_len"], seed=cfg["seed"] + 11)
+    buf = HipVectorReplayBuffer(pol.engine, E * cfg["ep_len"] * 2, E)
+    seed = cfg["seed"] + 7
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    keys = [str(k) for k in g["stat_keys"]]
+    si = keys.index("loss/step_size")
+    diffs = []
+    for c in range(cfg["cycles"]):
+        buf.reset()
+        st = _rollout(pol, env, buf)
+        pol.pre_update_fn(stats_train={"cost": st["cost"]})
+        n0 = len(log.rows)
+        pol.update(0, buf, batch_size=99999, repeat=cfg["repeat"])
+        rows = [r for r in log.rows[n0:] if "update/gradient_steps" not in r]
+        per = len(rows) // cfg["repeat"]
+        last = {}
+        for r in rows[-per:]:
+            last.update(r)
+        diffs.append((abs(st["reward"] - g["curve"][c][0]), abs(st["cost"] - g["curve"][c][1]),
+                      last["loss/step_size"], g["last_rows"][c][si]))
+    print(f"closed {kind} loop (|reward diff|, |cost diff|, step got, step want):")
+    for d in diffs:
+        print("   ", d)
+    th = np.abs(pol.engine.get_params() - g["theta_final"])
+    print("    theta mean/max diff", th.mean(), th.max())
+    assert diffs[0][0] <= 1e-3 and diffs[0][1] == 0
+    span = float(g["curve"][:, 0].max() - g["curve"][:, 0].min())
+    assert diffs[1][0] <= 0.05 * max(abs(float(g["curve"][1][0])), span), diffs[1]
+    if kind == "trpo":
+        assert max(d[0] for d in diffs) <= max(0.1 * span, 6.0), [d[0] for d in diffs]
+    pol.engine.close()
