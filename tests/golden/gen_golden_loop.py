@@ -119,6 +119,12 @@ def gen_trust(kind, name, obs_dim, act_dim, hidden, env_num, ep_len, cycles, rep
         for r in rows[-per:]:
             merged.update(r)
         last_rows.append([merged[k] for k in keys])
+        if c == 0:
+            out["theta_after_first"] = flat_params(ac)
+            first_merged = [dict(r) for r in rows]
+            out["first_update_rows"] = np.array([[m.get(k, np.nan) for k in keys] for m in
+                                                 [{**rows[i * per + 0], **(rows[i * per + 1] if per > 1 else {}),
+                                                   **(rows[i * per + 2] if per > 2 else {})} for i in range(repeat)]])
         curve.append([st["reward"], st["cost"], st["steps"]])
     out.update(curve=np.array(curve), last_rows=np.array(last_rows), stat_keys=np.array(keys), theta_final=flat_params(ac))
     cfg = dict(kind=kind, obs_dim=obs_dim, act_dim=act_dim, hidden=list(hidden), env_num=env_num, ep_len=ep_len, cycles=cycles,
