@@ -43,7 +43,16 @@ class FocopsConfig(C.Structure):
                 ("eta", C.c_float), ("tem_lambda", C.c_float), ("max_grad_norm", C.c_float)]
 
 
-CPO_NSTATS, TRPO_NSTATS, SAC_NSTATS, FOCOPS_NSTATS = 17, 11, 10, 8
+class CvpoConfig(C.Structure):
+    """struct fsrl_cvpo_config (include/fsrl_hip.h)"""
+    _fields_ = [("actor_lr", C.c_float), ("critic_lr", C.c_float), ("tau", C.c_float), ("n_step", C.c_int32),
+                ("double_critic", C.c_int32), ("sample_act_num", C.c_int32), ("estep_iter_num", C.c_int32),
+                ("mstep_iter_num", C.c_int32), ("estep_kl", C.c_float), ("estep_dual_max", C.c_float),
+                ("estep_dual_lr", C.c_float), ("mstep_kl_mu", C.c_float), ("mstep_kl_std", C.c_float),
+                ("mstep_dual_max", C.c_float), ("mstep_dual_lr", C.c_float), ("qc_thres", C.c_double)]
+
+
+CPO_NSTATS, TRPO_NSTATS, SAC_NSTATS, FOCOPS_NSTATS, CVPO_NSTATS = 17, 11, 10, 8, 17
 
 _P = C.POINTER
 _f, _d, _u8, _i32, _i64 = _P(C.c_float), _P(C.c_double), _P(C.c_uint8), _P(C.c_int32), _P(C.c_int64)
@@ -93,6 +102,13 @@ SIGNATURES = {
     "fsrl_sac_stats_drain": (C.c_int64, [_ctx, _f, C.c_int64]),
     "fsrl_sac_last_sample": (C.c_int, [_ctx, _i64, _f, _f, C.c_int32]),
     "fsrl_sac_actor_forward": (C.c_int, [_ctx, _f, C.c_int32, _f, _f]),
+    "fsrl_cvpo_init": (C.c_int, [_ctx, _P(CvpoConfig)]),
+    "fsrl_cvpo_pre_update": (C.c_int, [_ctx]),
+    "fsrl_cvpo_post_update": (C.c_int, [_ctx]),
+    "fsrl_cvpo_set_thres": (C.c_int, [_ctx, C.c_double]),
+    "fsrl_cvpo_update": (C.c_int, [_ctx, C.c_int32, _i64, _f, _f, C.c_uint64, _f]),
+    "fsrl_cvpo_duals_get": (C.c_int, [_ctx, _f]),
+    "fsrl_cvpo_last_particles": (C.c_int, [_ctx, _f, C.c_int64]),
     "fsrl_set_profiling": (C.c_int, [_ctx, C.c_int]),
     "fsrl_last_timing": (C.c_int, [_ctx, _d, C.c_int32]),
 }

@@ -1,0 +1,71 @@
+"""CVPOAgent: keyword arguments and defaults of fsrl/agent/cvpo_agent.py:81-231."""
+from typing import Tuple
+
+import numpy as np
+import torch
+from torch import nn
+from torch.distributions import Independent, Normal
+
+from fsrl_amd.agent.sac_lag_agent import OffpolicyAgent
+from fsrl_amd.policy.cvpo import CVPO
+from fsrl_amd.utils.exp_util import seed_all
+from fsrl_amd.utils.logger import DummyLogger
+from fsrl_amd.utils.net import ActorCritic, ActorProb, DoubleCritic, Net, SingleCritic
+
+
+class CVPOAgent(OffpolicyAgent):
+    name = "CVPOAgent"
+
+    def __init__(self, env, logger=None, cost_limit: float = 10, device: str = "cuda:0", thread: int = 4, seed: int = 10,
+                 estep_iter_num: int = 1, estep_kl: float = 0.02, estep_dual_max: float = 20, estep_dual_lr: float = 0.02,
+                 sample_act_num: int = 16, mstep_iter_num: int = 1, mstep_kl_mu: float = 0.005,
+                 mstep_kl_std: float = 0.0005, mstep_dual_max: float = 0.5, mstep_dual_lr: float = 0.1,
+                 actor_lr: float = 5e-4, critic_lr: float = 1e-3, gamma: float = 0.98, n_step: int = 2, tau: float = 0.05,
+                 hidden_sizes: Tuple[int, ...] = (128, 128), double_critic: bool = False, conditioned_sigma: bool = True,
+                 unbounded: bool = False, last_layer_scale: bool = False, deterministic_eval: bool = True,
+                 action_scaling: bool = True, action_bound_method: str = "clip", lr_scheduler=None,
+                 training_num: int = 10, buffer_size: int = 100000, reference_rng: bool = False) -> None:
+        super().__init__()
+        self.logger = logger if logger is not None else DummyLogger()
+        self.cost_limit = cost_limit
+        assert np.isscalar(cost_limit) and conditioned_sigma and not unbounded, \
+            "the HIP CVPO path: one cost, state-conditioned sigma, bounded mean (the reference defaults)"
+        seed_all(seed)
+        torch.set_num_threads(thread)
+        state_shape, action_shape = env.observation_space.shape, env.action_space.shape
+        assert hasattr(env.spec, "max_episode_steps"), \
+            "Please use an env wrapper to provide 'max_episode_steps' for CVPO"
+        actor = ActorProb(Net(state_shape, hidden_sizes=hidden_sizes), action_shape,
+                          max_action=float(env.action_space.high[0]), conditioned_sigma=True, unbounded=False)
+        actor_optim = torch.optim.Adam(actor.parameters(), lr=actor_lr)
+        critics = []
+        for _ in range(2):
+            if double_critic:
+                critics.append(DoubleCritic(Net(state_shape, action_shape, hidden_sizes=hidden_sizes, concat=True),
+                                            Net(state_shape, action_shape, hidden_sizes=hidden_sizes, concat=True)))
+            else:
+                critics.append(SingleCritic(Net(state_shape, action_shape, hidden_sizes=hidden_sizes, concat=True)))
+        critic_optim = torch.optim.Adam(nn.ModuleList(critics).parameters(), lr=critic_lr)
+        for m in ActorCritic(actor, critics).modules():
+            if isinstance(m, torch.nn.Linear):
+                torch.nn.init.orthogonal_(m.weight)
+                torch.nn.init.zeros_(m.bias)
+        if last_layer_scale:
+            for m in actor.mu.modules():
+                if isinstance(m, torch.nn.Linear):
+                    torch.nn.init.zeros_(m.bias)
+                    m.weight.data.copy_(0.01 * m.weight.data)
+
+        def dist(*logits):
+            return Independent(Normal(*logits), 1)
+
+        self.policy = CVPO(actor=actor, critics=critics, actor_optim=actor_optim, critic_optim=critic_optim,
+                           logger=self.logger, action_space=env.action_space, dist_fn=dist,
+                           max_episode_steps=env.spec.max_episode_steps, cost_limit=cost_limit, tau=tau, gamma=gamma,
+                           n_step=n_step, estep_iter_num=estep_iter_num, estep_kl=estep_kl, estep_dual_max=estep_dual_max,
+                           estep_dual_lr=estep_dual_lr, sample_act_num=sample_act_num, mstep_iter_num=mstep_iter_num,
+                           mstep_kl_mu=mstep_kl_mu, mstep_kl_std=mstep_kl_std, mstep_dual_max=mstep_dual_max,
+                           mstep_dual_lr=mstep_dual_lr, deterministic_eval=deterministic_eval,
+                           action_scaling=action_scaling, action_bound_method=action_bound_method,
+                           lr_scheduler=lr_scheduler, observation_space=env.observation_space, device=device,
+                           env_num=training_num, buffer_size=buffer_size, reference_rng=reference_rng, seed=seed)

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cstddef>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1742,6 +1743,7 @@ static int focops_pass(fsrl_ctx* c, int32_t* stopped_out) {
 
 // ====================================================================================== SAC-Lagrangian
 #include "kernels_sac.hpp"
+#include "kernels_cvpo.hpp"
 
 struct SacState {
     fsrl_sac_config cfg{};
@@ -1771,6 +1773,14 @@ struct SacState {
     SacBook* d_book = nullptr; SacBook* h_book = nullptr;      // device / pinned sub-buffer bookkeeping
     uint64_t book_version = 0;
     int last_B = 0;
+    int nstats = FSRL_SAC_NSTATS_K;           // floats per row of the statistics ring
+    // ---- CVPO mode (fsrl_cvpo_init): Gaussian actor + actor_old (PAT), E-step / M-step state
+    bool cvpo = false;
+    fsrl_cvpo_config ccfg{};
+    CvpoScalars* csc = nullptr;
+    int n_tiles_k = 0; bool k_rows4 = false;  // tiles of the K*B particle launch
+    float *MU_OLD = nullptr, *STD_OLD = nullptr, *XK = nullptr, *QK = nullptr, *q0 = nullptr, *q1 = nullptr;
+    float *Wk = nullptr, *eps_k = nullptr, *h_epsk = nullptr, *stqk = nullptr;
 };
 static constexpr int SAC_RING = 4096;
 
@@ -1813,14 +1823,14 @@ static void sac_layout(fsrl_ctx* c, SacState* s) {
         }
         int api = 0;
         auto add = [&](int dev_off, int n) { s->tmap_q.push_back(TensorMap{api, dev_off, n}); api += n; };
-        for (int i = 0; i < 2 && !s->ddpg; ++i) {
+        for (int i = 0; i < 2 && s->n_q == 4; ++i) {
             for (int j = 0; j < 2; ++j) {
                 const NetOff& no = md.net[2 * i + j];
                 add(no.W1, H * Din); add(no.b1, H); add(no.W2, H * H); add(no.b2, H);
             }
             for (int j = 0; j < 2; ++j) { const NetOff& no = md.net[2 * i + j]; add(no.W3, H); add(no.b3, 1); }
         }
-        for (int i = 0; i < 2 && s->ddpg; ++i) {       // tianshou Critic: preprocess MLP then the last layer
+        for (int i = 0; i < 2 && s->n_q == 2; ++i) {     // tianshou Critic / SingleCritic: preprocess MLP then the last layer
             const NetOff& no = md.net[i];
             add(no.W1, H * Din); add(no.b1, H); add(no.W2, H * H); add(no.b2, H); add(no.W3, H); add(no.b3, 1);
         }
@@ -1854,7 +1864,7 @@ extern "C" int fsrl_sac_init(fsrl_ctx* c, const fsrl_sac_config* cfg) {
     HIPCHK(hipMalloc(&s->sc, sizeof(SacScalars)));
     SacScalars init{cfg->auto_alpha ? 1.0f : cfg->alpha, 0.0f, 0.0f, 0.0f, 0, 0};
     HIPCHK(hipMemcpy(s->sc, &init, sizeof(init), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&s->d_stats, (size_t)SAC_RING * FSRL_SAC_NSTATS_K * 4));
+    HIPCHK(hipMalloc(&s->d_stats, (size_t)SAC_RING * s->nstats * 4));
     HIPCHK(hipMalloc(&s->d_book, (size_t)c->cfg.env_num * sizeof(SacBook)));
     HIPCHK(hipHostMalloc(&s->h_book, (size_t)c->cfg.env_num * sizeof(SacBook)));
     return 0;
@@ -1868,9 +1878,11 @@ static void sac_free(fsrl_ctx* c) {
                     (void*)s->XQ, (void*)s->OBS, (void*)s->OBSN, (void*)s->XN, (void*)s->XP, (void*)s->eps_t,
                     (void*)s->eps_p, (void*)s->LPN, (void*)s->LP, (void*)s->QT, (void*)s->QP, (void*)s->Y,
                     (void*)s->DA, (void*)s->A1, (void*)s->A2, (void*)s->D1, (void*)s->D2, (void*)s->DO,
-                    (void*)s->stq, (void*)s->stdin_, (void*)s->stpi, (void*)s->d_stats, (void*)s->d_book})
+                    (void*)s->stq, (void*)s->stdin_, (void*)s->stpi, (void*)s->d_stats, (void*)s->d_book,
+                    (void*)s->csc, (void*)s->MU_OLD, (void*)s->STD_OLD, (void*)s->XK, (void*)s->QK, (void*)s->q0,
+                    (void*)s->q1, (void*)s->Wk, (void*)s->eps_k, (void*)s->stqk})
         if (p) (void)hipFree(p);
-    for (void* p : {(void*)s->h_idx, (void*)s->h_chain, (void*)s->h_end, (void*)s->h_eps, (void*)s->h_book})
+    for (void* p : {(void*)s->h_idx, (void*)s->h_chain, (void*)s->h_end, (void*)s->h_eps, (void*)s->h_book, (void*)s->h_epsk})
         if (p) (void)hipHostFree(p);
     delete s;
     c->sac = nullptr;
@@ -1929,7 +1941,7 @@ extern "C" int fsrl_sac_params_put(fsrl_ctx* c, int32_t which, const float* in, 
     SacState* s = sac_of(c);
     if (!s) return fail(FSRL_ESTATE, "fsrl_sac_init first");
     CHECK_ARG(which >= 0 && which <= 3, "which must be 0..3");
-    CHECK_ARG(which != 3 || s->ddpg, "actor_old exists in the DDPG-Lagrangian mode only");
+    CHECK_ARG(which != 3 || s->ddpg || s->cvpo, "actor_old exists in the DDPG-Lagrangian and CVPO modes only");
     HIPCHK(hipSetDevice(c->device));
     if (which == 0 || which == 3) {
         CHECK_ARG(n == s->na_api, "expected %d actor parameters", s->na_api);
@@ -1963,6 +1975,10 @@ static int sac_alloc_batch(fsrl_ctx* c, SacState* s, int B) {
     s->n_tiles = (B + 15) / 16;
     s->q_rows4 = 4 * s->n_tiles * s->n_q <= c->n_cus && !getenv("FSRL_TILE16");
     s->a_rows4 = 4 * s->n_tiles <= c->n_cus && !getenv("FSRL_TILE16");
+    if (s->cvpo) {
+        s->n_tiles_k = (B * s->ccfg.sample_act_num + 15) / 16;
+        s->k_rows4 = 4 * s->n_tiles_k * s->n_q <= c->n_cus && !getenv("FSRL_TILE16");
+    }
     if (B <= s->cap_B) return 0;
     HIPCHK(hipStreamSynchronize(c->compute));
     const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim, Din = Do + Da, H = c->cfg.hidden, ns = s->cfg.n_step;
@@ -1994,6 +2010,13 @@ static int sac_alloc_batch(fsrl_ctx* c, SacState* s, int B) {
     // per-tile partial statistics: room for 4-row tiles (4 x the 16-row tile count)
     rc |= re(&s->stq, (size_t)(4 * s->n_tiles + 4) * 4 * FB_NSTAT * 4); rc |= re(&s->stdin_, (size_t)(4 * s->n_tiles + 4) * 4 * FB_NSTAT * 4);
     rc |= re(&s->stpi, (size_t)(4 * s->n_tiles + 4) * FB_NSTAT * 4);
+    if (s->cvpo) {
+        const size_t K = (size_t)s->ccfg.sample_act_num, KB = K * Bp;
+        rc |= re(&s->MU_OLD, Bp * Da * 4); rc |= re(&s->STD_OLD, Bp * Da * 4);
+        rc |= re(&s->XK, KB * Din * 4); rc |= re(&s->QK, 4 * KB * 4); rc |= re(&s->q0, KB * 4); rc |= re(&s->q1, KB * 4);
+        rc |= re(&s->Wk, KB * 4); rc |= re(&s->eps_k, KB * Da * 4); rc |= reh(&s->h_epsk, KB * Da * 4);
+        rc |= re(&s->stqk, (size_t)(4 * ((KB + 15) / 16) + 4) * 4 * FB_NSTAT * 4);
+    }
     if (rc) return FSRL_EHIP;
     s->cap_B = B;
     return 0;
@@ -2014,18 +2037,22 @@ static inline bool store_end_flag(const fsrl_ctx* c, int64_t idx) {
     return eb.size > 0 && local == (eb.index - 1 + eb.size) % eb.size;   // unfinished tail
 }
 
+// qout_override / n_tiles / rows4: the K*B particle launch of CVPO's E-step (forward only) reuses the Q-net kernel
 static int sac_q_launch(fsrl_ctx* c, SacState* s, const float* params, const float* X, int mode, float cr, float cc,
-                        float* statp, int B) {
+                        float* statp, int B, float* qout_override = nullptr, int n_tiles = -1, int rows4 = -1) {
     FbArgs a{};
+    if (n_tiles < 0) n_tiles = s->n_tiles;
+    const bool r4 = rows4 < 0 ? s->q_rows4 : rows4 != 0;
     a.obs = X; a.rd = nullptr; a.A1 = s->A1; a.A2 = s->A2; a.D1 = s->D1; a.D2 = s->D2; a.DO = s->DO; a.statp = statp;
-    a.N = B; a.rows_pad = s->n_tiles * 16; a.mode = mode; a.net0 = 0; a.cr = cr; a.cc = cc; a.max_action = 1.0f;
+    a.N = B; a.rows_pad = n_tiles * 16; a.mode = mode; a.net0 = 0; a.cr = cr; a.cc = cc; a.max_action = 1.0f;
     a.tgt = s->Y; a.qout = (mode == FB_MODE_Q_FWD && params == s->PQT) ? s->QT : s->QP; a.qin = s->QP; a.da_out = s->DA;
-    a.act_cols = c->cfg.act_dim; a.pair_shift = s->ddpg ? 0 : 1;
+    if (qout_override) a.qout = qout_override;
+    a.act_cols = c->cfg.act_dim; a.pair_shift = s->n_q == 2 ? 0 : 1;
     return dispatch_H(c->cfg.hidden, [&](auto hc) {
         constexpr int H = decltype(hc)::value;
         // 4-row tiles while they still fit the chip in one round (batch <= 256 for the four Q-nets)
-        if (s->q_rows4) hipLaunchKernelGGL((fb_tile_kernel<H, 4>), dim3(4 * s->n_tiles, s->n_q), dim3(4 * H), 0, c->compute, params, s->mdq, a);
-        else hipLaunchKernelGGL((fb_tile_kernel<H, 16>), dim3(s->n_tiles, s->n_q), dim3(4 * H), 0, c->compute, params, s->mdq, a);
+        if (r4) hipLaunchKernelGGL((fb_tile_kernel<H, 4>), dim3(4 * n_tiles, s->n_q), dim3(4 * H), 0, c->compute, params, s->mdq, a);
+        else hipLaunchKernelGGL((fb_tile_kernel<H, 16>), dim3(n_tiles, s->n_q), dim3(4 * H), 0, c->compute, params, s->mdq, a);
         HIPCHK(hipGetLastError());
         return 0;
     });
@@ -2064,6 +2091,7 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     SacState* s = sac_of(c);
     if (!s) return fail(FSRL_ESTATE, "fsrl_sac_init first");
     CHECK_ARG(B >= 1, "batch_size must be >= 1");
+    if (s->cvpo) return fail(FSRL_ESTATE, "this context runs CVPO: call fsrl_cvpo_update");
     const int64_t stored = fsrl_store_len(c);
     CHECK_ARG(stored > 0, "empty replay store");
     HIPCHK(hipSetDevice(c->device));
@@ -2175,7 +2203,7 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     adam_launch(c, s->mda, s->PA, s->MA, s->VA, c->wg_parts, s->na_dev, s->cfg.actor_lr, s->t_actor, nsplit, s->na_dev);
     // ---- alpha step + logged stats, then Polyak
     SacFinalArgs fa{};
-    float* stats_row = s->d_stats + (size_t)(s->n_updates % SAC_RING) * FSRL_SAC_NSTATS_K;
+    float* stats_row = s->d_stats + (size_t)(s->n_updates % SAC_RING) * s->nstats;
     fa.statp_q = s->stq; fa.statp_pi = s->stpi; fa.sc = s->sc; fa.stats = stats_row;
     fa.n_tiles_q = s->q_rows4 ? 4 * s->n_tiles : s->n_tiles; fa.n_tiles_pi = s->a_rows4 ? 4 * s->n_tiles : s->n_tiles; fa.B = B; fa.rescale = resc; fa.lam = lam; fa.target_entropy = s->cfg.target_entropy;
     fa.alpha_lr = s->cfg.alpha_lr; fa.beta1 = c->cfg.beta1; fa.beta2 = c->cfg.beta2; fa.adam_eps = c->cfg.adam_eps;
@@ -2200,6 +2228,244 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     return 0;
 }
 
+// ============================================================================== CVPO (cvpo.py:71-430)
+extern "C" int fsrl_cvpo_init(fsrl_ctx* c, const fsrl_cvpo_config* cfg) {
+    CHECK_ARG(c && cfg, "null argument");
+    CHECK_ARG(c->cfg.algo == FSRL_ALGO_SAC_LAG, "CVPO runs on a replay context (FSRL_ALGO_SAC_LAG)");
+    CHECK_ARG(c->cfg.act_dim <= 8, "the actor head has at most 16 outputs (act_dim <= 8)");
+    CHECK_ARG(c->cfg.obs_dim + c->cfg.act_dim <= FSRL_MAX_OBS, "obs_dim + act_dim too large");
+    CHECK_ARG(cfg->n_step >= 1 && cfg->n_step <= 8, "n_step must be in [1, 8]");
+    CHECK_ARG(cfg->tau >= 0.0f && cfg->tau <= 1.0f, "tau should be in [0, 1]");
+    CHECK_ARG(cfg->sample_act_num >= 1 && cfg->sample_act_num <= 64, "sample_act_num must be in [1, 64]");
+    CHECK_ARG(cfg->estep_iter_num >= 1 && cfg->mstep_iter_num >= 1, "estep_iter_num and mstep_iter_num must be >= 1");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->sac) sac_free(c);
+    SacState* s = new SacState();
+    c->sac = s;
+    s->cvpo = true; s->ccfg = *cfg; s->nstats = FSRL_CVPO_NSTATS_K;
+    s->n_q = cfg->double_critic ? 4 : 2;
+    s->cfg.actor_lr = cfg->actor_lr; s->cfg.critic_lr = cfg->critic_lr; s->cfg.tau = cfg->tau; s->cfg.n_step = cfg->n_step;
+    s->cfg.auto_alpha = 0; s->cfg.alpha = 0.0f; s->cfg.use_lagrangian = 0;      // no entropy term, no PID multiplier
+    sac_layout(c, s);
+    const size_t HH = (size_t)c->cfg.hidden * c->cfg.hidden;
+    const size_t ab = ((size_t)s->na_dev + HH) * 4, qb = ((size_t)s->nq_dev + 4 * HH) * 4;
+    for (float** p : {&s->PA, &s->MA, &s->VA, &s->PAT}) { HIPCHK(hipMalloc(p, ab)); HIPCHK(hipMemsetAsync(*p, 0, ab, c->compute)); }
+    for (float** p : {&s->PQ, &s->PQT, &s->MQ, &s->VQ}) { HIPCHK(hipMalloc(p, qb)); HIPCHK(hipMemsetAsync(*p, 0, qb, c->compute)); }
+    HIPCHK(hipMalloc(&s->sc, sizeof(SacScalars)));
+    HIPCHK(hipMemsetAsync(s->sc, 0, sizeof(SacScalars), c->compute));
+    HIPCHK(hipMalloc(&s->csc, sizeof(CvpoScalars)));
+    HIPCHK(hipMemsetAsync(s->csc, 0, sizeof(CvpoScalars), c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    const float eta0 = 1.0f;                                                     // estep_dual = [1, 0]  (cvpo.py:150-152)
+    HIPCHK(hipMemcpy(&s->csc->eta, &eta0, 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&s->d_stats, (size_t)SAC_RING * s->nstats * 4));
+    HIPCHK(hipMalloc(&s->d_book, (size_t)c->cfg.env_num * sizeof(SacBook)));
+    HIPCHK(hipHostMalloc(&s->h_book, (size_t)c->cfg.env_num * sizeof(SacBook)));
+    return 0;
+}
+
+static SacState* cvpo_of(fsrl_ctx* c) { SacState* s = c ? sac_of(c) : nullptr; return (s && s->cvpo) ? s : nullptr; }
+
+extern "C" int fsrl_cvpo_pre_update(fsrl_ctx* c) {
+    SacState* s = cvpo_of(c);
+    if (!s) return fail(FSRL_ESTATE, "fsrl_cvpo_init first");
+    HIPCHK(hipSetDevice(c->device));
+    // mdual .. dual_std are contiguous: multipliers, Adam moments, step count, clipped copies
+    const size_t off = offsetof(CvpoScalars, mdual), end = offsetof(CvpoScalars, estep_loss);
+    HIPCHK(hipMemsetAsync((char*)s->csc + off, 0, end - off, c->compute));
+    return 0;
+}
+
+extern "C" int fsrl_cvpo_post_update(fsrl_ctx* c) {
+    SacState* s = cvpo_of(c);
+    if (!s) return fail(FSRL_ESTATE, "fsrl_cvpo_init first");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(s->PAT, s->PA, ((size_t)s->na_dev + (size_t)c->cfg.hidden * c->cfg.hidden) * 4,
+                          hipMemcpyDeviceToDevice, c->compute));
+    return 0;
+}
+
+extern "C" int fsrl_cvpo_set_thres(fsrl_ctx* c, double qc_thres) {
+    SacState* s = cvpo_of(c);
+    if (!s) return fail(FSRL_ESTATE, "fsrl_cvpo_init first");
+    s->ccfg.qc_thres = qc_thres;
+    return 0;
+}
+
+extern "C" int fsrl_cvpo_duals_get(fsrl_ctx* c, float* out4) {
+    CHECK_ARG(c && out4, "null argument");
+    SacState* s = cvpo_of(c);
+    if (!s) return fail(FSRL_ESTATE, "fsrl_cvpo_init first");
+    HIPCHK(hipSetDevice(c->device));
+    CvpoScalars h;
+    HIPCHK(hipMemcpyAsync(&h, s->csc, sizeof(h), hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    out4[0] = h.eta; out4[1] = h.lam; out4[2] = h.mdual[0]; out4[3] = h.mdual[1];
+    return 0;
+}
+
+extern "C" int fsrl_cvpo_last_particles(fsrl_ctx* c, float* eps_particles, int64_t n) {
+    CHECK_ARG(c && eps_particles, "null argument");
+    SacState* s = cvpo_of(c);
+    if (!s) return fail(FSRL_ESTATE, "fsrl_cvpo_init first");
+    CHECK_ARG(s->last_B > 0 && n == (int64_t)s->ccfg.sample_act_num * s->last_B * c->cfg.act_dim,
+              "expected K * batch_size * act_dim floats of the last update (batch_size %d)", s->last_B);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(eps_particles, s->eps_k, (size_t)n * 4, hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    return 0;
+}
+
+extern "C" int fsrl_cvpo_update(fsrl_ctx* c, int32_t B, const int64_t* indices, const float* eps_target,
+                                const float* eps_particles, uint64_t seed, float* stats_out) {
+    CHECK_ARG(c, "null ctx");
+    SacState* s = cvpo_of(c);
+    if (!s) return fail(FSRL_ESTATE, "fsrl_cvpo_init first");
+    CHECK_ARG(B >= 1, "batch_size must be >= 1");
+    const int64_t stored = fsrl_store_len(c);
+    CHECK_ARG(stored > 0, "empty replay store");
+    CHECK_ARG((indices != nullptr) == (eps_target != nullptr) && (indices != nullptr) == (eps_particles != nullptr),
+              "indices, eps_target and eps_particles are given together (caller RNG) or all NULL (library RNG)");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = flush_stage(c);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->store_ready, c->side));
+    HIPCHK(hipStreamWaitEvent(c->compute, c->store_ready, 0));
+    rc = sac_alloc_batch(c, s, B);
+    if (rc) return rc;
+    hipStream_t st = c->compute;
+    const fsrl_cvpo_config& cc = s->ccfg;
+    const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim, ns = cc.n_step, K = cc.sample_act_num;
+    const size_t nk = (size_t)K * B * Da;
+    if (seed) s->key = seed * 0x9E3779B97F4A7C15ull + 0x243F6A8885A308D3ull;
+    if (indices) {
+        HIPCHK(hipStreamSynchronize(st));      // pinned staging of the previous update has landed
+        for (int b = 0; b < B; ++b) {
+            const int64_t idx = indices[b];
+            CHECK_ARG(idx >= 0 && idx < c->maxsize, "index %lld out of range", (long long)idx);
+            s->h_idx[b] = (int)idx;
+            int64_t cur = idx;
+            for (int n = 0; n < ns; ++n) {
+                if (n > 0) cur = store_next(c, cur);
+                s->h_chain[(size_t)n * B + b] = (int)cur;
+                s->h_end[(size_t)n * B + b] = store_end_flag(c, cur) ? 1 : 0;
+            }
+        }
+        memcpy(s->h_eps, eps_target, (size_t)B * Da * 4);
+        memcpy(s->h_epsk, eps_particles, nk * 4);
+        HIPCHK(hipMemcpyAsync(s->d_idx, s->h_idx, (size_t)B * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->d_chain, s->h_chain, (size_t)B * ns * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->d_end, s->h_end, (size_t)B * ns, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->eps_t, s->h_eps, (size_t)B * Da * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->eps_k, s->h_epsk, nk * 4, hipMemcpyHostToDevice, st));
+    } else {
+        if (s->book_version != c->store_version) {
+            HIPCHK(hipStreamSynchronize(st));
+            for (int e = 0; e < c->cfg.env_num; ++e) {
+                const EnvBook& eb = c->env[(size_t)e];
+                s->h_book[e] = SacBook{(int)eb.size, (int)eb.index, (int)eb.last_index, 0};
+            }
+            HIPCHK(hipMemcpyAsync(s->d_book, s->h_book, (size_t)c->cfg.env_num * sizeof(SacBook), hipMemcpyHostToDevice, st));
+            s->book_version = c->store_version;
+        }
+        SacSampleArgs sa{};
+        sa.book = s->d_book; sa.flags = c->st.flags; sa.idx = s->d_idx; sa.chain = s->d_chain; sa.endbits = s->d_end;
+        sa.eps_t = s->eps_t; sa.eps_p = s->eps_p; sa.env_num = c->cfg.env_num; sa.sub_size = (int)c->sub_size; sa.B = B;
+        sa.n_step = ns; sa.Da = Da; sa.stored = (unsigned long long)stored; sa.key = s->key;
+        sa.counter = (unsigned long long)s->n_updates;
+        hipLaunchKernelGGL(sac_sample_kernel, dim3((B + 255) / 256), dim3(256), 0, st, sa);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((nk / 4 + 256) / 256)), dim3(256), 0, st, s->eps_k, nk,
+                           (unsigned long long)s->key, (unsigned long long)s->n_updates, 0x40000000u);
+        HIPCHK(hipGetLastError());
+    }
+    s->last_B = B;
+    // ---- gather
+    SacGatherArgs ga{};
+    ga.st = c->st; ga.idx = s->d_idx; ga.term = s->d_chain + (size_t)(ns - 1) * B; ga.XQ = s->XQ; ga.OBS = s->OBS;
+    ga.OBSN = s->OBSN; ga.XN = s->XN; ga.XP = s->XP; ga.B = B; ga.Do = Do; ga.Da = Da;
+    hipLaunchKernelGGL(sac_gather_kernel, dim3(std::min(1024, (B * (Do + Da) + 255) / 256)), dim3(256), 0, st, ga);
+    HIPCHK(hipGetLastError());
+    auto actor_launch = [&](int mode, const float* PAx, const float* obs, const float* eps, float* X) {
+        CvpoActorArgs aa{};
+        aa.obs = obs; aa.eps = eps; aa.X = X; aa.mu_old = s->MU_OLD; aa.std_old = s->STD_OLD; aa.W = s->Wk; aa.XK = s->XK;
+        aa.sc = s->csc; aa.A1 = s->A1; aa.A2 = s->A2; aa.D1 = s->D1; aa.D2 = s->D2; aa.DO = s->DO; aa.statp = s->stpi;
+        aa.B = B; aa.K = K; aa.mode = mode; aa.max_action = c->cfg.max_action;
+        return dispatch_H(c->cfg.hidden, [&](auto hc) {
+            constexpr int H = decltype(hc)::value;
+            if (s->a_rows4) hipLaunchKernelGGL((cvpo_actor_tile_kernel<H, 4>), dim3(4 * s->n_tiles), dim3(4 * H), 0, st, PAx, s->mda, aa);
+            else hipLaunchKernelGGL((cvpo_actor_tile_kernel<H, 16>), dim3(s->n_tiles), dim3(4 * H), 0, st, PAx, s->mda, aa);
+            HIPCHK(hipGetLastError());
+            return 0;
+        });
+    };
+    // ---- n-step target: a' ~ actor(s_{t+n}), critics_old.predict, float64 return      (cvpo.py:206-222)
+    rc = actor_launch(CVPO_A_TARGET, s->PA, s->OBSN, s->eps_t, s->XN);
+    if (rc) return rc;
+    rc = sac_q_launch(c, s, s->PQT, s->XN, FB_MODE_Q_FWD, 0.f, 0.f, s->stq, B);
+    if (rc) return rc;
+    SacNstepArgs na{};
+    na.QT = s->QT; na.lpn = s->LPN; na.chain = s->d_chain; na.endbits = s->d_end; na.rew = c->st.rew; na.cost = c->st.cost;
+    na.flags = c->st.flags; na.sc = s->sc; na.Y = s->Y; na.B = B; na.n_step = ns; na.gamma = c->cfg.gamma;
+    na.auto_alpha = 0; na.alpha_fixed = 0.0f; na.single = s->n_q == 2 ? 1 : 0;    // LPN stays zero: no entropy term
+    hipLaunchKernelGGL(sac_nstep_kernel, dim3((B + 255) / 256), dim3(256), 0, st, na);
+    HIPCHK(hipGetLastError());
+    // ---- critic step                                                                (cvpo.py:248-276)
+    rc = sac_q_launch(c, s, s->PQ, s->XQ, FB_MODE_Q_TRAIN, 0.f, 0.f, s->stq, B);
+    if (rc) return rc;
+    int nsplit = 1;
+    rc = sac_wgrad(c, s, s->mdq, s->n_q, s->XQ, s->nq_dev, B, &nsplit);
+    if (rc) return rc;
+    s->t_critic += 1;
+    adam_launch(c, s->mdq, s->PQ, s->MQ, s->VQ, c->wg_parts, s->nq_dev, cc.critic_lr, s->t_critic, nsplit, s->nq_dev);
+    // ---- E-step: K particles of actor_old through the UPDATED critics                (cvpo.py:319-371)
+    rc = actor_launch(CVPO_A_PARTICLES, s->PAT, s->OBS, s->eps_k, s->XK);
+    if (rc) return rc;
+    rc = sac_q_launch(c, s, s->PQ, s->XK, FB_MODE_Q_FWD, 0.f, 0.f, s->stqk, K * B, s->QK, s->n_tiles_k, s->k_rows4 ? 1 : 0);
+    if (rc) return rc;
+    CvpoEstepArgs ea{};
+    ea.QK = s->QK; ea.q0 = s->q0; ea.q1 = s->q1; ea.W = s->Wk; ea.sc = s->csc; ea.B = B; ea.K = K; ea.n_q = s->n_q;
+    ea.iters = cc.estep_iter_num; ea.kl = cc.estep_kl; ea.thres = (float)cc.qc_thres; ea.lr = cc.estep_dual_lr;
+    ea.dual_max = cc.estep_dual_max; ea.beta1 = c->cfg.beta1; ea.beta2 = c->cfg.beta2; ea.adam_eps = c->cfg.adam_eps;
+    hipLaunchKernelGGL(cvpo_estep_kernel, dim3(1), dim3(1024), 0, st, ea);
+    HIPCHK(hipGetLastError());
+    // ---- M-step                                                                     (cvpo.py:378-417)
+    const int n_tiles_pi = s->a_rows4 ? 4 * s->n_tiles : s->n_tiles;
+    for (int it = 0; it < cc.mstep_iter_num; ++it) {
+        rc = actor_launch(CVPO_A_MFWD, s->PA, s->OBS, nullptr, nullptr);
+        if (rc) return rc;
+        CvpoMdualArgs ma{};
+        ma.statp = s->stpi; ma.n_tiles = n_tiles_pi; ma.B = B; ma.K = K; ma.sc = s->csc; ma.kl_mu_eps = cc.mstep_kl_mu;
+        ma.kl_std_eps = cc.mstep_kl_std; ma.dual_max = cc.mstep_dual_max; ma.lr = cc.mstep_dual_lr; ma.beta1 = c->cfg.beta1;
+        ma.beta2 = c->cfg.beta2; ma.adam_eps = c->cfg.adam_eps; ma.log_it = it == 0;
+        hipLaunchKernelGGL(cvpo_mdual_kernel, dim3(1), dim3(64), 0, st, ma);
+        HIPCHK(hipGetLastError());
+        rc = actor_launch(CVPO_A_MBWD, s->PA, s->OBS, nullptr, nullptr);
+        if (rc) return rc;
+        rc = sac_wgrad(c, s, s->mda, 1, s->OBS, s->na_dev, B, &nsplit);
+        if (rc) return rc;
+        s->t_actor += 1;
+        adam_launch(c, s->mda, s->PA, s->MA, s->VA, c->wg_parts, s->na_dev, cc.actor_lr, s->t_actor, nsplit, s->na_dev);
+    }
+    // ---- logged stats, then Polyak of the critics                                    (cvpo.py:202-204, 422-430)
+    CvpoFinalArgs fa{};
+    float* stats_row = s->d_stats + (size_t)(s->n_updates % SAC_RING) * s->nstats;
+    fa.statp_q = s->stq; fa.Y = s->Y; fa.sc = s->csc; fa.stats = stats_row;
+    fa.n_tiles_q = s->q_rows4 ? 4 * s->n_tiles : s->n_tiles; fa.n_q = s->n_q; fa.B = B; fa.thres = (float)cc.qc_thres;
+    hipLaunchKernelGGL(cvpo_finalize_kernel, dim3(1), dim3(64), 0, st, fa);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(polyak_kernel, dim3(256), dim3(256), 0, st, s->PQT, s->PQ, s->nq_dev, cc.tau,
+                       (float)(1.0 - (double)cc.tau), s->mdq);
+    HIPCHK(hipGetLastError());
+    s->n_updates += 1;
+    if (stats_out) {
+        HIPCHK(hipMemcpyAsync(stats_out, stats_row, (size_t)s->nstats * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        s->n_drained = s->n_updates;
+    }
+    return 0;
+}
+
 // Rows of logged statistics of the updates issued with stats_out == NULL since the last drain
 // (oldest first; at most SAC_RING = 4096 are kept).  Returns the number of rows written, < 0 on error.
 extern "C" int64_t fsrl_sac_stats_drain(fsrl_ctx* c, float* out, int64_t max_rows) {
@@ -2212,8 +2478,8 @@ extern "C" int64_t fsrl_sac_stats_drain(fsrl_ctx* c, float* out, int64_t max_row
     for (int64_t i = 0; i < n;) {              // at most two contiguous pieces of the ring
         const int64_t slot = (first + i) % SAC_RING;
         const int64_t run = std::min(n - i, (int64_t)SAC_RING - slot);
-        HIPCHK(hipMemcpyAsync(out + i * FSRL_SAC_NSTATS_K, s->d_stats + slot * FSRL_SAC_NSTATS_K,
-                              (size_t)run * FSRL_SAC_NSTATS_K * 4, hipMemcpyDeviceToHost, c->compute));
+        HIPCHK(hipMemcpyAsync(out + i * s->nstats, s->d_stats + slot * s->nstats,
+                              (size_t)run * s->nstats * 4, hipMemcpyDeviceToHost, c->compute));
         i += run;
     }
     HIPCHK(hipStreamSynchronize(c->compute));
@@ -2274,7 +2540,8 @@ extern "C" int fsrl_sac_actor_forward(fsrl_ctx* c, const float* obs, int32_t k, 
                 sigma_out[(size_t)r * Da + d] = s->cfg.exploration_sigma;
                 continue;
             }
-            mu_out[(size_t)r * Da + d] = raw[(size_t)r * 2 * Da + d];
+            mu_out[(size_t)r * Da + d] = s->cvpo ? c->cfg.max_action * std::tanh(raw[(size_t)r * 2 * Da + d])
+                                                 : raw[(size_t)r * 2 * Da + d];
             const float l = std::min(std::max(raw[(size_t)r * 2 * Da + Da + d], -20.0f), 2.0f);
             sigma_out[(size_t)r * Da + d] = std::exp(l);
         }
@@ -2284,4 +2551,4 @@ extern "C" int fsrl_sac_actor_forward(fsrl_ctx* c, const float* obs, int32_t k, 
 static int sac_actor_mu_sigma(fsrl_ctx* c, const float* obs, int32_t k, float* mu_out, float* sigma_out) {
     return fsrl_sac_actor_forward(c, obs, k, mu_out, sigma_out);
 }
-static bool sac_squashes(fsrl_ctx* c) { SacState* s = sac_of(c); return s && !s->ddpg; }
+static bool sac_squashes(fsrl_ctx* c) { SacState* s = sac_of(c); return s && !s->ddpg && !s->cvpo; }

@@ -1,0 +1,341 @@
+// kernels_cvpo.hpp -- CVPO update kernels (fsrl/policy/cvpo.py:206-430).  The replay gather, the
+// float64 n-step target, the Q-network launches, the weight-gradient / Adam / Polyak kernels are the
+// SAC path's (kernels_sac.hpp, kernels_fb.hpp); this file holds what is CVPO's own:
+//   * the Gaussian actor tile (mu = max_action * tanh(head), sigma = exp(clamp(head))) in four modes:
+//     target action, the K particles of actor_old, the M-step statistics, the M-step backward;
+//   * the E-step: Adam on the two duals (eta, lambda) of the logsumexp loss and the softmax weights;
+//   * the M-step dual step (Adam on the two KL multipliers) and the logged statistics.
+#pragma once
+#include "kernels_sac.hpp"
+
+#define FSRL_CVPO_NSTATS_K 17
+#define CVPO_EPS10 1.1920928955078125e-06f      // np.finfo(np.float32).eps * 10   (cvpo.py:163)
+
+// scalars that live on the device between updates
+struct CvpoScalars {
+    float eta, lam;              // estep_dual[0], estep_dual[1]                  (cvpo.py:150-155)
+    float em[2], ev[2]; int et;  // Adam moments / step count of the E-step duals
+    float mdual[2];              // mstep_dual_mu, mstep_dual_std (stored unclipped)  (cvpo.py:178-188)
+    float mm[2], mv[2]; int mt;  // their Adam state (reset by pre_update_fn)
+    float dual_mu, dual_std;     // clipped to [0, mstep_dual_max]: what the current M-step backward uses
+    float estep_loss;            // logged value of the first E-step iteration
+    float mstats[8];             // kl_mu kl_std loss_kl loss_mle loss_total dual_mu dual_std entropy (first M iteration)
+};
+
+#define CVPO_A_TARGET 0      // a' = mu + sigma * eps at s_{t+n}  -> action columns of X
+#define CVPO_A_PARTICLES 1   // actor_old at s_t: mu_old, std_old, K particles -> all columns of XK
+#define CVPO_A_MFWD 2        // actor at s_t: per-tile sums of w*loglik, KL_mu, KL_std, entropy
+#define CVPO_A_MBWD 3        // same forward + gradient of loss_mle + dual_mu*KL_mu + dual_std*KL_std
+struct CvpoActorArgs {
+    const float* obs;        // [B][Do]
+    const float* eps;        // TARGET: [B][Da] ; PARTICLES: [K][B][Da]
+    float* X;                // TARGET: [B][Do+Da] ; PARTICLES: [K*B][Do+Da], row k*B + b
+    float* mu_old; float* std_old;   // [B][Da]   written by PARTICLES, read by the M modes
+    const float* W;          // [K][B] E-step weights
+    const float* XK;         // [K*B][Do+Da] particles (M modes)
+    const CvpoScalars* sc;
+    float* A1; float* A2; float* D1; float* D2; float* DO;   // side buffers (MBWD)
+    float* statp;            // [n_tiles][FB_NSTAT]
+    int B, K, mode;
+    float max_action;
+};
+
+template <int H, int R>
+__global__ __launch_bounds__(4 * H) void cvpo_actor_tile_kernel(const float* __restrict__ P,
+                                                               const ModelDesc md, const CvpoActorArgs a) {
+    __shared__ TileSmem<H> sm;
+    constexpr int NT = TileGeom<H>::NT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * R;
+    const NetOff no = md.net[0];
+    const int Do = md.Do, Da = md.Da, Din = Do + Da;
+    const int n_valid = max(0, min(R, a.B - row0));
+
+    TileStage<H> stg;
+    stg.issue(P, no, Do, 0, a.obs + (size_t)row0 * Do, nullptr, n_valid, tid);
+    FwdW2Frag<H> wf;
+    wf.load(P + no.W2f, wave, lane);
+    for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
+    stg.commit(sm, no, Do, tid);
+    __syncthreads();
+    tile_forward<H, R>(sm, P, no, Do, tid, wf);     // sm.out[i][0..Da) = mean head, [Da..2Da) = raw log sigma
+
+    float wb[H / 16][4];
+    if (a.mode == CVPO_A_MBWD) {
+        const float* __restrict__ W2c = P + no.W2 + wave * 16 + li;
+#pragma unroll
+        for (int jc = 0; jc < H / 16; ++jc) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wb[jc][s] = W2c[(size_t)(16 * jc + 4 * q + s) * H];
+        }
+    }
+    if (a.mode == CVPO_A_PARTICLES) {               // observation columns of the K replicated rows
+        const int per = n_valid * Do;
+        for (int e = tid; e < a.K * per; e += NT) {
+            const int k = e / per, w = e - k * per;
+            const int i = w / Do, f = w - i * Do;
+            a.X[((size_t)k * a.B + row0 + i) * Din + f] = a.obs[(size_t)(row0 + i) * Do + f];
+        }
+    }
+    if (tid < 16 * R) {
+        const int i = tid >> 4, d = tid & 15;
+        const int r = row0 + i;
+        const bool valid = i < n_valid, on = valid && d < Da;
+        float th = 0.0f, mu = 0.0f, sig = 1.0f, pass = 0.0f;
+        if (on) {
+            th = tanhf(sm.out[i * FSRL_MAX_ACT + d]);
+            mu = a.max_action * th;
+            const float lraw = sm.out[i * FSRL_MAX_ACT + Da + d];
+            pass = (lraw >= SAC_LOG_SIG_MIN && lraw <= SAC_LOG_SIG_MAX) ? 1.0f : 0.0f;
+            sig = expf(fminf(fmaxf(lraw, SAC_LOG_SIG_MIN), SAC_LOG_SIG_MAX));
+        }
+        if (a.mode == CVPO_A_TARGET) {
+            if (on) a.X[(size_t)r * Din + Do + d] = a.eps[(size_t)r * Da + d] * sig + mu;
+        } else if (a.mode == CVPO_A_PARTICLES) {
+            if (on) {
+                a.mu_old[(size_t)r * Da + d] = mu;
+                a.std_old[(size_t)r * Da + d] = sig;
+                for (int k = 0; k < a.K; ++k) {
+                    const size_t rk = (size_t)k * a.B + r;
+                    a.X[rk * Din + Do + d] = a.eps[rk * Da + d] * sig + mu;     // Normal.sample: eps * std + mean
+                }
+            }
+        } else {
+            // ---- M-step row terms (cvpo.py:378-417), per action dimension then summed over d
+            float mle = 0.0f, klm = 0.0f, kls = 0.0f, ent = 0.0f;
+            if (on) {
+                const float mu_o = a.mu_old[(size_t)r * Da + d], sd_o = a.std_old[(size_t)r * Da + d];
+                const float var_o = sd_o * sd_o, var = sig * sig;
+                const float lso = logf(sd_o), ls = logf(sig);
+                float s_w = 0.0f, s_wdm = 0.0f, s_wdo2 = 0.0f;     // sum_k w, w*(a-mu), w*(a-mu_old)^2
+                for (int k = 0; k < a.K; ++k) {
+                    const size_t rk = (size_t)k * a.B + r;
+                    const float w = a.W[rk], ak = a.XK[rk * Din + Do + d];
+                    const float dm = ak - mu, dmo = ak - mu_o;
+                    // Normal(mu, std_old).log_prob(a) + Normal(mu_old, std).log_prob(a)
+                    const float ll = (-(dm * dm) / (2.0f * var_o) - lso - LOG_SQRT_2PI) +
+                                     (-(dmo * dmo) / (2.0f * var) - ls - LOG_SQRT_2PI);
+                    mle = fmaf(w, ll, mle);
+                    s_w += w; s_wdm = fmaf(w, dm, s_wdm); s_wdo2 = fmaf(w, dmo * dmo, s_wdo2);
+                }
+                const float var_oc = fmaxf(var_o, 1e-6f), var_c = fmaxf(var, 1e-6f);     // gaussian_kl clamps
+                const float dmu = mu_o - mu;
+                klm = 0.5f * (dmu * dmu) / var_oc;
+                kls = 0.5f * (logf(var_c / var_oc) + var_oc / var_c - 1.0f);
+                ent = (0.5f + 0.5f * 1.8378770664093453f + lso) + (0.5f + 0.5f * 1.8378770664093453f + ls);
+                if (a.mode == CVPO_A_MBWD) {
+                    const float invB = 1.0f / (float)a.B, invKB = invB / (float)a.K;
+                    const float dual_mu = a.sc->dual_mu, dual_std = a.sc->dual_std;
+                    // d loss_mle / d mu, / d sigma   (loss_mle = -mean_{k,b} w * loglik)
+                    float g_mu = -invKB * (s_wdm / var_o);
+                    float g_sg = -invKB * (s_wdo2 / (var * sig) - s_w / sig);
+                    // KL penalties: d kl_mu / d mu = (mu - mu_old) / var_old_c / B ; d kl_std / d sigma (0 where var is clamped)
+                    g_mu += dual_mu * invB * (-dmu / var_oc);
+                    if (var > 1e-6f) g_sg += dual_std * invB * (1.0f / sig - var_oc / (var * sig));
+                    sm.dout[i * FSRL_DOW + d] = g_mu * a.max_action * (1.0f - th * th);
+                    sm.dout[i * FSRL_DOW + Da + d] = g_sg * sig * pass;
+                }
+            }
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+            for (int dd = 0; dd < Da; ++dd) {
+                const int src = (lane & 48) + dd;
+                s0 += __shfl(mle, src, 64); s1 += __shfl(klm, src, 64);
+                s2 += __shfl(kls, src, 64); s3 += __shfl(ent, src, 64);
+            }
+            if (d == 0) {
+                sm.w1[i * FB_NSTAT + 0] = valid ? s0 : 0.0f; sm.w1[i * FB_NSTAT + 1] = valid ? s1 : 0.0f;
+                sm.w1[i * FB_NSTAT + 2] = valid ? s2 : 0.0f; sm.w1[i * FB_NSTAT + 3] = valid ? s3 : 0.0f;
+            }
+        }
+    }
+    if (a.mode < CVPO_A_MFWD) return;
+    __syncthreads();
+    if (a.mode == CVPO_A_MFWD) {
+        if (tid < 4) {
+            float t = 0.0f;
+            for (int i = 0; i < R; ++i) t += sm.w1[i * FB_NSTAT + tid];
+            a.statp[(size_t)blockIdx.x * FB_NSTAT + tid] = t;
+        }
+        return;
+    }
+    tile_backward<H, R>(sm, no, wb, a.A1 + (size_t)row0 * H, a.A2 + (size_t)row0 * H, a.D1 + (size_t)row0 * H,
+                        a.D2 + (size_t)row0 * H, a.DO + (size_t)row0 * FSRL_DOW, tid, false);
+}
+
+// ---- E-step (cvpo.py:278-288, 341-371): one workgroup.  Q values arrive as [n_q][K*B] (row k*B + b);
+//      q0 / q1 are [B][K] scratch.  The reference's in-place aliasing is kept: every dual-loss evaluation leaves
+//      q0 lowered by (pre-step lambda) * q1, and the weights subtract (post-step, clamped lambda) * q1 again.
+struct CvpoEstepArgs {
+    const float* QK; float* q0; float* q1; float* W;
+    CvpoScalars* sc;
+    int B, K, n_q, iters;
+    float kl, thres, lr, dual_max, beta1, beta2, adam_eps;
+};
+__global__ __launch_bounds__(1024) void cvpo_estep_kernel(const CvpoEstepArgs a) {
+    __shared__ double red[3][1024];
+    __shared__ float duals[2];
+    const int tid = threadIdx.x;
+    const size_t KB = (size_t)a.K * a.B;
+    for (int b = tid; b < a.B; b += 1024)
+        for (int k = 0; k < a.K; ++k) {
+            const size_t rk = (size_t)k * a.B + b;
+            float v0, v1;
+            if (a.n_q == 2) { v0 = a.QK[rk]; v1 = a.QK[KB + rk]; }
+            else { v0 = fminf(a.QK[rk], a.QK[KB + rk]); v1 = fminf(a.QK[2 * KB + rk], a.QK[3 * KB + rk]); }
+            a.q0[(size_t)b * a.K + k] = v0; a.q1[(size_t)b * a.K + k] = v1;
+        }
+    if (tid == 0) { duals[0] = a.sc->eta; duals[1] = a.sc->lam; }
+    __syncthreads();
+    const float logK = logf((float)a.K);
+    for (int it = 0; it < a.iters; ++it) {
+        const float eta = duals[0], lam = duals[1];
+        double s_lse = 0.0, s_pc = 0.0, s_pq = 0.0;
+        for (int b = tid; b < a.B; b += 1024) {
+            float* r0 = a.q0 + (size_t)b * a.K; const float* r1 = a.q1 + (size_t)b * a.K;
+            float mx = -INFINITY;
+            for (int k = 0; k < a.K; ++k) {
+                const float cq = r0[k] - lam * r1[k];
+                r0[k] = cq;                                    // combined_q aliases q_values[0]
+                mx = fmaxf(mx, cq / eta);
+            }
+            float se = 0.0f;
+            for (int k = 0; k < a.K; ++k) se += expf(r0[k] / eta - mx);
+            float pc = 0.0f, pq = 0.0f;
+            for (int k = 0; k < a.K; ++k) {
+                const float p = expf(r0[k] / eta - mx) / se;
+                pc = fmaf(p, r0[k], pc); pq = fmaf(p, r1[k], pq);
+            }
+            s_lse += (double)((mx + logf(se)) - logK); s_pc += (double)pc; s_pq += (double)pq;
+        }
+        red[0][tid] = s_lse; red[1][tid] = s_pc; red[2][tid] = s_pq;
+        __syncthreads();
+        for (int w = 512; w > 0; w >>= 1) {                   // fixed tree: order independent of scheduling
+            if (tid < w) { red[0][tid] += red[0][tid + w]; red[1][tid] += red[1][tid + w]; red[2][tid] += red[2][tid + w]; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            CvpoScalars sc = *a.sc;
+            const float m_lse = (float)(red[0][0] / a.B), m_pc = (float)(red[1][0] / a.B), m_pq = (float)(red[2][0] / a.B);
+            const float loss = eta * a.kl + lam * a.thres + eta * m_lse;
+            if (it == 0) sc.estep_loss = loss;
+            const float g[2] = {a.kl + m_lse - m_pc / eta, a.thres - m_pq};
+            sc.et += 1;
+            const double bc1 = 1.0 - pow((double)a.beta1, (double)sc.et), bc2 = 1.0 - pow((double)a.beta2, (double)sc.et);
+            const float step_size = (float)((double)a.lr / bc1);
+            float nd[2] = {eta, lam};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                sc.em[j] = sc.em[j] + (float)(1.0 - (double)a.beta1) * (g[j] - sc.em[j]);
+                sc.ev[j] = sc.ev[j] * a.beta2;
+                sc.ev[j] = sc.ev[j] + ((float)(1.0 - (double)a.beta2) * g[j]) * g[j];
+                const float denom = sqrtf(sc.ev[j]) / (float)sqrt(bc2) + a.adam_eps;
+                nd[j] = nd[j] + (-step_size * sc.em[j]) / denom;
+            }
+            if (it == a.iters - 1) {                          // estep_dual.data.clamp_(eps, max) after the loop
+                nd[0] = fminf(fmaxf(nd[0], CVPO_EPS10), a.dual_max);
+                nd[1] = fminf(fmaxf(nd[1], CVPO_EPS10), a.dual_max);
+            }
+            sc.eta = nd[0]; sc.lam = nd[1];
+            *a.sc = sc;
+            duals[0] = nd[0]; duals[1] = nd[1];
+        }
+        __syncthreads();
+    }
+    // optimal non-parametric distribution: softmax over the K particles of (q0 - lambda * q1) / eta
+    const float eta = duals[0], lam = duals[1];
+    for (int b = tid; b < a.B; b += 1024) {
+        const float* r0 = a.q0 + (size_t)b * a.K; const float* r1 = a.q1 + (size_t)b * a.K;
+        float mx = -INFINITY;
+        for (int k = 0; k < a.K; ++k) mx = fmaxf(mx, (r0[k] - lam * r1[k]) / eta);
+        float se = 0.0f;
+        for (int k = 0; k < a.K; ++k) se += expf((r0[k] - lam * r1[k]) / eta - mx);
+        for (int k = 0; k < a.K; ++k) a.W[(size_t)k * a.B + b] = expf((r0[k] - lam * r1[k]) / eta - mx) / se;
+    }
+}
+
+// ---- M-step dual step (cvpo.py:392-405): KL means over the tiles, Adam on (mstep_dual_mu, mstep_dual_std),
+//      the clipped multipliers for the backward, and the logged values of the first iteration.
+struct CvpoMdualArgs {
+    const float* statp; int n_tiles, B, K;
+    CvpoScalars* sc;
+    float kl_mu_eps, kl_std_eps, dual_max, lr, beta1, beta2, adam_eps;
+    int log_it;
+};
+__global__ __launch_bounds__(64) void cvpo_mdual_kernel(const CvpoMdualArgs a) {
+    const int lane = threadIdx.x;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t = lane; t < a.n_tiles; t += 64) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += (double)a.statp[(size_t)t * FB_NSTAT + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = wave_sum_d(s[k]);
+    if (lane != 0) return;
+    CvpoScalars sc = *a.sc;
+    const float loss_mle = -(float)(s[0] / ((double)a.B * a.K));
+    const float kl_mu = (float)(s[1] / a.B), kl_std = (float)(s[2] / a.B), ent = (float)(s[3] / a.B);
+    const float g[2] = {a.kl_mu_eps - kl_mu, a.kl_std_eps - kl_std};
+    sc.mt += 1;
+    const double bc1 = 1.0 - pow((double)a.beta1, (double)sc.mt), bc2 = 1.0 - pow((double)a.beta2, (double)sc.mt);
+    const float step_size = (float)((double)a.lr / bc1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        sc.mm[j] = sc.mm[j] + (float)(1.0 - (double)a.beta1) * (g[j] - sc.mm[j]);
+        sc.mv[j] = sc.mv[j] * a.beta2;
+        sc.mv[j] = sc.mv[j] + ((float)(1.0 - (double)a.beta2) * g[j]) * g[j];
+        const float denom = sqrtf(sc.mv[j]) / (float)sqrt(bc2) + a.adam_eps;
+        sc.mdual[j] = sc.mdual[j] + (-step_size * sc.mm[j]) / denom;
+    }
+    sc.dual_mu = fminf(fmaxf(sc.mdual[0], 0.0f), a.dual_max);
+    sc.dual_std = fminf(fmaxf(sc.mdual[1], 0.0f), a.dual_max);
+    if (a.log_it) {
+        const float loss_kl = sc.dual_mu * (kl_mu - a.kl_mu_eps) + sc.dual_std * (kl_std - a.kl_std_eps);
+        sc.mstats[0] = kl_mu; sc.mstats[1] = kl_std; sc.mstats[2] = loss_kl; sc.mstats[3] = loss_mle;
+        sc.mstats[4] = loss_mle + loss_kl; sc.mstats[5] = sc.dual_mu; sc.mstats[6] = sc.dual_std; sc.mstats[7] = ent;
+    }
+    *a.sc = sc;
+}
+
+// ---- one row of logged statistics, in the order the reference's logger receives them (cvpo.py:248-276, 341-417)
+struct CvpoFinalArgs {
+    const float* statp_q; const float* Y; const CvpoScalars* sc; float* stats;
+    int n_tiles_q, n_q, B;
+    float thres;
+};
+__global__ __launch_bounds__(64) void cvpo_finalize_kernel(const CvpoFinalArgs a) {
+    const int lane = threadIdx.x;
+    double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // td^2 of up to four Q-nets, sum y_r, sum y_c
+    for (int t = lane; t < a.n_tiles_q; t += 64) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < a.n_q) s[k] += (double)a.statp_q[((size_t)t * a.n_q + k) * FB_NSTAT];
+    }
+    for (int b = lane; b < a.B; b += 64) { s[4] += (double)a.Y[b]; s[5] += (double)a.Y[(size_t)a.B + b]; }
+    float m[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) m[k] = (float)(wave_sum_d(s[k]) / (double)a.B);
+    if (lane != 0) return;
+    const bool single = a.n_q == 2;
+    const float lq0 = single ? m[0] : m[0] + m[1], lq1 = single ? m[1] : m[2] + m[3];
+    const CvpoScalars sc = *a.sc;
+    float* o = a.stats;
+    o[0] = sc.estep_loss; o[1] = sc.eta; o[2] = sc.lam;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[3 + k] = sc.mstats[k];
+    o[11] = lq0; o[12] = m[4]; o[13] = lq1; o[14] = m[5]; o[15] = a.thres; o[16] = lq0 + lq1;
+}
+
+// N(0,1) block of the library-RNG mode: element pair p of stream `draw` (Philox counter (p, draw, update))
+__global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, size_t n, unsigned long long key,
+                                                            unsigned long long counter, uint32_t draw) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // four normals per thread
+    if (4 * p >= n) return;
+    uint32_t c[4] = {(uint32_t)p, draw + 0x1000u * (uint32_t)(p >> 32), (uint32_t)counter, (uint32_t)(counter >> 32)};
+    philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
+    float v[4];
+    box_muller(c[0], c[1], v[0], v[1]);
+    box_muller(c[2], c[3], v[2], v[3]);
+    for (int j = 0; j < 4; ++j)
+        if (4 * p + j < n) out[4 * p + j] = v[j];
+}

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
     const float invN = 1.0f / (float)a.N;
 
     TileStage<H> stg;
-    stg.issue(P, no, Do, Da, a.obs + (size_t)row0 * Do, a.rd + (size_t)row0 * FSRL_RD, n_valid, tid);
+    stg.issue(P, no, Do, Da, a.obs + (size_t)row0 * Do, a.rd ? a.rd + (size_t)row0 * FSRL_RD : nullptr, n_valid, tid);
     FwdW2Frag<H> wf;
     wf.load(P + no.W2f, wave, lane);
     for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;

@@ -330,7 +330,7 @@ class Engine:
 
     def sac_drain(self, max_rows=4096):
         """Statistics rows [n, SAC_NSTATS] of the sync=False updates since the last drain."""
-        out = np.empty((int(max_rows), _lib.SAC_NSTATS), np.float32)
+        out = np.empty((int(max_rows), getattr(self, "_ring_cols", _lib.SAC_NSTATS)), np.float32)
         n = int(self.lib.fsrl_sac_stats_drain(self._ctx, _ptr(out, _f32p), int(max_rows)))
         if n < 0:
             _lib.check(n)
@@ -350,6 +350,54 @@ class Engine:
         _lib.check(self.lib.fsrl_sac_actor_forward(self._ctx, _ptr(obs, _f32p), k, _ptr(mu, _f32p),
                                                    _ptr(sigma, _f32p)))
         return mu, sigma
+
+    # ---------------------------------------------------------------- CVPO (on the SAC replay context)
+    def cvpo_init(self, qc_thres, actor_lr=5e-4, critic_lr=1e-3, tau=0.05, n_step=2, double_critic=False,
+                  sample_act_num=16, estep_iter_num=1, mstep_iter_num=1, estep_kl=0.02, estep_dual_max=20.0,
+                  estep_dual_lr=0.02, mstep_kl_mu=0.005, mstep_kl_std=0.0005, mstep_dual_max=0.5, mstep_dual_lr=0.1):
+        """fsrl_cvpo_init (cvpo.py:71-163).  Parameters then move through the sac_* accessors (which=3: actor_old)."""
+        cfg = _lib.CvpoConfig(actor_lr, critic_lr, tau, int(n_step), int(double_critic), int(sample_act_num),
+                              int(estep_iter_num), int(mstep_iter_num), estep_kl, estep_dual_max, estep_dual_lr,
+                              mstep_kl_mu, mstep_kl_std, mstep_dual_max, mstep_dual_lr, float(qc_thres))
+        _lib.check(self.lib.fsrl_cvpo_init(self._ctx, C.byref(cfg)))
+        self.n_sac_actor = int(self.lib.fsrl_sac_param_count(self._ctx, 0))
+        self.n_sac_critics = int(self.lib.fsrl_sac_param_count(self._ctx, 1))
+        self._ring_cols = _lib.CVPO_NSTATS
+        self._cvpo_k = int(sample_act_num)
+
+    def cvpo_pre_update(self):
+        _lib.check(self.lib.fsrl_cvpo_pre_update(self._ctx))
+
+    def cvpo_post_update(self):
+        _lib.check(self.lib.fsrl_cvpo_post_update(self._ctx))
+
+    def cvpo_set_thres(self, qc_thres):
+        _lib.check(self.lib.fsrl_cvpo_set_thres(self._ctx, float(qc_thres)))
+
+    def cvpo_update(self, batch_size, indices=None, eps_target=None, eps_particles=None, seed=0, sync=True):
+        """One CVPO.update.  indices / eps_target [B,Da] / eps_particles [K,B,Da] together = caller RNG; all None =
+        device RNG.  sync=False only enqueues; rows come back through sac_drain()."""
+        idx = None if indices is None else np.ascontiguousarray(indices, np.int64)
+        et = None if eps_target is None else np.ascontiguousarray(eps_target, np.float32)
+        ek = None if eps_particles is None else np.ascontiguousarray(eps_particles, np.float32)
+        if idx is not None:
+            assert idx.size == batch_size and et.size == batch_size * self.cfg.act_dim
+            assert ek.size == self._cvpo_k * batch_size * self.cfg.act_dim
+        out = np.empty(_lib.CVPO_NSTATS, np.float32) if sync else None
+        _lib.check(self.lib.fsrl_cvpo_update(self._ctx, int(batch_size), _ptr(idx, _i64p), _ptr(et, _f32p),
+                                             _ptr(ek, _f32p), int(seed), _ptr(out, _f32p)))
+        return out
+
+    def cvpo_duals(self):
+        """(eta, lambda, mstep_dual_mu, mstep_dual_std)"""
+        out = np.empty(4, np.float32)
+        _lib.check(self.lib.fsrl_cvpo_duals_get(self._ctx, _ptr(out, _f32p)))
+        return out
+
+    def cvpo_last_particles(self, batch_size):
+        out = np.empty((self._cvpo_k, int(batch_size), self.cfg.act_dim), np.float32)
+        _lib.check(self.lib.fsrl_cvpo_last_particles(self._ctx, _ptr(out, _f32p), out.size))
+        return out
 
     def set_profiling(self, on: bool):
         _lib.check(self.lib.fsrl_set_profiling(self._ctx, int(on)))

@@ -33,6 +33,8 @@ class SyntheticSafetyVectorEnv:
         self.episode_len, self.busy_us = episode_len, busy_us
         self.observation_space = Box(-np.inf, np.inf, (obs_dim, ))
         self.action_space = Box(-1.0, 1.0, (act_dim, ))
+        from types import SimpleNamespace
+        self.spec = SimpleNamespace(id="SyntheticSafety-v0", max_episode_steps=episode_len)   # gym's env.spec (CVPO reads it)
         self.rng = np.random.default_rng(seed)
         k = np.random.default_rng(1234)
         self.A = (0.95 * np.eye(obs_dim) + 0.02 * k.standard_normal((obs_dim, obs_dim))).astype(np.float32)

@@ -7,5 +7,6 @@ from fsrl_amd.policy.cpo import CPO
 from fsrl_amd.policy.sac_lag import SACLagrangian
 from fsrl_amd.policy.ddpg_lag import DDPGLagrangian
 from fsrl_amd.policy.focops import FOCOPS
+from fsrl_amd.policy.cvpo import CVPO
 
-__all__ = ["BasePolicy", "LagrangianPolicy", "PPOLagrangian", "TRPOLagrangian", "CPO", "SACLagrangian", "DDPGLagrangian", "FOCOPS"]
+__all__ = ["BasePolicy", "LagrangianPolicy", "PPOLagrangian", "TRPOLagrangian", "CPO", "SACLagrangian", "DDPGLagrangian", "FOCOPS", "CVPO"]

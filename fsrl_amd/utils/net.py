@@ -132,6 +132,18 @@ class Critic(nn.Module):
         return self.last(logits)
 
 
+class SingleCritic(Critic):
+    """tianshou Critic whose forward returns a one-element list, like DoubleCritic's pair
+    (fsrl/utils/net/continuous.py:103-160); attribute names preprocess / last as in the reference's state_dict."""
+
+    def forward(self, obs, act=None, info={}):
+        return [super().forward(obs, act, info)]
+
+    def predict(self, obs, act=None, info={}):
+        q = self(obs, act, info)[0]
+        return q, [q]
+
+
 class ActorCritic(nn.Module):
     """Parameter container (fsrl/utils/net/common.py:6-18)."""
 

@@ -266,6 +266,47 @@ int fsrl_sac_last_sample(fsrl_ctx* ctx, int64_t* indices, float* eps_target, flo
 /* the actor for the collector: mu and sigma = exp(clamp(log sigma)) of the tanh-Gaussian policy   */
 int fsrl_sac_actor_forward(fsrl_ctx* ctx, const float* obs, int32_t k, float* mu_out, float* sigma_out);
 
+/* ---- CVPO (fsrl/policy/cvpo.py:71-430), on the replay context of SAC-Lagrangian: create the
+ *      context with algo = FSRL_ALGO_SAC_LAG, then fsrl_cvpo_init INSTEAD of fsrl_sac_init.
+ *      Networks (cvpo_agent.py:143-186): Gaussian actor, mu = max_action * tanh(head), sigma = exp(clamp(head,
+ *      -20, 2)), NOT squashed after sampling, with a hard-copied actor_old; per metric one SingleCritic
+ *      (double_critic == 0; vector layout as DDPG-Lag's critics) or one DoubleCritic (layout as SAC's) with
+ *      Polyak targets.  Parameters move through fsrl_sac_params_set / _get / _put (which = 3 is actor_old);
+ *      the collector's actor through fsrl_sac_actor_forward / fsrl_actor_sample; the statistics ring through
+ *      fsrl_sac_stats_drain with rows of FSRL_CVPO_NSTATS floats.                                            */
+typedef struct fsrl_cvpo_config {
+    float actor_lr, critic_lr;             /* 5e-4, 1e-3                           (cvpo_agent.py:101-102) */
+    float tau;                             /* Polyak of critics_old, 0.05                                  */
+    int32_t n_step;                        /* 2                                                            */
+    int32_t double_critic;                 /* 0: SingleCritic (default), 1: DoubleCritic, predict = min    */
+    int32_t sample_act_num;                /* K particles per state, 16                                    */
+    int32_t estep_iter_num, mstep_iter_num;/* 1, 1                                                         */
+    float estep_kl, estep_dual_max, estep_dual_lr;                 /* 0.02, 20, 0.02                       */
+    float mstep_kl_mu, mstep_kl_std, mstep_dual_max, mstep_dual_lr;/* 0.005, 0.0005, 0.5, 0.1              */
+    double qc_thres;                       /* cost_limit * (1 - gamma^T) / (1 - gamma) / T   (cvpo.py:138-141) */
+} fsrl_cvpo_config;
+#define FSRL_CVPO_NSTATS 17 /* estep_loss, dual0 (eta), dual1 (lambda)                      (cvpo.py:346-354)
+                               kl_mu, kl_std, loss_kl, loss_mle, loss_total, dual_mu, dual_std, entropy (:405-415)
+                               loss_q0, val_q0, loss_q1, val_q1, thres_q1, q_total           (:262-275)    */
+int fsrl_cvpo_init(fsrl_ctx* ctx, const fsrl_cvpo_config* cfg);
+/* CVPO.pre_update_fn (cvpo.py:178-188): zero the two M-step multipliers and their Adam state.             */
+int fsrl_cvpo_pre_update(fsrl_ctx* ctx);
+/* CVPO.post_update_fn (cvpo.py:190-193): actor_old <- actor.                                              */
+int fsrl_cvpo_post_update(fsrl_ctx* ctx);
+/* CVPO.update_cost_limit (cvpo.py:165-176): the new E-step threshold on Qc.                               */
+int fsrl_cvpo_set_thres(fsrl_ctx* ctx, double qc_thres);
+/* One CVPO.update(batch_size, buffer): sample + n-step targets (a' ~ actor, critics_old) + critic step +
+ * E-step (K particles of actor_old through the UPDATED critics, Adam on (eta, lambda), softmax weights) +
+ * M-step (weighted decoupled-Gaussian likelihood + KL multipliers, actor Adam) + Polyak (cvpo.py:206-430).
+ * Sampling as fsrl_sac_update: indices [B], eps_target [B][Da] and eps_particles [K][B][Da] are given
+ * together (caller RNG) or all NULL (Philox on the device).  stats_out: FSRL_CVPO_NSTATS floats or NULL.    */
+int fsrl_cvpo_update(fsrl_ctx* ctx, int32_t batch_size, const int64_t* indices, const float* eps_target,
+                     const float* eps_particles, uint64_t seed, float* stats_out);
+/* out[0..3] = eta, lambda (estep_dual, clamped) and mstep_dual_mu, mstep_dual_std (stored unclipped).      */
+int fsrl_cvpo_duals_get(fsrl_ctx* ctx, float* out4);
+/* The K particles' N(0,1) block of the last update ([K][B][Da]); indices / eps_target: fsrl_sac_last_sample. */
+int fsrl_cvpo_last_particles(fsrl_ctx* ctx, float* eps_particles, int64_t n);
+
 /* ---- timing of the last update, measured with hipEvents on the compute stream --------- */
 /* out[0] = process_fn ms, out[1] = learn ms (all passes), out[2] = fused fwd/bwd kernel
  * total ms over the update (sum of per-launch event pairs when profiling is enabled),
