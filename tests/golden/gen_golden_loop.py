@@ -278,12 +278,71 @@ def gen_sac(name, obs_dim, act_dim, hidden, env_num, ep_len, cycles, batch_size,
           f"alpha {alphas[0]:.4f} -> {alphas[-1]:.4f} lag {lags[0][0]:.3f} -> {lags[-1][0]:.3f}")
 
 
+def gen_cvpo(name, obs_dim, act_dim, hidden, env_num, ep_len, cycles, batch_size, updates_per_cycle, seed, cost_limit, n_step=2):
+    """CVPO closed loop (fsrl/trainer/offpolicy.py:96-105): collect -> pre_update_fn -> updates -> post_update_fn
+    (actor_old <- actor).  Default networks of cvpo_agent.py: Gaussian actor (bounded mean), SingleCritic pair."""
+    from fsrl.policy import CVPO
+    from fsrl.utils.net.common import ActorCritic
+    from fsrl.utils.net.continuous import SingleCritic
+    from ref_shim import ActorProb, Net, _Box
+    from torch import nn
+    from torch.distributions import Independent, Normal
+    seed_all(seed)
+    actor = ActorProb(Net((obs_dim, ), hidden_sizes=hidden), (act_dim, ), max_action=1.0, conditioned_sigma=True, unbounded=False)
+    critics = [SingleCritic(Net((obs_dim, ), (act_dim, ), hidden_sizes=hidden, concat=True)) for _ in range(2)]
+    for m in ActorCritic(actor, critics).modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.orthogonal_(m.weight)
+            torch.nn.init.zeros_(m.bias)
+    logger = CaptureLogger()
+    policy = CVPO(actor=actor, critics=critics, actor_optim=torch.optim.Adam(actor.parameters(), lr=5e-4),
+                  critic_optim=torch.optim.Adam(nn.ModuleList(critics).parameters(), lr=1e-3), logger=logger,
+                  action_space=_Box(-1, 1, (act_dim, )), dist_fn=lambda *l: Independent(Normal(*l), 1),
+                  max_episode_steps=ep_len, cost_limit=cost_limit, gamma=0.98, n_step=n_step)
+    policy.train()
+    env = SyntheticSafetyVectorEnv(env_num=env_num, obs_dim=obs_dim, act_dim=act_dim, episode_len=ep_len, seed=seed + 11)
+    buf = VectorReplayBuffer(env_num * ep_len * cycles, env_num)           # never wraps
+    flat = lambda mods: torch.cat([p.detach().reshape(-1) for m in mods for p in m.parameters()]).numpy().copy()  # noqa: E731
+    out = {"theta_actor0": flat([actor]), "theta_critics0": flat(critics)}
+    seed_all(seed + 7)
+    curve, last_rows, duals = [], [], []
+    for c in range(cycles):
+        st = rollout(policy, env, buf)
+        policy.pre_update_fn(stats_train={"cost": st["cost"]})
+        n0 = len(logger.rows)
+        for _ in range(updates_per_cycle):
+            policy.update(batch_size, buf)
+        policy.post_update_fn(stats_train={"cost": st["cost"]})
+        last, i = {}, len(logger.rows) - 1
+        while i >= n0 and not (last and "loss/q_total" in logger.rows[i]):      # the rows of the LAST update
+            last = {**logger.rows[i], **last}
+            i -= 1
+        keys = [k for k in last if not k.endswith("_time")]
+        last_rows.append([last[k] for k in keys])
+        duals.append(list(policy.estep_dual.detach().numpy()) + [policy.mstep_dual_mu.item(), policy.mstep_dual_std.item()])
+        curve.append([st["reward"], st["cost"], st["steps"]])
+    out.update(curve=np.array(curve), last_rows=np.array(last_rows), duals=np.array(duals, np.float64),
+               stat_keys=np.array(keys), theta_actor_final=flat([actor]), theta_critics_final=flat(critics),
+               theta_critics_old_final=flat(list(policy.critics_old)), theta_actor_old_final=flat([policy.actor_old]))
+    cfg = dict(obs_dim=obs_dim, act_dim=act_dim, hidden=list(hidden), env_num=env_num, ep_len=ep_len, cycles=cycles,
+               batch_size=batch_size, updates_per_cycle=updates_per_cycle, seed=seed, cost_limit=cost_limit, n_step=n_step,
+               actor_lr=5e-4, critic_lr=1e-3, tau=0.05, gamma=0.98)
+    out["cfg_json"] = np.array(json.dumps(cfg))
+    np.savez_compressed(os.path.join(HERE, f"loop_{name}.npz"), **out)
+    print(f"G11 loop_{name}.npz cycles={cycles} reward {curve[0][0]:.2f} -> {curve[-1][0]:.2f} cost {curve[0][1]:.2f} -> {curve[-1][1]:.2f} "
+          f"duals {duals[0]} -> {duals[-1]}")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "cvpo":
+        gen_cvpo("cvpo", 8, 2, (64, 64), env_num=6, ep_len=50, cycles=10, batch_size=64, updates_per_cycle=30, seed=76, cost_limit=2.0)
+        sys.exit(0)
     gen_sac("sac", 8, 2, (64, 64), env_num=6, ep_len=50, cycles=10, batch_size=64, updates_per_cycle=30, seed=71, cost_limit=5.0)
     gen_focops("focops", 8, 2, (64, 64), env_num=8, ep_len=60, cycles=10, batch_size=128, repeat=4, seed=72, cost_limit=8.0)
     gen_trust("cpo", "cpo", 8, 2, (64, 64), env_num=8, ep_len=60, cycles=8, repeat=2, seed=74, cost_limit=20.0)
     gen_trust("trpo", "trpo", 8, 2, (64, 64), env_num=8, ep_len=60, cycles=8, repeat=2, seed=75, cost_limit=20.0)
+    gen_cvpo("cvpo", 8, 2, (64, 64), env_num=6, ep_len=50, cycles=10, batch_size=64, updates_per_cycle=30, seed=76, cost_limit=2.0)
     gen_ddpg("ddpg", 8, 2, (64, 64), env_num=6, ep_len=50, cycles=10, batch_size=64, updates_per_cycle=30, seed=73, cost_limit=5.0)
     gen("ppo", 8, 2, (64, 64), env_num=8, ep_len=60, cycles=12, batch_size=128, repeat=4, seed=70, cost_limit=8.0,
         target_kl=0.5, max_grad_norm=0.5)

@@ -155,6 +155,55 @@ class _Cap:
     def print(self, *a, **k): pass
 
 
+def test_closed_cvpo_loop_tracks_the_reference_learning_curve():
+    """CVPO: 10 collects x 30 updates with actor_old refreshed after every cycle; same numpy (buffer.sample) and torch
+    (Normal.sample in acting, target action, the unused forward draws and the K particles) streams as the reference."""
+    from torch.distributions import Independent, Normal
+    from fsrl_amd.data import HipVectorReplayBuffer
+    from fsrl_amd.env import Box, SyntheticSafetyVectorEnv
+    from fsrl_amd.policy import CVPO, SACLagrangian
+    from fsrl_amd.utils.net import ActorProb, Net, SingleCritic
+    g = load_npz("loop_cvpo.npz"); cfg = json.loads(str(g["cfg_json"]))
+    Do, Da, h, E = cfg["obs_dim"], cfg["act_dim"], tuple(cfg["hidden"]), cfg["env_num"]
+    actor = ActorProb(Net((Do, ), hidden_sizes=h), (Da, ), conditioned_sigma=True, unbounded=False)
+    critics = [SingleCritic(Net((Do, ), (Da, ), hidden_sizes=h, concat=True)) for _ in range(2)]
+    SACLagrangian._unflat([actor], g["theta_actor0"]); SACLagrangian._unflat(critics, g["theta_critics0"])
+    log = _Cap()
+    pol = CVPO(actor, critics, torch.optim.Adam(actor.parameters(), lr=cfg["actor_lr"]),
+               torch.optim.Adam(torch.nn.ModuleList(critics).parameters(), lr=cfg["critic_lr"]), action_space=Box(-1, 1, (Da, )),
+               dist_fn=lambda *l: Independent(Normal(*l), 1), max_episode_steps=cfg["ep_len"], logger=log,
+               cost_limit=cfg["cost_limit"], tau=cfg["tau"], gamma=cfg["gamma"], n_step=cfg["n_step"],
+               observation_space=Box(-np.inf, np.inf, (Do, )), device=0, env_num=E,
+               buffer_size=E * cfg["ep_len"] * cfg["cycles"], reference_rng=True)
+    pol.train()
+    env = SyntheticSafetyVectorEnv(env_num=E, obs_dim=Do, act_dim=Da, episode_len=cfg["ep_len"], seed=cfg["seed"] + 11)
+    buf = HipVectorReplayBuffer(pol.engine, E * cfg["ep_len"] * cfg["cycles"], E)
+    seed = cfg["seed"] + 7
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    keys = [str(k) for k in g["stat_keys"]]
+    worst_r, worst_c = 0.0, 0.0
+    for c in range(cfg["cycles"]):
+        st = _rollout(pol, env, buf)
+        pol.pre_update_fn(stats_train={"cost": st["cost"]})
+        n0 = len(log.rows)
+        for _ in range(cfg["updates_per_cycle"]):
+            pol.update(cfg["batch_size"], buf)
+        duals = pol.engine.cvpo_duals()
+        pol.post_update_fn(stats_train={"cost": st["cost"]})
+        last = {}
+        for r in log.rows[-5:]:                       # one update = five store() calls in the façade
+            last.update(r)
+        worst_r = max(worst_r, abs(st["reward"] - g["curve"][c][0])); worst_c = max(worst_c, abs(st["cost"] - g["curve"][c][1]))
+        assert abs(st["reward"] - g["curve"][c][0]) <= 0.05 and abs(st["cost"] - g["curve"][c][1]) <= 0.5, (c, st, g["curve"][c])
+        tol = 2e-3 if c < 5 else 2e-2
+        np.testing.assert_allclose([last[k] for k in keys], g["last_rows"][c], rtol=tol, atol=tol, err_msg=f"cycle {c}")
+        np.testing.assert_allclose(duals, g["duals"][c], rtol=tol, atol=tol, err_msg=f"cycle {c}")
+    d = np.abs(pol.engine.sac_get_params(0)[0] - g["theta_actor_final"])
+    print("closed CVPO loop: max |reward diff|", worst_r, "max |cost diff|", worst_c, "actor theta mean/max diff", d.mean(), d.max())
+    assert d.mean() <= 1e-4, (d.mean(), d.max())
+    pol.engine.close()
+
+
 def test_closed_focops_loop_tracks_the_reference_learning_curve():
     """FOCOPS incl. the cycles in which the reference stops a pass early on the KL threshold."""
     from fsrl_amd.data import HipVectorReplayBuffer
