@@ -12,12 +12,12 @@ import sys
 import tempfile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from fsrl_amd.agent import CPOAgent, DDPGLagAgent, FOCOPSAgent, PPOLagAgent, SACLagAgent, TRPOLagAgent  # noqa: E402
+from fsrl_amd.agent import CPOAgent, CVPOAgent, DDPGLagAgent, FOCOPSAgent, PPOLagAgent, SACLagAgent, TRPOLagAgent  # noqa: E402
 from fsrl_amd.env import SyntheticSafetyVectorEnv  # noqa: E402
 from fsrl_amd.utils import BaseLogger  # noqa: E402
 
 AGENTS = {"ppol": PPOLagAgent, "cpo": CPOAgent, "trpol": TRPOLagAgent, "focops": FOCOPSAgent, "sacl": SACLagAgent,
-          "ddpgl": DDPGLagAgent}
+          "ddpgl": DDPGLagAgent, "cvpo": CVPOAgent}
 
 
 def main():
@@ -36,7 +36,7 @@ def main():
     logger = BaseLogger(tempfile.mkdtemp(prefix="fsrl_amd_"), name=a.algo)
     kw = dict(cost_limit=a.cost_limit, device=a.device, seed=a.seed, hidden_sizes=(a.hidden, a.hidden), training_num=a.envs)
     agent = AGENTS[a.algo](env, logger, **kw)
-    if a.algo in ("sacl", "ddpgl"):
+    if a.algo in ("sacl", "ddpgl", "cvpo"):
         out = agent.learn(env, test_env, epoch=a.epoch, episode_per_collect=a.envs, step_per_epoch=6000, update_per_step=0.2,
                           batch_size=256, testing_num=2, device_actor=a.device_actor, verbose=True, save_ckpt=False)
     else:
