@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""G8b: key order / shapes of SACLagrangian.state_dict() and DDPGLagrangian.state_dict() as the UNMODIFIED
-reference builds them (sac_lag_agent.py:126-176, ddpg_lag_agent.py:106-160); merged into
+"""G8b: key order / shapes of SACLagrangian.state_dict(), DDPGLagrangian.state_dict() and CVPO.state_dict() as the
+UNMODIFIED reference builds them (sac_lag_agent.py:126-176, ddpg_lag_agent.py:106-160, cvpo_agent.py:143-231); merged into
 state_dict_manifest.json.  Build container only.
 
     python tests/golden/gen_manifest_offpolicy.py
@@ -17,8 +17,9 @@ sys.path.insert(0, HERE)
 import ref_shim  # noqa: E402
 
 ref_shim.install()
-from fsrl.policy import DDPGLagrangian, SACLagrangian  # noqa: E402
-from fsrl.utils.net.continuous import DoubleCritic  # noqa: E402
+from fsrl.policy import CVPO, DDPGLagrangian, SACLagrangian  # noqa: E402
+from fsrl.utils.net.continuous import DoubleCritic, SingleCritic  # noqa: E402
+from torch.distributions import Independent, Normal  # noqa: E402
 from torch import nn  # noqa: E402
 
 from ref_shim import Actor, ActorProb, Critic, Net, _Box  # noqa: E402
@@ -43,9 +44,15 @@ critics2 = [Critic(Net((Do, ), (Da, ), hidden_sizes=hidden, concat=True)) for _ 
 ddpg = DDPGLagrangian(actor=actor2, critics=critics2, actor_optim=torch.optim.Adam(actor2.parameters(), lr=1e-3),
                       critic_optim=torch.optim.Adam(nn.ModuleList(critics2).parameters(), lr=1e-3), cost_limit=10.0,
                       exploration_noise=None, **spaces)
+actor3 = ActorProb(Net((Do, ), hidden_sizes=hidden), (Da, ), max_action=1.0, conditioned_sigma=True, unbounded=False)
+critics3 = [SingleCritic(Net((Do, ), (Da, ), hidden_sizes=hidden, concat=True)) for _ in range(2)]
+cvpo = CVPO(actor=actor3, critics=critics3, actor_optim=torch.optim.Adam(actor3.parameters(), lr=1e-3),
+            critic_optim=torch.optim.Adam(nn.ModuleList(critics3).parameters(), lr=1e-3), action_space=spaces["action_space"],
+            dist_fn=lambda *l: Independent(Normal(*l), 1), max_episode_steps=100, cost_limit=10.0)
 path = os.path.join(HERE, "state_dict_manifest.json")
 man = json.load(open(path))
 man["sac_lag_64x64_obs6_act3"] = manifest(sac)
 man["ddpg_lag_64x64_obs6_act3"] = manifest(ddpg)
+man["cvpo_64x64_obs6_act3"] = manifest(cvpo)
 json.dump(man, open(path, "w"), indent=0)
 print({k: len(v) for k, v in man.items()})
