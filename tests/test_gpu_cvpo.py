@@ -169,3 +169,115 @@ def test_cvpo_facade_matches_reference_and_agent_learns(tmp_path):
     ep, stat, info = agent.learn(env, None, epoch=2, episode_per_collect=4, step_per_epoch=240, update_per_step=0.2,
                                  batch_size=32, verbose=False, save_ckpt=False)
     assert ep == 2 and np.isfinite(list(stat.values())).all() and "loss/q_total" in stat and "mstep/mstep_kl_mu" in stat
+
+
+CVPO_VARIANTS = [  # Do, Da, H, rows per env, batch, K, n_step, double_critic, estep_iters, mstep_iters, max_action
+    (7, 3, 64, [40, 17], 100, 16, 1, False, 1, 1, 1.0),       # batch not a multiple of 16, 1-step targets
+    (20, 8, 128, [64, 64, 64], 16, 64, 3, True, 1, 2, 2.0),   # widest action head, most particles, DoubleCritic, scaled actions
+    (9, 2, 256, [33], 1, 1, 2, False, 3, 1, 1.0),             # one row, one particle (weights == 1), three E-step iterations
+    (41, 1, 64, [90, 45], 333, 5, 2, False, 1, 1, 0.5),       # batch larger than the store, K not a power of two
+]
+
+
+@pytest.mark.parametrize("Do,Da,H,rows,B,K,n_step,double,eit,mit,amax", CVPO_VARIANTS)
+def test_cvpo_variants_vs_oracle(Do, Da, H, rows, B, K, n_step, double, eit, mit, amax):
+    """Shapes and options outside the golden set, checked against the (pinned) oracle on the same random problem."""
+    from fsrl_amd import _lib
+    from fsrl_amd.engine import Engine, EngineConfig
+    from oracle.cvpo import CVPOConfig, CVPOOracle
+    from oracle.sac_lag import ReplayIndex
+    rng = np.random.default_rng(Do + 10 * Da)
+    E, sub = len(rows), 128
+    ocfg = CVPOConfig(obs_dim=Do, act_dim=Da, hidden=(H, H), max_action=amax, gamma=0.97, n_step=n_step, tau=0.1,
+                      double_critic=double, sample_act_num=K, estep_iter_num=eit, mstep_iter_num=mit, cost_limit=0.5,
+                      max_episode_steps=50, mstep_kl_mu=1e-4, mstep_kl_std=1e-5, actor_lr=1e-3)
+    eng = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=Do, act_dim=Da, hidden=H, n_critics=2, env_num=E,
+                              buffer_size=E * sub, gamma=0.97, max_action=amax, target_kl=None))
+    eng.cvpo_init(ocfg.qc_thres, actor_lr=1e-3, tau=0.1, n_step=n_step, double_critic=double, sample_act_num=K,
+                  estep_iter_num=eit, mstep_iter_num=mit, mstep_kl_mu=1e-4, mstep_kl_std=1e-5)
+    o = CVPOOracle(ocfg)
+    n_a = sum(int(np.prod(s)) for s in o.aspec.values()); n_c = sum(int(np.prod(s)) for s in o.cspec.values())
+    tha = (0.2 * rng.standard_normal(n_a)).astype(np.float32)
+    thc = (0.2 * rng.standard_normal(2 * n_c)).astype(np.float32)
+    o.set_params(tha, thc); eng.sac_set_params(tha, thc, 0.0)
+    store = {k: np.zeros((E * sub, ) + s, d) for k, s, d in (("obs", (Do, ), np.float32), ("obs_next", (Do, ), np.float32),
+             ("act", (Da, ), np.float32), ("rew", (), np.float64), ("cost", (), np.float64),
+             ("terminated", (), bool), ("truncated", (), bool))}
+    for t in range(max(rows)):
+        ids = [e for e in range(E) if t < rows[e]]
+        k = len(ids)
+        row = dict(obs=rng.standard_normal((k, Do)).astype(np.float32),
+                   act=np.clip(rng.standard_normal((k, Da)), -amax, amax).astype(np.float32), rew=rng.normal(0, 1, k),
+                   cost=(rng.random(k) < 0.3).astype(np.float64), terminated=rng.random(k) < 0.1,
+                   truncated=np.full(k, t % 11 == 10), obs_next=rng.standard_normal((k, Do)).astype(np.float32))
+        eng.push(ids, row["obs"], row["act"], row["rew"], row["cost"], row["terminated"], row["truncated"], row["obs_next"])
+        for e, j in zip(ids, range(k)):
+            for key in store:
+                store[key][e * sub + t] = row[key][j]
+    index = ReplayIndex(rows, sub, store["terminated"] | store["truncated"])
+    valid = np.concatenate([e * sub + np.arange(r) for e, r in enumerate(rows)])
+    keys = ["loss/estep_loss", "estep/dual0", "estep/dual1", "mstep/mstep_kl_mu", "mstep/mstep_kl_std", "mstep/mstep_loss_kl",
+            "mstep/mstep_loss_mle", "mstep/mstep_loss_total", "mstep/mstep_dual_mu", "mstep/mstep_dual_std", "mstep/entropy",
+            "loss/loss_q0", "estep/val_q0", "loss/loss_q1", "estep/val_q1", "estep/thres_q1", "loss/q_total"]
+    for cyc in range(2):
+        o.pre_update(); eng.cvpo_pre_update()
+        for u in range(2):
+            idx = rng.choice(valid, B)
+            et = rng.standard_normal((B, Da)).astype(np.float32); ek = rng.standard_normal((K, B, Da)).astype(np.float32)
+            want, _, _ = o.update(store, index, idx, et, ek)
+            st = eng.cvpo_update(B, indices=idx, eps_target=et, eps_particles=ek)
+            for j, kname in enumerate(keys):
+                w = float(want[kname])
+                assert abs(st[j] - w) <= 2e-4 * abs(w) + 2e-5, (cyc, u, kname, st[j], w)
+            d = eng.cvpo_duals()
+            np.testing.assert_allclose(d, [o.estep_dual[0].item(), o.estep_dual[1].item(), o.mstep_dual_mu.item(),
+                                           o.mstep_dual_std.item()], rtol=2e-4, atol=2e-5)
+        o.post_update(); eng.cvpo_post_update()
+    for got, ref in ((eng.sac_get_params(0)[0], o.actor_flat()), (eng.sac_get_params(3)[0], o.actor_flat(old=True)),
+                     (eng.sac_get_params(1)[0], o.critics_flat()), (eng.sac_get_params(2)[0], o.critics_flat(old=True))):
+        d = np.abs(got - ref)      # Adam: an entry whose gradient is rounding noise moves by +-lr per step either way
+        assert np.quantile(d, 0.99) <= 1e-5 and d.max() <= 5e-3, (np.quantile(d, 0.99), d.max())
+    eng.close()
+
+
+def test_cvpo_on_a_wrapped_store_device_and_host_chains_agree():
+    """Sub-buffers overwritten 2.5 times: the device sampler's n-step chains (sac_sample_kernel) and the caller-RNG
+    mode's (host) give bit-identical CVPO updates from the same indices and noise."""
+    from fsrl_amd import _lib
+    from fsrl_amd.engine import Engine, EngineConfig
+    rng = np.random.default_rng(4)
+    Do, Da, E, sub, B = 5, 3, 3, 40, 48
+
+    def make():
+        eng = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=Do, act_dim=Da, hidden=64, n_critics=2, env_num=E,
+                                  buffer_size=E * sub, gamma=0.97, target_kl=None))
+        eng.cvpo_init(0.2, n_step=3, sample_act_num=8)
+        r = np.random.default_rng(0)
+        eng.sac_set_params((0.2 * r.standard_normal(eng.n_sac_actor)).astype(np.float32),
+                           (0.2 * r.standard_normal(eng.n_sac_critics)).astype(np.float32), 0.0)
+        eng.cvpo_pre_update()
+        return eng
+    dev, twin = make(), make()
+    T = 100
+    obs = rng.standard_normal((T + 1, E, Do)).astype(np.float32)
+    act = np.clip(rng.standard_normal((T, E, Da)), -1, 1).astype(np.float32)
+    rew = rng.normal(0, 1, (T, E)); cost = (rng.random((T, E)) < 0.3).astype(np.float64)
+    term = rng.random((T, E)) < 0.05; trunc = np.zeros((T, E), bool); trunc[12::13] = True
+    for t in range(T):
+        ids = [0, 1, 2] if t % 7 else [0, 2]
+        for e_ in (dev, twin):
+            e_.push(ids, obs[t, ids], act[t, ids], rew[t, ids], cost[t, ids], term[t, ids], trunc[t, ids], obs[t + 1, ids])
+    assert len(dev) == E * sub
+    for u in range(5):
+        dev.cvpo_update(B, seed=9 if u == 0 else 0, sync=False)
+        idx, et, _ = dev.sac_last_sample(B)
+        ek = dev.cvpo_last_particles(B)
+        st = twin.cvpo_update(B, indices=idx, eps_target=et, eps_particles=ek)
+        if u == 2:
+            for e_ in (dev, twin):
+                e_.cvpo_post_update(); e_.cvpo_pre_update()
+    rows = dev.sac_drain()
+    assert np.isfinite(rows).all() and np.array_equal(rows[-1], st)
+    for which in (0, 1, 2, 3):
+        assert np.array_equal(dev.sac_get_params(which)[0], twin.sac_get_params(which)[0])
+    dev.close(); twin.close()

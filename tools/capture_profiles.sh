@@ -17,5 +17,9 @@ timeout 300 python tools/bench_sac.py > $O/${TAG}_bench_sac.json 2>/dev/null
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_sac -- python $R/tools/bench_sac.py --rows 200000 --updates 300 --no-cpu > /dev/null 2>&1
 cd $R
+timeout 300 python tools/bench_cvpo.py > $O/${TAG}_bench_cvpo.json 2>/dev/null
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_cvpo -- python $R/tools/bench_cvpo.py --updates 300 --no-cpu > /dev/null 2>&1
+cd $R
 timeout 600 python tools/bench_trust.py > $O/${TAG}_bench_trust.json 2>/dev/null
 ls $O | head -40
