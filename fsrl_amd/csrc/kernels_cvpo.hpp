@@ -172,22 +172,115 @@ struct CvpoEstepArgs {
     int B, K, n_q, iters;
     float kl, thres, lr, dual_max, beta1, beta2, adam_eps;
 };
+// Adam step of the two E-step duals from the batch means (shared by both work distributions below)
+__device__ __forceinline__ void cvpo_estep_adam(const CvpoEstepArgs& a, const int it, const float eta, const float lam,
+                                                const float m_lse, const float m_pc, const float m_pq, float* duals) {
+    CvpoScalars sc = *a.sc;
+    const float loss = eta * a.kl + lam * a.thres + eta * m_lse;
+    if (it == 0) sc.estep_loss = loss;
+    const float g[2] = {a.kl + m_lse - m_pc / eta, a.thres - m_pq};
+    sc.et += 1;
+    const double bc1 = 1.0 - pow((double)a.beta1, (double)sc.et), bc2 = 1.0 - pow((double)a.beta2, (double)sc.et);
+    const float step_size = (float)((double)a.lr / bc1);
+    float nd[2] = {eta, lam};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        sc.em[j] = sc.em[j] + (float)(1.0 - (double)a.beta1) * (g[j] - sc.em[j]);
+        sc.ev[j] = sc.ev[j] * a.beta2;
+        sc.ev[j] = sc.ev[j] + ((float)(1.0 - (double)a.beta2) * g[j]) * g[j];
+        const float denom = sqrtf(sc.ev[j]) / (float)sqrt(bc2) + a.adam_eps;
+        nd[j] = nd[j] + (-step_size * sc.em[j]) / denom;
+    }
+    if (it == a.iters - 1) {                          // estep_dual.data.clamp_(eps, max) after the loop
+        nd[0] = fminf(fmaxf(nd[0], CVPO_EPS10), a.dual_max);
+        nd[1] = fminf(fmaxf(nd[1], CVPO_EPS10), a.dual_max);
+    }
+    sc.eta = nd[0]; sc.lam = nd[1];
+    *a.sc = sc;
+    duals[0] = nd[0]; duals[1] = nd[1];
+}
+
+// sum / max over the KP adjacent lanes that hold one state's particles (KP a power of two <= 64)
+__device__ __forceinline__ float row_sum(float v, const int KP) {
+    for (int w = 1; w < KP; w <<= 1) v += __shfl_xor(v, w, 64);
+    return v;
+}
+__device__ __forceinline__ float row_max(float v, const int KP) {
+    for (int w = 1; w < KP; w <<= 1) v = fmaxf(v, __shfl_xor(v, w, 64));
+    return v;
+}
+
 __global__ __launch_bounds__(1024) void cvpo_estep_kernel(const CvpoEstepArgs a) {
     __shared__ double red[3][1024];
     __shared__ float duals[2];
     const int tid = threadIdx.x;
     const size_t KB = (size_t)a.K * a.B;
+    const float logK = logf((float)a.K);
+    if (tid == 0) { duals[0] = a.sc->eta; duals[1] = a.sc->lam; }
+    auto q_of = [&](const size_t rk, float& v0, float& v1) {
+        if (a.n_q == 2) { v0 = a.QK[rk]; v1 = a.QK[KB + rk]; }
+        else { v0 = fminf(a.QK[rk], a.QK[KB + rk]); v1 = fminf(a.QK[2 * KB + rk], a.QK[3 * KB + rk]); }
+    };
+    auto block_sums = [&](const double s0, const double s1, const double s2) {
+        red[0][tid] = s0; red[1][tid] = s1; red[2][tid] = s2;
+        __syncthreads();
+        for (int w = 512; w > 0; w >>= 1) {           // fixed tree: order independent of scheduling
+            if (tid < w) { red[0][tid] += red[0][tid + w]; red[1][tid] += red[1][tid + w]; red[2][tid] += red[2][tid + w]; }
+            __syncthreads();
+        }
+    };
+    if ((a.K & (a.K - 1)) == 0 && a.K <= 64) {
+        // ---- one thread per (state b, particle k): element e = b*K + k, a state's particles in K adjacent lanes
+        const int K = a.K, n = (int)KB;
+        for (int e = tid; e < n; e += 1024) {
+            const int b = e / K, k = e - b * K;
+            float v0, v1;
+            q_of((size_t)k * a.B + b, v0, v1);
+            a.q0[e] = v0; a.q1[e] = v1;
+        }
+        __syncthreads();
+        for (int it = 0; it < a.iters; ++it) {
+            const float eta = duals[0], lam = duals[1];
+            double s_lse = 0.0, s_pc = 0.0, s_pq = 0.0;
+            for (int e0 = 0; e0 < n; e0 += 1024) {    // n is a multiple of K and 1024 of K: rows never straddle
+                const int e = e0 + tid;
+                const bool on = e < n;
+                const float q1v = on ? a.q1[e] : 0.0f;
+                const float cq = on ? a.q0[e] - lam * q1v : -INFINITY;
+                if (on) a.q0[e] = cq;                 // combined_q aliases q_values[0]
+                const float z = cq / eta;
+                const float mx = row_max(z, K);
+                const float ex = on ? expf(z - mx) : 0.0f;
+                const float se = row_sum(ex, K);
+                const float p = ex / se;
+                const float pc = row_sum(on ? p * cq : 0.0f, K), pq = row_sum(p * q1v, K);
+                if (on && (e & (K - 1)) == 0) { s_lse += (double)((mx + logf(se)) - logK); s_pc += (double)pc; s_pq += (double)pq; }
+            }
+            block_sums(s_lse, s_pc, s_pq);
+            if (tid == 0)
+                cvpo_estep_adam(a, it, eta, lam, (float)(red[0][0] / a.B), (float)(red[1][0] / a.B), (float)(red[2][0] / a.B), duals);
+            __syncthreads();
+        }
+        const float eta = duals[0], lam = duals[1];
+        for (int e0 = 0; e0 < n; e0 += 1024) {
+            const int e = e0 + tid;
+            const bool on = e < n;
+            const float z = on ? (a.q0[e] - lam * a.q1[e]) / eta : -INFINITY;
+            const float mx = row_max(z, K);
+            const float ex = on ? expf(z - mx) : 0.0f;
+            const float se = row_sum(ex, K);
+            if (on) { const int b = e / K, k = e - b * K; a.W[(size_t)k * a.B + b] = ex / se; }
+        }
+        return;
+    }
+    // ---- any K: one thread per state, particles in a sequential loop
     for (int b = tid; b < a.B; b += 1024)
         for (int k = 0; k < a.K; ++k) {
-            const size_t rk = (size_t)k * a.B + b;
             float v0, v1;
-            if (a.n_q == 2) { v0 = a.QK[rk]; v1 = a.QK[KB + rk]; }
-            else { v0 = fminf(a.QK[rk], a.QK[KB + rk]); v1 = fminf(a.QK[2 * KB + rk], a.QK[3 * KB + rk]); }
+            q_of((size_t)k * a.B + b, v0, v1);
             a.q0[(size_t)b * a.K + k] = v0; a.q1[(size_t)b * a.K + k] = v1;
         }
-    if (tid == 0) { duals[0] = a.sc->eta; duals[1] = a.sc->lam; }
     __syncthreads();
-    const float logK = logf((float)a.K);
     for (int it = 0; it < a.iters; ++it) {
         const float eta = duals[0], lam = duals[1];
         double s_lse = 0.0, s_pc = 0.0, s_pq = 0.0;
@@ -208,38 +301,9 @@ __global__ __launch_bounds__(1024) void cvpo_estep_kernel(const CvpoEstepArgs a)
             }
             s_lse += (double)((mx + logf(se)) - logK); s_pc += (double)pc; s_pq += (double)pq;
         }
-        red[0][tid] = s_lse; red[1][tid] = s_pc; red[2][tid] = s_pq;
-        __syncthreads();
-        for (int w = 512; w > 0; w >>= 1) {                   // fixed tree: order independent of scheduling
-            if (tid < w) { red[0][tid] += red[0][tid + w]; red[1][tid] += red[1][tid + w]; red[2][tid] += red[2][tid + w]; }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            CvpoScalars sc = *a.sc;
-            const float m_lse = (float)(red[0][0] / a.B), m_pc = (float)(red[1][0] / a.B), m_pq = (float)(red[2][0] / a.B);
-            const float loss = eta * a.kl + lam * a.thres + eta * m_lse;
-            if (it == 0) sc.estep_loss = loss;
-            const float g[2] = {a.kl + m_lse - m_pc / eta, a.thres - m_pq};
-            sc.et += 1;
-            const double bc1 = 1.0 - pow((double)a.beta1, (double)sc.et), bc2 = 1.0 - pow((double)a.beta2, (double)sc.et);
-            const float step_size = (float)((double)a.lr / bc1);
-            float nd[2] = {eta, lam};
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                sc.em[j] = sc.em[j] + (float)(1.0 - (double)a.beta1) * (g[j] - sc.em[j]);
-                sc.ev[j] = sc.ev[j] * a.beta2;
-                sc.ev[j] = sc.ev[j] + ((float)(1.0 - (double)a.beta2) * g[j]) * g[j];
-                const float denom = sqrtf(sc.ev[j]) / (float)sqrt(bc2) + a.adam_eps;
-                nd[j] = nd[j] + (-step_size * sc.em[j]) / denom;
-            }
-            if (it == a.iters - 1) {                          // estep_dual.data.clamp_(eps, max) after the loop
-                nd[0] = fminf(fmaxf(nd[0], CVPO_EPS10), a.dual_max);
-                nd[1] = fminf(fmaxf(nd[1], CVPO_EPS10), a.dual_max);
-            }
-            sc.eta = nd[0]; sc.lam = nd[1];
-            *a.sc = sc;
-            duals[0] = nd[0]; duals[1] = nd[1];
-        }
+        block_sums(s_lse, s_pc, s_pq);
+        if (tid == 0)
+            cvpo_estep_adam(a, it, eta, lam, (float)(red[0][0] / a.B), (float)(red[1][0] / a.B), (float)(red[2][0] / a.B), duals);
         __syncthreads();
     }
     // optimal non-parametric distribution: softmax over the K particles of (q0 - lambda * q1) / eta
