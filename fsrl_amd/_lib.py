@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfsrl_hip.so")
+LIB_PATH = os.environ.get("FSRL_HIP_LIB") or os.path.join(_HERE, "libfsrl_hip.so")   # override: A/B runs of two builds
 
 FSRL_OK, FSRL_EINVAL, FSRL_ENOMEM, FSRL_EHIP, FSRL_ESTATE = 0, -22, -12, -5, -1
 PPO_NSTATS = 11

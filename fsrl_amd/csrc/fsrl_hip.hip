@@ -2075,13 +2075,15 @@ static int sac_wgrad(fsrl_ctx* c, SacState* s, const ModelDesc& md, int ny, cons
 }
 
 // Adam with the gradient read as the z-ordered sum of `nparts` split-K partials
+// tgt != NULL: the Polyak update of the target copy rides on the same pass (target <- tau * new + (1 - tau) * target)
 static void adam_launch(fsrl_ctx* c, const ModelDesc& md, float* P, float* M, float* V, const float* G, int n, float lr,
-                        int64_t t, int nparts, int stride) {
+                        int64_t t, int nparts, int stride, float* tgt = nullptr, float tau = 0.0f) {
     const double b1 = c->cfg.beta1, b2 = c->cfg.beta2;
     const double bc1 = 1.0 - std::pow(b1, (double)t), bc2 = 1.0 - std::pow(b2, (double)t);
     hipLaunchKernelGGL(adam_range_kernel, dim3((n + 255) / 256), dim3(256), 0, c->compute, P, M, V, G, 0, n, 0.0f,
                        (float)(1.0 - b1), c->cfg.beta2, (float)(1.0 - b2), (float)((double)lr / bc1),
-                       (float)std::sqrt(bc2), c->cfg.adam_eps, nparts, stride, md);
+                       (float)std::sqrt(bc2), c->cfg.adam_eps, nparts, stride, md, (const float*)nullptr, 0, 0.0f,
+                       (float*)nullptr, tgt, tau, (float)(1.0 - (double)tau));
 }
 
 extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, const float* eps_target,
@@ -2189,7 +2191,9 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     rc = sac_wgrad(c, s, s->mdq, s->n_q, s->XQ, s->nq_dev, B, &nsplit);
     if (rc) return rc;
     s->t_critic += 1;
-    adam_launch(c, s->mdq, s->PQ, s->MQ, s->VQ, c->wg_parts, s->nq_dev, s->cfg.critic_lr, s->t_critic, nsplit, s->nq_dev);
+    // sync_weight (sac_lag.py:132-134) is folded into this pass: the critics do not change again within the update
+    adam_launch(c, s->mdq, s->PQ, s->MQ, s->VQ, c->wg_parts, s->nq_dev, s->cfg.critic_lr, s->t_critic, nsplit, s->nq_dev,
+                s->PQT, s->cfg.tau);
     // ---- actor step: a ~ pi(s), Q(s, a) with the UPDATED critics, dL/da, actor backward
     rc = actor_launch(s->OBS, s->eps_p, s->XP, s->LP, SAC_A_FWD, s->PA);
     if (rc) return rc;
@@ -2200,8 +2204,10 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     rc = sac_wgrad(c, s, s->mda, 1, s->OBS, s->na_dev, B, &nsplit);
     if (rc) return rc;
     s->t_actor += 1;
-    adam_launch(c, s->mda, s->PA, s->MA, s->VA, c->wg_parts, s->na_dev, s->cfg.actor_lr, s->t_actor, nsplit, s->na_dev);
-    // ---- alpha step + logged stats, then Polyak
+    // DDPG-Lag: actor_old <- tau * actor + (1 - tau) * actor_old in the same pass (ddpg_lag.py:120-123)
+    adam_launch(c, s->mda, s->PA, s->MA, s->VA, c->wg_parts, s->na_dev, s->cfg.actor_lr, s->t_actor, nsplit, s->na_dev,
+                s->ddpg ? s->PAT : nullptr, s->cfg.tau);
+    // ---- alpha step + logged stats
     SacFinalArgs fa{};
     float* stats_row = s->d_stats + (size_t)(s->n_updates % SAC_RING) * s->nstats;
     fa.statp_q = s->stq; fa.statp_pi = s->stpi; fa.sc = s->sc; fa.stats = stats_row;
@@ -2211,14 +2217,6 @@ extern "C" int fsrl_sac_update(fsrl_ctx* c, int32_t B, const int64_t* indices, c
     fa.n_q = s->n_q;
     hipLaunchKernelGGL(sac_finalize_kernel, dim3(1), dim3(64), 0, st, fa);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(polyak_kernel, dim3(256), dim3(256), 0, st, s->PQT, s->PQ, s->nq_dev, s->cfg.tau,
-                       (float)(1.0 - (double)s->cfg.tau), s->mdq);
-    HIPCHK(hipGetLastError());
-    if (s->ddpg) {                              // actor_old <- tau * actor + (1 - tau) * actor_old  (ddpg_lag.py:120-123)
-        hipLaunchKernelGGL(polyak_kernel, dim3(128), dim3(256), 0, st, s->PAT, s->PA, s->na_dev, s->cfg.tau,
-                           (float)(1.0 - (double)s->cfg.tau), s->mda);
-        HIPCHK(hipGetLastError());
-    }
     s->n_updates += 1;
     if (stats_out) {                           // synchronous: this update's row (and mark it drained)
         HIPCHK(hipMemcpyAsync(stats_out, stats_row, FSRL_SAC_NSTATS_K * 4, hipMemcpyDeviceToHost, st));
@@ -2373,10 +2371,8 @@ extern "C" int fsrl_cvpo_update(fsrl_ctx* c, int32_t B, const int64_t* indices, 
         sa.eps_t = s->eps_t; sa.eps_p = s->eps_p; sa.env_num = c->cfg.env_num; sa.sub_size = (int)c->sub_size; sa.B = B;
         sa.n_step = ns; sa.Da = Da; sa.stored = (unsigned long long)stored; sa.key = s->key;
         sa.counter = (unsigned long long)s->n_updates;
-        hipLaunchKernelGGL(sac_sample_kernel, dim3((B + 255) / 256), dim3(256), 0, st, sa);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((nk / 4 + 256) / 256)), dim3(256), 0, st, s->eps_k, nk,
-                           (unsigned long long)s->key, (unsigned long long)s->n_updates, 0x40000000u);
+        sa.eps_k = s->eps_k; sa.K = K;
+        hipLaunchKernelGGL(sac_sample_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, sa);
         HIPCHK(hipGetLastError());
     }
     s->last_B = B;
@@ -2417,7 +2413,8 @@ extern "C" int fsrl_cvpo_update(fsrl_ctx* c, int32_t B, const int64_t* indices, 
     rc = sac_wgrad(c, s, s->mdq, s->n_q, s->XQ, s->nq_dev, B, &nsplit);
     if (rc) return rc;
     s->t_critic += 1;
-    adam_launch(c, s->mdq, s->PQ, s->MQ, s->VQ, c->wg_parts, s->nq_dev, cc.critic_lr, s->t_critic, nsplit, s->nq_dev);
+    // sync_weight (cvpo.py:202-204) rides on the same pass: the critics do not change again within the update
+    adam_launch(c, s->mdq, s->PQ, s->MQ, s->VQ, c->wg_parts, s->nq_dev, cc.critic_lr, s->t_critic, nsplit, s->nq_dev, s->PQT, cc.tau);
     // ---- E-step: K particles of actor_old through the UPDATED critics                (cvpo.py:319-371)
     rc = actor_launch(CVPO_A_PARTICLES, s->PAT, s->OBS, s->eps_k, s->XK);
     if (rc) return rc;
@@ -2453,9 +2450,6 @@ extern "C" int fsrl_cvpo_update(fsrl_ctx* c, int32_t B, const int64_t* indices, 
     fa.statp_q = s->stq; fa.Y = s->Y; fa.sc = s->csc; fa.stats = stats_row;
     fa.n_tiles_q = s->q_rows4 ? 4 * s->n_tiles : s->n_tiles; fa.n_q = s->n_q; fa.B = B; fa.thres = (float)cc.qc_thres;
     hipLaunchKernelGGL(cvpo_finalize_kernel, dim3(1), dim3(64), 0, st, fa);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(polyak_kernel, dim3(256), dim3(256), 0, st, s->PQT, s->PQ, s->nq_dev, cc.tau,
-                       (float)(1.0 - (double)cc.tau), s->mdq);
     HIPCHK(hipGetLastError());
     s->n_updates += 1;
     if (stats_out) {

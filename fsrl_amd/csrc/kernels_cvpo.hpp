@@ -389,17 +389,3 @@ __global__ __launch_bounds__(64) void cvpo_finalize_kernel(const CvpoFinalArgs a
     for (int k = 0; k < 8; ++k) o[3 + k] = sc.mstats[k];
     o[11] = lq0; o[12] = m[4]; o[13] = lq1; o[14] = m[5]; o[15] = a.thres; o[16] = lq0 + lq1;
 }
-
-// N(0,1) block of the library-RNG mode: element pair p of stream `draw` (Philox counter (p, draw, update))
-__global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, size_t n, unsigned long long key,
-                                                            unsigned long long counter, uint32_t draw) {
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // four normals per thread
-    if (4 * p >= n) return;
-    uint32_t c[4] = {(uint32_t)p, draw + 0x1000u * (uint32_t)(p >> 32), (uint32_t)counter, (uint32_t)(counter >> 32)};
-    philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
-    float v[4];
-    box_muller(c[0], c[1], v[0], v[1]);
-    box_muller(c[2], c[3], v[2], v[3]);
-    for (int j = 0; j < 4; ++j)
-        if (4 * p + j < n) out[4 * p + j] = v[j];
-}

@@ -1040,7 +1040,9 @@ __global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ P, 
                                                         float bc2_sqrt, float eps, int nparts, int stride,
                                                         const ModelDesc md, const float* __restrict__ gsq_part = nullptr,
                                                         int n_gsq = 0, float max_norm = 0.0f,
-                                                        float* __restrict__ psq_part = nullptr) {
+                                                        float* __restrict__ psq_part = nullptr,
+                                                        float* __restrict__ tgt = nullptr, float tau = 0.0f,
+                                                        float one_minus_tau = 0.0f) {
     __shared__ double shd[4];
     __shared__ float coef_s, shf[4];
     const int i = begin + blockIdx.x * 256 + threadIdx.x;
@@ -1072,6 +1074,11 @@ __global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ P, 
         P[i] = pn;
         const int mi = w2f_mirror_of(md, i);
         if (mi >= 0) P[mi] = pn;
+        if (tgt) {                           // target <- tau * param + (1 - tau) * target (BasePolicy.soft_update) in the same pass:
+            const float tv = tau * pn + one_minus_tau * tgt[i];   // the parameters do not change again before sync_weight
+            tgt[i] = tv;
+            if (mi >= 0) tgt[mi] = tv;
+        }
     }
     if (psq_part) {                          // per-block sum of squares of the PRE-update parameters (L2 term of the logged loss)
         psq = wave_sum(psq);

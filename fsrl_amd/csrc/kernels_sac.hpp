@@ -45,6 +45,7 @@ struct SacSampleArgs {
     int* idx; int* chain; uint8_t* endbits; float* eps_t; float* eps_p;
     int env_num, sub_size, B, n_step, Da;
     unsigned long long stored, key, counter;
+    float* eps_k; int K;      // CVPO: the K particles' N(0,1) block [K][B][Da] (NULL otherwise)
 };
 __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
@@ -64,9 +65,24 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
     n0 = rad * cs; n1 = rad * sn;
 }
 __global__ __launch_bounds__(256) void sac_sample_kernel(const SacSampleArgs a) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.B) return;
+    // SAC / DDPG: one thread per sampled row.  CVPO (eps_k != NULL): B * K threads, thread (b, kp) also draws particle
+    // kp's noise for row b; the row work is done by the kp == 0 threads.
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = a.eps_k ? t % a.B : t, kp = a.eps_k ? t / a.B : 0;
+    if (b >= a.B || kp >= max(a.K, 1)) return;
     const uint32_t k0 = (uint32_t)a.key, k1 = (uint32_t)(a.key >> 32);
+    if (a.eps_k) {
+        for (int d0 = 0; d0 < a.Da; d0 += 4) {             // draws 0x100.. : four normals per Philox block
+            uint32_t r[4] = {(uint32_t)b, 0x100u + (uint32_t)(kp * 4 + (d0 >> 2)), (uint32_t)a.counter, (uint32_t)(a.counter >> 32)};
+            philox4x32_10(r, k0, k1);
+            float v[4];
+            box_muller(r[0], r[1], v[0], v[1]);
+            box_muller(r[2], r[3], v[2], v[3]);
+            float* o = a.eps_k + ((size_t)kp * a.B + b) * a.Da + d0;
+            for (int j = 0; j < 4 && d0 + j < a.Da; ++j) o[j] = v[j];
+        }
+        if (kp != 0) return;
+    }
     uint32_t c[4] = {(uint32_t)b, 0u, (uint32_t)a.counter, (uint32_t)(a.counter >> 32)};
     philox4x32_10(c, k0, k1);
     unsigned long long k = ((unsigned long long)c[0] * a.stored) >> 32;    // uniform over the stored rows
@@ -340,16 +356,5 @@ __global__ __launch_bounds__(64) void sac_finalize_kernel(const SacFinalArgs a) 
         float* o = a.stats;
         o[0] = a.rescale; o[1] = a.lam; o[2] = actor_safety; o[3] = alpha_loss; o[4] = alpha_value;
         o[5] = actor_rew; o[6] = actor_total; o[7] = q0; o[8] = q1; o[9] = q0 + q1;
-    }
-}
-
-// target <- tau * source + (1 - tau) * target      (BasePolicy.soft_update, base_policy.py:220-224)
-__global__ void polyak_kernel(float* __restrict__ tgt, const float* __restrict__ src, int n, float tau,
-                              float one_minus_tau, const ModelDesc md) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float v = tau * src[i] + one_minus_tau * tgt[i];
-        tgt[i] = v;
-        const int mi = w2f_mirror_of(md, i);
-        if (mi >= 0) tgt[mi] = v;
     }
 }
