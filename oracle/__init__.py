@@ -8,7 +8,7 @@ Pinning status (see DESIGN.md "Oracle"):
   * pinned against golden vectors generated from the UNMODIFIED reference code
     (`tests/golden/*.npz`, generator `tests/golden/gen_golden.py`) for: gae_return,
     nstep_return, LagrangianOptimizer, PPOLagrangian.update, CPO, TRPOLagrangian,
-    SACLagrangian steps;
+    SACLagrangian, DDPGLagrangian, FOCOPS and CVPO updates (generators tests/golden/gen_golden_*.py);
   * the tianshou~=0.5.0 pieces (Batch.split order, VectorReplayBuffer sample(0) order,
     MLP/ActorProb/Critic topology) are restated from that release's published behaviour;
     tianshou's source is not available in the build image => "parity unpinned" vs tianshou
