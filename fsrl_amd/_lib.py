@@ -99,6 +99,9 @@ SIGNATURES = {
     "fsrl_sac_params_get": (C.c_int, [_ctx, C.c_int32, _f, C.c_int64, _f]),
     "fsrl_sac_update": (C.c_int, [_ctx, C.c_int32, _i64, _f, _f, C.c_uint64, _d, C.c_double, _f]),
     "fsrl_actor_sample": (C.c_int, [_ctx, _f, C.c_int32, C.c_int32, C.c_uint64, _f]),
+    "fsrl_collect_step": (C.c_int, [_ctx, _i32, C.c_int32, _f, _f, _d, _d, _u8, _u8, _f, _i64, _d, _i32, _i64,
+                                    _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, _f, _f]),
+    "fsrl_store_sizes": (C.c_int, [_ctx, _i64, C.c_int32]),
     "fsrl_sac_stats_drain": (C.c_int64, [_ctx, _f, C.c_int64]),
     "fsrl_sac_last_sample": (C.c_int, [_ctx, _i64, _f, _f, C.c_int32]),
     "fsrl_sac_actor_forward": (C.c_int, [_ctx, _f, C.c_int32, _f, _f]),

@@ -132,6 +132,11 @@ struct fsrl_ctx {
     float* mu_old = nullptr;        // [maxsize][Da] actor means at process time (FOCOPS)
     float* sigma_old = nullptr;     // [FSRL_MAX_ACT] sigma_param at process time (FOCOPS)
     void* h_actor = nullptr; size_t h_actor_bytes = 0;   // pinned staging of fsrl_actor_forward
+    int actor_k = 0; size_t actor_ob = 0, actor_mb = 0;  // geometry of the actor evaluation in flight
+    unsigned* h_done = nullptr; int done_cap = 0;        // pinned per-block completion words of that evaluation
+    unsigned actor_seq = 0; int actor_blocks = 0;
+    bool no_spin = getenv("FSRL_NO_SPIN") != nullptr;   // A/B switch: wait with hipStreamSynchronize instead
+    std::vector<float> act_mu, act_sg;                   // mean / std of the last actor evaluation (host)
     std::vector<int> perm_tmp;      // this pass's permutation before it goes to the pinned buffer
     hipEvent_t perm_copied = nullptr; bool perm_in_flight = false;
     uint64_t store_version = 1;     // bumped by every push / reset (device copies of the bookkeeping)
@@ -255,6 +260,7 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
     sac_free(c);
     foc_free(c);
     if (c->h_actor) (void)hipHostFree(c->h_actor);
+    if (c->h_done) (void)hipHostFree(c->h_done);
     if (c->mu_old) (void)hipFree(c->mu_old);
     if (c->sigma_old) (void)hipFree(c->sigma_old);
     void* dptrs[] = {c->P, c->M, c->V, c->G, c->ctrl, c->st.obs, c->st.obs_next, c->st.act, c->st.rew,
@@ -571,14 +577,23 @@ static int launch_infer(fsrl_ctx* c, const InferArgs& ia, int jobs_y, hipStream_
 }
 
 // ------------------------------------------------------------------------------ actor forward
-extern "C" int fsrl_actor_forward(fsrl_ctx* c, const float* obs, int32_t k, float* mu_out,
-                                  float* sigma_out) {
-    CHECK_ARG(c && obs && mu_out, "null argument");
-    CHECK_ARG(k >= 0, "negative row count");
-    HIPCHK(hipSetDevice(c->device));
+// Actor evaluation for the collector, in two halves so that host work can overlap the round trip:
+//   actor_eval_launch: copy the k observations into pinned host memory and launch the actor on them -- the kernel
+//     reads the observations from, and writes its head outputs to, pinned host memory (zero-copy: a few hundred
+//     bytes over PCIe), nothing else is staged;
+//   actor_eval_finish: wait, then turn the head outputs into (mean, std) of the policy's Gaussian.
+// PPO-family contexts: mu = max_action * tanh(head) (mlp_infer_kernel applies it), sigma = exp(sigma_param).
+// Replay contexts (SAC / DDPG / CVPO): raw head outputs [mu | log sigma], see actor_eval_finish.
+struct SacState;
+static bool ctx_is_replay(const fsrl_ctx* c) { return c->cfg.algo == FSRL_ALGO_SAC_LAG; }
+static int sac_actor_launch(fsrl_ctx* c, const float* h_obs, float* h_raw, int k);                 // defined with the SAC code
+static void sac_actor_finish(fsrl_ctx* c, const float* h_raw, int k, float* mu_out, float* sigma_out);
+static bool sac_squashes(fsrl_ctx* c);
+
+static int actor_eval_launch(fsrl_ctx* c, const float* obs, int32_t k, bool want_sigma) {
     const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim;
-    // pinned staging [obs | mu | sigma_param]: pageable pointers would make every copy a staged, synchronous one
-    const size_t ob = (size_t)k * Do * 4, mb = (size_t)k * Da * 4;
+    // pinned staging [obs | head outputs (2*Da per row) | sigma_param]
+    const size_t ob = (size_t)k * Do * 4, mb = (size_t)k * 2 * Da * 4;
     const size_t need = ob + mb + FSRL_MAX_ACT * 4;
     if (c->h_actor_bytes < need) {
         HIPCHK(hipStreamSynchronize(c->compute));
@@ -590,26 +605,68 @@ extern "C" int fsrl_actor_forward(fsrl_ctx* c, const float* obs, int32_t k, floa
     float* h_obs = (float*)c->h_actor;
     float* h_mu = (float*)((char*)c->h_actor + ob);
     float* h_sp = (float*)((char*)c->h_actor + ob + mb);
+    c->actor_k = k; c->actor_ob = ob; c->actor_mb = mb;
+    // completion words: one per 16-row tile, written by the kernel after its outputs; actor_eval_finish spins on them
+    // (a stream synchronisation costs several microseconds more than the kernel itself at these sizes)
+    c->actor_blocks = (k + 15) / 16;
+    if (c->actor_blocks > c->done_cap) {
+        if (c->h_done) HIPCHK(hipHostFree(c->h_done));
+        c->h_done = nullptr;
+        c->done_cap = std::max(2 * c->actor_blocks, 64);
+        HIPCHK(hipHostMalloc(&c->h_done, (size_t)c->done_cap * 4));
+        memset(c->h_done, 0, (size_t)c->done_cap * 4);
+    }
+    c->actor_seq += 1;
+    if (c->actor_seq == 0) c->actor_seq = 1;
+    if (k > 0) memcpy(h_obs, obs, ob);
+    if (ctx_is_replay(c)) return k > 0 ? sac_actor_launch(c, h_obs, h_mu, k) : 0;
     if (k > 0) {
-        // zero-copy: the kernel reads the observations from, and writes mu / sigma_param to, pinned host
-        // memory (a few hundred bytes over PCIe) -- one launch and one synchronisation per vector step
-        memcpy(h_obs, obs, ob);
         InferArgs ia{};
         ia.obs = h_obs; ia.obs_next = h_obs; ia.act = nullptr; ia.flags = nullptr; ia.values = nullptr;
         ia.vnext = nullptr; ia.logp_old = nullptr; ia.mu_out = h_mu; ia.N = k; ia.C = 0;
-        ia.max_action = c->cfg.max_action; ia.sigma_param_out = sigma_out ? h_sp : nullptr;
-        int rc = launch_infer(c, ia, 1, c->compute);   // job 0 == 2*C == actor
-        if (rc) return rc;
-    } else if (sigma_out) {
-        HIPCHK(hipMemcpyAsync(h_sp, c->P + c->md.net[0].sigma, (size_t)Da * 4, hipMemcpyDeviceToHost, c->compute));
+        ia.max_action = c->cfg.max_action; ia.sigma_param_out = want_sigma ? h_sp : nullptr;
+        ia.done = c->h_done; ia.seq = c->actor_seq;
+        return launch_infer(c, ia, 1, c->compute);   // job 0 == 2*C == actor
     }
-    HIPCHK(hipStreamSynchronize(c->compute));
-    if (k > 0) memcpy(mu_out, h_mu, mb);
+    if (want_sigma)
+        HIPCHK(hipMemcpyAsync(h_sp, c->P + c->md.net[0].sigma, (size_t)Da * 4, hipMemcpyDeviceToHost, c->compute));
+    return 0;
+}
+
+static int actor_eval_finish(fsrl_ctx* c, float* mu_out, float* sigma_out) {
+    const int Da = c->cfg.act_dim, k = c->actor_k;
+    bool landed = false;
+    if (k > 0 && !c->no_spin) {                        // spin on the kernel's completion words (bounded), else synchronise
+        landed = true;
+        for (int b = 0; b < c->actor_blocks && landed; ++b) {
+            int spins = 0;
+            while (__atomic_load_n(&c->h_done[b], __ATOMIC_ACQUIRE) != c->actor_seq) {
+                if (++spins > 2000000) { landed = false; break; }
+                __builtin_ia32_pause();
+            }
+        }
+    }
+    if (!landed) HIPCHK(hipStreamSynchronize(c->compute));
+    const float* h_mu = (const float*)((char*)c->h_actor + c->actor_ob);
+    const float* h_sp = (const float*)((char*)c->h_actor + c->actor_ob + c->actor_mb);
+    if (ctx_is_replay(c)) { if (k > 0) sac_actor_finish(c, h_mu, k, mu_out, sigma_out); return 0; }
+    if (k > 0) memcpy(mu_out, h_mu, (size_t)k * Da * 4);
     if (sigma_out) {
         for (int r = 0; r < k; ++r)
             for (int d = 0; d < Da; ++d) sigma_out[(size_t)r * Da + d] = expf(h_sp[d]);
     }
     return 0;
+}
+
+extern "C" int fsrl_actor_forward(fsrl_ctx* c, const float* obs, int32_t k, float* mu_out,
+                                  float* sigma_out) {
+    CHECK_ARG(c && obs && mu_out, "null argument");
+    CHECK_ARG(k >= 0, "negative row count");
+    CHECK_ARG(!ctx_is_replay(c), "replay contexts: fsrl_sac_actor_forward");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = actor_eval_launch(c, obs, k, sigma_out != nullptr);
+    if (rc) return rc;
+    return actor_eval_finish(c, mu_out, sigma_out);
 }
 
 static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
@@ -625,30 +682,86 @@ static uint64_t xoshiro_next(uint64_t* s) {
 //   SAC contexts:              a = tanh(mu + sigma(s) * eps)             (sac_lag.py:155-183)
 // deterministic != 0 returns the mean (tanh(mean) for SAC).  Noise is NOT torch's stream: callers that
 // need the reference's random numbers keep the host mirror of the actor (fsrl_amd/policy).
-static int sac_actor_mu_sigma(fsrl_ctx* c, const float* obs, int32_t k, float* mu_out, float* sigma_out);
-static bool sac_squashes(fsrl_ctx* c);
-extern "C" int fsrl_actor_sample(fsrl_ctx* c, const float* obs, int32_t k, int32_t deterministic, uint64_t seed,
-                                 float* act_out) {
-    CHECK_ARG(c && obs && act_out, "null argument");
-    CHECK_ARG(k >= 0, "negative row count");
-    if (k == 0) return 0;
-    const int Da = c->cfg.act_dim;
-    if (seed) { c->rng[2] ^= seed; c->rng[3] += seed * 0x9E3779B97F4A7C15ull; }
-    std::vector<float> mu((size_t)k * Da), sg((size_t)k * Da);
-    const bool sac = c->cfg.algo == FSRL_ALGO_SAC_LAG;
-    int rc = sac ? sac_actor_mu_sigma(c, obs, k, mu.data(), sg.data()) : fsrl_actor_forward(c, obs, k, mu.data(), sg.data());
+// second half of fsrl_actor_sample / fsrl_collect_step: wait for the actor, then a = mean (+ std * N(0,1))
+static int actor_sample_finish(fsrl_ctx* c, int32_t deterministic, float* act_out) {
+    const int Da = c->cfg.act_dim, k = c->actor_k;
+    c->act_mu.resize((size_t)k * Da); c->act_sg.resize((size_t)k * Da);
+    int rc = actor_eval_finish(c, c->act_mu.data(), c->act_sg.data());
     if (rc) return rc;
-    for (size_t i = 0; i < mu.size(); ++i) {
-        float u = mu[i];
+    const bool squash = ctx_is_replay(c) && sac_squashes(c);
+    for (size_t i = 0; i < c->act_mu.size(); ++i) {
+        float u = c->act_mu[i];
         if (!deterministic) {
             // Box-Muller on two 53-bit uniforms of the context's stream
             double u1 = (double)(xoshiro_next(c->rng) >> 11) * (1.0 / 9007199254740992.0);
             const double u2 = (double)(xoshiro_next(c->rng) >> 11) * (1.0 / 9007199254740992.0);
             if (u1 < 1e-300) u1 = 1e-300;
-            u += sg[i] * (float)(std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2));
+            u += c->act_sg[i] * (float)(std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2));
         }
-        act_out[i] = (sac && sac_squashes(c)) ? std::tanh(u) : u;     // DDPG-Lag: mu is already max_action * tanh
+        act_out[i] = squash ? std::tanh(u) : u;     // DDPG-Lag / CVPO: mu is already max_action * tanh
     }
+    return 0;
+}
+
+extern "C" int fsrl_actor_sample(fsrl_ctx* c, const float* obs, int32_t k, int32_t deterministic, uint64_t seed,
+                                 float* act_out) {
+    CHECK_ARG(c && obs && act_out, "null argument");
+    CHECK_ARG(k >= 0, "negative row count");
+    if (k == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    if (seed) { c->rng[2] ^= seed; c->rng[3] += seed * 0x9E3779B97F4A7C15ull; }
+    int rc = actor_eval_launch(c, obs, k, true);
+    if (rc) return rc;
+    return actor_sample_finish(c, deterministic, act_out);
+}
+
+// One vector step of FastCollector.collect with the actor on the device (fsrl/data/fast_collector.py:283-368) in ONE call:
+// launch the actor on the observations the next actions are for; while it runs store the transitions that just
+// finished (fsrl_store_push, bookkeeping included); wait; draw the noise; map the action to the env's range
+// (BasePolicy.map_action, base_policy.py:226-256).  Same random stream and the same results as fsrl_actor_sample +
+// fsrl_store_push called one after the other.
+extern "C" int fsrl_collect_step(fsrl_ctx* c, const int32_t* env_ids, int32_t k, const float* obs, const float* act,
+                                 const double* rew, const double* cost, const uint8_t* terminated,
+                                 const uint8_t* truncated, const float* obs_next, int64_t* ptr_out, double* ep_rew_out,
+                                 int32_t* ep_len_out, int64_t* ep_idx_out, const float* obs_act, int32_t k_act,
+                                 int32_t deterministic, int32_t bound_method, const float* act_low,
+                                 const float* act_high, float* act_out, float* env_act_out) {
+    CHECK_ARG(c, "null ctx");
+    CHECK_ARG(k >= 0 && k_act >= 0, "negative row count");
+    CHECK_ARG(k_act == 0 || (obs_act && act_out), "obs_act / act_out missing");
+    CHECK_ARG(bound_method >= 0 && bound_method <= 2, "bound_method: 0 none, 1 clip, 2 tanh");
+    CHECK_ARG((act_low == nullptr) == (act_high == nullptr), "act_low and act_high are given together");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = 0;
+    if (k_act > 0) {
+        rc = actor_eval_launch(c, obs_act, k_act, true);
+        if (rc) return rc;
+    }
+    if (k > 0) {
+        rc = fsrl_store_push(c, env_ids, k, obs, act, rew, cost, terminated, truncated, obs_next, ptr_out, ep_rew_out,
+                             ep_len_out, ep_idx_out);
+        if (rc) { if (k_act > 0) (void)hipStreamSynchronize(c->compute); return rc; }
+    }
+    if (k_act == 0) return 0;
+    rc = actor_sample_finish(c, deterministic, act_out);
+    if (rc) return rc;
+    if (env_act_out) {
+        const int Da = c->cfg.act_dim;
+        for (int r = 0; r < k_act; ++r)
+            for (int d = 0; d < Da; ++d) {
+                float a = act_out[(size_t)r * Da + d];
+                if (bound_method == 1) a = std::min(std::max(a, -1.0f), 1.0f);
+                else if (bound_method == 2) a = std::tanh(a);
+                if (act_low) a = act_low[d] + (act_high[d] - act_low[d]) * (a + 1.0f) / 2.0f;
+                env_act_out[(size_t)r * Da + d] = a;
+            }
+    }
+    return 0;
+}
+
+extern "C" int fsrl_store_sizes(const fsrl_ctx* c, int64_t* sizes_out, int32_t n) {
+    CHECK_ARG(c && sizes_out && n >= 0 && n <= c->cfg.env_num, "bad argument");
+    for (int e = 0; e < n; ++e) sizes_out[e] = c->env[(size_t)e].size;
     return 0;
 }
 
@@ -2498,51 +2611,48 @@ extern "C" int fsrl_sac_last_sample(fsrl_ctx* c, int64_t* indices, float* eps_ta
     return 0;
 }
 
-extern "C" int fsrl_sac_actor_forward(fsrl_ctx* c, const float* obs, int32_t k, float* mu_out, float* sigma_out) {
-    CHECK_ARG(c && obs && mu_out && sigma_out, "null argument");
+// replay-context halves of actor_eval_launch / actor_eval_finish: mlp_infer_kernel writes the raw head outputs
+// [mu | log sigma] (2*Da per row; DDPG-Lag: the mean head in the first Da) straight into pinned host memory
+static int sac_actor_launch(fsrl_ctx* c, const float* h_obs, float* h_raw, int k) {
     SacState* s = sac_of(c);
-    if (!s) return fail(FSRL_ESTATE, "fsrl_sac_init first");
-    if (k <= 0) return 0;
-    HIPCHK(hipSetDevice(c->device));
-    // run the actor tile kernel with eps = 0: the action columns then hold tanh(mu); mu / sigma are
-    // recovered on the host from a second tiny pass would cost more than the host MLP -- the
-    // collector-time actor therefore stays on the host mirror (fsrl_amd/policy); this entry point
-    // returns the device parameters' mu and sigma through mlp_infer_kernel's head outputs.
-    const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim;
-    const size_t ob = (size_t)k * Do * 4, ub = (size_t)k * 2 * Da * 4;
-    int rc = ensure_scratch(c, ob + ub + 512);
-    if (rc) return rc;
-    float* d_obs = (float*)c->scratch;
-    float* d_out = (float*)((char*)c->scratch + (ob + 255) / 256 * 256);
-    HIPCHK(hipMemcpyAsync(d_obs, obs, ob, hipMemcpyHostToDevice, c->compute));
+    if (!s) return fail(FSRL_ESTATE, "fsrl_sac_init / fsrl_cvpo_init first");
     InferArgs ia{};
-    ia.obs = d_obs; ia.obs_next = d_obs; ia.N = k; ia.C = 0; ia.max_action = 1.0f; ia.raw_out = d_out; ia.raw_cols = 2 * Da;
-    rc = dispatch_H(c->cfg.hidden, [&](auto hc) {
+    ia.obs = h_obs; ia.obs_next = h_obs; ia.N = k; ia.C = 0; ia.max_action = 1.0f; ia.raw_out = h_raw;
+    ia.raw_cols = 2 * c->cfg.act_dim; ia.done = c->h_done; ia.seq = c->actor_seq;
+    return dispatch_H(c->cfg.hidden, [&](auto hc) {
         constexpr int H = decltype(hc)::value;
         hipLaunchKernelGGL(mlp_infer_kernel<H>, dim3((k + 15) / 16, 1), dim3(4 * H), 0, c->compute, s->PA, s->mda, ia);
         HIPCHK(hipGetLastError());
         return 0;
     });
-    if (rc) return rc;
-    std::vector<float> raw((size_t)k * 2 * Da);
-    HIPCHK(hipMemcpyAsync(raw.data(), d_out, ub, hipMemcpyDeviceToHost, c->compute));
-    HIPCHK(hipStreamSynchronize(c->compute));
+}
+static void sac_actor_finish(fsrl_ctx* c, const float* raw, int k, float* mu_out, float* sigma_out) {
+    SacState* s = sac_of(c);
+    const int Da = c->cfg.act_dim;
     for (int r = 0; r < k; ++r)
         for (int d = 0; d < Da; ++d) {
             if (s->ddpg) {     // deterministic actor: the action itself, and the exploration-noise std
                 mu_out[(size_t)r * Da + d] = c->cfg.max_action * std::tanh(raw[(size_t)r * 2 * Da + d]);
-                sigma_out[(size_t)r * Da + d] = s->cfg.exploration_sigma;
+                if (sigma_out) sigma_out[(size_t)r * Da + d] = s->cfg.exploration_sigma;
                 continue;
             }
             mu_out[(size_t)r * Da + d] = s->cvpo ? c->cfg.max_action * std::tanh(raw[(size_t)r * 2 * Da + d])
                                                  : raw[(size_t)r * 2 * Da + d];
-            const float l = std::min(std::max(raw[(size_t)r * 2 * Da + Da + d], -20.0f), 2.0f);
-            sigma_out[(size_t)r * Da + d] = std::exp(l);
+            if (sigma_out) {
+                const float l = std::min(std::max(raw[(size_t)r * 2 * Da + Da + d], -20.0f), 2.0f);
+                sigma_out[(size_t)r * Da + d] = std::exp(l);
+            }
         }
-    return 0;
 }
 
-static int sac_actor_mu_sigma(fsrl_ctx* c, const float* obs, int32_t k, float* mu_out, float* sigma_out) {
-    return fsrl_sac_actor_forward(c, obs, k, mu_out, sigma_out);
+extern "C" int fsrl_sac_actor_forward(fsrl_ctx* c, const float* obs, int32_t k, float* mu_out, float* sigma_out) {
+    CHECK_ARG(c && obs && mu_out && sigma_out, "null argument");
+    if (!sac_of(c)) return fail(FSRL_ESTATE, "fsrl_sac_init first");
+    if (k <= 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = actor_eval_launch(c, obs, k, true);
+    if (rc) return rc;
+    return actor_eval_finish(c, mu_out, sigma_out);
 }
+
 static bool sac_squashes(fsrl_ctx* c) { SacState* s = sac_of(c); return s && !s->ddpg && !s->cvpo; }

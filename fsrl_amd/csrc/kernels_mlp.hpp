@@ -260,6 +260,8 @@ struct InferArgs {
     float* raw_out;         // optional [N][raw_cols] raw head outputs (SAC actor: mu | log sigma)
     int raw_cols;
     float* sigma_param_out; // optional [Da]: the actor's sigma_param (collector: one launch, no extra copy)
+    unsigned* done;         // optional [gridDim.x] in pinned host memory: block b stores `seq` here after its outputs are
+    unsigned seq;           //   visible system-wide -- the collector spins on these instead of a stream synchronisation
 };
 
 #define LOG_SQRT_2PI 0.9189385332046727f
@@ -291,9 +293,7 @@ __global__ __launch_bounds__(4 * H) void mlp_infer_kernel(const float* __restric
             const int i = e / a.raw_cols, o = e - i * a.raw_cols;
             a.raw_out[(size_t)(row0 + i) * a.raw_cols + o] = sm.out[i * FSRL_MAX_ACT + o];
         }
-        return;
-    }
-    if (tid < n_valid) {
+    } else if (tid < n_valid) {
         const int r = row0 + tid;
         if (!is_actor) {
             float v = sm.out[tid * FSRL_MAX_ACT];
@@ -317,6 +317,11 @@ __global__ __launch_bounds__(4 * H) void mlp_infer_kernel(const float* __restric
             }
             if (a.logp_old) a.logp_old[r] = logp;
         }
+    }
+    if (a.done) {
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.done + blockIdx.x, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

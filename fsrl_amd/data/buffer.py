@@ -34,6 +34,10 @@ class HipVectorReplayBuffer:
         for e in buffer_ids:
             self._sizes[e] = min(self._sizes[e] + 1, self._sub)
 
+    def sync_sizes(self) -> None:
+        """Fill levels from the engine (rows stored through fsrl_collect_step bypass this proxy)."""
+        self._sizes[:] = self.engine.store_sizes()
+
     def reset(self, keep_statistics: bool = False) -> None:
         self._sizes[:] = 0
         self.engine.reset_store(keep_statistics)

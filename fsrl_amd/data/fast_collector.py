@@ -16,11 +16,13 @@ from fsrl_amd.data.batch import Batch
 
 class FastCollector:
     def __init__(self, policy, env, buffer=None, preprocess_fn=None, exploration_noise: bool = False,
-                 device_actor: bool = False):
+                 device_actor: bool = False, fused_step: bool = True):
         # device_actor=True: actions come from fsrl_actor_sample (actor on the MI355X, library RNG) and rows go
         # straight to fsrl_store_push -- no torch call and no Batch objects per vector step.  False keeps the
         # host mirror of the actor with torch's random stream (what the reference consumes).
         self.device_actor = device_actor and getattr(policy, "engine", None) is not None
+        # fused_step (device_actor only): one fsrl_collect_step per vector step instead of fsrl_actor_sample + fsrl_store_push
+        self.fused_step = fused_step
         self.env = env
         self.env_num = len(env)
         self.policy = policy
@@ -65,6 +67,8 @@ class FastCollector:
         eng = self.policy.engine if self.device_actor else None
         if eng is not None and hasattr(self.policy, "_drain"):
             self.policy._drain()
+        if eng is not None and not random and self.buffer is not None and self.fused_step:
+            return self._collect_fused(eng, n_episode, ready, obs, t0, gym_reset_kwargs)
         while True:
             data = None if eng is not None and not random else Batch(obs=obs, info={})
             if eng is not None and not random:
@@ -111,6 +115,62 @@ class FastCollector:
                     ready, obs = ready[mask], obs[mask]
             if episode_count >= n_episode:
                 break
+        self.collect_step += step_count
+        self.collect_episode += episode_count
+        self.collect_time += max(time.time() - t0, 1e-9)
+        self.reset_env()
+        rews, lens = np.concatenate(ep_rews), np.concatenate(ep_lens)
+        done_count = term_count + trunc_count
+        return {"n/ep": episode_count, "n/st": step_count, "rew": float(rews.mean()),
+                "len": float(lens.mean()), "total_cost": total_cost,
+                "cost": total_cost / episode_count, "truncated": trunc_count / done_count,
+                "terminated": term_count / done_count}
+
+    def _collect_fused(self, eng, n_episode, ready, obs, t0, gym_reset_kwargs):
+        """The device-actor loop on fsrl_collect_step: per vector step ONE library call (store the finished transitions
+        while the actor for the next observations is in flight, then noise + map_action) and env.step."""
+        pol = self.policy
+        det = bool(pol._deterministic_eval and not pol.training)
+        space = pol.action_space
+        bound = {"": 0, "clip": 1, "tanh": 2}[pol.action_bound_method] if space is not None else 0
+        low = np.asarray(space.low, np.float32) if (space is not None and pol.action_scaling) else None
+        high = np.asarray(space.high, np.float32) if low is not None else None
+        step_count, total_cost, episode_count, term_count, trunc_count = 0, 0.0, 0, 0, 0
+        ep_rews, ep_lens = [], []
+        obs = np.asarray(obs, np.float32)
+        act, env_act, _, _ = eng.collect_step(None, obs, det, bound, low, high)
+        while True:
+            obs_next, rew, terminated, truncated, info = self.env.step(env_act, ready)
+            terminated, truncated = np.asarray(terminated, bool), np.asarray(truncated, bool)
+            done = terminated | truncated
+            cost = np.asarray(info.get("cost", np.zeros(len(ready))), np.float64) if isinstance(info, dict) \
+                else np.array([i.get("cost", 0.0) for i in info], np.float64)
+            total_cost += float(cost.sum())
+            step_count += len(ready)
+            prev = (ready, obs, act, rew, cost, terminated, truncated, obs_next)
+            nxt, nready = obs_next, ready
+            if done.any():
+                local = np.where(done)[0]
+                n_done = len(local)
+                term_count += int(terminated.sum()); trunc_count += int(truncated.sum())
+                nxt = np.array(obs_next, np.float32)
+                obs_reset, _ = self.env.reset(ready[local], **(gym_reset_kwargs or {}))
+                nxt[local] = obs_reset
+                surplus = len(ready) - (n_episode - episode_count - n_done)
+                if surplus > 0:      # drop finished envs that are no longer needed (unbiased tail)
+                    mask = np.ones(len(ready), bool)
+                    mask[local[:surplus]] = False
+                    nready, nxt = ready[mask], nxt[mask]
+                last = episode_count + n_done >= n_episode
+                act, env_act, ep_rew, ep_len = eng.collect_step(prev, None if last else nxt, det, bound, low, high)
+                episode_count += n_done
+                ep_lens.append(ep_len[local].copy()); ep_rews.append(ep_rew[local].copy())
+                if last:
+                    break
+            else:
+                act, env_act, _, _ = eng.collect_step(prev, nxt, det, bound, low, high)
+            obs, ready = np.asarray(nxt, np.float32), nready
+        self.buffer.sync_sizes()
         self.collect_step += step_count
         self.collect_episode += episode_count
         self.collect_time += max(time.time() - t0, 1e-9)

@@ -65,7 +65,8 @@ class Engine:
         ccfg = cfg.to_c()
         _lib.check(self.lib.fsrl_ctx_create(int(device), C.byref(ccfg), C.byref(self._ctx)))
         self.n_params = int(self.lib.fsrl_param_count(self._ctx))
-        self._act_stage = None      # cached staging arrays + ctypes pointers of the collector's hot calls
+        self._act_stage = None
+        self._collect_stage = None      # cached staging arrays + ctypes pointers of the collector's hot calls
         self._push_stage = None
 
     def close(self):
@@ -164,6 +165,48 @@ class Engine:
         np.copyto(st[0][:k], obs)
         _lib.check(self.lib.fsrl_actor_sample(self._ctx, st[2], k, int(deterministic), int(seed), st[3]))
         return st[1][:k].copy()
+
+    def collect_step(self, prev, obs_act, deterministic=False, bound_method=1, low=None, high=None):
+        """One vector step of the collector in one C call (fsrl_collect_step): store the finished transitions `prev` =
+        (env_ids, obs, act, rew, cost, terminated, truncated, obs_next) or None, and return (act, env_act, ep_rew,
+        ep_len) for the observations `obs_act` (None: store only).  Staging arrays / ctypes pointers are cached."""
+        Do, Da = self.cfg.obs_dim, self.cfg.act_dim
+        st = self._collect_stage
+        if st is None:
+            cap = self.cfg.env_num
+            arr = dict(ids=np.empty(cap, np.int32), obs=np.empty((cap, Do), np.float32), act=np.empty((cap, Da), np.float32),
+                       rew=np.empty(cap, np.float64), cost=np.empty(cap, np.float64), term=np.empty(cap, np.uint8),
+                       trunc=np.empty(cap, np.uint8), nxt=np.empty((cap, Do), np.float32), ptr=np.empty(cap, np.int64),
+                       er=np.empty(cap, np.float64), el=np.empty(cap, np.int32), ei=np.empty(cap, np.int64),
+                       oa=np.empty((cap, Do), np.float32), ao=np.empty((cap, Da), np.float32), eo=np.empty((cap, Da), np.float32),
+                       lo=np.empty(Da, np.float32), hi=np.empty(Da, np.float32))
+            types = dict(ids=_i32p, obs=_f32p, act=_f32p, rew=_f64p, cost=_f64p, term=_u8p, trunc=_u8p, nxt=_f32p, ptr=_i64p,
+                         er=_f64p, el=_i32p, ei=_i64p, oa=_f32p, ao=_f32p, eo=_f32p, lo=_f32p, hi=_f32p)
+            st = self._collect_stage = dict(a=arr, p={n: _ptr(arr[n], types[n]) for n in arr})
+        a, p = st["a"], st["p"]
+        k = 0
+        if prev is not None:
+            ids, obs, act, rew, cost, term, trunc, nxt = prev
+            k = len(ids)
+            a["ids"][:k] = ids; a["obs"][:k] = obs; a["act"][:k] = act; a["rew"][:k] = rew; a["cost"][:k] = cost
+            a["term"][:k] = term; a["trunc"][:k] = trunc; a["nxt"][:k] = nxt
+        ka = 0
+        if obs_act is not None:
+            ka = len(obs_act)
+            a["oa"][:ka] = obs_act
+        if low is not None:
+            a["lo"][:] = low; a["hi"][:] = high
+        _lib.check(self.lib.fsrl_collect_step(
+            self._ctx, p["ids"], k, p["obs"], p["act"], p["rew"], p["cost"], p["term"], p["trunc"], p["nxt"], p["ptr"],
+            p["er"], p["el"], p["ei"], p["oa"], ka, int(deterministic), int(bound_method),
+            p["lo"] if low is not None else None, p["hi"] if low is not None else None, p["ao"], p["eo"]))
+        return a["ao"][:ka].copy(), a["eo"][:ka].copy(), a["er"][:k], a["el"][:k]
+
+    def store_sizes(self, n=None):
+        n = self.cfg.env_num if n is None else int(n)
+        out = np.empty(n, np.int64)
+        _lib.check(self.lib.fsrl_store_sizes(self._ctx, _ptr(out, _i64p), n))
+        return out
 
     # ---------------------------------------------------------------- FOCOPS (on the PPO begin / pass / end calls)
     def focops_init(self, actor_lr=5e-4, critic_lr=1e-3, l2_reg=1e-3, delta=0.02, eta=0.02, tem_lambda=0.95,

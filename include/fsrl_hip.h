@@ -116,6 +116,22 @@ int fsrl_actor_forward(fsrl_ctx* ctx, const float* obs, int32_t k, float* mu_out
  * caller).  Not torch's random stream -- the host mirror of the actor remains for stream-exact runs.   */
 int fsrl_actor_sample(fsrl_ctx* ctx, const float* obs, int32_t k, int32_t deterministic, uint64_t seed,
                       float* act_out);
+/* One vector step of FastCollector.collect (fsrl/data/fast_collector.py:283-368) with the actor on the device, in
+ * ONE call: (1) launch the actor on obs_act[k_act] -- the observations the NEXT actions are for (obs_next with the
+ * reset observations of finished envs put in, surplus envs dropped); (2) while it runs, store the k transitions that
+ * just finished exactly as fsrl_store_push does (k = 0 on the first step of a collect); (3) wait, draw the noise
+ * as fsrl_actor_sample does (same stream: the two calls one after the other give the same numbers), and map the
+ * action for env.step as BasePolicy.map_action does (base_policy.py:226-256): bound_method 0 none / 1 clip to
+ * [-1, 1] / 2 tanh, then low + (high - low) * (a + 1) / 2 when act_low / act_high are given.
+ * act_out[k_act][act_dim]: the policy's action (what the buffer stores); env_act_out: what the env takes.        */
+int fsrl_collect_step(fsrl_ctx* ctx, const int32_t* env_ids, int32_t k, const float* obs, const float* act,
+                      const double* rew, const double* cost, const uint8_t* terminated, const uint8_t* truncated,
+                      const float* obs_next, int64_t* ptr_out, double* ep_rew_out, int32_t* ep_len_out,
+                      int64_t* ep_idx_out, const float* obs_act, int32_t k_act, int32_t deterministic,
+                      int32_t bound_method, const float* act_low, const float* act_high, float* act_out,
+                      float* env_act_out);
+/* Fill level of the first n sub-buffers (len(buffer.buffers[e]); ReplayBufferManager.sample_indices weighs by it). */
+int fsrl_store_sizes(const fsrl_ctx* ctx, int64_t* sizes_out, int32_t n);
 
 /* ---- PPO-Lagrangian update = BasePolicy.update (base_policy.py:332-355) -------------- */
 /* begin: buffer.sample(0) + PPOLagrangian.process_fn (ppo_lag.py:134-150): gathers the

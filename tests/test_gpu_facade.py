@@ -285,3 +285,39 @@ def test_agents_learn_the_synthetic_task_under_the_cost_constraint(tmp_path):
             assert agent.policy.lag_optims[0].get_lag() > 0
         else:
             assert c1 <= 20 * 1.2 and r1 > r0 - 20, (r0, r1, c1)    # CPO: feasible, reward not sacrificed
+
+
+def test_fused_collect_step_equals_actor_sample_plus_push(tmp_path):
+    """fsrl_collect_step (one library call per vector step: store the finished rows while the actor for the next
+    observations is in flight, noise, map_action) against fsrl_actor_sample + fsrl_store_push + the Python map_action:
+    same library random stream, so the collects -- statistics, stored rows, the update that consumes them -- are identical,
+    including the surplus-env dropping at the end of a collect (n_episode not a multiple of env_num)."""
+    from fsrl_amd.agent import PPOLagAgent, SACLagAgent
+    from fsrl_amd.data import FastCollector, HipVectorReplayBuffer
+    from fsrl_amd.env import SyntheticSafetyVectorEnv
+    from fsrl_amd.utils import BaseLogger
+    for cls, kw in ((PPOLagAgent, {}), (SACLagAgent, {})):
+        out = []
+        for fused in (True, False):
+            env = SyntheticSafetyVectorEnv(env_num=6, obs_dim=8, act_dim=2, episode_len=23, seed=4)
+            agent = cls(env, BaseLogger(str(tmp_path), name=f"c{fused}"), cost_limit=10, device="cuda:0", seed=2,
+                        hidden_sizes=(64, 64), training_num=6, **kw)
+            agent.policy.train()
+            eng = agent.policy.engine
+            buf = HipVectorReplayBuffer(eng, 6 * 200, 6)
+            col = FastCollector(agent.policy, env, buf, exploration_noise=True, device_actor=True, fused_step=fused)
+            eng.actor_sample(np.zeros((1, 8), np.float32), seed=77)            # key the library stream identically
+            st = [col.collect(n_episode=n) for n in (6, 10, 3)]
+            rows = eng.sample0()
+            sizes = buf._sizes.copy()
+            if cls is PPOLagAgent:
+                upd, _ = eng.ppo_update([0.3], 1 / 1.3, 64, 2, seed=5)
+            else:
+                upd = eng.sac_update(32, [0.3], 1 / 1.3, seed=5)
+            out.append((st, rows, sizes, np.asarray(upd)))
+            eng.close()
+        (st_a, rows_a, sz_a, upd_a), (st_b, rows_b, sz_b, upd_b) = out
+        assert st_a == st_b, (st_a, st_b)
+        assert np.array_equal(rows_a, rows_b) and np.array_equal(sz_a, sz_b)
+        assert np.array_equal(upd_a, upd_b)
+        assert sum(s["n/ep"] for s in st_a) == 19
