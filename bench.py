@@ -200,6 +200,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # test hooks (tests/test_gpu_facade.py): run the N > 1 code path on a one-GPU box -- every rank on device 0, gloo
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--share-gpu", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -209,8 +212,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        if args.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from fsrl_amd.engine import Engine, EngineConfig
@@ -255,7 +263,7 @@ def main():
     grad_steps = stats.shape[0]
     assert np.isfinite(stats).all()
     if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     # ---- roofline of the dominant kernel: HIP events around every ppo_fwd_bwd_kernel launch on

@@ -321,3 +321,22 @@ def test_fused_collect_step_equals_actor_sample_plus_push(tmp_path):
         assert np.array_equal(rows_a, rows_b) and np.array_equal(sz_a, sz_b)
         assert np.array_equal(upd_a, upd_b)
         assert sum(s["n/ep"] for s in st_a) == 19
+
+
+def test_bench_multi_rank_path_on_one_gpu():
+    """bench.py's N > 1 path (one process per rank, barrier + max-over-ranks timing, rank 0 prints the one JSON line
+    with the whole-job value) run as two ranks sharing this box's GPU over gloo: the launch line is the driver's."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--share-gpu"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]      # whole-job = ranks / step time
+    assert "roofline" in d and "cpu_baseline" not in d                               # CPU leg: rank 0 at N = 1 only
