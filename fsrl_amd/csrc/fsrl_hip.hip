@@ -1724,13 +1724,13 @@ struct FocState {
     fsrl_focops_config cfg{};
     double nu = 0.0, nu_loss = 0.0;
     int64_t t_actor = 0, t_critic = 0;
-    float *statp_vf = nullptr, *statp_pi = nullptr, *psq = nullptr, *gsq = nullptr;
+    float *statp_pi = nullptr, *psq = nullptr, *gsq = nullptr, *sig_stash = nullptr;   // statp_pi: [tiles][3 networks][FB_NSTAT]
     int cap_tiles = 0, cap_psq = 0;
 };
 static void foc_free(fsrl_ctx* c) {
     FocState* f = c->foc;
     if (!f) return;
-    for (float* p : {f->statp_vf, f->statp_pi, f->psq, f->gsq}) if (p) (void)hipFree(p);
+    for (float* p : {f->statp_pi, f->psq, f->gsq, f->sig_stash}) if (p) (void)hipFree(p);
     delete f;
     c->foc = nullptr;
 }
@@ -1767,14 +1767,18 @@ static int focops_pass(fsrl_ctx* c, int32_t* stopped_out) {
     const int nb_a = (c->md.net[0].end - c->md.net[0].begin + 255) / 256;
     if (f->cap_tiles < max_tiles || f->cap_psq < nb_c0 + nb_c1) {
         HIPCHK(hipStreamSynchronize(s));
-        for (float** p : {&f->statp_vf, &f->statp_pi, &f->psq, &f->gsq}) { if (*p) HIPCHK(hipFree(*p)); *p = nullptr; }
-        HIPCHK(hipMalloc(&f->statp_vf, (size_t)(4 * max_tiles + 4) * 2 * FB_NSTAT * 4));
-        HIPCHK(hipMalloc(&f->statp_pi, (size_t)(4 * max_tiles + 4) * FB_NSTAT * 4));
+        for (float** p : {&f->statp_pi, &f->psq, &f->gsq}) { if (*p) HIPCHK(hipFree(*p)); *p = nullptr; }
+        HIPCHK(hipMalloc(&f->statp_pi, (size_t)(4 * max_tiles + 4) * 3 * FB_NSTAT * 4));      // three networks per tile
+        if (!f->sig_stash) HIPCHK(hipMalloc(&f->sig_stash, FSRL_MAX_ACT * 4));
         HIPCHK(hipMalloc(&f->psq, (size_t)(nb_c0 + nb_c1) * 4));
         HIPCHK(hipMalloc(&f->gsq, (size_t)nb_a * 4));
         f->cap_tiles = max_tiles; f->cap_psq = nb_c0 + nb_c1;
     }
     const double b1 = c->cfg.beta1, b2 = c->cfg.beta2;
+    // One minibatch step = four launches: the activation side of all three networks (actor: FOCOPS loss head, critics:
+    // regression head), their weight gradients, then the parameter side in two (focops_prep_kernel, focops_step_kernel).
+    // The critics' and the actor's updates do not read each other's parameters, so one launch each is the reference's
+    // critics_loss -> policy_loss order (focops.py:236-246) with nothing reordered inside a network.
     for (int mb = 0; mb < nmb; ++mb) {
         const int start = c->mb_start[(size_t)mb], size = c->mb_size[(size_t)mb];
         const int tiles = (size + 15) / 16, rows_pad = tiles * 16;
@@ -1782,69 +1786,55 @@ static int focops_pass(fsrl_ctx* c, int32_t* stopped_out) {
         a.obs = c->obs_p + (size_t)start * Do; a.rd = c->rd_p + (size_t)start * FSRL_RD;
         a.A1 = c->A1; a.A2 = c->A2; a.D1 = c->D1; a.D2 = c->D2; a.DO = c->DO;
         a.N = size; a.rows_pad = rows_pad; a.max_action = c->cfg.max_action;
-        auto tile = [&](int mode, int net0, int ny, float* statp) -> int {
-            a.mode = mode; a.net0 = net0; a.statp = statp;
-            const bool rows4 = 4 * tiles * ny <= c->n_cus;
-            return dispatch_H(H, [&](auto hc) {
-                constexpr int HH = decltype(hc)::value;
-                if (rows4) hipLaunchKernelGGL((fb_tile_kernel<HH, 4>), dim3(4 * tiles, ny), dim3(4 * HH), 0, s, c->P, c->md, a);
-                else hipLaunchKernelGGL((fb_tile_kernel<HH, 16>), dim3(tiles, ny), dim3(4 * HH), 0, s, c->P, c->md, a);
-                HIPCHK(hipGetLastError());
-                return 0;
-            });
-        };
-        auto wgrad = [&](int net0, int ny, int* nsplit) -> int {
-            FbWgradArgs wa{};
-            for (int y = 0; y < ny; ++y) {
-                const size_t nb = (size_t)y * rows_pad;
-                FbWgradNet& wn = wa.nets[y];
-                wn.w2_ya = c->D2 + nb * H; wn.w2_xa = c->A1 + nb * H; wn.w1_y = c->D1 + nb * H;
-                wn.w3_xa = c->A2 + nb * H; wn.w3_ya = c->DO + nb * FSRL_DOW;
-                wn.b1_src = c->D1 + nb * H; wn.b2_src = c->D2 + nb * H; wn.do_src = c->DO + nb * FSRL_DOW;
-                wn.net = net0 + y;
-            }
-            wa.obs = a.obs; wa.rows = rows_pad; wa.N = size;
-            return wgrad_launch<false>(c, c->md, wa, ny, c->n_dev, nsplit);
-        };
-        auto adam = [&](int net, float lr, int64_t t, float l2, const float* G, int nparts, const float* gsq, int n_gsq,
-                        float max_norm, float* psq) {
-            const int begin = c->md.net[net].begin, end = c->md.net[net].end;
-            const double bc1 = 1.0 - std::pow(b1, (double)t), bc2 = 1.0 - std::pow(b2, (double)t);
-            hipLaunchKernelGGL(adam_range_kernel, dim3((end - begin + 255) / 256), dim3(256), 0, s, c->P, c->M, c->V, G, begin, end,
-                               l2, (float)(1.0 - b1), c->cfg.beta2, (float)(1.0 - b2), (float)((double)lr / bc1),
-                               (float)std::sqrt(bc2), c->cfg.adam_eps, nparts, c->n_dev, c->md, gsq, n_gsq, max_norm, psq);
-        };
-        // ---- critics (their own optimiser; L2 inside the loss)
-        int rc = tile(FB_MODE_VF, 1, 2, f->statp_vf);
-        if (rc) return rc;
-        int nsplit = 1;
-        rc = wgrad(1, 2, &nsplit);
-        if (rc) return rc;
-        f->t_critic += 1;
-        adam(1, f->cfg.critic_lr, f->t_critic, f->cfg.l2_reg, c->wg_parts, nsplit, nullptr, 0, 0.0f, f->psq);
-        adam(2, f->cfg.critic_lr, f->t_critic, f->cfg.l2_reg, c->wg_parts, nsplit, nullptr, 0, 0.0f, f->psq + nb_c0);
-        // ---- actor
         a.cr = 1.0f / f->cfg.tem_lambda; a.cc = (float)f->nu; a.eta = f->cfg.eta;
-        rc = tile(FB_MODE_FOCOPS, 0, 1, f->statp_pi);
+        a.mode = FB_MODE_FOCOPS; a.net0 = 0; a.statp = f->statp_pi;      // [tiles][3][FB_NSTAT]
+        const bool rows4 = 4 * tiles * 3 <= c->n_cus;
+        int rc = dispatch_H(H, [&](auto hc) {
+            constexpr int HH = decltype(hc)::value;
+            if (rows4) hipLaunchKernelGGL((fb_tile_kernel<HH, 4>), dim3(4 * tiles, 3), dim3(4 * HH), 0, s, c->P, c->md, a);
+            else hipLaunchKernelGGL((fb_tile_kernel<HH, 16>), dim3(tiles, 3), dim3(4 * HH), 0, s, c->P, c->md, a);
+            HIPCHK(hipGetLastError());
+            return 0;
+        });
         if (rc) return rc;
-        rc = wgrad(0, 1, &nsplit);
+        FbWgradArgs wa{};
+        for (int y = 0; y < 3; ++y) {
+            const size_t nb = (size_t)y * rows_pad;
+            FbWgradNet& wn = wa.nets[y];
+            wn.w2_ya = c->D2 + nb * H; wn.w2_xa = c->A1 + nb * H; wn.w1_y = c->D1 + nb * H;
+            wn.w3_xa = c->A2 + nb * H; wn.w3_ya = c->DO + nb * FSRL_DOW;
+            wn.b1_src = c->D1 + nb * H; wn.b2_src = c->D2 + nb * H; wn.do_src = c->DO + nb * FSRL_DOW;
+            wn.net = y;
+        }
+        wa.obs = a.obs; wa.rows = rows_pad; wa.N = size;
+        int nsplit = 1;
+        rc = wgrad_launch<false>(c, c->md, wa, 3, c->n_dev, &nsplit);
         if (rc) return rc;
-        hipLaunchKernelGGL(fb_sum_parts_kernel, dim3(nb_a), dim3(256), 0, s, c->G, c->wg_parts, c->md.net[0].begin,
-                           c->md.net[0].end, nsplit, c->n_dev, f->gsq);
-        // ---- logged row, pass KL sum, pass-level early stop flag
-        FocopsFinalArgs fa{};
-        const bool rows4_vf = 4 * tiles * 2 <= c->n_cus, rows4_pi = 4 * tiles <= c->n_cus;
-        fa.statp_vf = f->statp_vf; fa.statp_pi = f->statp_pi; fa.psq0 = f->psq; fa.psq1 = f->psq + nb_c0;
-        fa.n_psq0 = nb_c0; fa.n_psq1 = nb_c1; fa.P = c->P; fa.sigma_off = c->md.net[0].sigma; fa.Da = c->cfg.act_dim;
+        f->t_critic += 1; f->t_actor += 1;
+        FocopsStepArgs sa{};
+        sa.P = c->P; sa.M = c->M; sa.V = c->V; sa.parts = c->wg_parts; sa.nparts = nsplit; sa.stride = c->n_dev;
+        sa.G = c->G; sa.gsq = f->gsq; sa.psq = f->psq; sa.sig_stash = f->sig_stash;
+        sa.nb_a = nb_a; sa.nb_c0 = nb_c0; sa.nb_c1 = nb_c1; sa.max_norm = f->cfg.max_grad_norm; sa.l2 = f->cfg.l2_reg;
+        sa.one_minus_b1 = (float)(1.0 - b1); sa.beta2 = c->cfg.beta2; sa.one_minus_b2 = (float)(1.0 - b2);
+        sa.adam_eps = c->cfg.adam_eps;
+        sa.step_a = (float)((double)f->cfg.actor_lr / (1.0 - std::pow(b1, (double)f->t_actor)));
+        sa.bc2s_a = (float)std::sqrt(1.0 - std::pow(b2, (double)f->t_actor));
+        sa.step_c = (float)((double)f->cfg.critic_lr / (1.0 - std::pow(b1, (double)f->t_critic)));
+        sa.bc2s_c = (float)std::sqrt(1.0 - std::pow(b2, (double)f->t_critic));
+        // ---- logged row, pass KL sum, pass-level early stop flag (the extra block of the step launch)
+        FocopsFinalArgs& fa = sa.fin;
+        fa.statp_vf = f->statp_pi + FB_NSTAT; fa.statp_pi = f->statp_pi; fa.vf_stride = 3; fa.pi_stride = 3;
+        fa.psq0 = f->psq; fa.psq1 = f->psq + nb_c0; fa.n_psq0 = nb_c0; fa.n_psq1 = nb_c1;
+        fa.P = f->sig_stash; fa.sigma_off = 0; fa.Da = c->cfg.act_dim;          // entropy of the PRE-update policy
         fa.stats = c->d_stats + (size_t)(c->n_steps + mb) * FSRL_PPO_NSTATS; fa.ctrl = c->ctrl;
-        fa.n_tiles = rows4_vf ? 4 * tiles : tiles; fa.mb = size; fa.first_in_pass = mb == 0; fa.last_in_pass = mb == nmb - 1;
+        fa.n_tiles = rows4 ? 4 * tiles : tiles; fa.n_tiles_pi = fa.n_tiles; fa.mb = size;
+        fa.first_in_pass = mb == 0; fa.last_in_pass = mb == nmb - 1;
         fa.iters_in_pass = nmb; fa.pass = (int)c->pass_index; fa.l2 = f->cfg.l2_reg; fa.nu_loss = (float)f->nu_loss;
         fa.nu_value = (float)f->nu; fa.delta = f->cfg.delta;
-        fa.n_tiles_pi = rows4_pi ? 4 * tiles : tiles;
-        hipLaunchKernelGGL(focops_finalize_kernel, dim3(1), dim3(64), 0, s, fa);   // entropy of the PRE-update policy
+        const int nb_all = nb_a + nb_c0 + nb_c1;
+        hipLaunchKernelGGL(focops_prep_kernel, dim3(nb_all), dim3(256), 0, s, c->md, sa);
+        hipLaunchKernelGGL(focops_step_kernel, dim3(nb_all + 1), dim3(256), 0, s, c->md, sa);
         HIPCHK(hipGetLastError());
-        f->t_actor += 1;
-        adam(0, f->cfg.actor_lr, f->t_actor, 0.0f, c->G, 1, f->gsq, nb_a, f->cfg.max_grad_norm, nullptr);
     }
     c->n_steps += nmb;
     c->pass_index += 1;

@@ -951,17 +951,17 @@ struct FocopsFinalArgs {
     CtrlBlock* ctrl;
     int n_tiles, n_tiles_pi, mb, first_in_pass, last_in_pass, iters_in_pass, pass;
     float l2, nu_loss, nu_value, delta;
+    int vf_stride, pi_stride;   // networks interleaved per tile in statp_vf / statp_pi (one launch over all three: 3, 3)
 };
-__global__ __launch_bounds__(64) void focops_finalize_kernel(const FocopsFinalArgs a) {
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void focops_finalize_row(const FocopsFinalArgs& a, const int lane) {
     double s_vf0 = 0.0, s_vf1 = 0.0, s_loss = 0.0, s_kl = 0.0, s_p0 = 0.0, s_p1 = 0.0;
     for (int t = lane; t < a.n_tiles; t += 64) {
-        s_vf0 += (double)a.statp_vf[((size_t)t * 2 + 0) * FB_NSTAT];
-        s_vf1 += (double)a.statp_vf[((size_t)t * 2 + 1) * FB_NSTAT];
+        s_vf0 += (double)a.statp_vf[((size_t)t * a.vf_stride + 0) * FB_NSTAT];
+        s_vf1 += (double)a.statp_vf[((size_t)t * a.vf_stride + 1) * FB_NSTAT];
     }
     for (int t = lane; t < a.n_tiles_pi; t += 64) {
-        s_loss += (double)a.statp_pi[(size_t)t * FB_NSTAT];
-        s_kl += (double)a.statp_pi[(size_t)t * FB_NSTAT + 2];
+        s_loss += (double)a.statp_pi[(size_t)t * a.pi_stride * FB_NSTAT];
+        s_kl += (double)a.statp_pi[(size_t)t * a.pi_stride * FB_NSTAT + 2];
     }
     for (int k = lane; k < a.n_psq0; k += 64) s_p0 += (double)a.psq0[k];
     for (int k = lane; k < a.n_psq1; k += 64) s_p1 += (double)a.psq1[k];
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(64) void focops_finalize_kernel(const FocopsFinalAr
     if (lane == 0) {
         const float invB = 1.0f / (float)a.mb;
         float ent = 0.0f;
-        for (int d = 0; d < a.Da; ++d) ent += 1.4189385332046727f + logf(expf(a.P[a.sigma_off + d]));
+        for (int d = 0; d < a.Da; ++d) ent += 1.4189385332046727f + logf(expf(a.P[a.sigma_off + d]));   // P / sigma_off: the pre-step values
         const float vf0 = (float)s_vf0 * invB + (float)s_p0 * a.l2, vf1 = (float)s_vf1 * invB + (float)s_p1 * a.l2;
         const float kl = (float)s_kl * invB;
         float* o = a.stats;
@@ -980,6 +980,117 @@ __global__ __launch_bounds__(64) void focops_finalize_kernel(const FocopsFinalAr
         a.ctrl->kl_sum = ksum;
         if (a.last_in_pass && ksum / ((double)a.iters_in_pass + 1e-7) > (double)a.delta) a.ctrl->stopped_after = a.pass;
     }
+}
+
+// torch.optim.Adam single-tensor update of one element, operation order of torch (lerp_ / mul_ + addcmul_ / sqrt / div /
+// add_(eps) / addcdiv_).  ONE definition for every kernel that steps parameters of the full-batch / replay paths, so that
+// they round identically.
+__device__ __forceinline__ void adam_element(float* __restrict__ P, float* __restrict__ M, float* __restrict__ V, const int i,
+                                             const float p, const float gs, const float coef, const float l2,
+                                             const float one_minus_b1, const float beta2, const float one_minus_b2,
+                                             const float step_size, const float bc2_sqrt, const float eps,
+                                             const ModelDesc& md, float* __restrict__ tgt, const float tau,
+                                             const float one_minus_tau) {
+    const float g = gs * coef + 2.0f * l2 * p;
+    float m = M[i], v = V[i];
+    m = m + one_minus_b1 * (g - m);
+    v = v * beta2;
+    v = v + (one_minus_b2 * g) * g;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    M[i] = m; V[i] = v;
+    const float pn = p + (-step_size * m) / denom;
+    P[i] = pn;
+    const int mi = w2f_mirror_of(md, i);
+    if (mi >= 0) P[mi] = pn;
+    if (tgt) {                           // target <- tau * param + (1 - tau) * target (BasePolicy.soft_update) in the same pass:
+        const float tv = tau * pn + one_minus_tau * tgt[i];   // the parameters do not change again before sync_weight
+        tgt[i] = tv;
+        if (mi >= 0) tgt[mi] = tv;
+    }
+}
+
+// ---- FOCOPS minibatch step, parameter side, in two launches (focops.py:161-176, 205-213, 236-246).
+//      Blocks are 256 parameters wide and laid out actor | critic 0 | critic 1 (nb_a, nb_c0, nb_c1 blocks).
+struct FocopsStepArgs {
+    float* P; float* M; float* V;
+    const float* parts; int nparts, stride;  // split-K partial gradients of fb_wgrad_kernel (all three networks)
+    float* G;                                // summed actor gradient (written by prep, read by the step)
+    float* gsq;                              // [nb_a] per-block sums of squares of the actor gradient
+    float* psq;                              // [nb_c0 + nb_c1] per-block sums of squares of the critics' PRE-update parameters
+    float* sig_stash;                        // [Da] sigma_param before the step (entropy of the pre-update policy)
+    int nb_a, nb_c0, nb_c1;
+    float max_norm, l2;
+    float one_minus_b1, beta2, one_minus_b2, adam_eps;
+    float step_a, bc2s_a, step_c, bc2s_c;    // lr / (1 - beta1^t), sqrt(1 - beta2^t) of the two optimisers
+    FocopsFinalArgs fin;                     // the logged row / pass KL bookkeeping (done by the extra block of the step)
+};
+__device__ __forceinline__ void focops_block(const ModelDesc& md, const FocopsStepArgs& a, int& net, int& i) {
+    int b = blockIdx.x;
+    net = 0;
+    if (b >= a.nb_a) { b -= a.nb_a; net = 1; if (b >= a.nb_c0) { b -= a.nb_c0; net = 2; } }
+    i = md.net[net].begin + b * 256 + threadIdx.x;
+}
+// prep: actor blocks add the split-K partials in z order (-> G) and leave per-block sums of squares (clip_grad_norm_ over
+// the actor); critic blocks leave per-block sums of squares of their parameters (the L2 term of the logged loss).
+__global__ __launch_bounds__(256) void focops_prep_kernel(const ModelDesc md, const FocopsStepArgs a) {
+    __shared__ float sh[4];
+    int net, i;
+    focops_block(md, a, net, i);
+    float q = 0.0f;
+    if (i < md.net[net].end) {
+        if (net == 0) {
+            float v = a.parts[i];
+            for (int z = 1; z < a.nparts; ++z) v += a.parts[(size_t)z * a.stride + i];
+            a.G[i] = v;
+            q = v * v;
+        } else {
+            const float p = a.P[i];
+            q = p * p;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < md.Da) a.sig_stash[threadIdx.x] = a.P[md.net[0].sigma + threadIdx.x];
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        if (net == 0) a.gsq[blockIdx.x] = t; else a.psq[blockIdx.x - a.nb_a] = t;
+    }
+}
+// step: Adam of the actor (clipped to max_norm) and of both critics (L2 inside the gradient) in one launch; one extra
+// block writes the logged row from the per-tile statistics, the parameter sums and the stashed sigma_param.
+__global__ __launch_bounds__(256) void focops_step_kernel(const ModelDesc md, const FocopsStepArgs a) {
+    __shared__ double shd[4];
+    __shared__ float coef_s;
+    if ((int)blockIdx.x == a.nb_a + a.nb_c0 + a.nb_c1) {
+        if (threadIdx.x < 64) focops_finalize_row(a.fin, threadIdx.x);
+        return;
+    }
+    int net, i;
+    focops_block(md, a, net, i);
+    float coef = 1.0f;
+    if (net == 0 && a.max_norm > 0.0f) {     // same reduction order as adam_range_kernel's clip
+        double sq = 0.0;
+        for (int k = threadIdx.x; k < a.nb_a; k += 256) sq += (double)a.gsq[k];
+        sq = wave_sum_d(sq);
+        if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) coef_s = fminf(a.max_norm / (sqrtf((float)((shd[0] + shd[1]) + (shd[2] + shd[3]))) + 1e-6f), 1.0f);
+        __syncthreads();
+        coef = coef_s;
+    }
+    if (i >= md.net[net].end) return;
+    const float p = a.P[i];
+    float gs;
+    if (net == 0) gs = a.G[i];
+    else {
+        gs = a.parts[i];
+        for (int z = 1; z < a.nparts; ++z) gs += a.parts[(size_t)z * a.stride + i];
+    }
+    if (net == 0) adam_element(a.P, a.M, a.V, i, p, gs, coef, 0.0f, a.one_minus_b1, a.beta2, a.one_minus_b2, a.step_a, a.bc2s_a,
+                               a.adam_eps, md, nullptr, 0.0f, 0.0f);
+    else adam_element(a.P, a.M, a.V, i, p, gs, coef, a.l2, a.one_minus_b1, a.beta2, a.one_minus_b2, a.step_c, a.bc2s_c, a.adam_eps,
+                      md, nullptr, 0.0f, 0.0f);
 }
 
 // full-batch advantage normalisation (CPO cpo.py:127-131, TRPO trpo_lag.py:129-133): per critic
@@ -1063,22 +1174,8 @@ __global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ P, 
         psq = p * p;
         float gs = G[i];                                   // split-K partials of fb_wgrad_kernel, z order
         for (int z = 1; z < nparts; ++z) gs += G[(size_t)z * stride + i];
-        const float g = gs * coef + 2.0f * l2 * p;
-        float m = M[i], v = V[i];
-        m = m + one_minus_b1 * (g - m);
-        v = v * beta2;
-        v = v + (one_minus_b2 * g) * g;
-        const float denom = sqrtf(v) / bc2_sqrt + eps;
-        M[i] = m; V[i] = v;
-        const float pn = p + (-step_size * m) / denom;
-        P[i] = pn;
-        const int mi = w2f_mirror_of(md, i);
-        if (mi >= 0) P[mi] = pn;
-        if (tgt) {                           // target <- tau * param + (1 - tau) * target (BasePolicy.soft_update) in the same pass:
-            const float tv = tau * pn + one_minus_tau * tgt[i];   // the parameters do not change again before sync_weight
-            tgt[i] = tv;
-            if (mi >= 0) tgt[mi] = tv;
-        }
+        adam_element(P, M, V, i, p, gs, coef, l2, one_minus_b1, beta2, one_minus_b2, step_size, bc2_sqrt, eps, md, tgt, tau,
+                     one_minus_tau);
     }
     if (psq_part) {                          // per-block sum of squares of the PRE-update parameters (L2 term of the logged loss)
         psq = wave_sum(psq);
