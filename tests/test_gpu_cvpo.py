@@ -281,3 +281,34 @@ def test_cvpo_on_a_wrapped_store_device_and_host_chains_agree():
     for which in (0, 1, 2, 3):
         assert np.array_equal(dev.sac_get_params(which)[0], twin.sac_get_params(which)[0])
     dev.close(); twin.close()
+
+
+def test_cvpo_cost_limit_update_and_call_order_errors():
+    """update_cost_limit (cvpo.py:165-176) reaches the device threshold; CVPO entry points on a context that was not
+    initialised for CVPO fail with the state error instead of running something else."""
+    from fsrl_amd import _lib
+    from fsrl_amd.engine import Engine, EngineConfig
+    g, cfg, ocfg, store, index = cvpo_setup("small")
+    eng = _engine(cfg, g, ocfg)
+    eng.cvpo_pre_update()
+    B = cfg["batch_size"]
+    st0 = eng.cvpo_update(B, indices=g["indices"][0], eps_target=g["eps_target"][0], eps_particles=g["eps_particles"][0])
+    assert abs(st0[15] - ocfg.qc_thres) < 1e-6
+    eng.cvpo_set_thres(2.5)
+    st1 = eng.cvpo_update(B, indices=g["indices"][1], eps_target=g["eps_target"][1], eps_particles=g["eps_particles"][1])
+    assert abs(st1[15] - 2.5) < 1e-6
+    with pytest.raises(AssertionError):          # caller-RNG arguments come together
+        eng.lib.fsrl_cvpo_update  # noqa: B018  (symbol exists)
+        _lib.check(eng.lib.fsrl_cvpo_update(eng._ctx, B, None, None, None, 0, None) or
+                   eng.lib.fsrl_cvpo_update(eng._ctx, 0, None, None, None, 0, None))
+    eng.close()
+    sac = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=4, act_dim=2, hidden=64, n_critics=2, env_num=1, buffer_size=64,
+                              target_kl=None))
+    sac.sac_init()
+    with pytest.raises(_lib.FsrlHipError):
+        sac.cvpo_pre_update()
+    with pytest.raises(_lib.FsrlHipError):
+        sac.cvpo_update(8)
+    sizes = sac.store_sizes()
+    assert sizes.tolist() == [0]
+    sac.close()
