@@ -122,19 +122,19 @@ def end_to_end(local_rank, seed, seconds=6.0, device_actor=False):
                          verbose=False)
     tr.reset()
     t0 = time.perf_counter()
-    collects = 0
+    collects, update_s = 0, 0.0
     while time.perf_counter() - t0 < seconds:
         st = tr.train_step()
         t1 = time.perf_counter()
         tr.policy_update_fn(st)
-        tr.update_time += time.perf_counter() - t1
+        update_s += time.perf_counter() - t1
         collects += 1
     dt = time.perf_counter() - t0
     out = {"env": "synthetic SafetyCarCircle-shaped vector env (not PyBullet)", "envs": ENVS,
-           "actor": "device (fsrl_actor_sample, library RNG)" if device_actor else "host mirror (torch CPU, torch RNG)",
+           "actor": "device (fsrl_collect_step: one call per vector step, library RNG)" if device_actor else "host mirror (torch CPU, torch RNG)",
            "collects": collects, "env_steps_per_s": col.collect_step / dt,
            "collector_only_env_steps_per_s": col.collect_step / col.collect_time,
-           "update_ms_per_collect": tr.update_time / collects * 1e3,
+           "update_ms_per_collect": update_s / collects * 1e3,
            "policy_updates_per_s": collects / dt}
     agent.policy.engine.close()
     return out

@@ -1,8 +1,15 @@
-from fsrl_amd.agent.base_agent import BaseAgent, OnpolicyAgent
-from fsrl_amd.agent.ppo_lag_agent import PPOLagAgent
-from fsrl_amd.agent.trust_agents import CPOAgent, FOCOPSAgent, TRPOLagAgent
-from fsrl_amd.agent.sac_lag_agent import OffpolicyAgent, SACLagAgent
-from fsrl_amd.agent.ddpg_lag_agent import DDPGLagAgent
-from fsrl_amd.agent.cvpo_agent import CVPOAgent
+"""The seven agents of the reference (fsrl.agent) with their keyword arguments, over the HIP-backed policies."""
+from fsrl_amd._lazy import install
 
-__all__ = ["BaseAgent", "OnpolicyAgent", "PPOLagAgent", "CPOAgent", "TRPOLagAgent", "OffpolicyAgent", "SACLagAgent", "DDPGLagAgent", "FOCOPSAgent", "CVPOAgent"]
+install(__name__, globals(), {
+    "BaseAgent": "base_agent",
+    "OnpolicyAgent": "base_agent",
+    "OffpolicyAgent": "sac_lag_agent",
+    "PPOLagAgent": "ppo_lag_agent",
+    "CPOAgent": "trust_agents",
+    "TRPOLagAgent": "trust_agents",
+    "FOCOPSAgent": "trust_agents",
+    "SACLagAgent": "sac_lag_agent",
+    "DDPGLagAgent": "ddpg_lag_agent",
+    "CVPOAgent": "cvpo_agent",
+})

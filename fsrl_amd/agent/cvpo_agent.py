@@ -3,14 +3,12 @@ from typing import Tuple
 
 import numpy as np
 import torch
-from torch import nn
-from torch.distributions import Independent, Normal
 
+from fsrl_amd.agent._nets import adam, independent_normal, offpolicy_nets
 from fsrl_amd.agent.sac_lag_agent import OffpolicyAgent
 from fsrl_amd.policy.cvpo import CVPO
 from fsrl_amd.utils.exp_util import seed_all
 from fsrl_amd.utils.logger import DummyLogger
-from fsrl_amd.utils.net import ActorCritic, ActorProb, DoubleCritic, Net, SingleCritic
 
 
 class CVPOAgent(OffpolicyAgent):
@@ -32,35 +30,13 @@ class CVPOAgent(OffpolicyAgent):
             "the HIP CVPO path: one cost, state-conditioned sigma, bounded mean (the reference defaults)"
         seed_all(seed)
         torch.set_num_threads(thread)
-        state_shape, action_shape = env.observation_space.shape, env.action_space.shape
         assert hasattr(env.spec, "max_episode_steps"), \
             "Please use an env wrapper to provide 'max_episode_steps' for CVPO"
-        actor = ActorProb(Net(state_shape, hidden_sizes=hidden_sizes), action_shape,
-                          max_action=float(env.action_space.high[0]), conditioned_sigma=True, unbounded=False)
-        actor_optim = torch.optim.Adam(actor.parameters(), lr=actor_lr)
-        critics = []
-        for _ in range(2):
-            if double_critic:
-                critics.append(DoubleCritic(Net(state_shape, action_shape, hidden_sizes=hidden_sizes, concat=True),
-                                            Net(state_shape, action_shape, hidden_sizes=hidden_sizes, concat=True)))
-            else:
-                critics.append(SingleCritic(Net(state_shape, action_shape, hidden_sizes=hidden_sizes, concat=True)))
-        critic_optim = torch.optim.Adam(nn.ModuleList(critics).parameters(), lr=critic_lr)
-        for m in ActorCritic(actor, critics).modules():
-            if isinstance(m, torch.nn.Linear):
-                torch.nn.init.orthogonal_(m.weight)
-                torch.nn.init.zeros_(m.bias)
-        if last_layer_scale:
-            for m in actor.mu.modules():
-                if isinstance(m, torch.nn.Linear):
-                    torch.nn.init.zeros_(m.bias)
-                    m.weight.data.copy_(0.01 * m.weight.data)
-
-        def dist(*logits):
-            return Independent(Normal(*logits), 1)
-
+        actor, critics = offpolicy_nets(env, hidden_sizes, "double" if double_critic else "single", unbounded=False,
+                                        last_layer_scale=last_layer_scale)
+        actor_optim, critic_optim = adam(actor, actor_lr), adam(critics, critic_lr)
         self.policy = CVPO(actor=actor, critics=critics, actor_optim=actor_optim, critic_optim=critic_optim,
-                           logger=self.logger, action_space=env.action_space, dist_fn=dist,
+                           logger=self.logger, action_space=env.action_space, dist_fn=independent_normal,
                            max_episode_steps=env.spec.max_episode_steps, cost_limit=cost_limit, tau=tau, gamma=gamma,
                            n_step=n_step, estep_iter_num=estep_iter_num, estep_kl=estep_kl, estep_dual_max=estep_dual_max,
                            estep_dual_lr=estep_dual_lr, sample_act_num=sample_act_num, mstep_iter_num=mstep_iter_num,

@@ -7,13 +7,12 @@ from typing import Optional, Tuple
 
 import numpy as np
 import torch
-from torch.distributions import Independent, Normal
 
+from fsrl_amd.agent._nets import adam, independent_normal, onpolicy_nets
 from fsrl_amd.agent.base_agent import OnpolicyAgent
 from fsrl_amd.policy import PPOLagrangian
 from fsrl_amd.utils.exp_util import seed_all
 from fsrl_amd.utils.logger import BaseLogger, DummyLogger
-from fsrl_amd.utils.net import ActorCritic, ActorProb, Critic, Net
 
 
 class PPOLagAgent(OnpolicyAgent):
@@ -46,28 +45,9 @@ class PPOLagAgent(OnpolicyAgent):
             "the HIP path supports two equal hidden layers (64/128/256)"
         seed_all(seed)
         torch.set_num_threads(thread)
-        state_shape = env.observation_space.shape
-        action_shape = env.action_space.shape
-        max_action = float(env.action_space.high[0])
-        actor = ActorProb(Net(state_shape, hidden_sizes=hidden_sizes), action_shape, max_action=max_action,
-                          unbounded=unbounded)
-        critic = [Critic(Net(state_shape, hidden_sizes=hidden_sizes)) for _ in range(1 + cost_dim)]
-        torch.nn.init.constant_(actor.sigma_param, -0.5)
-        actor_critic = ActorCritic(actor, critic)
-        for m in actor_critic.modules():
-            if isinstance(m, torch.nn.Linear):
-                torch.nn.init.orthogonal_(m.weight)
-                torch.nn.init.zeros_(m.bias)
-        if last_layer_scale:
-            for m in actor.mu.modules():
-                if isinstance(m, torch.nn.Linear):
-                    torch.nn.init.zeros_(m.bias)
-                    m.weight.data.copy_(0.01 * m.weight.data)
-        optim = torch.optim.Adam(actor_critic.parameters(), lr=lr)
-
-        def dist(*logits):
-            return Independent(Normal(*logits), 1)
-
+        actor, critic, actor_critic = onpolicy_nets(env, hidden_sizes, 1 + cost_dim, last_layer_scale, unbounded)
+        optim = adam(actor_critic, lr)
+        dist = independent_normal
         self.policy = PPOLagrangian(
             actor, critic, optim, dist, logger=self.logger, target_kl=target_kl, vf_coef=vf_coef,
             max_grad_norm=max_grad_norm, gae_lambda=gae_lambda, eps_clip=eps_clip, dual_clip=dual_clip,

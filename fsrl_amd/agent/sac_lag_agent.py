@@ -4,15 +4,14 @@ from typing import Optional, Tuple
 
 import numpy as np
 import torch
-from torch import nn
 
+from fsrl_amd.agent._nets import adam, offpolicy_nets
 from fsrl_amd.agent.base_agent import BaseAgent
 from fsrl_amd.data import FastCollector, HipVectorReplayBuffer
 from fsrl_amd.policy.sac_lag import SACLagrangian
 from fsrl_amd.trainer.offpolicy import OffpolicyTrainer
 from fsrl_amd.utils.exp_util import seed_all
 from fsrl_amd.utils.logger import DummyLogger
-from fsrl_amd.utils.net import ActorCritic, ActorProb, DoubleCritic, Net
 
 
 class OffpolicyAgent(BaseAgent):
@@ -75,23 +74,8 @@ class SACLagAgent(OffpolicyAgent):
             "the HIP SAC path: one cost, state-conditioned sigma, unbounded mean (the reference defaults)"
         seed_all(seed)
         torch.set_num_threads(thread)
-        state_shape, action_shape = env.observation_space.shape, env.action_space.shape
-        actor = ActorProb(Net(state_shape, hidden_sizes=hidden_sizes), action_shape,
-                          max_action=float(env.action_space.high[0]), conditioned_sigma=True, unbounded=True)
-        actor_optim = torch.optim.Adam(actor.parameters(), lr=actor_lr)
-        critics = [DoubleCritic(Net(state_shape, action_shape, hidden_sizes=hidden_sizes, concat=True),
-                                Net(state_shape, action_shape, hidden_sizes=hidden_sizes, concat=True))
-                   for _ in range(2)]
-        critic_optim = torch.optim.Adam(nn.ModuleList(critics).parameters(), lr=critic_lr)
-        for m in ActorCritic(actor, critics).modules():
-            if isinstance(m, torch.nn.Linear):
-                torch.nn.init.orthogonal_(m.weight)
-                torch.nn.init.zeros_(m.bias)
-        if last_layer_scale:
-            for m in actor.mu.modules():
-                if isinstance(m, torch.nn.Linear):
-                    torch.nn.init.zeros_(m.bias)
-                    m.weight.data.copy_(0.01 * m.weight.data)
+        actor, critics = offpolicy_nets(env, hidden_sizes, "double", unbounded=True, last_layer_scale=last_layer_scale)
+        actor_optim, critic_optim = adam(actor, actor_lr), adam(critics, critic_lr)
         if auto_alpha:
             target_entropy = -float(np.prod(env.action_space.shape))
             log_alpha = torch.zeros(1, requires_grad=True)

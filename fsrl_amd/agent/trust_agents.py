@@ -4,38 +4,13 @@ from typing import Optional, Tuple
 
 import numpy as np
 import torch
-from torch import nn
-from torch.distributions import Independent, Normal
 
+from fsrl_amd.agent._nets import adam, independent_normal, onpolicy_nets
 from fsrl_amd.agent.base_agent import OnpolicyAgent
 from fsrl_amd.policy.cpo import CPO
 from fsrl_amd.policy.trpo_lag import TRPOLagrangian
 from fsrl_amd.utils.exp_util import seed_all
 from fsrl_amd.utils.logger import DummyLogger
-from fsrl_amd.utils.net import ActorCritic, ActorProb, Critic, Net
-
-
-def _build_nets(env, hidden_sizes, last_layer_scale, n_critics):
-    state_shape, action_shape = env.observation_space.shape, env.action_space.shape
-    actor = ActorProb(Net(state_shape, hidden_sizes=hidden_sizes), action_shape,
-                      max_action=float(env.action_space.high[0]))
-    critic = [Critic(Net(state_shape, hidden_sizes=hidden_sizes)) for _ in range(n_critics)]
-    torch.nn.init.constant_(actor.sigma_param, -0.5)
-    ac = ActorCritic(actor, critic)
-    for m in ac.modules():
-        if isinstance(m, torch.nn.Linear):
-            torch.nn.init.orthogonal_(m.weight)
-            torch.nn.init.zeros_(m.bias)
-    if last_layer_scale:
-        for m in actor.mu.modules():
-            if isinstance(m, torch.nn.Linear):
-                torch.nn.init.zeros_(m.bias)
-                m.weight.data.copy_(0.01 * m.weight.data)
-    return actor, critic, ac
-
-
-def _dist(*logits):
-    return Independent(Normal(*logits), 1)
 
 
 class CPOAgent(OnpolicyAgent):
@@ -58,9 +33,9 @@ class CPOAgent(OnpolicyAgent):
         assert not unbounded
         seed_all(seed)
         torch.set_num_threads(thread)
-        actor, critic, _ = _build_nets(env, hidden_sizes, last_layer_scale, 2)
-        optim = torch.optim.Adam(nn.ModuleList(critic).parameters(), lr=lr)
-        self.policy = CPO(actor, critic, optim, _dist, logger=self.logger, target_kl=target_kl,
+        actor, critic, _ = onpolicy_nets(env, hidden_sizes, 2, last_layer_scale)
+        optim = adam(critic, lr)
+        self.policy = CPO(actor, critic, optim, independent_normal, logger=self.logger, target_kl=target_kl,
                           backtrack_coeff=backtrack_coeff, damping_coeff=damping_coeff,
                           max_backtracks=max_backtracks, optim_critic_iters=optim_critic_iters,
                           l2_reg=l2_reg, gae_lambda=gae_lambda,
@@ -92,9 +67,9 @@ class TRPOLagAgent(OnpolicyAgent):
         assert np.isscalar(cost_limit) and not unbounded
         seed_all(seed)
         torch.set_num_threads(thread)
-        actor, critic, ac = _build_nets(env, hidden_sizes, last_layer_scale, 2)
-        optim = torch.optim.Adam(ac.parameters(), lr=lr)
-        self.policy = TRPOLagrangian(actor, critic, optim, _dist, logger=self.logger, target_kl=target_kl,
+        actor, critic, ac = onpolicy_nets(env, hidden_sizes, 2, last_layer_scale)
+        optim = adam(ac, lr)
+        self.policy = TRPOLagrangian(actor, critic, optim, independent_normal, logger=self.logger, target_kl=target_kl,
                                      backtrack_coeff=backtrack_coeff, max_backtracks=max_backtracks,
                                      optim_critic_iters=optim_critic_iters, gae_lambda=gae_lambda,
                                      advantage_normalization=advantage_normalization,
@@ -128,10 +103,9 @@ class FOCOPSAgent(OnpolicyAgent):
         assert np.isscalar(cost_limit) and auto_nu and not unbounded
         seed_all(seed)
         torch.set_num_threads(thread)
-        actor, critic, _ = _build_nets(env, hidden_sizes, last_layer_scale, 2)
-        actor_optim = torch.optim.Adam(actor.parameters(), lr=actor_lr)
-        critic_optim = torch.optim.Adam(nn.ModuleList(critic).parameters(), lr=critic_lr)
-        self.policy = FOCOPS(actor, critic, actor_optim, critic_optim, _dist, logger=self.logger, cost_limit=cost_limit,
+        actor, critic, _ = onpolicy_nets(env, hidden_sizes, 2, last_layer_scale)
+        actor_optim, critic_optim = adam(actor, actor_lr), adam(critic, critic_lr)
+        self.policy = FOCOPS(actor, critic, actor_optim, critic_optim, independent_normal, logger=self.logger, cost_limit=cost_limit,
                              nu=(nu_max, nu_lr, torch.zeros(1)), l2_reg=l2_reg, delta=delta, eta=eta, tem_lambda=tem_lambda,
                              gae_lambda=gae_lambda, max_grad_norm=max_grad_norm,
                              advantage_normalization=advantage_normalization, recompute_advantage=recompute_advantage,

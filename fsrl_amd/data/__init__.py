@@ -1,6 +1,8 @@
-"""Host-side data plumbing: minimal Batch, the HIP-resident buffer proxy and the collector."""
-from fsrl_amd.data.batch import Batch
-from fsrl_amd.data.buffer import HipVectorReplayBuffer
-from fsrl_amd.data.fast_collector import FastCollector
+"""Host-side data plumbing: a minimal Batch, the proxy of the HIP-resident store, the collector."""
+from fsrl_amd._lazy import install
 
-__all__ = ["Batch", "HipVectorReplayBuffer", "FastCollector"]
+install(__name__, globals(), {
+    "Batch": "batch",
+    "HipVectorReplayBuffer": "buffer",
+    "FastCollector": "fast_collector",
+})

@@ -1,12 +1,14 @@
-"""Policy package: the reference's class names over the HIP engine (fsrl/policy/__init__.py)."""
-from fsrl_amd.policy.base_policy import BasePolicy
-from fsrl_amd.policy.lagrangian_base import LagrangianPolicy
-from fsrl_amd.policy.ppo_lag import PPOLagrangian
-from fsrl_amd.policy.trpo_lag import TRPOLagrangian
-from fsrl_amd.policy.cpo import CPO
-from fsrl_amd.policy.sac_lag import SACLagrangian
-from fsrl_amd.policy.ddpg_lag import DDPGLagrangian
-from fsrl_amd.policy.focops import FOCOPS
-from fsrl_amd.policy.cvpo import CVPO
+"""The reference's policy class names over the HIP engine (what fsrl.policy exports, one per algorithm)."""
+from fsrl_amd._lazy import install
 
-__all__ = ["BasePolicy", "LagrangianPolicy", "PPOLagrangian", "TRPOLagrangian", "CPO", "SACLagrangian", "DDPGLagrangian", "FOCOPS", "CVPO"]
+install(__name__, globals(), {
+    "BasePolicy": "base_policy",
+    "LagrangianPolicy": "lagrangian_base",
+    "PPOLagrangian": "ppo_lag",
+    "TRPOLagrangian": "trpo_lag",
+    "CPO": "cpo",
+    "FOCOPS": "focops",
+    "SACLagrangian": "sac_lag",
+    "DDPGLagrangian": "ddpg_lag",
+    "CVPO": "cvpo",
+})

@@ -1,5 +1,8 @@
-from fsrl_amd.trainer.base_trainer import BaseTrainer
-from fsrl_amd.trainer.onpolicy import OnpolicyTrainer
-from fsrl_amd.trainer.offpolicy import OffpolicyTrainer
+"""Epoch loops that call the hot path (fsrl.trainer's three names)."""
+from fsrl_amd._lazy import install
 
-__all__ = ["BaseTrainer", "OnpolicyTrainer", "OffpolicyTrainer"]
+install(__name__, globals(), {
+    "BaseTrainer": "base_trainer",
+    "OnpolicyTrainer": "onpolicy",
+    "OffpolicyTrainer": "offpolicy",
+})

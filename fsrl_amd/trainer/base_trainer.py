@@ -1,14 +1,44 @@
-"""Epoch iterator: collect -> policy_update_fn -> test -> checkpoint/log, with the timing info
-of fsrl/trainer/base_trainer.py:181-356 (`train_speed` = env-steps/s, `train_model_time`, ...).
-The caller of the hot path; plain Python."""
+"""The epoch loop that calls the hot path: collect -> policy_update_fn -> (test) -> checkpoint / log.
+
+Interface of fsrl/trainer/base_trainer.py:181-356 as its callers use it -- iterate the trainer for
+`(epoch, epoch_stats, info)` triples, or `run()` -- with the same logger keys (`train/*`, `test/*`, `update/*`) and the
+same `info` fields (`train_speed` = env-steps/s, `train_model_time`, ...).  Organised differently: the best-so-far
+rule lives in `_Best`, the wall-clock bookkeeping in `_Clock`, and an epoch is three short phases.  Plain Python."""
 import time
 from abc import ABC, abstractmethod
-from collections import deque
 from typing import Any, Callable, Dict, Optional, Tuple, Union
 
 import numpy as np
 
 from fsrl_amd.utils.logger import BaseLogger, DummyLogger
+
+
+class _Best:
+    """Best (reward, cost) seen so far under a cost limit: while the incumbent violates the limit, anything feasible
+    or better-rewarded replaces it; once it is feasible, only feasible AND better-rewarded results do."""
+
+    def __init__(self, limit: float) -> None:
+        self.limit, self.reward, self.cost = limit, -np.inf, np.inf
+
+    def offer(self, reward: float, cost: float) -> bool:
+        feasible, richer = cost <= self.limit, reward > self.reward
+        accept = (feasible or richer) if self.cost > self.limit else (feasible and richer)
+        if accept:
+            self.reward, self.cost = reward, cost
+        return accept
+
+
+class _Clock:
+    """Wall-clock accounts of a run: total, and the part spent inside policy_update_fn."""
+
+    def __init__(self) -> None:
+        self.t0, self.in_update = time.time(), 0.0
+
+    def restart(self) -> None:
+        self.t0 = time.time()
+
+    def elapsed(self) -> float:
+        return max(0.0, time.time() - self.t0)
 
 
 class BaseTrainer(ABC):
@@ -19,120 +49,122 @@ class BaseTrainer(ABC):
                  episode_per_test: Optional[int] = None, episode_per_collect: int = 1,
                  stop_fn: Optional[Callable[[float, float], bool]] = None, resume_from_log: bool = False,
                  logger: BaseLogger = None, verbose: bool = True, show_progress: bool = True):
-        self.learning_type = learning_type
-        self.policy = policy
+        self.learning_type, self.policy = learning_type, policy
         self.train_collector, self.test_collector = train_collector, test_collector
-        self.logger = logger if logger is not None else DummyLogger()
-        self.cost_limit = cost_limit
-        self.start_time = time.time()
-        self.best_perf_rew, self.best_perf_cost = -np.inf, np.inf
-        self.start_epoch = 0
-        self.env_step, self.cum_cost, self.cum_episode = 0, 0, 0
-        self.max_epoch, self.step_per_epoch = max_epoch, step_per_epoch
+        self.logger = DummyLogger() if logger is None else logger
+        # schedule
+        self.max_epoch, self.step_per_epoch, self.save_model_interval = max_epoch, step_per_epoch, save_model_interval
         self.episode_per_collect, self.episode_per_test = episode_per_collect, episode_per_test
-        self.update_per_step, self.save_model_interval = update_per_step, save_model_interval
-        self.repeat_per_collect, self.batch_size = repeat_per_collect, batch_size
-        self.stop_fn = stop_fn
+        self.batch_size, self.repeat_per_collect, self.update_per_step = batch_size, repeat_per_collect, update_per_step
+        self.stop_fn, self.cost_limit = stop_fn, cost_limit
         self.verbose, self.show_progress, self.resume_from_log = verbose, show_progress, resume_from_log
-        self.epoch = self.start_epoch
-        self.stop_fn_flag = False
-        self.update_time = 0.0   # wall time spent inside policy_update_fn (device path)
+        # run state
+        self.start_epoch = 0
+        self.epoch, self.stop_fn_flag = self.start_epoch, False
+        self.env_step, self.cum_cost, self.cum_episode = 0, 0, 0
+        self._best, self._clock = _Best(cost_limit), _Clock()
 
+    # attributes the reference exposes under these names
+    best_perf_rew = property(lambda self: self._best.reward)
+    best_perf_cost = property(lambda self: self._best.cost)
+    update_time = property(lambda self: self._clock.in_update)
+    start_time = property(lambda self: self._clock.t0)
+
+    # ------------------------------------------------------------------ iteration protocol
     def reset(self) -> None:
-        self.env_step = 0
-        self.start_time = time.time()
+        self.env_step, self.epoch, self.stop_fn_flag = 0, self.start_epoch, False
+        self._clock.restart()
         self.train_collector.reset_stat()
         if self.test_collector is not None:
             assert self.episode_per_test is not None
             self.test_collector.reset_stat()
-        self.epoch = self.start_epoch
-        self.stop_fn_flag = False
 
     def __iter__(self):
         self.reset()
         return self
 
     def __next__(self) -> Tuple[int, Dict, Dict]:
-        self.epoch += 1
-        if self.epoch > self.max_epoch or self.stop_fn_flag:
+        if self.stop_fn_flag or self.epoch >= self.max_epoch:
             raise StopIteration
-        self.policy.train()
-        steps_this_epoch = 0
-        while steps_this_epoch < self.step_per_epoch:
-            stats_train = self.train_step()
-            steps_this_epoch += int(stats_train["n/st"])
-            t0 = time.time()
-            self.policy_update_fn(stats_train)
-            self.update_time += time.time() - t0
-            self.logger.write_without_reset(self.env_step)
+        self.epoch += 1
+        self._train_phase()
         if self.test_collector is not None:
             self.test_step()
-        update_info = self.gather_update_info()
-        self.logger.store(tab="update", **update_info)
+        info = self._close_epoch()
+        return self.epoch, self._epoch_stats, info
+
+    def run(self) -> Dict[str, Union[float, str]]:
+        for _ in self:
+            pass
+        return self.gather_update_info()
+
+    # ------------------------------------------------------------------ the three phases of an epoch
+    def _train_phase(self) -> None:
+        """collect / update cycles until the epoch's step budget is spent"""
+        self.policy.train()
+        budget = self.step_per_epoch
+        while budget > 0:
+            collected = self.train_step()
+            budget -= int(collected["n/st"])
+            tic = time.time()
+            self.policy_update_fn(collected)
+            self._clock.in_update += time.time() - tic
+            self.logger.write_without_reset(self.env_step)
+
+    def test_step(self) -> Dict[str, Any]:
+        col = self.test_collector
+        col.reset_env()
+        col.reset_buffer()
+        self.policy.eval()
+        res = col.collect(n_episode=self.episode_per_test)
+        self.logger.store(**{"test/reward": res["rew"], "test/cost": res["cost"], "test/length": int(res["len"])})
+        return res
+
+    def _close_epoch(self) -> Dict[str, Any]:
+        """log the timing info, checkpoint, track the best result, evaluate the stop rule, flush the logger"""
+        info = self.gather_update_info()
+        self.logger.store(tab="update", **info)
         if self.epoch % self.save_model_interval == 0:
             self.logger.save_checkpoint()
         if self.perf_is_better(test=True):
             self.logger.save_checkpoint(suffix="best")
-        if self.stop_fn and self.stop_fn(self.best_perf_rew, self.best_perf_cost):
+        if self.stop_fn is not None and self.stop_fn(self._best.reward, self._best.cost):
             self.stop_fn_flag = True
             self.logger.print("Early stop due to the stop_fn met.", "red")
-        epoch_stats = self.logger.stats_mean
+        self._epoch_stats = self.logger.stats_mean
         self.logger.write(self.env_step, display=self.verbose)
-        update_info.update({"best_reward": self.best_perf_rew, "best_cost": self.best_perf_cost})
-        return self.epoch, epoch_stats, update_info
+        info.update(best_reward=self._best.reward, best_cost=self._best.cost)
+        return info
+
+    # ------------------------------------------------------------------ pieces subclasses and callers use
+    def train_step(self) -> Dict[str, Any]:
+        res = self.train_collector.collect(self.episode_per_collect)
+        self.env_step += int(res["n/st"])
+        self.cum_episode += int(res["n/ep"])
+        self.cum_cost += res["total_cost"]
+        self.logger.store(**{"update/episode": self.cum_episode, "update/cum_cost": self.cum_cost,
+                             "train/reward": res["rew"], "train/cost": res["cost"], "train/length": int(res["len"])})
+        return res
 
     def perf_is_better(self, test: bool = True) -> bool:
-        mode = "test" if test and self.test_collector is not None else "train"
-        rew, cost = self.logger.get_mean(mode + "/reward"), self.logger.get_mean(mode + "/cost")
-        if self.best_perf_cost > self.cost_limit:
-            better = cost <= self.cost_limit or rew > self.best_perf_rew
-        else:
-            better = cost <= self.cost_limit and rew > self.best_perf_rew
-        if better:
-            self.best_perf_cost, self.best_perf_rew = cost, rew
-        return better
-
-    def test_step(self) -> Dict[str, Any]:
-        self.test_collector.reset_env()
-        self.test_collector.reset_buffer()
-        self.policy.eval()
-        stats_test = self.test_collector.collect(n_episode=self.episode_per_test)
-        self.logger.store(**{"test/reward": stats_test["rew"], "test/cost": stats_test["cost"],
-                             "test/length": int(stats_test["len"])})
-        return stats_test
-
-    def train_step(self) -> Dict[str, Any]:
-        stats_train = self.train_collector.collect(self.episode_per_collect)
-        self.env_step += int(stats_train["n/st"])
-        self.cum_cost += stats_train["total_cost"]
-        self.cum_episode += int(stats_train["n/ep"])
-        self.logger.store(**{"update/episode": self.cum_episode, "update/cum_cost": self.cum_cost,
-                             "train/reward": stats_train["rew"], "train/cost": stats_train["cost"],
-                             "train/length": int(stats_train["len"])})
-        return stats_train
+        tab = "test" if (test and self.test_collector is not None) else "train"
+        return self._best.offer(self.logger.get_mean(tab + "/reward"), self.logger.get_mean(tab + "/cost"))
 
     @abstractmethod
     def policy_update_fn(self, result: Dict[str, Any]) -> None:
-        pass
-
-    def run(self) -> Dict[str, Union[float, str]]:
-        deque(self, maxlen=0)
-        return self.gather_update_info()
+        """pre_update_fn -> update(s) -> post_update_fn of the concrete learning type"""
 
     def gather_update_info(self) -> Dict[str, Any]:
-        duration = max(0, time.time() - self.start_time)
-        model_time = max(0, duration - self.train_collector.collect_time)
-        result = {"duration": duration}
-        if self.test_collector is not None and self.test_collector.collect_time > 0:
-            collect_test = self.test_collector.collect_time
-            model_time = max(0, model_time - collect_test)
-            result.update({"test_time": collect_test,
-                           "test_speed": self.test_collector.collect_step / collect_test})
-            train_speed = self.train_collector.collect_step / max(duration - collect_test, 1e-9)
-        else:
-            train_speed = self.train_collector.collect_step / max(duration, 1e-9)
-        result.update({"train_collector_time": self.train_collector.collect_time,
-                       "train_model_time": model_time, "train_speed": train_speed,
-                       "policy_update_time": self.update_time,
-                       "remaining_epoch": self.max_epoch - self.epoch})
-        return result
+        total = self._clock.elapsed()
+        train_col = self.train_collector
+        test_s = self.test_collector.collect_time if self.test_collector is not None else 0.0
+        info: Dict[str, Any] = {"duration": total}
+        if test_s > 0:
+            info["test_time"] = test_s
+            info["test_speed"] = self.test_collector.collect_step / test_s
+        info["train_collector_time"] = train_col.collect_time
+        info["train_model_time"] = max(0.0, total - train_col.collect_time - test_s)
+        info["train_speed"] = train_col.collect_step / max(total - test_s, 1e-9)
+        info["policy_update_time"] = self._clock.in_update
+        info["remaining_epoch"] = self.max_epoch - self.epoch
+        return info

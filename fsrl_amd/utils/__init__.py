@@ -1,6 +1,9 @@
-"""Host utilities mirroring fsrl.utils (only what the policy-update path touches)."""
-from fsrl_amd.utils.exp_util import seed_all
-from fsrl_amd.utils.logger import BaseLogger, DummyLogger
-from fsrl_amd.utils.optim_util import LagrangianOptimizer
+"""Host utilities of the policy-update path: seeding, the scalar logger, the PID multiplier."""
+from fsrl_amd._lazy import install
 
-__all__ = ["BaseLogger", "DummyLogger", "LagrangianOptimizer", "seed_all"]
+install(__name__, globals(), {
+    "seed_all": "exp_util",
+    "BaseLogger": "logger",
+    "DummyLogger": "logger",
+    "LagrangianOptimizer": "optim_util",
+})
