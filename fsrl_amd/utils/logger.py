@@ -1,141 +1,129 @@
-"""Scalar sink with the interface the policy / trainer call (fsrl/utils/logger/base_logger.py:
-store(tab, **scalars), write, print, save_checkpoint, stats_mean, get_mean).  TensorBoard / W&B
-writers are out of scope; `progress.txt` TSV output is kept."""
+"""The scalar sink the policy and the trainer write to.
+
+Call surface of fsrl/utils/logger/base_logger.py as this path uses it: `store(tab=None, **scalars)` accumulates running
+means between two `write(step)` calls; `stats_mean` / `get_mean` read them; `save_checkpoint(suffix)` pickles whatever
+`setup_checkpoint_fn` registered; `progress.txt` receives one tab-separated row per `write`.  TensorBoard / W&B writers
+are outside this path; `DummyLogger` only accumulates."""
 import os
-import os.path as osp
 import time
-from collections import defaultdict
-from typing import Callable, Iterable, Optional
+from typing import Callable, Dict, Iterable, List, Optional
 
 import numpy as np
 
 
-class _RunningMean:
-    __slots__ = ("total", "count")
+class _Means:
+    """name -> running mean, in first-seen order"""
 
-    def __init__(self):
-        self.total, self.count = 0.0, 0
+    def __init__(self) -> None:
+        self._sum: Dict[str, float] = {}
+        self._n: Dict[str, int] = {}
 
-    def add(self, v):
-        self.total += float(v)
-        self.count += 1
+    def add(self, name: str, value) -> None:
+        self._sum[name] = self._sum.get(name, 0.0) + float(np.mean(value))
+        self._n[name] = self._n.get(name, 0) + 1
 
-    @property
-    def mean(self):
-        return self.total / self.count if self.count else 0.0
+    def names(self) -> List[str]:
+        return list(self._sum)
+
+    def mean(self, name: str) -> float:
+        n = self._n.get(name, 0)
+        return self._sum[name] / n if n else 0.0
 
 
 class BaseLogger:
     def __init__(self, log_dir: Optional[str] = None, log_txt: bool = True, name: Optional[str] = None):
-        self.name = name if name is not None else time.strftime("%Y-%m-%d_exp")
-        self.log_dir = osp.join(log_dir, self.name) if log_dir is not None else None
-        self.output_file = None
+        self.name = time.strftime("%Y-%m-%d_exp") if name is None else name
+        self.log_dir = None if log_dir is None else os.path.join(log_dir, self.name)
+        self.checkpoint_fn: Optional[Callable] = None
+        self._table = None                     # progress.txt, opened lazily with its header row
+        self._want_table = bool(log_txt and self.log_dir)
         if self.log_dir:
             os.makedirs(self.log_dir, exist_ok=True)
-            if log_txt:
-                self.output_file = open(osp.join(self.log_dir, "progress.txt"), "w")
-        self.first_row = True
-        self.checkpoint_fn: Optional[Callable] = None
         self.reset_data()
 
-    def setup_checkpoint_fn(self, checkpoint_fn: Optional[Callable] = None) -> None:
-        self.checkpoint_fn = checkpoint_fn
-
+    # ------------------------------------------------------------------ accumulate / read
     def reset_data(self) -> None:
-        self.log_data = defaultdict(_RunningMean)
+        self._means = _Means()
 
     def store(self, tab: Optional[str] = None, **kwargs) -> None:
-        for k, v in kwargs.items():
-            self.log_data[(tab + "/" + k) if tab is not None else k].add(np.mean(v))
+        prefix = "" if tab is None else tab + "/"
+        for key, value in kwargs.items():
+            self._means.add(prefix + key, value)
 
     @property
     def logger_keys(self) -> Iterable[str]:
-        return self.log_data.keys()
+        return self._means.names()
 
     def get_mean(self, key: str) -> float:
-        return self.log_data[key].mean
+        return self._means.mean(key) if key in self._means.names() else 0.0
 
-    def get_mean_list(self, keys: Iterable[str]):
+    def get_mean_list(self, keys: Iterable[str]) -> List[float]:
         return [self.get_mean(k) for k in keys]
 
-    def get_mean_dict(self, keys: Iterable[str]):
+    def get_mean_dict(self, keys: Iterable[str]) -> Dict[str, float]:
         return {k: self.get_mean(k) for k in keys}
 
     @property
-    def stats_mean(self) -> dict:
+    def stats_mean(self) -> Dict[str, float]:
         return self.get_mean_dict(self.logger_keys)
 
+    # ------------------------------------------------------------------ flush
     def write(self, step: int, display: bool = False, display_keys: Iterable[str] = None) -> None:
         if "update/env_step" not in self.logger_keys:
             self.store(tab="update", env_step=step)
-        if self.output_file is not None:
-            if self.first_row:
-                self.output_file.write("\t".join(["Steps"] + list(self.logger_keys)) + "\n")
-            vals = [step] + self.get_mean_list(self.logger_keys)
-            self.output_file.write("\t".join(map(str, vals)) + "\n")
-            self.output_file.flush()
-            self.first_row = False
+        if self._want_table:
+            keys = list(self.logger_keys)
+            if self._table is None:
+                self._table = open(os.path.join(self.log_dir, "progress.txt"), "w")
+                self._table.write("\t".join(["Steps"] + keys) + "\n")
+            self._table.write("\t".join(str(v) for v in [step] + self.get_mean_list(keys)) + "\n")
+            self._table.flush()
         if display:
             self.display_tabular(display_keys)
         self.reset_data()
 
     def write_without_reset(self, *args, **kwarg) -> None:
-        pass
+        """hook of the reference's TensorBoard / W&B loggers: nothing to do for the text table"""
 
     def display_tabular(self, display_keys: Iterable[str] = None) -> None:
         keys = sorted(display_keys or self.logger_keys)
         width = max([15] + [len(k) for k in keys])
-        print("-" * (width + 22))
+        rule = "-" * (width + 22)
+        print(rule)
         for k in keys:
             print(f"| {k:>{width}} | {self.get_mean(k):15.5g} |")
-        print("-" * (width + 22), flush=True)
+        print(rule, flush=True)
+
+    # ------------------------------------------------------------------ checkpoints / config
+    def setup_checkpoint_fn(self, checkpoint_fn: Optional[Callable] = None) -> None:
+        self.checkpoint_fn = checkpoint_fn
 
     def save_checkpoint(self, suffix=None) -> None:
-        if self.checkpoint_fn and self.log_dir:
-            import torch
-            fpath = osp.join(self.log_dir, "checkpoint")
-            os.makedirs(fpath, exist_ok=True)
-            suffix = "%d" % suffix if isinstance(suffix, int) else suffix
-            fname = "model" + ("_" + suffix if suffix is not None else "") + ".pt"
-            torch.save(self.checkpoint_fn(), osp.join(fpath, fname))
+        if not (self.checkpoint_fn and self.log_dir):
+            return
+        import torch
+        folder = os.path.join(self.log_dir, "checkpoint")
+        os.makedirs(folder, exist_ok=True)
+        tag = "" if suffix is None else "_" + (str(suffix) if not isinstance(suffix, int) else "%d" % suffix)
+        torch.save(self.checkpoint_fn(), os.path.join(folder, "model" + tag + ".pt"))
 
     def save_config(self, config: dict, verbose=True) -> None:
         if self.log_dir:
             import yaml
-            with open(osp.join(self.log_dir, "config.yaml"), "w") as f:
+            with open(os.path.join(self.log_dir, "config.yaml"), "w") as f:
                 yaml.dump(config, f, default_flow_style=False, indent=4, sort_keys=False)
 
     def restore_data(self) -> None:
-        pass
+        """nothing persistent to restore for the text table"""
 
     def print(self, msg: str, color="green") -> None:
         print(msg)
 
 
 class DummyLogger(BaseLogger):
-    """Swallows everything (fsrl/utils/logger/base_logger.py DummyLogger)."""
+    """Accumulates and forgets: no directory, no table, no checkpoints."""
 
     def __init__(self, *args, **kwarg) -> None:
+        self.name, self.log_dir, self.checkpoint_fn = "dummy", None, None
+        self._table, self._want_table = None, False
         self.reset_data()
-        self.checkpoint_fn = None
-        self.log_dir = None
-        self.output_file = None
-
-    def store(self, *args, **kwarg):
-        pass
-
-    def write(self, *args, **kwarg):
-        pass
-
-    def print(self, *args, **kwarg):
-        pass
-
-    def save_checkpoint(self, *args, **kwarg):
-        pass
-
-    def get_mean(self, key):
-        return 0.0
-
-    @property
-    def stats_mean(self):
-        return {}
