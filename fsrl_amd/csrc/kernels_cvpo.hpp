@@ -367,8 +367,7 @@ struct CvpoFinalArgs {
     int n_tiles_q, n_q, B;
     float thres;
 };
-__global__ __launch_bounds__(64) void cvpo_finalize_kernel(const CvpoFinalArgs a) {
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void cvpo_finalize_row(const CvpoFinalArgs& a, const int lane) {
     double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // td^2 of up to four Q-nets, sum y_r, sum y_c
     for (int t = lane; t < a.n_tiles_q; t += 64) {
 #pragma unroll

@@ -306,8 +306,7 @@ struct SacFinalArgs {
     int auto_alpha, use_lagrangian;
     int n_q;                 // Q-networks in statp_q: 4 (two double critics) or 2 (DDPG-Lag: single critics)
 };
-__global__ __launch_bounds__(64) void sac_finalize_kernel(const SacFinalArgs a) {
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void sac_finalize_row(const SacFinalArgs& a, const int lane) {
     // nine sums over the tiles (4 x td^2, 4 x min-Q, log pi): lanes stride the tiles, then a fixed
     // xor-tree adds the lanes (float64, order independent of scheduling)
     double s9[9];
@@ -357,4 +356,26 @@ __global__ __launch_bounds__(64) void sac_finalize_kernel(const SacFinalArgs a) 
         o[0] = a.rescale; o[1] = a.lam; o[2] = actor_safety; o[3] = alpha_loss; o[4] = alpha_value;
         o[5] = actor_rew; o[6] = actor_total; o[7] = q0; o[8] = q1; o[9] = q0 + q1;
     }
+}
+
+// The last Adam pass of an update with the update's bookkeeping riding along: blocks [0, gridDim.x - 1) step the
+// parameters exactly as adam_range_kernel does (one shared adam_element), the extra block writes the logged row
+// (FINAL = sac_finalize_row / cvpo_finalize_row) -- one kernel boundary less per update.
+template <class FinalArgs, void (*FINAL)(const FinalArgs&, int)>
+__global__ __launch_bounds__(256) void adam_final_kernel(float* __restrict__ P, float* __restrict__ M, float* __restrict__ V,
+                                                        const float* __restrict__ G, int n, float one_minus_b1, float beta2,
+                                                        float one_minus_b2, float step_size, float bc2_sqrt, float eps,
+                                                        int nparts, int stride, const ModelDesc md, float* __restrict__ tgt,
+                                                        float tau, float one_minus_tau, const FinalArgs fa) {
+    if (blockIdx.x == gridDim.x - 1) {
+        if (threadIdx.x < 64) FINAL(fa, threadIdx.x);
+        return;
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float p = P[i];
+    float gs = G[i];                                       // split-K partials of fb_wgrad_kernel, z order
+    for (int z = 1; z < nparts; ++z) gs += G[(size_t)z * stride + i];
+    adam_element(P, M, V, i, p, gs, 1.0f, 0.0f, one_minus_b1, beta2, one_minus_b2, step_size, bc2_sqrt, eps, md, tgt, tau,
+                 one_minus_tau);
 }
