@@ -38,22 +38,32 @@ struct CvpoActorArgs {
     float* statp;            // [n_tiles][FB_NSTAT]
     int B, K, mode;
     float max_action;
+    // a second batch in the same launch (tiles_half > 0): workgroups [tiles_half, 2 * tiles_half) run mode2 with the actor
+    // P2 on obs2 / eps2 into X2.  Used for TARGET (current actor at s_{t+n}) + PARTICLES (actor_old at s_t): neither
+    // depends on the critic step in between.
+    const float* P2; const float* obs2; const float* eps2; float* X2; int mode2, tiles_half;
 };
 
 template <int H, int R>
-__global__ __launch_bounds__(4 * H) void cvpo_actor_tile_kernel(const float* __restrict__ P,
+__global__ __launch_bounds__(4 * H) void cvpo_actor_tile_kernel(const float* __restrict__ P_,
                                                                const ModelDesc md, const CvpoActorArgs a) {
     __shared__ TileSmem<H> sm;
     constexpr int NT = TileGeom<H>::NT;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
-    const int row0 = blockIdx.x * R;
+    const bool second = a.tiles_half > 0 && (int)blockIdx.x >= a.tiles_half;
+    const float* __restrict__ P = second ? a.P2 : P_;
+    const float* __restrict__ obs_ = second ? a.obs2 : a.obs;
+    const float* __restrict__ eps_ = second ? a.eps2 : a.eps;
+    float* __restrict__ X_ = second ? a.X2 : a.X;
+    const int mode = second ? a.mode2 : a.mode;
+    const int row0 = (second ? (int)blockIdx.x - a.tiles_half : (int)blockIdx.x) * R;
     const NetOff no = md.net[0];
     const int Do = md.Do, Da = md.Da, Din = Do + Da;
     const int n_valid = max(0, min(R, a.B - row0));
 
     TileStage<H> stg;
-    stg.issue(P, no, Do, 0, a.obs + (size_t)row0 * Do, nullptr, n_valid, tid);
+    stg.issue(P, no, Do, 0, obs_ + (size_t)row0 * Do, nullptr, n_valid, tid);
     FwdW2Frag<H> wf;
     wf.load(P + no.W2f, wave, lane);
     for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
@@ -62,7 +72,7 @@ __global__ __launch_bounds__(4 * H) void cvpo_actor_tile_kernel(const float* __r
     tile_forward<H, R>(sm, P, no, Do, tid, wf);     // sm.out[i][0..Da) = mean head, [Da..2Da) = raw log sigma
 
     float wb[H / 16][4];
-    if (a.mode == CVPO_A_MBWD) {
+    if (mode == CVPO_A_MBWD) {
         const float* __restrict__ W2c = P + no.W2 + wave * 16 + li;
 #pragma unroll
         for (int jc = 0; jc < H / 16; ++jc) {
@@ -70,12 +80,12 @@ __global__ __launch_bounds__(4 * H) void cvpo_actor_tile_kernel(const float* __r
             for (int s = 0; s < 4; ++s) wb[jc][s] = W2c[(size_t)(16 * jc + 4 * q + s) * H];
         }
     }
-    if (a.mode == CVPO_A_PARTICLES) {               // observation columns of the K replicated rows
+    if (mode == CVPO_A_PARTICLES) {               // observation columns of the K replicated rows
         const int per = n_valid * Do;
         for (int e = tid; e < a.K * per; e += NT) {
             const int k = e / per, w = e - k * per;
             const int i = w / Do, f = w - i * Do;
-            a.X[((size_t)k * a.B + row0 + i) * Din + f] = a.obs[(size_t)(row0 + i) * Do + f];
+            X_[((size_t)k * a.B + row0 + i) * Din + f] = obs_[(size_t)(row0 + i) * Do + f];
         }
     }
     if (tid < 16 * R) {
@@ -90,15 +100,15 @@ __global__ __launch_bounds__(4 * H) void cvpo_actor_tile_kernel(const float* __r
             pass = (lraw >= SAC_LOG_SIG_MIN && lraw <= SAC_LOG_SIG_MAX) ? 1.0f : 0.0f;
             sig = expf(fminf(fmaxf(lraw, SAC_LOG_SIG_MIN), SAC_LOG_SIG_MAX));
         }
-        if (a.mode == CVPO_A_TARGET) {
-            if (on) a.X[(size_t)r * Din + Do + d] = a.eps[(size_t)r * Da + d] * sig + mu;
-        } else if (a.mode == CVPO_A_PARTICLES) {
+        if (mode == CVPO_A_TARGET) {
+            if (on) X_[(size_t)r * Din + Do + d] = eps_[(size_t)r * Da + d] * sig + mu;
+        } else if (mode == CVPO_A_PARTICLES) {
             if (on) {
                 a.mu_old[(size_t)r * Da + d] = mu;
                 a.std_old[(size_t)r * Da + d] = sig;
                 for (int k = 0; k < a.K; ++k) {
                     const size_t rk = (size_t)k * a.B + r;
-                    a.X[rk * Din + Do + d] = a.eps[rk * Da + d] * sig + mu;     // Normal.sample: eps * std + mean
+                    X_[rk * Din + Do + d] = eps_[rk * Da + d] * sig + mu;     // Normal.sample: eps * std + mean
                 }
             }
         } else {
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(4 * H) void cvpo_actor_tile_kernel(const float* __r
                 klm = 0.5f * (dmu * dmu) / var_oc;
                 kls = 0.5f * (logf(var_c / var_oc) + var_oc / var_c - 1.0f);
                 ent = (0.5f + 0.5f * 1.8378770664093453f + lso) + (0.5f + 0.5f * 1.8378770664093453f + ls);
-                if (a.mode == CVPO_A_MBWD) {
+                if (mode == CVPO_A_MBWD) {
                     const float invB = 1.0f / (float)a.B, invKB = invB / (float)a.K;
                     const float dual_mu = a.sc->dual_mu, dual_std = a.sc->dual_std;
                     // d loss_mle / d mu, / d sigma   (loss_mle = -mean_{k,b} w * loglik)
@@ -149,9 +159,9 @@ __global__ __launch_bounds__(4 * H) void cvpo_actor_tile_kernel(const float* __r
             }
         }
     }
-    if (a.mode < CVPO_A_MFWD) return;
+    if (mode < CVPO_A_MFWD) return;
     __syncthreads();
-    if (a.mode == CVPO_A_MFWD) {
+    if (mode == CVPO_A_MFWD) {
         if (tid < 4) {
             float t = 0.0f;
             for (int i = 0; i < R; ++i) t += sm.w1[i * FB_NSTAT + tid];

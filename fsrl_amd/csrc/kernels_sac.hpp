@@ -140,33 +140,43 @@ struct SacActorArgs {
     int B, mode;
     float rescale;       // lagrangian rescaling 1/(sum(lambda)+1)
     int auto_alpha; float alpha_fixed;
+    // FWD only: a second batch in the same launch (tiles_half > 0): workgroups [tiles_half, 2 * tiles_half) evaluate the
+    // actor P2 on obs2 / eps2 into X2 / lp2.  One launch then serves both a' ~ pi(s_{t+n}) for the targets and a ~ pi(s_t)
+    // for the actor step -- neither depends on the critic update in between.
+    const float* P2; const float* obs2; const float* eps2; float* X2; float* lp2; int tiles_half;
 };
 
 template <int H, int R>
-__global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __restrict__ P,
+__global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __restrict__ P_,
                                                               const ModelDesc md, const SacActorArgs a) {
     __shared__ TileSmem<H> sm;
     constexpr int NT = TileGeom<H>::NT;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
-    const int row0 = blockIdx.x * R;
+    const bool second = a.tiles_half > 0 && (int)blockIdx.x >= a.tiles_half;
+    const float* __restrict__ Pn = second ? a.P2 : P_;
+    const float* __restrict__ obs_ = second ? a.obs2 : a.obs;
+    const float* __restrict__ eps_ = second ? a.eps2 : a.eps;
+    float* __restrict__ X_ = second ? a.X2 : a.X;
+    float* __restrict__ lp_ = second ? a.lp2 : a.lp_out;
+    const int row0 = (second ? (int)blockIdx.x - a.tiles_half : (int)blockIdx.x) * R;
     const NetOff no = md.net[0];
     const int Do = md.Do, Da = md.Da;
     const int n_valid = max(0, min(R, a.B - row0));
     const float invB = 1.0f / (float)a.B;
 
     TileStage<H> stg;
-    stg.issue(P, no, Do, 0, a.obs + (size_t)row0 * Do, nullptr, n_valid, tid);
+    stg.issue(Pn, no, Do, 0, obs_ + (size_t)row0 * Do, nullptr, n_valid, tid);
     FwdW2Frag<H> wf;
-    wf.load(P + no.W2f, wave, lane);
+    wf.load(Pn + no.W2f, wave, lane);
     for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
     stg.commit(sm, no, Do, tid);
     __syncthreads();
-    tile_forward<H, R>(sm, P, no, Do, tid, wf);     // sm.out[i][0..Da) = mu, [Da..2Da) = raw log sigma
+    tile_forward<H, R>(sm, Pn, no, Do, tid, wf);     // sm.out[i][0..Da) = mu, [Da..2Da) = raw log sigma
 
     float wb[H / 16][4];
     if (a.mode == SAC_A_BWD) {
-        const float* __restrict__ W2c = P + no.W2 + wave * 16 + li;
+        const float* __restrict__ W2c = Pn + no.W2 + wave * 16 + li;
 #pragma unroll
         for (int jc = 0; jc < H / 16; ++jc) {
 #pragma unroll
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
             float th = 0.0f;
             if (valid && d < Da) th = tanhf(sm.out[i * FSRL_MAX_ACT + d]);
             if (a.mode == SAC_A_FWD) {
-                if (valid && d < Da) a.X[(size_t)r * (Do + Da) + Do + d] = a.max_action * th;
+                if (valid && d < Da) X_[(size_t)r * (Do + Da) + Do + d] = a.max_action * th;
             } else if (valid && d < Da) {
                 // dL/da_d = (cr * dQ_r/da_d + cc * dQ_c/da_d) / B ; a_d = max_action * tanh(out_d)
                 const float ga = (a.cr * invB) * a.DA[((size_t)0 * a.B + r) * Da + d] +
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
             const float lraw = sm.out[i * FSRL_MAX_ACT + Da + d];
             pass = (lraw >= SAC_LOG_SIG_MIN && lraw <= SAC_LOG_SIG_MAX) ? 1.0f : 0.0f;
             sig = expf(fminf(fmaxf(lraw, SAC_LOG_SIG_MIN), SAC_LOG_SIG_MAX));
-            ep = a.eps[(size_t)r * Da + d];
+            ep = eps_[(size_t)r * Da + d];
             const float u = mu + ep * sig;
             const float dv = u - mu;
             act = tanhf(u);
@@ -208,8 +218,8 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
         // reference; summed per dim here (difference: fp32 rounding only)
         for (int dd = 0; dd < Da; ++dd) logp += __shfl(lpd, (lane & 48) + dd, 64);
         if (a.mode == SAC_A_FWD) {
-            if (valid && d < Da) a.X[(size_t)r * (Do + Da) + Do + d] = act;
-            if (valid && d == 0) a.lp_out[r] = logp;
+            if (valid && d < Da) X_[(size_t)r * (Do + Da) + Do + d] = act;
+            if (valid && d == 0) lp_[r] = logp;
         } else if (valid && d < Da) {
             // dL/da_d = sum over the two double critics of weight * d min(Q1,Q2)/da_d / B ; torch's
             // tie rule for min: the smaller one gets the gradient, equal values share it
