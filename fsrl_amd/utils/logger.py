@@ -3,7 +3,7 @@
 Call surface of fsrl/utils/logger/base_logger.py as this path uses it: `store(tab=None, **scalars)` accumulates running
 means between two `write(step)` calls; `stats_mean` / `get_mean` read them; `save_checkpoint(suffix)` pickles whatever
 `setup_checkpoint_fn` registered; `progress.txt` receives one tab-separated row per `write`.  TensorBoard / W&B writers
-are outside this path; `DummyLogger` only accumulates."""
+are outside this path; `DummyLogger` drops everything."""
 import os
 import time
 from typing import Callable, Dict, Iterable, List, Optional
@@ -121,9 +121,29 @@ class BaseLogger:
 
 
 class DummyLogger(BaseLogger):
-    """Accumulates and forgets: no directory, no table, no checkpoints."""
+    """The sink of runs that log nothing: every call is accepted and dropped (no accumulation either -- the policies store
+    a dozen scalars per optimiser step), reads return zeros / an empty dict."""
 
     def __init__(self, *args, **kwarg) -> None:
         self.name, self.log_dir, self.checkpoint_fn = "dummy", None, None
         self._table, self._want_table = None, False
         self.reset_data()
+
+    def store(self, *args, **kwarg) -> None:
+        pass
+
+    def write(self, *args, **kwarg) -> None:
+        pass
+
+    def print(self, *args, **kwarg) -> None:
+        pass
+
+    def save_checkpoint(self, *args, **kwarg) -> None:
+        pass
+
+    def get_mean(self, key: str) -> float:
+        return 0.0
+
+    @property
+    def stats_mean(self) -> dict:
+        return {}
