@@ -137,6 +137,10 @@ class CVPO(BasePolicy):
         self._dirty = True
 
     def _log_rows(self, rows) -> None:
+        table = getattr(self.logger, "store_rows", None)         # fsrl_amd loggers take the drained rows at once
+        if table is not None and len(rows):
+            table([k if tab is None else tab + "/" + k for tab, k in CVPO_KEYS], rows)
+            return
         for st in rows:
             v = [float(x) for x in st]
             self.logger.store(tab="loss", estep_loss=v[0])

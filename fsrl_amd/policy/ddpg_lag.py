@@ -98,6 +98,12 @@ class DDPGLagrangian(LagrangianPolicy):
         raise NotImplementedError("the HIP path runs process_fn + learn inside update()")
 
     def _log_rows(self, rows) -> None:
+        table = getattr(self.logger, "store_rows", None)         # fsrl_amd loggers take the drained rows at once
+        if table is not None and len(rows):
+            drop = _DROP + (() if self.use_lagrangian else ("loss/lagrangian", "loss/actor_safety"))
+            cols = [j for j, k in enumerate(SAC_KEYS) if k not in drop]
+            table([SAC_KEYS[j] for j in cols], np.asarray(rows)[:, cols])
+            return
         for st in rows:
             d = {k: float(v) for k, v in zip(SAC_KEYS, st) if k not in _DROP}
             if not self.use_lagrangian:

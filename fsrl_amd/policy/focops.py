@@ -78,7 +78,10 @@ class FOCOPS(BasePolicy):
                 self.logger.print("Early stop at step %d due to reaching max kl." % step)
                 break
         stats = eng.ppo_end_stats(max(1, -(-n // max(batch_size, 1))) * max(repeat, 1))[:, :_lib.FOCOPS_NSTATS]
-        for row in stats:
+        table = getattr(self.logger, "store_rows", None)         # fsrl_amd loggers take the per-step table at once
+        if table is not None:
+            table(FOCOPS_KEYS, stats)
+        for row in (stats if table is None else ()):
             d = dict(zip(FOCOPS_KEYS, (float(v) for v in row)))
             self.logger.store(**{k: d[k] for k in FOCOPS_KEYS[:2]})
             self.logger.store(**{k: d[k] for k in FOCOPS_KEYS[2:5]})

@@ -99,7 +99,10 @@ class PPOLagrangian(LagrangianPolicy):
                 break
         steps_per_pass = max(1, -(-n // max(batch_size, 1)))
         stats = eng.ppo_end_stats(steps_per_pass * max(repeat, 1))
-        for row in stats:                                        # one row per optimiser step
+        table = getattr(self.logger, "store_rows", None)         # fsrl_amd loggers take the per-step table at once
+        if table is not None:
+            table(PPO_STAT_KEYS, stats)
+        for row in (stats if table is None else ()):             # any other logger: the reference's per-step calls
             d = dict(zip(PPO_STAT_KEYS, (float(v) for v in row)))
             total, entropy = d.pop("loss/total"), d.pop("loss/entropy")
             self.logger.store(**d)

@@ -137,6 +137,13 @@ class SACLagrangian(LagrangianPolicy):
         return act + self._noise(act.shape) if isinstance(act, np.ndarray) else act
 
     def _log_rows(self, rows) -> None:
+        table = getattr(self.logger, "store_rows", None)         # fsrl_amd loggers take the drained rows at once
+        if table is not None and len(rows):
+            drop = (() if self._is_auto_alpha else ("loss/alpha_loss", "loss/alpha_value")) + \
+                   (() if self.use_lagrangian else ("loss/lagrangian", "loss/actor_safety"))
+            cols = [j for j, k in enumerate(SAC_KEYS) if k not in drop]
+            table([SAC_KEYS[j] for j in cols], np.asarray(rows)[:, cols])
+            return
         for st in rows:
             d = dict(zip(SAC_KEYS, (float(v) for v in st)))
             if not self._is_auto_alpha:

@@ -19,8 +19,12 @@ class _Means:
         self._n: Dict[str, int] = {}
 
     def add(self, name: str, value) -> None:
-        self._sum[name] = self._sum.get(name, 0.0) + float(np.mean(value))
-        self._n[name] = self._n.get(name, 0) + 1
+        v = value if isinstance(value, (int, float)) else float(np.mean(value))
+        self.add_sum(name, v, 1)
+
+    def add_sum(self, name: str, total: float, count: int) -> None:
+        self._sum[name] = self._sum.get(name, 0.0) + total
+        self._n[name] = self._n.get(name, 0) + count
 
     def names(self) -> List[str]:
         return list(self._sum)
@@ -49,6 +53,15 @@ class BaseLogger:
         prefix = "" if tab is None else tab + "/"
         for key, value in kwargs.items():
             self._means.add(prefix + key, value)
+
+    def store_rows(self, keys, rows) -> None:
+        """`rows[i][j]` = value of `keys[j]` at optimiser step i: the same running means as one store() per row, taken
+        as column sums -- the policies hand over the whole per-update table the device wrote (hundreds of rows)."""
+        rows = np.asarray(rows, np.float64)
+        if rows.size == 0:
+            return
+        for key, total in zip(keys, rows.sum(axis=0)):
+            self._means.add_sum(key, float(total), rows.shape[0])
 
     @property
     def logger_keys(self) -> Iterable[str]:
@@ -130,6 +143,9 @@ class DummyLogger(BaseLogger):
         self.reset_data()
 
     def store(self, *args, **kwarg) -> None:
+        pass
+
+    def store_rows(self, *args, **kwarg) -> None:
         pass
 
     def write(self, *args, **kwarg) -> None:

