@@ -77,6 +77,7 @@ SIGNATURES = {
     "fsrl_actor_forward": (C.c_int, [_ctx, _f, C.c_int32, _f, _f]),
     "fsrl_ppo_begin": (C.c_int, [_ctx, _d, C.c_double, C.c_int32, _i64]),
     "fsrl_ppo_pass": (C.c_int, [_ctx, _i64, C.c_uint64, _i32]),
+    "fsrl_ppo_pass_result": (C.c_int, [_ctx, _i32]),
     "fsrl_ppo_end": (C.c_int, [_ctx, _f, C.c_int64, _i64]),
     "fsrl_ppo_update": (C.c_int, [_ctx, _d, C.c_double, C.c_int32, C.c_int32, _i64, C.c_uint64, _f,
                                   C.c_int64, _i64, _i32]),

@@ -77,6 +77,7 @@ struct fsrl_ctx {
     int64_t adam_t = 0;
     CtrlBlock* ctrl = nullptr;
     CtrlBlock* h_ctrl = nullptr;  // pinned
+    bool verdict_pending = false; // a pass's stop flag is on its way to h_ctrl (fsrl_ppo_pass with stopped_out == NULL)
 
     // store
     int64_t sub_size = 0, maxsize = 0;
@@ -148,6 +149,7 @@ static void sac_free(fsrl_ctx* c);
 static void tr_free(fsrl_ctx* c);
 static void foc_free(fsrl_ctx* c);
 static int focops_pass(fsrl_ctx* c, int32_t* stopped_out);
+static int pass_verdict(fsrl_ctx* c, int32_t* stopped_out);
 
 // Make the rows pushed so far visible to the compute stream: flush the staging window and order the side stream's
 // copies before whatever the compute stream runs next.  Off-policy trainers call update() many times between collects;

@@ -229,12 +229,19 @@ class Engine:
         self._n = n.value
         return n.value
 
-    def ppo_pass(self, perm=None, seed: int = 0) -> bool:
+    def ppo_pass(self, perm=None, seed: int = 0, wait: bool = True) -> bool:
+        """One pass of minibatch steps -> True if the KL early stop fired.  wait=False only enqueues the pass (returns
+        False); ppo_pass_result() then collects the verdict -- the caller can prepare the next pass meanwhile."""
         stopped = C.c_int32()
         if perm is not None:
             perm = np.ascontiguousarray(perm, np.int64)
             assert perm.size == self._n, "permutation length != batch length"
-        _lib.check(self.lib.fsrl_ppo_pass(self._ctx, _ptr(perm, _i64p), int(seed), C.byref(stopped)))
+        _lib.check(self.lib.fsrl_ppo_pass(self._ctx, _ptr(perm, _i64p), int(seed), C.byref(stopped) if wait else None))
+        return bool(stopped.value)
+
+    def ppo_pass_result(self) -> bool:
+        stopped = C.c_int32()
+        _lib.check(self.lib.fsrl_ppo_pass_result(self._ctx, C.byref(stopped)))
         return bool(stopped.value)
 
     def ppo_end(self):

@@ -68,12 +68,19 @@ class FOCOPS(BasePolicy):
             for m in _chunk_sizes(n, self._max_batchsize):
                 torch.normal(torch.zeros(m, da), torch.ones(m, da))
         stopped_at = -1
+        perm = np.random.permutation(n) if n > 0 else None           # Batch.split(shuffle=True) of the first pass
         for step in range(repeat):
-            perm = np.random.permutation(n) if n > 0 else None       # Batch.split(shuffle=True)
             if burn:                                                 # policy_loss: forward per minibatch
                 for m in _chunk_sizes(n, batch_size):
                     torch.normal(torch.zeros(m, da), torch.ones(m, da))
-            if eng.ppo_pass(perm):
+            eng.ppo_pass(perm, wait=False)
+            # next permutation while the device works; rolled back if this pass was the last (see ppo_lag.py here)
+            rng_state = np.random.get_state() if (n > 0 and step + 1 < repeat) else None
+            if rng_state is not None:
+                perm = np.random.permutation(n)
+            if eng.ppo_pass_result():
+                if rng_state is not None:
+                    np.random.set_state(rng_state)
                 stopped_at = step
                 self.logger.print("Early stop at step %d due to reaching max kl." % step)
                 break

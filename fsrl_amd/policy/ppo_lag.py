@@ -89,11 +89,19 @@ class PPOLagrangian(LagrangianPolicy):
         if burn:                                                 # process_fn's forward over chunks of max_batchsize
             self._burn_samples(_chunk_sizes(n, self._max_batchsize))
         stopped_at = -1
+        perm = np.random.permutation(n) if n > 0 else None       # Batch.split(shuffle=True) of the first pass
         for step in range(repeat):                               # ppo_lag.py:217
-            perm = np.random.permutation(n) if n > 0 else None   # Batch.split(shuffle=True)
             if burn:
                 self._burn_samples(_chunk_sizes(n, batch_size))  # one forward per minibatch
-            if eng.ppo_pass(perm):
+            eng.ppo_pass(perm, wait=False)
+            # the next pass's permutation is drawn while the device runs this one; if this pass turns out to be the last
+            # (KL early stop) numpy's stream is rolled back, so it stays where the reference's would be
+            rng_state = np.random.get_state() if (n > 0 and step + 1 < repeat) else None
+            if rng_state is not None:
+                perm = np.random.permutation(n)
+            if eng.ppo_pass_result():
+                if rng_state is not None:
+                    np.random.set_state(rng_state)
                 stopped_at = step
                 self.logger.print("Early stop at step %d due to reaching max kl." % step)
                 break

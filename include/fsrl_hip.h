@@ -146,6 +146,9 @@ int fsrl_ppo_begin(fsrl_ctx* ctx, const double* lagrangians, double rescaling,
  * 1.5*target_kl (the caller must then stop calling, like the reference's break).
  * perm == NULL: the library draws its own permutation (xoshiro256**, seeded by `seed`).  */
 int fsrl_ppo_pass(fsrl_ctx* ctx, const int64_t* perm, uint64_t seed, int32_t* stopped_out);
+/* stopped_out == NULL above only enqueues the pass: the caller may draw the next permutation while the device works
+ * (rolling its RNG back if the pass turns out to be the last) and collects the verdict here before the next call.       */
+int fsrl_ppo_pass_result(fsrl_ctx* ctx, int32_t* stopped_out);
 /* end: drains per-minibatch stats ([n_steps][FSRL_PPO_NSTATS] float32, row-major).       */
 int fsrl_ppo_end(fsrl_ctx* ctx, float* stats_out, int64_t cap_steps, int64_t* n_steps_out);
 /* convenience: begin + `repeat` passes (perms = [repeat][n] or NULL) + end.              */

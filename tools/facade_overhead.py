@@ -9,9 +9,10 @@ from fsrl_amd.env import SyntheticSafetyVectorEnv  # noqa: E402
 from fsrl_amd.utils import BaseLogger  # noqa: E402
 
 env = SyntheticSafetyVectorEnv(env_num=20, obs_dim=8, act_dim=2, episode_len=1000, seed=0)
-for name, logger in (("BaseLogger", BaseLogger(tempfile.mkdtemp(), name="x")), ("no logger", None)):
+for name, logger, tkl in (("BaseLogger", BaseLogger(tempfile.mkdtemp(), name="x"), None), ("no logger", None, None),
+                          ("KL check on", None, 1e6)):       # target_kl set (never reached): one readback per pass
     agent = PPOLagAgent(env, logger, cost_limit=10, device="cuda:0", seed=0, hidden_sizes=(256, 256), max_grad_norm=0.5,
-                        target_kl=None, training_num=20)
+                        target_kl=tkl, training_num=20)
     agent.policy.train()
     buf = HipVectorReplayBuffer(agent.policy.engine, 100000, 20)
     col = FastCollector(agent.policy, env, buf, exploration_noise=True, device_actor=True)
