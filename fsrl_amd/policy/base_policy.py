@@ -69,13 +69,23 @@ class BasePolicy(ABC, nn.Module):
         self._push_params()
 
     # ------------------------------------------------------------------ parameter plumbing
-    def _flat_params(self) -> np.ndarray:
+    def _flat_params(self, fresh: bool = True) -> np.ndarray:
+        """The host mirror as one vector (refreshed from the device first when an update has run since)"""
+        if fresh and getattr(self, "_stale", False):
+            self._pull_params()
         return torch.cat([p.detach().reshape(-1) for p in self._actor_critic.parameters()]).numpy().astype(np.float32)
 
     def _push_params(self) -> None:
-        self.engine.set_params(self._flat_params())
+        self._stale = False                      # the mirror is the source now
+        self.engine.set_params(self._flat_params(fresh=False))
+
+    def _mark_stale(self) -> None:
+        """The device parameters moved on (an update ran): the host mirror is refreshed when it is next needed -- acting on
+        the host, state_dict() -- not after every update (collecting with the device actor never needs it)."""
+        self._stale = True
 
     def _pull_params(self) -> None:
+        self._stale = False
         flat = torch.from_numpy(self.engine.get_params())
         off = 0
         with torch.no_grad():
@@ -84,14 +94,22 @@ class BasePolicy(ABC, nn.Module):
                 p.copy_(flat[off:off + n].view_as(p))
                 off += n
 
+    def state_dict(self, *args, **kwargs):
+        if getattr(self, "_stale", False):
+            self._pull_params()
+        return super().state_dict(*args, **kwargs)
+
     def load_state_dict(self, state_dict, strict: bool = True):
         out = super().load_state_dict(state_dict, strict=strict)
         if self.engine is not None:
             self._push_params()
+            self._stale = False
         return out
 
     # ------------------------------------------------------------------ acting
     def forward(self, batch: Batch, state=None, **kwargs: Any) -> Batch:
+        if getattr(self, "_stale", False):
+            self._pull_params()
         logits, hidden = self.actor(batch.obs, state=state)
         dist = self.dist_fn(*logits) if isinstance(logits, tuple) else self.dist_fn(logits)
         if self._deterministic_eval and not self.training:

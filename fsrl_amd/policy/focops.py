@@ -95,7 +95,7 @@ class FOCOPS(BasePolicy):
             self.logger.store(**{k: d[k] for k in FOCOPS_KEYS[5:]})
         self.gradient_steps += len(stats)
         self.logger.store(gradient_steps=self.gradient_steps, tab="update")
-        self._pull_params()
+        self._mark_stale()                                       # host mirror refreshed on demand
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()
         self.updating = False

@@ -117,7 +117,7 @@ class PPOLagrangian(LagrangianPolicy):
             self.logger.store(total=total, entropy=entropy, tab="loss")
         self.gradient_steps += len(stats)
         self.logger.store(gradient_steps=self.gradient_steps, tab="update")
-        self._pull_params()                                      # host mirror for acting / checkpoints
+        self._mark_stale()                                       # host mirror refreshed on demand
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()
         self.updating = False

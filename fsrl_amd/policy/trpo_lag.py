@@ -76,7 +76,7 @@ class TRPOLagrangian(LagrangianPolicy):
         self.logger.store(gradient_steps=self.gradient_steps, tab="update")
         if n > 0:   # process_fn: one forward; per repeat: 2 forward(s) + one per line-search evaluation
             self._burn(n, 1 + 2 * len(stats) + int(eng.tr_linesearch_evals().sum()))
-        self._pull_params()
+        self._mark_stale()                                       # host mirror refreshed on demand
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()
         self.updating = False
