@@ -587,7 +587,9 @@ static int launch_infer(fsrl_ctx* c, const InferArgs& ia, int jobs_y, hipStream_
     if (tiles == 0) return 0;
     return dispatch_H(c->cfg.hidden, [&](auto hc) {
         constexpr int H = decltype(hc)::value;
-        hipLaunchKernelGGL(mlp_infer_kernel<H>, dim3(tiles, jobs_y), dim3(4 * H), 0, s, c->P, c->md, ia);
+        // persistent over tiles: about one workgroup per CU in total (their LDS footprint allows no more)
+        const int gx = std::min(tiles, std::max(1, c->n_cus / jobs_y));
+        hipLaunchKernelGGL(mlp_infer_kernel<H>, dim3(gx, jobs_y), dim3(4 * H), 0, s, c->P, c->md, ia);
         HIPCHK(hipGetLastError());
         return 0;
     });
