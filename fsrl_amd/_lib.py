@@ -70,9 +70,14 @@ SIGNATURES = {
     "fsrl_params_get": (C.c_int, [_ctx, _f, C.c_int64]),
     "fsrl_grads_get": (C.c_int, [_ctx, _f, C.c_int64]),
     "fsrl_optim_reset": (C.c_int, [_ctx]),
+    "fsrl_set_lr": (C.c_int, [_ctx, C.c_int32, C.c_float]),
+    "fsrl_get_lr": (C.c_float, [_ctx, C.c_int32]),
+    "fsrl_ppo_abort": (C.c_int, [_ctx]),
     "fsrl_store_push": (C.c_int, [_ctx, _i32, C.c_int32, _f, _f, _d, _d, _u8, _u8, _f, _i64, _d, _i32, _i64]),
     "fsrl_store_reset": (C.c_int, [_ctx, C.c_int]),
     "fsrl_store_len": (C.c_int64, [_ctx]),
+    "fsrl_store_configure": (C.c_int, [_ctx, C.c_int64, C.c_int32]),
+    "fsrl_store_geometry": (C.c_int, [_ctx, _i64, _i32]),
     "fsrl_store_sample0": (C.c_int, [_ctx, _i64, C.c_int64, _i64]),
     "fsrl_actor_forward": (C.c_int, [_ctx, _f, C.c_int32, _f, _f]),
     "fsrl_ppo_begin": (C.c_int, [_ctx, _d, C.c_double, C.c_int32, _i64]),

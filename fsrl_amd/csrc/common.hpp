@@ -75,8 +75,16 @@ struct PpoStepArgs {
     double kl_thresh;  // 1.5 * target_kl in float64 (python float in the reference)
     float step_size;   // lr / (1 - beta1^t)          (host float64 -> f32, like torch)
     float bc2_sqrt;    // sqrt(1 - beta2^t)
-    int dbg_phase;     // 0 = normal; >0: timing experiments only (env FSRL_DBG_PHASE), results invalid
+    int dbg_phase;     // probe builds only (-DFSRL_PROBES, env FSRL_DBG_PHASE): early-exit timing experiments, results invalid
 };
+// Early-exit timing probes of the step kernels (tools/phase_probe.sh).  They exist only in a build with -DFSRL_PROBES
+// (fsrl_amd/csrc/build.sh --probes -> libfsrl_hip_probe.so); in the shipped library the conditions fold to false and
+// no environment variable can change a result.
+#ifdef FSRL_PROBES
+#define FSRL_PROBE(sa, n) ((sa).dbg_phase == (n))
+#else
+#define FSRL_PROBE(sa, n) false
+#endif
 
 // Device-resident control block (one per context).
 struct CtrlBlock {

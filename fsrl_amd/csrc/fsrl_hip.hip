@@ -81,6 +81,8 @@ struct fsrl_ctx {
 
     // store
     int64_t sub_size = 0, maxsize = 0;
+    int64_t alloc_rows = 0;            // rows every store / batch array was allocated for (fsrl_store_configure stays inside)
+    int active_envs = 0;               // sub-buffers in use (<= cfg.env_num)
     std::vector<EnvBook> env;
     std::vector<uint8_t> h_flags;      // host mirror of (terminated|truncated<<1) per slot
     StorePtrs st{};
@@ -136,7 +138,11 @@ struct fsrl_ctx {
     int actor_k = 0; size_t actor_ob = 0, actor_mb = 0;  // geometry of the actor evaluation in flight
     unsigned* h_done = nullptr; int done_cap = 0;        // pinned per-block completion words of that evaluation
     unsigned actor_seq = 0; int actor_blocks = 0;
-    bool no_spin = getenv("FSRL_NO_SPIN") != nullptr;   // A/B switch: wait with hipStreamSynchronize instead
+    // timing-probe switches: always 0 / false in the shipped library; a -DFSRL_PROBES build reads them ONCE, at
+    // fsrl_ctx_create, from FSRL_DBG_PHASE / FSRL_TILE16 / FSRL_WGRAD_SKIP / FSRL_NO_SPIN (tools/phase_probe.sh)
+    int probe_phase = 0, probe_wgrad_skip = 0;
+    bool probe_tile16 = false;
+    bool no_spin = false;           // wait for the collector's actor with hipStreamSynchronize instead of the completion words
     std::vector<float> act_mu, act_sg;                   // mean / std of the last actor evaluation (host)
     std::vector<int> perm_tmp;      // this pass's permutation before it goes to the pinned buffer
     hipEvent_t perm_copied = nullptr; bool perm_in_flight = false;
@@ -148,6 +154,8 @@ struct fsrl_ctx {
 static void sac_free(fsrl_ctx* c);
 static void tr_free(fsrl_ctx* c);
 static void foc_free(fsrl_ctx* c);
+static void tr_reset_optim(fsrl_ctx* c);
+static void foc_reset_optim(fsrl_ctx* c);
 static int focops_pass(fsrl_ctx* c, int32_t* stopped_out);
 static int pass_verdict(fsrl_ctx* c, int32_t* stopped_out);
 
@@ -207,7 +215,7 @@ static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int n
     int rc = ensure_parts(c, stride, pl.nsplit);
     if (rc) return rc;
     wa.out = c->wg_parts; wa.ks_per_split = pl.ks_per_split; wa.split_stride = stride;
-    { const char* e = getenv("FSRL_WGRAD_SKIP"); wa.dbg_skip = e ? atoi(e) : 0; }
+    wa.dbg_skip = c->probe_wgrad_skip;
     *nsplit = pl.nsplit;
     return dispatch_H(c->cfg.hidden, [&](auto hc) {
         constexpr int HH = decltype(hc)::value;
@@ -331,6 +339,12 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     c->cfg = *cfg;
     c->device = device_id;
     c->n_cus = n_cus_probe > 0 ? n_cus_probe : 256;
+#ifdef FSRL_PROBES
+    { const char* e = getenv("FSRL_DBG_PHASE"); c->probe_phase = e ? atoi(e) : 0; }
+    { const char* e = getenv("FSRL_WGRAD_SKIP"); c->probe_wgrad_skip = e ? atoi(e) : 0; }
+    c->probe_tile16 = getenv("FSRL_TILE16") != nullptr;
+    c->no_spin = getenv("FSRL_NO_SPIN") != nullptr;
+#endif
     build_layout(c);
 #define TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { fail(FSRL_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); fsrl_ctx_destroy(c); return FSRL_EHIP; } } while (0)
     TRY(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
@@ -344,6 +358,7 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     // store: n sub-buffers of ceil(total/n) rows (tianshou VectorReplayBuffer)
     c->sub_size = (cfg->buffer_size + cfg->env_num - 1) / cfg->env_num;
     c->maxsize = c->sub_size * cfg->env_num;
+    c->alloc_rows = c->maxsize; c->active_envs = cfg->env_num;
     c->env.resize(cfg->env_num);
     c->h_flags.assign((size_t)c->maxsize, 0);
     const size_t ms = (size_t)c->maxsize;
@@ -433,6 +448,8 @@ extern "C" int fsrl_optim_reset(fsrl_ctx* c) {
     HIPCHK(hipMemsetAsync(c->V, 0, (size_t)c->n_dev * 4, c->compute));
     HIPCHK(hipStreamSynchronize(c->compute));
     c->adam_t = 0;
+    tr_reset_optim(c);                                          // the critics' optimiser of CPO / TRPO-Lag shares M / V
+    foc_reset_optim(c);
     return 0;
 }
 
@@ -472,13 +489,13 @@ extern "C" int fsrl_store_push(fsrl_ctx* c, const int32_t* env_ids, int32_t k, c
                                const float* obs_next, int64_t* ptr_out, double* ep_rew_out,
                                int32_t* ep_len_out, int64_t* ep_idx_out) {
     CHECK_ARG(c && env_ids && obs && act && rew && terminated && truncated && obs_next, "null argument");
-    CHECK_ARG(k >= 0 && k <= c->cfg.env_num, "k=%d rows but %d sub-buffers", k, c->cfg.env_num);
+    CHECK_ARG(k >= 0 && k <= c->active_envs, "k=%d rows but %d sub-buffers", k, c->active_envs);
     HIPCHK(hipSetDevice(c->device));
     c->store_version += 1;
     const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim;
     for (int j = 0; j < k; ++j) {
         const int e = env_ids[j];
-        CHECK_ARG(e >= 0 && e < c->cfg.env_num, "buffer id %d out of range", e);
+        CHECK_ARG(e >= 0 && e < c->active_envs, "buffer id %d out of range", e);
         // flush when the window is full -- or when this sub-buffer would wrap onto a slot that is
         // already in the window: the scatter kernel writes a window's rows in parallel, so one slot
         // must not appear twice in it (windows themselves are ordered on the side stream)
@@ -525,13 +542,47 @@ extern "C" int fsrl_store_push(fsrl_ctx* c, const int32_t* env_ids, int32_t k, c
 
 extern "C" int fsrl_store_reset(fsrl_ctx* c, int keep_statistics) {
     CHECK_ARG(c, "null ctx");
-    (void)keep_statistics;
     HIPCHK(hipSetDevice(c->device));
     int rc = flush_stage(c);   // rows already staged still land (then become unreachable)
     if (rc) return rc;
-    for (EnvBook& e : c->env) e = EnvBook();
+    // tianshou-0.5 ReplayBuffer.reset(keep_statistics): index / size / last_index go back to zero; the running episode's
+    // reward, length and start index survive when keep_statistics is set (OnpolicyTrainer resets the buffer after every
+    // update, fsrl/trainer/onpolicy.py:109, while episodes are still in flight)
+    for (EnvBook& e : c->env) {
+        EnvBook fresh;
+        if (keep_statistics) { fresh.ep_rew = e.ep_rew; fresh.ep_len = e.ep_len; fresh.ep_idx = e.ep_idx; }
+        e = fresh;
+    }
     c->batch_ready = false;
     c->store_version += 1;
+    return 0;
+}
+
+// VectorReplayBuffer(total_size, buffer_num) as the agents' learn() builds it (fsrl/agent/base_agent.py:279): re-cut the
+// allocated store into buffer_num sub-buffers of ceil(total_size / buffer_num) rows.  The new geometry must fit the
+// allocation made at fsrl_ctx_create (cfg.buffer_size rows, cfg.env_num sub-buffers); the store is emptied.
+extern "C" int fsrl_store_configure(fsrl_ctx* c, int64_t total_size, int32_t buffer_num) {
+    CHECK_ARG(c, "null ctx");
+    CHECK_ARG(buffer_num >= 1 && buffer_num <= c->cfg.env_num, "buffer_num %d: the context has %d sub-buffers", buffer_num,
+              c->cfg.env_num);
+    CHECK_ARG(total_size >= buffer_num, "total_size must be >= buffer_num");
+    const int64_t sub = (total_size + buffer_num - 1) / buffer_num;
+    CHECK_ARG(sub * buffer_num <= c->alloc_rows,
+              "a store of %lld x %d rows does not fit the %lld rows allocated at fsrl_ctx_create (buffer_size)",
+              (long long)sub, buffer_num, (long long)c->alloc_rows);
+    CHECK_ARG(!c->in_update, "fsrl_store_configure inside an update");
+    int rc = fsrl_store_reset(c, 0);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->side));
+    c->sub_size = sub;
+    c->maxsize = sub * buffer_num;
+    c->active_envs = buffer_num;
+    std::fill(c->h_flags.begin(), c->h_flags.end(), (uint8_t)0);
+    return 0;
+}
+extern "C" int fsrl_store_geometry(const fsrl_ctx* c, int64_t* sub_size_out, int32_t* buffer_num_out) {
+    CHECK_ARG(c && sub_size_out && buffer_num_out, "null argument");
+    *sub_size_out = c->sub_size; *buffer_num_out = c->active_envs;
     return 0;
 }
 
@@ -831,6 +882,16 @@ extern "C" int fsrl_gae_return(fsrl_ctx* c, const float* v, const float* v_next,
 
 #include "host_ppo.inc"
 
+// abandon an update that began with fsrl_ppo_begin and cannot reach fsrl_ppo_end (an exception between the calls on the
+// caller's side): drain the stream, clear the state machine.  No-op outside an update.
+extern "C" int fsrl_ppo_abort(fsrl_ctx* c) {
+    CHECK_ARG(c, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->in_update) (void)hipStreamSynchronize(c->compute);
+    c->in_update = false; c->verdict_pending = false;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ timing
 extern "C" int fsrl_set_profiling(fsrl_ctx* c, int enable) {
     CHECK_ARG(c, "null ctx");
@@ -851,3 +912,40 @@ extern "C" int fsrl_last_timing(fsrl_ctx* c, double* out, int32_t n) {
 #include "host_sac.inc"
 
 #include "host_cvpo.inc"
+
+// ------------------------------------------------------------------------------ learning rates
+// lr_scheduler.step() of BasePolicy.update (fsrl/policy/base_policy.py:352-354): the caller's scheduler owns the
+// schedule, this call moves the result into the engine.  Takes effect from the next optimiser step.
+extern "C" int fsrl_set_lr(fsrl_ctx* c, int32_t group, float lr) {
+    CHECK_ARG(c, "null ctx");
+    CHECK_ARG(lr >= 0.0f && std::isfinite(lr), "learning rate must be finite and >= 0");
+    if (ctx_is_replay(c)) {
+        SacState* s = sac_of(c);
+        if (!s) return fail(FSRL_ESTATE, "fsrl_set_lr before fsrl_sac_init / fsrl_cvpo_init");
+        CHECK_ARG(group >= 0 && group <= 2, "replay contexts: group 0 actor, 1 critics, 2 alpha");
+        if (group == 0) { s->cfg.actor_lr = lr; if (s->cvpo) s->ccfg.actor_lr = lr; }
+        else if (group == 1) { s->cfg.critic_lr = lr; if (s->cvpo) s->ccfg.critic_lr = lr; }
+        else s->cfg.alpha_lr = lr;
+        return 0;
+    }
+    if (c->cfg.algo == FSRL_ALGO_FOCOPS) {
+        if (!c->foc) return fail(FSRL_ESTATE, "fsrl_set_lr before fsrl_focops_init");
+        CHECK_ARG(group == 0 || group == 1, "FOCOPS: group 0 actor, 1 critics");
+        if (group == 0) c->foc->cfg.actor_lr = lr; else c->foc->cfg.critic_lr = lr;
+        return 0;
+    }
+    CHECK_ARG(group == 0, "on-policy contexts have one optimiser (group 0)");
+    c->cfg.lr = lr;
+    if (c->tr) c->tr->cfg.critic_lr = lr;      // CPO / TRPO-Lag: the optimiser steps the critics (fsrl_tr_begin re-reads it too)
+    return 0;
+}
+extern "C" float fsrl_get_lr(const fsrl_ctx* c, int32_t group) {
+    if (!c) return -1.0f;
+    if (c->cfg.algo == FSRL_ALGO_SAC_LAG) {
+        const SacState* s = reinterpret_cast<const SacState*>(c->sac);
+        if (!s) return -1.0f;
+        return group == 0 ? s->cfg.actor_lr : group == 1 ? s->cfg.critic_lr : group == 2 ? s->cfg.alpha_lr : -1.0f;
+    }
+    if (c->cfg.algo == FSRL_ALGO_FOCOPS) return !c->foc ? -1.0f : group == 0 ? c->foc->cfg.actor_lr : group == 1 ? c->foc->cfg.critic_lr : -1.0f;
+    return group == 0 ? c->cfg.lr : -1.0f;
+}

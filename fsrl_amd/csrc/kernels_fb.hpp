@@ -587,8 +587,10 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
     const int c = lane & 15, q = lane >> 4;
     const int Do = md.Do, out = no.out;
 
+#ifdef FSRL_PROBES
     if (wa.dbg_skip && ((rb < NT2 && (wa.dbg_skip & 1)) || (rb >= NT2 && rb < NT2 + NA && (wa.dbg_skip & 2)) ||
                         (rb >= NT2 + NA && (wa.dbg_skip & 4)))) return;
+#endif
     if (rb < NT2) {
         // ---- dW2[j][k] += sum_r Ya[r][j] Xa[r][k] (+ Yb Xb): a 64 x 64 tile per block, 16-way split-K over
         // the waves.  Per k-step (4 rows) a lane loads ONE float4 of each operand (256 B contiguous per

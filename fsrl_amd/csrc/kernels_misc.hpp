@@ -227,7 +227,7 @@ __global__ __launch_bounds__(ADAM_NT) void adam_clip_kernel(float* __restrict__ 
     __shared__ double sh[ADAM_NT / 64];
     __shared__ float coef_s;
     const int tid = threadIdx.x;
-    if (sa.dbg_phase == 30) return;                     // launch floor of this kernel (timing experiments only)
+    if (FSRL_PROBE(sa, 30)) return;                     // launch floor of this kernel (timing experiments only)
     const int i4 = (blockIdx.x * ADAM_NT + tid) * 4;   // float4 per thread
     // issue every load of this thread first (one cold round trip), then reduce the norm
     f32x4 g = {0, 0, 0, 0}, m = g, v = g, p = g;

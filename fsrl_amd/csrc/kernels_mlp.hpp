@@ -398,12 +398,12 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
 
     // ---- prologue: ONE burst of independent loads (W2 slice, obs tile, row data, small
     //      parameters); nothing below waits on a second cold round trip.
-    if (sa.dbg_phase == 10) return;                     // pure launch floor of this kernel
+    if (FSRL_PROBE(sa, 10)) return;                     // pure launch floor of this kernel
     TileStage<H> stg;
     stg.issue(P, no, Do, Da, bp.obs_p + grow0 * Do, bp.rd_p + grow0 * FSRL_RD, n_valid, tid);
-    if (sa.dbg_phase == 13) { asm volatile("" ::"v"(stg.b1v), "v"(stg.xv[0])); return; }
+    if (FSRL_PROBE(sa, 13)) { asm volatile("" ::"v"(stg.b1v), "v"(stg.xv[0])); return; }
     FwdW2Frag<H> wf;
-    if (sa.dbg_phase == 14) {                           // a quarter of the W2 burst
+    if (FSRL_PROBE(sa, 14)) {                           // a quarter of the W2 burst
         const float* row = P + no.W2 + (size_t)(wave * 16 + li) * H + 4 * q;
 #pragma unroll
         for (int kc = 0; kc < H / 64; ++kc) wf.b[kc] = *reinterpret_cast<const f32x4*>(row + 16 * kc);
@@ -412,20 +412,20 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
     }
     wf.load(P + no.W2f, wave, lane);
     for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
-    if (sa.dbg_phase == 11) {                           // loads issued, nobody waits for them
+    if (FSRL_PROBE(sa, 11)) {                           // loads issued, nobody waits for them
         asm volatile("" ::"v"(stg.b1v), "v"(wf.b[0]));
         return;
     }
     stg.commit(sm, no, Do, tid);
-    if (sa.dbg_phase == 12) {                           // + small loads landed, W2 not awaited
+    if (FSRL_PROBE(sa, 12)) {                           // + small loads landed, W2 not awaited
         asm volatile("" ::"v"(wf.b[0]));
         return;
     }
-    if (sa.dbg_phase == 9) return;                      // launch + address setup only
+    if (FSRL_PROBE(sa, 9)) return;                      // launch + address setup only
     __syncthreads();
-    if (sa.dbg_phase == 1) { if (wf.b[0][0] == 123.f && sm.xT[tid] == 1.f) bp.statp[0] = 1.f; return; }
+    if (FSRL_PROBE(sa, 1)) { if (wf.b[0][0] == 123.f && sm.xT[tid] == 1.f) bp.statp[0] = 1.f; return; }
     tile_forward<H, R>(sm, P, no, Do, tid, wf);
-    if (sa.dbg_phase == 4) { if (sm.out[tid & 15] == 123.f) bp.statp[0] = 1.f; return; }
+    if (FSRL_PROBE(sa, 4)) { if (sm.out[tid & 15] == 123.f) bp.statp[0] = 1.f; return; }
     const size_t nb = (size_t)net * bp.mbp_max;
     {   // spill relu(z1), relu(z2) for the weight-gradient kernel now: the stores retire while
         // the loss head and the backward GEMM run (coalesced float4)
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
         }
     }
 
-    if (sa.dbg_phase == 5) { if (wb[0][0] == 123.f) bp.statp[0] = 1.f; return; }
+    if (FSRL_PROBE(sa, 5)) { if (wb[0][0] == 123.f) bp.statp[0] = 1.f; return; }
     // ---- loss head: thread (row i = tid>>4, dim d = tid&15), 16-lane shuffles per row
     if (tid < 16 * R) {
         const int i = tid >> 4, d = tid & 15;
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
         bp.statp[((size_t)tile * md.n_nets + net) * 4 + tid] = t;
     }
 
-    if (sa.dbg_phase == 6) { if (wb[0][0] == 123.f) bp.statp[1] = 1.f; return; }
+    if (FSRL_PROBE(sa, 6)) { if (wb[0][0] == 123.f) bp.statp[1] = 1.f; return; }
     // ---- dL/dz2 = (dout @ W3) * relu'(z2); thread = (column k, group of 4 rows)
     if (R == 16 || tid < H) {
         const int k = tid % H, rg = tid / H;
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
             acc[r] += __shfl_xor(acc[r], 16, 64);
             acc[r] += __shfl_xor(acc[r], 32, 64);
         }
-        if (sa.dbg_phase == 7) { if (acc[0] == 123.f) bp.statp[1] = 1.f; return; }
+        if (FSRL_PROBE(sa, 7)) { if (acc[0] == 123.f) bp.statp[1] = 1.f; return; }
         if (q == 0) {
             float* __restrict__ D1 = bp.D1 + (nb + row0) * H;
             const int col = wave * 16 + li;
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = mfma_16x16x4(a[s], wb[jc][s], acc);
         }
-        if (sa.dbg_phase == 7) { if (acc[0] == 123.f) bp.statp[1] = 1.f; return; }
+        if (FSRL_PROBE(sa, 7)) { if (acc[0] == 123.f) bp.statp[1] = 1.f; return; }
         float* __restrict__ D1 = bp.D1 + (nb + row0) * H;
         const int col = wave * 16 + li;
 #pragma unroll
@@ -694,9 +694,9 @@ __global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, con
     __shared__ float red[1024 * 9];      // 8 split-K partial slots of a 32x32 tile / aux reduce scratch
     __shared__ float wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (sa.dbg_phase == 20) return;
+    if (FSRL_PROBE(sa, 20)) return;
     if ((int)blockIdx.x == md.n_nets * PB) {  // the stats block
-        if (sa.dbg_phase == 21 || sa.dbg_phase == 22) return;
+        if (FSRL_PROBE(sa, 21) || FSRL_PROBE(sa, 22)) return;
         if (wave == 0) ppo_stats_finalize(md, wp, sa, n_stat_tiles, lane);
         // db3[o] / dsigma[d] = column sums of DO over the minibatch rows, for every network:
         // thread (col = tid & 31, row phase = tid >> 5); all loads of a thread in one burst
@@ -745,9 +745,9 @@ __global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, con
     const float* __restrict__ DOb = wp.DO + nb * FSRL_DOW;
     float sq = 0.0f;
 
-    if (sa.dbg_phase == 23) return;
-    if (sa.dbg_phase == 21 && rb >= NT2) return;
-    if (sa.dbg_phase == 22 && rb < NT2) return;
+    if (FSRL_PROBE(sa, 23)) return;
+    if (FSRL_PROBE(sa, 21) && rb >= NT2) return;
+    if (FSRL_PROBE(sa, 22) && rb < NT2) return;
     if (rb < NT2) {
         // ---- dW2[j][k] = sum_r D2[r][j] * A1[r][k]; wave w takes k-steps s = w, w+16, ...
         const int tj = rb / TPD, tk = rb % TPD;

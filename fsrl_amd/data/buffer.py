@@ -10,10 +10,17 @@ import numpy as np
 class HipVectorReplayBuffer:
     def __init__(self, engine, total_size=None, buffer_num=None):
         self.engine = engine
-        self.buffer_num = engine.cfg.env_num if buffer_num is None else buffer_num
+        self.buffer_num = engine.cfg.env_num if buffer_num is None else int(buffer_num)
         assert self.buffer_num <= engine.cfg.env_num, "more sub-buffers requested than the engine has"
-        self.maxsize = engine.cfg.buffer_size
-        self._sub = -(-engine.cfg.buffer_size // engine.cfg.env_num)      # rows per sub-buffer
+        total = engine.cfg.buffer_size if total_size is None else int(total_size)
+        # the reference cuts VectorReplayBuffer(total_size, buffer_num) into ceil(total / num)-row sub-buffers
+        # (base_agent.py:279): take exactly that geometry (slot ids, wrap-around, sample indices depend on it);
+        # it has to fit what the engine allocated, otherwise the C ABI refuses (AssertionError)
+        want_sub = -(-total // self.buffer_num)
+        if (want_sub, self.buffer_num) != engine.store_geometry():
+            engine.store_configure(total, self.buffer_num)
+        self._sub, _ = engine.store_geometry()
+        self.maxsize = self._sub * self.buffer_num
         self._sizes = np.zeros(engine.cfg.env_num, np.int64)             # host mirror of the fill levels
 
     def add(self, batch, buffer_ids=None):

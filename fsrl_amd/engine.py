@@ -101,6 +101,16 @@ class Engine:
     def optim_reset(self):
         _lib.check(self.lib.fsrl_optim_reset(self._ctx))
 
+    def set_lr(self, group: int, lr: float):
+        """Learning rate of one optimiser (fsrl_set_lr): what lr_scheduler.step() produced on the host."""
+        _lib.check(self.lib.fsrl_set_lr(self._ctx, int(group), float(lr)))
+
+    def get_lr(self, group: int = 0) -> float:
+        return float(self.lib.fsrl_get_lr(self._ctx, int(group)))
+
+    def ppo_abort(self):
+        _lib.check(self.lib.fsrl_ppo_abort(self._ctx))
+
     # ---------------------------------------------------------------- store
     def push(self, env_ids, obs, act, rew, cost, terminated, truncated, obs_next):
         """VectorReplayBuffer.add for k rows -> (ptr, ep_rew, ep_len, ep_idx).  Called once per vector step:
@@ -134,6 +144,16 @@ class Engine:
 
     def __len__(self):
         return int(self.lib.fsrl_store_len(self._ctx))
+
+    def store_configure(self, total_size: int, buffer_num: int):
+        """VectorReplayBuffer(total_size, buffer_num): re-cut the allocated store (empties it)."""
+        _lib.check(self.lib.fsrl_store_configure(self._ctx, int(total_size), int(buffer_num)))
+
+    def store_geometry(self):
+        """-> (rows per sub-buffer, sub-buffers in use)"""
+        sub, num = C.c_int64(), C.c_int32()
+        _lib.check(self.lib.fsrl_store_geometry(self._ctx, C.byref(sub), C.byref(num)))
+        return int(sub.value), int(num.value)
 
     def sample0(self):
         n = C.c_int64()
@@ -260,11 +280,15 @@ class Engine:
         n = self.ppo_begin(lagrangians, rescaling, batch_size)
         stopped_pass = -1
         steps_per_pass = max(1, -(-n // max(batch_size, 1)))
-        for k in range(repeat):
-            if self.ppo_pass(None if perms is None else perms[k], seed + k if seed else 0):
-                stopped_pass = k
-                break
-        stats = self.ppo_end_stats(steps_per_pass * max(repeat, 1))
+        try:
+            for k in range(repeat):
+                if self.ppo_pass(None if perms is None else perms[k], seed + k if seed else 0):
+                    stopped_pass = k
+                    break
+            stats = self.ppo_end_stats(steps_per_pass * max(repeat, 1))
+        except BaseException:
+            self.ppo_abort()                     # a bad permutation / HIP error must not wedge the begin ... end state
+            raise
         return stats, stopped_pass
 
     def batch_get(self, which: str):

@@ -106,6 +106,29 @@ class BasePolicy(ABC, nn.Module):
             self._stale = False
         return out
 
+    # ------------------------------------------------------------------ learning-rate schedule
+    def _lr_groups(self):
+        """(engine optimiser group, host torch optimiser) pairs; include/fsrl_hip.h fsrl_set_lr names the groups."""
+        groups = []
+        if getattr(self, "optim", None) is not None:
+            groups.append((0, self.optim))
+        if getattr(self, "actor_optim", None) is not None:
+            groups.append((0, self.actor_optim))
+        if getattr(self, "critics_optim", None) is not None:
+            groups.append((1, self.critics_optim))
+        if getattr(self, "_alpha_optim", None) is not None:
+            groups.append((2, self._alpha_optim))
+        return groups
+
+    def _step_lr_scheduler(self) -> None:
+        """End of BasePolicy.update (fsrl/policy/base_policy.py:352-354): step the caller's scheduler on the host
+        optimisers, then move every group's new rate into the engine -- the kernels read the engine's copy."""
+        if self.lr_scheduler is None:
+            return
+        self.lr_scheduler.step()
+        for gid, opt in self._lr_groups():
+            self.engine.set_lr(gid, float(opt.param_groups[0]["lr"]))
+
     # ------------------------------------------------------------------ acting
     def forward(self, batch: Batch, state=None, **kwargs: Any) -> Batch:
         if getattr(self, "_stale", False):

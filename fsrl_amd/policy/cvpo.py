@@ -70,6 +70,7 @@ class CVPO(BasePolicy):
         # reference_rng: buffer.sample through numpy's and every Normal.sample through torch's global RNG, in the
         # order the reference consumes them (cvpo.py:208, 331, 334, 382); False: Philox on the device, async updates
         self._dirty, self._reference_rng, self._seed, self._pending = False, reference_rng, int(seed), 0
+        self._rest_dirty = False
 
     def update_cost_limit(self, cost_limit, push: bool = True) -> None:
         """cvpo.py:165-176"""
@@ -92,12 +93,14 @@ class CVPO(BasePolicy):
             SACLagrangian._unflat([self.actor_old], self.engine.sac_get_params(3)[0])
             SACLagrangian._unflat(list(self.critics), self.engine.sac_get_params(1)[0])
             SACLagrangian._unflat(list(self.critics_old), self.engine.sac_get_params(2)[0])
-        self._dirty = False
+        self._dirty = False                      # the actor mirror is current ...
+        if everything:
+            self._rest_dirty = False             # ... critics / targets only after a full pull
 
     def state_dict(self, *args, **kwargs):
         if getattr(self, "_pending", 0):
             self._drain()
-        if getattr(self, "_dirty", False):
+        if getattr(self, "_dirty", False) or getattr(self, "_rest_dirty", False):
             self._pull_params(everything=True)
         return super().state_dict(*args, **kwargs)
 
@@ -106,7 +109,7 @@ class CVPO(BasePolicy):
         if getattr(self, "engine", None) is not None:
             for which, mods in ((0, [self.actor]), (3, [self.actor_old]), (1, list(self.critics)), (2, list(self.critics_old))):
                 self.engine.sac_put_params(which, SACLagrangian._flat(mods))
-            self._dirty = False
+            self._dirty = self._rest_dirty = False
         return out
 
     def get_extra_state(self):
@@ -117,7 +120,7 @@ class CVPO(BasePolicy):
 
     # ------------------------------------------------------------------ acting (host mirror)
     def forward(self, batch: Batch, state=None, model: str = "actor", input: str = "obs", **kwargs: Any) -> Batch:
-        if self._dirty:
+        if self._dirty or (model != "actor" and self._rest_dirty):
             self._pull_params(everything=model != "actor")
         logits, hidden = getattr(self, model)(batch[input], state=state)
         dist = self.dist_fn(*logits) if isinstance(logits, tuple) else self.dist_fn(logits)
@@ -134,7 +137,7 @@ class CVPO(BasePolicy):
     def post_update_fn(self, **kwarg: Any) -> None:
         self._drain()
         self.engine.cvpo_post_update()
-        self._dirty = True
+        self._dirty = self._rest_dirty = True      # actor mirror AND critics / targets are behind the device now
 
     def _log_rows(self, rows) -> None:
         table = getattr(self.logger, "store_rows", None)         # fsrl_amd loggers take the drained rows at once
@@ -175,8 +178,7 @@ class CVPO(BasePolicy):
             if self._pending >= 2048:
                 self._drain()
         self.gradient_steps += 1
-        self._dirty = True
-        if self.lr_scheduler is not None:
-            self.lr_scheduler.step()
+        self._dirty = self._rest_dirty = True      # actor mirror AND critics / targets are behind the device now
+        self._step_lr_scheduler()
         self.updating = False
         return {}

@@ -50,6 +50,7 @@ class DDPGLagrangian(LagrangianPolicy):
                              exploration_sigma=getattr(exploration_noise, "_sigma", 0.0))
         self.engine.sac_set_params(SACLagrangian._flat([self.actor]), SACLagrangian._flat(list(self.critics)), 0.0)
         self._dirty, self._reference_rng, self._seed, self._pending = False, reference_rng, int(seed), 0
+        self._rest_dirty = False
 
     def set_exp_noise(self, noise) -> None:
         self._noise = noise
@@ -66,12 +67,14 @@ class DDPGLagrangian(LagrangianPolicy):
             SACLagrangian._unflat([self.actor_old], self.engine.sac_get_params(3)[0])
             SACLagrangian._unflat(list(self.critics), self.engine.sac_get_params(1)[0])
             SACLagrangian._unflat(list(self.critics_old), self.engine.sac_get_params(2)[0])
-        self._dirty = False
+        self._dirty = False                      # the actor mirror is current ...
+        if everything:
+            self._rest_dirty = False             # ... critics / targets only after a full pull
 
     def state_dict(self, *args, **kwargs):
         if self._pending:
             self._drain()
-        if self._dirty:
+        if self._dirty or self._rest_dirty:
             self._pull_params(everything=True)
         return super().state_dict(*args, **kwargs)
 
@@ -80,11 +83,11 @@ class DDPGLagrangian(LagrangianPolicy):
         if getattr(self, "engine", None) is not None:
             for which, mods in ((0, [self.actor]), (3, [self.actor_old]), (1, list(self.critics)), (2, list(self.critics_old))):
                 self.engine.sac_put_params(which, SACLagrangian._flat(mods))
-            self._dirty = False
+            self._dirty = self._rest_dirty = False
         return out
 
     def forward(self, batch: Batch, state=None, model: str = "actor", input: str = "obs", **kwargs: Any) -> Batch:
-        if self._dirty:
+        if self._dirty or (model != "actor" and self._rest_dirty):
             self._pull_params(everything=model != "actor")
         actions, hidden = getattr(self, model)(batch[input], state=state)
         return Batch(act=actions, state=hidden)
@@ -138,8 +141,7 @@ class DDPGLagrangian(LagrangianPolicy):
             if self._pending >= 2048:
                 self._drain()
         self.gradient_steps += 1
-        self._dirty = True
-        if self.lr_scheduler is not None:
-            self.lr_scheduler.step()
+        self._dirty = self._rest_dirty = True      # actor mirror AND critics / targets are behind the device now
+        self._step_lr_scheduler()
         self.updating = False
         return {}

@@ -62,29 +62,34 @@ class FOCOPS(BasePolicy):
         eng = self.engine
         _lib.check(eng.lib.fsrl_focops_set_nu(eng._ctx, float(self._nu), float(loss_nu)))
         n = eng.ppo_begin([0.0], 1.0, batch_size)
-        burn = self._reference_rng and (self.training or not self._deterministic_eval)
-        da = eng.cfg.act_dim
-        if burn:                                                     # process_fn: forward per chunk of max_batchsize
-            for m in _chunk_sizes(n, self._max_batchsize):
-                torch.normal(torch.zeros(m, da), torch.ones(m, da))
-        stopped_at = -1
-        perm = np.random.permutation(n) if n > 0 else None           # Batch.split(shuffle=True) of the first pass
-        for step in range(repeat):
-            if burn:                                                 # policy_loss: forward per minibatch
-                for m in _chunk_sizes(n, batch_size):
+        try:
+            burn = self._reference_rng and (self.training or not self._deterministic_eval)
+            da = eng.cfg.act_dim
+            if burn:                                                     # process_fn: forward per chunk of max_batchsize
+                for m in _chunk_sizes(n, self._max_batchsize):
                     torch.normal(torch.zeros(m, da), torch.ones(m, da))
-            eng.ppo_pass(perm, wait=False)
-            # next permutation while the device works; rolled back if this pass was the last (see ppo_lag.py here)
-            rng_state = np.random.get_state() if (n > 0 and step + 1 < repeat) else None
-            if rng_state is not None:
-                perm = np.random.permutation(n)
-            if eng.ppo_pass_result():
+            stopped_at = -1
+            perm = np.random.permutation(n) if n > 0 else None           # Batch.split(shuffle=True) of the first pass
+            for step in range(repeat):
+                if burn:                                                 # policy_loss: forward per minibatch
+                    for m in _chunk_sizes(n, batch_size):
+                        torch.normal(torch.zeros(m, da), torch.ones(m, da))
+                eng.ppo_pass(perm, wait=False)
+                # next permutation while the device works; rolled back if this pass was the last (see ppo_lag.py here)
+                rng_state = np.random.get_state() if (n > 0 and step + 1 < repeat) else None
                 if rng_state is not None:
-                    np.random.set_state(rng_state)
-                stopped_at = step
-                self.logger.print("Early stop at step %d due to reaching max kl." % step)
-                break
-        stats = eng.ppo_end_stats(max(1, -(-n // max(batch_size, 1))) * max(repeat, 1))[:, :_lib.FOCOPS_NSTATS]
+                    perm = np.random.permutation(n)
+                if eng.ppo_pass_result():
+                    if rng_state is not None:
+                        np.random.set_state(rng_state)
+                    stopped_at = step
+                    self.logger.print("Early stop at step %d due to reaching max kl." % step)
+                    break
+            stats = eng.ppo_end_stats(max(1, -(-n // max(batch_size, 1))) * max(repeat, 1))[:, :_lib.FOCOPS_NSTATS]
+        except BaseException:                                        # never leave the library between begin and end
+            eng.ppo_abort()
+            self.updating = False
+            raise
         table = getattr(self.logger, "store_rows", None)         # fsrl_amd loggers take the per-step table at once
         if table is not None:
             table(FOCOPS_KEYS, stats)
@@ -96,7 +101,6 @@ class FOCOPS(BasePolicy):
         self.gradient_steps += len(stats)
         self.logger.store(gradient_steps=self.gradient_steps, tab="update")
         self._mark_stale()                                       # host mirror refreshed on demand
-        if self.lr_scheduler is not None:
-            self.lr_scheduler.step()
+        self._step_lr_scheduler()
         self.updating = False
         return {"gradient_steps": len(stats), "early_stop_pass": stopped_at}

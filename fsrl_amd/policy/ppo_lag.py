@@ -85,40 +85,52 @@ class PPOLagrangian(LagrangianPolicy):
         lags, rescaling = self.lagrangians_and_rescaling() if self.use_lagrangian else ([], 1.0)
         eng = self.engine
         n = eng.ppo_begin(lags, rescaling, batch_size)          # buffer.sample(0) + process_fn
-        burn = self._reference_rng and (self.training or not self._deterministic_eval)
-        if burn:                                                 # process_fn's forward over chunks of max_batchsize
-            self._burn_samples(_chunk_sizes(n, self._max_batchsize))
-        stopped_at = -1
-        perm = np.random.permutation(n) if n > 0 else None       # Batch.split(shuffle=True) of the first pass
-        for step in range(repeat):                               # ppo_lag.py:217
-            if burn:
-                self._burn_samples(_chunk_sizes(n, batch_size))  # one forward per minibatch
-            eng.ppo_pass(perm, wait=False)
-            # the next pass's permutation is drawn while the device runs this one; if this pass turns out to be the last
-            # (KL early stop) numpy's stream is rolled back, so it stays where the reference's would be
-            rng_state = np.random.get_state() if (n > 0 and step + 1 < repeat) else None
-            if rng_state is not None:
-                perm = np.random.permutation(n)
-            if eng.ppo_pass_result():
+        try:                                                     # begin ... end is a state machine in the library:
+            burn = self._reference_rng and (self.training or not self._deterministic_eval)
+            if burn:                                                 # process_fn's forward over chunks of max_batchsize
+                self._burn_samples(_chunk_sizes(n, self._max_batchsize))
+            stopped_at = -1
+            perm = np.random.permutation(n) if n > 0 else None       # Batch.split(shuffle=True) of the first pass
+            for step in range(repeat):                               # ppo_lag.py:217
+                if burn:
+                    self._burn_samples(_chunk_sizes(n, batch_size))  # one forward per minibatch
+                eng.ppo_pass(perm, wait=False)
+                # the next pass's permutation is drawn while the device runs this one; if this pass turns out to be the last
+                # (KL early stop) numpy's stream is rolled back, so it stays where the reference's would be
+                rng_state = np.random.get_state() if (n > 0 and step + 1 < repeat) else None
                 if rng_state is not None:
-                    np.random.set_state(rng_state)
-                stopped_at = step
-                self.logger.print("Early stop at step %d due to reaching max kl." % step)
-                break
-        steps_per_pass = max(1, -(-n // max(batch_size, 1)))
-        stats = eng.ppo_end_stats(steps_per_pass * max(repeat, 1))
+                    perm = np.random.permutation(n)
+                if eng.ppo_pass_result():
+                    if rng_state is not None:
+                        np.random.set_state(rng_state)
+                    stopped_at = step
+                    self.logger.print("Early stop at step %d due to reaching max kl." % step)
+                    break
+            steps_per_pass = max(1, -(-n // max(batch_size, 1)))
+            stats = eng.ppo_end_stats(steps_per_pass * max(repeat, 1))
+        except BaseException:                                    # leave it (and `updating`) clean on any error / interrupt
+            eng.ppo_abort()
+            self.updating = False
+            raise
+        # keys the reference would not log in this configuration (lagrangian_base.py:158-165, ppo_lag.py:169-170)
+        drop = set()
+        if not self.use_lagrangian or self.critics_num < 2:
+            drop |= {"loss/lagrangian", "loss/actor_safety"}
+        if self.critics_num < 2:
+            drop.add("loss/vf1")
+        cols = [j for j, k in enumerate(PPO_STAT_KEYS) if k not in drop]
+        keys = [PPO_STAT_KEYS[j] for j in cols]
         table = getattr(self.logger, "store_rows", None)         # fsrl_amd loggers take the per-step table at once
         if table is not None:
-            table(PPO_STAT_KEYS, stats)
+            table(keys, stats[:, cols] if drop else stats)
         for row in (stats if table is None else ()):             # any other logger: the reference's per-step calls
-            d = dict(zip(PPO_STAT_KEYS, (float(v) for v in row)))
+            d = {k: float(row[j]) for j, k in zip(cols, keys)}
             total, entropy = d.pop("loss/total"), d.pop("loss/entropy")
             self.logger.store(**d)
             self.logger.store(total=total, entropy=entropy, tab="loss")
         self.gradient_steps += len(stats)
         self.logger.store(gradient_steps=self.gradient_steps, tab="update")
         self._mark_stale()                                       # host mirror refreshed on demand
-        if self.lr_scheduler is not None:
-            self.lr_scheduler.step()
+        self._step_lr_scheduler()
         self.updating = False
         return {"gradient_steps": len(stats), "early_stop_pass": stopped_at}

@@ -60,7 +60,7 @@ class SACLagrangian(LagrangianPolicy):
                              alpha=alpha_fixed, target_entropy=self._target_entropy, n_step=n_step,
                              auto_alpha=self._is_auto_alpha, use_lagrangian=use_lagrangian)
         self._push_params()
-        self._dirty = False
+        self._dirty = self._rest_dirty = False
         # reference_rng=True: buffer.sample through numpy's and rsample through torch's global RNG,
         # exactly the streams the reference consumes (bit-comparable runs; one host round trip per
         # update).  False (default): sampling and noise on the device, updates only enqueue work
@@ -95,12 +95,14 @@ class SACLagrangian(LagrangianPolicy):
         if everything:
             self._unflat(list(self.critics), self.engine.sac_get_params(1)[0])
             self._unflat(list(self.critics_old), self.engine.sac_get_params(2)[0])
-        self._dirty = False
+        self._dirty = False                      # the actor mirror is current ...
+        if everything:
+            self._rest_dirty = False             # ... critics / targets only after a full pull
 
     def state_dict(self, *args, **kwargs):
         if getattr(self, "_pending", 0):
             self._drain()
-        if getattr(self, "_dirty", False):
+        if getattr(self, "_dirty", False) or getattr(self, "_rest_dirty", False):
             self._pull_params(everything=True)
         return super().state_dict(*args, **kwargs)
 
@@ -110,7 +112,7 @@ class SACLagrangian(LagrangianPolicy):
             self.engine.sac_put_params(0, self._flat([self.actor]))
             self.engine.sac_put_params(1, self._flat(list(self.critics)))
             self.engine.sac_put_params(2, self._flat(list(self.critics_old)))
-            self._dirty = False
+            self._dirty = self._rest_dirty = False
         return out
 
     def train(self, mode: bool = True):
@@ -186,8 +188,7 @@ class SACLagrangian(LagrangianPolicy):
             if self._pending >= 2048:
                 self._drain()
         self.gradient_steps += 1
-        self._dirty = True
-        if self.lr_scheduler is not None:
-            self.lr_scheduler.step()
+        self._dirty = self._rest_dirty = True      # actor mirror AND critics / targets are behind the device now
+        self._step_lr_scheduler()
         self.updating = False
         return {}

@@ -77,7 +77,6 @@ class TRPOLagrangian(LagrangianPolicy):
         if n > 0:   # process_fn: one forward; per repeat: 2 forward(s) + one per line-search evaluation
             self._burn(n, 1 + 2 * len(stats) + int(eng.tr_linesearch_evals().sum()))
         self._mark_stale()                                       # host mirror refreshed on demand
-        if self.lr_scheduler is not None:
-            self.lr_scheduler.step()
+        self._step_lr_scheduler()
         self.updating = False
         return {"gradient_steps": len(stats)}

@@ -89,6 +89,12 @@ int fsrl_params_set(fsrl_ctx* ctx, const float* flat, int64_t n);
 int fsrl_params_get(fsrl_ctx* ctx, float* flat, int64_t n);
 int fsrl_grads_get(fsrl_ctx* ctx, float* flat, int64_t n);   /* last minibatch gradient  */
 int fsrl_optim_reset(fsrl_ctx* ctx);                /* zero Adam moments and step count  */
+/* lr_scheduler.step() at the end of BasePolicy.update (fsrl/policy/base_policy.py:352-354): the caller's torch
+ * scheduler owns the schedule, this call moves the new rate of one optimiser into the engine; it applies from the next
+ * optimiser step.  group: on-policy contexts 0 (the one Adam; for CPO / TRPO-Lag the critics' Adam); FOCOPS 0 actor,
+ * 1 critics; replay contexts (SAC / DDPG / CVPO) 0 actor, 1 critics, 2 alpha.  fsrl_get_lr returns < 0 for a bad group. */
+int fsrl_set_lr(fsrl_ctx* ctx, int32_t group, float lr);
+float fsrl_get_lr(const fsrl_ctx* ctx, int32_t group);
 
 /* ---- HIP-resident transition store (tianshou VectorReplayBuffer as used at
  *      fsrl/agent/base_agent.py:279, fsrl/data/fast_collector.py:333-335,
@@ -102,6 +108,12 @@ int fsrl_store_push(fsrl_ctx* ctx, const int32_t* env_ids, int32_t k, const floa
                     int32_t* ep_len_out, int64_t* ep_idx_out);
 int fsrl_store_reset(fsrl_ctx* ctx, int keep_statistics);   /* buffer.reset()            */
 int64_t fsrl_store_len(const fsrl_ctx* ctx);                /* len(buffer)               */
+/* VectorReplayBuffer(total_size, buffer_num) built inside learn() (fsrl/agent/base_agent.py:279,
+ * fsrl/agent/sac_lag_agent.py learn): re-cut the store into buffer_num sub-buffers of ceil(total_size / buffer_num)
+ * rows -- slot numbering, wrap-around and sample indices then are the reference's for that geometry.  It must fit the
+ * allocation of fsrl_ctx_create (cfg.buffer_size rows, cfg.env_num sub-buffers), else FSRL_EINVAL; empties the store. */
+int fsrl_store_configure(fsrl_ctx* ctx, int64_t total_size, int32_t buffer_num);
+int fsrl_store_geometry(const fsrl_ctx* ctx, int64_t* sub_size_out, int32_t* buffer_num_out);
 /* buffer.sample_indices(0): env-major, chronological inside each sub-buffer.             */
 int fsrl_store_sample0(fsrl_ctx* ctx, int64_t* indices_out, int64_t cap, int64_t* n_out);
 
@@ -151,6 +163,9 @@ int fsrl_ppo_pass(fsrl_ctx* ctx, const int64_t* perm, uint64_t seed, int32_t* st
 int fsrl_ppo_pass_result(fsrl_ctx* ctx, int32_t* stopped_out);
 /* end: drains per-minibatch stats ([n_steps][FSRL_PPO_NSTATS] float32, row-major).       */
 int fsrl_ppo_end(fsrl_ctx* ctx, float* stats_out, int64_t cap_steps, int64_t* n_steps_out);
+/* abandon an update after fsrl_ppo_begin when fsrl_ppo_end cannot be reached (an exception between the calls on the
+ * caller's side, base_policy.py:345-351 has no such state): drains the stream and clears the begin/end state.       */
+int fsrl_ppo_abort(fsrl_ctx* ctx);
 /* convenience: begin + `repeat` passes (perms = [repeat][n] or NULL) + end.              */
 int fsrl_ppo_update(fsrl_ctx* ctx, const double* lagrangians, double rescaling,
                     int32_t batch_size, int32_t repeat, const int64_t* perms, uint64_t seed,
