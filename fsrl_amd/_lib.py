@@ -76,6 +76,7 @@ SIGNATURES = {
     "fsrl_store_push": (C.c_int, [_ctx, _i32, C.c_int32, _f, _f, _d, _d, _u8, _u8, _f, _i64, _d, _i32, _i64]),
     "fsrl_store_reset": (C.c_int, [_ctx, C.c_int]),
     "fsrl_store_len": (C.c_int64, [_ctx]),
+    "fsrl_store_read": (C.c_int, [_ctx, _i64, C.c_int64, _f, _f, _d, _d, _u8, _u8, _f]),
     "fsrl_store_configure": (C.c_int, [_ctx, C.c_int64, C.c_int32]),
     "fsrl_store_geometry": (C.c_int, [_ctx, _i64, _i32]),
     "fsrl_store_sample0": (C.c_int, [_ctx, _i64, C.c_int64, _i64]),

@@ -42,7 +42,7 @@ class OnpolicyAgent(BaseAgent):
         pass
 
     def learn(self, train_envs, test_envs=None, epoch: int = 300, episode_per_collect: int = 20,
-              step_per_epoch: int = 10000, repeat_per_collect: int = 4, buffer_size: int = 100000,
+              step_per_epoch: int = 10000, repeat_per_collect: int = 4, buffer_size: Optional[int] = None,
               testing_num: int = 2, batch_size: int = 512, reward_threshold: float = 450,
               save_interval: int = 4, resume: bool = False, save_ckpt: bool = True,
               verbose: bool = True, show_progress: bool = True, device_actor: bool = False):
@@ -51,6 +51,9 @@ class OnpolicyAgent(BaseAgent):
         eng = self.policy.engine
         assert eng.cfg.env_num >= len(train_envs), \
             f"agent built for {eng.cfg.env_num} env sub-buffers, got {len(train_envs)} envs (pass training_num)"
+        # VectorReplayBuffer(buffer_size, len(train_envs)) of the reference (base_agent.py:279): the store is re-cut to
+        # that geometry.  None = the size the agent was built with (its `buffer_size`, default 100 000 like the
+        # reference's learn()); an explicit size must fit that allocation (AssertionError otherwise).
         buffer = HipVectorReplayBuffer(eng, buffer_size, len(train_envs))
         train_collector = FastCollector(self.policy, train_envs, buffer, exploration_noise=True,
                                         device_actor=device_actor)   # True: actor + noise on the MI355X

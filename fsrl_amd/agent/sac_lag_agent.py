@@ -21,7 +21,7 @@ class OffpolicyAgent(BaseAgent):
         pass
 
     def learn(self, train_envs, test_envs=None, epoch: int = 300, episode_per_collect: int = 5,
-              step_per_epoch: int = 3000, update_per_step: float = 0.1, buffer_size: int = 100000,
+              step_per_epoch: int = 3000, update_per_step: float = 0.1, buffer_size: Optional[int] = None,
               testing_num: int = 2, batch_size: int = 256, reward_threshold: float = 450,
               save_interval: int = 4, resume: bool = False, save_ckpt: bool = True, verbose: bool = True,
               show_progress: bool = True, device_actor: bool = False):
@@ -29,6 +29,9 @@ class OffpolicyAgent(BaseAgent):
         self.policy.train()
         eng = self.policy.engine
         assert eng.cfg.env_num >= len(train_envs)
+        # VectorReplayBuffer(buffer_size, len(train_envs)) of the reference (base_agent.py:279): the store is re-cut to
+        # that geometry.  None = the size the agent was built with (its `buffer_size`, default 100 000 like the
+        # reference's learn()); an explicit size must fit that allocation (AssertionError otherwise).
         buffer = HipVectorReplayBuffer(eng, buffer_size, len(train_envs))
         train_collector = FastCollector(self.policy, train_envs, buffer, exploration_noise=True,
                                         device_actor=device_actor)   # True: actor + noise on the MI355X

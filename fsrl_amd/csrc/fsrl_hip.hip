@@ -358,10 +358,11 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     // store: n sub-buffers of ceil(total/n) rows (tianshou VectorReplayBuffer)
     c->sub_size = (cfg->buffer_size + cfg->env_num - 1) / cfg->env_num;
     c->maxsize = c->sub_size * cfg->env_num;
-    c->alloc_rows = c->maxsize; c->active_envs = cfg->env_num;
+    // + env_num rows of slack: fsrl_store_configure with fewer sub-buffers rounds ceil(total / n) * n up past `total`
+    c->alloc_rows = c->maxsize + cfg->env_num; c->active_envs = cfg->env_num;
     c->env.resize(cfg->env_num);
-    c->h_flags.assign((size_t)c->maxsize, 0);
-    const size_t ms = (size_t)c->maxsize;
+    c->h_flags.assign((size_t)c->alloc_rows, 0);
+    const size_t ms = (size_t)c->alloc_rows;
     const int Do = cfg->obs_dim, Da = cfg->act_dim;
     TRY(hipMalloc(&c->st.obs, ms * Do * 4)); TRY(hipMalloc(&c->st.obs_next, ms * Do * 4));
     TRY(hipMalloc(&c->st.act, ms * Da * 4)); TRY(hipMalloc(&c->st.rew, ms * 8));
@@ -618,6 +619,54 @@ extern "C" int fsrl_store_sample0(fsrl_ctx* c, int64_t* out, int64_t cap, int64_
     if (out) {
         CHECK_ARG(cap >= n, "indices_out too small (%lld < %lld)", (long long)cap, (long long)n);
         for (int64_t i = 0; i < n; ++i) out[i] = c->h_indices[i];
+    }
+    return 0;
+}
+
+// buffer[indices] (tianshou ReplayBufferManager.__getitem__): the stored rows at the given slots, copied to the host.
+// Not on the training path (the update gathers on the device); evaluation tooling and the parity tests read rows back.
+extern "C" int fsrl_store_read(fsrl_ctx* c, const int64_t* indices, int64_t n, float* obs_out, float* act_out,
+                               double* rew_out, double* cost_out, uint8_t* terminated_out, uint8_t* truncated_out,
+                               float* obs_next_out) {
+    CHECK_ARG(c && (indices || n == 0), "null argument");
+    CHECK_ARG(n >= 0 && n <= c->maxsize, "bad row count");
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = join_store(c);
+    if (rc) return rc;
+    const size_t N = (size_t)n, Do = (size_t)c->cfg.obs_dim, Da = (size_t)c->cfg.act_dim;
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_idx = 0, o_end = o_idx + al(N * 4), o_obs = o_end + al(N), o_nxt = o_obs + al(N * Do * 4),
+                 o_act = o_nxt + al(N * Do * 4), o_rew = o_act + al(N * Da * 4), o_cost = o_rew + al(N * 8),
+                 o_fl = o_cost + al(N * 8), total = o_fl + al(N);
+    rc = ensure_scratch(c, total);
+    if (rc) return rc;
+    std::vector<int> idx(N);
+    for (size_t i = 0; i < N; ++i) {
+        CHECK_ARG(indices[i] >= 0 && indices[i] < c->maxsize, "index %lld out of range", (long long)indices[i]);
+        idx[i] = (int)indices[i];
+    }
+    char* base = (char*)c->scratch;
+    hipStream_t s = c->compute;
+    HIPCHK(hipMemcpyAsync(base + o_idx, idx.data(), N * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(base + o_end, 0, N, s));
+    BatchPtrs b{(float*)(base + o_obs), (float*)(base + o_nxt), (float*)(base + o_act), (double*)(base + o_rew),
+                (double*)(base + o_cost), (uint8_t*)(base + o_fl)};
+    const size_t work = N * (2 * Do + Da + 1);
+    hipLaunchKernelGGL(batch_gather_kernel, dim3((int)std::min<size_t>(2048, (work + 255) / 256)), dim3(256), 0, s, c->st, b,
+                       (const int*)(base + o_idx), (const uint8_t*)(base + o_end), (int)n, (int)Do, (int)Da);
+    HIPCHK(hipGetLastError());
+    std::vector<uint8_t> fl(N);
+    if (obs_out) HIPCHK(hipMemcpyAsync(obs_out, b.obs, N * Do * 4, hipMemcpyDeviceToHost, s));
+    if (obs_next_out) HIPCHK(hipMemcpyAsync(obs_next_out, b.obs_next, N * Do * 4, hipMemcpyDeviceToHost, s));
+    if (act_out) HIPCHK(hipMemcpyAsync(act_out, b.act, N * Da * 4, hipMemcpyDeviceToHost, s));
+    if (rew_out) HIPCHK(hipMemcpyAsync(rew_out, b.rew, N * 8, hipMemcpyDeviceToHost, s));
+    if (cost_out) HIPCHK(hipMemcpyAsync(cost_out, b.cost, N * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(fl.data(), b.flags, N, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (size_t i = 0; i < N; ++i) {
+        if (terminated_out) terminated_out[i] = fl[i] & 1;
+        if (truncated_out) truncated_out[i] = (fl[i] >> 1) & 1;
     }
     return 0;
 }

@@ -145,6 +145,19 @@ class Engine:
     def __len__(self):
         return int(self.lib.fsrl_store_len(self._ctx))
 
+    def store_read(self, indices):
+        """buffer[indices] -> dict(obs, act, rew, cost, terminated, truncated, obs_next) on the host."""
+        idx = np.ascontiguousarray(indices, np.int64).reshape(-1)
+        n, Do, Da = idx.size, self.cfg.obs_dim, self.cfg.act_dim
+        out = dict(obs=np.empty((n, Do), np.float32), act=np.empty((n, Da), np.float32), rew=np.empty(n, np.float64),
+                   cost=np.empty(n, np.float64), terminated=np.empty(n, np.uint8), truncated=np.empty(n, np.uint8),
+                   obs_next=np.empty((n, Do), np.float32))
+        _lib.check(self.lib.fsrl_store_read(self._ctx, _ptr(idx, _i64p), n, _ptr(out["obs"], _f32p), _ptr(out["act"], _f32p),
+                                            _ptr(out["rew"], _f64p), _ptr(out["cost"], _f64p), _ptr(out["terminated"], _u8p),
+                                            _ptr(out["truncated"], _u8p), _ptr(out["obs_next"], _f32p)))
+        out["terminated"] = out["terminated"].astype(bool); out["truncated"] = out["truncated"].astype(bool)
+        return out
+
     def store_configure(self, total_size: int, buffer_num: int):
         """VectorReplayBuffer(total_size, buffer_num): re-cut the allocated store (empties it)."""
         _lib.check(self.lib.fsrl_store_configure(self._ctx, int(total_size), int(buffer_num)))

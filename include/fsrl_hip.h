@@ -108,6 +108,10 @@ int fsrl_store_push(fsrl_ctx* ctx, const int32_t* env_ids, int32_t k, const floa
                     int32_t* ep_len_out, int64_t* ep_idx_out);
 int fsrl_store_reset(fsrl_ctx* ctx, int keep_statistics);   /* buffer.reset()            */
 int64_t fsrl_store_len(const fsrl_ctx* ctx);                /* len(buffer)               */
+/* buffer[indices] (tianshou ReplayBufferManager.__getitem__ as FSRL's evaluation / dataset tooling uses it): the rows
+ * stored at the given slots, copied to the host; any output pointer may be NULL.  Not on the training path.            */
+int fsrl_store_read(fsrl_ctx* ctx, const int64_t* indices, int64_t n, float* obs_out, float* act_out, double* rew_out,
+                    double* cost_out, uint8_t* terminated_out, uint8_t* truncated_out, float* obs_next_out);
 /* VectorReplayBuffer(total_size, buffer_num) built inside learn() (fsrl/agent/base_agent.py:279,
  * fsrl/agent/sac_lag_agent.py learn): re-cut the store into buffer_num sub-buffers of ceil(total_size / buffer_num)
  * rows -- slot numbering, wrap-around and sample indices then are the reference's for that geometry.  It must fit the

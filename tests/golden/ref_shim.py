@@ -283,7 +283,8 @@ class ReplayBuffer:
     def reset(self, keep_statistics=False):
         self.last_index = np.array([0])
         self._index = self._size = 0
-        self._ep_rew, self._ep_len, self._ep_idx = 0.0, 0, 0
+        if not keep_statistics:          # tianshou 0.5: the running episode's reward / length / start survive otherwise
+            self._ep_rew, self._ep_len, self._ep_idx = 0.0, 0, 0
 
     def __len__(self):
         return self._size

@@ -48,6 +48,35 @@ def test_state_dict_keys_and_shapes_match_reference_manifest():
             assert list(sd[k].shape) == shape, k
 
 
+@pytest.mark.parametrize("which", ["cpo", "trpo_lag", "focops"])
+def test_trust_region_and_focops_state_dict_match_reference_manifest(which):
+    """Checkpoint wire format of CPO / TRPO-Lagrangian / FOCOPS: same keys, order and shapes as the unmodified reference
+    builds (tests/golden/gen_manifest_onpolicy.py); module tree only, no HIP engine."""
+    from fsrl_amd.env import Box
+    from fsrl_amd.policy.base_policy import BasePolicy
+    from fsrl_amd.policy.cpo import CPO
+    from fsrl_amd.policy.focops import FOCOPS
+    from fsrl_amd.policy.lagrangian_base import LagrangianPolicy
+    from fsrl_amd.policy.trpo_lag import TRPOLagrangian
+    from fsrl_amd.utils.net import ActorProb, Critic, Net
+    Do, Da, h = 6, 3, (64, 64)
+    actor = ActorProb(Net((Do, ), hidden_sizes=h), (Da, ), max_action=1.0)
+    critics = [Critic(Net((Do, ), hidden_sizes=h)) for _ in range(2)]
+    sp = dict(observation_space=Box(-np.inf, np.inf, (Do, )), action_space=Box(-1, 1, (Da, )))
+    cls = {"cpo": CPO, "trpo_lag": TRPOLagrangian, "focops": FOCOPS}[which]
+    pol = cls.__new__(cls)
+    if which == "trpo_lag":
+        LagrangianPolicy.__init__(pol, actor, critics, None, None, cost_limit=10.0, **sp)
+    else:
+        BasePolicy.__init__(pol, actor, critics, None, None, **sp)
+    man = json.load(open(os.path.join(GOLDEN, "state_dict_manifest.json")))[which + "_64x64_obs6_act3"]
+    sd = pol.state_dict()
+    assert [k for k, _ in man] == list(sd.keys())
+    for k, shape in man:
+        if shape is not None:
+            assert list(sd[k].shape) == shape, k
+
+
 def test_extra_state_roundtrip():
     a, b = _host_policy(), _host_policy()
     a.pre_update_fn(stats_train={"cost": 25.0})

@@ -1,0 +1,112 @@
+"""the collector's device-actor path pinned against the host torch mirror (the reference's own actor
+modules, fsrl/data/fast_collector.py:263-300 -> policy.forward, base_policy.py:178-190 / sac_lag.py:155-183).
+
+  * fsrl_actor_forward / fsrl_sac_actor_forward: (mu, sigma) of the device actor == the host nn.Module on the same
+    observations, 1e-6 (fp32, different summation order), every hidden width, ragged row counts;
+  * fsrl_collect_step(deterministic = 1): a whole collect with the actor on the device stores the same rows, in the same
+    slots, and reports the same statistics as the collector that runs the host mirror (policy.eval(): act = mean, so no
+    random stream is involved) -- rows compared through fsrl_store_read."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("hidden,obs_dim,act_dim", [(64, 8, 2), (128, 8, 2), (256, 8, 2), (256, 60, 2), (128, 33, 8)])
+def test_actor_forward_equals_host_mirror(hidden, obs_dim, act_dim, tmp_path):
+    from fsrl_amd.agent import PPOLagAgent
+    from fsrl_amd.data.batch import Batch
+    from fsrl_amd.env import SyntheticSafetyVectorEnv
+    env = SyntheticSafetyVectorEnv(env_num=4, obs_dim=obs_dim, act_dim=act_dim, episode_len=20, seed=1)
+    agent = PPOLagAgent(env, None, cost_limit=10, device="cuda:0", seed=3, hidden_sizes=(hidden, hidden), training_num=4)
+    pol, eng = agent.policy, agent.policy.engine
+    with torch.no_grad():                       # move sigma_param and the head off their init so every term is exercised
+        pol.actor.sigma_param.add_(0.1 * torch.randn_like(pol.actor.sigma_param))
+        for p in pol.actor.mu.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    pol._push_params()
+    rng = np.random.default_rng(0)
+    for k in (1, 4, 7, 16, 17, 37, 200):
+        obs = (2.0 * rng.standard_normal((k, obs_dim))).astype(np.float32)
+        mu, sigma = eng.actor_forward(obs)
+        with torch.no_grad():
+            (hm, hs), _ = pol.actor(obs)
+        np.testing.assert_allclose(mu, hm.numpy(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(sigma, np.broadcast_to(hs.numpy(), sigma.shape), rtol=1e-6, atol=0)
+        # deterministic sampling == the mean, bit for bit, and what policy.forward() returns in eval mode
+        pol.eval()
+        with torch.no_grad():
+            act = pol(Batch(obs=obs, info={})).act.numpy()
+        assert np.array_equal(eng.actor_sample(obs, deterministic=True), mu)
+        np.testing.assert_allclose(mu, act, rtol=0, atol=1e-6)
+    eng.close()
+
+
+@pytest.mark.parametrize("hidden", [64, 256])
+def test_sac_and_ddpg_actor_forward_equal_host_mirror(hidden, tmp_path):
+    from fsrl_amd.agent import DDPGLagAgent, SACLagAgent
+    from fsrl_amd.data.batch import Batch
+    from fsrl_amd.env import SyntheticSafetyVectorEnv
+    env = SyntheticSafetyVectorEnv(env_num=4, obs_dim=33, act_dim=8, episode_len=20, seed=1)
+    rng = np.random.default_rng(1)
+    sac = SACLagAgent(env, None, cost_limit=10, device="cuda:0", seed=3, hidden_sizes=(hidden, hidden), training_num=4,
+                      buffer_size=400, deterministic_eval=True)
+    pol, eng = sac.policy, sac.policy.engine
+    for k in (1, 5, 16, 33, 130):
+        obs = (1.5 * rng.standard_normal((k, 33))).astype(np.float32)
+        mu, sigma = eng.sac_actor_forward(obs)
+        with torch.no_grad():
+            (hm, hs), _ = pol.actor(obs)
+        np.testing.assert_allclose(mu, hm.numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(sigma, hs.numpy(), rtol=2e-6, atol=1e-9)       # sigma = exp(clamp(head)): relative
+        pol.eval()
+        with torch.no_grad():
+            act = pol(Batch(obs=obs, info={})).act.numpy()                       # tanh(mean)
+        np.testing.assert_allclose(eng.actor_sample(obs, deterministic=True), act, rtol=0, atol=2e-6)
+    eng.close()
+    ddpg = DDPGLagAgent(env, None, cost_limit=10, device="cuda:0", seed=3, hidden_sizes=(hidden, hidden), training_num=4,
+                        buffer_size=400)
+    pol, eng = ddpg.policy, ddpg.policy.engine
+    obs = (1.5 * rng.standard_normal((21, 33))).astype(np.float32)
+    pol.eval()
+    with torch.no_grad():
+        act = pol(Batch(obs=obs, info={})).act.numpy()                           # max_action * tanh(MLP)
+    np.testing.assert_allclose(eng.actor_sample(obs, deterministic=True), act, rtol=0, atol=2e-6)
+    eng.close()
+
+
+def _collect_and_read(device_actor, agent_cls, kw, n_list):
+    from fsrl_amd.data import FastCollector, HipVectorReplayBuffer
+    from fsrl_amd.env import SyntheticSafetyVectorEnv
+    env = SyntheticSafetyVectorEnv(env_num=6, obs_dim=8, act_dim=2, episode_len=23, seed=4)
+    agent = agent_cls(env, None, cost_limit=10, device="cuda:0", seed=2, hidden_sizes=(64, 64), training_num=6, **kw)
+    agent.policy.eval()                                  # deterministic_eval: act = the actor's mean
+    eng = agent.policy.engine
+    buf = HipVectorReplayBuffer(eng, 6 * 200, 6)
+    col = FastCollector(agent.policy, env, buf, exploration_noise=False, device_actor=device_actor)
+    stats = [col.collect(n_episode=n) for n in n_list]
+    idx = eng.sample0()
+    rows = eng.store_read(idx)
+    eng.close()
+    return stats, idx, rows
+
+
+@pytest.mark.parametrize("which", ["ppo", "sac"])
+def test_deterministic_collect_step_rows_equal_host_mirror_collector(which):
+    """Same env seed, policy.eval(): FastCollector over fsrl_collect_step vs FastCollector over the host mirror.  n_episode
+    values that are and are not multiples of the env count (surplus-env dropping, fast_collector.py:352-366)."""
+    from fsrl_amd.agent import PPOLagAgent, SACLagAgent
+    cls, kw = (PPOLagAgent, {}) if which == "ppo" else (SACLagAgent, {"buffer_size": 1200, "deterministic_eval": True})
+    st_d, idx_d, rows_d = _collect_and_read(True, cls, kw, (6, 10, 3))
+    st_h, idx_h, rows_h = _collect_and_read(False, cls, kw, (6, 10, 3))
+    assert np.array_equal(idx_d, idx_h)                                       # same slots in the same order
+    for a, b in zip(st_d, st_h):
+        assert a["n/ep"] == b["n/ep"] and a["n/st"] == b["n/st"] and a["total_cost"] == b["total_cost"]
+        assert abs(a["rew"] - b["rew"]) <= 1e-4 and a["len"] == b["len"]
+    for k in ("terminated", "truncated", "cost"):
+        assert np.array_equal(rows_d[k], rows_h[k]), k
+    # the device actor's mean differs from torch's by fp32 summation order (<= 1e-6); the env's linear dynamics are
+    # contracting, so rows stay within 1e-5 over the 23-step episodes
+    for k in ("obs", "act", "obs_next", "rew"):
+        np.testing.assert_allclose(rows_d[k], rows_h[k], rtol=0, atol=1e-5, err_msg=k)

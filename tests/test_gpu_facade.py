@@ -340,3 +340,62 @@ def test_bench_multi_rank_path_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]      # whole-job = ranks / step time
     assert "roofline" in d and "cpu_baseline" not in d                               # CPU leg: rank 0 at N = 1 only
+
+
+@pytest.mark.parametrize("which", ["sac", "ddpg", "cvpo"])
+def test_offpolicy_state_dict_after_a_host_forward_holds_the_device_critics(which, tmp_path):
+    """update -> policy(batch) (the host forward refreshes the ACTOR mirror only) -> state_dict(): the checkpoint must
+    still carry the device's critics and targets, not the mirror's stale ones (what agent.learn() with a test collector
+    and agent.evaluate() do between updates and logger.save_checkpoint())."""
+    from fsrl_amd.agent import CVPOAgent, DDPGLagAgent, SACLagAgent
+    from fsrl_amd.data import Batch, FastCollector, HipVectorReplayBuffer
+    from fsrl_amd.env import SyntheticSafetyVectorEnv
+    from fsrl_amd.policy.sac_lag import SACLagrangian
+    cls = {"sac": SACLagAgent, "ddpg": DDPGLagAgent, "cvpo": CVPOAgent}[which]
+    env = SyntheticSafetyVectorEnv(env_num=4, episode_len=30, seed=2)
+    agent = cls(env, None, cost_limit=10, device="cuda:0", seed=1, hidden_sizes=(64, 64), training_num=4, buffer_size=2000)
+    pol, eng = agent.policy, agent.policy.engine
+    pol.train()
+    buf = HipVectorReplayBuffer(eng, 2000, 4)
+    FastCollector(pol, env, buf, exploration_noise=True).collect(n_episode=8)
+    c0 = eng.sac_get_params(1)[0].copy()
+    pol.pre_update_fn(stats_train={"cost": 20.0})
+    for _ in range(5):
+        pol.update(64, buf)
+    pol.post_update_fn(stats_train={"cost": 20.0})
+    assert np.abs(eng.sac_get_params(1)[0] - c0).max() > 1e-5          # the critics did move on the device
+    pol(Batch(obs=np.zeros((3, eng.cfg.obs_dim), np.float32), info={}))  # actor-only refresh of the host mirror
+    sd = pol.state_dict()
+    assert np.array_equal(SACLagrangian._flat(list(pol.critics)), eng.sac_get_params(1)[0])
+    assert np.array_equal(SACLagrangian._flat(list(pol.critics_old)), eng.sac_get_params(2)[0])
+    assert np.array_equal(SACLagrangian._flat([pol.actor]), eng.sac_get_params(0)[0])
+    k = [k for k in sd if k.startswith("critics.") and k.endswith("weight")][0]
+    assert np.array_equal(sd[k].numpy(), dict(pol.named_parameters())[k].detach().numpy())
+    eng.close()
+
+
+def test_lr_scheduler_rate_reaches_the_engine(tmp_path):
+    """BasePolicy.update steps lr_scheduler last (base_policy.py:352-354); the engine must see the new rate."""
+    from fsrl_amd.agent import PPOLagAgent, SACLagAgent
+    from fsrl_amd.env import SyntheticSafetyVectorEnv
+    env = SyntheticSafetyVectorEnv(env_num=4, episode_len=30, seed=2)
+    agent = PPOLagAgent(env, None, cost_limit=10, device="cuda:0", seed=1, hidden_sizes=(64, 64), training_num=4, lr=1e-3)
+    pol = agent.policy
+    pol.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(pol.optim, lambda e: 0.5 ** e)
+    assert abs(pol.engine.get_lr(0) - 1e-3) < 1e-12
+    agent.learn(env, None, epoch=1, episode_per_collect=4, step_per_epoch=240, repeat_per_collect=1, batch_size=64,
+                verbose=False, save_ckpt=False, show_progress=False)
+    n_updates = pol.lr_scheduler.last_epoch
+    assert n_updates >= 1
+    assert abs(pol.engine.get_lr(0) - 1e-3 * 0.5 ** n_updates) < 1e-10
+    assert abs(pol.optim.param_groups[0]["lr"] - pol.engine.get_lr(0)) < 1e-10
+    with pytest.raises(AssertionError):
+        pol.engine.set_lr(1, 1e-3)                                      # one optimiser: group 0 only
+    pol.engine.close()
+    sac = SACLagAgent(env, None, cost_limit=10, device="cuda:0", seed=1, hidden_sizes=(64, 64), training_num=4,
+                      buffer_size=2000, actor_lr=4e-4, critic_lr=2e-3)
+    e = sac.policy.engine
+    assert abs(e.get_lr(0) - 4e-4) < 1e-10 and abs(e.get_lr(1) - 2e-3) < 1e-10
+    e.set_lr(1, 5e-4)
+    assert abs(e.get_lr(1) - 5e-4) < 1e-10
+    e.close()

@@ -236,3 +236,47 @@ def test_full_size_update_vs_oracle():
     print("fp64 yardstick: |hip-f64| stats", np.abs(stats - xstats).max(), "|f32-f64| stats",
           np.abs(ostats - xstats).max())
     eng.close()
+
+
+def test_two_updates_under_an_lr_schedule_vs_golden():
+    """fsrl_set_lr between updates = what the facade does after lr_scheduler.step(): the reference's two updates at lr and
+    lr / 2 (tests/golden/ppo_lrsched.npz, LambdaLR on the unmodified PPOLagrangian) are reproduced -- stats 2e-5, theta 2e-6."""
+    cfg, g = ppo_case("lrsched")
+    eng = _engine(cfg)
+    eng.set_params(g["theta0"])
+    _push_golden(eng, g)
+    lag = g["lagrangian"]
+    R = cfg["repeat"]
+    for u in range(2):
+        eng.set_lr(0, float(g["lrs"][u]))
+        assert abs(eng.get_lr(0) - g["lrs"][u]) < 1e-10
+        stats, _ = eng.ppo_update(lag, _rescale(lag), cfg["batch_size"], R, perms=g["perms"][u * R:(u + 1) * R])
+        np.testing.assert_allclose(stats, g[f"stats{u}"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(eng.get_params(), g[f"theta_after{u}"], rtol=0, atol=2e-6)
+    # without the rate change the second update lands elsewhere (the schedule is not a no-op here)
+    eng2 = _engine(cfg)
+    eng2.set_params(g["theta0"]); _push_golden(eng2, g)
+    for u in range(2):
+        eng2.ppo_update(lag, _rescale(lag), cfg["batch_size"], R, perms=g["perms"][u * R:(u + 1) * R])
+    assert np.abs(eng2.get_params() - g["theta_after1"]).max() > 1e-4
+    eng.close(); eng2.close()
+
+
+def test_abort_clears_the_begin_end_state():
+    """A failure between fsrl_ppo_begin and fsrl_ppo_end (here: a bad permutation) must not wedge the context."""
+    cfg, g = ppo_case("tiny")
+    eng = _engine(cfg)
+    eng.set_params(g["theta0"]); _push_golden(eng, g)
+    lag = g["lagrangian"]
+    n = eng.ppo_begin(lag, _rescale(lag), cfg["batch_size"])
+    with pytest.raises(AssertionError):
+        eng.ppo_pass(np.zeros(n, np.int64))                 # not a permutation
+    with pytest.raises(AssertionError):
+        eng.ppo_begin(lag, _rescale(lag), cfg["batch_size"])   # still inside the update
+    eng.ppo_abort()
+    stats, _ = eng.ppo_update(lag, _rescale(lag), cfg["batch_size"], cfg["repeat"], perms=g["perms"])
+    np.testing.assert_allclose(stats, g["stats"], rtol=2e-5, atol=2e-5)
+    with pytest.raises(AssertionError):                     # ppo_update cleans up after itself
+        eng.ppo_update(lag, _rescale(lag), cfg["batch_size"], 1, perms=[np.zeros(n, np.int64)])
+    eng.ppo_update(lag, _rescale(lag), cfg["batch_size"], 1, perms=g["perms"][:1])
+    eng.close()

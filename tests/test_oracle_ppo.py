@@ -49,3 +49,22 @@ def test_full_update(name):
     assert (stopped >= 0) == bool(g["early_stop_msgs"])
     np.testing.assert_allclose(stats, g["stats"], rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(o.get_params(), g["theta_final"], rtol=0, atol=2e-6)
+
+
+def test_two_updates_under_an_lr_schedule():
+    """ppo_lrsched.npz (tests/golden/gen_golden_lr.py): the reference steps LambdaLR(0.5 ** epoch) at the end of every
+    update() (base_policy.py:352-354) -- update 0 at lr, update 1 at lr / 2 with the Adam state carried over."""
+    torch.set_num_threads(4)
+    cfg, g = ppo_case("lrsched")
+    ocfg, data = oracle_cfg_and_data(cfg, g)
+    o = PPOLagOracle(ocfg)
+    o.set_params(g["theta0"])
+    lag = g["lagrangian"]
+    R = cfg["repeat"]
+    for u in range(2):
+        for pg in o.optim.param_groups:
+            pg["lr"] = float(g["lrs"][u])
+        _, stats, _ = o.update(data, lag, rescaling_factor(lag), cfg["batch_size"], R, perms=g["perms"][u * R:(u + 1) * R])
+        np.testing.assert_allclose(stats, g[f"stats{u}"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(o.get_params(), g[f"theta_after{u}"], rtol=0, atol=2e-6)
+    assert g["lrs"][1] == 0.5 * g["lrs"][0] and g["lrs"][2] == 0.25 * g["lrs"][0]

@@ -58,7 +58,10 @@ def run(kind, obs_dim, act_dim, hid, envs=20, T=1000, ep=1000, repeat=4, cpu_rep
     eng.sync()
 
     def device_update():
-        eng.set_params(theta)
+        # every timed update is the same workload: initial weights AND a fresh optimiser state -- round 1 restored the
+        # weights only, so the critics' Adam moments of the previous update leaked into the next one and the reported
+        # first-repeat vf losses drifted from the (fresh) oracle's (profiles/r01_bench_trust.json: 55.9 vs 43.3)
+        eng.set_params(theta); eng.optim_reset()
         if kind == "cpo":
             eng.tr_begin(target_kl=0.01, l2_reg=0.001, critic_lr=1e-3, max_backtracks=10, optim_critic_iters=10,
                          cost_limit=10.0)
@@ -110,7 +113,7 @@ def run_focops(obs_dim=8, act_dim=2, hid=256, envs=20, T=1000, ep=250, batch=256
     eng.sync()
 
     def device_update(k):
-        eng.set_params(theta)
+        eng.set_params(theta); eng.optim_reset()
         return eng.focops_update(0.1, -15.0, batch, repeat, perms=None, seed=k + 1)
 
     device_update(0)
