@@ -10,6 +10,7 @@ from typing import Any, Callable, Dict, Optional, Tuple, Union
 
 import numpy as np
 
+from fsrl_amd import parallel
 from fsrl_amd.utils.logger import BaseLogger, DummyLogger
 
 
@@ -63,6 +64,9 @@ class BaseTrainer(ABC):
         self.epoch, self.stop_fn_flag = self.start_epoch, False
         self.env_step, self.cum_cost, self.cum_episode = 0, 0, 0
         self._best, self._clock = _Best(cost_limit), _Clock()
+        self._acc: Dict[str, float] = {}     # this rank's sums of the current epoch (parallel.EPOCH_KEYS)
+        self.job_stats: Dict[str, float] = {}   # last epoch's job-level figures (all ranks; == this rank's alone)
+        self.rank, self.world = parallel.rank_world()
 
     # attributes the reference exposes under these names
     best_perf_rew = property(lambda self: self._best.reward)
@@ -87,9 +91,12 @@ class BaseTrainer(ABC):
         if self.stop_fn_flag or self.epoch >= self.max_epoch:
             raise StopIteration
         self.epoch += 1
+        self._acc = {}
+        t_epoch = time.time()
         self._train_phase()
         if self.test_collector is not None:
             self.test_step()
+        self._acc["duration"] = time.time() - t_epoch
         info = self._close_epoch()
         return self.epoch, self._epoch_stats, info
 
@@ -104,11 +111,17 @@ class BaseTrainer(ABC):
         self.policy.train()
         budget = self.step_per_epoch
         while budget > 0:
+            tic = time.time()
             collected = self.train_step()
             budget -= int(collected["n/st"])
-            tic = time.time()
+            self._bump("collect_time", time.time() - tic)
+            tic, g0 = time.time(), int(getattr(self.policy, "gradient_steps", 0))
             self.policy_update_fn(collected)
             self._clock.in_update += time.time() - tic
+            self._bump("update_time", time.time() - tic)
+            self._bump("n_updates", 1 if self.learning_type == "onpolicy" else
+                       round(self.update_per_step * collected["n/st"]))
+            self._bump("n_grad_steps", int(getattr(self.policy, "gradient_steps", 0)) - g0)
             self.logger.write_without_reset(self.env_step)
 
     def test_step(self) -> Dict[str, Any]:
@@ -118,6 +131,8 @@ class BaseTrainer(ABC):
         self.policy.eval()
         res = col.collect(n_episode=self.episode_per_test)
         self.logger.store(**{"test/reward": res["rew"], "test/cost": res["cost"], "test/length": int(res["len"])})
+        self._bump("test_n_ep", res["n/ep"]); self._bump("test_sum_rew", res["rew"] * res["n/ep"])
+        self._bump("test_sum_cost", res["total_cost"])
         return res
 
     def _close_epoch(self) -> Dict[str, Any]:
@@ -128,13 +143,32 @@ class BaseTrainer(ABC):
             self.logger.save_checkpoint()
         if self.perf_is_better(test=True):
             self.logger.save_checkpoint(suffix="best")
-        if self.stop_fn is not None and self.stop_fn(self._best.reward, self._best.cost):
+        stop_here = self.stop_fn is not None and self.stop_fn(self._best.reward, self._best.cost)
+        # ---- the one exchange step of the multi-GPU layout: the epoch vector, all-reduced over the ranks.
+        # The loss means come from this rank's logger (per-step rows of the epoch), weighted by its optimiser steps.
+        gsteps = self._acc.get("n_grad_steps", 0.0)
+        self._acc["sum_loss_total"] = self.logger.get_mean("loss/total") * gsteps
+        self._acc["sum_kl"] = self.logger.get_mean("loss/kl") * gsteps
+        self._acc["stop"] = 1.0 if stop_here else 0.0
+        self.job_stats = parallel.reduce_epoch(self._acc)
+        if self.world > 1:
+            # independent agents, one collective per epoch: every rank must enter it the same number of times, so the
+            # job stops when EVERY rank's stop rule has fired (a rank that is done early keeps training until then)
+            stop_here = self.job_stats["job/all_stop"] > 0
+            if self.rank == 0:
+                self.logger.store(**self.job_stats)
+        if stop_here:
             self.stop_fn_flag = True
             self.logger.print("Early stop due to the stop_fn met.", "red")
         self._epoch_stats = self.logger.stats_mean
         self.logger.write(self.env_step, display=self.verbose)
         info.update(best_reward=self._best.reward, best_cost=self._best.cost)
+        if self.world > 1:
+            info.update(self.job_stats)
         return info
+
+    def _bump(self, key: str, value: float) -> None:
+        self._acc[key] = self._acc.get(key, 0.0) + float(value)
 
     # ------------------------------------------------------------------ pieces subclasses and callers use
     def train_step(self) -> Dict[str, Any]:
@@ -144,6 +178,9 @@ class BaseTrainer(ABC):
         self.cum_cost += res["total_cost"]
         self.logger.store(**{"update/episode": self.cum_episode, "update/cum_cost": self.cum_cost,
                              "train/reward": res["rew"], "train/cost": res["cost"], "train/length": int(res["len"])})
+        self._bump("n_st", res["n/st"]); self._bump("n_ep", res["n/ep"])
+        self._bump("sum_rew", res["rew"] * res["n/ep"]); self._bump("sum_cost", res["total_cost"])
+        self._bump("sum_len", res["len"] * res["n/ep"])
         return res
 
     def perf_is_better(self, test: bool = True) -> bool:

@@ -95,17 +95,21 @@ def test_cpo_configs2_full_size():
     np.testing.assert_allclose(got["loss/step_size"], sa["loss/step_size"], rtol=1e-6)   # same backtrack count
     # critic regression after 10 Adam steps: 2e-4 relative
     assert _rel(st[14], sc["loss/vf0"]) <= 2e-4 and _rel(st[15], sc["loss/vf1"]) <= 2e-4, (st[14:], sc)
-    # before CG: 2e-5
-    for k in ("loss/entropy", "loss/cost_loss", "loss/optim_C", "loss/rew_loss"):
+    # before CG: 2e-5 relative; rew_loss = mean(ratio * A) with normalised advantages at theta_old is a sum of 20 000
+    # O(1) terms that cancels to ~1e-7: absolute 2e-6
+    for k in ("loss/entropy", "loss/cost_loss", "loss/optim_C"):
         assert _rel(got[k], sa[k]) <= 2e-5 + 1e-6, (k, got[k], sa[k])
-    # everything downstream of the two fp32 CG solves (Q, R, S and what the dual solve derives from them): 5e-3
+    assert abs(got["loss/rew_loss"] - sa["loss/rew_loss"]) <= 2e-6
+    # everything downstream of the two fp32 CG solves (Q, R, S and what the dual solve derives from them): 5e-4
+    # (observed on MI355X: Q 2.5e-5, S 1.4e-5, R 8e-5 of sqrt(QS), nu 7e-6 -- at N = 20 000 the batch Hessian is far
+    # better conditioned than in the N = 480 fixtures, where the reference itself moves by 1e-3 with the row order)
     # R = g.H^-1 b is a cross term (here |R| << sqrt(Q S): the two gradients are nearly H-orthogonal), so it is measured
     # against sqrt(Q S), the scale its rounding noise has
     qs = float(np.sqrt(sa["loss/optim_Q"] * sa["loss/optim_S"]))
     for k in ("loss/optim_Q", "loss/optim_R", "loss/optim_S", "loss/optim_A", "loss/optim_B", "loss/optim_lam",
               "loss/optim_nu"):
         floor = qs if k == "loss/optim_R" else 1e-3
-        assert _rel(got[k], sa[k], floor) <= 5e-3, (k, got[k], sa[k])
+        assert _rel(got[k], sa[k], floor) <= 5e-4, (k, got[k], sa[k])
     th = eng.get_params()
     d = np.abs(th - o.get_params())
     print("cpo theta diff max / mean", d.max(), d.mean())
@@ -135,7 +139,7 @@ def test_trpo_full_size():
     print("trpo full size hip:", {k: float(v) for k, v in got.items()})
     print("trpo full size oracle:", so)
     for k in keys:
-        tol = 5e-3 if k in ("loss/kl", "loss/step_size") else 2e-4
+        tol = 2e-3 if k in ("loss/kl", "loss/step_size") else 2e-4
         assert _rel(got[k], so[k]) <= tol + 1e-6, (k, got[k], so[k])
     d = np.abs(eng.get_params() - o.get_params())
     print("trpo theta diff max / mean", d.max(), d.mean())
