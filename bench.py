@@ -102,23 +102,29 @@ def cpu_baseline(theta, inputs, seconds=12.0):
                       f"torch CPU fp32, {threads} threads of {os.cpu_count()} host cpus"}
 
 
-def end_to_end(local_rank, seed, seconds=6.0, device_actor=False):
+def end_to_end(local_rank, seed, seconds=6.0, device_actor=False, workers=0, busy_us=0.0, envs=ENVS):
     """Secondary figure (outside the timed region): the whole training loop of
     OnpolicyAgent.learn -- host collector over a SYNTHETIC SafetyCarCircle-shaped vector env
-    (20 envs, 300-step episodes, 20 episodes per collect) feeding the HIP-resident store, one
-    device update per collect -- reported like the reference's `train_speed` (env-steps/s)."""
+    (300-step episodes, one episode per env and collect) feeding the HIP-resident store, one
+    device update per collect -- reported like the reference's `train_speed` (env-steps/s).
+    workers == 0: the in-process vector env (a zero-cost env: the collector's own ceiling).  workers > 0: the
+    shared-memory multi-process env (fsrl_amd/env/shmem.py: `workers` processes over `envs` envs, `busy_us` of host time
+    burnt per env step in the worker -- SURVEY 8(d): 0 and ~100 us to mimic PyBullet, 4 / 32 worker processes)."""
     from fsrl_amd.agent import PPOLagAgent
     from fsrl_amd.data import FastCollector, HipVectorReplayBuffer
-    from fsrl_amd.env import SyntheticSafetyVectorEnv
+    from fsrl_amd.env import ShmemVectorEnv, SyntheticSafetyVectorEnv
     from fsrl_amd.trainer import OnpolicyTrainer
-    env = SyntheticSafetyVectorEnv(env_num=ENVS, obs_dim=OBS, act_dim=ACT, episode_len=300, seed=seed)
+    if workers > 0:
+        env = ShmemVectorEnv(env_num=envs, workers=workers, obs_dim=OBS, act_dim=ACT, episode_len=300, seed=seed, busy_us=busy_us)
+    else:
+        env = SyntheticSafetyVectorEnv(env_num=envs, obs_dim=OBS, act_dim=ACT, episode_len=300, seed=seed, busy_us=busy_us)
     agent = PPOLagAgent(env, cost_limit=10, device=f"cuda:{local_rank}", seed=seed, hidden_sizes=(HID, HID),
-                        max_grad_norm=0.5, training_num=ENVS)
+                        max_grad_norm=0.5, training_num=envs)
     agent.policy.train()
-    buf = HipVectorReplayBuffer(agent.policy.engine, 100000, ENVS)
+    buf = HipVectorReplayBuffer(agent.policy.engine, 100000, envs)
     col = FastCollector(agent.policy, env, buf, exploration_noise=True, device_actor=device_actor)
     tr = OnpolicyTrainer(agent.policy, col, None, max_epoch=10**6, batch_size=BATCH, cost_limit=10,
-                         step_per_epoch=6000, repeat_per_collect=REPEAT, episode_per_collect=20,
+                         step_per_epoch=6000, repeat_per_collect=REPEAT, episode_per_collect=envs,
                          verbose=False)
     tr.reset()
     t0 = time.perf_counter()
@@ -130,13 +136,18 @@ def end_to_end(local_rank, seed, seconds=6.0, device_actor=False):
         update_s += time.perf_counter() - t1
         collects += 1
     dt = time.perf_counter() - t0
-    out = {"env": "synthetic SafetyCarCircle-shaped vector env (not PyBullet)", "envs": ENVS,
+    kind = (f"shared-memory multi-process vector env: {workers} worker processes, {busy_us:g} us of host time per env step"
+            if workers > 0 else "in-process vector env, zero-cost step")
+    out = {"env": "synthetic SafetyCarCircle-shaped dynamics (not PyBullet); " + kind, "envs": envs, "workers": workers,
+           "busy_us": busy_us,
            "actor": "device (fsrl_collect_step: one call per vector step, library RNG)" if device_actor else "host mirror (torch CPU, torch RNG)",
            "collects": collects, "env_steps_per_s": col.collect_step / dt,
            "collector_only_env_steps_per_s": col.collect_step / col.collect_time,
            "update_ms_per_collect": update_s / collects * 1e3,
            "policy_updates_per_s": collects / dt}
     agent.policy.engine.close()
+    if hasattr(env, "close"):
+        env.close()
     return out
 
 
@@ -262,7 +273,14 @@ def main():
     dt = time.perf_counter() - t0
     grad_steps = stats.shape[0]
     assert np.isfinite(stats).all()
+    per_rank = None
     if dist is not None:
+        # the SURVEY 8(e) exchange: every rank's figures gathered once (RCCL all_gather of a 5-double vector), then the
+        # max-over-ranks time the contract asks for
+        from fsrl_amd import parallel
+        per_rank = parallel.allgather_metrics({"rank": float(rank), "seed": float(seed), "updates": float(args.steps),
+                                               "grad_steps": float(grad_steps * args.steps), "seconds": dt,
+                                               "updates_per_s": args.steps / dt})
         tt = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -304,12 +322,19 @@ def main():
                          "launches_timed": int(k_n),
                          "flops_per_launch": flops_fwdbwd_launch(rows_avg)},
         }
+        if per_rank is not None:
+            out["ranks_seen"] = len(per_rank)
+            out["per_rank_updates_per_s"] = [round(r["updates_per_s"], 3) for r in sorted(per_rank, key=lambda r: r["rank"])]
+            out["sum_of_rank_rates"] = sum(r["updates_per_s"] for r in per_rank)
         pmc = pmc_traffic()
         if pmc is not None:
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
             out["end_to_end"] = end_to_end(local_rank, seed, device_actor=True)
             out["end_to_end_host_actor"] = end_to_end(local_rank, seed, seconds=4.0, device_actor=False)
+            # the host vector-env side of the headline metric: worker processes x simulated step cost
+            out["end_to_end_shmem"] = [end_to_end(local_rank, seed, seconds=3.0, device_actor=True, workers=w, busy_us=b,
+                                                  envs=32) for w in (4, 32) for b in (0.0, 100.0)]
             out["multi_seed"] = multi_seed()
             out["cpu_baseline"] = cpu_baseline(theta, inputs)
             out["speedup_vs_cpu_port"] = out["value"] / world / out["cpu_baseline"]["value"]

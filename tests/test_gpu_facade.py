@@ -340,6 +340,36 @@ def test_bench_multi_rank_path_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]      # whole-job = ranks / step time
     assert "roofline" in d and "cpu_baseline" not in d                               # CPU leg: rank 0 at N = 1 only
+    assert d["ranks_seen"] == 2 and len(d["per_rank_updates_per_s"]) == 2              # the 8(e) exchange saw both ranks
+    assert d["value"] <= d["sum_of_rank_rates"] * (1 + 1e-9)                           # max-over-ranks time <= any rank's own
+
+
+def test_multi_gpu_launcher_two_ranks_share_this_gpu(tmp_path):
+    """examples/train_multi_gpu.py under the driver's launch line, two ranks on this box's one GPU over gloo: two real
+    (tiny) PPO-Lag training loops, seeds base + rank, the epoch vector all-reduced from BaseTrainer._close_epoch.  The
+    pooled job reward must be the mean of the two ranks' own last-epoch rewards (same episode count per rank here)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "examples", "train_multi_gpu.py"), "--algo", "ppol", "--envs", "4",
+           "--epoch", "2", "--step-per-epoch", "480", "--episode-len", "40", "--hidden", "64", "--backend", "gloo",
+           "--share-gpu", "--json", "--seed", "5", "--logdir", str(tmp_path)]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["ranks"] == 2 and d["epochs"] == 2 and sorted(r["seed"] for r in d["per_seed"]) == [5.0, 6.0]
+    job = d["job_last_epoch"]
+    assert job["job/ranks"] == 2.0 and job["job/env_step"] == 2 * 480 and job["job/episodes"] == 2 * 12
+    mean_of_ranks = sum(r["reward"] for r in d["per_seed"]) / 2
+    assert abs(job["job/reward"] - mean_of_ranks) <= 1e-9 * max(1.0, abs(mean_of_ranks))
+    assert abs(job["job/cost"] - sum(r["cost"] for r in d["per_seed"]) / 2) <= 1e-9 * 100
+    assert d["per_seed"][0]["reward"] != d["per_seed"][1]["reward"]                  # two different seeds really ran
+    assert job["job/env_steps_per_s"] > 0 and job["job/updates_per_s"] > 0
+    for seed in (5, 6):                                                              # every rank kept its own curve
+        assert os.path.exists(os.path.join(str(tmp_path), f"ppol-seed{seed}", "progress.txt"))
 
 
 @pytest.mark.parametrize("which", ["sac", "ddpg", "cvpo"])
