@@ -82,8 +82,11 @@ struct PpoStepArgs {
 // no environment variable can change a result.
 #ifdef FSRL_PROBES
 #define FSRL_PROBE(sa, n) ((sa).dbg_phase == (n))
+// in-kernel timeline (probe builds): lane 0 of wave 0 stores the shader clock at phase boundary k of its workgroup
+#define FSRL_TS(buf, k) do { if ((buf) && threadIdx.x == 0) (buf)[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define FSRL_PROBE(sa, n) false
+#define FSRL_TS(buf, k) do { } while (0)
 #endif
 
 // Device-resident control block (one per context).

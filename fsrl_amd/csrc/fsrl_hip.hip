@@ -141,6 +141,7 @@ struct fsrl_ctx {
     // timing-probe switches: always 0 / false in the shipped library; a -DFSRL_PROBES build reads them ONCE, at
     // fsrl_ctx_create, from FSRL_DBG_PHASE / FSRL_TILE16 / FSRL_WGRAD_SKIP / FSRL_NO_SPIN (tools/phase_probe.sh)
     int probe_phase = 0, probe_wgrad_skip = 0;
+    unsigned long long* probe_ts = nullptr;   // probe builds: [1024][16] phase stamps of the last fused-kernel launch
     bool probe_tile16 = false;
     bool no_spin = false;           // wait for the collector's actor with hipStreamSynchronize instead of the completion words
     std::vector<float> act_mu, act_sg;                   // mean / std of the last actor evaluation (host)
@@ -344,6 +345,10 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     { const char* e = getenv("FSRL_WGRAD_SKIP"); c->probe_wgrad_skip = e ? atoi(e) : 0; }
     c->probe_tile16 = getenv("FSRL_TILE16") != nullptr;
     c->no_spin = getenv("FSRL_NO_SPIN") != nullptr;
+    if (getenv("FSRL_TSTAMP")) {
+        (void)hipMalloc(&c->probe_ts, 1024 * 16 * sizeof(unsigned long long));
+        (void)hipMemset(c->probe_ts, 0, 1024 * 16 * sizeof(unsigned long long));
+    }
 #endif
     build_layout(c);
 #define TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { fail(FSRL_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); fsrl_ctx_destroy(c); return FSRL_EHIP; } } while (0)
@@ -961,6 +966,15 @@ extern "C" int fsrl_last_timing(fsrl_ctx* c, double* out, int32_t n) {
 #include "host_sac.inc"
 
 #include "host_cvpo.inc"
+
+#ifdef FSRL_PROBES
+// probe builds only (not in include/fsrl_hip.h): the phase stamps of the last ppo_fwd_bwd_kernel launch
+extern "C" int fsrl_probe_tstamps(fsrl_ctx* c, unsigned long long* out, int64_t n) {
+    if (!c || !c->probe_ts) return FSRL_ESTATE;
+    (void)hipStreamSynchronize(c->compute);
+    return hipMemcpy(out, c->probe_ts, (size_t)std::min<int64_t>(n, 1024 * 16) * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : FSRL_EHIP;
+}
+#endif
 
 // ------------------------------------------------------------------------------ learning rates
 // lr_scheduler.step() of BasePolicy.update (fsrl/policy/base_policy.py:352-354): the caller's scheduler owns the

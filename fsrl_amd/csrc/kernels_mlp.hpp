@@ -61,6 +61,9 @@ struct FwdW2Frag {
 // LDS (commit()).  VMEM returns in issue order, so commit() waits for the small loads only and
 // the 256 KB W2 burst keeps streaming in underneath layer 1.
 // `x` points at the tile's first row (rows are contiguous), n_valid rows exist.
+// Straight-line code: every load is unconditional on a clamped index and masked afterwards (a predicated load
+// compiles to an exec-mask branch: the first version of this prologue had ~30 of them and three integer divisions by
+// the runtime obs_dim, and took 2 900 shader cycles -- 1.2 us -- just to ISSUE its loads; tools/tstamp_probe.py).
 template <int H>
 struct TileStage {
     static constexpr int NT = TileGeom<H>::NT;
@@ -72,34 +75,50 @@ struct TileStage {
                                           const int Da, const float* __restrict__ x,
                                           const float* __restrict__ rd, const int n_valid,
                                           const int tid) {
+        // rows of the tile are contiguous: element e = row * Do + k is valid iff e < n_valid * Do
+        const int nx = n_valid * Do;
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
             const int e = tid + u * NT;
-            xv[u] = (e < 16 * Do && e / Do < n_valid) ? x[e] : 0.0f;
+            const float v = x[min(e, max(nx - 1, 0))];
+            xv[u] = (e < nx) ? v : 0.0f;
         }
+        const int n3 = no.out * H, n1 = (Do <= FSRL_W1_LDS) ? H * Do : 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = tid + u * NT;
-            w3v[u] = (e < no.out * H) ? P[no.W3 + e] : 0.0f;
-            w1v[u] = (Do <= FSRL_W1_LDS && e < H * Do) ? P[no.W1 + e] : 0.0f;
+            const float a = P[no.W3 + min(e, n3 - 1)];
+            const float b = P[no.W1 + min(e, max(n1 - 1, 0))];
+            w3v[u] = (e < n3) ? a : 0.0f;
+            w1v[u] = (e < n1) ? b : 0.0f;
         }
+        const int nr = n_valid * FSRL_RD;
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
             const int e = tid + u * NT;
-            rdv[u] = (rd != nullptr && e < 16 * FSRL_RD && e / FSRL_RD < n_valid) ? rd[e] : 0.0f;
+            const float v = (rd != nullptr) ? rd[min(e, max(nr - 1, 0))] : 0.0f;      // rd: kernel-uniform
+            rdv[u] = (rd != nullptr && e < nr) ? v : 0.0f;
         }
-        b1v = (tid < H) ? P[no.b1 + tid] : 0.0f;
-        b2v = (tid < H) ? P[no.b2 + tid] : 0.0f;
-        b3v = (tid < no.out) ? P[no.b3 + tid] : 0.0f;
-        sgv = (no.sigma >= 0 && tid < Da) ? P[no.sigma + tid] : 0.0f;
+        const float t1 = P[no.b1 + min(tid, H - 1)], t2 = P[no.b2 + min(tid, H - 1)];
+        const float t3 = P[no.b3 + min(tid, no.out - 1)];
+        const float t4 = P[max(no.sigma, 0) + min(tid, Da - 1)];
+        b1v = (tid < H) ? t1 : 0.0f;
+        b2v = (tid < H) ? t2 : 0.0f;
+        b3v = (tid < no.out) ? t3 : 0.0f;
+        sgv = (no.sigma >= 0 && tid < Da) ? t4 : 0.0f;
     }
 
     __device__ __forceinline__ void commit(TileSmem<H>& sm, const NetOff no, const int Do,
                                            const int tid) const {
+        // e -> (row i, column k) = (e / Do, e % Do) by a multiply-high with ceil(2^32 / Do): exact for e < 2^16
+        const unsigned magic = 0xFFFFFFFFu / (unsigned)Do + 1u;
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
             const int e = tid + u * NT;
-            if (e < 16 * Do) { const int i = e / Do, k = e - i * Do; sm.xT[k * 16 + i] = xv[u]; }
+            if (e < 16 * Do) {
+                const int i = (int)__umulhi((unsigned)e, magic), k = e - i * Do;
+                sm.xT[k * 16 + i] = xv[u];
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -127,7 +146,7 @@ struct TileStage {
 template <int H, int R = 16>
 __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __restrict__ P,
                                              const NetOff no, const int Do, const int tid,
-                                             const FwdW2Frag<H>& wf) {
+                                             const FwdW2Frag<H>& wf, unsigned long long* ts = nullptr) {
     constexpr int LD = TileSmem<H>::LD;
     constexpr int WAVES = TileGeom<H>::WAVES;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
@@ -190,6 +209,7 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
         }
     }
     __syncthreads();
+    FSRL_TS(ts, 3);
 
     // ---- layer 2: h2[R,H] = relu(h1[R,H] @ W2^T + b2) on MFMA (fp32)
     if constexpr (R == 4) {
@@ -201,6 +221,7 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = mfma_4x4x1(a[s], wf.b[kc][s], acc);
         }
+        FSRL_TS(ts, 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {            // add the four k-classes: (q0 + q1) + (q2 + q3)
             acc[r] += __shfl_xor(acc[r], 16, 64);
@@ -227,6 +248,7 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
         for (int r = 0; r < 4; ++r) sm.h2[(4 * q + r) * LD + j] = fmaxf(acc[r] + bias, 0.0f);
     }
     __syncthreads();
+    FSRL_TS(ts, 5);
 
     // ---- head (out <= 16): one wave per row, 64-lane shuffle reduce
     for (int i = wave; i < R; i += WAVES) {
@@ -285,6 +307,7 @@ __global__ __launch_bounds__(4 * H) void mlp_infer_kernel(const float* __restric
     const NetOff no = md.net[net];
     const int Do = md.Do;
     const int n_tiles = (a.N + 15) >> 4;
+    const unsigned magic = 0xFFFFFFFFu / (unsigned)Do + 1u;      // e / Do as a multiply-high (exact for e < 2^16)
     const float* __restrict__ X = use_next ? a.obs_next : a.obs;
     int tile = blockIdx.x;
     int row0 = tile * 16;
@@ -303,7 +326,7 @@ __global__ __launch_bounds__(4 * H) void mlp_infer_kernel(const float* __restric
 #pragma unroll
             for (int u = 0; u < NX; ++u) {
                 const int e = tid + u * NT;
-                xn[u] = (e < 16 * Do && e / Do < nn_valid) ? X[(size_t)nrow0 * Do + e] : 0.0f;
+                xn[u] = (e < nn_valid * Do) ? X[(size_t)nrow0 * Do + e] : 0.0f;      // rows are contiguous
             }
         }
         __syncthreads();
@@ -344,7 +367,7 @@ __global__ __launch_bounds__(4 * H) void mlp_infer_kernel(const float* __restric
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
             const int e = tid + u * NT;
-            if (e < 16 * Do) { const int i = e / Do, k = e - i * Do; sm.xT[k * 16 + i] = xn[u]; }
+            if (e < 16 * Do) { const int i = (int)__umulhi((unsigned)e, magic), k = e - i * Do; sm.xT[k * 16 + i] = xn[u]; }
         }
         tile = ntile; row0 = nrow0; n_valid = nn_valid;
     }
@@ -372,6 +395,7 @@ struct PpoBatchPtrs {
     float* DO;               // [n_nets][mbp_max][FSRL_DOW]
     float* statp;            // [n_tiles_max][n_nets][4] partial sums of the logged stats
     int mbp_max;
+    unsigned long long* ts;  // probe builds: [blocks][16] shader-clock stamps of the phase boundaries (else null)
 };
 
 template <int H, int R>
@@ -399,6 +423,7 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
     // ---- prologue: ONE burst of independent loads (W2 slice, obs tile, row data, small
     //      parameters); nothing below waits on a second cold round trip.
     if (FSRL_PROBE(sa, 10)) return;                     // pure launch floor of this kernel
+    FSRL_TS(bp.ts, 0);
     TileStage<H> stg;
     stg.issue(P, no, Do, Da, bp.obs_p + grow0 * Do, bp.rd_p + grow0 * FSRL_RD, n_valid, tid);
     if (FSRL_PROBE(sa, 13)) { asm volatile("" ::"v"(stg.b1v), "v"(stg.xv[0])); return; }
@@ -416,6 +441,7 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
         asm volatile("" ::"v"(stg.b1v), "v"(wf.b[0]));
         return;
     }
+    FSRL_TS(bp.ts, 1);
     stg.commit(sm, no, Do, tid);
     if (FSRL_PROBE(sa, 12)) {                           // + small loads landed, W2 not awaited
         asm volatile("" ::"v"(wf.b[0]));
@@ -423,8 +449,10 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
     }
     if (FSRL_PROBE(sa, 9)) return;                      // launch + address setup only
     __syncthreads();
+    FSRL_TS(bp.ts, 2);
     if (FSRL_PROBE(sa, 1)) { if (wf.b[0][0] == 123.f && sm.xT[tid] == 1.f) bp.statp[0] = 1.f; return; }
-    tile_forward<H, R>(sm, P, no, Do, tid, wf);
+    tile_forward<H, R>(sm, P, no, Do, tid, wf, bp.ts);
+    FSRL_TS(bp.ts, 6);
     if (FSRL_PROBE(sa, 4)) { if (sm.out[tid & 15] == 123.f) bp.statp[0] = 1.f; return; }
     const size_t nb = (size_t)net * bp.mbp_max;
     {   // spill relu(z1), relu(z2) for the weight-gradient kernel now: the stores retire while
@@ -441,8 +469,13 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
         }
     }
 
-    // W2 slice for the backward GEMM dz1 = dz2 @ W2 (column block of this wave): issued now
-    // (L2-warm after the forward burst), consumed after the loss head.
+
+    // W2 slice for the backward GEMM dz1 = dz2 @ W2 (column block of this wave): issued now (L2-warm after the forward
+    // burst), consumed after the loss head.  The 256 KB ingest is NOT hidden by issuing it earlier: a wave stalls at a VMEM
+    // instruction while the CU's memory queue is full, so the burst costs its ~1.4 us wherever it sits (in-kernel stamps,
+    // tools/tstamp_probe.py: right after the forward MFMA loop 25 600 cycles per workgroup, interleaved chunk by chunk
+    // into that loop 24 700, here 23 900); nor by a fragment-ordered mirror (16 dwordx4 instead of 64 dword loads per
+    // lane: same time in this kernel, +1.0 us in the Adam kernel that has to keep the mirror).  DESIGN.md section 3.
     float wb[H / 16][4];
     {
         const float* __restrict__ W2c = P + no.W2 + wave * 16 + li;
@@ -452,7 +485,7 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
             for (int s = 0; s < 4; ++s) wb[jc][s] = W2c[(size_t)(16 * jc + 4 * q + s) * H];
         }
     }
-
+    FSRL_TS(bp.ts, 7);
     if (FSRL_PROBE(sa, 5)) { if (wb[0][0] == 123.f) bp.statp[0] = 1.f; return; }
     // ---- loss head: thread (row i = tid>>4, dim d = tid&15), 16-lane shuffles per row
     if (tid < 16 * R) {
@@ -521,7 +554,9 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
         }
         if (d == 0) { sm.st[i * 4 + 0] = st0; sm.st[i * 4 + 1] = st1; sm.st[i * 4 + 2] = st2; }
     }
+    FSRL_TS(bp.ts, 8);
     __syncthreads();
+    FSRL_TS(bp.ts, 9);
     if (tid < 4) {   // rows summed in ascending order (fixed => deterministic)
         float t = 0.0f;
         if (tid < 3)
@@ -546,6 +581,7 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
         }
     }
     __syncthreads();
+    FSRL_TS(bp.ts, 10);
 
     {   // dz2 and dout tiles -> side buffers (retire under the backward GEMM)
         float* __restrict__ D2 = bp.D2 + (nb + row0) * H;
@@ -558,6 +594,7 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
         float* __restrict__ DOb = bp.DO + (nb + row0) * FSRL_DOW;
         for (int e = tid; e < R * FSRL_DOW; e += NT) DOb[e] = sm.dout[e];
     }
+    FSRL_TS(bp.ts, 11);
     // ---- dL/dz1 = (dz2 @ W2) * relu'(z1) on MFMA; result goes straight to L2/HBM
     if constexpr (R == 4) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -573,6 +610,7 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
             acc[r] += __shfl_xor(acc[r], 16, 64);
             acc[r] += __shfl_xor(acc[r], 32, 64);
         }
+        FSRL_TS(bp.ts, 12);
         if (FSRL_PROBE(sa, 7)) { if (acc[0] == 123.f) bp.statp[1] = 1.f; return; }
         if (q == 0) {
             float* __restrict__ D1 = bp.D1 + (nb + row0) * H;
@@ -598,7 +636,7 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
             D1[(size_t)i * H + col] = (sm.h1[i * LD + col] > 0.0f) ? acc[r] : 0.0f;
         }
     }
-
+    FSRL_TS(bp.ts, 13);
 }
 
 // ---------------------------------------------------------------- weight gradients
