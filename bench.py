@@ -190,6 +190,35 @@ def multi_seed(seeds=3, steps=6):
             "note": "same configs[1] workload per agent; not the headline value (that is one agent per GPU)"}
 
 
+def no_clip_variant(theta, inputs, steps=6):
+    """Secondary figure: the same update with max_grad_norm off -- PPOLagAgent's default (ppo_lag_agent.py:97; the 0.5 of
+    the headline comes from the reference's config file, ppol_cfg.py:21).  Without a global gradient norm nothing stands
+    between a reduced gradient element and its Adam update: the weight-gradient kernel applies it, 2 launches per step."""
+    from fsrl_amd.engine import Engine, EngineConfig
+    eng = Engine(EngineConfig(obs_dim=OBS, act_dim=ACT, hidden=HID, env_num=ENVS, buffer_size=100000, max_grad_norm=None,
+                              target_kl=None))
+    obs, act, rew, cost, term, trunc = inputs
+    ids = np.arange(ENVS)
+    for t in range(NROWS // ENVS):
+        eng.push(ids, obs[t], act[t], rew[t], cost[t], term[t], trunc[t], obs[t + 1])
+    eng.sync()
+    lag, resc = np.array([0.75]), 1.0 / 1.75
+
+    def one(k):
+        eng.set_params(theta); eng.optim_reset()
+        return eng.ppo_update(lag, resc, BATCH, REPEAT, perms=None, seed=k + 1)[0]
+    one(0)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        st = one(k + 1)
+    eng.sync()
+    dt = (time.perf_counter() - t0) / steps
+    eng.close()
+    return {"value": 1.0 / dt, "unit": "updates/s", "ms_per_update": dt * 1e3, "launches_per_step": 2,
+            "us_per_step": dt * 1e6 / st.shape[0],
+            "note": "max_grad_norm=None (agent default): Adam fused into the weight-gradient kernel; not the headline config"}
+
+
 def pmc_traffic():
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE, separate runs; tools/capture_profiles.sh + tools/collect_profiles.py apply
@@ -336,6 +365,7 @@ def main():
             out["end_to_end_shmem"] = [end_to_end(local_rank, seed, seconds=3.0, device_actor=True, workers=w, busy_us=b,
                                                   envs=32) for w in (4, 32) for b in (0.0, 100.0)]
             out["multi_seed"] = multi_seed()
+            out["no_clip"] = no_clip_variant(theta, inputs)
             out["cpu_baseline"] = cpu_baseline(theta, inputs)
             out["speedup_vs_cpu_port"] = out["value"] / world / out["cpu_baseline"]["value"]
         print(json.dumps(out))

@@ -75,6 +75,7 @@ struct PpoStepArgs {
     double kl_thresh;  // 1.5 * target_kl in float64 (python float in the reference)
     float step_size;   // lr / (1 - beta1^t)          (host float64 -> f32, like torch)
     float bc2_sqrt;    // sqrt(1 - beta2^t)
+    int fuse_adam;     // max_grad_norm off (the agent default): the weight-gradient kernel applies Adam itself, 2 launches per step
     int dbg_phase;     // probe builds only (-DFSRL_PROBES, env FSRL_DBG_PHASE): early-exit timing experiments, results invalid
 };
 // Early-exit timing probes of the step kernels (tools/phase_probe.sh).  They exist only in a build with -DFSRL_PROBES
@@ -88,6 +89,18 @@ struct PpoStepArgs {
 #define FSRL_PROBE(sa, n) false
 #define FSRL_TS(buf, k) do { } while (0)
 #endif
+
+// torch.optim.Adam single-tensor update of one element (lerp_ / mul_ + addcmul_ / sqrt / div / add_(eps) / addcdiv_), the
+// PPO step's ONE definition: adam_clip_kernel and the fused weight-gradient kernel both inline it, with the contractions
+// written out (contract(off) + explicit fmaf), so that the 3-launch and the 2-launch step round identically.
+__device__ __forceinline__ void ppo_adam_math(const float g, float& m, float& v, float& p, const PpoStepArgs& sa) {
+#pragma clang fp contract(off)
+    m = fmaf(sa.one_minus_b1, g - m, m);
+    v = v * sa.beta2;
+    v = fmaf(sa.one_minus_b2 * g, g, v);
+    const float denom = sqrtf(v) / sa.bc2_sqrt + sa.adam_eps;
+    p = p + (-sa.step_size * m) / denom;
+}
 
 // Device-resident control block (one per context).
 struct CtrlBlock {

@@ -143,6 +143,7 @@ struct fsrl_ctx {
     int probe_phase = 0, probe_wgrad_skip = 0;
     unsigned long long* probe_ts = nullptr;   // probe builds: [1024][16] phase stamps of the last fused-kernel launch
     bool probe_tile16 = false;
+    bool no_fuse_adam = false;      // probe builds: FSRL_NO_FUSE_ADAM keeps the separate Adam launch without a clip (A/B, bit-compare)
     bool no_spin = false;           // wait for the collector's actor with hipStreamSynchronize instead of the completion words
     std::vector<float> act_mu, act_sg;                   // mean / std of the last actor evaluation (host)
     std::vector<int> perm_tmp;      // this pass's permutation before it goes to the pinned buffer
@@ -345,6 +346,7 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     { const char* e = getenv("FSRL_WGRAD_SKIP"); c->probe_wgrad_skip = e ? atoi(e) : 0; }
     c->probe_tile16 = getenv("FSRL_TILE16") != nullptr;
     c->no_spin = getenv("FSRL_NO_SPIN") != nullptr;
+    c->no_fuse_adam = getenv("FSRL_NO_FUSE_ADAM") != nullptr;
     if (getenv("FSRL_TSTAMP")) {
         (void)hipMalloc(&c->probe_ts, 1024 * 16 * sizeof(unsigned long long));
         (void)hipMemset(c->probe_ts, 0, 1024 * 16 * sizeof(unsigned long long));

@@ -255,14 +255,9 @@ __global__ __launch_bounds__(ADAM_NT) void adam_clip_kernel(float* __restrict__ 
     if (i4 < n) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float ge = g[e] * coef;
-            float me = m[e], ve = v[e];
-            me = me + sa.one_minus_b1 * (ge - me);
-            ve = ve * sa.beta2;
-            ve = ve + (sa.one_minus_b2 * ge) * ge;
-            const float denom = sqrtf(ve) / sa.bc2_sqrt + sa.adam_eps;
-            m[e] = me; v[e] = ve;
-            p[e] = p[e] + (-sa.step_size * me) / denom;
+            float me = m[e], ve = v[e], pe = p[e];
+            ppo_adam_math(g[e] * coef, me, ve, pe, sa);
+            m[e] = me; v[e] = ve; p[e] = pe;
         }
         *reinterpret_cast<f32x4*>(M + i4) = m;
         *reinterpret_cast<f32x4*>(V + i4) = v;

@@ -657,7 +657,21 @@ struct WgradPtrs {
     const float* statp;
     float* stats;      // [steps][FSRL_PPO_NSTATS]
     int mbp_max;
+    float* Pw; float* M; float* V;   // fused-Adam instantiation (FUSE): parameters and Adam moments, updated in place
 };
+
+// torch.optim.Adam single-tensor update of ONE element with an unclipped gradient -- the same operations in the same
+// order as adam_clip_kernel with coef == 1 (g * 1.0f == g), so the two launch sequences are bit-identical.  Used by the
+// weight-gradient kernel when max_grad_norm is off (PPOLagAgent's default, fsrl/agent/ppo_lag_agent.py:97): every gradient
+// element is final the moment its block has reduced it, nothing global (no norm) stands between it and the update.
+// `mi`: position of the element in the forward-fragment mirror of W2, or -1 (the caller knows: only the dW2 tiles have one).
+__device__ __forceinline__ void ppo_adam_elem(const WgradPtrs& wp, const PpoStepArgs& sa, const int i, const float g,
+                                              const int mi = -1) {
+    float m = wp.M[i], v = wp.V[i], p = wp.Pw[i];
+    ppo_adam_math(g, m, v, p, sa);
+    wp.M[i] = m; wp.V[i] = v; wp.Pw[i] = p;
+    if (mi >= 0) wp.Pw[mi] = p;
+}
 
 #define WG_MAXU 8      // k-steps per wave and load burst in the tile role (512 rows per burst)
 #define AUX_MAXU 32    // rows per thread in the aux role:   mbp/16   <= 32
@@ -720,7 +734,9 @@ __device__ __forceinline__ void ppo_stats_finalize(const ModelDesc& md, const Wg
 
 // BIG = false: mbp <= 512, every role is one straight-line load burst (the common case: batch <= 256).
 // BIG = true: the same code inside a loop over 512-row chunks (merged last minibatch of batch 512: 1023).
-template <int H, bool BIG>
+// FUSE: apply Adam to every gradient element as soon as it is reduced (max_grad_norm off); a separate instantiation so
+// that the clipped path keeps its register budget (one kernel with a runtime switch spilled 42 VGPRs).
+template <int H, bool BIG, bool FUSE>
 __global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, const WgradPtrs wp,
                                                         const int mbp, const PpoStepArgs sa,
                                                         const int n_stat_tiles) {
@@ -735,7 +751,14 @@ __global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, con
     if (FSRL_PROBE(sa, 20)) return;
     if ((int)blockIdx.x == md.n_nets * PB) {  // the stats block
         if (FSRL_PROBE(sa, 21) || FSRL_PROBE(sa, 22)) return;
-        if (wave == 0) ppo_stats_finalize(md, wp, sa, n_stat_tiles, lane);
+        if (wave == 0) {
+            ppo_stats_finalize(md, wp, sa, n_stat_tiles, lane);
+            // fused mode: the pass-level KL stop that adam_clip_kernel's first block decides otherwise (ppo_lag.py:251-255)
+            if (FUSE && lane == 0 && sa.last_in_pass && sa.target_kl > 0.0f) {
+                const double mean_kl = wp.ctrl->kl_sum / ((double)sa.iters_in_pass + 1e-7);
+                if (mean_kl > sa.kl_thresh) wp.ctrl->stopped_after = sa.pass;
+            }
+        }
         // db3[o] / dsigma[d] = column sums of DO over the minibatch rows, for every network:
         // thread (col = tid & 31, row phase = tid >> 5); all loads of a thread in one burst
         float sqs = 0.0f;
@@ -761,9 +784,13 @@ __global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, con
                 float tot = 0.0f;
 #pragma unroll
                 for (int p2 = 0; p2 < 32; ++p2) tot += red[p2 * 33 + tid];
-                if (tid < no.out) { wp.grad[no.b3 + tid] = tot; sqs = fmaf(tot, tot, sqs); }
+                if (tid < no.out) {
+                    wp.grad[no.b3 + tid] = tot; sqs = fmaf(tot, tot, sqs);
+                    if constexpr (FUSE) ppo_adam_elem(wp, sa, no.b3 + tid, tot);
+                }
                 if (no.sigma >= 0 && tid >= 16 && tid < 16 + md.Da) {
                     wp.grad[no.sigma + tid - 16] = tot; sqs = fmaf(tot, tot, sqs);
+                    if constexpr (FUSE) ppo_adam_elem(wp, sa, no.sigma + tid - 16, tot);   // wave 0 logged the entropy first
                 }
             }
         }
@@ -849,8 +876,11 @@ __global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, con
             float v = 0.0f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) v += red[w * (32 * 33) + jl * 33 + kl];
-            wp.grad[no.W2 + (size_t)(tj * 32 + jl) * H + tk * 32 + kl] = v;
+            const int gi = no.W2 + (tj * 32 + jl) * H + tk * 32 + kl;
+            wp.grad[gi] = v;
             sq = v * v;
+            if constexpr (FUSE)
+                ppo_adam_elem(wp, sa, gi, v, no.W2f + w2f_index(H, tj * 32 + jl, tk * 32 + kl));
         }
     } else {
         // ---- aux: 32 columns j0..j0+31 of this network; same 16-way split-K MFMA structure as
@@ -956,20 +986,25 @@ __global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, con
                 const int jl = e >> 4, kk = e & 15;
                 if (tid < 512) {
                     if (k0 + kk < Do) {
-                        wp.grad[no.W1 + (size_t)(j0 + jl) * Do + k0 + kk] = v;
+                        const int gi = no.W1 + (j0 + jl) * Do + k0 + kk;
+                        wp.grad[gi] = v;
                         sq = fmaf(v, v, sq);
+                        if constexpr (FUSE) ppo_adam_elem(wp, sa, gi, v);
                     }
                 } else if (first && kk < out) {
-                    wp.grad[no.W3 + (size_t)kk * H + j0 + jl] = v;
+                    const int gi = no.W3 + kk * H + j0 + jl;
+                    wp.grad[gi] = v;
                     sq = fmaf(v, v, sq);
+                    if constexpr (FUSE) ppo_adam_elem(wp, sa, gi, v);
                 }
                 if (first && tid < 64) {
                     float bsum = 0.0f;
 #pragma unroll
                     for (int w = 0; w < 8; ++w) bsum += red[w * 1088 + 1024 + tid];
-                    if (tid < 32) wp.grad[no.b1 + j0 + tid] = bsum;
-                    else wp.grad[no.b2 + j0 + tid - 32] = bsum;
+                    const int gi = (tid < 32) ? no.b1 + j0 + tid : no.b2 + j0 + tid - 32;
+                    wp.grad[gi] = bsum;
                     sq = fmaf(bsum, bsum, sq);
+                    if constexpr (FUSE) ppo_adam_elem(wp, sa, gi, bsum);
                 }
             }
         }

@@ -280,3 +280,22 @@ def test_abort_clears_the_begin_end_state():
         eng.ppo_update(lag, _rescale(lag), cfg["batch_size"], 1, perms=[np.zeros(n, np.int64)])
     eng.ppo_update(lag, _rescale(lag), cfg["batch_size"], 1, perms=g["perms"][:1])
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["c2", "tiny"])
+def test_fused_adam_step_is_bit_identical_to_the_three_launch_step(name):
+    """max_grad_norm off (PPOLagAgent's default): the weight-gradient kernel applies Adam itself (2 launches per step).
+    With a clip threshold nothing ever reaches (coef == 1.0f exactly) the 3-launch sequence runs the same arithmetic:
+    parameters, Adam moments' effect on a second update and the logged statistics are bit-identical."""
+    cfg, g = ppo_case(name)
+    lag = g["lagrangian"]
+    out = []
+    for mgn in (None, 1e30):
+        eng = _engine(cfg, max_grad_norm=mgn)
+        eng.set_params(g["theta0"]); _push_golden(eng, g)
+        s1, _ = eng.ppo_update(lag, _rescale(lag), cfg["batch_size"], cfg["repeat"], perms=g["perms"])
+        s2, _ = eng.ppo_update(lag, _rescale(lag), cfg["batch_size"], cfg["repeat"], perms=g["perms"])   # moments carried over
+        out.append((s1.copy(), s2.copy(), eng.get_params(), eng.get_grads()))
+        eng.close()
+    for k, (a, b) in enumerate(zip(out[0], out[1])):
+        assert np.array_equal(a, b), (k, float(np.abs(a - b).max()), int((a != b).sum()), a.size)
