@@ -64,8 +64,10 @@ struct Staging {           // pinned host staging + its device mirror (one of tw
     bool in_flight = false;
 };
 
+struct fsrl_group;
 struct fsrl_ctx {
     fsrl_config cfg{};
+    fsrl_group* group = nullptr;   // set while the context is a member of a grouped-update set (host_group.inc)
     int device = 0;
     hipStream_t compute = nullptr, side = nullptr;
     ModelDesc md{};
@@ -158,6 +160,7 @@ static void tr_free(fsrl_ctx* c);
 static void foc_free(fsrl_ctx* c);
 static void tr_reset_optim(fsrl_ctx* c);
 static void foc_reset_optim(fsrl_ctx* c);
+static void group_detach(fsrl_ctx* c);
 static int focops_pass(fsrl_ctx* c, int32_t* stopped_out);
 static int pass_verdict(fsrl_ctx* c, int32_t* stopped_out);
 
@@ -283,6 +286,7 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    if (c->group) group_detach(c);          // a member destroyed before its group: take its own stream back
     tr_free(c);
     sac_free(c);
     foc_free(c);
@@ -937,6 +941,8 @@ extern "C" int fsrl_gae_return(fsrl_ctx* c, const float* v, const float* v_next,
 }
 
 #include "host_ppo.inc"
+
+#include "host_group.inc"
 
 // abandon an update that began with fsrl_ppo_begin and cannot reach fsrl_ppo_end (an exception between the calls on the
 // caller's side): drain the stream, clear the state machine.  No-op outside an update.

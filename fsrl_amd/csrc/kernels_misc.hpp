@@ -218,12 +218,12 @@ __global__ __launch_bounds__(256) void w2f_sync_kernel(float* __restrict__ P, co
 #endif
 // clip_grad_norm_(max_norm) then torch.optim.Adam single-tensor update, same operation order
 // as torch (lerp_ / mul_+addcmul_ / sqrt / div / add_(eps) / addcdiv_), ppo_lag.py:235-241.
-__global__ __launch_bounds__(ADAM_NT) void adam_clip_kernel(float* __restrict__ P, float* __restrict__ M,
-                                                       float* __restrict__ V,
-                                                       const float* __restrict__ G,
-                                                       const float* __restrict__ gsq_part, int nparts,
-                                                       int n, const PpoStepArgs sa,
-                                                       CtrlBlock* ctrl, const ModelDesc md) {
+__device__ __forceinline__ void adam_clip_body(float* __restrict__ P, float* __restrict__ M,
+                                               float* __restrict__ V,
+                                               const float* __restrict__ G,
+                                               const float* __restrict__ gsq_part, int nparts,
+                                               int n, const PpoStepArgs& sa,
+                                               CtrlBlock* ctrl, const ModelDesc& md) {
     __shared__ double sh[ADAM_NT / 64];
     __shared__ float coef_s;
     const int tid = threadIdx.x;
@@ -270,4 +270,13 @@ __global__ __launch_bounds__(ADAM_NT) void adam_clip_kernel(float* __restrict__ 
         const double mean_kl = ctrl->kl_sum / ((double)sa.iters_in_pass + 1e-7);
         if (mean_kl > sa.kl_thresh) ctrl->stopped_after = sa.pass;
     }
+}
+
+__global__ __launch_bounds__(ADAM_NT) void adam_clip_kernel(float* __restrict__ P, float* __restrict__ M,
+                                                       float* __restrict__ V,
+                                                       const float* __restrict__ G,
+                                                       const float* __restrict__ gsq_part, int nparts,
+                                                       int n, const PpoStepArgs sa,
+                                                       CtrlBlock* ctrl, const ModelDesc md) {
+    adam_clip_body(P, M, V, G, gsq_part, nparts, n, sa, ctrl, md);
 }

@@ -399,11 +399,8 @@ struct PpoBatchPtrs {
 };
 
 template <int H, int R>
-__global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restrict__ P,
-                                                           const ModelDesc md,
-                                                           const PpoBatchPtrs bp,
-                                                           const PpoStepArgs sa) {
-    __shared__ TileSmem<H> sm;
+__device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* __restrict__ P, const ModelDesc& md,
+                                                 const PpoBatchPtrs& bp, const PpoStepArgs& sa) {
     constexpr int LD = TileSmem<H>::LD;
     constexpr int NT = TileGeom<H>::NT;
     const int tid = threadIdx.x;
@@ -414,6 +411,7 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
     // rows past mb_size are written as zeros
     const int n_tiles = ((sa.mb_size + 15) >> 4) * (16 / R);
     const int tile = blockIdx.x % n_tiles, net = blockIdx.x / n_tiles;
+    if (net >= md.n_nets) return;       // grouped launches size grid.x for the largest member's minibatch
     const int row0 = tile * R;
     const NetOff no = md.net[net];
     const int Do = md.Do, Da = md.Da, C = md.n_nets - 1;
@@ -639,6 +637,15 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
     FSRL_TS(bp.ts, 13);
 }
 
+template <int H, int R>
+__global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restrict__ P,
+                                                           const ModelDesc md,
+                                                           const PpoBatchPtrs bp,
+                                                           const PpoStepArgs sa) {
+    __shared__ TileSmem<H> sm;
+    ppo_fwd_bwd_body<H, R>(sm, P, md, bp, sa);
+}
+
 // ---------------------------------------------------------------- weight gradients
 // block = 1024 threads (16 waves).  grid.x = n_nets * (NT2 + NA) + 1:
 //   NT2 = (H/32)^2 MFMA tile blocks (dW2, 32x32 outputs, 16-way split-K over the waves)
@@ -737,9 +744,8 @@ __device__ __forceinline__ void ppo_stats_finalize(const ModelDesc& md, const Wg
 // FUSE: apply Adam to every gradient element as soon as it is reduced (max_grad_norm off); a separate instantiation so
 // that the clipped path keeps its register budget (one kernel with a runtime switch spilled 42 VGPRs).
 template <int H, bool BIG, bool FUSE>
-__global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, const WgradPtrs wp,
-                                                        const int mbp, const PpoStepArgs sa,
-                                                        const int n_stat_tiles) {
+__device__ __forceinline__ void ppo_wgrad_body(const ModelDesc& md, const WgradPtrs& wp, const int mbp,
+                                               const PpoStepArgs& sa, const int n_stat_tiles) {
     const int CH = BIG ? (mbp + 511) / 512 : 1;      // row chunks
     constexpr int TPD = H / 32;          // tiles per dimension
     constexpr int NT2 = TPD * TPD;
@@ -1020,4 +1026,77 @@ __global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, con
         for (int w = 0; w < 16; ++w) t += wsum[w];
         wp.gsq_part[blockIdx.x] = t;
     }
+}
+
+template <int H, bool BIG, bool FUSE>
+__global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, const WgradPtrs wp,
+                                                        const int mbp, const PpoStepArgs sa,
+                                                        const int n_stat_tiles) {
+    ppo_wgrad_body<H, BIG, FUSE>(md, wp, mbp, sa, n_stat_tiles);
+}
+
+// ---------------------------------------------------------------- grouped launches (several agents, one stream)
+// k independent agents of one shape (multi-seed runs: SURVEY 8e "within-GPU batching of k seeds") step in lock step:
+// every launch of the minibatch step carries all members as grid.y.  One agent's step is a chain of dependent launches
+// whose fixed costs (launch floor, cold first touch of the freshly written parameters) dominate; k agents share each of
+// them.  The arithmetic per member is the single-agent body, inlined: grouped and one-by-one updates are bit-identical.
+struct GroupAgent {          // per member; device memory, rewritten at the start of every grouped update
+    const float* P;
+    float *Pw, *M, *V, *G;
+    PpoBatchPtrs bp;
+    WgradPtrs wp;            // wp.X is per step: obs_p + mb_start * Do, formed in the kernel
+    const float* gsq_part; CtrlBlock* ctrl;
+    float rescale; float lam[FSRL_MAX_CRITICS];
+    int n_dev, nparts;
+};
+struct GroupStep {           // per (minibatch index of the pass, member); device memory, rewritten every pass
+    int mb_start, mb_size, step, mb_index;
+    int first_in_pass, last_in_pass, iters_in_pass, active;
+    int pass; float step_size, bc2_sqrt; int pad;
+};
+__device__ __forceinline__ PpoStepArgs group_step_args(const PpoStepArgs& base, const GroupAgent& a, const GroupStep& st) {
+    PpoStepArgs sa = base;
+    sa.mb_start = st.mb_start; sa.mb_size = st.mb_size; sa.step = st.step; sa.mb_index = st.mb_index;
+    sa.first_in_pass = st.first_in_pass; sa.last_in_pass = st.last_in_pass; sa.iters_in_pass = st.iters_in_pass;
+    sa.pass = st.pass; sa.step_size = st.step_size; sa.bc2_sqrt = st.bc2_sqrt;
+    sa.rescale = a.rescale;
+#pragma unroll
+    for (int i = 0; i < FSRL_MAX_CRITICS; ++i) sa.lam[i] = a.lam[i];
+    return sa;
+}
+
+template <int H, int R>
+__global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_group_kernel(const ModelDesc md, const GroupAgent* __restrict__ tab,
+                                                                 const GroupStep* __restrict__ steps,
+                                                                 const PpoStepArgs base) {
+    __shared__ TileSmem<H> sm;
+    const GroupStep st = steps[blockIdx.y];
+    if (!st.active) return;
+    const GroupAgent& a = tab[blockIdx.y];
+    const PpoStepArgs sa = group_step_args(base, a, st);
+    ppo_fwd_bwd_body<H, R>(sm, a.P, md, a.bp, sa);
+}
+
+template <int H, bool BIG, bool FUSE, int R>
+__global__ __launch_bounds__(1024) void ppo_wgrad_group_kernel(const ModelDesc md, const GroupAgent* __restrict__ tab,
+                                                              const GroupStep* __restrict__ steps,
+                                                              const PpoStepArgs base) {
+    const GroupStep st = steps[blockIdx.y];
+    if (!st.active) return;
+    const GroupAgent& a = tab[blockIdx.y];
+    const PpoStepArgs sa = group_step_args(base, a, st);
+    WgradPtrs wp = a.wp;
+    wp.X = a.bp.obs_p + (size_t)st.mb_start * md.Do;
+    const int tiles = (st.mb_size + 15) >> 4;
+    ppo_wgrad_body<H, BIG, FUSE>(md, wp, tiles * 16, sa, R == 4 ? tiles * 4 : tiles);
+}
+
+__global__ __launch_bounds__(ADAM_NT) void adam_clip_group_kernel(const ModelDesc md, const GroupAgent* __restrict__ tab,
+                                                                 const GroupStep* __restrict__ steps,
+                                                                 const PpoStepArgs base) {
+    const GroupStep st = steps[blockIdx.y];
+    if (!st.active) return;
+    const GroupAgent& a = tab[blockIdx.y];
+    const PpoStepArgs sa = group_step_args(base, a, st);
+    adam_clip_body(a.Pw, a.M, a.V, a.G, a.gsq_part, a.nparts, a.n_dev, sa, a.ctrl, md);
 }

@@ -494,3 +494,55 @@ class Engine:
         _lib.check(self.lib.fsrl_last_timing(self._ctx, _ptr(out, _f64p), 5))
         return dict(process_ms=out[0], learn_ms=out[1], fwdbwd_ms=out[2], fwdbwd_launches=int(out[3]),
                     fwdbwd_raw_ms=out[4])
+
+
+class EngineGroup:
+    """k PPO-Lagrangian engines of one network shape on one GPU, updated in lock step (fsrl_group_*): every launch of
+    the minibatch step carries all members.  Members keep their own store, parameters and random streams; use the
+    engines as usual for everything else (push, collect_step, get_params ...)."""
+
+    def __init__(self, engines):
+        self.engines = list(engines)
+        assert self.engines, "a group needs at least one engine"
+        self.lib = self.engines[0].lib
+        k = len(self.engines)
+        arr = (C.c_void_p * k)(*[e._ctx for e in self.engines])
+        self._g = C.c_void_p()
+        _lib.check(self.lib.fsrl_group_create(arr, k, C.byref(self._g)))
+
+    def close(self):
+        if getattr(self, "_g", None) is not None and self._g:
+            self.lib.fsrl_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ppo_update(self, lagrangians, rescalings, batch_size, repeat, perms=None, seed=0):
+        """k x Engine.ppo_update.  lagrangians: [k][n_critics - 1]; rescalings: [k]; perms: None or per member a list /
+        array [repeat][N_i].  -> (list of stats arrays [steps_i, 11], list of stopped passes (-1 = none))."""
+        k = len(self.engines)
+        lag = np.ascontiguousarray(lagrangians, np.float64).reshape(k, -1)
+        resc = np.ascontiguousarray(rescalings, np.float64).reshape(k)
+        sizes = [len(e) for e in self.engines]
+        cap = max(1, max(-(-n // max(batch_size, 1)) for n in sizes)) * max(repeat, 1)
+        stats = [np.empty((cap, _lib.PPO_NSTATS), np.float32) for _ in range(k)]
+        sp = (_f32p * k)(*[_ptr(s, _f32p) for s in stats])
+        pp, keep = None, []
+        if perms is not None:
+            for i in range(k):
+                a = np.ascontiguousarray(np.stack([np.asarray(p, np.int64) for p in perms[i]]), np.int64)
+                assert a.shape == (repeat, sizes[i]), "perms[i] must be [repeat][N_i]"
+                keep.append(a)
+            pp = (_i64p * k)(*[_ptr(a, _i64p) for a in keep])
+        nst = np.zeros(k, np.int64)
+        stop = np.zeros(k, np.int32)
+        _lib.check(self.lib.fsrl_group_ppo_update(self._g, _ptr(lag, _f64p) if lag.size else None, _ptr(resc, _f64p),
+                                                  int(batch_size), int(repeat), pp, int(seed), sp, cap, _ptr(nst, _i64p),
+                                                  _ptr(stop, _i32p)))
+        for e, n in zip(self.engines, sizes):
+            e._n = n
+        return [s[:int(n)] for s, n in zip(stats, nst)], [int(x) for x in stop]

@@ -176,6 +176,23 @@ int fsrl_ppo_update(fsrl_ctx* ctx, const double* lagrangians, double rescaling,
                     float* stats_out, int64_t cap_steps, int64_t* n_steps_out,
                     int32_t* stopped_pass_out);
 
+/* ---- grouped updates: k independent PPO-Lagrangian agents of ONE network shape on one GPU, stepped in lock step
+ *      (multi-seed runs; SURVEY 8e "within-GPU batching of k seeds").  The reference runs seeds as separate jobs; one
+ *      agent's update is a chain of small dependent launches that leaves most of an MI355X idle, so k agents share every
+ *      launch of the minibatch step (grid.y = member).  Per member the result is bit-identical to fsrl_ppo_update on
+ *      that member alone (same kernels' bodies, same permutation stream).  Members keep their own store, parameters,
+ *      Adam state and random streams; shape and PPO hyper-parameters must agree, batch sizes N_i may differ.
+ *      While grouped, a member's own update calls still work (they run on the group's stream).                         */
+typedef struct fsrl_group fsrl_group;
+int fsrl_group_create(fsrl_ctx** ctxs, int32_t k, fsrl_group** out);       /* 1 <= k <= 16; members are not owned   */
+int fsrl_group_destroy(fsrl_group* group);
+/* k x BasePolicy.update (base_policy.py:332-355).  lagrangians [k][n_critics - 1], rescaling [k]; perms: NULL (library
+ * shuffle, member i seeded by seed + 1000003 i + pass) or k pointers to [repeat][N_i]; stats_out: NULL or k pointers to
+ * [cap_steps][FSRL_PPO_NSTATS]; n_steps_out [k]; stopped_pass_out [k] (-1 = ran every pass).                          */
+int fsrl_group_ppo_update(fsrl_group* group, const double* lagrangians, const double* rescaling, int32_t batch_size,
+                          int32_t repeat, const int64_t* const* perms, uint64_t seed, float* const* stats_out,
+                          int64_t cap_steps, int64_t* n_steps_out, int32_t* stopped_pass_out);
+
 /* read back process_fn products of the current batch: which = "values" | "rets" | "advs"
  * ([n][n_critics] float32, like torch.stack(.., -1)) | "logp_old" ([n]).                 */
 int fsrl_batch_get(fsrl_ctx* ctx, const char* which, float* out, int64_t cap);

@@ -1,0 +1,129 @@
+"""Grouped PPO-Lagrangian updates (fsrl_group_*): k agents of one shape stepped in lock step, every launch of the minibatch
+step carrying all members.  Per member the update must be the single-agent update: bit-identical when the tile shape of
+the fused kernel agrees (the group picks 4-row tiles only while ALL members fit the chip in one round), within the fp32
+tolerances of the golden tests otherwise."""
+import numpy as np
+import pytest
+
+from helpers import ppo_case
+from test_gpu_ppo import _engine, _push_golden, _rescale
+
+pytestmark = pytest.mark.gpu
+
+
+def _members(cfg, g, k, **over):
+    """k engines on the golden case's store; member i starts from theta0 perturbed by seed i and uses its own multipliers"""
+    engs, thetas, lags = [], [], []
+    for i in range(k):
+        eng = _engine(cfg, **over)
+        th = g["theta0"] + (0.01 * np.random.default_rng(100 + i).standard_normal(g["theta0"].size)).astype(np.float32) * (i > 0)
+        eng.set_params(th)
+        _push_golden(eng, g)
+        engs.append(eng); thetas.append(th); lags.append(g["lagrangian"] * (1.0 + 0.5 * i))
+    return engs, thetas, lags
+
+
+@pytest.mark.parametrize("name,k,over", [("c1", 3, {}), ("c2", 2, {}), ("tiny", 4, {}), ("earlystop", 3, {}),
+                                         ("c1", 3, {"max_grad_norm": None})])
+def test_grouped_update_equals_member_by_member(name, k, over):
+    from fsrl_amd.engine import EngineGroup
+    cfg, g = ppo_case(name)
+    R, B = cfg["repeat"], cfg["batch_size"]
+    n = len(g["indices"])
+    rng = np.random.default_rng(5)
+    perms = [[rng.permutation(n) for _ in range(R)] for _ in range(k)]
+    for j, pj in enumerate(g["perms"][:R]):             # member 0 replays the golden case (all the passes it recorded)
+        perms[0][j] = pj
+    # ---- one by one
+    solo, thetas, lags = _members(cfg, g, k, **over)
+    want = []
+    for i, eng in enumerate(solo):
+        st, stop = eng.ppo_update(lags[i], _rescale(lags[i]), B, R, perms=perms[i])
+        st2, _ = eng.ppo_update(lags[i], _rescale(lags[i]), B, R, perms=perms[i])       # Adam state carried over
+        want.append((st, stop, st2, eng.get_params()))
+        eng.close()
+    # ---- grouped
+    engs, _, _ = _members(cfg, g, k, **over)
+    grp = EngineGroup(engs)
+    resc = [_rescale(l) for l in lags]
+    st_a, stop_a = grp.ppo_update(np.stack(lags), resc, B, R, perms=perms)
+    st_b, _ = grp.ppo_update(np.stack(lags), resc, B, R, perms=perms)
+    same_shape = k == 1          # a lone member follows the single-agent tile rule step by step; k >= 2 runs 16-row tiles
+    for i in range(k):
+        st, stop, st2, th = want[i]
+        assert stop_a[i] == stop, (i, stop_a, stop)
+        assert st_a[i].shape == st.shape and st_b[i].shape == st2.shape
+        if same_shape:
+            assert np.array_equal(st_a[i], st) and np.array_equal(st_b[i], st2) and np.array_equal(engs[i].get_params(), th)
+        else:
+            np.testing.assert_allclose(st_a[i], st, rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(st_b[i], st2, rtol=2e-4, atol=2e-4)
+            # 16-row vs 4-row tiles round differently; two updates of clipped / sign-sensitive Adam steps amplify that on
+            # the few entries whose gradient is rounding noise (an Adam step there is +-lr whatever the magnitude): 99 % of
+            # the entries agree to 1 % of one learning-rate step, the tail stays below a fifth of a step
+            d = np.abs(engs[i].get_params() - th)
+            assert np.quantile(d, 0.99) <= 0.01 * cfg["lr"] and d.max() <= 0.2 * cfg["lr"], (np.quantile(d, 0.99), d.max())
+    if not over:                                        # member 0 == the reference's golden update
+        np.testing.assert_allclose(st_a[0], g["stats"], rtol=2e-5, atol=2e-5)
+    grp.close()
+    for e in engs:
+        e.close()
+
+
+def test_group_of_one_is_the_single_agent_update_bit_for_bit():
+    from fsrl_amd.engine import EngineGroup
+    cfg, g = ppo_case("c2")
+    lag = g["lagrangian"]
+    a = _engine(cfg); a.set_params(g["theta0"]); _push_golden(a, g)
+    b = _engine(cfg); b.set_params(g["theta0"]); _push_golden(b, g)
+    sa, _ = a.ppo_update(lag, _rescale(lag), cfg["batch_size"], cfg["repeat"], perms=g["perms"])
+    grp = EngineGroup([b])
+    sb, _ = grp.ppo_update([lag], [_rescale(lag)], cfg["batch_size"], cfg["repeat"], perms=[g["perms"]])
+    assert np.array_equal(sa, sb[0]) and np.array_equal(a.get_params(), b.get_params())
+    # a member's own update still works while grouped (it runs on the group's stream) ...
+    sc, _ = b.ppo_update(lag, _rescale(lag), cfg["batch_size"], cfg["repeat"], perms=g["perms"])
+    sd, _ = a.ppo_update(lag, _rescale(lag), cfg["batch_size"], cfg["repeat"], perms=g["perms"])
+    assert np.array_equal(sc, sd)
+    grp.close()
+    # ... and after the group is gone
+    se, _ = b.ppo_update(lag, _rescale(lag), cfg["batch_size"], cfg["repeat"], perms=g["perms"])
+    sf, _ = a.ppo_update(lag, _rescale(lag), cfg["batch_size"], cfg["repeat"], perms=g["perms"])
+    assert np.array_equal(se, sf)
+    a.close(); b.close()
+
+
+def test_members_with_different_batch_lengths_and_shape_checks():
+    """N_i may differ (episodes end at different times): members with fewer minibatches sit out the tail steps."""
+    from fsrl_amd.engine import Engine, EngineConfig, EngineGroup
+    rng = np.random.default_rng(0)
+    Do, Da, H = 8, 2, 64
+    lens = [300, 212, 431]
+    engs, solo = [], []
+    for which in (engs, solo):
+        for i, T in enumerate(lens):
+            e = Engine(EngineConfig(obs_dim=Do, act_dim=Da, hidden=H, env_num=2, max_grad_norm=0.5, target_kl=None))
+            r = np.random.default_rng(10 + i)
+            e.set_params((0.1 * r.standard_normal(e.n_params)).astype(np.float32))
+            obs = r.standard_normal((T + 1, 2, Do)).astype(np.float32)
+            for t in range(T):
+                e.push([0, 1], obs[t], 0.3 * r.standard_normal((2, Da)).astype(np.float32), r.normal(0.5, 0.5, 2),
+                       (r.random(2) < 0.1).astype(np.float64), [False, False], [t == T - 1] * 2, obs[t + 1])
+            which.append(e)
+    grp = EngineGroup(engs)
+    perms = [[rng.permutation(2 * T) for _ in range(2)] for T in lens]
+    lags = np.array([[0.2], [0.5], [0.9]])
+    resc = [1 / 1.2, 1 / 1.5, 1 / 1.9]
+    st, stop = grp.ppo_update(lags, resc, 128, 2, perms=perms)
+    for i, e in enumerate(solo):
+        s1, _ = e.ppo_update(lags[i], resc[i], 128, 2, perms=perms[i])
+        assert st[i].shape == s1.shape
+        np.testing.assert_allclose(st[i], s1, rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(engs[i].get_params(), e.get_params(), rtol=0, atol=5e-6)
+    other = Engine(EngineConfig(obs_dim=Do, act_dim=Da, hidden=128, env_num=2))
+    with pytest.raises(AssertionError):
+        EngineGroup([solo[0], other])                   # one network shape per group
+    with pytest.raises(AssertionError):
+        EngineGroup([engs[0]])                          # already a member of a group
+    grp.close()
+    for e in engs + solo + [other]:
+        e.close()

@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Aggregate policy-updates/s of k independent PPO-Lagrangian agents on ONE MI355X, stepped in lock step by the grouped
+launches (fsrl_group_ppo_update): the BASELINE configs[1] workload per agent (obs 8 / act 2 / 256x256 / N = 20 000 /
+batch 256 / 4 passes / grad-clip 0.5).  One JSON line per k.
+
+    python tools/bench_group.py [--ks 1 2 4 8] [--updates 6] [--no-clip]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import ACT, BATCH, ENVS, F32_MFMA_PEAK_TFLOPS, HID, NROWS, OBS, REPEAT, flops_fwdbwd_launch, make_inputs, orthogonal_theta  # noqa: E402
+from fsrl_amd.engine import Engine, EngineConfig, EngineGroup  # noqa: E402
+
+
+def run(k, updates, clip):
+    engs, thetas = [], []
+    for i in range(k):
+        e = Engine(EngineConfig(obs_dim=OBS, act_dim=ACT, hidden=HID, env_num=ENVS, buffer_size=100000, max_grad_norm=clip,
+                                target_kl=None))
+        th = orthogonal_theta(i, e.n_params)
+        obs, act, rew, cost, term, trunc = make_inputs(i)
+        ids = np.arange(ENVS)
+        for t in range(NROWS // ENVS):
+            e.push(ids, obs[t], act[t], rew[t], cost[t], term[t], trunc[t], obs[t + 1])
+        e.sync()
+        engs.append(e); thetas.append(th)
+    grp = EngineGroup(engs)
+    lags, resc = np.full((k, 1), 0.75), np.full(k, 1 / 1.75)
+
+    def one(u):
+        for e, th in zip(engs, thetas):                 # same workload every update: initial weights, fresh Adam state
+            e.set_params(th); e.optim_reset()
+        return grp.ppo_update(lags, resc, BATCH, REPEAT, seed=u + 1)[0]
+    one(0)
+    for e in engs:
+        e.sync()
+    t0 = time.perf_counter()
+    for u in range(updates):
+        st = one(u + 1)
+    for e in engs:
+        e.sync()
+    dt = (time.perf_counter() - t0) / updates
+    steps = st[0].shape[0]
+    assert all(np.isfinite(s).all() for s in st)
+    grp.close()
+    for e in engs:
+        e.close()
+    return {"agents_per_gpu": k, "aggregate_updates_per_s": k / dt, "per_agent_updates_per_s": 1 / dt,
+            "ms_per_group_update": dt * 1e3, "us_per_step_all_agents": dt * 1e6 / steps,
+            "us_per_agent_step": dt * 1e6 / steps / k, "grad_clip": clip,
+            "fwdbwd_flops_per_step_all_agents": flops_fwdbwd_launch(NROWS / (steps / REPEAT)) * k}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ks", type=int, nargs="+", default=[1, 2, 4, 8])
+    ap.add_argument("--updates", type=int, default=6)
+    ap.add_argument("--no-clip", action="store_true")
+    a = ap.parse_args()
+    for k in a.ks:
+        print(json.dumps(run(k, a.updates, None if a.no_clip else 0.5)), flush=True)
