@@ -190,6 +190,17 @@ def multi_seed(seeds=3, steps=6):
             "note": "same configs[1] workload per agent; not the headline value (that is one agent per GPU)"}
 
 
+def grouped(k=4, updates=5):
+    """Secondary figure: k independent agents of the SAME configs[1] workload on ONE GPU, stepped in lock step by the
+    grouped launches (fsrl_group_ppo_update: grid.y = agent): aggregate updates/s.  Not the headline (one agent per GPU)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_group import run
+    r = run(k, updates, 0.5)
+    r["unit"] = "updates/s (aggregate over the agents on this GPU)"
+    r["fwdbwd_tflops_all_agents"] = None
+    return r
+
+
 def no_clip_variant(theta, inputs, steps=6):
     """Secondary figure: the same update with max_grad_norm off -- PPOLagAgent's default (ppo_lag_agent.py:97; the 0.5 of
     the headline comes from the reference's config file, ppol_cfg.py:21).  Without a global gradient norm nothing stands
@@ -366,6 +377,7 @@ def main():
                                                   envs=32) for w in (4, 32) for b in (0.0, 100.0)]
             out["multi_seed"] = multi_seed()
             out["no_clip"] = no_clip_variant(theta, inputs)
+            out["grouped"] = grouped()
             out["cpu_baseline"] = cpu_baseline(theta, inputs)
             out["speedup_vs_cpu_port"] = out["value"] / world / out["cpu_baseline"]["value"]
         print(json.dumps(out))

@@ -11,4 +11,5 @@ install(__name__, globals(), {
     "SACLagrangian": "sac_lag",
     "DDPGLagrangian": "ddpg_lag",
     "CVPO": "cvpo",
+    "PolicyGroup": "grouped",
 })
