@@ -788,8 +788,11 @@ __global__ __launch_bounds__(256) void fb_sum_parts_kernel(float* __restrict__ o
     const int i = begin + blockIdx.x * 256 + threadIdx.x;
     float v = 0.0f;
     if (i < end) {
-        v = parts[i];
-        for (int z = 1; z < nparts; ++z) v += parts[(size_t)z * stride + i];
+        // the split-K partials (each an fp32 MFMA chain over >= 256 rows) are combined in float64, z ascending, and rounded
+        // once: at N = 20 000 that is up to 24 terms -- the summation-order noise fp32 conjugate gradients amplify
+        double acc = (double)parts[i];
+        for (int z = 1; z < nparts; ++z) acc += (double)parts[(size_t)z * stride + i];
+        v = (float)acc;
         out[i] = v;
     }
     if (gsq_part) {                          // per-block sum of squares (clip_grad_norm_ of the consumer)
@@ -822,27 +825,30 @@ __global__ __launch_bounds__(256) void fb_reduce_stats_kernel(const float* __res
 struct CgScal { float rs[2]; int done; int iters; };     // rs[it & 1] = r.r entering iteration `it`
 #define CG_NB 96                                          // blocks of the CG kernels (256 threads, float4 each, grid-stride)
 
-__device__ __forceinline__ float cg_block_sum256(float v, float* sh, int tid) {
-    v = wave_sum(v);
+// The dot products of conjugate gradients (p.z, r.r over ~8e4 entries) accumulate in float64 and are rounded to fp32 once:
+// fp32 CG on the damped KL Hessian amplifies summation-order noise (DESIGN.md "conditioning note"), and these sums are its
+// cheapest source to remove.  Fixed order throughout (lane tree, waves 0..3, blocks 0..CG_NB-1): deterministic.
+__device__ __forceinline__ double cg_block_sum256(double v, double* sh, int tid) {
+    v = wave_sum_d(v);
     __syncthreads();
     if ((tid & 63) == 0) sh[tid >> 6] = v;
     __syncthreads();
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 // every block adds the CG_NB partials in the same fixed order (cheap, and no extra launch)
-__device__ __forceinline__ float cg_sum_parts(const float* __restrict__ part, float* sh, int tid) {
-    float v = (tid < CG_NB) ? part[tid] : 0.0f;
-    return cg_block_sum256(v, sh, tid);
+__device__ __forceinline__ float cg_sum_parts(const double* __restrict__ part, double* sh, int tid) {
+    double v = (tid < CG_NB) ? part[tid] : 0.0;
+    return (float)cg_block_sum256(v, sh, tid);
 }
 
 // r = g, p = g (with the W2 mirror), x = 0 ; partial r.r
 __global__ __launch_bounds__(256) void cg_init_kernel(const float* __restrict__ g, float* __restrict__ r,
                                                      float* __restrict__ p, float* __restrict__ x,
-                                                     CgScal* __restrict__ sc, float* __restrict__ part, int n,
+                                                     CgScal* __restrict__ sc, double* __restrict__ part, int n,
                                                      const ModelDesc md) {
-    __shared__ float sh[4];
+    __shared__ double sh[4];
     const int tid = threadIdx.x;
-    float acc = 0.0f;
+    double acc = 0.0;
     for (int i4 = (blockIdx.x * 256 + tid) * 4; i4 < n; i4 += CG_NB * 1024) {
         const f32x4 gi = *reinterpret_cast<const f32x4*>(g + i4);
         *reinterpret_cast<f32x4*>(r + i4) = gi;
@@ -850,39 +856,41 @@ __global__ __launch_bounds__(256) void cg_init_kernel(const float* __restrict__ 
         *reinterpret_cast<f32x4*>(x + i4) = f32x4{0.f, 0.f, 0.f, 0.f};
         const int mi = w2f_mirror_of(md, i4);
         if (mi >= 0) *reinterpret_cast<f32x4*>(p + mi) = gi;
-        acc += (gi[0] * gi[0] + gi[1] * gi[1]) + (gi[2] * gi[2] + gi[3] * gi[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += (double)gi[e] * (double)gi[e];
     }
-    const float t = cg_block_sum256(acc, sh, tid);
+    const double t = cg_block_sum256(acc, sh, tid);
     if (tid == 0) part[blockIdx.x] = t;
     if (blockIdx.x == 0 && tid == 0) { sc->done = 0; sc->iters = 0; }
 }
 
 // z = H p + damping p (in place in hz) ; partial p.z
 __global__ __launch_bounds__(256) void cg_pz_kernel(float* __restrict__ hz, const float* __restrict__ p,
-                                                   const CgScal* __restrict__ sc, float* __restrict__ part, int n,
+                                                   const CgScal* __restrict__ sc, double* __restrict__ part, int n,
                                                    float damping) {
-    __shared__ float sh[4];
+    __shared__ double sh[4];
     const int tid = threadIdx.x;
     if (sc->done) return;
-    float acc = 0.0f;
+    double acc = 0.0;
     for (int i4 = (blockIdx.x * 256 + tid) * 4; i4 < n; i4 += CG_NB * 1024) {
         const f32x4 pi = *reinterpret_cast<const f32x4*>(p + i4);
         f32x4 z = *reinterpret_cast<const f32x4*>(hz + i4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) z[e] = z[e] + pi[e] * damping;
         *reinterpret_cast<f32x4*>(hz + i4) = z;
-        acc += (pi[0] * z[0] + pi[1] * z[1]) + (pi[2] * z[2] + pi[3] * z[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += (double)pi[e] * (double)z[e];
     }
-    const float t = cg_block_sum256(acc, sh, tid);
+    const double t = cg_block_sum256(acc, sh, tid);
     if (tid == 0) part[blockIdx.x] = t;
 }
 
 // alpha = rs_old / p.z ; x += alpha p ; r -= alpha z ; partial r.r       (rs_old = sum of part_rr when it == 0)
 __global__ __launch_bounds__(256) void cg_xr_kernel(const float* __restrict__ hz, float* __restrict__ r,
                                                    const float* __restrict__ p, float* __restrict__ x,
-                                                   CgScal* __restrict__ sc, const float* __restrict__ part_pz,
-                                                   float* __restrict__ part_rr, int n, int it) {
-    __shared__ float sh[4];
+                                                   CgScal* __restrict__ sc, const double* __restrict__ part_pz,
+                                                   double* __restrict__ part_rr, int n, int it) {
+    __shared__ double sh[4];
     const int tid = threadIdx.x;
     if (sc->done) return;
     float rs_old;
@@ -892,7 +900,7 @@ __global__ __launch_bounds__(256) void cg_xr_kernel(const float* __restrict__ hz
     const float pAp = cg_sum_parts(part_pz, sh, tid);
     __syncthreads();
     const float alpha = rs_old / pAp;
-    float acc = 0.0f;
+    double acc = 0.0;
     for (int i4 = (blockIdx.x * 256 + tid) * 4; i4 < n; i4 += CG_NB * 1024) {
         const f32x4 pi = *reinterpret_cast<const f32x4*>(p + i4);
         const f32x4 z = *reinterpret_cast<const f32x4*>(hz + i4);
@@ -901,10 +909,11 @@ __global__ __launch_bounds__(256) void cg_xr_kernel(const float* __restrict__ hz
         for (int e = 0; e < 4; ++e) { xi[e] = xi[e] + alpha * pi[e]; ri[e] = ri[e] - alpha * z[e]; }
         *reinterpret_cast<f32x4*>(x + i4) = xi;
         *reinterpret_cast<f32x4*>(r + i4) = ri;
-        acc += (ri[0] * ri[0] + ri[1] * ri[1]) + (ri[2] * ri[2] + ri[3] * ri[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += (double)ri[e] * (double)ri[e];
     }
     __syncthreads();
-    const float t = cg_block_sum256(acc, sh, tid);
+    const double t = cg_block_sum256(acc, sh, tid);
     // the new partials must not overwrite part_rr while other blocks still read it at it == 0:
     // they go to the second half of the buffer on even iterations, the first half on odd ones
     if (tid == 0) part_rr[((it & 1) ? 0 : CG_NB) + blockIdx.x] = t;
@@ -913,9 +922,9 @@ __global__ __launch_bounds__(256) void cg_xr_kernel(const float* __restrict__ hz
 
 // rs_new = sum partials ; converged -> done ; else p = r + (rs_new / rs_old) p (with the W2 mirror)
 __global__ __launch_bounds__(256) void cg_p_kernel(const float* __restrict__ r, float* __restrict__ p,
-                                                  CgScal* __restrict__ sc, const float* __restrict__ part_rr, int n,
+                                                  CgScal* __restrict__ sc, const double* __restrict__ part_rr, int n,
                                                   int it, float tol, const ModelDesc md) {
-    __shared__ float sh[4];
+    __shared__ double sh[4];
     const int tid = threadIdx.x;
     if (sc->done) return;
     const float rs_new = cg_sum_parts(part_rr + ((it & 1) ? 0 : CG_NB), sh, tid);

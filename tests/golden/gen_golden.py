@@ -160,7 +160,7 @@ def build_ppo(obs_dim, act_dim, hidden, seed, max_action=1.0, last_layer_scale=F
 
 
 def fill_buffer(rng, env_num, ep_lens_per_env, obs_dim, act_dim, term_prob=0.3,
-                buffer_size=100000):
+                buffer_size=100000, cost_prob=0.1):
     """Synthetic rollouts pushed in lock-step like FastCollector does (fast_collector.py:333).
     ep_lens_per_env[e] = list of episode lengths; the LAST episode of env e may be left
     unfinished by giving a negative length (-k => k steps, no done)."""
@@ -185,7 +185,7 @@ def fill_buffer(rng, env_num, ep_lens_per_env, obs_dim, act_dim, term_prob=0.3,
         nxt = rng.standard_normal((k, obs_dim)).astype(np.float32)
         act = (0.3 * rng.standard_normal((k, act_dim))).astype(np.float32)
         rew = rng.normal(0.5, 0.5, k)
-        cost = (rng.random(k) < 0.1).astype(np.float64)
+        cost = (rng.random(k) < cost_prob).astype(np.float64)      # same draws for every cost_prob
         term = np.array([plan[e][t][0] for e in ids])
         trunc = np.array([plan[e][t][1] for e in ids])
         done = term | trunc

@@ -72,17 +72,24 @@ def record_batch(out, buf):
 
 
 def gen_cpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cost_stat, cost_limit,
-            lr=1e-3, perturb_actor=0.0, **kw):
+            lr=1e-3, perturb_actor=0.0, zero_cost_signal=False, **kw):
     """cost_stat / cost_limit steer the optim_case; perturb_actor moves theta away from the
     theta that produced mean_old (exercises the exact-Hessian path on the very first call)."""
     actor, critic, ac = build_nets(obs_dim, act_dim, hidden, seed)
+    if zero_cost_signal:
+        # optim_case 4 (cpo.py:261-268: grad_b . grad_b <= 1e-8 and c < 0): no cost in the data and a cost critic that
+        # answers 0 everywhere (zero last layer) => cost advantages are exactly 0 => the cost-surrogate gradient vanishes
+        with torch.no_grad():
+            for p in critic[1].last.parameters():
+                p.zero_()
     optim = torch.optim.Adam(nn.ModuleList(critic).parameters(), lr=lr)
     logger = CaptureLogger()
     policy = CPO(actor, critic, optim, dist, logger=logger, cost_limit=cost_limit,
                  observation_space=_Box(-np.inf, np.inf, (obs_dim, )),
                  action_space=_Box(-1, 1, (act_dim, )), **kw)
     policy.train()
-    buf = fill_buffer(np.random.default_rng(seed + 1000), env_num, ep_lens, obs_dim, act_dim)
+    buf = fill_buffer(np.random.default_rng(seed + 1000), env_num, ep_lens, obs_dim, act_dim,
+                      cost_prob=0.0 if zero_cost_signal else 0.1)
     out = {"theta0": flat_params(ac)}
     record_batch(out, buf)
     policy.pre_update_fn(stats_train={"cost": cost_stat})
@@ -209,6 +216,11 @@ def gen_trpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cos
 if __name__ == "__main__":
     torch.set_num_threads(4)
     eps = [[100, 100], [100, -60], [120, 80]]
+    if sys.argv[1:] == ["case4"]:
+        # the vanishing-cost-gradient branch: zero cost signal, no advantage normalisation (0 / 0 otherwise), c < 0
+        gen_cpo("case4", 8, 2, (64, 64), 3, eps, repeat=2, seed=16, cost_stat=0.0, cost_limit=10.0,
+                optim_critic_iters=3, max_backtracks=12, advantage_normalization=False, zero_cost_signal=True)
+        sys.exit(0)
     # cost far above the limit (c > 0): infeasible / recovery branches
     gen_cpo("infeasible", 8, 2, (64, 64), 3, eps, repeat=2, seed=10, cost_stat=25.0, cost_limit=10.0,
             optim_critic_iters=5, max_backtracks=10)

@@ -100,16 +100,27 @@ def test_cpo_configs2_full_size():
     for k in ("loss/entropy", "loss/cost_loss", "loss/optim_C"):
         assert _rel(got[k], sa[k]) <= 2e-5 + 1e-6, (k, got[k], sa[k])
     assert abs(got["loss/rew_loss"] - sa["loss/rew_loss"]) <= 2e-6
-    # everything downstream of the two fp32 CG solves (Q, R, S and what the dual solve derives from them): 5e-4
-    # (observed on MI355X: Q 2.5e-5, S 1.4e-5, R 8e-5 of sqrt(QS), nu 7e-6 -- at N = 20 000 the batch Hessian is far
-    # better conditioned than in the N = 480 fixtures, where the reference itself moves by 1e-3 with the row order)
+    # everything downstream of the two CG solves (Q, R, S and what the dual solve derives from them).  fp32 CG amplifies
+    # rounding: the reference's own fp32 arithmetic sits 3e-4 .. 6e-4 from the float64 evaluation of the same algorithm
+    # (S, nu; measured).  The device accumulates the CG dot products and the split-K partial sums in float64, so it must
+    # be (a) within 2e-3 of the fp32 oracle and (b) at least as close to the float64 oracle as the fp32 oracle is
+    # (observed: S 8e-5 vs 6e-4, nu 4e-5 vs 3e-4, Q 4.5e-4 vs 4.4e-4).
+    o64 = CPOOracle(ocfg, dtype=torch.float64)
+    o64.set_params(theta)
+    _, rows64 = o64.update(data, 25.0, 1)
+    s64 = rows64[0][0]
+    print("cpo full size  float64 oracle:", {k: s64[k] for k in ("loss/optim_Q", "loss/optim_R", "loss/optim_S", "loss/optim_nu")})
     # R = g.H^-1 b is a cross term (here |R| << sqrt(Q S): the two gradients are nearly H-orthogonal), so it is measured
     # against sqrt(Q S), the scale its rounding noise has
     qs = float(np.sqrt(sa["loss/optim_Q"] * sa["loss/optim_S"]))
+    assert int(s64["loss/optim_case"]) == int(sa["loss/optim_case"])
     for k in ("loss/optim_Q", "loss/optim_R", "loss/optim_S", "loss/optim_A", "loss/optim_B", "loss/optim_lam",
               "loss/optim_nu"):
         floor = qs if k == "loss/optim_R" else 1e-3
-        assert _rel(got[k], sa[k], floor) <= 5e-4, (k, got[k], sa[k])
+        assert _rel(got[k], sa[k], floor) <= 2e-3, (k, got[k], sa[k])
+        scale = max(abs(float(s64[k])), floor)
+        err_dev, err_ref = abs(float(got[k]) - float(s64[k])) / scale, abs(float(sa[k]) - float(s64[k])) / scale
+        assert err_dev <= 1.25 * err_ref + 1e-4, (k, float(got[k]), sa[k], s64[k], err_dev, err_ref)
     th = eng.get_params()
     d = np.abs(th - o.get_params())
     print("cpo theta diff max / mean", d.max(), d.mean())

@@ -3,9 +3,11 @@ gradients and Hessian-vector products against torch autograd (double backward) o
 full learn() against the golden vectors recorded from the unmodified reference.
 
 Tolerances: single gradients / HVPs 2e-5 of the vector's max-norm (fp32, different summation
-order); anything downstream of conjugate gradients is compared at 2e-2 relative: the reference
-itself moves by ~1e-3 in Q/R/S when the (mathematically irrelevant) row order of its shuffled
-full batch changes -- fp32 CG on the damped Hessian amplifies summation-order noise."""
+order); anything downstream of conjugate gradients is compared at 8e-3 (CPO) / 2e-3 (TRPO-Lag) relative: the
+reference itself moves by ~1e-3 in Q/R/S when the (mathematically irrelevant) row order of its shuffled
+full batch changes -- fp32 CG on the damped Hessian amplifies summation-order noise.  The device's CG dot
+products and split-K sums accumulate in float64 (round 2): it sits closer to the float64 evaluation of the
+algorithm than the reference's own fp32 run does (tests/test_gpu_fullsize.py checks exactly that at N = 20 000)."""
 import json
 
 import numpy as np
@@ -88,7 +90,7 @@ CPO_KEYS = ["loss/kl", "loss/entropy", "loss/rew_loss", "loss/cost_loss", "loss/
             "loss/optim_nu", "loss/optim_case", "loss/step_size", "loss/vf0", "loss/vf1", "loss/vf_total"]
 
 
-@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2"])
+@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4"])
 def test_cpo_learn_vs_golden(name):
     g = load_npz(f"cpo_{name}.npz")
     cfg = json.loads(str(g["cfg_json"]))
@@ -113,11 +115,13 @@ def test_cpo_learn_vs_golden(name):
         assert abs(k) <= (1.05 if r == 1 else 4.05), (stats[:, si], want[:, si])
     # first repeat: everything downstream of CG at 2e-2; critic losses tight
     for j, k in enumerate(CPO_KEYS):
-        tol = 2e-5 if k.startswith("loss/vf") or k in ("loss/entropy", "loss/cost_loss", "loss/optim_C") else 2e-2
+        # downstream of CG: 8e-3 (observed <= 4.5e-3 on these N ~ 500 batches with the float64 CG dot products; 2e-2 in
+        # round 1 with fp32 dots) -- the reference itself moves by ~1e-3 when its batch is re-ordered
+        tol = 2e-5 if k.startswith("loss/vf") or k in ("loss/entropy", "loss/cost_loss", "loss/optim_C") else 8e-3
         scale = max(abs(want[0, j]), 1e-3)
         assert abs(stats[0, j] - want[0, j]) <= tol * scale + 1e-6, (k, stats[0, j], want[0, j])
     th = eng.get_params()
-    assert np.abs(th - g["theta_final"]).max() <= 5e-3 and np.abs(th - g["theta_final"]).mean() <= 2e-4
+    assert np.abs(th - g["theta_final"]).max() <= 3e-3 and np.abs(th - g["theta_final"]).mean() <= 5e-5
     eng.close()
 
 
@@ -138,10 +142,10 @@ def test_trpo_learn_vs_golden(name):
     keys = [str(k) for k in g["stats_keys"]]
     want = g["stats"][:, [keys.index(k) for k in TRPO_KEYS]]
     for j, k in enumerate(TRPO_KEYS):
-        tol = 2e-2 if k in ("loss/kl", "loss/step_size") else 2e-4
+        tol = 2e-3 if k in ("loss/kl", "loss/step_size") else 2e-4      # observed <= 4e-4
         scale = max(abs(want[0, j]), 1e-3)
         assert abs(stats[0, j] - want[0, j]) <= tol * scale + 1e-6, (k, stats[0], want[0])
     np.testing.assert_allclose(stats, want, rtol=5e-2, atol=2e-3)
     th = eng.get_params()
-    assert np.abs(th - g["theta_final"]).max() <= 5e-3 and np.abs(th - g["theta_final"]).mean() <= 2e-4
+    assert np.abs(th - g["theta_final"]).max() <= 1.5e-3 and np.abs(th - g["theta_final"]).mean() <= 5e-6
     eng.close()

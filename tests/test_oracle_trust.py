@@ -34,7 +34,7 @@ def trpo_cfg(cfg):
                       use_lagrangian=cfg["use_lagrangian"], lr=cfg["lr"])
 
 
-@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2"])
+@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4"])
 def test_cpo_update(name):
     torch.set_num_threads(4)
     g = load_npz(f"cpo_{name}.npz")
