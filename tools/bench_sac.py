@@ -76,6 +76,17 @@ def main():
            "config": {"workload": f"SAC-Lag SafetyAntRun shape obs {Do} act {Da} {H}x{H}, store {T * E} rows in HBM, "
                                   f"batch {B}, n_step 2", "updates": a.updates},
            "store_fill_rows_per_s": T * E / fill_s, "dtype": "fp32"}
+    # roofline of the whole update (12 launches): algorithmic FLOPs per sample (~4.9 MFLOP at 256x256)
+    Fq = 2 * ((Do + Da) * H + H * H + H); Fa = 2 * (Do * H + H * H + H * 2 * Da)
+    per_sample = (2 * Fa            # actor forwards at s_{t+n} and s_t
+                  + 4 * Fq          # four target Q-nets
+                  + 4 * 3 * Fq      # critic step: forward + backward of four Q-nets
+                  + 4 * 2 * Fq      # Q(s, a_pi) forward + input gradient of four Q-nets
+                  + 2 * Fa)         # actor backward
+    flops = per_sample * B
+    out["roofline"] = {"bound": "mfma", "scope": "whole update (12 launches)", "achieved": flops / dev / 1e12, "peak": 157.3,
+                       "unit": "TFLOP/s", "frac": flops / dev / 1e12 / 157.3, "flops_per_update": flops,
+                       "algorithmic_gather_bytes": B * ((2 * Do + Da) * 4 + 17), "traffic": None}
     if not a.no_cpu:
         torch.set_num_threads(4)
         o.set_params(th_a, th_c, 0.0)

@@ -74,8 +74,20 @@ def run(kind, obs_dim, act_dim, hid, envs=20, T=1000, ep=1000, repeat=4, cpu_rep
     for _ in range(n):
         stats = device_update()
     dt = (time.perf_counter() - t0) / n
+    # ---- roofline of the whole update: algorithmic FLOPs (forward F = 2(Do H + H H + H out) per row and
+    #      network, gradient = 3 F, Hessian-vector product = 3 F_actor) over the measured time, against the fp32 MFMA peak
+    N = envs * T
+    Fa = 2 * (obs_dim * hid + hid * hid + hid * act_dim); Fc = 2 * (obs_dim * hid + hid * hid + hid)
+    evals = float(np.sum(eng.tr_linesearch_evals()))                       # line-search forwards of the last update
+    if kind == "cpo":       # per repeat: 10 critic steps x 2 critics, 2 gradients, 2 CG solves x (10 + 1) HVPs
+        flops = repeat * (10 * 2 * 3 * Fc + (2 + 22) * 3 * Fa) * N + evals * Fa * N
+    else:                   # per repeat: 1 gradient, 10 + 1 HVPs, 20 critic steps x 2 critics
+        flops = repeat * ((1 + 11) * 3 * Fa + 20 * 2 * 3 * Fc) * N + evals * Fa * N
+    roof = {"bound": "mfma", "scope": "whole update (all launches, host line-search control included)",
+            "achieved": flops / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / dt / 1e12 / 157.3,
+            "flops_per_update": flops, "traffic": None}
     if os.environ.get("FSRL_NO_CPU"):
-        print(json.dumps({"bench": kind, "hip_ms_per_update": dt * 1e3})); eng.close(); return
+        print(json.dumps({"bench": kind, "hip_ms_per_update": dt * 1e3, "roofline": roof})); eng.close(); return
     em = lambda a: np.concatenate([a[:, e] for e in range(envs)])
     data = OnPolicyData(obs=em(obs[:-1]), act=em(act), rew=em(rew), cost=em(cost), terminated=em(term),
                         truncated=em(trunc), obs_next=em(obs[1:]), end_flag=em(term | trunc))
@@ -92,6 +104,8 @@ def run(kind, obs_dim, act_dim, hid, envs=20, T=1000, ep=1000, repeat=4, cpu_rep
     print(json.dumps({"bench": kind, "obs": obs_dim, "act": act_dim, "hidden": hid, "N": envs * T,
                       "repeat": repeat, "hip_ms_per_update": dt * 1e3, "hip_updates_per_s": 1 / dt,
                       "cpu_oracle_ms_per_update_4thr": cdt * 1e3, "speedup": cdt / dt,
+                      "roofline": roof, "cpu_baseline": {"value": 1.0 / cdt, "unit": "updates/s", "cores": 4, "kind": "port",
+                                                         "sample": f"{cpu_repeat} of {repeat} repeats of the same update (oracle, torch fp32)"},
                       "hip_first_repeat": [float(x) for x in stats[0]],
                       "oracle_first_repeat": {k: float(v) for k, v in ostat.items()}}))
     eng.close()
@@ -121,8 +135,12 @@ def run_focops(obs_dim=8, act_dim=2, hid=256, envs=20, T=1000, ep=250, batch=256
     for k in range(n):
         stats, _ = device_update(k + 1)
     dt = (time.perf_counter() - t0) / n
+    Fa = 2 * (obs_dim * hid + hid * hid + hid * act_dim); Fc = 2 * (obs_dim * hid + hid * hid + hid)
+    flops = repeat * envs * T * 3 * (Fa + 2 * Fc) + envs * T * (4 * Fc + Fa)          # learn + process_fn, like PPO-Lag
     out = {"bench": "focops", "obs": obs_dim, "act": act_dim, "hidden": hid, "N": envs * T, "batch": batch, "repeat": repeat,
-           "steps": int(stats.shape[0]), "hip_ms_per_update": dt * 1e3, "hip_us_per_step": dt * 1e6 / stats.shape[0]}
+           "steps": int(stats.shape[0]), "hip_ms_per_update": dt * 1e3, "hip_us_per_step": dt * 1e6 / stats.shape[0],
+           "roofline": {"bound": "mfma", "scope": "whole update", "achieved": flops / dt / 1e12, "peak": 157.3,
+                        "unit": "TFLOP/s", "frac": flops / dt / 1e12 / 157.3, "flops_per_update": flops, "traffic": None}}
     if not os.environ.get("FSRL_NO_CPU"):
         em = lambda a: np.concatenate([a[:, e] for e in range(envs)])  # noqa: E731
         data = OnPolicyData(obs=em(obs[:-1]), act=em(act), rew=em(rew), cost=em(cost), terminated=em(term),

@@ -12,7 +12,15 @@ cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_profiled.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+# MFMA utilisation (north_star: "rocprof HBM GB/s and MFMA utilisation"): busy cycles of the matrix pipe, the fp32 MFMA
+# op count and the GPU-active cycles per dispatch -- its own pass, kernel trace only
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_pmc_mfma -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_pmc_mfma_trust -- env FSRL_NO_CPU=1 python $R/tools/bench_trust.py > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_pmc_mfma_sac -- python $R/tools/bench_sac.py --rows 200000 --updates 200 --no-cpu > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_trust -- env FSRL_NO_CPU=1 python $R/tools/bench_trust.py > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_group -- python $R/tools/bench_group.py --ks 4 --updates 3 > /dev/null 2>&1
 cd $R
+timeout 300 python tools/bench_group.py > $O/${TAG}_bench_group.json 2>/dev/null
 timeout 300 python tools/bench_sac.py > $O/${TAG}_bench_sac.json 2>/dev/null
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_sac -- python $R/tools/bench_sac.py --rows 200000 --updates 300 --no-cpu > /dev/null 2>&1

@@ -23,11 +23,12 @@ def one(pattern):
 
 for src, dst in ((f"{tag}_bench.json", f"{tag}_bench.json"), (f"{tag}_bench_profiled.json", f"{tag}_bench_profiled.json"),
                  (f"{tag}_bench_sac.json", f"{tag}_bench_sac.json"), (f"{tag}_bench_trust.json", f"{tag}_bench_trust.json"),
-                 (f"{tag}_bench_cvpo.json", f"{tag}_bench_cvpo.json")):
+                 (f"{tag}_bench_cvpo.json", f"{tag}_bench_cvpo.json"), (f"{tag}_bench_group.json", f"{tag}_bench_group.json")):
     if os.path.exists(os.path.join(go, src)):
         shutil.copy(os.path.join(go, src), os.path.join(pr, dst))
 for sub, dst in ((f"{tag}_prof_bench", f"{tag}_kernel_stats.csv"), (f"{tag}_prof_sac", f"{tag}_sac_kernel_stats.csv"),
-                 (f"{tag}_prof_cvpo", f"{tag}_cvpo_kernel_stats.csv")):
+                 (f"{tag}_prof_cvpo", f"{tag}_cvpo_kernel_stats.csv"), (f"{tag}_prof_trust", f"{tag}_trust_kernel_stats.csv"),
+                 (f"{tag}_prof_group", f"{tag}_group_kernel_stats.csv")):
     f = one(f"{sub}/**/*_kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(pr, dst))
@@ -56,3 +57,31 @@ for name, t in traffic.items():
 if out:
     json.dump(out, open(os.path.join(pr, f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps({k: round(v["hbm_bytes_per_launch"]) for k, v in out.items()}, indent=1))
+
+# ---- MFMA utilisation per kernel from the SQ counter passes (one dispatch = one row per counter):
+#      util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMDs) -- rocprofv3's own MfmaUtil expression, 256 CUs x 4 SIMDs --
+#      and the fp32 MFMA FLOPs the hardware counted per launch (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512).
+SIMDS = 256 * 4
+mf = {}
+for sub in (f"{tag}_pmc_mfma", f"{tag}_pmc_mfma_trust", f"{tag}_pmc_mfma_sac"):
+    f = one(f"{sub}/**/*_counter_collection.csv")
+    if not f:
+        continue
+    acc = defaultdict(lambda: defaultdict(float))
+    disp = defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0]
+        acc[name][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[name].add(r.get("Dispatch_Id", r.get("Correlation_Id", "")))
+    for name, c in acc.items():
+        n = max(len(disp[name]), 1)
+        gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+        mf[name] = {"launches": n, "mfma_busy_cycles_per_launch": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / n,
+                    "gpu_active_cycles_per_launch": gui / n,
+                    "mfma_util_pct": 100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * SIMDS) if gui else None,
+                    "mfma_f32_flops_per_launch": c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512 / n,
+                    "sq_busy_cycles_per_launch": c.get("SQ_BUSY_CYCLES", 0.0) / n, "source": sub}
+if mf:
+    json.dump(mf, open(os.path.join(pr, f"{tag}_pmc_mfma.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: (round(v["mfma_util_pct"], 2) if v["mfma_util_pct"] is not None else None) for k, v in mf.items()
+                      if v["mfma_f32_flops_per_launch"] > 0}, indent=1))
