@@ -18,7 +18,7 @@ class Config(C.Structure):
                 ("gae_lambda", C.c_double), ("eps_clip", C.c_float), ("dual_clip", C.c_float),
                 ("vf_coef", C.c_float), ("max_grad_norm", C.c_float), ("target_kl", C.c_float),
                 ("norm_adv", C.c_int32), ("use_lagrangian", C.c_int32), ("lr", C.c_float),
-                ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float)]
+                ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float), ("recompute_adv", C.c_int32)]
 
 
 class TrConfig(C.Structure):

@@ -99,6 +99,7 @@ struct fsrl_ctx {
     int* h_indices = nullptr; uint8_t* h_end = nullptr; int* h_seg = nullptr;  // pinned
     float *values = nullptr, *vnext = nullptr, *advs = nullptr, *rets = nullptr, *logp_old = nullptr;
     int64_t N = 0;
+    int n_seg = 0;                 // episode segments of the current batch (GAE scan)
     bool batch_ready = false;
 
     // ppo working set

@@ -41,6 +41,7 @@ class EngineConfig:
     beta1: float = 0.9
     beta2: float = 0.999
     adam_eps: float = 1e-8
+    recompute_adv: bool = False
     algo: int = _lib.ALGO_PPO_LAG
 
     def to_c(self):
@@ -54,6 +55,7 @@ class EngineConfig:
         c.target_kl = 0.0 if (tk is None or not np.isfinite(tk) or tk >= 1e8) else tk
         c.norm_adv, c.use_lagrangian = int(self.norm_adv), int(self.use_lagrangian)
         c.lr, c.beta1, c.beta2, c.adam_eps = self.lr, self.beta1, self.beta2, self.adam_eps
+        c.recompute_adv = int(self.recompute_adv)
         return c
 
 

@@ -71,6 +71,8 @@ typedef struct fsrl_config {
     int32_t use_lagrangian;
     float lr;                /* Adam, one optimiser over actor+critics                   */
     float beta1, beta2, adam_eps;
+    int32_t recompute_adv;   /* PPO: recompute V, GAE, returns with the CURRENT critics before every pass after the
+                                first (ppo_lag.py:218-221 recompute_advantage); logp_old stays                       */
 } fsrl_config;
 
 const char* fsrl_last_error(void);

@@ -51,6 +51,7 @@ class PPOLagConfig:
     lr: float = 5e-4
     betas: Tuple[float, float] = (0.9, 0.999)
     adam_eps: float = 1e-8
+    recompute_advantage: bool = False
 
 
 @dataclass
@@ -206,7 +207,7 @@ class PPOLagOracle:
         loss = loss_actor + cfg.vf_coef * loss_vf
         return loss, dist, stats
 
-    def learn(self, pb, lagrangians, rescaling, batch_size, repeat, perms=None):
+    def learn(self, pb, lagrangians, rescaling, batch_size, repeat, perms=None, data=None):
         """Minibatch SGD passes.  `perms[k]` = permutation of pass k (None: draw from the
         numpy global RNG like Batch.split).  Returns (stats [steps, 11] f64, early_stop_pass)."""
         cfg = self.cfg
@@ -214,6 +215,9 @@ class PPOLagOracle:
         rows = []
         stopped_at = -1
         for k in range(repeat):
+            if cfg.recompute_advantage and k > 0:      # ppo_lag.py:218-221: values / rets / advs from the current critics
+                fresh = self.process(data)
+                pb = dict(pb, values=fresh["values"], rets=fresh["rets"], advs=fresh["advs"])
             perm = np.random.permutation(n) if perms is None else perms[k]
             approx_kl, iters = 0.0, 0
             for idx in split_chunks(n, batch_size, perm, merge_last=True):
@@ -237,5 +241,5 @@ class PPOLagOracle:
 
     def update(self, data: OnPolicyData, lagrangians, rescaling, batch_size, repeat, perms=None):
         pb = self.process(data)
-        stats, stopped_at = self.learn(pb, lagrangians, rescaling, batch_size, repeat, perms)
+        stats, stopped_at = self.learn(pb, lagrangians, rescaling, batch_size, repeat, perms, data=data)
         return pb, stats, stopped_at

@@ -313,11 +313,19 @@ def gen_ppo():
     gen_ppo_case("earlystop", obs_dim=8, act_dim=2, hidden=(64, 64), env_num=2,
                  ep_lens=[[200, 100], [150, 150]], batch_size=64, repeat=6, seed=3,
                  max_grad_norm=0.5, target_kl=0.005, lr=3e-3)
+    gen_ppo_recompute()
     # lagrangian off / no adv-norm / dual clip branch
     gen_ppo_case("dualclip", obs_dim=6, act_dim=2, hidden=(64, 64), env_num=2,
                  ep_lens=[[100, 100], [100, -60]], batch_size=128, repeat=2, seed=4,
                  max_grad_norm=None, target_kl=1e9, dual_clip=3.0,
                  advantage_normalization=False)
+
+
+def gen_ppo_recompute():
+    # recompute_advantage (ppo_lag.py:218-221): GAE from the CURRENT critics before passes 2 and 3
+    gen_ppo_case("recompute", obs_dim=6, act_dim=2, hidden=(64, 64), env_num=3,
+                 ep_lens=[[70, 60, -25], [80, 75], [50, 50, 50]], batch_size=64, repeat=3, seed=5,
+                 max_grad_norm=0.5, target_kl=1e9, recompute_advantage=True)
 
 
 def gen_manifest():
@@ -333,5 +341,5 @@ if __name__ == "__main__":
     torch.set_num_threads(4)
     which = sys.argv[1:] or ["gae", "nstep", "pid", "ppo", "manifest"]
     for w in which:
-        {"gae": gen_gae, "nstep": gen_nstep, "pid": gen_pid, "ppo": gen_ppo,
+        {"gae": gen_gae, "nstep": gen_nstep, "pid": gen_pid, "ppo": gen_ppo, "recompute": gen_ppo_recompute,
          "manifest": gen_manifest}[w]()

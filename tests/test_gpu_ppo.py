@@ -13,7 +13,7 @@ from helpers import load_npz, oracle_cfg_and_data, ppo_case
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["tiny", "dualclip", "earlystop", "c1", "c2"]
+CASES = ["tiny", "dualclip", "earlystop", "c1", "c2", "recompute"]
 
 
 def _engine(cfg, **over):
@@ -24,7 +24,7 @@ def _engine(cfg, **over):
                       eps_clip=cfg["eps_clip"], dual_clip=cfg["dual_clip"], vf_coef=cfg["vf_coef"],
                       max_grad_norm=cfg["max_grad_norm"], target_kl=cfg["target_kl"],
                       norm_adv=cfg["advantage_normalization"], use_lagrangian=cfg["use_lagrangian"],
-                      lr=cfg["lr"])
+                      lr=cfg["lr"], recompute_adv=bool(cfg.get("recompute_advantage", False)))
     for k, v in over.items():
         setattr(ec, k, v)
     return Engine(ec)

@@ -10,7 +10,7 @@ from helpers import oracle_cfg_and_data, ppo_case
 from oracle.pid import rescaling_factor
 from oracle.ppo_lag import PPOLagOracle, split_chunks
 
-CASES = ["tiny", "c1", "c2", "earlystop", "dualclip"]
+CASES = ["tiny", "c1", "c2", "earlystop", "dualclip", "recompute"]
 
 
 def test_split_chunks_matches_tianshou_semantics():

@@ -59,9 +59,12 @@ if out:
     print(json.dumps({k: round(v["hbm_bytes_per_launch"]) for k, v in out.items()}, indent=1))
 
 # ---- MFMA utilisation per kernel from the SQ counter passes (one dispatch = one row per counter):
-#      util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMDs) -- rocprofv3's own MfmaUtil expression, 256 CUs x 4 SIMDs --
+#      util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x SIMDs) -- rocprofv3's own MfmaUtil expression, 256 CUs x 4
+#      SIMDs; SQ_VALU_MFMA_BUSY_CYCLES is the sum over all SIMDs of the cycles their matrix pipe was busy (K1: 192
+#      workgroups x 16 waves x 128 v_mfma_f32_4x4x1 x 8 cycles = 3 145 728, the reported value to the digit) --
 #      and the fp32 MFMA FLOPs the hardware counted per launch (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512).
-SIMDS = 256 * 4
+SIMDS, XCDS = 256 * 4, 8      # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs (checked: = 8 x kernel duration x clock),
+                                # the MfmaUtil expression takes one instance (reduce(max)): divide by 8
 mf = {}
 for sub in (f"{tag}_pmc_mfma", f"{tag}_pmc_mfma_trust", f"{tag}_pmc_mfma_sac"):
     f = one(f"{sub}/**/*_counter_collection.csv")
@@ -75,7 +78,7 @@ for sub in (f"{tag}_pmc_mfma", f"{tag}_pmc_mfma_trust", f"{tag}_pmc_mfma_sac"):
         disp[name].add(r.get("Dispatch_Id", r.get("Correlation_Id", "")))
     for name, c in acc.items():
         n = max(len(disp[name]), 1)
-        gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+        gui = c.get("GRBM_GUI_ACTIVE", 0.0) / XCDS
         mf[name] = {"launches": n, "mfma_busy_cycles_per_launch": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / n,
                     "gpu_active_cycles_per_launch": gui / n,
                     "mfma_util_pct": 100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * SIMDS) if gui else None,
