@@ -313,7 +313,7 @@ def main():
     dt = time.perf_counter() - t0
     grad_steps = stats.shape[0]
     assert np.isfinite(stats).all()
-    per_rank = None
+    per_rank, lib_comm, dt_local = None, None, dt
     if dist is not None:
         # the SURVEY 8(e) exchange: every rank's figures gathered once (RCCL all_gather of a 5-double vector), then the
         # max-over-ranks time the contract asks for
@@ -324,6 +324,26 @@ def main():
         tt = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # the same exchange through the C ABI's own RCCL communicator (fsrl_comm_init + fsrl_metrics_allreduce), checked
+        # against torch.distributed's sum; outside the timed region.  Every rank first proves it can reach RCCL, so a rank
+        # that cannot does not leave the others waiting inside ncclCommInitRank.
+        if args.backend == "nccl" and os.environ.get("FSRL_BENCH_LIB_COMM", "1") != "0":
+            try:
+                eng.comm_unique_id(); ok = 1.0
+            except Exception as e:                          # noqa: BLE001
+                ok, lib_comm = 0.0, f"unavailable: {e}"
+            flag = torch.tensor([ok], device="cuda", dtype=torch.float64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) == 1.0:
+                eng.comm_init_from_torch()
+                mine = np.array([1.0, float(rank), args.steps / dt_local, float(seed)])
+                got = eng.metrics_allreduce(mine)
+                want = torch.from_numpy(mine).cuda()
+                dist.all_reduce(want, op=dist.ReduceOp.SUM)
+                lib_comm = "ok" if np.array_equal(got, want.cpu().numpy()) and eng.comm_info() == (rank, world) else "mismatch"
+                eng.comm_destroy()
+            elif ok == 1.0:
+                lib_comm = "skipped: another rank cannot reach RCCL"
     # ---- roofline of the dominant kernel: HIP events around every ppo_fwd_bwd_kernel launch on
     #      the library's compute stream, over K more updates of the same workload
     eng.set_profiling(True)
@@ -364,6 +384,8 @@ def main():
         }
         if per_rank is not None:
             out["ranks_seen"] = len(per_rank)
+            if lib_comm is not None:
+                out["lib_metrics_allreduce"] = lib_comm
             out["per_rank_updates_per_s"] = [round(r["updates_per_s"], 3) for r in sorted(per_rank, key=lambda r: r["rank"])]
             out["sum_of_rank_rates"] = sum(r["updates_per_s"] for r in per_rank)
         pmc = pmc_traffic()

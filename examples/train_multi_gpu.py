@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--busy-us", type=float, default=0.0, help="host time burnt per env step (a simulator's cost)")
     ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"])
     ap.add_argument("--share-gpu", action="store_true")
+    ap.add_argument("--metrics-via", default="torch", choices=["torch", "lib"],
+                    help="lib: the epoch vector goes through the C ABI's own RCCL communicator (fsrl_metrics_allreduce); "
+                         "torch.distributed then only hands the 128-byte communicator id around")
     ap.add_argument("--logdir", default=None)
     ap.add_argument("--json", action="store_true", help="rank 0: print the final job summary as one JSON line")
     a = ap.parse_args()
@@ -60,6 +63,8 @@ def main():
     logger = BaseLogger(logdir, name=f"{a.algo}-seed{seed}")            # every rank keeps its own seed's curve
     agent = agents[a.algo](env, logger, cost_limit=a.cost_limit, device=f"cuda:{local_rank}", seed=seed,
                            hidden_sizes=(a.hidden, a.hidden), training_num=a.envs)
+    if a.metrics_via == "lib" and world > 1:
+        agent.policy.engine.comm_init_from_torch()
     kw = dict(epoch=a.epoch, episode_per_collect=a.envs, step_per_epoch=a.step_per_epoch, device_actor=True,
               verbose=False, save_ckpt=False, show_progress=False)
     if a.algo in ("sacl", "ddpgl", "cvpo"):

@@ -123,6 +123,11 @@ SIGNATURES = {
     "fsrl_cvpo_update": (C.c_int, [_ctx, C.c_int32, _i64, _f, _f, C.c_uint64, _f]),
     "fsrl_cvpo_duals_get": (C.c_int, [_ctx, _f]),
     "fsrl_cvpo_last_particles": (C.c_int, [_ctx, _f, C.c_int64]),
+    "fsrl_comm_unique_id": (C.c_int, [_u8, C.c_int32]),
+    "fsrl_comm_init": (C.c_int, [_ctx, C.c_int32, C.c_int32, _u8, C.c_int32]),
+    "fsrl_metrics_allreduce": (C.c_int, [_ctx, _d, C.c_int32]),
+    "fsrl_comm_info": (C.c_int, [_ctx, _i32, _i32]),
+    "fsrl_comm_destroy": (C.c_int, [_ctx]),
     "fsrl_set_profiling": (C.c_int, [_ctx, C.c_int]),
     "fsrl_last_timing": (C.c_int, [_ctx, _d, C.c_int32]),
 }

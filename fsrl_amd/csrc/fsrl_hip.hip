@@ -68,6 +68,7 @@ struct fsrl_group;
 struct fsrl_ctx {
     fsrl_config cfg{};
     fsrl_group* group = nullptr;   // set while the context is a member of a grouped-update set (host_group.inc)
+    struct CommState* comm = nullptr;   // RCCL communicator of the metric exchange (host_comm.inc), owned
     int device = 0;
     hipStream_t compute = nullptr, side = nullptr;
     ModelDesc md{};
@@ -162,6 +163,7 @@ static void foc_free(fsrl_ctx* c);
 static void tr_reset_optim(fsrl_ctx* c);
 static void foc_reset_optim(fsrl_ctx* c);
 static void group_detach(fsrl_ctx* c);
+static void comm_free(fsrl_ctx* c);
 static int focops_pass(fsrl_ctx* c, int32_t* stopped_out);
 static int pass_verdict(fsrl_ctx* c, int32_t* stopped_out);
 
@@ -288,6 +290,7 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     if (c->group) group_detach(c);          // a member destroyed before its group: take its own stream back
+    comm_free(c);
     tr_free(c);
     sac_free(c);
     foc_free(c);
@@ -975,6 +978,8 @@ extern "C" int fsrl_last_timing(fsrl_ctx* c, double* out, int32_t n) {
 #include "host_sac.inc"
 
 #include "host_cvpo.inc"
+
+#include "host_comm.inc"
 
 #ifdef FSRL_PROBES
 // probe builds only (not in include/fsrl_hip.h): the phase stamps of the last ppo_fwd_bwd_kernel launch

@@ -488,6 +488,40 @@ class Engine:
         _lib.check(self.lib.fsrl_cvpo_last_particles(self._ctx, _ptr(out, _f32p), out.size))
         return out
 
+    # ---------------------------------------------------------------- metric exchange (RCCL through the C ABI)
+    def comm_unique_id(self) -> bytes:
+        buf = np.zeros(128, np.uint8)
+        _lib.check(self.lib.fsrl_comm_unique_id(_ptr(buf, _u8p), 128))
+        return buf.tobytes()
+
+    def comm_init(self, rank: int, world: int, uid: bytes):
+        buf = np.frombuffer(uid, np.uint8).copy()
+        _lib.check(self.lib.fsrl_comm_init(self._ctx, int(rank), int(world), _ptr(buf, _u8p), buf.size))
+
+    def comm_init_from_torch(self):
+        """Join the library's own RCCL communicator using the process group torch.distributed already has (any backend,
+        gloo included) only to hand rank 0's 128-byte id around; afterwards fsrl_metrics_allreduce needs torch no more."""
+        import torch.distributed as dist
+        assert dist.is_initialized(), "init a torch.distributed process group first (it only carries the id)"
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [self.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        self.comm_init(rank, world, box[0])
+
+    def comm_info(self):
+        r, w = C.c_int32(), C.c_int32()
+        _lib.check(self.lib.fsrl_comm_info(self._ctx, C.byref(r), C.byref(w)))
+        return int(r.value), int(w.value)
+
+    def metrics_allreduce(self, vec):
+        """Element-wise sum of a float64 vector (<= 64 entries) over the ranks; the identity without a communicator."""
+        v = np.ascontiguousarray(vec, np.float64).copy()
+        _lib.check(self.lib.fsrl_metrics_allreduce(self._ctx, _ptr(v, _f64p), v.size))
+        return v
+
+    def comm_destroy(self):
+        _lib.check(self.lib.fsrl_comm_destroy(self._ctx))
+
     def set_profiling(self, on: bool):
         _lib.check(self.lib.fsrl_set_profiling(self._ctx, int(on)))
 

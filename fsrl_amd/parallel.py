@@ -106,7 +106,7 @@ def allgather_metrics(metrics: Dict[str, float], device=None):
     return [{k: float(v) for k, v in zip(keys, o.tolist())} for o in out]
 
 
-def reduce_epoch(local: Dict[str, float]) -> Dict[str, float]:
+def reduce_epoch(local: Dict[str, float], engine=None) -> Dict[str, float]:
     """ONE all-reduce(sum) of the fixed EPOCH_KEYS vector (missing keys count as 0) and the job-level figures derived
     from it on every rank:
 
@@ -117,10 +117,14 @@ def reduce_epoch(local: Dict[str, float]) -> Dict[str, float]:
         job/env_steps_per_s, job/updates_per_s               whole-job throughput: totals / max-free mean duration
         job/all_stop                                         1.0 when every rank's stop rule fired
 
-    Identity layout without a process group (ranks = 1), so single-GPU runs log the same keys."""
+    Identity layout without a process group (ranks = 1), so single-GPU runs log the same keys.  `engine`: when its context
+    has joined the library's RCCL communicator (Engine.comm_init / comm_init_from_torch), the sum goes through the C ABI
+    (`fsrl_metrics_allreduce`: ncclAllReduce on the engine's compute stream) instead of torch.distributed."""
     vec = np.array([float(local.get(k, 0.0)) for k in EPOCH_KEYS], np.float64)
     vec[0] = 1.0
-    if is_distributed():
+    if engine is not None and engine.comm_info()[1] > 1:
+        vec = engine.metrics_allreduce(vec)          # the library's own RCCL communicator (fsrl_metrics_allreduce)
+    elif is_distributed():
         import torch
         import torch.distributed as dist
         t = torch.from_numpy(vec).to(_reduce_device())

@@ -150,7 +150,11 @@ class BaseTrainer(ABC):
         self._acc["sum_loss_total"] = self.logger.get_mean("loss/total") * gsteps
         self._acc["sum_kl"] = self.logger.get_mean("loss/kl") * gsteps
         self._acc["stop"] = 1.0 if stop_here else 0.0
-        self.job_stats = parallel.reduce_epoch(self._acc)
+        eng = getattr(self.policy, "engine", None)
+        lib_world = eng.comm_info()[1] if eng is not None and hasattr(eng, "comm_info") else 1
+        self.job_stats = parallel.reduce_epoch(self._acc, eng if lib_world > 1 else None)
+        if lib_world > 1 and self.world == 1:          # ranks joined through the library only (no torch process group)
+            self.rank, self.world = eng.comm_info()
         if self.world > 1:
             # independent agents, one collective per epoch: every rank must enter it the same number of times, so the
             # job stops when EVERY rank's stop rule has fired (a rank that is done early keeps training until then)

@@ -372,8 +372,19 @@ int fsrl_cvpo_last_particles(fsrl_ctx* ctx, float* eps_particles, int64_t n);
 int fsrl_set_profiling(fsrl_ctx* ctx, int enable);
 int fsrl_last_timing(fsrl_ctx* ctx, double* out, int32_t n);
 
-/* ---- metrics exchange across the node's GPUs is done by the Python host with
- *      torch.distributed (RCCL); the library has no collective of its own.              */
+/* ---- the one collective of the multi-GPU layout: independent agents, one process per GPU; once per epoch the
+ *      ranks sum a short float64 metric vector [n_st, n_ep, sum rew, sum cost, ...] (fsrl_amd/parallel.py EPOCH_KEYS).  The
+ *      reference has no multi-GPU code.  RCCL (ncclAllReduce, sum, float64, on the context's compute stream) is reached through
+ *      dlopen -- the copy of librccl the process already uses (torch's, when torch.distributed runs "nccl"), else /opt/rocm's --
+ *      so the library links against nothing and loads on boxes without RCCL.  The Python host may equally use torch.distributed
+ *      (fsrl_amd.parallel.reduce_epoch does when no communicator was initialised here).
+ *      fsrl_comm_unique_id: rank 0, 128 bytes (ncclUniqueId), handed to every rank by the caller (file / TCP / launcher store);
+ *      fsrl_comm_init: every rank, collective; fsrl_metrics_allreduce: in place, 1 <= n <= 64, the identity without a communicator. */
+int fsrl_comm_unique_id(uint8_t* id_out, int32_t cap);
+int fsrl_comm_init(fsrl_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id, int32_t id_bytes);
+int fsrl_metrics_allreduce(fsrl_ctx* ctx, double* v, int32_t n);
+int fsrl_comm_info(const fsrl_ctx* ctx, int32_t* rank_out, int32_t* world_out);
+int fsrl_comm_destroy(fsrl_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -434,3 +434,27 @@ def test_lr_scheduler_rate_reaches_the_engine(tmp_path):
     e.set_lr(1, 5e-4)
     assert abs(e.get_lr(1) - 5e-4) < 1e-10
     e.close()
+
+
+def test_metrics_allreduce_through_the_c_abi():
+    """fsrl_metrics_allreduce: the identity without a communicator; with the library's RCCL communicator of world size 1
+    (ncclGetUniqueId -> ncclCommInitRank, reached through dlopen) the sum of one rank's vector is that vector.  World sizes
+    above 1 need one GPU per rank (RCCL refuses two ranks on one device): the driver's multi-GPU node."""
+    from fsrl_amd import parallel
+    from fsrl_amd.engine import Engine, EngineConfig
+    eng = Engine(EngineConfig(hidden=64, env_num=2))
+    v = np.arange(17, dtype=np.float64) * 1.5
+    assert np.array_equal(eng.metrics_allreduce(v), v) and eng.comm_info() == (0, 1)
+    uid = eng.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    eng.comm_init(0, 1, uid)
+    assert eng.comm_info() == (0, 1)
+    assert np.array_equal(eng.metrics_allreduce(v), v)
+    with pytest.raises(AssertionError):
+        eng.metrics_allreduce(np.zeros(65))                         # at most 64 metrics
+    with pytest.raises(AssertionError):
+        eng.comm_init(2, 2, uid)                                    # rank outside the world
+    job = parallel.reduce_epoch({"n_st": 100.0, "n_ep": 4.0, "sum_rew": 40.0, "sum_cost": 8.0, "duration": 2.0}, eng)
+    assert job["job/ranks"] == 1.0 and job["job/reward"] == 10.0 and job["job/env_steps_per_s"] == 50.0
+    eng.comm_destroy()
+    eng.close()
