@@ -18,7 +18,8 @@ class Config(C.Structure):
                 ("gae_lambda", C.c_double), ("eps_clip", C.c_float), ("dual_clip", C.c_float),
                 ("vf_coef", C.c_float), ("max_grad_norm", C.c_float), ("target_kl", C.c_float),
                 ("norm_adv", C.c_int32), ("use_lagrangian", C.c_int32), ("lr", C.c_float),
-                ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float), ("recompute_adv", C.c_int32)]
+                ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float), ("recompute_adv", C.c_int32),
+                ("unbounded", C.c_int32), ("rew_norm", C.c_int32), ("value_clip", C.c_int32)]
 
 
 class TrConfig(C.Structure):
@@ -70,6 +71,8 @@ SIGNATURES = {
     "fsrl_params_get": (C.c_int, [_ctx, _f, C.c_int64]),
     "fsrl_grads_get": (C.c_int, [_ctx, _f, C.c_int64]),
     "fsrl_optim_reset": (C.c_int, [_ctx]),
+    "fsrl_ret_rms_get": (C.c_int, [_ctx, _d, C.c_int32]),
+    "fsrl_ret_rms_set": (C.c_int, [_ctx, _d, C.c_int32]),
     "fsrl_set_lr": (C.c_int, [_ctx, C.c_int32, C.c_float]),
     "fsrl_get_lr": (C.c_float, [_ctx, C.c_int32]),
     "fsrl_ppo_abort": (C.c_int, [_ctx]),

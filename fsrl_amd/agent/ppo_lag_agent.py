@@ -40,7 +40,6 @@ class PPOLagAgent(OnpolicyAgent):
         self.logger = logger if logger is not None else DummyLogger()
         self.cost_limit = cost_limit
         cost_dim = 1 if np.isscalar(cost_limit) else len(cost_limit)
-        assert not unbounded, "unbounded actor is not built in the HIP path (tanh-bounded mean)"
         assert len(hidden_sizes) == 2 and hidden_sizes[0] == hidden_sizes[1], \
             "the HIP path supports two equal hidden layers (64/128/256)"
         seed_all(seed)

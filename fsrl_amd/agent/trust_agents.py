@@ -30,10 +30,9 @@ class CPOAgent(OnpolicyAgent):
         self.cost_limit = cost_limit
         if not np.isscalar(cost_limit):
             raise RuntimeError("CPO does not support multiple costs.")
-        assert not unbounded
         seed_all(seed)
         torch.set_num_threads(thread)
-        actor, critic, _ = onpolicy_nets(env, hidden_sizes, 2, last_layer_scale)
+        actor, critic, _ = onpolicy_nets(env, hidden_sizes, 2, last_layer_scale, unbounded)
         optim = adam(critic, lr)
         self.policy = CPO(actor, critic, optim, independent_normal, logger=self.logger, target_kl=target_kl,
                           backtrack_coeff=backtrack_coeff, damping_coeff=damping_coeff,
@@ -64,10 +63,10 @@ class TRPOLagAgent(OnpolicyAgent):
         super().__init__()
         self.logger = logger if logger is not None else DummyLogger()
         self.cost_limit = cost_limit
-        assert np.isscalar(cost_limit) and not unbounded
+        assert np.isscalar(cost_limit)
         seed_all(seed)
         torch.set_num_threads(thread)
-        actor, critic, ac = onpolicy_nets(env, hidden_sizes, 2, last_layer_scale)
+        actor, critic, ac = onpolicy_nets(env, hidden_sizes, 2, last_layer_scale, unbounded)
         optim = adam(ac, lr)
         self.policy = TRPOLagrangian(actor, critic, optim, independent_normal, logger=self.logger, target_kl=target_kl,
                                      backtrack_coeff=backtrack_coeff, max_backtracks=max_backtracks,
@@ -100,10 +99,10 @@ class FOCOPSAgent(OnpolicyAgent):
         from fsrl_amd.policy.focops import FOCOPS
         self.logger = logger if logger is not None else DummyLogger()
         self.cost_limit = cost_limit
-        assert np.isscalar(cost_limit) and auto_nu and not unbounded
+        assert np.isscalar(cost_limit) and auto_nu
         seed_all(seed)
         torch.set_num_threads(thread)
-        actor, critic, _ = onpolicy_nets(env, hidden_sizes, 2, last_layer_scale)
+        actor, critic, _ = onpolicy_nets(env, hidden_sizes, 2, last_layer_scale, unbounded)
         actor_optim, critic_optim = adam(actor, actor_lr), adam(critic, critic_lr)
         self.policy = FOCOPS(actor, critic, actor_optim, critic_optim, independent_normal, logger=self.logger, cost_limit=cost_limit,
                              nu=(nu_max, nu_lr, torch.zeros(1)), l2_reg=l2_reg, delta=delta, eta=eta, tem_lambda=tem_lambda,

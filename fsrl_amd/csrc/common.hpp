@@ -11,11 +11,12 @@
 #define FSRL_MAX_OBS 128
 #define FSRL_MAX_ACT 16
 #define FSRL_W1_LDS 16      // W1 is staged to LDS when obs_dim <= 16
-// per-row loss inputs: act[16] | logp_old | adv_n[4] | ret[4] | pad | mean_old[16] | std_old[16]
+// per-row loss inputs: act[16] | logp_old | adv_n[4] | ret[4] | v_old[4] | pad | mean_old[16] | std_old[16]
 #define FSRL_RD 64
 #define FSRL_RD_LOGP 16
 #define FSRL_RD_ADV 17
 #define FSRL_RD_RET 21
+#define FSRL_RD_VOLD 25     // value_clip: the critics' process_fn-time outputs (batch.values)
 #define FSRL_RD_MEAN 32
 #define FSRL_RD_STD 48
 
@@ -33,6 +34,7 @@ struct NetOff {
 
 struct ModelDesc {
     int Do, Da, H, n_nets;  // n_nets = 1 + n_critics ; net 0 = actor
+    int unbounded;          // on-policy actor head: 0 -> mu = max_action * tanh(head); 1 -> mu = head (ActorProb unbounded=True)
     NetOff net[FSRL_MAX_NETS];
 };
 
@@ -75,6 +77,7 @@ struct PpoStepArgs {
     double kl_thresh;  // 1.5 * target_kl in float64 (python float in the reference)
     float step_size;   // lr / (1 - beta1^t)          (host float64 -> f32, like torch)
     float bc2_sqrt;    // sqrt(1 - beta2^t)
+    int value_clip;    // ppo_lag.py:158-164 (only with reward_normalization, as the reference asserts)
     int fuse_adam;     // max_grad_norm off (the agent default): the weight-gradient kernel applies Adam itself, 2 launches per step
     int dbg_phase;     // probe builds only (-DFSRL_PROBES, env FSRL_DBG_PHASE): early-exit timing experiments, results invalid
 };

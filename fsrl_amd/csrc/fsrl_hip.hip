@@ -84,6 +84,8 @@ struct fsrl_ctx {
 
     // store
     int64_t sub_size = 0, maxsize = 0;
+    double* d_rms = nullptr;           // reward_normalization: [n_critics][3] running (mean, var, count) of the returns
+    double* ret64 = nullptr; int64_t ret64_cap = 0;   // float64 normalised returns of the current batch (rms update input)
     int64_t alloc_rows = 0;            // rows every store / batch array was allocated for (fsrl_store_configure stays inside)
     int active_envs = 0;               // sub-buffers in use (<= cfg.env_num)
     std::vector<EnvBook> env;
@@ -250,6 +252,7 @@ static void build_layout(fsrl_ctx* c) {
     const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim, H = c->cfg.hidden;
     ModelDesc& md = c->md;
     md.Do = Do; md.Da = Da; md.H = H; md.n_nets = 1 + c->cfg.n_critics;
+    md.unbounded = (c->cfg.unbounded && c->cfg.algo != FSRL_ALGO_SAC_LAG) ? 1 : 0;     // replay actors have their own (raw mu | log sigma) head
     int api = 0, dev = 0;
     auto add = [&](int n) {
         TensorMap t{api, dev, n};
@@ -296,6 +299,8 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
     foc_free(c);
     if (c->h_actor) (void)hipHostFree(c->h_actor);
     if (c->h_done) (void)hipHostFree(c->h_done);
+    if (c->d_rms) (void)hipFree(c->d_rms);
+    if (c->ret64) (void)hipFree(c->ret64);
     if (c->mu_old) (void)hipFree(c->mu_old);
     if (c->sigma_old) (void)hipFree(c->sigma_old);
     void* dptrs[] = {c->P, c->M, c->V, c->G, c->ctrl, c->st.obs, c->st.obs_next, c->st.act, c->st.rew,
@@ -339,6 +344,9 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     CHECK_ARG(cfg->dual_clip == 0.0f || cfg->dual_clip > 1.0f,
               "Dual-clip PPO parameter should greater than 1.0.");
     CHECK_ARG(cfg->buffer_size + cfg->env_num < (int64_t)INT_MAX / 2, "buffer too large for 32-bit slot ids");
+    CHECK_ARG(cfg->rew_norm || !cfg->value_clip, "value clip is available only when `reward_normalization` is True");
+    CHECK_ARG(!cfg->value_clip || cfg->algo == FSRL_ALGO_PPO_LAG, "value_clip is a PPO-Lagrangian option (ppo_lag.py:158-164)");
+    CHECK_ARG(!cfg->rew_norm || cfg->algo != FSRL_ALGO_SAC_LAG, "reward_normalization acts on GAE returns: on-policy contexts only");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     CHECK_ARG(device_id >= 0 && device_id < ndev, "device %d not present (%d devices)", device_id, ndev);
@@ -369,6 +377,12 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     TRY(hipMalloc(&c->M, pb)); TRY(hipMalloc(&c->V, pb)); TRY(hipMalloc(&c->G, pb));
     TRY(hipMemsetAsync(c->M, 0, pb, c->compute)); TRY(hipMemsetAsync(c->V, 0, pb, c->compute)); TRY(hipMemsetAsync(c->G, 0, pb, c->compute));
     TRY(hipMalloc(&c->ctrl, sizeof(CtrlBlock)));
+    if (cfg->rew_norm) {      // RunningMeanStd(): mean 0, var 1, count 0 per critic
+        TRY(hipMalloc(&c->d_rms, 3 * FSRL_MAX_CRITICS * sizeof(double)));
+        double init[3 * FSRL_MAX_CRITICS];
+        for (int i = 0; i < FSRL_MAX_CRITICS; ++i) { init[3 * i] = 0.0; init[3 * i + 1] = 1.0; init[3 * i + 2] = 0.0; }
+        TRY(hipMemcpy(c->d_rms, init, sizeof(init), hipMemcpyHostToDevice));
+    }
     TRY(hipHostMalloc(&c->h_ctrl, sizeof(CtrlBlock)));
     // store: n sub-buffers of ceil(total/n) rows (tianshou VectorReplayBuffer)
     c->sub_size = (cfg->buffer_size + cfg->env_num - 1) / cfg->env_num;
@@ -989,6 +1003,30 @@ extern "C" int fsrl_probe_tstamps(fsrl_ctx* c, unsigned long long* out, int64_t 
     return hipMemcpy(out, c->probe_ts, (size_t)std::min<int64_t>(n, 1024 * 16) * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : FSRL_EHIP;
 }
 #endif
+
+// ------------------------------------------------------------------------------ return statistics
+// BasePolicy.ret_rms (base_policy.py:111): one RunningMeanStd per critic, rows of (mean, var, count).  The reference keeps
+// them as plain attributes (not in state_dict); a host that wants them across a restart reads / writes them here.
+extern "C" int fsrl_ret_rms_get(fsrl_ctx* c, double* out, int32_t n) {
+    CHECK_ARG(c && out, "null argument");
+    CHECK_ARG(n == 3 * c->cfg.n_critics, "expected 3 * n_critics = %d doubles", 3 * c->cfg.n_critics);
+    if (!c->d_rms) return fail(FSRL_ESTATE, "reward_normalization is off in this context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    HIPCHK(hipMemcpy(out, c->d_rms, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int fsrl_ret_rms_set(fsrl_ctx* c, const double* in, int32_t n) {
+    CHECK_ARG(c && in, "null argument");
+    CHECK_ARG(n == 3 * c->cfg.n_critics, "expected 3 * n_critics = %d doubles", 3 * c->cfg.n_critics);
+    if (!c->d_rms) return fail(FSRL_ESTATE, "reward_normalization is off in this context");
+    for (int i = 0; i < c->cfg.n_critics; ++i)
+        CHECK_ARG(std::isfinite(in[3 * i]) && in[3 * i + 1] >= 0.0 && in[3 * i + 2] >= 0.0, "row %d: var and count must be >= 0", i);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    HIPCHK(hipMemcpy(c->d_rms, in, (size_t)n * 8, hipMemcpyHostToDevice));
+    return 0;
+}
 
 // ------------------------------------------------------------------------------ learning rates
 // lr_scheduler.step() of BasePolicy.update (fsrl/policy/base_policy.py:352-354): the caller's scheduler owns the

@@ -175,16 +175,23 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
         for (int k = 0; k < FB_NSTAT; ++k) st[k] = 0.0f;
         if (net == 0 && !qmode) {
             float th = 0.f, var = 1.f, df = 0.f, lp = 0.f, klp = 0.f, dmu = 0.f, so2 = 0.f;
+            float hs = a.max_action;       // d mu / d head = hs * (1 - th * th); an unbounded head: th = 0, hs = 1
             if (d < Da) {
-                th = tanhf(sm.out[i * FSRL_MAX_ACT + d]);
+                const float x = sm.out[i * FSRL_MAX_ACT + d];
+                th = tanhf(x);
                 const float sig = expf(sm.sig[d]);
                 var = sig * sig;
                 const float mu = a.max_action * th;
                 df = rd[d] - mu;
+                dmu = mu - rd[FSRL_RD_MEAN + d];
+                if (md.unbounded) {            // ActorProb(unbounded=True): the mean is the head itself (the bounded path's
+                    df = rd[d] - x;            // expressions above stay as they were, so its rounding does not move)
+                    dmu = x - rd[FSRL_RD_MEAN + d];
+                    th = 0.0f; hs = 1.0f;
+                }
                 lp = -(df * df) / (2.0f * var) - logf(sig) - LOG_SQRT_2PI;
                 // KL(old || new), torch.distributions.kl._kl_normal_normal
                 const float so = rd[FSRL_RD_STD + d];
-                dmu = mu - rd[FSRL_RD_MEAN + d];
                 so2 = so * so;
                 const float var_ratio = (so / sig) * (so / sig);
                 const float t1 = (dmu / sig) * (dmu / sig);
@@ -208,16 +215,16 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
             if (valid && d < Da) {
                 if (a.mode == FB_MODE_SUR) {
                     const float dL_dlogp = (a.cr * ar + a.cc * ac) * ratio * invN;
-                    sm.dout[i * FSRL_DOW + d] = dL_dlogp * (df / var) * a.max_action * (1.0f - th * th);
+                    sm.dout[i * FSRL_DOW + d] = dL_dlogp * (df / var) * hs * (1.0f - th * th);
                     sm.dout[i * FSRL_DOW + 16 + d] = dL_dlogp * (df * df / var - 1.0f);
                 } else if (a.mode == FB_MODE_KL) {
-                    sm.dout[i * FSRL_DOW + d] = (dmu / var) * invN * a.max_action * (1.0f - th * th);
+                    sm.dout[i * FSRL_DOW + d] = (dmu / var) * invN * hs * (1.0f - th * th);
                     sm.dout[i * FSRL_DOW + 16 + d] = (1.0f - (so2 + dmu * dmu) / var) * invN;
                 } else if (a.mode == FB_MODE_FOCOPS) {
                     // loss_row = (KL - cr * ratio * (A_r - cc * A_c)) * mask ; cr = 1/lambda, cc = nu
                     const float mask = (klrow <= a.eta) ? invN : 0.0f;
                     const float dL_dlogp = -a.cr * (ar - a.cc * ac) * ratio;
-                    sm.dout[i * FSRL_DOW + d] = (dL_dlogp * (df / var) + dmu) * a.max_action * (1.0f - th * th) * mask;
+                    sm.dout[i * FSRL_DOW + d] = (dL_dlogp * (df / var) + dmu) * hs * (1.0f - th * th) * mask;
                     sm.dout[i * FSRL_DOW + 16 + d] = (dL_dlogp * (df * df / var - 1.0f) + (so2 - 1.0f)) * mask;
                 }
             }
@@ -464,18 +471,21 @@ __global__ __launch_bounds__(4 * H) void fb_hvp_tile_kernel(const float* __restr
     if (tid < 256) {
         const int i = tid >> 4, d = tid & 15;
         if (i < n_valid && d < Da) {
-            const float t = tanhf(sm.out[i * FSRL_MAX_ACT + d]);
+            const float x = sm.out[i * FSRL_MAX_ACT + d];
+            const float t = md.unbounded ? 0.0f : tanhf(x);           // unbounded head: mu = x, dmu/dout = 1, second derivative 0
+            const float hs = md.unbounded ? 1.0f : a.max_action;
             const float ro = sm.rout[i * FSRL_MAX_ACT + d];
             const float sp = P[no.sigma + d], rls = V[no.sigma + d];   // R{log sigma} = v_sigma
             const float sig = expf(sp), var = sig * sig;
-            const float dt = a.max_action * (1.0f - t * t);            // dmu/dout
+            const float dt = hs * (1.0f - t * t);                       // dmu/dout
             const float rmu = dt * ro;
-            const float dmu = a.max_action * t - sm.rd[i * FSRL_RD + FSRL_RD_MEAN + d];
+            const float dmu_b = a.max_action * t - sm.rd[i * FSRL_RD + FSRL_RD_MEAN + d];
+            const float dmu = md.unbounded ? x - sm.rd[i * FSRL_RD + FSRL_RD_MEAN + d] : dmu_b;
             const float so = sm.rd[i * FSRL_RD + FSRL_RD_STD + d], so2 = so * so;
             const float gmu = dmu / var;                                // dKL/dmu
             const float rgmu = rmu / var - 2.0f * gmu * rls;
             const float rgls = -2.0f * dmu * rmu / var + 2.0f * (so2 + dmu * dmu) / var * rls;
-            const float rdt = a.max_action * (-2.0f * t) * (1.0f - t * t) * ro;   // R{dmu/dout}
+            const float rdt = hs * (-2.0f * t) * (1.0f - t * t) * ro;   // R{dmu/dout}
             sm.dout[i * FSRL_DOW + d] = invN * gmu * dt;
             sm.rdout[i * FSRL_DOW + d] = invN * (rgmu * dt + gmu * rdt);
             sm.dout[i * FSRL_DOW + 16 + d] = invN * (1.0f - (so2 + dmu * dmu) / var);

@@ -75,7 +75,13 @@ struct GaeArgs {
     double* adv64;         // optional [C][N]
     int N;
     double gamma, gl;      // gl = gamma*lambda
+    // reward_normalization (base_policy.py:430-444): rms = [C][3] running (mean, var, count) of the normalised returns.  Values
+    // are un-normalised by sqrt(var + 1e-8) before the scan, returns divided by it after; ret64 keeps the float64 returns the
+    // running statistics are then updated with (ret_rms_update_kernel).  Null = off.
+    const double* rms;
+    double* ret64;         // [C][N]
 };
+#define FSRL_RMS_EPS 1e-8   // BasePolicy._eps
 
 __device__ __forceinline__ double readlane_f64(double x, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
@@ -90,6 +96,9 @@ __global__ __launch_bounds__(64) void gae_kernel(const GaeArgs a) {
     const float* __restrict__ v = a.values + (size_t)c * a.N;
     const float* __restrict__ vn = a.vnext + (size_t)c * a.N;
     const double* __restrict__ met = (c == 0) ? a.rew : a.cost;
+    // numpy: float32 array * float64 scalar (np.sqrt(var + eps)) -> float64 products (NumPy 2 promotion; NumPy 1's value-based
+    // casting would round them to float32 -- a 6e-8 relative difference, inside every tolerance downstream)
+    const double scale = a.rms ? sqrt(a.rms[3 * c + 1] + FSRL_RMS_EPS) : 1.0;
     double g = 0.0;
     for (int base = e - 64; base > s - 64; base -= 64) {
         const int idx = base + lane;
@@ -97,7 +106,9 @@ __global__ __launch_bounds__(64) void gae_kernel(const GaeArgs a) {
         double delta = 0.0, disc = 0.0, vv = 0.0;
         if (ok) {
             vv = (double)v[idx];
-            const double t0 = (double)vn[idx] * a.gamma;
+            double vnx = (double)vn[idx];
+            if (a.rms) { vv = vv * scale; vnx = vnx * scale; }
+            const double t0 = vnx * a.gamma;
             const double t1 = met[idx] + t0;
             delta = t1 - vv;
             disc = (1.0 - ((a.flags[idx] & 4) ? 1.0 : 0.0)) * a.gl;
@@ -114,10 +125,47 @@ __global__ __launch_bounds__(64) void gae_kernel(const GaeArgs a) {
         if (ok) {
             const size_t o = (size_t)c * a.N + idx;
             a.advs[o] = (float)res;
-            const double ret = res + vv;
+            double ret = res + vv;
+            if (a.rms) { ret = ret / scale; a.ret64[o] = ret; }
             a.rets[o] = (float)ret;
             if (a.adv64) a.adv64[o] = res;
         }
+    }
+}
+
+// RunningMeanStd.update(ret) of tianshou 0.5 (utils/statistics.py:89-103) for every critic: batch mean and (biased) variance
+// in float64, two passes like np.var, then the parallel-variance merge.  One block per critic; runs after gae_kernel on the
+// same stream, so the scan above has already read the previous variance.
+__global__ __launch_bounds__(1024) void ret_rms_update_kernel(const double* __restrict__ ret64, double* __restrict__ rms,
+                                                              const int N) {
+    __shared__ double sh[16];
+    __shared__ double bc;
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const double* __restrict__ x = ret64 + (size_t)c * N;
+    auto block_sum = [&](double v) {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((tid & 63) == 0) sh[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) { double t = 0.0; for (int w = 0; w < 16; ++w) t += sh[w]; bc = t; }
+        __syncthreads();
+        const double r = bc;
+        __syncthreads();
+        return r;
+    };
+    double s = 0.0;
+    for (int i = tid; i < N; i += 1024) s += x[i];
+    const double mean = block_sum(s) / (double)N;
+    double q = 0.0;
+    for (int i = tid; i < N; i += 1024) { const double d = x[i] - mean; q += d * d; }
+    const double var = block_sum(q) / (double)N;
+    if (tid == 0) {
+#pragma clang fp contract(off)
+        const double m0 = rms[3 * c], v0 = rms[3 * c + 1], n0 = rms[3 * c + 2];
+        const double nb = (double)N, delta = mean - m0, tot = n0 + nb;
+        const double new_mean = m0 + delta * nb / tot;
+        const double m_a = v0 * n0, m_b = var * nb;
+        const double m_2 = m_a + m_b + delta * delta * n0 * nb / tot;
+        rms[3 * c] = new_mean; rms[3 * c + 1] = m_2 / tot; rms[3 * c + 2] = tot;
     }
 }
 
@@ -132,6 +180,7 @@ struct PrepArgs {
     const int* perm; const int* mb_start; const int* mb_size;
     float* obs_p; float* rd_p;
     int N, C, Do, Da, norm_adv;
+    const float* values;     // optional [C][N]: value_clip's batch.values -> rd_p[FSRL_RD_VOLD + c]
     const float* mean_old;   // optional [N][Da] + sigma_old[Da] (log std at process time): FOCOPS needs the old distribution
     const float* sigma_old;
 };
@@ -187,6 +236,8 @@ __global__ __launch_bounds__(1024) void ppo_prepare_pass_kernel(const PrepArgs a
                 if (a.norm_adv) v = (v - mean_f[c]) / sd_f[c];
             } else if (f >= FSRL_RD_RET && f < FSRL_RD_RET + a.C) {
                 v = a.rets[(size_t)(f - FSRL_RD_RET) * a.N + r];
+            } else if (a.values && f >= FSRL_RD_VOLD && f < FSRL_RD_VOLD + a.C) {
+                v = a.values[(size_t)(f - FSRL_RD_VOLD) * a.N + r];
             } else if (a.mean_old && f >= FSRL_RD_MEAN && f < FSRL_RD_MEAN + a.Da) {
                 v = a.mean_old[(size_t)r * a.Da + f - FSRL_RD_MEAN];
             } else if (a.mean_old && f >= FSRL_RD_STD && f < FSRL_RD_STD + a.Da) {

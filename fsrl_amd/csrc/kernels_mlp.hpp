@@ -351,7 +351,8 @@ __global__ __launch_bounds__(4 * H) void mlp_infer_kernel(const float* __restric
             } else {
                 float logp = 0.0f;
                 for (int d = 0; d < md.Da; ++d) {
-                    const float mu = a.max_action * tanhf(sm.out[tid * FSRL_MAX_ACT + d]);
+                    const float x = sm.out[tid * FSRL_MAX_ACT + d];
+                    const float mu = md.unbounded ? x : a.max_action * tanhf(x);     // ActorProb(unbounded=True): mu = head
                     const float sig = expf(sm.sig[d]);
                     if (a.mu_out) a.mu_out[(size_t)r * md.Da + d] = mu;
                     if (a.act) {
@@ -494,11 +495,14 @@ __device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* _
         float st0 = 0.f, st1 = 0.f, st2 = 0.f;
         if (net == 0) {
             float th = 0.f, var = 1.f, df = 0.f, lp = 0.f;
+            float hs = sa.max_action;      // d mu / d head = hs * (1 - th * th); an unbounded head: th = 0, hs = 1
             if (d < Da) {
-                th = tanhf(sm.out[i * FSRL_MAX_ACT + d]);
+                const float x = sm.out[i * FSRL_MAX_ACT + d];
+                th = tanhf(x);
                 const float sig = expf(sm.sig[d]);
                 var = sig * sig;
                 df = rd[d] - sa.max_action * th;
+                if (md.unbounded) { df = rd[d] - x; th = 0.0f; hs = 1.0f; }     // ActorProb(unbounded=True): mu = head
                 lp = -(df * df) / (2.0f * var) - logf(sig) - LOG_SQRT_2PI;
             }
             // sum over the action dims in ascending order (Independent(Normal).log_prob)
@@ -537,7 +541,7 @@ __device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* _
             }
             const float dL_dlogp = sa.rescale * dL_dratio * ratio;
             if (valid && d < Da) {
-                sm.dout[i * FSRL_DOW + d] = dL_dlogp * (df / var) * sa.max_action * (1.0f - th * th);
+                sm.dout[i * FSRL_DOW + d] = dL_dlogp * (df / var) * hs * (1.0f - th * th);
                 sm.dout[i * FSRL_DOW + 16 + d] = dL_dlogp * (df * df / var - 1.0f);
             }
             if (valid) { st0 = term; st1 = safety_sum; st2 = lpo - logp; }
@@ -545,9 +549,22 @@ __device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* _
             const int c = net - 1;
             const float v = sm.out[i * FSRL_MAX_ACT];
             const float dd = rd[FSRL_RD_RET + c] - v;
+            float g = -2.0f * dd, vf = dd * dd;
+            if (sa.value_clip) {
+                // ppo_lag.py:158-164: v_clip = v_old + clamp(v - v_old, -eps, eps); vf = max((ret - v)^2, (ret - v_clip)^2).
+                // Gradients as autograd routes them: clamp passes 1 inside [-eps, eps] (bounds included), max splits a tie
+                const float vo = rd[FSRL_RD_VOLD + c];
+                const float dv = v - vo;
+                const float vc = vo + fminf(fmaxf(dv, -sa.eps_clip), sa.eps_clip);
+                const float d2 = rd[FSRL_RD_RET + c] - vc;
+                const float vf2 = d2 * d2;
+                const float g2 = (dv >= -sa.eps_clip && dv <= sa.eps_clip) ? -2.0f * d2 : 0.0f;
+                g = (vf > vf2) ? g : (vf == vf2 ? 0.5f * g + 0.5f * g2 : g2);
+                vf = fmaxf(vf, vf2);
+            }
             if (valid) {
-                if (d == 0) sm.dout[i * FSRL_DOW] = -2.0f * sa.vf_coef * dd * invB;
-                st0 = dd * dd;
+                if (d == 0) sm.dout[i * FSRL_DOW] = sa.vf_coef * g * invB;
+                st0 = vf;
             }
         }
         if (d == 0) { sm.st[i * 4 + 0] = st0; sm.st[i * 4 + 1] = st1; sm.st[i * 4 + 2] = st2; }

@@ -42,6 +42,9 @@ class EngineConfig:
     beta2: float = 0.999
     adam_eps: float = 1e-8
     recompute_adv: bool = False
+    unbounded: bool = False           # on-policy actor head without max_action * tanh
+    rew_norm: bool = False            # reward_normalization (base_policy.py:430-444)
+    value_clip: bool = False          # PPO clipped value loss (needs rew_norm)
     algo: int = _lib.ALGO_PPO_LAG
 
     def to_c(self):
@@ -56,6 +59,7 @@ class EngineConfig:
         c.norm_adv, c.use_lagrangian = int(self.norm_adv), int(self.use_lagrangian)
         c.lr, c.beta1, c.beta2, c.adam_eps = self.lr, self.beta1, self.beta2, self.adam_eps
         c.recompute_adv = int(self.recompute_adv)
+        c.unbounded, c.rew_norm, c.value_clip = int(self.unbounded), int(self.rew_norm), int(self.value_clip)
         return c
 
 
@@ -102,6 +106,16 @@ class Engine:
 
     def optim_reset(self):
         _lib.check(self.lib.fsrl_optim_reset(self._ctx))
+
+    def ret_rms_get(self) -> np.ndarray:
+        """[n_critics, 3] running (mean, var, count) of the normalised returns (BasePolicy.ret_rms)."""
+        out = np.zeros(3 * self.cfg.n_critics, np.float64)
+        _lib.check(self.lib.fsrl_ret_rms_get(self._ctx, _ptr(out, _f64p), out.size))
+        return out.reshape(-1, 3)
+
+    def ret_rms_set(self, rms):
+        v = np.ascontiguousarray(rms, np.float64).reshape(-1)
+        _lib.check(self.lib.fsrl_ret_rms_set(self._ctx, _ptr(v, _f64p), v.size))
 
     def set_lr(self, group: int, lr: float):
         """Learning rate of one optimiser (fsrl_set_lr): what lr_scheduler.step() produced on the host."""

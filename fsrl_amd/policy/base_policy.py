@@ -34,7 +34,7 @@ class BasePolicy(ABC, nn.Module):
         self.dist_fn = dist_fn
         self.logger = logger if logger is not None else DummyLogger()
         assert 0.0 <= gamma <= 1.0, "discount factor should be in [0, 1]."
-        assert not reward_normalization, "reward_normalization is not built in the HIP path (off in every config)"
+        self._rew_norm = bool(reward_normalization)
         self._gamma = gamma
         self._deterministic_eval = deterministic_eval
         self._max_batchsize = max_batchsize
@@ -60,13 +60,22 @@ class BasePolicy(ABC, nn.Module):
         dev = device if isinstance(device, int) else (int(str(device).split(":")[-1]) if ":" in str(device) else 0)
         kw = dict(obs_dim=int(obs_dim), act_dim=int(act_dim), hidden=int(hidden), n_critics=self.critics_num,
                   env_num=int(env_num), buffer_size=int(buffer_size),
-                  max_action=float(getattr(self.actor, "_max", 1.0)), gamma=self._gamma)
+                  max_action=float(getattr(self.actor, "_max", 1.0)), gamma=self._gamma,
+                  unbounded=bool(getattr(self.actor, "_unbounded", False)), rew_norm=self._rew_norm)
         if optim is not None:
             g = optim.param_groups[0]
             kw.update(lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], adam_eps=g["eps"])
         kw.update(cfg_over)
         self.engine = Engine(EngineConfig(**kw), device=dev)
         self._push_params()
+
+    @property
+    def ret_rms(self) -> np.ndarray:
+        """BasePolicy.ret_rms of the reference (base_policy.py:111) as rows of (mean, var, count), one per critic; they live
+        in the engine (`fsrl_ret_rms_get`).  Without reward_normalization: the untouched initial state."""
+        if self._rew_norm and self.engine is not None:
+            return self.engine.ret_rms_get()
+        return np.array([[0.0, 1.0, 0.0]] * self.critics_num)
 
     # ------------------------------------------------------------------ parameter plumbing
     def _flat_params(self, fresh: bool = True) -> np.ndarray:

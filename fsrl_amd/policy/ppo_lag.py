@@ -50,7 +50,8 @@ class PPOLagrangian(LagrangianPolicy):
                          rescaling, gamma, max_batchsize, reward_normalization, deterministic_eval,
                          action_scaling, action_bound_method, observation_space, action_space, lr_scheduler)
         assert dual_clip is None or dual_clip > 1.0, "Dual-clip PPO parameter should greater than 1.0."
-        assert not value_clip, "value clip is available only when `reward_normalization` is True"
+        assert reward_normalization or not value_clip, "value clip is available only when `reward_normalization` is True"
+        self._value_clip = bool(value_clip)
         assert 0.0 <= gae_lambda <= 1.0, "GAE lambda should be in [0, 1]."
         self.optim = optim
         self._lambda, self._weight_vf, self._grad_norm = gae_lambda, vf_coef, max_grad_norm
@@ -64,7 +65,8 @@ class PPOLagrangian(LagrangianPolicy):
         self._make_engine(device, env_num, buffer_size, optim, gae_lambda=gae_lambda, eps_clip=eps_clip,
                           dual_clip=dual_clip, vf_coef=vf_coef, max_grad_norm=max_grad_norm,
                           target_kl=target_kl, norm_adv=advantage_normalization,
-                          use_lagrangian=use_lagrangian, recompute_adv=bool(recompute_advantage))
+                          use_lagrangian=use_lagrangian, recompute_adv=bool(recompute_advantage),
+                          value_clip=bool(value_clip))
 
     def learn(self, batch, **kwargs: Any):
         raise NotImplementedError("the HIP path runs process_fn + learn inside update()")

@@ -73,6 +73,11 @@ typedef struct fsrl_config {
     float beta1, beta2, adam_eps;
     int32_t recompute_adv;   /* PPO: recompute V, GAE, returns with the CURRENT critics before every pass after the
                                 first (ppo_lag.py:218-221 recompute_advantage); logp_old stays                       */
+    int32_t unbounded;       /* on-policy actor: 1 = mean head without max_action * tanh (ActorProb(unbounded=True),
+                                tianshou 0.5 utils/net/continuous.py; fsrl/agent/ppo_lag_agent.py:134)                */
+    int32_t rew_norm;        /* reward_normalization (base_policy.py:114, 430-444): critics learn returns divided by the
+                                running std of the returns; on-policy contexts                                        */
+    int32_t value_clip;      /* PPO: clipped value loss (ppo_lag.py:158-164); needs rew_norm like the reference      */
 } fsrl_config;
 
 const char* fsrl_last_error(void);
@@ -95,6 +100,11 @@ int fsrl_optim_reset(fsrl_ctx* ctx);                /* zero Adam moments and ste
  * scheduler owns the schedule, this call moves the new rate of one optimiser into the engine; it applies from the next
  * optimiser step.  group: on-policy contexts 0 (the one Adam; for CPO / TRPO-Lag the critics' Adam); FOCOPS 0 actor,
  * 1 critics; replay contexts (SAC / DDPG / CVPO) 0 actor, 1 critics, 2 alpha.  fsrl_get_lr returns < 0 for a bad group. */
+/* BasePolicy.ret_rms (fsrl/policy/base_policy.py:111, 442-444): per critic the running (mean, var, count) of the normalised
+ * returns, rows of 3 doubles, n = 3 * n_critics.  Only in contexts created with rew_norm.  The reference keeps these outside
+ * state_dict; a host that wants them to survive a restart carries them itself. */
+int fsrl_ret_rms_get(fsrl_ctx* ctx, double* out, int32_t n);
+int fsrl_ret_rms_set(fsrl_ctx* ctx, const double* in, int32_t n);
 int fsrl_set_lr(fsrl_ctx* ctx, int32_t group, float lr);
 float fsrl_get_lr(const fsrl_ctx* ctx, int32_t group);
 

@@ -52,6 +52,9 @@ class PPOLagConfig:
     betas: Tuple[float, float] = (0.9, 0.999)
     adam_eps: float = 1e-8
     recompute_advantage: bool = False
+    unbounded: bool = False              # ActorProb(unbounded=True): no max_action * tanh on the mean head
+    reward_normalization: bool = False   # base_policy.py:114, 430-444
+    value_clip: bool = False             # ppo_lag.py:158-164 (the reference asserts reward_normalization with it)
 
 
 @dataclass
@@ -96,6 +99,18 @@ class PPOLagOracle:
         self._leaves: List[torch.Tensor] = []
         self.set_params(np.zeros(self.n_params, np.float32))
         self.gradient_steps = 0
+        # BasePolicy.ret_rms (base_policy.py:111): tianshou 0.5 RunningMeanStd() per critic -> rows (mean, var, count)
+        self.ret_rms = np.array([[0.0, 1.0, 0.0]] * cfg.n_critics, np.float64)
+
+    def _rms_update(self, i, x):
+        """tianshou 0.5 utils/statistics.py:89-103 RunningMeanStd.update"""
+        mean, var, count = self.ret_rms[i]
+        b_mean, b_var, b_count = np.mean(x), np.var(x), len(x)
+        delta = b_mean - mean
+        tot = count + b_count
+        new_mean = mean + delta * b_count / tot
+        m_2 = var * count + b_var * b_count + delta ** 2 * count * b_count / tot
+        self.ret_rms[i] = (new_mean, m_2 / tot, tot)
 
     # ------------------------------------------------------------------ params
     def set_params(self, flat):
@@ -122,7 +137,9 @@ class PPOLagOracle:
 
     def actor_dist(self, obs):
         p = self.nets[0]
-        mu = self.cfg.max_action * torch.tanh(self._trunk(p, obs))
+        mu = self._trunk(p, obs)
+        if not self.cfg.unbounded:
+            mu = self.cfg.max_action * torch.tanh(mu)
         sigma = (p["sigma_param"].view(1, -1) + torch.zeros_like(mu)).exp()
         return Independent(Normal(mu, sigma), 1)
 
@@ -143,6 +160,18 @@ class PPOLagOracle:
             for i in range(cfg.n_critics):
                 v = self.value(i, obs)
                 vn = self.value(i, obs_next).numpy() * value_mask  # f32 * bool -> f32
+                if cfg.reward_normalization:       # un-normalise v_s, v_s_ (float32 array * np.float64 -> float64)
+                    from .scans import gae_return_np
+                    scale = np.sqrt(self.ret_rms[i][1] + 1e-8)
+                    vs = v.numpy().astype(np.float64) * scale
+                    adv = gae_return_np(vs, vn.astype(np.float64) * scale, metrics[i], data.end_flag, cfg.gamma,
+                                        cfg.gae_lambda)
+                    ret = (adv + vs) / scale
+                    self._rms_update(i, ret)
+                    values.append(v)
+                    rets.append(torch.from_numpy(ret).to(dt))
+                    advs.append(torch.from_numpy(adv).to(dt))
+                    continue
                 if dt == torch.float32:
                     adv = gae_return_c(v.numpy(), vn, metrics[i], data.end_flag, cfg.gamma,
                                        cfg.gae_lambda)
@@ -166,6 +195,7 @@ class PPOLagOracle:
         obs, act = pb["obs"][idx_t], pb["act"][idx_t]
         advs = pb["advs"][idx_t].clone()  # fancy index = copy; normalised per minibatch copy
         rets, logp_old = pb["rets"][idx_t], pb["logp_old"][idx_t]
+        vold = pb["values"][idx_t]
         dist = self.actor_dist(obs)
         logp = dist.log_prob(act)
         ratio = (logp - logp_old).exp().to(self.dtype)
@@ -200,7 +230,11 @@ class PPOLagOracle:
         loss_vf = 0
         for i in range(cfg.n_critics):
             v = self.value(i, obs)
-            vf = (rets[..., i] - v).pow(2).mean()
+            if cfg.value_clip:
+                v_clip = vold[..., i] + (v - vold[..., i]).clamp(-cfg.eps_clip, cfg.eps_clip)
+                vf = torch.max((rets[..., i] - v).pow(2), (rets[..., i] - v_clip).pow(2)).mean()
+            else:
+                vf = (rets[..., i] - v).pow(2).mean()
             loss_vf = loss_vf + vf
             stats["loss/vf" + str(i)] = vf.item()
         stats["loss/vf_total"] = loss_vf.item()

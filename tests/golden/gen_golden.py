@@ -130,13 +130,13 @@ def gen_pid():
 
 # ----------------------------------------------------------------------------- G4
 def build_ppo(obs_dim, act_dim, hidden, seed, max_action=1.0, last_layer_scale=False,
-              logger=None, lr=5e-4, **ppo_kw):
+              logger=None, lr=5e-4, unbounded=False, **ppo_kw):
     """Mirror of fsrl/agent/ppo_lag_agent.py:127-200 using the shim's tianshou nets."""
     seed_all(seed)
     obs_space = _Box(-np.inf, np.inf, (obs_dim, ))
     act_space = _Box(-max_action, max_action, (act_dim, ))
     net = Net((obs_dim, ), hidden_sizes=hidden)
-    actor = ActorProb(net, (act_dim, ), max_action=max_action, unbounded=False)
+    actor = ActorProb(net, (act_dim, ), max_action=max_action, unbounded=unbounded)
     critic = [Critic(Net((obs_dim, ), hidden_sizes=hidden)) for _ in range(2)]
     torch.nn.init.constant_(actor.sigma_param, -0.5)
     actor_critic = ActorCritic(actor, critic)
@@ -203,7 +203,7 @@ def flat_params(module):
 
 
 def gen_ppo_case(name, obs_dim, act_dim, hidden, env_num, ep_lens, batch_size, repeat,
-                 seed, cost_stat=25.0, cost_limit=10.0, **ppo_kw):
+                 seed, cost_stat=25.0, cost_limit=10.0, ret_rms0=None, **ppo_kw):
     logger = CaptureLogger()
     policy, actor_critic, optim = build_ppo(obs_dim, act_dim, hidden, seed, logger=logger,
                                             cost_limit=cost_limit, **ppo_kw)
@@ -226,8 +226,15 @@ def gen_ppo_case(name, obs_dim, act_dim, hidden, env_num, ep_lens, batch_size, r
     out["unfinished_index"] = buf.unfinished_index()
     out["env_rows"] = np.array([len(b) for b in buf.buffers])
 
-    # process_fn outputs (deterministic, side-effect free with rew_norm off): record them
+    if ret_rms0 is not None:      # running return statistics as an earlier update would have left them (fixture input state)
+        for rms, (m, v, n) in zip(policy.ret_rms, ret_rms0):
+            rms.mean, rms.var, rms.count = float(m), float(v), float(n)
+    out["ret_rms0"] = np.array([[r.mean, r.var, r.count] for r in policy.ret_rms], np.float64)
+    # process_fn outputs: record them (with reward_normalization the call also updates ret_rms: put the state back)
+    import copy
+    rms_keep = copy.deepcopy(policy.ret_rms)
     pb = policy.process_fn(batch, buf, indices)
+    policy.ret_rms = rms_keep
     out["values"], out["rets"], out["advs"] = (pb.values.numpy().copy(), pb.rets.numpy().copy(),
                                                pb.advs.numpy().copy())
     out["logp_old"] = pb.logp_old.numpy().copy()
@@ -277,6 +284,7 @@ def gen_ppo_case(name, obs_dim, act_dim, hidden, env_num, ep_lens, batch_size, r
         stats.append([merged[k] for k in keys])
     out["stats"] = np.array(stats, np.float64)
     out["stats_keys"] = np.array(keys)
+    out["ret_rms_final"] = np.array([[r.mean, r.var, r.count] for r in policy.ret_rms], np.float64)
     out["gradient_steps"] = np.array(policy.gradient_steps)
     out["early_stop_msgs"] = np.array(len(logger.msgs))
     cfg = dict(obs_dim=obs_dim, act_dim=act_dim, hidden=list(hidden), env_num=env_num,
@@ -328,6 +336,28 @@ def gen_ppo_recompute():
                  max_grad_norm=0.5, target_kl=1e9, recompute_advantage=True)
 
 
+def gen_ppo_options():
+    # reward_normalization + value_clip (base_policy.py:430-444, ppo_lag.py:158-164) from a non-trivial running state
+    rms0 = [(2.9, 6.5, 1500.0), (0.35, 0.8, 1500.0)]
+    gen_ppo_case("rewnorm", obs_dim=6, act_dim=2, hidden=(64, 64), env_num=3,
+                 ep_lens=[[70, 60, -25], [80, 75], [50, 50, 50]], batch_size=64, repeat=3, seed=6,
+                 max_grad_norm=0.5, target_kl=1e9, reward_normalization=True, value_clip=True, ret_rms0=rms0,
+                 eps_clip=0.05, lr=2e-3)      # small clip range + larger steps: rows on both sides of the value clip
+    # the same from the initial state (mean 0, var 1, count 0), value clip off
+    gen_ppo_case("rewnorm_first", obs_dim=6, act_dim=2, hidden=(64, 64), env_num=3,
+                 ep_lens=[[70, 60, -25], [80, 75], [50, 50, 50]], batch_size=64, repeat=2, seed=6,
+                 max_grad_norm=0.5, target_kl=1e9, reward_normalization=True)
+    # recompute_advantage on top: ret_rms is updated once more before passes 2 and 3, value_clip uses the fresh values
+    gen_ppo_case("rewnorm_recompute", obs_dim=6, act_dim=2, hidden=(64, 64), env_num=3,
+                 ep_lens=[[70, 60, -25], [80, 75], [50, 50, 50]], batch_size=64, repeat=3, seed=8,
+                 max_grad_norm=0.5, target_kl=1e9, reward_normalization=True, value_clip=True, ret_rms0=rms0,
+                 recompute_advantage=True)
+    # unbounded actor (ActorProb unbounded=True: the mean is the head's raw output)
+    gen_ppo_case("unbounded", obs_dim=6, act_dim=2, hidden=(64, 64), env_num=3,
+                 ep_lens=[[70, 60, -25], [80, 75], [50, 50, 50]], batch_size=64, repeat=3, seed=9,
+                 max_grad_norm=0.5, target_kl=1e9, unbounded=True)
+
+
 def gen_manifest():
     policy, _, _ = build_ppo(8, 2, (128, 128), 0, logger=CaptureLogger(), cost_limit=10.0)
     sd = policy.state_dict()
@@ -341,5 +371,5 @@ if __name__ == "__main__":
     torch.set_num_threads(4)
     which = sys.argv[1:] or ["gae", "nstep", "pid", "ppo", "manifest"]
     for w in which:
-        {"gae": gen_gae, "nstep": gen_nstep, "pid": gen_pid, "ppo": gen_ppo, "recompute": gen_ppo_recompute,
+        {"gae": gen_gae, "nstep": gen_nstep, "pid": gen_pid, "ppo": gen_ppo, "recompute": gen_ppo_recompute, "options": gen_ppo_options,
          "manifest": gen_manifest}[w]()

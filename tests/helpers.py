@@ -34,7 +34,10 @@ def oracle_cfg_and_data(cfg, g):
                         max_grad_norm=cfg["max_grad_norm"], target_kl=cfg["target_kl"],
                         advantage_normalization=cfg["advantage_normalization"],
                         use_lagrangian=cfg["use_lagrangian"], lr=cfg["lr"],
-                        recompute_advantage=bool(cfg.get("recompute_advantage", False)))
+                        recompute_advantage=bool(cfg.get("recompute_advantage", False)),
+                        unbounded=bool(cfg.get("unbounded", False)),
+                        reward_normalization=bool(cfg.get("reward_normalization", False)),
+                        value_clip=bool(cfg.get("value_clip", False)))
     data = OnPolicyData(obs=g["buf_obs"], act=g["buf_act"], rew=g["buf_rew"], cost=g["buf_cost"],
                         terminated=g["buf_terminated"], truncated=g["buf_truncated"],
                         obs_next=g["buf_obs_next"], end_flag=end_flag_of(g))

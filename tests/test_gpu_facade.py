@@ -14,7 +14,8 @@ def _policy_from_case(cfg, g, logger=None):
     from fsrl_amd.policy import PPOLagrangian
     from fsrl_amd.utils.net import ActorCritic, ActorProb, Critic, Net
     h, Do, Da = tuple(cfg["hidden"]), cfg["obs_dim"], cfg["act_dim"]
-    actor = ActorProb(Net((Do, ), hidden_sizes=h), (Da, ), max_action=cfg["max_action"])
+    actor = ActorProb(Net((Do, ), hidden_sizes=h), (Da, ), max_action=cfg["max_action"],
+                      unbounded=bool(cfg.get("unbounded", False)))
     critics = [Critic(Net((Do, ), hidden_sizes=h)) for _ in range(2)]
     ac = ActorCritic(actor, critics)
     flat, off = torch.from_numpy(g["theta0"]), 0
@@ -27,6 +28,9 @@ def _policy_from_case(cfg, g, logger=None):
                          max_grad_norm=cfg["max_grad_norm"], gae_lambda=cfg["gae_lambda"],
                          eps_clip=cfg["eps_clip"], dual_clip=cfg["dual_clip"],
                          advantage_normalization=cfg["advantage_normalization"],
+                         recompute_advantage=bool(cfg.get("recompute_advantage", False)),
+                         value_clip=bool(cfg.get("value_clip", False)),
+                         reward_normalization=bool(cfg.get("reward_normalization", False)),
                          use_lagrangian=cfg["use_lagrangian"], cost_limit=cfg["cost_limit"],
                          gamma=cfg["gamma"], observation_space=Box(-np.inf, np.inf, (Do, )),
                          action_space=Box(-1, 1, (Da, )), device=0, env_num=cfg["env_num"])
@@ -43,7 +47,7 @@ class _Capture:
         self.msgs.append(msg)
 
 
-@pytest.mark.parametrize("name", ["tiny", "c1", "earlystop"])
+@pytest.mark.parametrize("name", ["tiny", "c1", "earlystop", "rewnorm_first", "rewnorm_recompute", "unbounded"])
 def test_policy_update_through_facade_matches_reference(name):
     """Same call sequence as OnpolicyTrainer.policy_update_fn, numpy RNG seeded like the golden
     generator: the facade draws the SAME permutations as the reference's Batch.split."""
@@ -63,6 +67,9 @@ def test_policy_update_through_facade_matches_reference(name):
                       truncated=g["buf_truncated"][sel], obs_next=g["buf_obs_next"][sel]), buffer_ids=ids)
     pol.pre_update_fn(stats_train={"cost": cfg["cost_stat"]})
     assert pol.lag_optims[0].get_lag() == g["lagrangian"][0]
+    assert np.array_equal(pol.ret_rms, [[0.0, 1.0, 0.0]] * 2)          # RunningMeanStd(): mean 0, var 1, count 0
+    if cfg.get("reward_normalization"):
+        pol.engine.ret_rms_set(g["ret_rms0"])
     seed = cfg["seed"] + 7
     random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
     out = pol.update(0, buf, batch_size=cfg["batch_size"], repeat=cfg["repeat"])
@@ -73,6 +80,7 @@ def test_policy_update_through_facade_matches_reference(name):
     got = np.array([[{**rows_[i], **rows_[i + 1]}[k] for k in keys] for i in range(0, len(rows_), 2)])
     np.testing.assert_allclose(got, g["stats"], rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(pol._flat_params(), g["theta_final"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(pol.ret_rms, g["ret_rms_final"], rtol=1e-5, atol=1e-7)
     # checkpoint round trip under the reference's key names
     sd = pol.state_dict()
     pol2 = _policy_from_case(cfg, g)
@@ -282,8 +290,8 @@ def test_agents_learn_the_synthetic_task_under_the_cost_constraint(tmp_path):
                                      save_ckpt=False, device_actor=True, **lk)
             hist.append((stat["train/reward"], stat["train/cost"]))
         assert c0 > 30, (name, c0)                                   # the untrained policy violates the limit of 20
-        if name == "cpo":                                            # trust-region projection: at the limit within epochs
-            assert hist[-1][1] <= 1.3 * 20, (name, hist)
+        if name == "cpo":       # trust-region projection: hovers at the limit within epochs (one epoch = 20 episodes, +-8 of noise)
+            assert np.mean([h[1] for h in hist[-3:]]) <= 1.3 * 20 and max(h[1] for h in hist) < 0.75 * c0, (name, hist, c0)
         else:                                                        # PID multiplier: swings around the limit on its way down
             assert hist[-1][1] <= 0.75 * hist[0][1] and hist[-1][1] <= 1.6 * 20, (name, hist)
         assert hist[-1][0] > hist[0][0] + 30, (name, hist)           # and the reward keeps rising under it

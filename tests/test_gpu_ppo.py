@@ -13,7 +13,7 @@ from helpers import load_npz, oracle_cfg_and_data, ppo_case
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["tiny", "dualclip", "earlystop", "c1", "c2", "recompute"]
+CASES = ["tiny", "dualclip", "earlystop", "c1", "c2", "recompute", "rewnorm", "rewnorm_first", "rewnorm_recompute", "unbounded"]
 
 
 def _engine(cfg, **over):
@@ -24,10 +24,23 @@ def _engine(cfg, **over):
                       eps_clip=cfg["eps_clip"], dual_clip=cfg["dual_clip"], vf_coef=cfg["vf_coef"],
                       max_grad_norm=cfg["max_grad_norm"], target_kl=cfg["target_kl"],
                       norm_adv=cfg["advantage_normalization"], use_lagrangian=cfg["use_lagrangian"],
-                      lr=cfg["lr"], recompute_adv=bool(cfg.get("recompute_advantage", False)))
+                      lr=cfg["lr"], recompute_adv=bool(cfg.get("recompute_advantage", False)),
+                      unbounded=bool(cfg.get("unbounded", False)), rew_norm=bool(cfg.get("reward_normalization", False)),
+                      value_clip=bool(cfg.get("value_clip", False)))
     for k, v in over.items():
         setattr(ec, k, v)
     return Engine(ec)
+
+
+def _start(eng, g, oracle=None):
+    """theta0 and, with reward_normalization, the running return statistics the fixture starts from"""
+    eng.set_params(g["theta0"])
+    if eng.cfg.rew_norm:
+        eng.ret_rms_set(g["ret_rms0"])
+        assert np.array_equal(eng.ret_rms_get(), g["ret_rms0"])
+    if oracle is not None:
+        oracle.set_params(g["theta0"])
+        oracle.ret_rms[:] = g["ret_rms0"]
 
 
 def _push_golden(eng, g):
@@ -111,7 +124,7 @@ def test_store_semantics(name):
 def test_process_fn_vs_golden(name):
     cfg, g = ppo_case(name)
     eng = _engine(cfg)
-    eng.set_params(g["theta0"])
+    _start(eng, g)
     assert np.array_equal(eng.get_params(), g["theta0"])
     _push_golden(eng, g)
     lag = g["lagrangian"]
@@ -131,7 +144,9 @@ def test_minibatch_gradient_vs_autograd(name):
     from oracle.ppo_lag import PPOLagOracle, split_chunks
     cfg, g = ppo_case(name)
     eng = _engine(cfg, lr=0.0, target_kl=None)
-    eng.set_params(g["theta0"])
+    ocfg, data = oracle_cfg_and_data(cfg, g)
+    o = PPOLagOracle(ocfg)
+    _start(eng, g, o)
     _push_golden(eng, g)
     lag = g["lagrangian"]
     eng.ppo_begin(lag, _rescale(lag), cfg["batch_size"])
@@ -139,8 +154,6 @@ def test_minibatch_gradient_vs_autograd(name):
     eng.ppo_end()
     grads = eng.get_grads()
     assert np.array_equal(eng.get_params(), g["theta0"])
-    ocfg, data = oracle_cfg_and_data(cfg, g)
-    o = PPOLagOracle(ocfg); o.set_params(g["theta0"])
     pb = o.process(data)
     chunk = split_chunks(len(data), cfg["batch_size"], g["perms"][0])[-1]
     loss, _, _ = o._minibatch_losses(pb, chunk, lag, _rescale(lag))
@@ -154,14 +167,17 @@ def test_minibatch_gradient_vs_autograd(name):
 def test_full_update_vs_golden(name):
     cfg, g = ppo_case(name)
     eng = _engine(cfg)
-    eng.set_params(g["theta0"])
+    _start(eng, g)
     _push_golden(eng, g)
     lag = g["lagrangian"]
     stats, stopped = eng.ppo_update(lag, _rescale(lag), cfg["batch_size"], cfg["repeat"], perms=g["perms"])
     assert stats.shape == g["stats"].shape
     assert (stopped >= 0) == bool(g["early_stop_msgs"])
     np.testing.assert_allclose(stats, g["stats"], rtol=2e-5, atol=2e-5)
-    np.testing.assert_allclose(eng.get_params(), g["theta_final"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(eng.get_params(), g["theta_final"], rtol=0, atol=2e-6 * max(1.0, cfg["lr"] / 5e-4))
+    if eng.cfg.rew_norm:      # RunningMeanStd after the update (one update() per pass with recompute_advantage)
+        np.testing.assert_allclose(eng.ret_rms_get(), g["ret_rms_final"], rtol=1e-5, atol=1e-7)
+        assert np.array_equal(eng.ret_rms_get()[:, 2], g["ret_rms_final"][:, 2])
     eng.close()
 
 

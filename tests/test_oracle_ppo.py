@@ -10,7 +10,8 @@ from helpers import oracle_cfg_and_data, ppo_case
 from oracle.pid import rescaling_factor
 from oracle.ppo_lag import PPOLagOracle, split_chunks
 
-CASES = ["tiny", "c1", "c2", "earlystop", "dualclip", "recompute"]
+CASES = ["tiny", "c1", "c2", "earlystop", "dualclip", "recompute", "rewnorm", "rewnorm_first", "rewnorm_recompute",
+         "unbounded"]
 
 
 def test_split_chunks_matches_tianshou_semantics():
@@ -29,6 +30,7 @@ def test_process_fn(name):
     ocfg, data = oracle_cfg_and_data(cfg, g)
     o = PPOLagOracle(ocfg)
     o.set_params(g["theta0"])
+    o.ret_rms[:] = g["ret_rms0"]
     pb = o.process(data)
     for k in ("values", "rets", "advs", "logp_old"):
         np.testing.assert_allclose(pb[k].numpy(), g[k], rtol=1e-5, atol=1e-5, err_msg=k)
@@ -41,9 +43,11 @@ def test_full_update(name):
     ocfg, data = oracle_cfg_and_data(cfg, g)
     o = PPOLagOracle(ocfg)
     o.set_params(g["theta0"])
+    o.ret_rms[:] = g["ret_rms0"]
     lag = g["lagrangian"]
     pb, stats, stopped = o.update(data, lag, rescaling_factor(lag), cfg["batch_size"],
                                   cfg["repeat"], perms=g["perms"])
+    np.testing.assert_allclose(o.ret_rms, g["ret_rms_final"], rtol=1e-12, atol=0)      # float64 host arithmetic both sides
     assert stats.shape == g["stats"].shape
     assert o.gradient_steps == int(g["gradient_steps"])
     assert (stopped >= 0) == bool(g["early_stop_msgs"])
