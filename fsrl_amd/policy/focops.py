@@ -29,7 +29,6 @@ class FOCOPS(BasePolicy):
         super().__init__(actor, critics, dist_fn, logger, gamma, max_batchsize, reward_normalization, deterministic_eval,
                          action_scaling, action_bound_method, observation_space, action_space, lr_scheduler)
         assert self.critics_num == 2, "FOCOPS uses a reward and a cost critic"
-        assert not recompute_advantage, "recompute_advantage is not built in the HIP path"
         assert isinstance(nu, tuple), "the reference's nu_loss needs the (nu_max, nu_lr, nu) form (focops.py:154-159)"
         self.actor_optim, self.critics_optim = actor_optim, critic_optim
         self.cost_limit = cost_limit
@@ -38,7 +37,7 @@ class FOCOPS(BasePolicy):
         self._ave_cost_return = 0.0
         self._reference_rng = reference_rng     # burn the torch draws the reference's forward() wastes in update()
         self._make_engine(device, env_num, buffer_size, actor_optim, algo=_lib.ALGO_FOCOPS, gae_lambda=gae_lambda,
-                          norm_adv=advantage_normalization, target_kl=None)
+                          norm_adv=advantage_normalization, target_kl=None, recompute_adv=bool(recompute_advantage))
         self.engine.focops_init(actor_lr=actor_optim.param_groups[0]["lr"], critic_lr=critic_optim.param_groups[0]["lr"],
                                 l2_reg=l2_reg, delta=delta, eta=eta, tem_lambda=tem_lambda, max_grad_norm=max_grad_norm)
 

@@ -71,8 +71,8 @@ typedef struct fsrl_config {
     int32_t use_lagrangian;
     float lr;                /* Adam, one optimiser over actor+critics                   */
     float beta1, beta2, adam_eps;
-    int32_t recompute_adv;   /* PPO: recompute V, GAE, returns with the CURRENT critics before every pass after the
-                                first (ppo_lag.py:218-221 recompute_advantage); logp_old stays                       */
+    int32_t recompute_adv;   /* PPO-Lag, FOCOPS: recompute V, GAE, returns with the CURRENT critics before every pass after
+                                the first (ppo_lag.py:218-221, focops.py:223-226 recompute_advantage); logp_old stays */
     int32_t unbounded;       /* on-policy actor: 1 = mean head without max_action * tanh (ActorProb(unbounded=True),
                                 tianshou 0.5 utils/net/continuous.py; fsrl/agent/ppo_lag_agent.py:134)                */
     int32_t rew_norm;        /* reward_normalization (base_policy.py:114, 430-444): critics learn returns divided by the

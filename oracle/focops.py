@@ -40,13 +40,16 @@ class FOCOPSConfig:
     nu_max: float = 2.0
     nu_lr: float = 1e-2
     cost_limit: float = 10.0
+    unbounded: bool = False      # ActorProb(unbounded=True)
+    recompute_advantage: bool = False    # focops.py:223-226
 
 
 class FOCOPSOracle(PPOLagOracle):
     def __init__(self, cfg: FOCOPSConfig, dtype=torch.float32):
         self.fcfg = cfg
         super().__init__(PPOLagConfig(obs_dim=cfg.obs_dim, act_dim=cfg.act_dim, hidden=cfg.hidden, max_action=cfg.max_action,
-                                      gamma=cfg.gamma, gae_lambda=cfg.gae_lambda, lr=cfg.actor_lr), dtype)
+                                      gamma=cfg.gamma, gae_lambda=cfg.gae_lambda, lr=cfg.actor_lr,
+                                      unbounded=cfg.unbounded), dtype)
 
     def set_params(self, flat, nu=0.0):
         super().set_params(flat)
@@ -103,10 +106,13 @@ class FOCOPSOracle(PPOLagOracle):
         return {"loss/actor_loss": loss.item(), "loss/kl": kl.mean().item(), "loss/entropy": ent.item()}, sc
 
     def update(self, data: OnPolicyData, ave_cost_return, batch_size, repeat, perms):
-        pb = self.process(data)
+        pb = pb0 = self.process(data)
         snu = self.nu_step(ave_cost_return)
         rows, stopped = [], -1
         for k in range(repeat):
+            if self.fcfg.recompute_advantage and k > 0:      # values / rets / advs from the current critics; old dist stays
+                fresh = PPOLagOracle.process(self, data)
+                pb = dict(pb, values=fresh["values"], rets=fresh["rets"], advs=fresh["advs"])
             kl_sum, n = 0.0, 0
             for chunk in split_chunks(len(data), batch_size, perms[k]):
                 sa, sc = self.step(pb, chunk)
@@ -115,4 +121,4 @@ class FOCOPSOracle(PPOLagOracle):
             if kl_sum / (n + 1e-7) > self.fcfg.delta:
                 stopped = k
                 break
-        return pb, rows, stopped
+        return pb0, rows, stopped

@@ -45,6 +45,8 @@ class CPOConfig:
     advantage_normalization: bool = True
     cost_limit: float = 10.0
     lr: float = 1e-3           # Adam over the CRITIC parameters only (cpo_agent.py:147-148)
+    unbounded: bool = False              # ActorProb(unbounded=True)
+    reward_normalization: bool = False   # base_policy.py:430-444 (shared compute_gae_returns)
 
 
 @dataclass
@@ -63,6 +65,8 @@ class TRPOConfig:
     use_lagrangian: bool = True
     lr: float = 5e-4           # Adam over all params; only the critics ever receive gradients
     damping: float = 0.1       # trpo_lag.py:115
+    unbounded: bool = False
+    reward_normalization: bool = False
 
 
 class _TrustRegionBase(PPOLagOracle):
@@ -70,7 +74,8 @@ class _TrustRegionBase(PPOLagOracle):
 
     def __init__(self, cfg, dtype=torch.float32):
         base = PPOLagConfig(obs_dim=cfg.obs_dim, act_dim=cfg.act_dim, hidden=cfg.hidden,
-                            max_action=cfg.max_action, gamma=cfg.gamma, gae_lambda=cfg.gae_lambda, lr=cfg.lr)
+                            max_action=cfg.max_action, gamma=cfg.gamma, gae_lambda=cfg.gae_lambda, lr=cfg.lr,
+                            unbounded=cfg.unbounded, reward_normalization=cfg.reward_normalization)
         self.tcfg = cfg
         super().__init__(base, dtype)
 

@@ -26,8 +26,8 @@ from ref_shim import _Box  # noqa: E402
 
 
 def gen(name, obs_dim, act_dim, hidden, env_num, ep_lens, batch_size, repeat, seed, cost_stat, cost_limit=10.0,
-        actor_lr=5e-4, critic_lr=1e-3, auto_nu=True, nu=0.01, nu_max=2.0, nu_lr=1e-2, prior_updates=0, **kw):
-    actor, critic, ac = build_nets(obs_dim, act_dim, hidden, seed)
+        actor_lr=5e-4, critic_lr=1e-3, auto_nu=True, nu=0.01, nu_max=2.0, nu_lr=1e-2, prior_updates=0, unbounded=False, **kw):
+    actor, critic, ac = build_nets(obs_dim, act_dim, hidden, seed, unbounded)
     g = torch.Generator().manual_seed(seed + 3)
     with torch.no_grad():
         for p in ac.parameters():
@@ -70,6 +70,8 @@ def gen(name, obs_dim, act_dim, hidden, env_num, ep_lens, batch_size, repeat, se
                     advantage_normalization=True, gamma=0.99)
     defaults.update(kw)
     cfg.update(defaults)
+    if unbounded:
+        cfg["unbounded"] = True
     out["cfg_json"] = np.array(json.dumps(cfg))
     np.savez_compressed(os.path.join(HERE, f"focops_{name}.npz"), **out)
     print(f"G10 focops_{name}.npz N={len(out['indices'])} steps={steps} perms={len(pr.perms)} keys={kn}{ka}{kc} "
@@ -79,6 +81,11 @@ def gen(name, obs_dim, act_dim, hidden, env_num, ep_lens, batch_size, repeat, se
 if __name__ == "__main__":
     torch.set_num_threads(4)
     eps = [[60, 50, -17], [70, 55], [40, 40, 40, -9]]
+    if sys.argv[1:] == ["options"]:
+        gen("unbounded", 6, 2, (64, 64), 3, eps, batch_size=64, repeat=3, seed=53, cost_stat=25.0, unbounded=True)
+        # recompute_advantage (focops.py:223-226): GAE from the current critics before passes 2 and 3
+        gen("recompute", 6, 2, (64, 64), 3, eps, batch_size=64, repeat=3, seed=54, cost_stat=25.0, recompute_advantage=True)
+        sys.exit(0)
     gen("small", 6, 2, (64, 64), 3, eps, batch_size=64, repeat=3, seed=50, cost_stat=25.0)
     gen("c1", 8, 2, (128, 128), 4, [[150, 150], [300], [200, -60], [120, 120, -40]], batch_size=256, repeat=4, seed=51,
         cost_stat=4.0, nu=0.3)

@@ -26,9 +26,9 @@ from gen_golden import CaptureLogger, fill_buffer, flat_params, seed_all  # noqa
 from ref_shim import ActorProb, Critic, Net, _Box  # noqa: E402
 
 
-def build_nets(obs_dim, act_dim, hidden, seed):
+def build_nets(obs_dim, act_dim, hidden, seed, unbounded=False):
     seed_all(seed)
-    actor = ActorProb(Net((obs_dim, ), hidden_sizes=hidden), (act_dim, ), max_action=1.0)
+    actor = ActorProb(Net((obs_dim, ), hidden_sizes=hidden), (act_dim, ), max_action=1.0, unbounded=unbounded)
     critic = [Critic(Net((obs_dim, ), hidden_sizes=hidden)) for _ in range(2)]
     torch.nn.init.constant_(actor.sigma_param, -0.5)
     ac = ActorCritic(actor, critic)
@@ -61,6 +61,14 @@ class PermRecorder:
         np.random.permutation = self._orig
 
 
+def preset_rms(out, policy, ret_rms0):
+    """reward_normalization cases: start from the running return statistics an earlier update would have left"""
+    if ret_rms0 is not None:
+        for rms, (m, v, n) in zip(policy.ret_rms, ret_rms0):
+            rms.mean, rms.var, rms.count = float(m), float(v), float(n)
+        out["ret_rms0"] = np.array([[r.mean, r.var, r.count] for r in policy.ret_rms], np.float64)
+
+
 def record_batch(out, buf):
     batch, indices = buf.sample(0)
     out["indices"] = indices
@@ -72,10 +80,10 @@ def record_batch(out, buf):
 
 
 def gen_cpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cost_stat, cost_limit,
-            lr=1e-3, perturb_actor=0.0, zero_cost_signal=False, **kw):
+            lr=1e-3, perturb_actor=0.0, zero_cost_signal=False, unbounded=False, ret_rms0=None, **kw):
     """cost_stat / cost_limit steer the optim_case; perturb_actor moves theta away from the
     theta that produced mean_old (exercises the exact-Hessian path on the very first call)."""
-    actor, critic, ac = build_nets(obs_dim, act_dim, hidden, seed)
+    actor, critic, ac = build_nets(obs_dim, act_dim, hidden, seed, unbounded)
     if zero_cost_signal:
         # optim_case 4 (cpo.py:261-268: grad_b . grad_b <= 1e-8 and c < 0): no cost in the data and a cost critic that
         # answers 0 everywhere (zero last layer) => cost advantages are exactly 0 => the cost-surrogate gradient vanishes
@@ -103,8 +111,12 @@ def gen_cpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cost
         return x
 
     policy._conjugate_gradients = cg
+    preset_rms(out, policy, ret_rms0)
     batch, indices = buf.sample(0)
+    import copy
+    rms_keep = copy.deepcopy(policy.ret_rms)      # the recording call below must not advance the running statistics
     pbatch = policy.process_fn(batch, buf, indices)
+    policy.ret_rms = rms_keep
     out["advs_norm"] = pbatch.advs.numpy().copy()
     out["rets"] = pbatch.rets.numpy().copy()
     out["logp_old"] = pbatch.logp_old.numpy().copy()
@@ -140,9 +152,13 @@ def gen_cpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cost
         out["stats_critic"] = np.array([[rows[2 * i + 1][k] for k in keys_c] for i in range(repeat)])
         out["H_inv_g_first"] = cap["cg"][0]
         out["theta_final"] = flat_params(ac)
+        if ret_rms0 is not None:
+            out["ret_rms_final"] = np.array([[r.mean, r.var, r.count] for r in policy.ret_rms], np.float64)
     cfg = dict(obs_dim=obs_dim, act_dim=act_dim, hidden=list(hidden), env_num=env_num, repeat=repeat,
                seed=seed, cost_stat=cost_stat, cost_limit=cost_limit, lr=lr, max_action=1.0,
                perturb_actor=perturb_actor)
+    if unbounded:
+        cfg["unbounded"] = True
     defaults = dict(target_kl=0.01, backtrack_coeff=0.8, damping_coeff=0.1, max_backtracks=10,
                     optim_critic_iters=20, l2_reg=0.001, gae_lambda=0.95, advantage_normalization=True,
                     gamma=0.99)
@@ -161,8 +177,8 @@ def gen_cpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cost
 
 
 def gen_trpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cost_stat, cost_limit,
-             lr=5e-4, **kw):
-    actor, critic, ac = build_nets(obs_dim, act_dim, hidden, seed)
+             lr=5e-4, unbounded=False, ret_rms0=None, **kw):
+    actor, critic, ac = build_nets(obs_dim, act_dim, hidden, seed, unbounded)
     optim = torch.optim.Adam(ac.parameters(), lr=lr)
     logger = CaptureLogger()
     policy = TRPOLagrangian(actor, critic, optim, dist, logger=logger, cost_limit=cost_limit,
@@ -183,9 +199,12 @@ def gen_trpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cos
         return x
 
     policy._conjugate_gradients = cg
+    preset_rms(out, policy, ret_rms0)
     with PermRecorder() as pr:
         policy.update(0, buf, batch_size=99999, repeat=repeat)
     out["perms"] = np.stack(pr.perms)
+    if ret_rms0 is not None:
+        out["ret_rms_final"] = np.array([[r.mean, r.var, r.count] for r in policy.ret_rms], np.float64)
     rows = [r for r in logger.rows if "update/gradient_steps" not in r]
     assert len(rows) == 3 * repeat
     keys = []
@@ -200,6 +219,8 @@ def gen_trpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cos
     out["msgs"] = np.array(len(logger.msgs))
     cfg = dict(obs_dim=obs_dim, act_dim=act_dim, hidden=list(hidden), env_num=env_num, repeat=repeat,
                seed=seed, cost_stat=cost_stat, cost_limit=cost_limit, lr=lr, max_action=1.0)
+    if unbounded:
+        cfg["unbounded"] = True
     defaults = dict(target_kl=0.001, backtrack_coeff=0.8, max_backtracks=10, optim_critic_iters=5,
                     gae_lambda=0.95, advantage_normalization=True, gamma=0.99,
                     lagrangian_pid=(0.05, 0.0005, 0.1), rescaling=True, use_lagrangian=True)
@@ -220,6 +241,14 @@ if __name__ == "__main__":
         # the vanishing-cost-gradient branch: zero cost signal, no advantage normalisation (0 / 0 otherwise), c < 0
         gen_cpo("case4", 8, 2, (64, 64), 3, eps, repeat=2, seed=16, cost_stat=0.0, cost_limit=10.0,
                 optim_critic_iters=3, max_backtracks=12, advantage_normalization=False, zero_cost_signal=True)
+        sys.exit(0)
+    if sys.argv[1:] == ["options"]:
+        # unbounded actor head + reward_normalization from a non-trivial running state, through the trust-region updates
+        rms0 = [(2.9, 6.5, 1500.0), (0.35, 0.8, 1500.0)]
+        gen_cpo("options", 8, 2, (64, 64), 3, eps, repeat=2, seed=17, cost_stat=25.0, cost_limit=10.0,
+                optim_critic_iters=5, max_backtracks=10, unbounded=True, reward_normalization=True, ret_rms0=rms0)
+        gen_trpo("options", 8, 2, (64, 64), 3, eps, repeat=2, seed=22, cost_stat=25.0, cost_limit=10.0,
+                 optim_critic_iters=5, unbounded=True, reward_normalization=True, ret_rms0=rms0)
         sys.exit(0)
     # cost far above the limit (c > 0): infeasible / recovery branches
     gen_cpo("infeasible", 8, 2, (64, 64), 3, eps, repeat=2, seed=10, cost_stat=25.0, cost_limit=10.0,

@@ -16,7 +16,9 @@ def _engine(cfg, g):
     from fsrl_amd.engine import Engine, EngineConfig
     eng = Engine(EngineConfig(algo=_lib.ALGO_FOCOPS, obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"], hidden=cfg["hidden"][0],
                               n_critics=2, env_num=cfg["env_num"], max_action=cfg["max_action"], gamma=cfg["gamma"],
-                              gae_lambda=cfg["gae_lambda"], norm_adv=cfg["advantage_normalization"], target_kl=None))
+                              gae_lambda=cfg["gae_lambda"], norm_adv=cfg["advantage_normalization"], target_kl=None,
+                              unbounded=bool(cfg.get("unbounded", False)),
+                              recompute_adv=bool(cfg.get("recompute_advantage", False))))
     eng.focops_init(actor_lr=cfg["actor_lr"], critic_lr=cfg["critic_lr"], l2_reg=cfg["l2_reg"], delta=cfg["delta"],
                     eta=cfg["eta"], tem_lambda=cfg["tem_lambda"], max_grad_norm=cfg["max_grad_norm"])
     eng.set_params(g["theta0"])
@@ -29,7 +31,7 @@ def _engine(cfg, g):
     return eng
 
 
-@pytest.mark.parametrize("name", ["small", "c1", "earlystop"])
+@pytest.mark.parametrize("name", ["small", "c1", "earlystop", "unbounded", "recompute"])
 def test_focops_update_vs_golden(name):
     g = load_npz(f"focops_{name}.npz")
     cfg = json.loads(str(g["cfg_json"]))
@@ -37,7 +39,7 @@ def test_focops_update_vs_golden(name):
     nu = float(g["stats_nu"][0][1]); nu_loss = float(g["stats_nu"][0][0])       # the host-side nu step (focops.py:154-159)
     perms = list(g["perms"]) + [np.arange(len(g["indices"]))] * (cfg["repeat"] - len(g["perms"]))
     stats, stopped = eng.focops_update(nu, nu_loss, cfg["batch_size"], cfg["repeat"], perms=perms)
-    for k in ("rets", "advs", "logp_old"):
+    for k in ("logp_old", ) if cfg.get("recompute_advantage") else ("rets", "advs", "logp_old"):   # recompute overwrites rets / advs
         scale = max(1.0, float(np.abs(g[k]).max()))
         np.testing.assert_allclose(eng.batch_get(k), g[k], rtol=0, atol=5e-6 * scale, err_msg=k)
     want = np.concatenate([g["stats_nu"], g["stats_actor"], g["stats_critic"]], 1)

@@ -15,10 +15,12 @@ def focops_cfg(cfg):
                         gamma=cfg["gamma"], gae_lambda=cfg["gae_lambda"], actor_lr=cfg["actor_lr"], critic_lr=cfg["critic_lr"],
                         l2_reg=cfg["l2_reg"], delta=cfg["delta"], eta=cfg["eta"], tem_lambda=cfg["tem_lambda"],
                         max_grad_norm=cfg["max_grad_norm"], advantage_normalization=cfg["advantage_normalization"],
-                        nu_max=cfg["nu_max"], nu_lr=cfg["nu_lr"], cost_limit=cfg["cost_limit"])
+                        nu_max=cfg["nu_max"], nu_lr=cfg["nu_lr"], cost_limit=cfg["cost_limit"],
+                        unbounded=bool(cfg.get("unbounded", False)),
+                        recompute_advantage=bool(cfg.get("recompute_advantage", False)))
 
 
-@pytest.mark.parametrize("name", ["small", "c1", "earlystop"])
+@pytest.mark.parametrize("name", ["small", "c1", "earlystop", "unbounded", "recompute"])
 def test_focops_update(name):
     torch.set_num_threads(4)
     g = load_npz(f"focops_{name}.npz")

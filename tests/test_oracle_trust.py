@@ -22,7 +22,8 @@ def cpo_cfg(cfg):
                      backtrack_coeff=cfg["backtrack_coeff"], damping_coeff=cfg["damping_coeff"],
                      max_backtracks=cfg["max_backtracks"], optim_critic_iters=cfg["optim_critic_iters"],
                      l2_reg=cfg["l2_reg"], advantage_normalization=cfg["advantage_normalization"],
-                     cost_limit=cfg["cost_limit"], lr=cfg["lr"])
+                     cost_limit=cfg["cost_limit"], lr=cfg["lr"], unbounded=bool(cfg.get("unbounded", False)),
+                     reward_normalization=bool(cfg.get("reward_normalization", False)))
 
 
 def trpo_cfg(cfg):
@@ -31,17 +32,22 @@ def trpo_cfg(cfg):
                       backtrack_coeff=cfg["backtrack_coeff"], max_backtracks=cfg["max_backtracks"],
                       optim_critic_iters=cfg["optim_critic_iters"],
                       advantage_normalization=cfg["advantage_normalization"],
-                      use_lagrangian=cfg["use_lagrangian"], lr=cfg["lr"])
+                      use_lagrangian=cfg["use_lagrangian"], lr=cfg["lr"], unbounded=bool(cfg.get("unbounded", False)),
+                      reward_normalization=bool(cfg.get("reward_normalization", False)))
 
 
-@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4"])
+@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options"])
 def test_cpo_update(name):
     torch.set_num_threads(4)
     g = load_npz(f"cpo_{name}.npz")
     cfg = json.loads(str(g["cfg_json"]))
     o = CPOOracle(cpo_cfg(cfg))
     o.set_params(g["theta0"])
+    if "ret_rms0" in g:
+        o.ret_rms[:] = g["ret_rms0"]
     pb, rows = o.update(_data(g), cfg["cost_stat"], cfg["repeat"], perms=g["perms"])
+    if "ret_rms0" in g:
+        np.testing.assert_allclose(o.ret_rms, g["ret_rms_final"], rtol=1e-10)
     np.testing.assert_allclose(pb["advs"].numpy(), g["advs_norm"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(pb["mean_old"].numpy(), g["mean_old"], rtol=0, atol=1e-6)
     ka = [str(k) for k in g["stats_actor_keys"]]
@@ -73,13 +79,15 @@ def test_cpo_policy_loss_away_from_theta_old():
     np.testing.assert_allclose(o.get_params(), g["theta_after_pl"], rtol=0, atol=2e-6)
 
 
-@pytest.mark.parametrize("name", ["small", "c1"])
+@pytest.mark.parametrize("name", ["small", "c1", "options"])
 def test_trpo_update(name):
     torch.set_num_threads(4)
     g = load_npz(f"trpo_{name}.npz")
     cfg = json.loads(str(g["cfg_json"]))
     o = TRPOLagOracle(trpo_cfg(cfg))
     o.set_params(g["theta0"])
+    if "ret_rms0" in g:
+        o.ret_rms[:] = g["ret_rms0"]
     lag = g["lagrangian"]
     pb, rows = o.update(_data(g), lag, 1.0 / (lag.sum() + 1.0), cfg["repeat"], perms=g["perms"])
     keys = [str(k) for k in g["stats_keys"]]
