@@ -344,6 +344,22 @@ def main():
                 eng.comm_destroy()
             elif ok == 1.0:
                 lib_comm = "skipped: another rank cannot reach RCCL"
+    # ---- the other half of the headline metric at N > 1: every rank's whole training loop (host collector -> HIP store ->
+    #      update) side by side for a few seconds on its own slice of the host cores; job env-steps/s = the sum over ranks
+    e2e_job = None
+    if dist is not None:
+        from fsrl_amd import parallel
+        cores = parallel.pin_rank_cores(local_rank if not args.share_gpu else rank, world)
+        dist.barrier()
+        e2e = end_to_end(local_rank, seed, seconds=4.0, device_actor=True)
+        rows = parallel.allgather_metrics({"rank": float(rank), "env_steps_per_s": e2e["env_steps_per_s"],
+                                           "policy_updates_per_s": e2e["policy_updates_per_s"], "cores": float(len(cores))})
+        rows.sort(key=lambda r: r["rank"])
+        e2e_job = {"env": e2e["env"], "actor": e2e["actor"], "envs_per_rank": e2e["envs"], "ranks": len(rows),
+                   "env_steps_per_s": sum(r["env_steps_per_s"] for r in rows),
+                   "policy_updates_per_s": sum(r["policy_updates_per_s"] for r in rows),
+                   "per_rank_env_steps_per_s": [round(r["env_steps_per_s"], 1) for r in rows],
+                   "host_cores_per_rank": int(rows[0]["cores"])}
     # ---- roofline of the dominant kernel: HIP events around every ppo_fwd_bwd_kernel launch on
     #      the library's compute stream, over K more updates of the same workload
     eng.set_profiling(True)
@@ -386,6 +402,8 @@ def main():
             out["ranks_seen"] = len(per_rank)
             if lib_comm is not None:
                 out["lib_metrics_allreduce"] = lib_comm
+            if e2e_job is not None:
+                out["end_to_end_job"] = e2e_job
             out["per_rank_updates_per_s"] = [round(r["updates_per_s"], 3) for r in sorted(per_rank, key=lambda r: r["rank"])]
             out["sum_of_rank_rates"] = sum(r["updates_per_s"] for r in per_rank)
         pmc = pmc_traffic()

@@ -355,6 +355,9 @@ def test_bench_multi_rank_path_on_one_gpu():
     assert "roofline" in d and "cpu_baseline" not in d                               # CPU leg: rank 0 at N = 1 only
     assert d["ranks_seen"] == 2 and len(d["per_rank_updates_per_s"]) == 2              # the 8(e) exchange saw both ranks
     assert d["value"] <= d["sum_of_rank_rates"] * (1 + 1e-9)                           # max-over-ranks time <= any rank's own
+    job = d["end_to_end_job"]                                                          # env-steps/s of the whole job
+    assert job["ranks"] == 2 and len(job["per_rank_env_steps_per_s"]) == 2
+    assert abs(job["env_steps_per_s"] - sum(job["per_rank_env_steps_per_s"])) < 1.0 and job["env_steps_per_s"] > 1000
 
 
 def test_multi_gpu_launcher_two_ranks_share_this_gpu(tmp_path):
