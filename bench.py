@@ -136,10 +136,13 @@ def end_to_end(local_rank, seed, seconds=6.0, device_actor=False, workers=0, bus
         update_s += time.perf_counter() - t1
         collects += 1
     dt = time.perf_counter() - t0
+    from fsrl_amd.parallel import usable_cpus
     kind = (f"shared-memory multi-process vector env: {workers} worker processes, {busy_us:g} us of host time per env step"
             if workers > 0 else "in-process vector env, zero-cost step")
     out = {"env": "synthetic SafetyCarCircle-shaped dynamics (not PyBullet); " + kind, "envs": envs, "workers": workers,
-           "busy_us": busy_us,
+           "busy_us": busy_us, "host_cpus_usable": usable_cpus(),
+           "handshake": (("polled sequence numbers" if getattr(env, "spin_us", 0) > 0 else "semaphores") if workers > 0 else None),
+           "env_bound_env_steps_per_s": (min(envs, usable_cpus()) / (busy_us * 1e-6) if busy_us > 0 else None),
            "actor": "device (fsrl_collect_step: one call per vector step, library RNG)" if device_actor else "host mirror (torch CPU, torch RNG)",
            "collects": collects, "env_steps_per_s": col.collect_step / dt,
            "collector_only_env_steps_per_s": col.collect_step / col.collect_time,

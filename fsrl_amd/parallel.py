@@ -53,6 +53,31 @@ def init_from_env(backend: Optional[str] = None, share_gpu: bool = False) -> Tup
     return rank, local_rank, world
 
 
+def usable_cpus() -> float:
+    """CPUs this process can actually run on: the affinity mask, capped by the cgroup CPU quota (a container may see 256 CPUs
+    and be allowed 16 CPU-seconds per second: cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us / cpu.cfs_period_us`)."""
+    try:
+        n = float(len(os.sched_getaffinity(0)))
+    except AttributeError:
+        n = float(os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, float(quota) / float(period))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = float(f.read())
+            if quota > 0:
+                n = min(n, quota / period)
+        except (OSError, ValueError):
+            pass
+    return max(n, 1.0)
+
+
 def pin_rank_cores(local_rank: int, local_world: int, reserve: int = 0) -> List[int]:
     """Give this rank a disjoint slice of the host cores (its collector loop + env workers inherit it): SURVEY 8e
     "envs_per_rank host workers pinned to disjoint core sets".  Returns the slice; a no-op where affinity is unsupported."""

@@ -21,10 +21,12 @@ def _rollout(env, steps, seed):
     return out
 
 
-def test_one_worker_is_bit_identical_to_the_in_process_env():
+@pytest.mark.parametrize("spin_us", [0.0, 300.0])
+def test_one_worker_is_bit_identical_to_the_in_process_env(spin_us):
+    """both handshakes: semaphores only (spin_us = 0, small hosts) and polled sequence numbers with parking"""
     from fsrl_amd.env import ShmemVectorEnv, SyntheticSafetyVectorEnv
     a = SyntheticSafetyVectorEnv(env_num=6, episode_len=11, seed=3)
-    b = ShmemVectorEnv(env_num=6, workers=1, episode_len=11, seed=3)
+    b = ShmemVectorEnv(env_num=6, workers=1, episode_len=11, seed=3, spin_us=spin_us)
     try:
         ra, rb = _rollout(a, 40, 0), _rollout(b, 40, 0)
         assert len(ra) == len(rb)
@@ -73,10 +75,15 @@ def test_collector_runs_over_the_shmem_env():
         def map_action(self, a): return a
         def map_action_inverse(self, a): return a
 
-    env = ShmemVectorEnv(env_num=6, workers=3, episode_len=9, seed=2)
+    env = ShmemVectorEnv(env_num=6, workers=3, episode_len=9, seed=2, spin_us=200.0)     # polling; parks between collects
     try:
         col = FastCollector(_Pol(), env, None)
         st = col.collect(n_episode=10, random=True)
         assert st["n/ep"] == 10 and st["len"] == 9.0 and st["truncated"] == 1.0
+        import time
+        time.sleep(0.02)                                  # the workers park (nothing for 200 us) ...
+        assert int(env._v["parked"][:3, 0].sum()) == 3
+        st = col.collect(n_episode=6, random=True)        # ... and are woken by the next command
+        assert st["n/ep"] == 6 and st["len"] == 9.0
     finally:
         env.close()
