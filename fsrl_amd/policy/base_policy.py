@@ -70,12 +70,14 @@ class BasePolicy(ABC, nn.Module):
         self._push_params()
 
     @property
-    def ret_rms(self) -> np.ndarray:
-        """BasePolicy.ret_rms of the reference (base_policy.py:111) as rows of (mean, var, count), one per critic; they live
-        in the engine (`fsrl_ret_rms_get`).  Without reward_normalization: the untouched initial state."""
-        if self._rew_norm and self.engine is not None:
-            return self.engine.ret_rms_get()
-        return np.array([[0.0, 1.0, 0.0]] * self.critics_num)
+    def ret_rms(self):
+        """BasePolicy.ret_rms of the reference (base_policy.py:111): one running mean / var / count of the normalised returns
+        per critic, read from the engine (`fsrl_ret_rms_get`) -- a list of objects with tianshou's RunningMeanStd attribute
+        names.  Without reward_normalization: the untouched initial state (mean 0, var 1, count 0)."""
+        from types import SimpleNamespace
+        rows = (self.engine.ret_rms_get() if self._rew_norm and self.engine is not None
+                else np.array([[0.0, 1.0, 0.0]] * self.critics_num))
+        return [SimpleNamespace(mean=float(m), var=float(v), count=float(n)) for m, v, n in rows]
 
     # ------------------------------------------------------------------ parameter plumbing
     def _flat_params(self, fresh: bool = True) -> np.ndarray:
