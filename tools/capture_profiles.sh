@@ -30,4 +30,6 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_cvpo -- python $R/tools/bench_cvpo.py --updates 300 --no-cpu > /dev/null 2>&1
 cd $R
 timeout 600 python tools/bench_trust.py > $O/${TAG}_bench_trust.json 2>/dev/null
+timeout 300 python tools/learning_curves.py > $O/${TAG}_learning_curves.json 2>/dev/null
+timeout 300 python tools/bench_shmem.py > $O/${TAG}_bench_shmem.json 2>/dev/null
 ls $O | head -40
