@@ -73,12 +73,12 @@ def flops_fwdbwd_launch(rows):
     return per_row * rows
 
 
-def cpu_baseline(theta, inputs, seconds=12.0):
+def cpu_baseline(theta, inputs, seconds=12.0, threads=4):
     """The oracle (torch CPU fp32 port of the reference update) timed on the host cores,
-    on a bounded sample: whole updates of the SAME workload until `seconds` elapsed."""
+    on a bounded sample: whole updates of the SAME workload until `seconds` elapsed.
+    threads = 4: the reference default `thread=4` (fsrl/config/ppol_cfg.py:11)."""
     import torch
     from oracle.ppo_lag import OnPolicyData, PPOLagConfig, PPOLagOracle
-    threads = 4  # reference default `thread=4` (fsrl/config/ppol_cfg.py:11)
     torch.set_num_threads(threads)
     obs, act, rew, cost, term, trunc = inputs
     em = lambda a: np.concatenate([a[:, e] for e in range(ENVS)])
@@ -422,6 +422,10 @@ def main():
             out["no_clip"] = no_clip_variant(theta, inputs)
             out["grouped"] = grouped()
             out["cpu_baseline"] = cpu_baseline(theta, inputs)
+            from fsrl_amd.parallel import usable_cpus
+            allc = max(1, int(usable_cpus()))          # "... and with all host cores" (the cgroup quota counts)
+            if allc > 4:
+                out["cpu_baseline_all_cores"] = cpu_baseline(theta, inputs, seconds=6.0, threads=allc)
             out["speedup_vs_cpu_port"] = out["value"] / world / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     eng.close()
