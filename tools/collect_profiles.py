@@ -17,8 +17,14 @@ go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 
 
 def one(pattern):
+    """the file of the LAST capture's main process: gpurun merges into gpurun_out/ without deleting what earlier captures left,
+    and a traced command that spawns processes (the bench's env workers) leaves one file per pid -- newest run, largest file"""
     f = glob.glob(os.path.join(go, pattern), recursive=True)
-    return f[0] if f else None
+    if not f:
+        return None
+    newest = max(os.path.getmtime(x) for x in f)
+    f = [x for x in f if newest - os.path.getmtime(x) < 1200]
+    return max(f, key=os.path.getsize)
 
 
 for src, dst in ((f"{tag}_bench.json", f"{tag}_bench.json"), (f"{tag}_bench_profiled.json", f"{tag}_bench_profiled.json"),
