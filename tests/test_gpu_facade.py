@@ -470,3 +470,34 @@ def test_metrics_allreduce_through_the_c_abi():
     assert job["job/ranks"] == 1.0 and job["job/reward"] == 10.0 and job["job/env_steps_per_s"] == 50.0
     eng.comm_destroy()
     eng.close()
+
+
+@pytest.mark.parametrize("kind", ["ppol", "cpo", "trpol", "focops"])
+def test_agents_accept_the_on_policy_options_of_the_reference(kind, tmp_path):
+    """unbounded actor head + reward_normalization (+ value_clip and recompute_advantage where the reference has them) through
+    Agent.__init__ -> learn(): the arguments reach the engine, the running return statistics advance once per
+    compute_gae_returns call, training stays finite."""
+    from fsrl_amd.agent import CPOAgent, FOCOPSAgent, PPOLagAgent, TRPOLagAgent
+    from fsrl_amd.env import SyntheticSafetyVectorEnv
+    from fsrl_amd.utils import BaseLogger
+    cls, kw, lk = {"ppol": (PPOLagAgent, dict(value_clip=True, recompute_advantage=True, max_grad_norm=0.5), dict(repeat_per_collect=3, batch_size=64)),
+                   "cpo": (CPOAgent, {}, dict(repeat_per_collect=2, batch_size=99999)),
+                   "trpol": (TRPOLagAgent, {}, dict(repeat_per_collect=2, batch_size=99999)),
+                   "focops": (FOCOPSAgent, dict(recompute_advantage=True), dict(repeat_per_collect=3, batch_size=64))}[kind]
+    env = SyntheticSafetyVectorEnv(env_num=4, episode_len=50, seed=1)
+    agent = cls(env, BaseLogger(str(tmp_path), name="t"), cost_limit=10, device="cuda:0", seed=3, hidden_sizes=(64, 64),
+                training_num=4, unbounded=True, reward_normalization=True, **kw)
+    cfg = agent.policy.engine.cfg
+    assert cfg.unbounded and cfg.rew_norm and agent.policy.actor._unbounded
+    assert cfg.value_clip == (kind == "ppol") and cfg.recompute_adv == (kind in ("ppol", "focops"))
+    ep, stat, info = agent.learn(env, None, epoch=2, episode_per_collect=4, step_per_epoch=400, verbose=False, save_ckpt=False, **lk)
+    assert ep == 2 and np.isfinite([v for v in stat.values() if isinstance(v, (int, float))]).all()
+    rms = agent.policy.ret_rms
+    collects = 2 * 2                                  # 2 epochs x (400 steps / (4 episodes x 50 steps)) collects
+    per_update = 3 if kind in ("ppol", "focops") else 1   # recompute_advantage: once more before passes 2 and 3 (fewer after
+    assert len(rms) == 2 and rms[0].count == rms[1].count and rms[0].count % 200 == 0       # a KL early stop)
+    assert collects * 200 <= rms[0].count <= collects * per_update * 200, [r.count for r in rms]
+    assert all(r.var > 0 and np.isfinite(r.mean) for r in rms)
+    mu = agent.policy.engine.actor_forward(np.full((1, 8), 3.0, np.float32))[0]
+    assert np.isfinite(mu).all()
+    agent.policy.engine.close()
