@@ -235,3 +235,36 @@ def test_sac_configs3_full_size():
         assert np.quantile(d, 0.99) <= 5e-6 and d.max() <= 3.1e-3, (np.quantile(d, 0.99), d.max())
     assert abs(eng.sac_get_params(0)[1] - float(o.alpha)) < 1e-6
     eng.close()
+
+
+def test_hessian_vector_product_properties_at_full_size():
+    """Size-independent properties of the exact R-op Hessian-vector product of the mean KL (cpo.py:177-182) at configs[2]'s
+    size (N = 20 000 rows, 256x256, obs 60), no oracle needed: linearity H(a v + b w) = a Hv + b Hw, symmetry v.Hw = w.Hv,
+    positive semi-definiteness at theta_old (the Hessian of a KL at its minimum is the Fisher matrix), and -- after the actor
+    has moved away from theta_old -- still symmetric (the exact Hessian, not the Fisher approximation)."""
+    from oracle.trust_region import CPOConfig, CPOOracle
+    eng, _ = _setup_onpolicy(60, 2, 256, 1000, 1e-3)
+    o = CPOOracle(CPOConfig(obs_dim=60, act_dim=2, hidden=(256, 256)))
+    theta = _orth_theta(o, 0)
+    eng.set_params(theta); eng.optim_reset()
+    n = eng.tr_begin(target_kl=0.01, l2_reg=0.001, critic_lr=1e-3, max_backtracks=10, optim_critic_iters=10, cost_limit=10.0)
+    assert n == 20000
+    na = eng.n_actor_params
+    rng = np.random.default_rng(3)
+    v, w = rng.standard_normal(na).astype(np.float32), rng.standard_normal(na).astype(np.float32)
+
+    def check(tag):
+        hv, hw = eng.tr_hvp(v).astype(np.float64), eng.tr_hvp(w).astype(np.float64)
+        hvw = eng.tr_hvp((0.5 * v - 2.0 * w).astype(np.float32)).astype(np.float64)
+        scale = np.abs(hvw).max()
+        assert np.abs(hvw - (0.5 * hv - 2.0 * hw)).max() <= 2e-5 * scale, (tag, np.abs(hvw - (0.5 * hv - 2.0 * hw)).max(), scale)
+        a, b = float(v.astype(np.float64) @ hw), float(w.astype(np.float64) @ hv)
+        assert abs(a - b) <= 2e-5 * np.sqrt(float(v @ hv) * float(w @ hw)), (tag, a, b)
+        return float(v @ hv), float(w @ hw)
+    qv, qw = check("theta_old")
+    assert qv > 0 and qw > 0                                        # Fisher matrix at theta_old: v.Hv = E[(J v)^2 / var] >= 0
+    moved = theta.copy()
+    moved[:na] += (0.02 * rng.standard_normal(na)).astype(np.float32)           # actor away from the theta of mean_old
+    eng.set_params(moved)
+    check("moved")
+    eng.close()
