@@ -81,7 +81,9 @@ def test_collector_runs_over_the_shmem_env():
         st = col.collect(n_episode=10, random=True)
         assert st["n/ep"] == 10 and st["len"] == 9.0 and st["truncated"] == 1.0
         import time
-        time.sleep(0.02)                                  # the workers park (nothing for 200 us) ...
+        t0 = time.time()                                  # the workers park (nothing for 200 us; a loaded host may
+        while int(env._v["parked"][:3, 0].sum()) < 3 and time.time() - t0 < 5.0:      # schedule them late) ...
+            time.sleep(0.005)
         assert int(env._v["parked"][:3, 0].sum()) == 3
         st = col.collect(n_episode=6, random=True)        # ... and are woken by the next command
         assert st["n/ep"] == 6 and st["len"] == 9.0
