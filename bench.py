@@ -73,6 +73,11 @@ def flops_fwdbwd_launch(rows):
     return per_row * rows
 
 
+def _usable_cpus():
+    from fsrl_amd.parallel import usable_cpus
+    return usable_cpus()
+
+
 def cpu_baseline(theta, inputs, seconds=12.0, threads=4):
     """The oracle (torch CPU fp32 port of the reference update) timed on the host cores,
     on a bounded sample: whole updates of the SAME workload until `seconds` elapsed.
@@ -99,7 +104,8 @@ def cpu_baseline(theta, inputs, seconds=12.0, threads=4):
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "updates/s", "cores": threads, "kind": "port",
             "sample": f"{n} full updates (312 grad steps each) of the same 20k-row workload, "
-                      f"torch CPU fp32, {threads} threads of {os.cpu_count()} host cpus"}
+                      f"torch CPU fp32, {threads} threads; host: {os.cpu_count()} cpus visible, "
+                      f"{_usable_cpus():g} usable (affinity / cgroup quota)"}
 
 
 def end_to_end(local_rank, seed, seconds=6.0, device_actor=False, workers=0, busy_us=0.0, envs=ENVS):
