@@ -51,7 +51,7 @@ def main():
         print(json.dumps({"agent": name, "hidden": a.hidden, "epochs": a.epochs, "cost_limit": 20,
                           "eval_before_reward_len_cost": [round(float(x), 2) for x in before],
                           "eval_after_reward_len_cost": [round(float(x), 2) for x in after],
-                          "curve_train_reward_cost_multiplier": curve, "wall_s": round(wall, 1),
+                          "curve_train_reward_cost_multiplier": curve, "wall_s": round(wall, 3),
                           "env_steps_per_s_incl_updates": round(steps / wall)}), flush=True)
         agent.policy.engine.close()
 
