@@ -575,6 +575,138 @@ struct FbWgradArgs {
     int dbg_skip;        // timing experiments: bit0 skip dW2 tiles, bit1 skip aux blocks, bit2 skip the db3 block
 };
 
+// one pass of an aux block of fb_wgrad_kernel over its rows: NCH 16-column chunks of dW1 (columns k0 ..), and with FIRST the
+// dW3 / db1 / db2 outputs of the block's 32 hidden columns.  Accumulation order per output = row order: the result does not
+// depend on NCH.
+template <int H, bool PAIR2, bool FIRST, int NCH>
+__device__ __forceinline__ void wgrad_aux_pass(const FbWgradArgs& wa, const FbWgradNet& wn, const NetOff& no, float* red,
+                                               float* __restrict__ gout, const int j0, const int k0, const int KS0,
+                                               const int KS, const int Do, const int out, const int tid) {
+    const int lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
+    {
+        {
+            constexpr bool first = FIRST;
+            f32x4 ax[NCH][2];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) ax[ch][0] = ax[ch][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 ad0 = {0, 0, 0, 0}, ad1 = {0, 0, 0, 0};
+            f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+            for (int sb = KS0 + wave; sb < KS; sb += 16 * 4) {
+                f32x2 y1[4], xa3[4], xb3[4], b1v[4], b2v[4];
+                float bx[4][NCH], bda[4], bdb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int s = sb + 16 * u;
+                    y1[u] = xa3[u] = xb3[u] = b1v[u] = b2v[u] = f32x2{0.f, 0.f};
+                    bda[u] = bdb[u] = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch) bx[u][ch] = 0.f;
+                    if (s < KS) {
+                        const size_t r = (size_t)(4 * s + q);
+                        y1[u] = *reinterpret_cast<const f32x2*>(wn.w1_y + r * H + j0 + 2 * c);
+#pragma unroll
+                        for (int ch = 0; ch < NCH; ++ch)
+                            if (k0 + 16 * ch + c < Do && r < (size_t)wa.N) bx[u][ch] = wa.obs[r * Do + k0 + 16 * ch + c];
+                        if (first) {
+                            xa3[u] = *reinterpret_cast<const f32x2*>(wn.w3_xa + r * H + j0 + 2 * c);
+                            bda[u] = wn.w3_ya[r * FSRL_DOW + c];
+                            if constexpr (PAIR2) {
+                                xb3[u] = *reinterpret_cast<const f32x2*>(wn.w3_xb + r * H + j0 + 2 * c);
+                                bdb[u] = wn.w3_yb[r * FSRL_DOW + c];
+                            }
+                            b1v[u] = *reinterpret_cast<const f32x2*>(wn.b1_src + r * H + j0 + 2 * c);
+                            b2v[u] = *reinterpret_cast<const f32x2*>(wn.b2_src + r * H + j0 + 2 * c);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch) {
+                        if (k0 + 16 * ch < Do) {           // block-uniform: chunks past Do cost nothing
+                            ax[ch][0] = mfma_16x16x4(y1[u][0], bx[u][ch], ax[ch][0]);
+                            ax[ch][1] = mfma_16x16x4(y1[u][1], bx[u][ch], ax[ch][1]);
+                        }
+                    }
+                    if (first) {
+                        ad0 = mfma_16x16x4(xa3[u][0], bda[u], ad0);
+                        ad1 = mfma_16x16x4(xa3[u][1], bda[u], ad1);
+                        if constexpr (PAIR2) {
+                            ad0 = mfma_16x16x4(xb3[u][0], bdb[u], ad0);
+                            ad1 = mfma_16x16x4(xb3[u][1], bdb[u], ad1);
+                        }
+                        s1 += b1v[u];
+                        s2 += b2v[u];
+                    }
+                }
+            }
+            if (first) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    s1[t] += __shfl_xor(s1[t], 16, 64); s1[t] += __shfl_xor(s1[t], 32, 64);
+                    s2[t] += __shfl_xor(s2[t], 16, 64); s2[t] += __shfl_xor(s2[t], 32, 64);
+                }
+            }
+            float* slot = red + (wave & 7) * 1088;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                if (k0 + 16 * ch >= Do) continue;             // block-uniform
+                const bool f0 = first && ch == 0;           // dW3 and the bias sums ride with the first chunk
+                const f32x4 ax0 = ax[ch][0], ax1 = ax[ch][1];
+                __syncthreads();
+#pragma unroll
+                for (int round = 0; round < 2; ++round) {
+                    if ((wave >> 3) == round) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int jl = 2 * (4 * q + r);
+                            if (round == 0) {
+                                slot[(jl + 0) * 16 + c] = ax0[r]; slot[(jl + 1) * 16 + c] = ax1[r];
+                                if (f0) { slot[512 + (jl + 0) * 16 + c] = ad0[r]; slot[512 + (jl + 1) * 16 + c] = ad1[r]; }
+                            } else {
+                                slot[(jl + 0) * 16 + c] += ax0[r]; slot[(jl + 1) * 16 + c] += ax1[r];
+                                if (f0) { slot[512 + (jl + 0) * 16 + c] += ad0[r]; slot[512 + (jl + 1) * 16 + c] += ad1[r]; }
+                            }
+                        }
+                        if (f0 && q == 0) {
+                            if (round == 0) {
+                                slot[1024 + 2 * c] = s1[0]; slot[1024 + 2 * c + 1] = s1[1];
+                                slot[1056 + 2 * c] = s2[0]; slot[1056 + 2 * c + 1] = s2[1];
+                            } else {
+                                slot[1024 + 2 * c] += s1[0]; slot[1024 + 2 * c + 1] += s1[1];
+                                slot[1056 + 2 * c] += s2[0]; slot[1056 + 2 * c + 1] += s2[1];
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+                const int e = tid & 511;
+                float v = 0.0f;
+                const int off = (tid < 512) ? e : 512 + e;
+                if (tid < 512 || f0) {
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) v += red[w * 1088 + off];
+                }
+                const int jl = e >> 4, kk = e & 15;
+                const int kc0 = k0 + 16 * ch;
+                if (tid < 512) {
+                    if (kc0 + kk < Do) gout[no.W1 + (size_t)(j0 + jl) * Do + kc0 + kk] = v;
+                } else if (f0 && kk < out) {
+                    gout[no.W3 + (size_t)kk * H + j0 + jl] = v;
+                }
+                if (f0 && tid < 64) {
+                    float bsum = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) bsum += red[w * 1088 + 1024 + tid];
+                    if (tid < 32) gout[no.b1 + j0 + tid] = bsum;
+                    else gout[no.b2 + j0 + tid - 32] = bsum;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // Weight-side products over a row range.  grid = (NT2 + NA + 1, ny, nsplit): blockIdx.z owns the rows
 // [4*z*ks_per_split, 4*(z+1)*ks_per_split) and writes a PARTIAL gradient; the consumer
 // (fb_sum_parts_kernel or adam_range_kernel's nparts) adds the partials in z order, so the result
@@ -663,106 +795,16 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
             gout[no.W2 + (size_t)(tj * 64 + jl) * H + tk * 64 + kl] = v;
         }
     } else if (rb < NT2 + NA) {
+        // dW1 is [H][Do]: the obs columns go through the MFMA 16 at a time, several 16-column chunks per pass over the rows (one
+        // read of the dz1 column block serves them all).  With a pass per chunk the aux block of a Do = 60 network walked its
+        // rows four times and took as long as a dW2 tile block while doing 1/16 of its FLOPs (probe build, CPO at N = 20 000:
+        // the 184 aux blocks alone 49 us, the 368 tile blocks alone 85 us, together 121 us on 256 CUs).  The first pass also
+        // carries dW3 and the bias sums (more operands in flight), so it takes two chunks (one in the R-op instantiation), the later ones four.
         const int j0 = (rb - NT2) * 32;
-        for (int k0 = 0; k0 < Do; k0 += 16) {
-            const bool first = (k0 == 0);
-            f32x4 ax0 = {0, 0, 0, 0}, ax1 = {0, 0, 0, 0}, ad0 = {0, 0, 0, 0}, ad1 = {0, 0, 0, 0};
-            f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
-            for (int sb = KS0 + wave; sb < KS; sb += 16 * 4) {
-                f32x2 y1[4], xa3[4], xb3[4], b1v[4], b2v[4];
-                float bx[4], bda[4], bdb[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int s = sb + 16 * u;
-                    y1[u] = xa3[u] = xb3[u] = b1v[u] = b2v[u] = f32x2{0.f, 0.f};
-                    bx[u] = bda[u] = bdb[u] = 0.f;
-                    if (s < KS) {
-                        const size_t r = (size_t)(4 * s + q);
-                        y1[u] = *reinterpret_cast<const f32x2*>(wn.w1_y + r * H + j0 + 2 * c);
-                        if (k0 + c < Do && r < (size_t)wa.N) bx[u] = wa.obs[r * Do + k0 + c];
-                        if (first) {
-                            xa3[u] = *reinterpret_cast<const f32x2*>(wn.w3_xa + r * H + j0 + 2 * c);
-                            bda[u] = wn.w3_ya[r * FSRL_DOW + c];
-                            if constexpr (PAIR2) {
-                                xb3[u] = *reinterpret_cast<const f32x2*>(wn.w3_xb + r * H + j0 + 2 * c);
-                                bdb[u] = wn.w3_yb[r * FSRL_DOW + c];
-                            }
-                            b1v[u] = *reinterpret_cast<const f32x2*>(wn.b1_src + r * H + j0 + 2 * c);
-                            b2v[u] = *reinterpret_cast<const f32x2*>(wn.b2_src + r * H + j0 + 2 * c);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    ax0 = mfma_16x16x4(y1[u][0], bx[u], ax0);
-                    ax1 = mfma_16x16x4(y1[u][1], bx[u], ax1);
-                    if (first) {
-                        ad0 = mfma_16x16x4(xa3[u][0], bda[u], ad0);
-                        ad1 = mfma_16x16x4(xa3[u][1], bda[u], ad1);
-                        if constexpr (PAIR2) {
-                            ad0 = mfma_16x16x4(xb3[u][0], bdb[u], ad0);
-                            ad1 = mfma_16x16x4(xb3[u][1], bdb[u], ad1);
-                        }
-                        s1 += b1v[u];
-                        s2 += b2v[u];
-                    }
-                }
-            }
-            if (first) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    s1[t] += __shfl_xor(s1[t], 16, 64); s1[t] += __shfl_xor(s1[t], 32, 64);
-                    s2[t] += __shfl_xor(s2[t], 16, 64); s2[t] += __shfl_xor(s2[t], 32, 64);
-                }
-            }
-            float* slot = red + (wave & 7) * 1088;
-            __syncthreads();
-#pragma unroll
-            for (int round = 0; round < 2; ++round) {
-                if ((wave >> 3) == round) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int jl = 2 * (4 * q + r);
-                        if (round == 0) {
-                            slot[(jl + 0) * 16 + c] = ax0[r]; slot[(jl + 1) * 16 + c] = ax1[r];
-                            slot[512 + (jl + 0) * 16 + c] = ad0[r]; slot[512 + (jl + 1) * 16 + c] = ad1[r];
-                        } else {
-                            slot[(jl + 0) * 16 + c] += ax0[r]; slot[(jl + 1) * 16 + c] += ax1[r];
-                            slot[512 + (jl + 0) * 16 + c] += ad0[r]; slot[512 + (jl + 1) * 16 + c] += ad1[r];
-                        }
-                    }
-                    if (q == 0) {
-                        if (round == 0) {
-                            slot[1024 + 2 * c] = s1[0]; slot[1024 + 2 * c + 1] = s1[1];
-                            slot[1056 + 2 * c] = s2[0]; slot[1056 + 2 * c + 1] = s2[1];
-                        } else {
-                            slot[1024 + 2 * c] += s1[0]; slot[1024 + 2 * c + 1] += s1[1];
-                            slot[1056 + 2 * c] += s2[0]; slot[1056 + 2 * c + 1] += s2[1];
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-            const int e = tid & 511;
-            float v = 0.0f;
-            const int off = (tid < 512) ? e : 512 + e;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) v += red[w * 1088 + off];
-            const int jl = e >> 4, kk = e & 15;
-            if (tid < 512) {
-                if (k0 + kk < Do) gout[no.W1 + (size_t)(j0 + jl) * Do + k0 + kk] = v;
-            } else if (first && kk < out) {
-                gout[no.W3 + (size_t)kk * H + j0 + jl] = v;
-            }
-            if (first && tid < 64) {
-                float bsum = 0.0f;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) bsum += red[w * 1088 + 1024 + tid];
-                if (tid < 32) gout[no.b1 + j0 + tid] = bsum;
-                else gout[no.b2 + j0 + tid - 32] = bsum;
-            }
-            __syncthreads();
-        }
+        constexpr int NCH0 = PAIR2 ? 1 : 2;          // the R-op instantiation has two more operands in flight in its first pass
+        wgrad_aux_pass<H, PAIR2, true, NCH0>(wa, wn, no, red, gout, j0, 0, KS0, KS, Do, out, tid);
+        for (int k0 = 16 * NCH0; k0 < Do; k0 += 64)
+            wgrad_aux_pass<H, PAIR2, false, 4>(wa, wn, no, red, gout, j0, k0, KS0, KS, Do, out, tid);
     } else {
         // db3[o] / dsigma[d]: column sums of the dout-like buffer over all rows
         const int col = tid & 31, php = tid >> 5;

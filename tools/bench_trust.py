@@ -157,6 +157,10 @@ def run_focops(obs_dim=8, act_dim=2, hid=256, envs=20, T=1000, ep=250, batch=256
 
 
 if __name__ == "__main__":
-    run("cpo", 60, 2, 256)
-    run("trpo", 8, 2, 256, ep=250)
-    run_focops()
+    only = os.environ.get("FSRL_ONLY", "")          # FSRL_ONLY=cpo|trpo|focops: one of the three (per-algorithm kernel traces)
+    if only in ("", "cpo"):
+        run("cpo", 60, 2, 256)
+    if only in ("", "trpo"):
+        run("trpo", 8, 2, 256, ep=250)
+    if only in ("", "focops"):
+        run_focops()

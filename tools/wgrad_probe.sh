@@ -4,7 +4,7 @@
 R=$PWD; cd /tmp; export TMPDIR=/tmp
 export FSRL_HIP_LIB=$R/fsrl_amd/libfsrl_hip_probe.so
 for sk in 0 1 2 4 3 7; do
-  rm -rf /tmp/pw; FSRL_NO_CPU=1 FSRL_WGRAD_SKIP=$sk rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pw -o p -- python $R/tools/bench_trust.py > /dev/null 2>&1
+  rm -rf /tmp/pw; FSRL_ONLY=${FSRL_ONLY:-} FSRL_NO_CPU=1 FSRL_WGRAD_SKIP=$sk rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pw -o p -- python $R/tools/bench_trust.py > /dev/null 2>&1
   python - "$sk" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open('/tmp/pw/p_kernel_stats.csv')))
