@@ -195,9 +195,13 @@ static int ensure_scratch(fsrl_ctx* c, size_t bytes) {
 // ---- split-K launch of fb_wgrad_kernel.  Rows are cut into <= 24 splits of >= 256 rows; every split
 //      writes a partial gradient at parts + z * stride, summed later in z order.
 struct WgradPlan { int nsplit, ks_per_split; };
-static WgradPlan wgrad_plan(int rows) {
+static WgradPlan wgrad_plan(int rows, int blocks_per_split, int n_cus) {
     const int KS = rows >> 2;
     int n = std::max(1, std::min((rows + 255) / 256, 24));
+    // One 1024-thread workgroup per CU: more than n_cus blocks means several rounds, and a last round that is mostly empty
+    // costs as much as a full one (CPO's HVP weight products at N = 20 000: 25 x 23 = 575 blocks = 3 rounds of 40 us where
+    // 250 blocks of 2.3x the rows take one round of 83 us).  Past one round, split so that the grid is exactly one round.
+    if (blocks_per_split * n > n_cus) n = std::max(1, n_cus / std::max(blocks_per_split, 1));
     const int per = round_up((KS + n - 1) / n, 16);
     n = (KS + per - 1) / per;
     return WgradPlan{std::max(n, 1), per};
@@ -221,7 +225,8 @@ static int ensure_parts(fsrl_ctx* c, int stride, int nsplit) {
 }
 template <bool PAIR2>
 static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int ny, int stride, int* nsplit) {
-    const WgradPlan pl = wgrad_plan(wa.rows);
+    const int H_ = c->cfg.hidden;
+    const WgradPlan pl = wgrad_plan(wa.rows, ((H_ / 64) * (H_ / 64) + H_ / 32 + 1) * ny, c->n_cus);
     int rc = ensure_parts(c, stride, pl.nsplit);
     if (rc) return rc;
     wa.out = c->wg_parts; wa.ks_per_split = pl.ks_per_split; wa.split_stride = stride;
