@@ -1248,14 +1248,18 @@ __global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ P, 
     }
 }
 
-__global__ __launch_bounds__(256) void sumsq_range_kernel(const float* __restrict__ P, int begin, int end,
+// sum of squares of P[begin, end): blockIdx.x strides over the range, out[blockIdx.y * gridDim.x + blockIdx.x] = this block's
+// partial (float64); the caller adds the gridDim.x partials in index order.  grid.y selects one of `ranges` (begin, end) pairs.
+struct SumsqRanges { int begin[FSRL_MAX_NETS], end[FSRL_MAX_NETS]; };
+__global__ __launch_bounds__(256) void sumsq_range_kernel(const float* __restrict__ P, const SumsqRanges rg,
                                                          double* __restrict__ out) {
     __shared__ double sh[4];
     const int tid = threadIdx.x;
+    const int begin = rg.begin[blockIdx.y], end = rg.end[blockIdx.y];
     double s = 0.0;
-    for (int i = begin + tid; i < end; i += 256) s += (double)P[i] * (double)P[i];
+    for (int i = begin + blockIdx.x * 256 + tid; i < end; i += 256 * gridDim.x) s += (double)P[i] * (double)P[i];
     s = wave_sum_d(s);
     if ((tid & 63) == 0) sh[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) out[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (tid == 0) out[blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
