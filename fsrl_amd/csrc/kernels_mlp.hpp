@@ -1045,6 +1045,13 @@ __device__ __forceinline__ void ppo_wgrad_body(const ModelDesc& md, const WgradP
     }
 }
 
+// The logged row of one step on its own: used when the weight gradients of a LARGE minibatch (more than 512 rows) go through
+// fb_wgrad_kernel (split-K over workgroups) instead of ppo_wgrad_kernel, whose extra block writes the row otherwise.
+__global__ __launch_bounds__(64) void ppo_stats_kernel(const ModelDesc md, const WgradPtrs wp, const PpoStepArgs sa,
+                                                      const int n_stat_tiles) {
+    ppo_stats_finalize(md, wp, sa, n_stat_tiles, (int)threadIdx.x);
+}
+
 template <int H, bool BIG, bool FUSE>
 __global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, const WgradPtrs wp,
                                                         const int mbp, const PpoStepArgs sa,

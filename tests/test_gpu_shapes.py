@@ -32,6 +32,8 @@ SHAPES = [  # obs, act, hidden, rows per env, episode length, batch, repeat
     (17, 1, 256, [300, 300], 75, 256, 2),              # merged last minibatch (344 rows) -> 16-row kernel
     (3, 2, 64, [90, 1, 35], 30, 1000, 3),              # batch > N: one minibatch; a single-row sub-buffer
     (60, 2, 256, [520], 520, 512, 1),                  # one env, unfinished episode only, two 16-row steps
+    (8, 2, 256, [700, 600], 100, 1024, 2),             # one merged minibatch of 1 300 rows: the split-K weight-gradient path
+    (12, 3, 128, [900, 900, 500], 150, 1024, 2),       # 1 024 + 1 276 rows per pass at 128 wide
 ]
 
 
@@ -274,3 +276,34 @@ def test_one_shot_ppo_update_entry_point_matches_the_stepwise_calls():
         eng.close()
     assert outs[0][0].shape == outs[1][0].shape and np.array_equal(outs[0][0], outs[1][0])
     assert outs[0][1] == outs[1][1] and np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_large_minibatch_without_grad_clip_vs_oracle():
+    """max_grad_norm off + a minibatch above 512 rows: the fused-Adam instantiation does not apply (the weight gradients of a
+    large minibatch come from the split-K kernel), Adam runs as its own launch with a clip coefficient of 1."""
+    from fsrl_amd.engine import Engine, EngineConfig
+    from oracle.ppo_lag import OnPolicyData, PPOLagConfig, PPOLagOracle
+    Do, Da, H, rows, ep, B, repeat = 8, 2, 256, [640, 640], 80, 640, 2
+    rng = np.random.default_rng(77)
+    cols = _synthetic(rng, rows, Do, Da, ep)
+    eng = Engine(EngineConfig(obs_dim=Do, act_dim=Da, hidden=H, env_num=2, buffer_size=4096, max_grad_norm=None, target_kl=None))
+    o = PPOLagOracle(PPOLagConfig(obs_dim=Do, act_dim=Da, hidden=(H, H), max_grad_norm=None, target_kl=1e9))
+    torch.manual_seed(5)
+    theta = (0.15 * torch.randn(o.n_params)).numpy()
+    o.set_params(theta); eng.set_params(theta)
+    for t in range(max(rows)):
+        ids = [e for e in range(2) if t < rows[e]]
+        eng.push(ids, *[np.stack([cols[k][e][t] for e in ids]) for k in ("obs", "act", "rew", "cost", "term", "trunc", "obs_next")])
+    cat = {k: np.concatenate(v) for k, v in cols.items()}
+    end = (cat["term"] | cat["trunc"]).copy(); end[np.cumsum(rows) - 1] = True
+    data = OnPolicyData(obs=cat["obs"], act=cat["act"], rew=cat["rew"], cost=cat["cost"], terminated=cat["term"],
+                        truncated=cat["trunc"], obs_next=cat["obs_next"], end_flag=end)
+    perms = [rng.permutation(len(data)) for _ in range(repeat)]
+    lag = np.array([0.4])
+    _, ostats, _ = o.update(data, lag, 1 / 1.4, B, repeat, perms=perms)
+    stats, stopped = eng.ppo_update(lag, 1 / 1.4, B, repeat, perms=perms)
+    assert stopped == -1 and stats.shape == np.asarray(ostats).shape == (4, 11)
+    np.testing.assert_allclose(stats, np.asarray(ostats), rtol=3e-5, atol=3e-5)
+    d = np.abs(eng.get_params() - o.get_params())
+    assert np.quantile(d, 0.999) <= 5e-6 and d.max() <= 1e-4, (np.quantile(d, 0.999), d.max())
+    eng.close()
