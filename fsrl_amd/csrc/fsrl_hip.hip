@@ -84,6 +84,7 @@ struct fsrl_ctx {
 
     // store
     int64_t sub_size = 0, maxsize = 0;
+    float* mbstat = nullptr; size_t mbstat_cap = 0;      // per-minibatch advantage statistics of the current pass
     double* d_rms = nullptr;           // reward_normalization: [n_critics][3] running (mean, var, count) of the returns
     double* ret64 = nullptr; int64_t ret64_cap = 0;   // float64 normalised returns of the current batch (rms update input)
     int64_t alloc_rows = 0;            // rows every store / batch array was allocated for (fsrl_store_configure stays inside)
@@ -304,6 +305,7 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
     foc_free(c);
     if (c->h_actor) (void)hipHostFree(c->h_actor);
     if (c->h_done) (void)hipHostFree(c->h_done);
+    if (c->mbstat) (void)hipFree(c->mbstat);
     if (c->d_rms) (void)hipFree(c->d_rms);
     if (c->ret64) (void)hipFree(c->ret64);
     if (c->mu_old) (void)hipFree(c->mu_old);

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(1024) void ret_rms_update_kernel(const double* __re
 }
 
 // ---------------------------------------------------------------- per-pass batch preparation
-// One block per minibatch of the pass: (1) mean and unbiased std of each critic's advantages
+// Two launches per pass: (1) mean and unbiased std of each critic's advantages
 // over the minibatch rows (the reference normalises the minibatch copy every pass,
 // ppo_lag.py:178-182; float64 accumulate), (2) the minibatch's rows permuted into pass order:
 // obs_p[pos] and the per-row loss inputs rd_p[pos] = act | logp_old | adv_n[c] | ret[c].
@@ -183,14 +183,14 @@ struct PrepArgs {
     const float* values;     // optional [C][N]: value_clip's batch.values -> rd_p[FSRL_RD_VOLD + c]
     const float* mean_old;   // optional [N][Da] + sigma_old[Da] (log std at process time): FOCOPS needs the old distribution
     const float* sigma_old;
+    float* mbstat;           // [n_minibatches][FSRL_MAX_CRITICS][2]: mean, std of the minibatch's advantages per critic
+    int batch, nmb;          // minibatch k covers pass positions [k * batch, (k + 1) * batch), the last one to the end
 };
 
-__global__ __launch_bounds__(1024) void ppo_prepare_pass_kernel(const PrepArgs a) {
+// (1) one block per minibatch: mean and unbiased std of each critic's advantages over the minibatch rows -> mbstat[mb][c][2]
+__global__ __launch_bounds__(1024) void ppo_adv_stats_kernel(const PrepArgs a) {
     constexpr int NT = 1024, NW = NT / 64;
     __shared__ double sh[NW];
-    __shared__ double mean_s;
-    __shared__ float mean_f[FSRL_MAX_CRITICS], sd_f[FSRL_MAX_CRITICS];
-    __shared__ int perm_s[1024];            // this minibatch's row indices (n <= 2*batch-1; chunks of 1024)
     const int mb = blockIdx.x, tid = threadIdx.x;
     const int st = a.mb_start[mb], n = a.mb_size[mb];
     auto block_sum = [&](double v) -> double {      // fixed order: waves 0..15
@@ -203,52 +203,65 @@ __global__ __launch_bounds__(1024) void ppo_prepare_pass_kernel(const PrepArgs a
         for (int w = 0; w < NW; ++w) t += sh[w];
         return t;
     };
-    if (a.norm_adv) {
-        for (int c = 0; c < a.C; ++c) {
-            const float* __restrict__ adv = a.advs + (size_t)c * a.N;
-            double s = 0.0;
-            for (int m = tid; m < n; m += NT) s += (double)adv[a.perm[st + m]];
-            const double mean = block_sum(s) / (double)n;
-            double q = 0.0;
-            for (int m = tid; m < n; m += NT) {
-                const double d = (double)adv[a.perm[st + m]] - mean;
-                q += d * d;
-            }
-            const double var = block_sum(q) / (double)(n - 1);
-            if (tid == 0) { mean_f[c] = (float)mean; sd_f[c] = (float)sqrt(var); }
+    for (int c = 0; c < a.C; ++c) {
+        const float* __restrict__ adv = a.advs + (size_t)c * a.N;
+        double s = 0.0;
+        for (int m = tid; m < n; m += NT) s += (double)adv[a.perm[st + m]];
+        const double mean = block_sum(s) / (double)n;
+        double q = 0.0;
+        for (int m = tid; m < n; m += NT) {
+            const double d = (double)adv[a.perm[st + m]] - mean;
+            q += d * d;
         }
-        __syncthreads();
+        const double var = block_sum(q) / (double)(n - 1);
+        if (tid == 0) {
+            a.mbstat[((size_t)mb * FSRL_MAX_CRITICS + c) * 2 + 0] = (float)mean;
+            a.mbstat[((size_t)mb * FSRL_MAX_CRITICS + c) * 2 + 1] = (float)sqrt(var);
+        }
     }
-    for (int m0 = 0; m0 < n; m0 += 1024) {       // rows in chunks whose indices sit in LDS
-        const int nc = min(1024, n - m0);
-        __syncthreads();
-        if (tid < nc) perm_s[tid] = a.perm[st + m0 + tid];
-        __syncthreads();
-        for (int e = tid; e < nc * FSRL_RD; e += NT) {
-            const int m = e / FSRL_RD, f = e - m * FSRL_RD;
-            const int r = perm_s[m];
-            float v = 0.0f;
-            if (f < a.Da) v = a.act[(size_t)r * a.Da + f];
-            else if (f == FSRL_RD_LOGP) v = a.logp_old[r];
-            else if (f >= FSRL_RD_ADV && f < FSRL_RD_ADV + a.C) {
-                const int c = f - FSRL_RD_ADV;
-                v = a.advs[(size_t)c * a.N + r];
-                if (a.norm_adv) v = (v - mean_f[c]) / sd_f[c];
-            } else if (f >= FSRL_RD_RET && f < FSRL_RD_RET + a.C) {
-                v = a.rets[(size_t)(f - FSRL_RD_RET) * a.N + r];
-            } else if (a.values && f >= FSRL_RD_VOLD && f < FSRL_RD_VOLD + a.C) {
-                v = a.values[(size_t)(f - FSRL_RD_VOLD) * a.N + r];
-            } else if (a.mean_old && f >= FSRL_RD_MEAN && f < FSRL_RD_MEAN + a.Da) {
-                v = a.mean_old[(size_t)r * a.Da + f - FSRL_RD_MEAN];
-            } else if (a.mean_old && f >= FSRL_RD_STD && f < FSRL_RD_STD + a.Da) {
-                v = expf(a.sigma_old[f - FSRL_RD_STD]);
-            }
-            a.rd_p[(size_t)(st + m0 + m) * FSRL_RD + f] = v;
+}
+
+// (2) 64 pass positions per block: the rows permuted into pass order, advantages normalised with their minibatch's statistics.
+// One block per minibatch did both steps and took 28 us at batch 256 (78 blocks) and 106 us at batch 1 024 (19 blocks of a
+// 256-CU chip, each walking 1 024+ rows); as two launches the row work spreads over N / 64 blocks.
+__global__ __launch_bounds__(256) void ppo_permute_rows_kernel(const PrepArgs a) {
+    __shared__ int perm_s[64];
+    __shared__ float mean_f[64][FSRL_MAX_CRITICS], sd_f[64][FSRL_MAX_CRITICS];      // per row: its minibatch's statistics
+    const int tid = threadIdx.x;
+    const int p0 = blockIdx.x * 64, nc = min(64, a.N - p0);
+    if (tid < nc) {
+        perm_s[tid] = a.perm[p0 + tid];
+        const int mb = min((p0 + tid) / a.batch, a.nmb - 1);          // minibatches are [k * batch, ...), the last one merged
+        for (int c = 0; c < a.C; ++c) {
+            mean_f[tid][c] = a.norm_adv ? a.mbstat[((size_t)mb * FSRL_MAX_CRITICS + c) * 2 + 0] : 0.0f;
+            sd_f[tid][c] = a.norm_adv ? a.mbstat[((size_t)mb * FSRL_MAX_CRITICS + c) * 2 + 1] : 1.0f;
         }
-        for (int e = tid; e < nc * a.Do; e += NT) {
-            const int m = e / a.Do, k = e - m * a.Do;
-            a.obs_p[(size_t)(st + m0 + m) * a.Do + k] = a.obs[(size_t)perm_s[m] * a.Do + k];
+    }
+    __syncthreads();
+    for (int e = tid; e < nc * FSRL_RD; e += 256) {
+        const int m = e / FSRL_RD, f = e - m * FSRL_RD;
+        const int r = perm_s[m];
+        float v = 0.0f;
+        if (f < a.Da) v = a.act[(size_t)r * a.Da + f];
+        else if (f == FSRL_RD_LOGP) v = a.logp_old[r];
+        else if (f >= FSRL_RD_ADV && f < FSRL_RD_ADV + a.C) {
+            const int c = f - FSRL_RD_ADV;
+            v = a.advs[(size_t)c * a.N + r];
+            if (a.norm_adv) v = (v - mean_f[m][c]) / sd_f[m][c];
+        } else if (f >= FSRL_RD_RET && f < FSRL_RD_RET + a.C) {
+            v = a.rets[(size_t)(f - FSRL_RD_RET) * a.N + r];
+        } else if (a.values && f >= FSRL_RD_VOLD && f < FSRL_RD_VOLD + a.C) {
+            v = a.values[(size_t)(f - FSRL_RD_VOLD) * a.N + r];
+        } else if (a.mean_old && f >= FSRL_RD_MEAN && f < FSRL_RD_MEAN + a.Da) {
+            v = a.mean_old[(size_t)r * a.Da + f - FSRL_RD_MEAN];
+        } else if (a.mean_old && f >= FSRL_RD_STD && f < FSRL_RD_STD + a.Da) {
+            v = expf(a.sigma_old[f - FSRL_RD_STD]);
         }
+        a.rd_p[(size_t)(p0 + m) * FSRL_RD + f] = v;
+    }
+    for (int e = tid; e < nc * a.Do; e += 256) {
+        const int m = e / a.Do, k = e - m * a.Do;
+        a.obs_p[(size_t)(p0 + m) * a.Do + k] = a.obs[(size_t)perm_s[m] * a.Do + k];
     }
 }
 

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(4 * H) void mlp_infer_kernel(const float* __restric
 // Implements, for its 16 rows: PPOLagrangian.policy_loss / critics_loss gradients
 // (fsrl/policy/ppo_lag.py:152-212, lagrangian_base.py:145-166) analytically.
 struct PpoBatchPtrs {
-    // the pass's batch, already permuted into minibatch order by ppo_prepare_pass_kernel
+    // the pass's batch, already permuted into minibatch order by ppo_permute_rows_kernel
     const float* obs_p;      // [N + pad][Do]
     const float* rd_p;       // [N + pad][FSRL_RD]  act | logp_old | adv_n[c] | ret[c]
     // per-net activation side buffers, row = position inside the minibatch
