@@ -156,7 +156,7 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
     //      W1 fetched in ONE burst of <= 16 independent loads per 64 inputs -- a k-loop of dependent
     //      global loads cost one L2 round trip per input (measured: 20 us of a 27 us kernel).
     if (Do <= FSRL_W1_LDS) {
-        if (R == 16 || tid < H) {
+        if (tid < (R / 4) * H) {            // thread = (column j, group of 4 rows): R / 4 row groups
             const int j = tid % H, rg = tid / H;
             const float b = sm.b1[j];
             float acc[4] = {b, b, b, b};
@@ -171,9 +171,9 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
             for (int e = 0; e < 4; ++e) sm.h1[(4 * rg + e) * LD + j] = fmaxf(acc[e], 0.0f);
         }
     } else {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc8 = {0.f, 0.f, 0.f, 0.f};     // acc8: rows 4..7 of an 8-row tile
         const float* __restrict__ wrow = P + no.W1 + (size_t)(wave * 16 + li) * Do;
-        const int arow = (R == 4) ? (lane & 3) : li;
+        const int arow = (R == 16) ? li : (lane & 3);
         for (int k0 = 0; k0 < Do; k0 += 64) {
             float b[16];
 #pragma unroll
@@ -186,22 +186,27 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
                 const int k = k0 + 4 * s + q;
                 if (k0 + 4 * s < Do) {
                     const float a = (k < Do) ? sm.xT[k * 16 + arow] : 0.0f;
-                    if constexpr (R == 4) acc = mfma_4x4x1(a, b[s], acc);
-                    else acc = mfma_16x16x4(a, b[s], acc);
+                    if constexpr (R == 16) acc = mfma_16x16x4(a, b[s], acc);
+                    else acc = mfma_4x4x1(a, b[s], acc);
+                    if constexpr (R == 8) acc8 = mfma_4x4x1((k < Do) ? sm.xT[k * 16 + 4 + arow] : 0.0f, b[s], acc8);
                 }
             }
         }
         const int j = wave * 16 + li;
         const float bias = sm.b1[j];
-        if constexpr (R == 4) {
+        if constexpr (R != 16) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 acc[r] += __shfl_xor(acc[r], 16, 64);
                 acc[r] += __shfl_xor(acc[r], 32, 64);
+                if constexpr (R == 8) { acc8[r] += __shfl_xor(acc8[r], 16, 64); acc8[r] += __shfl_xor(acc8[r], 32, 64); }
             }
             if (q == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sm.h1[r * LD + j] = fmaxf(acc[r] + bias, 0.0f);
+                for (int r = 0; r < 4; ++r) {
+                    sm.h1[r * LD + j] = fmaxf(acc[r] + bias, 0.0f);
+                    if constexpr (R == 8) sm.h1[(4 + r) * LD + j] = fmaxf(acc8[r] + bias, 0.0f);
+                }
             }
         } else {
 #pragma unroll
@@ -212,26 +217,35 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
     FSRL_TS(ts, 3);
 
     // ---- layer 2: h2[R,H] = relu(h1[R,H] @ W2^T + b2) on MFMA (fp32)
-    if constexpr (R == 4) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (R != 16) {          // 4 rows per v_mfma_f32_4x4x1 pass; an 8-row tile runs two passes on the same fragments
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc8 = {0.f, 0.f, 0.f, 0.f};
         const float* arow = &sm.h1[(lane & 3) * LD + 4 * q];
 #pragma unroll
         for (int kc = 0; kc < H / 16; ++kc) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * kc);
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = mfma_4x4x1(a[s], wf.b[kc][s], acc);
+            if constexpr (R == 8) {
+                const f32x4 a8 = *reinterpret_cast<const f32x4*>(arow + 4 * LD + 16 * kc);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc8 = mfma_4x4x1(a8[s], wf.b[kc][s], acc8);
+            }
         }
         FSRL_TS(ts, 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {            // add the four k-classes: (q0 + q1) + (q2 + q3)
             acc[r] += __shfl_xor(acc[r], 16, 64);
             acc[r] += __shfl_xor(acc[r], 32, 64);
+            if constexpr (R == 8) { acc8[r] += __shfl_xor(acc8[r], 16, 64); acc8[r] += __shfl_xor(acc8[r], 32, 64); }
         }
         if (q == 0) {
             const int j = wave * 16 + li;
             const float bias = sm.b2[j];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sm.h2[r * LD + j] = fmaxf(acc[r] + bias, 0.0f);
+            for (int r = 0; r < 4; ++r) {
+                sm.h2[r * LD + j] = fmaxf(acc[r] + bias, 0.0f);
+                if constexpr (R == 8) sm.h2[(4 + r) * LD + j] = fmaxf(acc8[r] + bias, 0.0f);
+            }
         }
     } else {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -581,7 +595,7 @@ __device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* _
 
     if (FSRL_PROBE(sa, 6)) { if (wb[0][0] == 123.f) bp.statp[1] = 1.f; return; }
     // ---- dL/dz2 = (dout @ W3) * relu'(z2); thread = (column k, group of 4 rows)
-    if (R == 16 || tid < H) {
+    if (tid < (R / 4) * H) {
         const int k = tid % H, rg = tid / H;
         float g[4] = {0.f, 0.f, 0.f, 0.f};
         for (int o = 0; o < no.out; ++o) {
@@ -611,19 +625,25 @@ __device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* _
     }
     FSRL_TS(bp.ts, 11);
     // ---- dL/dz1 = (dz2 @ W2) * relu'(z1) on MFMA; result goes straight to L2/HBM
-    if constexpr (R == 4) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (R != 16) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc8 = {0.f, 0.f, 0.f, 0.f};
         const float* arow = &sm.d2[(lane & 3) * LD + 4 * q];
 #pragma unroll
         for (int jc = 0; jc < H / 16; ++jc) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * jc);
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = mfma_4x4x1(a[s], wb[jc][s], acc);
+            if constexpr (R == 8) {
+                const f32x4 a8 = *reinterpret_cast<const f32x4*>(arow + 4 * LD + 16 * jc);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc8 = mfma_4x4x1(a8[s], wb[jc][s], acc8);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             acc[r] += __shfl_xor(acc[r], 16, 64);
             acc[r] += __shfl_xor(acc[r], 32, 64);
+            if constexpr (R == 8) { acc8[r] += __shfl_xor(acc8[r], 16, 64); acc8[r] += __shfl_xor(acc8[r], 32, 64); }
         }
         FSRL_TS(bp.ts, 12);
         if (FSRL_PROBE(sa, 7)) { if (acc[0] == 123.f) bp.statp[1] = 1.f; return; }
@@ -631,7 +651,10 @@ __device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* _
             float* __restrict__ D1 = bp.D1 + (nb + row0) * H;
             const int col = wave * 16 + li;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) D1[(size_t)r * H + col] = (sm.h1[r * LD + col] > 0.0f) ? acc[r] : 0.0f;
+            for (int r = 0; r < 4; ++r) {
+                D1[(size_t)r * H + col] = (sm.h1[r * LD + col] > 0.0f) ? acc[r] : 0.0f;
+                if constexpr (R == 8) D1[(size_t)(4 + r) * H + col] = (sm.h1[(4 + r) * LD + col] > 0.0f) ? acc8[r] : 0.0f;
+            }
         }
     } else {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1112,7 +1135,7 @@ __global__ __launch_bounds__(1024) void ppo_wgrad_group_kernel(const ModelDesc m
     WgradPtrs wp = a.wp;
     wp.X = a.bp.obs_p + (size_t)st.mb_start * md.Do;
     const int tiles = (st.mb_size + 15) >> 4;
-    ppo_wgrad_body<H, BIG, FUSE>(md, wp, tiles * 16, sa, R == 4 ? tiles * 4 : tiles);
+    ppo_wgrad_body<H, BIG, FUSE>(md, wp, tiles * 16, sa, tiles * (16 / R));
 }
 
 __global__ __launch_bounds__(ADAM_NT) void adam_clip_group_kernel(const ModelDesc md, const GroupAgent* __restrict__ tab,
