@@ -56,3 +56,41 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_ctypes_structs_have_the_layout_the_c_compiler_gives_the_header(tmp_path):
+    """Every configuration struct of include/fsrl_hip.h against its ctypes mirror in fsrl_amd/_lib.py: size and the offset of
+    every field, as gcc lays the header out (a field added on one side only shifts everything behind it silently)."""
+    import ctypes as C
+    import re
+    import subprocess
+    from fsrl_amd import _lib
+    pairs = {"fsrl_config": _lib.Config, "fsrl_tr_config": _lib.TrConfig, "fsrl_sac_config": _lib.SacConfig,
+             "fsrl_focops_config": _lib.FocopsConfig, "fsrl_cvpo_config": _lib.CvpoConfig}
+    lines = ["#include <stddef.h>", "#include <stdio.h>", '#include "fsrl_hip.h"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(root, "include"), str(src), "-o", exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr            # a ctypes field the header does not have fails to compile here
+    got = {}
+    for l in subprocess.run([exe], capture_output=True, text=True).stdout.splitlines():
+        cname, fname, val = l.split()
+        got[(cname, fname)] = int(val)
+    for cname, cls in pairs.items():
+        assert got[(cname, "size")] == C.sizeof(cls), (cname, got[(cname, "size")], C.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+    # and the other direction: every field the header declares is mirrored (count of `;`-terminated members per struct)
+    hdr = open(os.path.join(root, "include", "fsrl_hip.h")).read()
+    for cname, cls in pairs.items():
+        body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname + ";", hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        n_members = sum(len(decl.split(",")) for decl in body.split(";") if decl.strip())
+        assert n_members == len(cls._fields_), (cname, n_members, len(cls._fields_))
