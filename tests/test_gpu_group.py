@@ -18,13 +18,16 @@ def _members(cfg, g, k, **over):
         eng = _engine(cfg, **over)
         th = g["theta0"] + (0.01 * np.random.default_rng(100 + i).standard_normal(g["theta0"].size)).astype(np.float32) * (i > 0)
         eng.set_params(th)
+        if eng.cfg.rew_norm:
+            eng.ret_rms_set(g["ret_rms0"])
         _push_golden(eng, g)
         engs.append(eng); thetas.append(th); lags.append(g["lagrangian"] * (1.0 + 0.5 * i))
     return engs, thetas, lags
 
 
 @pytest.mark.parametrize("name,k,over", [("c1", 3, {}), ("c2", 2, {}), ("tiny", 4, {}), ("earlystop", 3, {}),
-                                         ("c1", 3, {"max_grad_norm": None})])
+                                         ("c1", 3, {"max_grad_norm": None}),
+                                         ("rewnorm_recompute", 2, {}), ("unbounded", 2, {})])      # the on-policy options, grouped
 def test_grouped_update_equals_member_by_member(name, k, over):
     from fsrl_amd.engine import EngineGroup
     cfg, g = ppo_case(name)
