@@ -265,15 +265,14 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
     FSRL_TS(ts, 5);
 
     // ---- head (out <= 16): one wave per row, 64-lane shuffle reduce
-    for (int i = wave; i < R; i += WAVES) {
-        for (int o = 0; o < no.out; ++o) {
-            const float* w3 = &sm.w3[o * H];
-            float s = 0.0f;
+    for (int idx = wave; idx < R * no.out; idx += WAVES) {      // one wave per (row, output): a 4-row actor tile keeps 8 waves busy
+        const int i = idx / no.out, o = idx - i * no.out;
+        const float* w3 = &sm.w3[o * H];
+        float s = 0.0f;
 #pragma unroll
-            for (int k = lane; k < H; k += 64) s = fmaf(sm.h2[i * LD + k], w3[k], s);
-            s = wave_sum(s);
-            if (lane == 0) sm.out[i * FSRL_MAX_ACT + o] = s + sm.b3[o];
-        }
+        for (int k = lane; k < H; k += 64) s = fmaf(sm.h2[i * LD + k], w3[k], s);
+        s = wave_sum(s);
+        if (lane == 0) sm.out[i * FSRL_MAX_ACT + o] = s + sm.b3[o];
     }
     __syncthreads();
 }
