@@ -67,6 +67,16 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
 __global__ __launch_bounds__(256) void sac_sample_kernel(const SacSampleArgs a) {
     // SAC / DDPG: one thread per sampled row.  CVPO (eps_k != NULL): B * K threads, thread (b, kp) also draws particle
     // kp's noise for row b; the row work is done by the kp == 0 threads.
+    // the sub-buffers' bookkeeping goes to LDS first: the row's sub-buffer is found by a linear scan over it and the n-step chain
+    // looks it up again per step -- from global memory every probe was a dependent round trip (7 us for this kernel)
+    constexpr int BOOK_LDS = 512;
+    __shared__ SacBook book_s[BOOK_LDS];
+    const bool in_lds = a.env_num <= BOOK_LDS;
+    if (in_lds) {
+        for (int e = threadIdx.x; e < a.env_num; e += blockDim.x) book_s[e] = a.book[e];
+        __syncthreads();
+    }
+    const SacBook* __restrict__ book = in_lds ? book_s : a.book;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = a.eps_k ? t % a.B : t, kp = a.eps_k ? t / a.B : 0;
     if (b >= a.B || kp >= max(a.K, 1)) return;
@@ -87,12 +97,12 @@ __global__ __launch_bounds__(256) void sac_sample_kernel(const SacSampleArgs a) 
     philox4x32_10(c, k0, k1);
     unsigned long long k = ((unsigned long long)c[0] * a.stored) >> 32;    // uniform over the stored rows
     int e = 0;
-    while (e < a.env_num - 1 && k >= (unsigned long long)a.book[e].size) { k -= a.book[e].size; ++e; }
+    while (e < a.env_num - 1 && k >= (unsigned long long)book[e].size) { k -= book[e].size; ++e; }
     int cur = e * a.sub_size + (int)k;
     a.idx[b] = cur;
     for (int n = 0; n < a.n_step; ++n) {
         const int env = cur / a.sub_size, local = cur - env * a.sub_size;
-        const SacBook bk = a.book[env];
+        const SacBook bk = book[env];
         if (n > 0) {                                   // indices[n] = buffer.next(indices[n-1])
             const bool end = a.flags[cur] != 0 || local == bk.last_index;
             if (!end && bk.size > 0) cur = env * a.sub_size + (local + 1) % bk.size;
