@@ -27,6 +27,9 @@ sys.path.insert(0, ROOT)
 
 OBS, ACT, HID, NROWS, ENVS, EPLEN, BATCH, REPEAT = 8, 2, 256, 20000, 20, 250, 256, 4
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix = vector peak
+# Duration of an EMPTY launch of each of the optimiser step's three grids behind its predecessor on the same stream (probe
+# build, every role returning at once: DESIGN.md section 3, "role timing"): the part of a step no kernel work can remove.
+LAUNCH_FLOORS_US = {"fwdbwd": 3.5, "wgrad": 4.2, "adam": 4.8}
 
 
 def make_inputs(seed):
@@ -43,9 +46,10 @@ def make_inputs(seed):
     return obs, act, rew, cost, term, trunc
 
 
-def orthogonal_theta(seed, n_params_check=None):
+def orthogonal_theta(seed, n_params_check=None, hid=None):
     """PPOLagAgent init (ppo_lag_agent.py:147-153): orthogonal W, zero b, sigma_param = -0.5."""
     import torch
+    HID = hid or globals()["HID"]
     torch.manual_seed(seed)
     parts = []
 
@@ -73,17 +77,26 @@ def flops_fwdbwd_launch(rows):
     return per_row * rows
 
 
+def flops_wgrad_launch(rows):
+    """Algorithmic FLOPs of ONE ppo_wgrad_kernel launch: dW_l = (upstream)^T (input) for the three layers of the 3 nets."""
+    per_row = 0
+    for out in (ACT, 1, 1):
+        per_row += 2 * (OBS * HID + HID * HID + HID * out)
+    return per_row * rows
+
+
 def _usable_cpus():
     from fsrl_amd.parallel import usable_cpus
     return usable_cpus()
 
 
-def cpu_baseline(theta, inputs, seconds=12.0, threads=4):
+def cpu_baseline(theta, inputs, seconds=12.0, threads=4, hid=None):
     """The oracle (torch CPU fp32 port of the reference update) timed on the host cores,
     on a bounded sample: whole updates of the SAME workload until `seconds` elapsed.
     threads = 4: the reference default `thread=4` (fsrl/config/ppol_cfg.py:11)."""
     import torch
     from oracle.ppo_lag import OnPolicyData, PPOLagConfig, PPOLagOracle
+    HID = hid or globals()["HID"]
     torch.set_num_threads(threads)
     obs, act, rew, cost, term, trunc = inputs
     em = lambda a: np.concatenate([a[:, e] for e in range(ENVS)])
@@ -103,9 +116,48 @@ def cpu_baseline(theta, inputs, seconds=12.0, threads=4):
             break
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "updates/s", "cores": threads, "kind": "port",
-            "sample": f"{n} full updates (312 grad steps each) of the same 20k-row workload, "
+            "sample": f"{n} full updates (312 grad steps each) of the same 20k-row workload, {HID}x{HID} MLPs, "
                       f"torch CPU fp32, {threads} threads; host: {os.cpu_count()} cpus visible, "
                       f"{_usable_cpus():g} usable (affinity / cgroup quota)"}
+
+
+def gpu_config0(inputs, seed, steps=8):
+    """BASELINE configs[0]'s shape (128x128 MLPs, otherwise the headline workload) through the HIP path, beside
+    `cpu_baseline_c0`: the reference's CPU-runnable configuration on both sides of this box."""
+    from fsrl_amd.engine import Engine, EngineConfig
+    eng = Engine(EngineConfig(obs_dim=OBS, act_dim=ACT, hidden=128, env_num=ENVS, buffer_size=100000, max_grad_norm=0.5,
+                              target_kl=None))
+    theta = orthogonal_theta(seed, eng.n_params, hid=128)
+    obs, act, rew, cost, term, trunc = inputs
+    ids = np.arange(ENVS)
+    for t in range(NROWS // ENVS):
+        eng.push(ids, obs[t], act[t], rew[t], cost[t], term[t], trunc[t], obs[t + 1])
+    eng.sync()
+    lag, resc = np.array([0.75]), 1.0 / 1.75
+
+    def one(k):
+        eng.set_params(theta); eng.optim_reset()
+        return eng.ppo_update(lag, resc, BATCH, REPEAT, perms=None, seed=k + 1)[0]
+    one(0)
+    eng.sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        st = one(k + 1)
+    eng.sync()
+    dt = (time.perf_counter() - t0) / steps
+    eng.close()
+    return {"value": 1.0 / dt, "unit": "updates/s", "ms_per_update": dt * 1e3, "us_per_step": dt * 1e6 / st.shape[0],
+            "workload": "BASELINE configs[0] shape: 128x128 MLPs, N=20000, batch 256, repeat 4, grad-clip 0.5"}
+
+
+def env_bound(envs, workers, busy_us, cpus):
+    """Upper bound on env-steps/s of a vector env whose every env step burns `busy_us` of host time: a vector step takes
+    ceil(envs / lanes) serial env steps, lanes = the worker processes that can run at once = min(workers, usable CPUs)
+    (4 workers x 8 envs x 100 us => 40 k/s however many CPUs there are; 32 workers on 16 CPUs => 2 rounds => 160 k/s)."""
+    if busy_us <= 0:
+        return None
+    lanes = max(1, min(int(workers) if workers > 0 else 1, int(cpus)))
+    return envs / (-(-envs // lanes) * busy_us * 1e-6)
 
 
 def end_to_end(local_rank, seed, seconds=6.0, device_actor=False, workers=0, busy_us=0.0, envs=ENVS):
@@ -148,9 +200,11 @@ def end_to_end(local_rank, seed, seconds=6.0, device_actor=False, workers=0, bus
     out = {"env": "synthetic SafetyCarCircle-shaped dynamics (not PyBullet); " + kind, "envs": envs, "workers": workers,
            "busy_us": busy_us, "host_cpus_usable": usable_cpus(),
            "handshake": (("polled sequence numbers" if getattr(env, "spin_us", 0) > 0 else "semaphores") if workers > 0 else None),
-           "env_bound_env_steps_per_s": (min(envs, usable_cpus()) / (busy_us * 1e-6) if busy_us > 0 else None),
+           "env_bound_env_steps_per_s": env_bound(envs, workers, busy_us, usable_cpus()),
            "actor": "device (fsrl_collect_step: one call per vector step, library RNG)" if device_actor else "host mirror (torch CPU, torch RNG)",
            "collects": collects, "env_steps_per_s": col.collect_step / dt,
+           "frac_of_env_bound": (col.collect_step / dt / env_bound(envs, workers, busy_us, usable_cpus())
+                                 if busy_us > 0 else None),
            "collector_only_env_steps_per_s": col.collect_step / col.collect_time,
            "update_ms_per_collect": update_s / collects * 1e3,
            "policy_updates_per_s": collects / dt}
@@ -254,12 +308,85 @@ def pmc_traffic():
     return None
 
 
+class Legs:
+    """Secondary legs of the bench line.  The headline dict is complete BEFORE any of them runs; every leg runs inside
+    try/except (its key becomes {"error": ...} on failure) under a watchdog thread with a per-leg deadline: when a leg
+    hangs (a collective another rank never joins, a worker process that never answers), rank 0 prints the line as it
+    stands -- exactly one JSON line in every case -- and every rank leaves with os._exit(0), so one stuck leg cannot
+    forfeit the measured headline or stall the other ranks.  Test hooks: FSRL_BENCH_FAIL_LEG=<key> raises inside that leg,
+    FSRL_BENCH_HANG_LEG=<key> sleeps forever inside it."""
+
+    def __init__(self, out, rank, total_budget_s):
+        import threading
+        self.out, self.rank = out, rank
+        self.lock = threading.Lock()
+        self.printed = False
+        self.leg, self.leg_deadline = None, None
+        self.t_end = time.monotonic() + total_budget_s
+        self.fail = os.environ.get("FSRL_BENCH_FAIL_LEG", "").split(",")
+        self.hang = os.environ.get("FSRL_BENCH_HANG_LEG", "").split(",")
+        th = threading.Thread(target=self._watch, daemon=True)
+        th.start()
+
+    def _watch(self):
+        while True:
+            time.sleep(0.25)
+            with self.lock:
+                dl, leg = self.leg_deadline, self.leg
+            if dl is not None and time.monotonic() > dl:
+                if self.out is not None and leg is not None:
+                    self.out[leg] = {"error": "watchdog: leg did not finish within its deadline; later legs skipped"}
+                self.emit()
+                sys.stdout.flush(); sys.stderr.flush()
+                os._exit(0)
+
+    def emit(self):
+        with self.lock:
+            if self.printed:
+                return
+            self.printed = True
+        if self.rank == 0 and self.out is not None:
+            print(json.dumps(self.out), flush=True)
+
+    def remaining(self):
+        return self.t_end - time.monotonic()
+
+    def run(self, key, fn, timeout_s, store=True):
+        """fn() under the leg's deadline; returns its value or None.  A leg is skipped when the total budget is spent."""
+        if self.remaining() <= 1.0:
+            if store and self.out is not None:
+                self.out[key] = {"error": "skipped: secondary-leg time budget spent"}
+            return None
+        with self.lock:
+            self.leg, self.leg_deadline = key, time.monotonic() + min(timeout_s, max(self.remaining(), 1.0))
+        try:
+            if key in self.fail:
+                raise RuntimeError(f"FSRL_BENCH_FAIL_LEG={key} (test hook)")
+            if key in self.hang:
+                while True:
+                    time.sleep(1.0)
+            val = fn()
+            if store and self.out is not None:
+                self.out[key] = val
+            return val
+        except BaseException as e:                                   # noqa: BLE001 -- a leg must never take the headline down
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            if store and self.out is not None:
+                self.out[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            return None
+        finally:
+            with self.lock:
+                self.leg, self.leg_deadline = None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip every secondary leg (profiling runs)")
     # test hooks (tests/test_gpu_facade.py): run the N > 1 code path on a one-GPU box -- every rank on device 0, gloo
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--share-gpu", action="store_true")
@@ -322,69 +449,19 @@ def main():
     dt = time.perf_counter() - t0
     grad_steps = stats.shape[0]
     assert np.isfinite(stats).all()
-    per_rank, lib_comm, dt_local = None, None, dt
+    per_rank, dt_local = None, dt
     if dist is not None:
-        # the SURVEY 8(e) exchange: every rank's figures gathered once (RCCL all_gather of a 5-double vector), then the
-        # max-over-ranks time the contract asks for
+        # the contract's max-over-ranks time, and the SURVEY 8(e) exchange: every rank's figures gathered once
         from fsrl_amd import parallel
-        per_rank = parallel.allgather_metrics({"rank": float(rank), "seed": float(seed), "updates": float(args.steps),
-                                               "grad_steps": float(grad_steps * args.steps), "seconds": dt,
-                                               "updates_per_s": args.steps / dt})
         tt = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        # the same exchange through the C ABI's own RCCL communicator (fsrl_comm_init + fsrl_metrics_allreduce), checked
-        # against torch.distributed's sum; outside the timed region.  Every rank first proves it can reach RCCL, so a rank
-        # that cannot does not leave the others waiting inside ncclCommInitRank.
-        if args.backend == "nccl" and os.environ.get("FSRL_BENCH_LIB_COMM", "1") != "0":
-            try:
-                eng.comm_unique_id(); ok = 1.0
-            except Exception as e:                          # noqa: BLE001
-                ok, lib_comm = 0.0, f"unavailable: {e}"
-            flag = torch.tensor([ok], device="cuda", dtype=torch.float64)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if float(flag.item()) == 1.0:
-                eng.comm_init_from_torch()
-                mine = np.array([1.0, float(rank), args.steps / dt_local, float(seed)])
-                got = eng.metrics_allreduce(mine)
-                want = torch.from_numpy(mine).cuda()
-                dist.all_reduce(want, op=dist.ReduceOp.SUM)
-                lib_comm = "ok" if np.array_equal(got, want.cpu().numpy()) and eng.comm_info() == (rank, world) else "mismatch"
-                eng.comm_destroy()
-            elif ok == 1.0:
-                lib_comm = "skipped: another rank cannot reach RCCL"
-    # ---- the other half of the headline metric at N > 1: every rank's whole training loop (host collector -> HIP store ->
-    #      update) side by side for a few seconds on its own slice of the host cores; job env-steps/s = the sum over ranks
-    e2e_job = None
-    if dist is not None:
-        from fsrl_amd import parallel
-        cores = parallel.pin_rank_cores(local_rank if not args.share_gpu else rank, world)
-        dist.barrier()
-        e2e = end_to_end(local_rank, seed, seconds=4.0, device_actor=True)
-        rows = parallel.allgather_metrics({"rank": float(rank), "env_steps_per_s": e2e["env_steps_per_s"],
-                                           "policy_updates_per_s": e2e["policy_updates_per_s"], "cores": float(len(cores))})
-        rows.sort(key=lambda r: r["rank"])
-        e2e_job = {"env": e2e["env"], "actor": e2e["actor"], "envs_per_rank": e2e["envs"], "ranks": len(rows),
-                   "env_steps_per_s": sum(r["env_steps_per_s"] for r in rows),
-                   "policy_updates_per_s": sum(r["policy_updates_per_s"] for r in rows),
-                   "per_rank_env_steps_per_s": [round(r["env_steps_per_s"], 1) for r in rows],
-                   "host_cores_per_rank": int(rows[0]["cores"])}
-    # ---- roofline of the dominant kernel: HIP events around every ppo_fwd_bwd_kernel launch on
-    #      the library's compute stream, over K more updates of the same workload
-    eng.set_profiling(True)
-    k_ms, k_raw, k_n, learn_ms, proc_ms = 0.0, 0.0, 0, 0.0, 0.0
-    prof_steps = max(1, min(args.steps, 5))
-    for k in range(prof_steps):
-        one_update(10_000 + k)
-        tm = eng.last_timing()
-        k_ms += tm["fwdbwd_ms"]; k_raw += tm["fwdbwd_raw_ms"]; k_n += tm["fwdbwd_launches"]
-        learn_ms += tm["learn_ms"]; proc_ms += tm["process_ms"]
-    eng.set_profiling(False)
-    avg_launch_s = (k_ms / max(k_n, 1)) * 1e-3
-    # rows per launch: 77 launches of 256 rows + 1 of 288 per pass
-    rows_avg = NROWS / (grad_steps / REPEAT)
-    achieved = flops_fwdbwd_launch(rows_avg) / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+        per_rank = parallel.allgather_metrics({"rank": float(rank), "seed": float(seed), "updates": float(args.steps),
+                                               "grad_steps": float(grad_steps * args.steps), "seconds": dt_local,
+                                               "updates_per_s": args.steps / dt_local})
 
+    # ---- the headline dict: complete here, before the roofline leg and every secondary leg
+    out = None
     if rank == 0:
         ups = args.steps / dt
         out = {
@@ -398,46 +475,136 @@ def main():
             "grad_steps_per_update": int(grad_steps),
             "grad_steps_per_s": ups * grad_steps * world,
             "buffer_rows_per_s": ups * NROWS * world,
-            "phase_ms": {"process_fn": proc_ms / prof_steps, "learn": learn_ms / prof_steps},
-            "roofline": {"bound": "mfma", "kernel": "ppo_fwd_bwd_kernel<256>", "achieved": achieved,
-                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "avg_launch_us": avg_launch_s * 1e6,
-                         "avg_launch_us_raw_event_bracket": k_raw / max(k_n, 1) * 1e3,
-                         "launches_timed": int(k_n),
-                         "flops_per_launch": flops_fwdbwd_launch(rows_avg)},
         }
         if per_rank is not None:
             out["ranks_seen"] = len(per_rank)
-            if lib_comm is not None:
-                out["lib_metrics_allreduce"] = lib_comm
-            if e2e_job is not None:
-                out["end_to_end_job"] = e2e_job
             out["per_rank_updates_per_s"] = [round(r["updates_per_s"], 3) for r in sorted(per_rank, key=lambda r: r["rank"])]
             out["sum_of_rank_rates"] = sum(r["updates_per_s"] for r in per_rank)
+    legs = Legs(out, rank, total_budget_s=float(os.environ.get("FSRL_BENCH_LEG_BUDGET_S", "420")))
+
+    # ---- roofline of the dominant kernel: HIP events around every ppo_fwd_bwd_kernel launch on
+    #      the library's compute stream, over K more updates of the same workload
+    def roofline_leg():
+        eng.set_profiling(True)
+        k_ms, k_raw, k_n, learn_ms, proc_ms = 0.0, 0.0, 0, 0.0, 0.0
+        step_ms = {"fwdbwd": 0.0, "wgrad": 0.0, "adam": 0.0}
+        prof_steps = max(1, min(args.steps, 5))
+        for k in range(prof_steps):
+            one_update(10_000 + k)
+            tm = eng.last_timing()
+            k_ms += tm["fwdbwd_ms"]; k_raw += tm["fwdbwd_raw_ms"]; k_n += tm["fwdbwd_launches"]
+            learn_ms += tm["learn_ms"]; proc_ms += tm["process_ms"]
+        eng.set_profiling(False)
+        avg_launch_s = (k_ms / max(k_n, 1)) * 1e-3
+        rows_avg = NROWS / (grad_steps / REPEAT)        # 77 launches of 256 rows + 1 of 288 per pass
+        fl = flops_fwdbwd_launch(rows_avg)
+        achieved = fl / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+        r = {"bound": "mfma", "kernel": "ppo_fwd_bwd_kernel<256>", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
+             "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+             "avg_launch_us": avg_launch_s * 1e6, "avg_launch_us_raw_event_bracket": k_raw / max(k_n, 1) * 1e3,
+             "launches_timed": int(k_n), "flops_per_launch": fl}
+        # the bound that actually applies to a chain of dependent ~0.2 GFLOP launches ("report the achieved
+        # fraction of the latency floor as well"): per optimiser step, the floors of its dependent launches (an empty
+        # launch of each grid, measured with the probe build: DESIGN section 3) + the step's MFMA work at the chip's peak
+        floors_us = LAUNCH_FLOORS_US["fwdbwd"] + LAUNCH_FLOORS_US["wgrad"] + LAUNCH_FLOORS_US["adam"]
+        step_flops = fl + flops_wgrad_launch(rows_avg)
+        floor_us = floors_us + step_flops / (F32_MFMA_PEAK_TFLOPS * 1e12) * 1e6
+        step_us = learn_ms / prof_steps * 1e3 / grad_steps
+        r["latency_floor_us"] = floor_us
+        r["latency_floor_parts_us"] = dict(LAUNCH_FLOORS_US, mfma_at_peak=floor_us - floors_us)
+        r["step_us"] = step_us
+        r["frac_of_latency_floor"] = floor_us / step_us if step_us > 0 else None
         pmc = pmc_traffic()
         if pmc is not None:
-            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc
-        if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
-            out["end_to_end"] = end_to_end(local_rank, seed, device_actor=True)
-            out["end_to_end_host_actor"] = end_to_end(local_rank, seed, seconds=4.0, device_actor=False)
-            # the host vector-env side of the headline metric: worker processes x simulated step cost
-            out["end_to_end_shmem"] = [end_to_end(local_rank, seed, seconds=3.0, device_actor=True, workers=w, busy_us=b,
-                                                  envs=32) for w in (4, 32) for b in (0.0, 100.0)]
-            out["multi_seed"] = multi_seed()
-            out["no_clip"] = no_clip_variant(theta, inputs)
-            out["grouped"] = grouped()
-            out["cpu_baseline"] = cpu_baseline(theta, inputs)
+            r["traffic"], r["traffic_source"] = pmc
+        if out is not None:
+            out["phase_ms"] = {"process_fn": proc_ms / prof_steps, "learn": learn_ms / prof_steps}
+        return r
+
+    legs.run("roofline", roofline_leg, 60.0)
+
+    if dist is not None and not args.headline_only:
+        from fsrl_amd import parallel
+        # ---- the other half of the headline metric at N > 1: every rank's whole training loop (host collector -> HIP store
+        #      -> update) side by side for a few seconds on its own slice of the host cores; job env-steps/s = sum over ranks.
+        #      A rank whose loop fails contributes NaNs, so the gather below is still joined by every rank.
+        cores = parallel.pin_rank_cores(local_rank if not args.share_gpu else rank, world)
+        e2e = legs.run("end_to_end_rank", lambda: end_to_end(local_rank, seed, seconds=4.0, device_actor=True), 90.0, store=False)
+        mine = {"rank": float(rank), "cores": float(len(cores)),
+                "env_steps_per_s": e2e["env_steps_per_s"] if e2e else float("nan"),
+                "policy_updates_per_s": e2e["policy_updates_per_s"] if e2e else float("nan")}
+
+        def job_leg():
+            rows = parallel.allgather_metrics(mine)
+            rows.sort(key=lambda r: r["rank"])
+            ok = [r for r in rows if r["env_steps_per_s"] == r["env_steps_per_s"]]
+            return {"env": e2e["env"] if e2e else None, "actor": e2e["actor"] if e2e else None,
+                    "envs_per_rank": e2e["envs"] if e2e else None, "ranks": len(rows), "ranks_ok": len(ok),
+                    "env_steps_per_s": sum(r["env_steps_per_s"] for r in ok),
+                    "policy_updates_per_s": sum(r["policy_updates_per_s"] for r in ok),
+                    "per_rank_env_steps_per_s": [round(r["env_steps_per_s"], 1) for r in rows],
+                    "host_cores_per_rank": int(rows[0]["cores"])}
+        legs.run("end_to_end_job", job_leg, 60.0)
+
+        # ---- LAST (it is the one leg that has never run on hardware): the same exchange through the C ABI's own RCCL
+        #      communicator (fsrl_comm_init + fsrl_metrics_allreduce), checked against torch.distributed's sum.  Every rank
+        #      first proves it can reach RCCL, so a rank that cannot does not leave the others inside ncclCommInitRank; a
+        #      rank that still hangs there trips the watchdog (30 s), which prints the line and ends every rank.
+        if args.backend == "nccl" and os.environ.get("FSRL_BENCH_LIB_COMM", "1") != "0":
+            def lib_comm_leg():
+                try:
+                    eng.comm_unique_id(); ok, why = 1.0, None
+                except Exception as e:                          # noqa: BLE001
+                    ok, why = 0.0, f"unavailable: {e}"
+                flag = torch.tensor([ok], device="cuda", dtype=torch.float64)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if float(flag.item()) != 1.0:
+                    return why or "skipped: another rank cannot reach RCCL"
+                eng.comm_init_from_torch()
+                v = np.array([1.0, float(rank), args.steps / dt_local, float(seed)])
+                got = eng.metrics_allreduce(v)
+                want = torch.from_numpy(v).cuda()
+                dist.all_reduce(want, op=dist.ReduceOp.SUM)
+                res = "ok" if np.array_equal(got, want.cpu().numpy()) and eng.comm_info() == (rank, world) else "mismatch"
+                eng.comm_destroy()
+                return res
+            legs.run("lib_metrics_allreduce", lib_comm_leg, 30.0)
+
+    if rank == 0 and world == 1 and not args.headline_only:       # rank 0 at N = 1 only
+        if not args.no_cpu_baseline:
+            legs.run("cpu_baseline", lambda: cpu_baseline(theta, inputs), 90.0)
+            if isinstance(out.get("cpu_baseline"), dict) and "value" in out["cpu_baseline"]:
+                out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+            # BASELINE configs[0]: the reference's own CPU-runnable case (128x128, 4 threads: fsrl/config/ppol_cfg.py:11,15)
+            legs.run("cpu_baseline_c0", lambda: cpu_baseline(orthogonal_theta(seed, hid=128), inputs, seconds=8.0, threads=4,
+                                                             hid=128), 60.0)
+            legs.run("gpu_c0", lambda: gpu_config0(inputs, seed), 60.0)
             from fsrl_amd.parallel import usable_cpus
             allc = max(1, int(usable_cpus()))          # "... and with all host cores" (the cgroup quota counts)
             if allc > 4:
-                out["cpu_baseline_all_cores"] = cpu_baseline(theta, inputs, seconds=6.0, threads=allc)
-            out["speedup_vs_cpu_port"] = out["value"] / world / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
-    eng.close()
+                legs.run("cpu_baseline_all_cores", lambda: cpu_baseline(theta, inputs, seconds=6.0, threads=allc), 60.0)
+        legs.run("no_clip", lambda: no_clip_variant(theta, inputs), 60.0)
+        legs.run("end_to_end", lambda: end_to_end(local_rank, seed, device_actor=True), 60.0)
+        legs.run("end_to_end_host_actor", lambda: end_to_end(local_rank, seed, seconds=4.0, device_actor=False), 60.0)
+        # the host vector-env side of the headline metric: worker processes x simulated step cost
+        shm = []
+        out["end_to_end_shmem"] = shm
+        for w in (4, 32):
+            for b in (0.0, 100.0):
+                r = legs.run(f"end_to_end_shmem_w{w}_b{int(b)}",
+                             lambda: end_to_end(local_rank, seed, seconds=3.0, device_actor=True, workers=w, busy_us=b, envs=32),
+                             60.0, store=False)
+                shm.append(r if r is not None else {"workers": w, "busy_us": b, "error": "leg failed or timed out"})
+        legs.run("grouped", lambda: grouped(4), 90.0)
+        legs.run("grouped_k8", lambda: grouped(8), 90.0)
+        legs.run("multi_seed", multi_seed, 90.0)
+    legs.emit()
+    try:
+        eng.close()
+    except Exception:                                             # noqa: BLE001
+        pass
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        legs.run("_teardown", lambda: (dist.barrier(), dist.destroy_process_group()), 30.0, store=False)
 
 
 if __name__ == "__main__":

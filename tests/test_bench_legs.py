@@ -1,0 +1,61 @@
+"""bench.py's secondary-leg guard: the headline line must survive a failing or hanging leg."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_env_bound_counts_serial_envs_per_worker():
+    import bench
+    assert bench.env_bound(32, 4, 100.0, 16) == 40000.0          # 4 workers x 8 serial envs x 100 us
+    assert bench.env_bound(32, 32, 100.0, 16) == 160000.0        # 32 workers on 16 CPUs: two rounds
+    assert bench.env_bound(32, 32, 100.0, 64) == 320000.0
+    assert bench.env_bound(32, 0, 100.0, 16) == 32 / (32 * 100e-6)   # in-process env: one lane
+    assert bench.env_bound(32, 4, 0.0, 16) is None
+
+
+def test_failing_leg_is_recorded_and_later_legs_still_run(capsys):
+    import bench
+    out = {"value": 1.0}
+    os.environ["FSRL_BENCH_FAIL_LEG"] = "grouped"
+    try:
+        legs = bench.Legs(out, 0, 30.0)
+    finally:
+        del os.environ["FSRL_BENCH_FAIL_LEG"]
+    assert legs.run("a", lambda: 3, 5.0) == 3
+    assert legs.run("grouped", lambda: 4, 5.0) is None
+    assert legs.run("b", lambda: 1 / 0, 5.0) is None
+    assert legs.run("c", lambda: {"x": 1}, 5.0) == {"x": 1}
+    legs.emit(); legs.emit()
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] == 1.0 and d["a"] == 3 and d["c"] == {"x": 1}
+    assert "test hook" in d["grouped"]["error"] and "ZeroDivisionError" in d["b"]["error"]
+
+
+def test_hanging_leg_trips_the_watchdog_and_the_headline_is_printed_once():
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "out = {'value': 2.5}\n"
+            "legs = bench.Legs(out, 0, 60.0)\n"
+            "legs.run('first', lambda: 'ok', 5.0)\n"
+            "legs.run('stuck', lambda: time.sleep(3600), 1.0)\n"
+            "legs.run('never', lambda: 'no', 5.0)\n"
+            "legs.emit()\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-1000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] == 2.5 and d["first"] == "ok" and "watchdog" in d["stuck"]["error"] and "never" not in d
+
+
+def test_nonzero_rank_watchdog_exits_quietly():
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "legs = bench.Legs(None, 1, 60.0)\n"
+            "legs.run('stuck', lambda: time.sleep(3600), 1.0)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip() == ""

@@ -361,6 +361,25 @@ def test_bench_multi_rank_path_on_one_gpu():
     assert abs(job["env_steps_per_s"] - sum(job["per_rank_env_steps_per_s"])) < 1.0 and job["env_steps_per_s"] > 1000
 
 
+def test_bench_headline_survives_a_failing_leg():
+    """a secondary leg that raises on one code path must not cost the headline line.  Two ranks over
+    gloo sharing this GPU, the per-rank training-loop leg forced to fail on every rank: the line is still printed, the
+    headline fields are intact, the job figure says no rank contributed."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FSRL_BENCH_FAIL_LEG="end_to_end_rank,grouped")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--share-gpu"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["ranks_seen"] == 2 and d["roofline"]["frac"] > 0
+    assert d["end_to_end_job"]["ranks"] == 2 and d["end_to_end_job"]["ranks_ok"] == 0
+
+
 def test_multi_gpu_launcher_two_ranks_share_this_gpu(tmp_path):
     """examples/train_multi_gpu.py under the driver's launch line, two ranks on this box's one GPU over gloo: two real
     (tiny) PPO-Lag training loops, seeds base + rank, the epoch vector all-reduced from BaseTrainer._close_epoch.  The
