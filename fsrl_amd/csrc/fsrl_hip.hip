@@ -11,6 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <functional>
+#include <queue>
 #include <string>
 #include <vector>
 

@@ -46,7 +46,7 @@ struct FbArgs {
 // keep_dz1: also leave dz1 in sm.d2 (used for input gradients).  Always leaves dz1 in sm.d2 when
 // `FB_MODE_Q_DIN` callers ask for it via the trailing flag == true or read it after a barrier.
 template <int H, int R = 16>
-__device__ __forceinline__ void tile_backward(TileSmem<H>& sm, const NetOff no, const float (&wb)[H / 16][4],
+__device__ __forceinline__ void tile_backward(TileSmem<H, tile_rows(R)>& sm, const NetOff no, const float (&wb)[H / 16][4],
                                               float* __restrict__ A1, float* __restrict__ A2,
                                               float* __restrict__ D1, float* __restrict__ D2,
                                               float* __restrict__ DOb, const int tid, const bool) {
@@ -59,8 +59,8 @@ __device__ __forceinline__ void tile_backward(TileSmem<H>& sm, const NetOff no, 
         *reinterpret_cast<f32x4*>(&A1[(size_t)i * H + 4 * c4]) = *reinterpret_cast<const f32x4*>(&sm.h1[i * LD + 4 * c4]);
         *reinterpret_cast<f32x4*>(&A2[(size_t)i * H + 4 * c4]) = *reinterpret_cast<const f32x4*>(&sm.h2[i * LD + 4 * c4]);
     }
-    if (R == 16 || tid < H) {   // dz2 = (dout @ W3) * relu'(z2)
-        const int k = tid % H, rg = tid / H;
+    for (int t = tid; t < (R / 4) * H; t += NT) {   // dz2 = (dout @ W3) * relu'(z2); one trip up to 16 rows, two for 32
+        const int k = t % H, rg = t / H;
         float g[4] = {0.f, 0.f, 0.f, 0.f};
         for (int o = 0; o < no.out; ++o) {
             const float w = sm.w3[o * H + k];
@@ -107,48 +107,61 @@ __device__ __forceinline__ void tile_backward(TileSmem<H>& sm, const NetOff no, 
             for (int r = 0; r < 4; ++r) sm.d2[r * LD + col] = v[r];   // dz1, for input gradients
         }
     } else {
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};                  // rows 16..31 of a 32-row tile: same fragment, second pass
         const float* arow = &sm.d2[li * LD + 4 * q];
 #pragma unroll
         for (int jc = 0; jc < H / 16; ++jc) {
             const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * jc);
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = mfma_16x16x4(av[s], wb[jc][s], acc);
+            if constexpr (R == 32) {
+                const f32x4 av2 = *reinterpret_cast<const f32x4*>(arow + 16 * LD + 16 * jc);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc2 = mfma_16x16x4(av2[s], wb[jc][s], acc2);
+            }
         }
-        float v[4];
+        float v[4], v2[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * q + r;
             v[r] = (sm.h1[i * LD + col] > 0.0f) ? acc[r] : 0.0f;
             D1[(size_t)i * H + col] = v[r];
+            if constexpr (R == 32) {
+                v2[r] = (sm.h1[(16 + i) * LD + col] > 0.0f) ? acc2[r] : 0.0f;
+                D1[(size_t)(16 + i) * H + col] = v2[r];
+            }
         }
         __syncthreads();          // every wave is done reading dz2 from sm.d2
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sm.d2[(4 * q + r) * LD + col] = v[r];   // dz1, for input gradients
+        for (int r = 0; r < 4; ++r) {
+            sm.d2[(4 * q + r) * LD + col] = v[r];   // dz1, for input gradients
+            if constexpr (R == 32) sm.d2[(16 + 4 * q + r) * LD + col] = v2[r];
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // R = rows per tile (16, or 4 on v_mfma_f32_4x4x1 when 16-row tiles would leave most CUs idle)
+// One tile of R rows starting at row0.  stat_tile: the tile's slot in a.statp (a 32-row tile fills stat_tile and stat_tile + 1).
 template <int H, int R>
-__global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict__ P,
-                                                       const ModelDesc md, const FbArgs a) {
-    __shared__ TileSmem<H> sm;
+__device__ __forceinline__ void fb_tile_body(TileSmem<H, tile_rows(R)>& sm, const float* __restrict__ P, const ModelDesc& md,
+                                             const FbArgs& a, const int row0, const int stat_tile, const int y, const int ny) {
+    constexpr int ROWS = tile_rows(R);
     constexpr int LD = TileSmem<H>::LD;
     constexpr int NT = TileGeom<H>::NT;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
-    const int tile = blockIdx.x, net = a.net0 + blockIdx.y;
-    const int row0 = tile * R;
+    const int net = a.net0 + y;
     const NetOff no = md.net[net];
     const int Do = md.Do, Da = md.Da;
     const int n_valid = max(0, min(R, a.N - row0));
     const float invN = 1.0f / (float)a.N;
 
-    TileStage<H> stg;
+    TileStage<H, ROWS> stg;
     stg.issue(P, no, Do, Da, a.obs + (size_t)row0 * Do, a.rd ? a.rd + (size_t)row0 * FSRL_RD : nullptr, n_valid, tid);
     FwdW2Frag<H> wf;
     wf.load(P + no.W2f, wave, lane);
-    for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
+    for (int e = tid; e < ROWS * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
     stg.commit(sm, no, Do, tid);
     __syncthreads();
     tile_forward<H, R>(sm, P, no, Do, tid, wf);
@@ -166,6 +179,7 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
     }
 
     // ---- head: thread (row i = tid>>4, dim d = tid&15)
+    static_assert(16 * R <= NT, "one head thread per (row, dim): a 32-row tile needs H >= 128");
     if (tid < 16 * R) {
         const int i = tid >> 4, d = tid & 15;
         const bool valid = i < n_valid;
@@ -265,14 +279,25 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
         }
     }
     __syncthreads();
-    if (tid < FB_NSTAT) {   // rows summed in ascending order (fixed => deterministic)
-        float t = 0.0f;
-        for (int i = 0; i < R; ++i) t += sm.w1[i * FB_NSTAT + tid];
-        a.statp[((size_t)tile * gridDim.y + blockIdx.y) * FB_NSTAT + tid] = t;
+    if constexpr (R <= 16) {
+        if (tid < FB_NSTAT) {   // rows summed in ascending order (fixed => deterministic)
+            float t = 0.0f;
+            for (int i = 0; i < R; ++i) t += sm.w1[i * FB_NSTAT + tid];
+            a.statp[((size_t)stat_tile * ny + y) * FB_NSTAT + tid] = t;
+        }
+    } else {
+        // a 32-row tile leaves the partial sums of its two 16-row halves in the slots the 16-row tiles 2t, 2t + 1 would
+        // write: the reduction over the tiles (fb_reduce_stats_kernel) then adds the same numbers in the same order
+        if (tid < 2 * FB_NSTAT) {
+            const int half = tid >> 3, f = tid & 7;
+            float t = 0.0f;
+            for (int i = 0; i < 16; ++i) t += sm.w1[(16 * half + i) * FB_NSTAT + f];
+            a.statp[((size_t)(stat_tile + half) * ny + y) * FB_NSTAT + f] = t;
+        }
     }
     if (!backward) return;
 
-    const size_t nb = (size_t)blockIdx.y * a.rows_pad;
+    const size_t nb = (size_t)y * a.rows_pad;
     tile_backward<H, R>(sm, no, wb, a.A1 + (nb + row0) * H, a.A2 + (nb + row0) * H, a.D1 + (nb + row0) * H,
                      a.D2 + (nb + row0) * H, a.DO + (nb + row0) * FSRL_DOW, tid, false);
     if (a.mode == FB_MODE_Q_DIN) {
@@ -299,8 +324,35 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
             s_ += __shfl_xor(s_, 2, 64);
             s_ += __shfl_xor(s_, 4, 64);
             if (jp == 0 && ik < R * Dact && i < n_valid)
-                a.da_out[((size_t)blockIdx.y * a.N + row0 + i) * Dact + kk] = s_;
+                a.da_out[((size_t)y * a.N + row0 + i) * Dact + kk] = s_;
         }
+    }
+}
+
+template <int H, int R>
+__global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict__ P,
+                                                       const ModelDesc md, const FbArgs a) {
+    __shared__ TileSmem<H, tile_rows(R)> sm;
+    fb_tile_body<H, R>(sm, P, md, a, blockIdx.x * R, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// Mixed-height 1-D grid of the full-batch launches (host: mixed_plan): the first ny * n32 blocks take the 32-row tiles of the
+// ny networks (two MFMA passes per weight fragment: half the L2 -> register weight traffic per row), the ny * n16 blocks
+// behind them 16-row tiles of the remaining rows, so that the last round of workgroups is a round of the cheap tiles.
+// A row's arithmetic does not depend on its tile's height and the per-tile statistics keep the 16-row slots: bit-identical
+// to fb_tile_kernel<H, 16>.
+template <int H>
+__global__ __launch_bounds__(4 * H) void fb_tile_mixed_kernel(const float* __restrict__ P, const ModelDesc md, const FbArgs a,
+                                                             const int n32, const int n16, const int ny) {
+    __shared__ TileSmem<H, 32> sm;
+    int b = blockIdx.x;
+    if (b < ny * n32) {
+        const int y = b / n32, t = b - y * n32;
+        fb_tile_body<H, 32>(sm, P, md, a, 32 * t, 2 * t, y, ny);
+    } else {
+        b -= ny * n32;
+        const int y = b / n16, t = b - y * n16;
+        fb_tile_body<H, 16>(*reinterpret_cast<TileSmem<H, 16>*>(&sm), P, md, a, 32 * n32 + 16 * t, 2 * n32 + t, y, ny);
     }
 }
 
@@ -549,6 +601,311 @@ __global__ __launch_bounds__(4 * H) void fb_hvp_tile_kernel(const float* __restr
             a.RDO[(size_t)row0 * FSRL_DOW + e] = sm.rdout[e];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// The same product on 32-row tiles, with the theta-only part cached.  Conjugate gradients call the HVP 22 times per
+// CPO repeat at ONE theta on ONE batch (cpo.py:255-268: H^-1 g, then H^-1 b): h1, h2, dout and dz2 are the same in all
+// of them.  CACHED = false computes everything and leaves A1 / A2 / D2 / DO in the side buffers (first product at a theta);
+// CACHED = true reads h1 / h2 back (2 x 32 KB per tile, MALL-resident: N x 2 x H floats = 41 MB at N = 20 000), skips the
+// z GEMMs and the four theta-only spills.  32 rows per tile = two MFMA passes per weight fragment: the four 256 KB
+// fragment ingests (W2 and V2, forward and backward order) are paid per 32 rows instead of per 16.  Every output element
+// sees the arithmetic of fb_hvp_tile_kernel in the same order (K order inside a row does not depend on the tile height;
+// relu'(z) is read off h > 0), so the three kernels agree bit for bit (tests/test_gpu_trust.py).
+// LDS: four 32 x (H + 4) slots -- h1 | R{h1}, later dz2 | h2 | R{h2}, later R{dz2} -- 158 KB at H = 256.
+template <int H>
+struct Hvp32Smem {
+    static constexpr int LD = H + 4;
+    float s0[32 * LD], s1[32 * LD], s2[32 * LD], s3[32 * LD];
+    float xT[64 * 32];                                        // obs tile transposed [k][i], obs_dim <= 64
+    float out[32 * FSRL_MAX_ACT], rout[32 * FSRL_MAX_ACT];
+    float dout[32 * FSRL_DOW], rdout[32 * FSRL_DOW];
+    float mo[32 * 32];                                        // per row: mean_old[16] | std_old[16]
+};
+
+// NH 16-row passes over one fragment set: acc[hf] = rows 16 hf .. 16 hf + 15
+template <int H, int NH>
+__device__ __forceinline__ void mma_rows_n(const float* A, const FwdW2Frag<H>& wf, int li, int q, f32x4 (&acc)[NH]) {
+    constexpr int LD = H + 4;
+    const float* arow = A + li * LD + 4 * q;
+#pragma unroll
+    for (int kc = 0; kc < H / 16; ++kc) {
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * hf * LD + 16 * kc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[hf] = mfma_16x16x4(av[s], wf.b[kc][s], acc[hf]);
+        }
+    }
+}
+template <int H, int NH>
+__device__ __forceinline__ void mma_cols_n(const float* A, const float* __restrict__ W, int wave, int li, int q,
+                                           f32x4 (&acc)[NH]) {
+    constexpr int LD = H + 4;
+    const float* __restrict__ Wc = W + wave * 16 + li;
+    float wb[H / 16][4];
+#pragma unroll
+    for (int jc = 0; jc < H / 16; ++jc) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wb[jc][s] = Wc[(size_t)(16 * jc + 4 * q + s) * H];
+    }
+    const float* arow = A + li * LD + 4 * q;
+#pragma unroll
+    for (int jc = 0; jc < H / 16; ++jc) {
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * hf * LD + 16 * jc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[hf] = mfma_16x16x4(av[s], wb[jc][s], acc[hf]);
+        }
+    }
+}
+
+// one tile of 16 NH rows starting at row0
+template <int H, bool CACHED, int NH>
+__device__ __forceinline__ void hvp_tile_body(Hvp32Smem<H>& sm, const float* __restrict__ P, const ModelDesc& md,
+                                              const HvpArgs& a, const int row0) {
+    constexpr int LD = Hvp32Smem<H>::LD;
+    constexpr int NT = 4 * H;
+    constexpr int WAVES = H / 16;
+    constexpr int H4 = H / 4;
+    constexpr int R = 16 * NH;
+    static_assert(NT >= 16 * R, "one head thread per (row, dim)");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+    const NetOff no = md.net[0];
+    const float* __restrict__ V = a.V;
+    const int Do = md.Do, Da = md.Da;
+    const int n_valid = min(R, a.N - row0);
+    const float invN = 1.0f / (float)a.N;
+    const size_t base = (size_t)row0 * H;
+    float* h1 = sm.s0; float* rh1 = sm.s1; float* h2 = sm.s2; float* rh2 = sm.s3;
+    float* d2 = sm.s1; float* rd2 = sm.s3;          // later owners of the two tangent slots
+
+    FwdW2Frag<H> wf;
+    wf.load(P + no.W2f, wave, lane);
+    if constexpr (CACHED) {                          // h1, h2 of this theta, left by the CACHED = false launch
+        for (int e = tid; e < R * H4; e += NT) {
+            const int i = e / H4, c4 = e - i * H4;
+            *reinterpret_cast<f32x4*>(&h1[i * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(a.A1 + base + (size_t)i * H + 4 * c4);
+            *reinterpret_cast<f32x4*>(&h2[i * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(a.A2 + base + (size_t)i * H + 4 * c4);
+        }
+    }
+    for (int e = tid; e < R * Do; e += NT) {
+        const int i = e / Do, k = e - i * Do;
+        sm.xT[k * 32 + i] = (i < n_valid) ? a.obs[(size_t)row0 * Do + e] : 0.0f;
+    }
+    for (int e = tid; e < R * 32; e += NT) {
+        const int i = e >> 5, f = e & 31;
+        sm.mo[e] = (i < n_valid) ? a.rd[(size_t)(row0 + i) * FSRL_RD + FSRL_RD_MEAN + f] : 0.0f;   // MEAN and STD are adjacent
+    }
+    for (int e = tid; e < R * FSRL_DOW; e += NT) { sm.dout[e] = 0.0f; sm.rdout[e] = 0.0f; }
+    __syncthreads();
+
+    // ---- layer 1 and its tangent on MFMA: the wave's 16 rows of W1 and of V1 in one load burst, NH row halves
+    {
+        f32x4 acc[NH], racc[NH];
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) acc[hf] = racc[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* __restrict__ wrow = P + no.W1 + (size_t)(wave * 16 + li) * Do;
+        const float* __restrict__ vrow = V + no.W1 + (size_t)(wave * 16 + li) * Do;
+        for (int k0 = 0; k0 < Do; k0 += 64) {
+            float b[16], vb_[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int k = k0 + 4 * s + q;
+                if constexpr (!CACHED) b[s] = (k < Do) ? wrow[k] : 0.0f;
+                vb_[s] = (k < Do) ? vrow[k] : 0.0f;
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int k = k0 + 4 * s + q;
+                if (k0 + 4 * s < Do) {
+#pragma unroll
+                    for (int hf = 0; hf < NH; ++hf) {
+                        const float a_ = (k < Do) ? sm.xT[k * 32 + 16 * hf + li] : 0.0f;
+                        if constexpr (!CACHED) acc[hf] = mfma_16x16x4(a_, b[s], acc[hf]);
+                        racc[hf] = mfma_16x16x4(a_, vb_[s], racc[hf]);
+                    }
+                }
+            }
+        }
+        const int j = wave * 16 + li;
+        const float b1 = P[no.b1 + j], vb1 = V[no.b1 + j];
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int l = (16 * hf + 4 * q + r) * LD + j;
+                bool on;
+                if constexpr (CACHED) on = h1[l] > 0.0f;
+                else {
+                    const float z = acc[hf][r] + b1;
+                    on = z > 0.0f;
+                    h1[l] = on ? z : 0.0f;
+                }
+                rh1[l] = on ? racc[hf][r] + vb1 : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- layer 2:  z2 = W2 h1 + b2 ; R{z2} = W2 R{h1} + V2 h1 + vb2
+    {
+        f32x4 z[NH], rz[NH];
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) z[hf] = rz[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (!CACHED) mma_rows_n<H, NH>(h1, wf, li, q, z);
+        mma_rows_n<H, NH>(rh1, wf, li, q, rz);
+        wf.load(V + no.W2f, wave, lane);
+        mma_rows_n<H, NH>(h1, wf, li, q, rz);
+        const int j = wave * 16 + li;
+        const float bias = P[no.b2 + j], vbias = V[no.b2 + j];
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int l = (16 * hf + 4 * q + r) * LD + j;
+                bool on;
+                if constexpr (CACHED) on = h2[l] > 0.0f;
+                else {
+                    const float zz = z[hf][r] + bias;
+                    on = zz > 0.0f;
+                    h2[l] = on ? zz : 0.0f;
+                }
+                rh2[l] = on ? rz[hf][r] + vbias : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    // R{h1} (and h1 on the first product) leave for the weight-side kernel; slot 1 is free after the next barrier
+    for (int e = tid; e < R * H4; e += NT) {
+        const int i = e / H4, c4 = e - i * H4;
+        const size_t o = base + (size_t)i * H + 4 * c4;
+        const int l = i * LD + 4 * c4;
+        *reinterpret_cast<f32x4*>(a.RA1 + o) = *reinterpret_cast<const f32x4*>(&rh1[l]);
+        if constexpr (!CACHED) *reinterpret_cast<f32x4*>(a.A1 + o) = *reinterpret_cast<const f32x4*>(&h1[l]);
+    }
+    // ---- head pre-activations: out = W3 h2 + b3 ; R{out} = W3 R{h2} + V3 h2 + vb3
+    for (int i = wave; i < R; i += WAVES) {
+        for (int o = 0; o < Da; ++o) {
+            const float* __restrict__ w3 = P + no.W3 + (size_t)o * H;
+            const float* __restrict__ v3 = V + no.W3 + (size_t)o * H;
+            float s = 0.0f, rs = 0.0f;
+#pragma unroll
+            for (int k = lane; k < H; k += 64) {
+                const float h = h2[i * LD + k];
+                s = fmaf(h, w3[k], s);
+                rs = fmaf(rh2[i * LD + k], w3[k], rs);
+                rs = fmaf(h, v3[k], rs);
+            }
+            s = wave_sum(s);
+            rs = wave_sum(rs);
+            if (lane == 0) {
+                sm.out[i * FSRL_MAX_ACT + o] = s + P[no.b3 + o];
+                sm.rout[i * FSRL_MAX_ACT + o] = rs + V[no.b3 + o];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- KL head (per row, per action dim): dout, R{dout}, and the sigma_param rows
+    if (tid < 16 * R) {
+        const int i = tid >> 4, d = tid & 15;
+        if (i < n_valid && d < Da) {
+            const float x = sm.out[i * FSRL_MAX_ACT + d];
+            const float t = md.unbounded ? 0.0f : tanhf(x);           // unbounded head: mu = x, dmu/dout = 1, second derivative 0
+            const float hs = md.unbounded ? 1.0f : a.max_action;
+            const float ro = sm.rout[i * FSRL_MAX_ACT + d];
+            const float sp = P[no.sigma + d], rls = V[no.sigma + d];   // R{log sigma} = v_sigma
+            const float sig = expf(sp), var = sig * sig;
+            const float dt = hs * (1.0f - t * t);                       // dmu/dout
+            const float rmu = dt * ro;
+            const float dmu_b = a.max_action * t - sm.mo[i * 32 + d];
+            const float dmu = md.unbounded ? x - sm.mo[i * 32 + d] : dmu_b;
+            const float so = sm.mo[i * 32 + 16 + d], so2 = so * so;
+            const float gmu = dmu / var;                                // dKL/dmu
+            const float rgmu = rmu / var - 2.0f * gmu * rls;
+            const float rgls = -2.0f * dmu * rmu / var + 2.0f * (so2 + dmu * dmu) / var * rls;
+            const float rdt = hs * (-2.0f * t) * (1.0f - t * t) * ro;   // R{dmu/dout}
+            sm.dout[i * FSRL_DOW + d] = invN * gmu * dt;
+            sm.rdout[i * FSRL_DOW + d] = invN * (rgmu * dt + gmu * rdt);
+            sm.dout[i * FSRL_DOW + 16 + d] = invN * (1.0f - (so2 + dmu * dmu) / var);
+            sm.rdout[i * FSRL_DOW + 16 + d] = invN * rgls;
+        }
+    }
+    // R{h2} (and h2) leave; slot 3 is free after the barrier
+    for (int e = tid; e < R * H4; e += NT) {
+        const int i = e / H4, c4 = e - i * H4;
+        const size_t o = base + (size_t)i * H + 4 * c4;
+        const int l = i * LD + 4 * c4;
+        *reinterpret_cast<f32x4*>(a.RA2 + o) = *reinterpret_cast<const f32x4*>(&rh2[l]);
+        if constexpr (!CACHED) *reinterpret_cast<f32x4*>(a.A2 + o) = *reinterpret_cast<const f32x4*>(&h2[l]);
+    }
+    __syncthreads();
+    // ---- dz2 = relu'(z2) (dout W3) ; R{dz2} = relu'(z2) (R{dout} W3 + dout V3)      (dz2 -> slot 1, R{dz2} -> slot 3)
+    for (int t = tid; t < (R / 4) * H; t += NT) {
+        const int k = t % H, rg = t / H;
+        float g[4] = {0, 0, 0, 0}, rg_[4] = {0, 0, 0, 0};
+        for (int o = 0; o < Da; ++o) {
+            const float w = P[no.W3 + (size_t)o * H + k], v = V[no.W3 + (size_t)o * H + k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dd = sm.dout[(4 * rg + e) * FSRL_DOW + o];
+                g[e] = fmaf(dd, w, g[e]);
+                rg_[e] = fmaf(sm.rdout[(4 * rg + e) * FSRL_DOW + o], w, rg_[e]);
+                rg_[e] = fmaf(dd, v, rg_[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * rg + e;
+            const bool on = h2[i * LD + k] > 0.0f;
+            d2[i * LD + k] = on ? g[e] : 0.0f;
+            rd2[i * LD + k] = on ? rg_[e] : 0.0f;
+        }
+    }
+    __syncthreads();
+    // ---- R{dz1} = relu'(z1) (R{dz2} W2 + dz2 V2)
+    {
+        f32x4 acc[NH];
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) acc[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mma_cols_n<H, NH>(rd2, P + no.W2, wave, li, q, acc);
+        mma_cols_n<H, NH>(d2, V + no.W2, wave, li, q, acc);
+        float* __restrict__ RD1 = a.RD1 + base;
+        const int col = wave * 16 + li;
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * hf + 4 * q + r;
+                RD1[(size_t)i * H + col] = (h1[i * LD + col] > 0.0f) ? acc[hf][r] : 0.0f;
+            }
+        }
+    }
+    // ---- the remaining operands of the weight-side products
+    for (int e = tid; e < R * H4; e += NT) {
+        const int i = e / H4, c4 = e - i * H4;
+        const size_t o = base + (size_t)i * H + 4 * c4;
+        const int l = i * LD + 4 * c4;
+        *reinterpret_cast<f32x4*>(a.RD2 + o) = *reinterpret_cast<const f32x4*>(&rd2[l]);
+        if constexpr (!CACHED) *reinterpret_cast<f32x4*>(a.D2 + o) = *reinterpret_cast<const f32x4*>(&d2[l]);
+    }
+    for (int e = tid; e < R * FSRL_DOW; e += NT) {
+        a.RDO[(size_t)row0 * FSRL_DOW + e] = sm.rdout[e];
+        if constexpr (!CACHED) a.DO[(size_t)row0 * FSRL_DOW + e] = sm.dout[e];
+    }
+}
+
+// Mixed-height grid: blocks [0, n32) take 32-row tiles, the rest 16-row tiles behind them (host: hvp_plan): the tile
+// counts are chosen so that the LAST round of workgroups is a round of the cheap tiles (N = 20 000 on 256 CUs: 512 x 32
+// rows = two full rounds, then 226 x 16 rows, instead of 625 x 32 rows = two rounds and a 44 %-full third).
+template <int H, bool CACHED>
+__global__ __launch_bounds__(4 * H) void fb_hvp_mixed_kernel(const float* __restrict__ P, const ModelDesc md, const HvpArgs a,
+                                                            const int n32) {
+    __shared__ Hvp32Smem<H> sm;
+    const int b = blockIdx.x;
+    if (b < n32) hvp_tile_body<H, CACHED, 2>(sm, P, md, a, 32 * b);
+    else hvp_tile_body<H, CACHED, 1>(sm, P, md, a, 32 * n32 + 16 * (b - n32));
 }
 
 // ------------------------------------------------------------------------------------------

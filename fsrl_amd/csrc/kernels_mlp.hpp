@@ -20,17 +20,24 @@
 #pragma once
 #include "common.hpp"
 
-template <int H>
+// rows a tile of R rows needs room for: 4-, 8- and 16-row tiles share the 16-row layout, a 32-row tile (two 16-row MFMA
+// passes per weight fragment: half the L2 -> register weight traffic per row) has its own
+__host__ __device__ constexpr int tile_rows(int R) { return R > 16 ? R : 16; }
+
+template <int H, int ROWS = 16>
 struct TileSmem {
     static constexpr int LD = H + 4;  // +4 floats: rows land on different banks, b128-aligned
-    float xT[FSRL_MAX_OBS * 16];      // obs tile transposed [k][i]
-    float h1[16 * LD];
-    float h2[16 * LD];
-    float d2[16 * LD];                // dL/dz2 (after ReLU mask)
-    float out[16 * FSRL_MAX_ACT];     // head pre-activation [i][o]
-    float dout[16 * FSRL_DOW];        // [i][0..16) dL/dout, [i][16..32) dL/dsigma_param rows
-    float rd[16 * FSRL_RD];           // per-row loss inputs (act, logp_old, adv_n, ret)
-    float st[16 * 4];                 // per-row partial stats
+    // observation columns held: a 32-row tile of a 256-wide network sits at 158 KB of the CU's 160 KB with 64 columns
+    // (the hosts select 32-row tiles only for obs_dim <= 64)
+    static constexpr int XK = (ROWS > 16) ? 64 : FSRL_MAX_OBS;
+    float xT[XK * ROWS];              // obs tile transposed [k][i]
+    float h1[ROWS * LD];
+    float h2[ROWS * LD];
+    float d2[ROWS * LD];              // dL/dz2 (after ReLU mask)
+    float out[ROWS * FSRL_MAX_ACT];   // head pre-activation [i][o]
+    float dout[ROWS * FSRL_DOW];      // [i][0..16) dL/dout, [i][16..32) dL/dsigma_param rows
+    float rd[ROWS * FSRL_RD];         // per-row loss inputs (act, logp_old, adv_n, ret)
+    float st[ROWS * 4];               // per-row partial stats
     // small parameters staged once per tile (one burst at kernel entry)
     float w3[FSRL_MAX_ACT * H];
     float b1[H], b2[H], b3[FSRL_MAX_ACT], sig[FSRL_MAX_ACT];
@@ -64,11 +71,11 @@ struct FwdW2Frag {
 // Straight-line code: every load is unconditional on a clamped index and masked afterwards (a predicated load
 // compiles to an exec-mask branch: the first version of this prologue had ~30 of them and three integer divisions by
 // the runtime obs_dim, and took 2 900 shader cycles -- 1.2 us -- just to ISSUE its loads; tools/tstamp_probe.py).
-template <int H>
+template <int H, int ROWS = 16>
 struct TileStage {
     static constexpr int NT = TileGeom<H>::NT;
-    static constexpr int NX = (16 * FSRL_MAX_OBS + NT - 1) / NT;   // obs elements per thread
-    static constexpr int NR = (16 * FSRL_RD + NT - 1) / NT;        // row-data elements per thread
+    static constexpr int NX = (ROWS * TileSmem<H, ROWS>::XK + NT - 1) / NT;   // obs elements per thread
+    static constexpr int NR = (ROWS * FSRL_RD + NT - 1) / NT;                // row-data elements per thread
     float xv[NX], w3v[4], w1v[4], rdv[NR], b1v, b2v, b3v, sgv;
 
     __device__ __forceinline__ void issue(const float* __restrict__ P, const NetOff no, const int Do,
@@ -108,16 +115,16 @@ struct TileStage {
         sgv = (no.sigma >= 0 && tid < Da) ? t4 : 0.0f;
     }
 
-    __device__ __forceinline__ void commit(TileSmem<H>& sm, const NetOff no, const int Do,
+    __device__ __forceinline__ void commit(TileSmem<H, ROWS>& sm, const NetOff no, const int Do,
                                            const int tid) const {
         // e -> (row i, column k) = (e / Do, e % Do) by a multiply-high with ceil(2^32 / Do): exact for e < 2^16
         const unsigned magic = 0xFFFFFFFFu / (unsigned)Do + 1u;
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
             const int e = tid + u * NT;
-            if (e < 16 * Do) {
+            if (e < ROWS * Do) {
                 const int i = (int)__umulhi((unsigned)e, magic), k = e - i * Do;
-                sm.xT[k * 16 + i] = xv[u];
+                sm.xT[k * ROWS + i] = xv[u];
             }
         }
 #pragma unroll
@@ -129,7 +136,7 @@ struct TileStage {
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
             const int e = tid + u * NT;
-            if (e < 16 * FSRL_RD) sm.rd[e] = rdv[u];
+            if (e < ROWS * FSRL_RD) sm.rd[e] = rdv[u];
         }
         if (tid < H) { sm.b1[tid] = b1v; sm.b2[tid] = b2v; }
         if (tid < FSRL_MAX_ACT) { sm.b3[tid] = b3v; sm.sig[tid] = sgv; }
@@ -143,12 +150,16 @@ struct TileStage {
 // rate with a quarter of the rows, for launches whose 16-row tiles would leave most CUs idle).  The
 // 4-row variant uses the SAME W2 fragment: the 16 blocks of the instruction are (q = k-class, 4
 // column quads), each q-class accumulates its quarter of K and the classes are added at the end.
+// R = 32: two 16-row MFMA passes per weight fragment (the fragment registers are the same; the per-element K order is
+// the 16-row tile's, so a row's result does not depend on the tile height).
 template <int H, int R = 16>
-__device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __restrict__ P,
+__device__ __forceinline__ void tile_forward(TileSmem<H, tile_rows(R)>& sm, const float* __restrict__ P,
                                              const NetOff no, const int Do, const int tid,
                                              const FwdW2Frag<H>& wf, unsigned long long* ts = nullptr) {
     constexpr int LD = TileSmem<H>::LD;
     constexpr int WAVES = TileGeom<H>::WAVES;
+    constexpr int ROWS = tile_rows(R);
+    constexpr int NT = TileGeom<H>::NT;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
 
     // ---- layer 1.  Do <= FSRL_W1_LDS: W1 sits in LDS, plain FMA, thread = (column j, group of 4
@@ -156,14 +167,14 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
     //      W1 fetched in ONE burst of <= 16 independent loads per 64 inputs -- a k-loop of dependent
     //      global loads cost one L2 round trip per input (measured: 20 us of a 27 us kernel).
     if (Do <= FSRL_W1_LDS) {
-        if (tid < (R / 4) * H) {            // thread = (column j, group of 4 rows): R / 4 row groups
-            const int j = tid % H, rg = tid / H;
+        for (int t = tid; t < (R / 4) * H; t += NT) {   // thread = (column j, group of 4 rows): R / 4 row groups (one trip up to 16 rows)
+            const int j = t % H, rg = t / H;
             const float b = sm.b1[j];
             float acc[4] = {b, b, b, b};
             const float* __restrict__ w = &sm.w1[j * Do];
             for (int k = 0; k < Do; ++k) {
                 const float wk = w[k];
-                const f32x4 x = *reinterpret_cast<const f32x4*>(&sm.xT[k * 16 + 4 * rg]);
+                const f32x4 x = *reinterpret_cast<const f32x4*>(&sm.xT[k * ROWS + 4 * rg]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] = fmaf(x[e], wk, acc[e]);
             }
@@ -171,9 +182,9 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
             for (int e = 0; e < 4; ++e) sm.h1[(4 * rg + e) * LD + j] = fmaxf(acc[e], 0.0f);
         }
     } else {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc8 = {0.f, 0.f, 0.f, 0.f};     // acc8: rows 4..7 of an 8-row tile
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc8 = {0.f, 0.f, 0.f, 0.f};     // acc8: rows 4..7 of an 8-row tile / rows 16..31 of a 32-row tile
         const float* __restrict__ wrow = P + no.W1 + (size_t)(wave * 16 + li) * Do;
-        const int arow = (R == 16) ? li : (lane & 3);
+        const int arow = (R >= 16) ? li : (lane & 3);
         for (int k0 = 0; k0 < Do; k0 += 64) {
             float b[16];
 #pragma unroll
@@ -185,16 +196,17 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
             for (int s = 0; s < 16; ++s) {
                 const int k = k0 + 4 * s + q;
                 if (k0 + 4 * s < Do) {
-                    const float a = (k < Do) ? sm.xT[k * 16 + arow] : 0.0f;
-                    if constexpr (R == 16) acc = mfma_16x16x4(a, b[s], acc);
+                    const float a = (k < Do) ? sm.xT[k * ROWS + arow] : 0.0f;
+                    if constexpr (R >= 16) acc = mfma_16x16x4(a, b[s], acc);
                     else acc = mfma_4x4x1(a, b[s], acc);
-                    if constexpr (R == 8) acc8 = mfma_4x4x1((k < Do) ? sm.xT[k * 16 + 4 + arow] : 0.0f, b[s], acc8);
+                    if constexpr (R == 8) acc8 = mfma_4x4x1((k < Do) ? sm.xT[k * ROWS + 4 + arow] : 0.0f, b[s], acc8);
+                    if constexpr (R == 32) acc8 = mfma_16x16x4((k < Do) ? sm.xT[k * ROWS + 16 + arow] : 0.0f, b[s], acc8);
                 }
             }
         }
         const int j = wave * 16 + li;
         const float bias = sm.b1[j];
-        if constexpr (R != 16) {
+        if constexpr (R < 16) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 acc[r] += __shfl_xor(acc[r], 16, 64);
@@ -210,14 +222,17 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sm.h1[(4 * q + r) * LD + j] = fmaxf(acc[r] + bias, 0.0f);
+            for (int r = 0; r < 4; ++r) {
+                sm.h1[(4 * q + r) * LD + j] = fmaxf(acc[r] + bias, 0.0f);
+                if constexpr (R == 32) sm.h1[(16 + 4 * q + r) * LD + j] = fmaxf(acc8[r] + bias, 0.0f);
+            }
         }
     }
     __syncthreads();
     FSRL_TS(ts, 3);
 
     // ---- layer 2: h2[R,H] = relu(h1[R,H] @ W2^T + b2) on MFMA (fp32)
-    if constexpr (R != 16) {          // 4 rows per v_mfma_f32_4x4x1 pass; an 8-row tile runs two passes on the same fragments
+    if constexpr (R < 16) {           // 4 rows per v_mfma_f32_4x4x1 pass; an 8-row tile runs two passes on the same fragments
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc8 = {0.f, 0.f, 0.f, 0.f};
         const float* arow = &sm.h1[(lane & 3) * LD + 4 * q];
 #pragma unroll
@@ -248,18 +263,26 @@ __device__ __forceinline__ void tile_forward(TileSmem<H>& sm, const float* __res
             }
         }
     } else {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};     // acc2: rows 16..31 of a 32-row tile
         const float* arow = &sm.h1[li * LD + 4 * q];
 #pragma unroll
         for (int kc = 0; kc < H / 16; ++kc) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * kc);
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = mfma_16x16x4(a[s], wf.b[kc][s], acc);
+            if constexpr (R == 32) {
+                const f32x4 a2 = *reinterpret_cast<const f32x4*>(arow + 16 * LD + 16 * kc);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc2 = mfma_16x16x4(a2[s], wf.b[kc][s], acc2);
+            }
         }
         const int j = wave * 16 + li;
         const float bias = sm.b2[j];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sm.h2[(4 * q + r) * LD + j] = fmaxf(acc[r] + bias, 0.0f);
+        for (int r = 0; r < 4; ++r) {
+            sm.h2[(4 * q + r) * LD + j] = fmaxf(acc[r] + bias, 0.0f);
+            if constexpr (R == 32) sm.h2[(16 + 4 * q + r) * LD + j] = fmaxf(acc2[r] + bias, 0.0f);
+        }
     }
     __syncthreads();
     FSRL_TS(ts, 5);

@@ -259,6 +259,13 @@ int fsrl_tr_grad(fsrl_ctx* ctx, int32_t which, float* out, int64_t n);
 int fsrl_tr_hvp(fsrl_ctx* ctx, const float* v, float* out, int64_t n);
 /* stats8: mean(ratio*A_r), mean(ratio*A_c), mean KL, mean(logp_old - logp), mean A_r, mean A_c, 0, 0 */
 int fsrl_tr_eval(fsrl_ctx* ctx, double* stats8);
+/* Kernel plan of the full-batch path, for A/B timing and the bit-identity tests (no reference counterpart: the reference
+ * has one code path).  tile_rows: 0 = automatic (mixed 32- / 16-row tiles where the batch spans more than one round of
+ * workgroups), 16 = 16-row tiles only.  hvp: 0 = automatic (mixed tiles; the theta-only activations of the KL Hessian
+ * product are computed by the first product of a conjugate-gradient solve and read back by the others: cpo.py:184-204
+ * calls _MVP 10 + 1 times per right-hand side at one theta), 1 = the 16-row kernel that recomputes everything,
+ * 2 = mixed tiles without the cache.  All plans give bit-identical results.                                        */
+int fsrl_tr_set_plan(fsrl_ctx* ctx, int32_t tile_rows, int32_t hvp);
 
 /* ---- FOCOPS (fsrl/policy/focops.py:126-251), on the PPO entry points: create the context
  *      with algo = FSRL_ALGO_FOCOPS (same networks and parameter vector as PPO-Lag), call fsrl_focops_init once,

@@ -268,3 +268,50 @@ def test_hessian_vector_product_properties_at_full_size():
     eng.set_params(moved)
     check("moved")
     eng.close()
+
+
+@pytest.mark.parametrize("obs_dim,hid,T", [(60, 256, 1000), (8, 256, 300), (24, 128, 700)])
+def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
+    """The full-batch path's three kernel plans (fsrl_tr_set_plan) must agree BIT FOR BIT: 16-row tiles + the HVP kernel
+    that recomputes everything (round 2's path) | mixed 32- / 16-row tiles without the HVP cache | mixed tiles + the
+    theta-only activations of the KL Hessian product computed once per conjugate-gradient solve and read back (default).
+    A row's arithmetic does not depend on its tile's height, relu'(z) is read off h > 0, and the per-tile statistics keep
+    their 16-row slots.  Checked on the building blocks (three gradients, line-search statistics, one HVP) and on whole
+    CPO / TRPO-Lag updates of two repeats (22 + 11 HVPs per repeat through the cached kernel)."""
+    from fsrl_amd.engine import Engine, EngineConfig
+    envs = 20
+    rng = np.random.default_rng(11)
+    obs, act, rew, cost, term, trunc = _inputs(rng, envs, T, obs_dim, 2, 250)
+    eng = Engine(EngineConfig(obs_dim=obs_dim, act_dim=2, hidden=hid, env_num=envs, target_kl=None, lr=1e-3))
+    ids = np.arange(envs)
+    for t in range(T):
+        eng.push(ids, obs[t], act[t], rew[t], cost[t], term[t], trunc[t], obs[t + 1])
+    theta = (0.1 * np.random.default_rng(3).standard_normal(eng.n_params)).astype(np.float32)
+    v = np.random.default_rng(4).standard_normal(eng.n_actor_params).astype(np.float32)
+
+    def run(tile_rows, hvp):
+        out = {}
+        eng.tr_set_plan(tile_rows, hvp)
+        eng.set_params(theta); eng.optim_reset()
+        assert eng.tr_begin(target_kl=0.01, l2_reg=0.001, critic_lr=1e-3, max_backtracks=10, optim_critic_iters=3,
+                            cost_limit=10.0) == envs * T
+        for w in range(3):
+            out[f"grad{w}"] = eng.tr_grad(w)
+        out["eval"] = eng.tr_eval()
+        out["hvp"] = eng.tr_hvp(v)
+        out["cpo"] = eng.cpo_learn(25.0, 2).copy()
+        out["theta_cpo"] = eng.get_params().copy()
+        eng.set_params(theta); eng.optim_reset()
+        eng.tr_begin(target_kl=0.001, critic_lr=1e-3, max_backtracks=10, optim_critic_iters=3)
+        out["trpo"] = eng.trpo_learn([0.4], 1 / 1.4, 2).copy()
+        out["theta_trpo"] = eng.get_params().copy()
+        return out
+
+    ref = run(16, 1)
+    assert np.isfinite(ref["cpo"]).all() and np.isfinite(ref["trpo"]).all() and np.abs(ref["hvp"]).max() > 0
+    for plan in ((0, 2), (0, 0), (16, 0)):
+        got = run(*plan)
+        for k in ref:
+            assert np.array_equal(ref[k], got[k]), (plan, k, np.abs(np.asarray(ref[k], np.float64) - got[k]).max())
+    eng.tr_set_plan(0, 0)
+    eng.close()

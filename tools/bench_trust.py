@@ -57,6 +57,10 @@ def run(kind, obs_dim, act_dim, hid, envs=20, T=1000, ep=1000, repeat=4, cpu_rep
         eng.push(ids, obs[t], act[t], rew[t], cost[t], term[t], trunc[t], obs[t + 1])
     eng.sync()
 
+    plan = os.environ.get("FSRL_TR_PLAN")                  # "tile_rows,hvp" (fsrl_tr_set_plan): A/B of the kernel plans
+    if plan:
+        eng.tr_set_plan(*[int(x) for x in plan.split(",")])
+
     def device_update():
         # every timed update is the same workload: initial weights AND a fresh optimiser state -- round 1 restored the
         # weights only, so the critics' Adam moments of the previous update leaked into the next one and the reported
