@@ -141,6 +141,7 @@ struct fsrl_ctx {
     struct Parts { int stride = 0; float* p = nullptr; size_t floats = 0; } parts[3];
     float* wg_parts = nullptr;      // the buffer the last wgrad_launch wrote
     int n_cus = 256;                // compute units of the device (tile-shape heuristic)
+    bool wgrad_xcd = false;         // fb_wgrad_kernel: XCD-aware placement of the splits (fsrl_tr_set_plan)
     struct FocState* foc = nullptr; // FOCOPS working set, owned
     float* mu_old = nullptr;        // [maxsize][Da] actor means at process time (FOCOPS)
     float* sigma_old = nullptr;     // [FSRL_MAX_ACT] sigma_param at process time (FOCOPS)
@@ -239,6 +240,10 @@ static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int n
     return dispatch_H(c->cfg.hidden, [&](auto hc) {
         constexpr int HH = decltype(hc)::value;
         constexpr int NB = (HH / 64) * (HH / 64) + HH / 32 + 1;   // 64x64 dW2 tiles + 32-column aux blocks + db3 block
+        if (c->wgrad_xcd) {
+            wa.remap_total = NB * ny * pl.nsplit; wa.remap_ny = ny;
+            hipLaunchKernelGGL((fb_wgrad_kernel<HH, PAIR2>), dim3(round_up(wa.remap_total, 8)), dim3(1024), 0, c->compute, md, wa);
+        } else
         hipLaunchKernelGGL((fb_wgrad_kernel<HH, PAIR2>), dim3(NB, ny, pl.nsplit), dim3(1024), 0, c->compute, md, wa);
         HIPCHK(hipGetLastError());
         return 0;

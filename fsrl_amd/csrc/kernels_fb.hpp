@@ -930,6 +930,11 @@ struct FbWgradArgs {
     int ks_per_split;    // k-steps (4 rows each) per blockIdx.z
     int split_stride;    // floats between the partial gradients of consecutive splits
     int dbg_skip;        // timing experiments: bit0 skip dW2 tiles, bit1 skip aux blocks, bit2 skip the db3 block
+    // XCD-aware placement (0 = off: 3-D grid as is).  Else the grid is 1-D, padded to a multiple of 8, and carries
+    // remap_total logical blocks in the order (block of a split, network, split): hardware block L runs on XCD L % 8
+    // (observed placement, used for speed only), so logical block (L % 8) * (grid / 8) + L / 8 puts CONSECUTIVE logical
+    // blocks -- the blocks of one split, which stream the same rows -- behind one L2.
+    int remap_total, remap_ny;
 };
 
 // one pass of an aux block of fb_wgrad_kernel over its rows: NCH 16-column chunks of dW1 (columns k0 ..), and with FIRST the
@@ -1077,12 +1082,21 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
     constexpr int SLOT = 64 * 65;           // one 64 x 64 partial tile (+1 column of padding)
     __shared__ float red[4 * SLOT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const FbWgradNet wn = wa.nets[blockIdx.y];
+    int rb = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (wa.remap_total) {
+        const int L = blockIdx.x, per = gridDim.x >> 3;
+        const int Lp = (L & 7) * per + (L >> 3);
+        if (Lp >= wa.remap_total) return;
+        constexpr int NB = (H / 64) * (H / 64) + H / 32 + 1;
+        rb = Lp % NB;
+        const int g = Lp / NB;
+        by = g % wa.remap_ny; bz = g / wa.remap_ny;
+    }
+    const FbWgradNet wn = wa.nets[by];
     const NetOff no = md.net[wn.net];
-    const int rb = blockIdx.x;
-    const int KS0 = blockIdx.z * wa.ks_per_split;
+    const int KS0 = bz * wa.ks_per_split;
     const int KS = min(wa.rows >> 2, KS0 + wa.ks_per_split);     // this split's k-step range [KS0, KS)
-    float* __restrict__ gout = wa.out + (size_t)blockIdx.z * wa.split_stride;
+    float* __restrict__ gout = wa.out + (size_t)bz * wa.split_stride;
     const int c = lane & 15, q = lane >> 4;
     const int Do = md.Do, out = no.out;
 
@@ -1357,6 +1371,104 @@ __global__ __launch_bounds__(256) void cg_p_kernel(const float* __restrict__ r, 
         if (mi >= 0) *reinterpret_cast<f32x4*>(p + mi) = pi;
     }
     if (blockIdx.x == 0 && tid == 0) { sc->rs[(it + 1) & 1] = rs_new; sc->iters = it + 1; }
+}
+
+// ---- flat-vector algebra of the trust-region updates on the device (actor layout, length n = md.net[0].end, padding zero).
+// Round 2 kept g, b, H^-1 g, H^-1 b, the step direction and the line-search parameters on the host: every HVP outside CG, every
+// line-search evaluation and every gradient cost a stream drain, a repack of 8e4 floats and two synchronous copies -- 6 ms of
+// a 45 ms CPO update were GPU idle time.  The expressions are the host's (float32 element-wise, no contraction; float64
+// accumulation of the dot products, rounded once), so results move only by the order of the float64 sums.
+struct TrDotArgs { const float* a[4]; const float* b[4]; int n_pairs; };
+// partial sums of up to four dot products: part[pair * CG_NB + block]
+__global__ __launch_bounds__(256) void tr_dots_kernel(const TrDotArgs da, double* __restrict__ part, int n) {
+    __shared__ double sh[4];
+    const int tid = threadIdx.x;
+    for (int k = 0; k < da.n_pairs; ++k) {
+        const float* __restrict__ a = da.a[k];
+        const float* __restrict__ b = da.b[k];
+        double acc = 0.0;
+        for (int i4 = (blockIdx.x * 256 + tid) * 4; i4 < n; i4 += CG_NB * 1024) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(a + i4), y = *reinterpret_cast<const f32x4*>(b + i4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc += (double)x[e] * (double)y[e];
+        }
+        const double t = cg_block_sum256(acc, sh, tid);
+        if (tid == 0) part[k * CG_NB + blockIdx.x] = t;
+        __syncthreads();
+    }
+}
+// dst = src (+ the W2 mirror when `mirror`): a gradient / solution vector becomes the tangent the HVP kernels read
+__global__ __launch_bounds__(256) void tr_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, int n, int mirror,
+                                                     float scale, const ModelDesc md) {
+    for (int i4 = (blockIdx.x * 256 + threadIdx.x) * 4; i4 < n; i4 += CG_NB * 1024) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(src + i4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * scale;
+        *reinterpret_cast<f32x4*>(dst + i4) = v;
+        if (mirror) {
+            const int mi = w2f_mirror_of(md, i4);
+            if (mi >= 0) *reinterpret_cast<f32x4*>(dst + mi) = v;
+        }
+    }
+}
+// out = hz + v * damping    (cpo.py:182: _MVP + damping_coeff * v)
+__global__ __launch_bounds__(256) void tr_damp_kernel(float* __restrict__ out, const float* __restrict__ hz,
+                                                     const float* __restrict__ v, float damping, int n) {
+#pragma clang fp contract(off)
+    for (int i4 = (blockIdx.x * 256 + threadIdx.x) * 4; i4 < n; i4 += CG_NB * 1024) {
+        const f32x4 h = *reinterpret_cast<const f32x4*>(hz + i4), x = *reinterpret_cast<const f32x4*>(v + i4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = h[e] + x[e] * damping;
+        *reinterpret_cast<f32x4*>(out + i4) = o;
+    }
+}
+// CPO step direction (cpo.py:306-310): dir = combined ? inv_lam * (Hg + nu * Hb) : nu * Hb ; partial dir.dir
+__global__ __launch_bounds__(256) void tr_dir_kernel(float* __restrict__ dir, const float* __restrict__ Hg,
+                                                    const float* __restrict__ Hb, float inv_lam, float nu, int combined,
+                                                    double* __restrict__ part, int n) {
+#pragma clang fp contract(off)
+    __shared__ double sh[4];
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    for (int i4 = (blockIdx.x * 256 + tid) * 4; i4 < n; i4 += CG_NB * 1024) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(Hg + i4), b = *reinterpret_cast<const f32x4*>(Hb + i4);
+        f32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            d[e] = combined ? inv_lam * (g[e] + nu * b[e]) : nu * b[e];
+            acc += (double)d[e] * (double)d[e];
+        }
+        *reinterpret_cast<f32x4*>(dir + i4) = d;
+    }
+    const double t = cg_block_sum256(acc, sh, tid);
+    if (tid == 0) part[blockIdx.x] = t;
+}
+// dir /= sqrt(dir.dir)   (cpo.py:310: the unit-norm step direction)
+__global__ __launch_bounds__(256) void tr_unit_kernel(float* __restrict__ dir, const double* __restrict__ part, int n) {
+    __shared__ double sh[4];
+    const int tid = threadIdx.x;
+    const float nrm = sqrtf(cg_sum_parts(part, sh, tid));
+    for (int i4 = (blockIdx.x * 256 + tid) * 4; i4 < n; i4 += CG_NB * 1024) {
+        f32x4 d = *reinterpret_cast<f32x4*>(dir + i4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = d[e] / nrm;
+        *reinterpret_cast<f32x4*>(dir + i4) = d;
+    }
+}
+// line-search candidate written straight into the parameters (+ W2 mirror): theta = coef * dir + theta0
+__global__ __launch_bounds__(256) void tr_step_kernel(float* __restrict__ P, const float* __restrict__ theta0,
+                                                     const float* __restrict__ dir, float coef, int n, const ModelDesc md) {
+#pragma clang fp contract(off)
+    for (int i4 = (blockIdx.x * 256 + threadIdx.x) * 4; i4 < n; i4 += CG_NB * 1024) {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(theta0 + i4), d = *reinterpret_cast<const f32x4*>(dir + i4);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = coef * d[e] + t0[e];
+        *reinterpret_cast<f32x4*>(P + i4) = v;
+        const int mi = w2f_mirror_of(md, i4);
+        if (mi >= 0) *reinterpret_cast<f32x4*>(P + mi) = v;
+    }
 }
 
 // ---- FOCOPS: logged statistics of one minibatch step (focops.py:161-215, 232-241) and the pass-level KL sum

@@ -369,9 +369,9 @@ class Engine:
         _lib.check(self.lib.fsrl_tr_hvp(self._ctx, _ptr(v, _f32p), _ptr(out, _f32p), v.size))
         return out
 
-    def tr_set_plan(self, tile_rows: int = 0, hvp: int = 0):
+    def tr_set_plan(self, tile_rows: int = 0, hvp: int = 0, wgrad: int = 0):
         """Kernel plan of the full-batch path (A/B timing, bit-identity tests); 0 / 0 = automatic."""
-        _lib.check(self.lib.fsrl_tr_set_plan(self._ctx, int(tile_rows), int(hvp)))
+        _lib.check(self.lib.fsrl_tr_set_plan(self._ctx, int(tile_rows), int(hvp), int(wgrad)))
 
     def tr_eval(self):
         out = np.zeros(8, np.float64)

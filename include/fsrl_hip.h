@@ -264,8 +264,9 @@ int fsrl_tr_eval(fsrl_ctx* ctx, double* stats8);
  * workgroups), 16 = 16-row tiles only.  hvp: 0 = automatic (mixed tiles; the theta-only activations of the KL Hessian
  * product are computed by the first product of a conjugate-gradient solve and read back by the others: cpo.py:184-204
  * calls _MVP 10 + 1 times per right-hand side at one theta), 1 = the 16-row kernel that recomputes everything,
- * 2 = mixed tiles without the cache.  All plans give bit-identical results.                                        */
-int fsrl_tr_set_plan(fsrl_ctx* ctx, int32_t tile_rows, int32_t hvp);
+ * 2 = mixed tiles without the cache.  wgrad: 1 = XCD-aware placement of the split-K weight-gradient blocks (the blocks
+ * of one row split behind one L2).  All plans give bit-identical results.                                          */
+int fsrl_tr_set_plan(fsrl_ctx* ctx, int32_t tile_rows, int32_t hvp, int32_t wgrad);
 
 /* ---- FOCOPS (fsrl/policy/focops.py:126-251), on the PPO entry points: create the context
  *      with algo = FSRL_ALGO_FOCOPS (same networks and parameter vector as PPO-Lag), call fsrl_focops_init once,

@@ -289,9 +289,9 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
     theta = (0.1 * np.random.default_rng(3).standard_normal(eng.n_params)).astype(np.float32)
     v = np.random.default_rng(4).standard_normal(eng.n_actor_params).astype(np.float32)
 
-    def run(tile_rows, hvp):
+    def run(tile_rows, hvp, wgrad=0):
         out = {}
-        eng.tr_set_plan(tile_rows, hvp)
+        eng.tr_set_plan(tile_rows, hvp, wgrad)
         eng.set_params(theta); eng.optim_reset()
         assert eng.tr_begin(target_kl=0.01, l2_reg=0.001, critic_lr=1e-3, max_backtracks=10, optim_critic_iters=3,
                             cost_limit=10.0) == envs * T
@@ -309,9 +309,9 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
 
     ref = run(16, 1)
     assert np.isfinite(ref["cpo"]).all() and np.isfinite(ref["trpo"]).all() and np.abs(ref["hvp"]).max() > 0
-    for plan in ((0, 2), (0, 0), (16, 0)):
+    for plan in ((0, 2), (0, 0), (16, 0), (0, 0, 1)):
         got = run(*plan)
         for k in ref:
             assert np.array_equal(ref[k], got[k]), (plan, k, np.abs(np.asarray(ref[k], np.float64) - got[k]).max())
-    eng.tr_set_plan(0, 0)
+    eng.tr_set_plan(0, 0, 0)
     eng.close()
