@@ -99,6 +99,8 @@ SIGNATURES = {
     "fsrl_tr_begin": (C.c_int, [_ctx, _P(TrConfig), _i64]),
     "fsrl_cpo_learn": (C.c_int, [_ctx, C.c_double, C.c_int32, _f]),
     "fsrl_trpo_learn": (C.c_int, [_ctx, _d, C.c_double, C.c_int32, _f]),
+    "fsrl_cpo_learn_mb": (C.c_int, [_ctx, C.c_double, C.c_int32, C.c_int32, _i64, C.c_uint64, _f, C.c_int64, _i64]),
+    "fsrl_trpo_learn_mb": (C.c_int, [_ctx, _d, C.c_double, C.c_int32, C.c_int32, _i64, C.c_uint64, _f, C.c_int64, _i64]),
     "fsrl_tr_linesearch_evals": (C.c_int32, [_ctx, _i32, C.c_int32]),
     "fsrl_actor_param_count": (C.c_int64, [_ctx]),
     "fsrl_tr_grad": (C.c_int, [_ctx, C.c_int32, _f, C.c_int64]),

@@ -1674,6 +1674,29 @@ __global__ void fb_rowdata_kernel(const FbRowArgs a) {
     }
 }
 
+// mean_old / std_old columns of n rows of row data := the given means and exp(sigma_param)
+__global__ void fb_rd_old_kernel(float* __restrict__ rd, const float* __restrict__ mean, const float* __restrict__ sigma,
+                                 int n, int Da) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * 32; e += gridDim.x * blockDim.x) {
+        const int r = e >> 5, f = e & 31;
+        float v = 0.0f;
+        if (f < Da) v = mean[(size_t)r * Da + f];
+        else if (f >= 16 && f < 16 + Da) v = expf(sigma[f - 16]);
+        rd[(size_t)r * FSRL_RD + FSRL_RD_MEAN + f] = v;         // MEAN [32, 48) and STD [48, 64) are adjacent
+    }
+}
+// Batch.split(shuffle=True) of the trust-region learn loops: row j of the permuted copy = row perm[j] of the batch
+__global__ void fb_gather_rows_kernel(float* __restrict__ obs_p, float* __restrict__ rd_p, const float* __restrict__ obs,
+                                      const float* __restrict__ rd, const int* __restrict__ perm, int n, int Do) {
+    const int per = Do + FSRL_RD;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < (long long)n * per; e += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(e / per), f = (int)(e - (long long)j * per);
+        const int r = perm[j];
+        if (f < Do) obs_p[(size_t)j * Do + f] = obs[(size_t)r * Do + f];
+        else rd_p[(size_t)j * FSRL_RD + f - Do] = rd[(size_t)r * FSRL_RD + f - Do];
+    }
+}
+
 // Adam on a parameter range with optional L2 term (CPO critics: loss += l2 * sum(theta^2)),
 // and the per-network sum of squares of the PRE-update parameters (for the logged vf loss).
 __global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ P, float* __restrict__ M,

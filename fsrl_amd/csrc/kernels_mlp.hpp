@@ -1108,7 +1108,8 @@ __global__ __launch_bounds__(1024) void ppo_wgrad_kernel(const ModelDesc md, con
 // k independent agents of one shape (multi-seed runs: SURVEY 8e "within-GPU batching of k seeds") step in lock step:
 // every launch of the minibatch step carries all members as grid.y.  One agent's step is a chain of dependent launches
 // whose fixed costs (launch floor, cold first touch of the freshly written parameters) dominate; k agents share each of
-// them.  The arithmetic per member is the single-agent body, inlined: grouped and one-by-one updates are bit-identical.
+// them.  The arithmetic per member is the single-agent body, inlined; grouped and one-by-one updates are bit-identical when
+// the tile shapes agree (a group of one, minibatches <= 512 rows) and within the golden tolerances otherwise.
 struct GroupAgent {          // per member; device memory, rewritten at the start of every grouped update
     const float* P;
     float *Pw, *M, *V, *G;

@@ -378,17 +378,36 @@ class Engine:
         _lib.check(self.lib.fsrl_tr_eval(self._ctx, _ptr(out, _f64p)))
         return out
 
-    def cpo_learn(self, ave_cost_return: float, repeat: int):
-        out = np.empty((repeat, _lib.CPO_NSTATS), np.float32)
-        _lib.check(self.lib.fsrl_cpo_learn(self._ctx, float(ave_cost_return), int(repeat), _ptr(out, _f32p)))
-        return out
+    def _tr_perms(self, perms, repeat, batch_size):
+        """perms: None or [repeat][N] -> (pointer or None, keep-alive array, minibatches per repeat)"""
+        n = max(int(self._n), 0)
+        b = max(1, min(int(batch_size), max(n, 1)))
+        nmb = max(1, n // b) if n else 1                # Batch.split(merge_last=True): the remainder joins the last chunk
+        if perms is None:
+            return None, None, nmb
+        a = np.ascontiguousarray(np.stack([np.asarray(p, np.int64) for p in perms]), np.int64)
+        assert a.shape == (repeat, n), "perms must be [repeat][N]"
+        return _ptr(a, _i64p), a, nmb
 
-    def trpo_learn(self, lagrangians, rescaling: float, repeat: int):
+    def cpo_learn(self, ave_cost_return: float, repeat: int, batch_size: int = 2**31 - 1, perms=None, seed: int = 0):
+        """CPO.learn (cpo.py:353-370) on the batch of the last tr_begin.  batch_size < N: Batch.split minibatches of the
+        permutations `perms` ([repeat][N]; None = library shuffle), one stats row per minibatch."""
+        pp, keep, nmb = self._tr_perms(perms, repeat, batch_size)
+        out = np.empty((repeat * nmb, _lib.CPO_NSTATS), np.float32)
+        rows = C.c_int64()
+        _lib.check(self.lib.fsrl_cpo_learn_mb(self._ctx, float(ave_cost_return), int(repeat), int(min(batch_size, 2**31 - 1)), pp,
+                                              int(seed), _ptr(out, _f32p), out.shape[0], C.byref(rows)))
+        return out[:rows.value]
+
+    def trpo_learn(self, lagrangians, rescaling: float, repeat: int, batch_size: int = 2**31 - 1, perms=None, seed: int = 0):
         lag = np.ascontiguousarray(lagrangians, np.float64).reshape(-1)
-        out = np.empty((repeat, _lib.TRPO_NSTATS), np.float32)
-        _lib.check(self.lib.fsrl_trpo_learn(self._ctx, _ptr(lag, _f64p) if lag.size else None,
-                                            float(rescaling), int(repeat), _ptr(out, _f32p)))
-        return out
+        pp, keep, nmb = self._tr_perms(perms, repeat, batch_size)
+        out = np.empty((repeat * nmb, _lib.TRPO_NSTATS), np.float32)
+        rows = C.c_int64()
+        _lib.check(self.lib.fsrl_trpo_learn_mb(self._ctx, _ptr(lag, _f64p) if lag.size else None, float(rescaling), int(repeat),
+                                               int(min(batch_size, 2**31 - 1)), pp, int(seed), _ptr(out, _f32p), out.shape[0],
+                                               C.byref(rows)))
+        return out[:rows.value]
 
     # ---------------------------------------------------------------- SAC-Lagrangian
     def sac_init(self, actor_lr=5e-4, critic_lr=1e-3, alpha_lr=3e-4, tau=0.05, alpha=0.005,

@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from fsrl_amd.policy.base_policy import BasePolicy
+from fsrl_amd.policy.trpo_lag import _split_sizes
 
 CPO_ACTOR_KEYS = ("loss/kl", "loss/entropy", "loss/rew_loss", "loss/cost_loss", "loss/optim_A",
                   "loss/optim_B", "loss/optim_C", "loss/optim_Q", "loss/optim_R", "loss/optim_S",
@@ -73,15 +74,22 @@ class CPO(BasePolicy):
                          damping=self._damping_coeff, l2_reg=self._l2_reg, critic_lr=g["lr"],
                          max_backtracks=self._max_backtracks, optim_critic_iters=self._optim_critic_iters,
                          cg_iters=10, norm_adv=self._norm_adv, cost_limit=float(self._cost_limit))
-        assert n <= batch_size, "CPO on the HIP path is full-batch (reference default batch_size=99999)"
-        stats = eng.cpo_learn(float(self._ave_cost_return), repeat) if n > 0 else np.zeros((0, 17), np.float32)
+        # Batch.split(batch_size, merge_last=True) inside learn (cpo.py:357-358) draws one np.random.permutation per repeat
+        # from numpy's global stream -- also when one minibatch covers the batch (then the order only moves sums and the
+        # device keeps store order)
+        perms = [np.random.permutation(n) for _ in range(repeat)] if n > 0 else None
+        sizes = _split_sizes(n, batch_size)
+        stats = (eng.cpo_learn(float(self._ave_cost_return), repeat, batch_size=batch_size,
+                               perms=perms if len(sizes) > 1 else None) if n > 0 else np.zeros((0, 17), np.float32))
         for row in stats:
             self.gradient_steps += 1
             self.logger.store(**dict(zip(CPO_ACTOR_KEYS, (float(v) for v in row[:14]))))
             self.logger.store(**dict(zip(CPO_CRITIC_KEYS, (float(v) for v in row[14:]))))
         self.logger.store(gradient_steps=self.gradient_steps, tab="update")
-        if n > 0:   # process_fn: one forward; per repeat: 1 forward(s) + one per line-search evaluation
-            self._burn(n, 1 + 1 * len(stats) + int(eng.tr_linesearch_evals().sum()))
+        if n > 0:   # process_fn: one forward over the batch; per minibatch: 1 forward(s) + one per line-search evaluation
+            self._burn(n, 1)
+            for rows, ev in zip(sizes * repeat, eng.tr_linesearch_evals(cap=len(stats) + 1)):
+                self._burn(rows, 1 + int(ev))
         self._mark_stale()                                       # host mirror refreshed on demand
         self._step_lr_scheduler()
         self.updating = False

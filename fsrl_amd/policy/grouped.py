@@ -21,6 +21,9 @@ class PolicyGroup:
     def __init__(self, policies: Sequence[PPOLagrangian], seed: int = 1):
         self.policies = list(policies)
         assert all(isinstance(p, PPOLagrangian) for p in self.policies), "grouped updates: PPOLagrangian policies"
+        # PPOLagrangian(reference_rng=True) burns the torch draws the reference wastes inside update(); a grouped update has no
+        # single-policy random stream to follow
+        assert not any(getattr(p, "_reference_rng", False) for p in self.policies), "reference_rng policies cannot be grouped"
         self.group = EngineGroup([p.engine for p in self.policies])
         self._seed, self._calls = int(seed), 0
 
@@ -32,12 +35,19 @@ class PolicyGroup:
         for p, b in zip(pols, buffers):
             assert getattr(b, "engine", None) is p.engine, "buffer i must be the HipVectorReplayBuffer of policy i"
             p.updating = True
-        lr = [p.lagrangians_and_rescaling() if p.use_lagrangian else ([0.0] * (p.critics_num - 1), 1.0) for p in pols]
-        lags = np.array([x[0] if len(x[0]) else [0.0] for x in lr], np.float64)
-        resc = [x[1] for x in lr]
-        self._calls += 1
-        stats, stopped = self.group.ppo_update(lags, resc, batch_size, repeat, perms=perms,
-                                               seed=0 if perms is not None else self._seed + 7919 * self._calls)
+        try:
+            lr = [p.lagrangians_and_rescaling() if p.use_lagrangian else ([0.0] * (p.critics_num - 1), 1.0) for p in pols]
+            lags = np.array([x[0] if len(x[0]) else [0.0] for x in lr], np.float64)
+            resc = [x[1] for x in lr]
+            self._calls += 1
+            stats, stopped = self.group.ppo_update(lags, resc, batch_size, repeat, perms=perms,
+                                                   seed=0 if perms is not None else self._seed + 7919 * self._calls)
+        except BaseException:
+            # a failed group update may have stepped some parameters already: the host mirrors are stale, nobody is updating
+            for p in pols:
+                p.updating = False
+                p._mark_stale()
+            raise
         out = []
         for p, st, sp in zip(pols, stats, stopped):
             drop = set()

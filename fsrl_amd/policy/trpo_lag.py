@@ -14,6 +14,19 @@ TRPO_KEYS = ("loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss/act
              "loss/vf0", "loss/vf1", "loss/vf_total", "loss/kl", "loss/step_size", "loss/entropy")
 
 
+def _split_sizes(n: int, size: int):
+    """row counts of tianshou's Batch.split(size, merge_last=True) over n rows"""
+    size = max(1, min(int(size), max(n, 1)))
+    out, i, merge = [], 0, (n % size) > 0
+    while i < n:
+        if merge and i + 2 * size >= n:
+            out.append(n - i)
+            break
+        out.append(min(size, n - i))
+        i += size
+    return out
+
+
 class TRPOLagrangian(LagrangianPolicy):
     def __init__(self, actor: nn.Module, critics: Union[nn.Module, List[nn.Module]],
                  optim: torch.optim.Optimizer, dist_fn, logger=None,
@@ -64,9 +77,14 @@ class TRPOLagrangian(LagrangianPolicy):
         n = eng.tr_begin(target_kl=self._delta, backtrack_coeff=self._backtrack_coeff, damping=self._damping,
                          l2_reg=0.0, critic_lr=g["lr"], max_backtracks=self._max_backtracks,
                          optim_critic_iters=self._optim_critic_iters, cg_iters=10, norm_adv=self._norm_adv)
-        assert n <= batch_size, "TRPO-Lag on the HIP path is full-batch (reference default batch_size=99999)"
         lags, rescaling = self.lagrangians_and_rescaling() if self.use_lagrangian else ([], 1.0)
-        stats = eng.trpo_learn(lags, rescaling, repeat) if n > 0 else np.zeros((0, 11), np.float32)
+        # Batch.split(batch_size, merge_last=True) inside learn (trpo_lag.py:177-178) draws one np.random.permutation per
+        # repeat from numpy's global stream -- also when one minibatch covers the batch (then the order only moves sums and
+        # the device keeps store order)
+        perms = [np.random.permutation(n) for _ in range(repeat)] if n > 0 else None
+        sizes = _split_sizes(n, batch_size)
+        stats = (eng.trpo_learn(lags, rescaling, repeat, batch_size=batch_size, perms=perms if len(sizes) > 1 else None)
+                 if n > 0 else np.zeros((0, 11), np.float32))
         for row in stats:
             d = dict(zip(TRPO_KEYS, (float(v) for v in row)))
             kl, step, ent = d.pop("loss/kl"), d.pop("loss/step_size"), d.pop("loss/entropy")
@@ -74,8 +92,10 @@ class TRPOLagrangian(LagrangianPolicy):
             self.logger.store(**d)
             self.logger.store(kl=kl, step_size=step, entropy=ent, tab="loss")
         self.logger.store(gradient_steps=self.gradient_steps, tab="update")
-        if n > 0:   # process_fn: one forward; per repeat: 2 forward(s) + one per line-search evaluation
-            self._burn(n, 1 + 2 * len(stats) + int(eng.tr_linesearch_evals().sum()))
+        if n > 0:   # process_fn: one forward over the batch; per minibatch: 2 forward(s) + one per line-search evaluation
+            self._burn(n, 1)
+            for rows, ev in zip(sizes * repeat, eng.tr_linesearch_evals(cap=len(stats) + 1)):
+                self._burn(rows, 2 + int(ev))
         self._mark_stale()                                       # host mirror refreshed on demand
         self._step_lr_scheduler()
         self.updating = False

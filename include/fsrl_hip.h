@@ -191,8 +191,10 @@ int fsrl_ppo_update(fsrl_ctx* ctx, const double* lagrangians, double rescaling,
 /* ---- grouped updates: k independent PPO-Lagrangian agents of ONE network shape on one GPU, stepped in lock step
  *      (multi-seed runs; SURVEY 8e "within-GPU batching of k seeds").  The reference runs seeds as separate jobs; one
  *      agent's update is a chain of small dependent launches that leaves most of an MI355X idle, so k agents share every
- *      launch of the minibatch step (grid.y = member).  Per member the result is bit-identical to fsrl_ppo_update on
- *      that member alone (same kernels' bodies, same permutation stream).  Members keep their own store, parameters,
+ *      launch of the minibatch step (grid.y = member).  Per member the result is fsrl_ppo_update's on that member
+ *      alone within the golden tests' tolerances, and bit-identical only when the launch shapes agree (a group of one,
+ *      minibatches of at most 512 rows): the group picks its tile height from the number of active members and keeps the
+ *      in-kernel weight-gradient reduction above 512 rows.  Members keep their own store, parameters,
  *      Adam state and random streams; shape and PPO hyper-parameters must agree, batch sizes N_i may differ.
  *      While grouped, a member's own update calls still work (they run on the group's stream).                         */
 typedef struct fsrl_group fsrl_group;
@@ -246,6 +248,16 @@ int fsrl_cpo_learn(fsrl_ctx* ctx, double ave_cost_return, int32_t repeat, float*
 /* TRPOLagrangian.learn (trpo_lag.py:173-251).  stats_out: [repeat][FSRL_TRPO_NSTATS].          */
 int fsrl_trpo_learn(fsrl_ctx* ctx, const double* lagrangians, double rescaling, int32_t repeat,
                     float* stats_out);
+/* The same two with Batch.split(batch_size, shuffle=True, merge_last=True) INSIDE learn (cpo.py:357-358, trpo_lag.py:178):
+ * every repeat walks the minibatches of one permutation (a remainder is merged into the last one), critic steps and the
+ * policy step per minibatch, one stats row per minibatch.  perms: [repeat][N] (np.random.permutation draws of the caller)
+ * or NULL = the library shuffles (seed).  batch_size >= N: one minibatch, the whole batch in store order (perms ignored:
+ * the reference's shuffle of a full batch only reorders sums) -- fsrl_cpo_learn / fsrl_trpo_learn are that case.
+ * stats_out: [cap_rows][FSRL_*_NSTATS]; *n_rows_out = rows written = repeat x minibatches.                              */
+int fsrl_cpo_learn_mb(fsrl_ctx* ctx, double ave_cost_return, int32_t repeat, int32_t batch_size, const int64_t* perms,
+                      uint64_t seed, float* stats_out, int64_t cap_rows, int64_t* n_rows_out);
+int fsrl_trpo_learn_mb(fsrl_ctx* ctx, const double* lagrangians, double rescaling, int32_t repeat, int32_t batch_size,
+                       const int64_t* perms, uint64_t seed, float* stats_out, int64_t cap_rows, int64_t* n_rows_out);
 /* policy evaluations the line search of each repeat of the last learn call made (cpo.py:306-333,
  * trpo_lag.py:205-231); returns the number written.  The reference samples an action in every one of them --
  * callers that follow its random streams need the count.                                        */

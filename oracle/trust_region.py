@@ -28,6 +28,20 @@ def _permuted(pb, perm):
     return {k: v[idx] for k, v in pb.items()}
 
 
+def _split(pb, perm, size):
+    """tianshou-0.5 Batch.split(size, shuffle=True, merge_last=True) as FSRL calls it (cpo.py:358, trpo_lag.py:178): the rows
+    in `perm` order (None: stored order), cut every `size` rows, a remainder merged into the last chunk."""
+    n = len(next(iter(pb.values())))
+    idx = np.arange(n) if perm is None else np.asarray(perm)
+    merge = (n % size) > 0
+    for i in range(0, n, size):
+        if merge and i + 2 * size >= n:
+            yield _permuted(pb, idx[i:]) if (perm is not None or i > 0) else pb
+            return
+        chunk = idx[i:i + size]
+        yield _permuted(pb, chunk) if (perm is not None or len(chunk) < n) else pb
+
+
 @dataclass
 class CPOConfig:
     obs_dim: int
@@ -239,17 +253,17 @@ class CPOOracle(_TrustRegionBase):
                  "loss/optim_case": case, "loss/step_size": beta}
         return stats, H_inv_g.detach(), (H_inv_b.detach() if case != 4 else None)
 
-    def update(self, data: OnPolicyData, ave_cost_return, repeat, perms=None):
-        """`perms[k]`: the shuffle Batch.split(99999, merge_last=True) applies to the full batch
-        in repeat k (the reference draws np.random.permutation; None = keep the stored order)."""
+    def update(self, data: OnPolicyData, ave_cost_return, repeat, perms=None, batch_size=99999):
+        """`perms[k]`: the shuffle Batch.split(batch_size, merge_last=True) applies to the batch in repeat k (the reference
+        draws np.random.permutation; None = keep the stored order).  One row per minibatch of every repeat (cpo.py:357-366)."""
         pb = self.process(data)
         rows = []
         for k in range(repeat):
-            mb = pb if perms is None else _permuted(pb, perms[k])
-            for _ in range(self.tcfg.optim_critic_iters):
-                sc = self.critics_step(mb)
-            sa, hg, hb = self.policy_step(mb, ave_cost_return)
-            rows.append((sa, sc, hg))
+            for mb in _split(pb, None if perms is None else perms[k], batch_size):
+                for _ in range(self.tcfg.optim_critic_iters):
+                    sc = self.critics_step(mb)
+                sa, hg, hb = self.policy_step(mb, ave_cost_return)
+                rows.append((sa, sc, hg))
         return pb, rows
 
 
@@ -335,10 +349,11 @@ class TRPOLagOracle(_TrustRegionBase):
                       "loss/entropy": dist.entropy().mean().item()})
         return stats, x.detach()
 
-    def update(self, data: OnPolicyData, lagrangians, rescaling, repeat, perms=None):
+    def update(self, data: OnPolicyData, lagrangians, rescaling, repeat, perms=None, batch_size=99999):
+        """One row per minibatch of every repeat (trpo_lag.py:177-178: batch.split(batch_size, merge_last=True))."""
         pb = self.process(data)
         rows = []
         for k in range(repeat):
-            mb = pb if perms is None else _permuted(pb, perms[k])
-            rows.append(self.learn_step(mb, lagrangians, rescaling))
+            for mb in _split(pb, None if perms is None else perms[k], batch_size):
+                rows.append(self.learn_step(mb, lagrangians, rescaling))
         return pb, rows

@@ -80,7 +80,7 @@ def record_batch(out, buf):
 
 
 def gen_cpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cost_stat, cost_limit,
-            lr=1e-3, perturb_actor=0.0, zero_cost_signal=False, unbounded=False, ret_rms0=None, **kw):
+            lr=1e-3, perturb_actor=0.0, zero_cost_signal=False, unbounded=False, ret_rms0=None, batch_size=99999, **kw):
     """cost_stat / cost_limit steer the optim_case; perturb_actor moves theta away from the
     theta that produced mean_old (exercises the exact-Hessian path on the very first call)."""
     actor, critic, ac = build_nets(obs_dim, act_dim, hidden, seed, unbounded)
@@ -140,16 +140,19 @@ def gen_cpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cost
         out["theta_after_pl"] = flat_params(ac)
     else:
         with PermRecorder() as pr:
-            policy.update(0, buf, batch_size=99999, repeat=repeat)
+            policy.update(0, buf, batch_size=batch_size, repeat=repeat)
         out["perms"] = np.stack(pr.perms)
         rows = [r for r in logger.rows if "update/gradient_steps" not in r]
-        assert len(rows) == 2 * repeat
+        n_rows = len(rows) // 2                       # one (actor, critic) row pair per minibatch of every repeat (cpo.py:357-366)
+        assert len(rows) == 2 * n_rows and n_rows % repeat == 0 and (batch_size < len(indices) or n_rows == repeat)
         keys_a = [k for k in rows[0].keys()]
         keys_c = [k for k in rows[1].keys()]
         out["stats_actor_keys"] = np.array(keys_a)
         out["stats_critic_keys"] = np.array(keys_c)
-        out["stats_actor"] = np.array([[rows[2 * i][k] for k in keys_a] for i in range(repeat)])
-        out["stats_critic"] = np.array([[rows[2 * i + 1][k] for k in keys_c] for i in range(repeat)])
+        out["stats_actor"] = np.array([[rows[2 * i][k] for k in keys_a] for i in range(n_rows)])
+        out["stats_critic"] = np.array([[rows[2 * i + 1][k] for k in keys_c] for i in range(n_rows)])
+        if batch_size < len(indices):
+            out["gradient_steps"] = np.array(policy.gradient_steps)
         out["H_inv_g_first"] = cap["cg"][0]
         out["theta_final"] = flat_params(ac)
         if ret_rms0 is not None:
@@ -159,6 +162,8 @@ def gen_cpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cost
                perturb_actor=perturb_actor)
     if unbounded:
         cfg["unbounded"] = True
+    if batch_size != 99999:
+        cfg["batch_size"] = batch_size
     defaults = dict(target_kl=0.01, backtrack_coeff=0.8, damping_coeff=0.1, max_backtracks=10,
                     optim_critic_iters=20, l2_reg=0.001, gae_lambda=0.95, advantage_normalization=True,
                     gamma=0.99)
@@ -177,7 +182,7 @@ def gen_cpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cost
 
 
 def gen_trpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cost_stat, cost_limit,
-             lr=5e-4, unbounded=False, ret_rms0=None, **kw):
+             lr=5e-4, unbounded=False, ret_rms0=None, batch_size=99999, **kw):
     actor, critic, ac = build_nets(obs_dim, act_dim, hidden, seed, unbounded)
     optim = torch.optim.Adam(ac.parameters(), lr=lr)
     logger = CaptureLogger()
@@ -201,18 +206,19 @@ def gen_trpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cos
     policy._conjugate_gradients = cg
     preset_rms(out, policy, ret_rms0)
     with PermRecorder() as pr:
-        policy.update(0, buf, batch_size=99999, repeat=repeat)
+        policy.update(0, buf, batch_size=batch_size, repeat=repeat)
     out["perms"] = np.stack(pr.perms)
     if ret_rms0 is not None:
         out["ret_rms_final"] = np.array([[r.mean, r.var, r.count] for r in policy.ret_rms], np.float64)
     rows = [r for r in logger.rows if "update/gradient_steps" not in r]
-    assert len(rows) == 3 * repeat
+    n_rows = len(rows) // 3                           # three logger rows per minibatch of every repeat (trpo_lag.py:178-249)
+    assert len(rows) == 3 * n_rows and n_rows % repeat == 0 and (batch_size < len(out["indices"]) or n_rows == repeat)
     keys = []
     for r in rows[:3]:
         keys += list(r.keys())
     out["stats_keys"] = np.array(keys)
     out["stats"] = np.array([[{**rows[3 * i], **rows[3 * i + 1], **rows[3 * i + 2]}[k] for k in keys]
-                             for i in range(repeat)])
+                             for i in range(n_rows)])
     out["cg_first"] = cap["cg"][0]
     out["theta_final"] = flat_params(ac)
     out["gradient_steps"] = np.array(policy.gradient_steps)
@@ -221,6 +227,8 @@ def gen_trpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cos
                seed=seed, cost_stat=cost_stat, cost_limit=cost_limit, lr=lr, max_action=1.0)
     if unbounded:
         cfg["unbounded"] = True
+    if batch_size != 99999:
+        cfg["batch_size"] = batch_size
     defaults = dict(target_kl=0.001, backtrack_coeff=0.8, max_backtracks=10, optim_critic_iters=5,
                     gae_lambda=0.95, advantage_normalization=True, gamma=0.99,
                     lagrangian_pid=(0.05, 0.0005, 0.1), rescaling=True, use_lagrangian=True)
@@ -249,6 +257,14 @@ if __name__ == "__main__":
                 optim_critic_iters=5, max_backtracks=10, unbounded=True, reward_normalization=True, ret_rms0=rms0)
         gen_trpo("options", 8, 2, (64, 64), 3, eps, repeat=2, seed=22, cost_stat=25.0, cost_limit=10.0,
                  optim_critic_iters=5, unbounded=True, reward_normalization=True, ret_rms0=rms0)
+        sys.exit(0)
+    if sys.argv[1:] == ["minibatch"]:
+        # batch_size below the buffer: Batch.split(batch_size, merge_last=True) inside learn (cpo.py:357-358,
+        # trpo_lag.py:178).  N = 560 rows, batch 150 -> minibatches of 150 / 150 / 260 (the remainder merged into the last)
+        gen_cpo("minibatch", 8, 2, (64, 64), 3, eps, repeat=2, seed=31, cost_stat=25.0, cost_limit=10.0,
+                optim_critic_iters=3, max_backtracks=10, batch_size=150)
+        gen_trpo("minibatch", 8, 2, (64, 64), 3, eps, repeat=2, seed=32, cost_stat=25.0, cost_limit=10.0,
+                 optim_critic_iters=3, batch_size=150)
         sys.exit(0)
     # cost far above the limit (c > 0): infeasible / recovery branches
     gen_cpo("infeasible", 8, 2, (64, 64), 3, eps, repeat=2, seed=10, cost_stat=25.0, cost_limit=10.0,

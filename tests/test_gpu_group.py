@@ -143,3 +143,62 @@ def test_policy_group_trains_k_seeds_in_lock_step(tmp_path):
                           "--epoch", "1", "--envs", "4", "--grouped"], capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "3 seeds x 1 epochs grouped" in out.stdout and out.stdout.count("epoch 1 seed") == 3
+
+
+def _filled(T, seed, target_kl, lr=5e-4, Do=8, Da=2, H=64):
+    from fsrl_amd.engine import Engine, EngineConfig
+    e = Engine(EngineConfig(obs_dim=Do, act_dim=Da, hidden=H, env_num=2, max_grad_norm=0.5, target_kl=target_kl, lr=lr))
+    r = np.random.default_rng(seed)
+    e.set_params((0.1 * r.standard_normal(e.n_params)).astype(np.float32))
+    obs = r.standard_normal((T + 1, 2, Do)).astype(np.float32)
+    for t in range(T):
+        e.push([0, 1], obs[t], 0.3 * r.standard_normal((2, Da)).astype(np.float32), r.normal(0.5, 0.5, 2),
+               (r.random(2) < 0.1).astype(np.float64), [False, False], [t == T - 1] * 2, obs[t + 1])
+    return e
+
+
+def test_longest_member_stops_on_kl_first_and_an_empty_member_sits_out():
+    """minibatch indices that no ACTIVE member has must not launch an empty grid.  Member 0 has the most
+    minibatches and a learning rate that trips the KL stop in pass 0; member 1 (fewer minibatches) runs all passes; member 2
+    holds no data at all but carries a longer stale plan from an earlier update."""
+    from fsrl_amd.engine import EngineGroup
+    lens = [700, 200, 500]
+    engs = [_filled(lens[0], 1, 0.01, lr=2e-2), _filled(lens[1], 2, 0.01, lr=1e-5), _filled(lens[2], 3, 0.01, lr=1e-5)]
+    solo = [_filled(lens[0], 1, 0.01, lr=2e-2), _filled(lens[1], 2, 0.01, lr=1e-5)]
+    engs[2].ppo_update([0.3], 1 / 1.3, 64, 1, seed=3)                 # leaves a 15-minibatch plan behind ...
+    engs[2].reset_store()                                               # ... and then no rows
+    assert len(engs[2]) == 0
+    grp = EngineGroup(engs)
+    rng = np.random.default_rng(0)
+    perms = [[rng.permutation(2 * T) for _ in range(4)] for T in lens[:2]] + [[np.zeros(0, np.int64) for _ in range(4)]]
+    lags, resc = np.array([[0.2], [0.5], [0.9]]), [1 / 1.2, 1 / 1.5, 1 / 1.9]
+    st, stop = grp.ppo_update(lags, resc, 128, 4, perms=perms)
+    assert stop[0] == 0 and stop[1] == -1 and st[2].shape[0] == 0, (stop, [s.shape for s in st])
+    assert st[0].shape[0] == 10 and st[1].shape[0] == 4 * 3            # one pass of 10 minibatches; four passes of 3
+    for i, e in enumerate(solo):
+        s1, sp = e.ppo_update(lags[i], resc[i], 128, 4, perms=perms[i])
+        assert sp == stop[i] and s1.shape == st[i].shape
+        np.testing.assert_allclose(st[i], s1, rtol=2e-4, atol=2e-4)
+    grp.close()
+    for e in engs + solo:
+        e.close()
+
+
+def test_destroying_member_zero_first_leaves_the_other_members_usable():
+    """the shared stream is the group's own; when a member dies first the survivors get their own streams back
+    and keep working, and destroying the broken group afterwards is harmless."""
+    from fsrl_amd.engine import EngineGroup
+    engs = [_filled(150, 5, None), _filled(150, 6, None)]
+    ref = _filled(150, 6, None)
+    grp = EngineGroup(engs)
+    grp.ppo_update(np.array([[0.2], [0.4]]), [1 / 1.2, 1 / 1.4], 64, 1, seed=9)
+    ref.ppo_update([0.4], 1 / 1.4, 64, 1, seed=9)                      # not the same shuffle stream: only shapes compared
+    engs[0].close()                                                     # member 0 goes first
+    s_a, _ = engs[1].ppo_update([0.4], 1 / 1.4, 64, 1, seed=11)          # the survivor's own calls still work
+    assert np.isfinite(s_a).all() and np.isfinite(engs[1].get_params()).all()
+    with pytest.raises(Exception):
+        grp.ppo_update(np.array([[0.2], [0.4]]), [1 / 1.2, 1 / 1.4], 64, 1, seed=9)    # the group itself is over
+    grp.close()
+    s_b, _ = engs[1].ppo_update([0.4], 1 / 1.4, 64, 1, seed=12)
+    assert np.isfinite(s_b).all()
+    engs[1].close(); ref.close()

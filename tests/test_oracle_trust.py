@@ -36,7 +36,7 @@ def trpo_cfg(cfg):
                       reward_normalization=bool(cfg.get("reward_normalization", False)))
 
 
-@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options"])
+@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options", "minibatch"])
 def test_cpo_update(name):
     torch.set_num_threads(4)
     g = load_npz(f"cpo_{name}.npz")
@@ -45,7 +45,7 @@ def test_cpo_update(name):
     o.set_params(g["theta0"])
     if "ret_rms0" in g:
         o.ret_rms[:] = g["ret_rms0"]
-    pb, rows = o.update(_data(g), cfg["cost_stat"], cfg["repeat"], perms=g["perms"])
+    pb, rows = o.update(_data(g), cfg["cost_stat"], cfg["repeat"], perms=g["perms"], batch_size=cfg.get("batch_size", 99999))
     if "ret_rms0" in g:
         np.testing.assert_allclose(o.ret_rms, g["ret_rms_final"], rtol=1e-10)
     np.testing.assert_allclose(pb["advs"].numpy(), g["advs_norm"], rtol=1e-5, atol=1e-6)
@@ -79,7 +79,7 @@ def test_cpo_policy_loss_away_from_theta_old():
     np.testing.assert_allclose(o.get_params(), g["theta_after_pl"], rtol=0, atol=2e-6)
 
 
-@pytest.mark.parametrize("name", ["small", "c1", "options"])
+@pytest.mark.parametrize("name", ["small", "c1", "options", "minibatch"])
 def test_trpo_update(name):
     torch.set_num_threads(4)
     g = load_npz(f"trpo_{name}.npz")
@@ -89,7 +89,8 @@ def test_trpo_update(name):
     if "ret_rms0" in g:
         o.ret_rms[:] = g["ret_rms0"]
     lag = g["lagrangian"]
-    pb, rows = o.update(_data(g), lag, 1.0 / (lag.sum() + 1.0), cfg["repeat"], perms=g["perms"])
+    pb, rows = o.update(_data(g), lag, 1.0 / (lag.sum() + 1.0), cfg["repeat"], perms=g["perms"],
+                        batch_size=cfg.get("batch_size", 99999))
     keys = [str(k) for k in g["stats_keys"]]
     got = np.array([[r[0][k] for k in keys] for r in rows])
     np.testing.assert_allclose(got, g["stats"], rtol=1e-4, atol=1e-6)
