@@ -180,7 +180,7 @@ def end_to_end(local_rank, seed, seconds=6.0, device_actor=False, workers=0, bus
                         max_grad_norm=0.5, training_num=envs)
     agent.policy.train()
     buf = HipVectorReplayBuffer(agent.policy.engine, 100000, envs)
-    col = FastCollector(agent.policy, env, buf, exploration_noise=True, device_actor=device_actor)
+    col = FastCollector(agent.policy, env, buf, exploration_noise=True, device_actor=device_actor, split_phase="auto")
     tr = OnpolicyTrainer(agent.policy, col, None, max_epoch=10**6, batch_size=BATCH, cost_limit=10,
                          step_per_epoch=6000, repeat_per_collect=REPEAT, episode_per_collect=envs,
                          verbose=False)
@@ -199,7 +199,9 @@ def end_to_end(local_rank, seed, seconds=6.0, device_actor=False, workers=0, bus
             if workers > 0 else "in-process vector env, zero-cost step")
     out = {"env": "synthetic SafetyCarCircle-shaped dynamics (not PyBullet); " + kind, "envs": envs, "workers": workers,
            "busy_us": busy_us, "host_cpus_usable": usable_cpus(),
-           "handshake": (("polled sequence numbers" if getattr(env, "spin_us", 0) > 0 else "semaphores") if workers > 0 else None),
+           "handshake": (("futex generation word + completion counter per lane (libfsrl_env.so), spin "
+                          f"{getattr(env, 'spin_us', 0):g} us before sleeping") if workers > 0 else None),
+           "split_phase": bool(col.split_phase),
            "env_bound_env_steps_per_s": env_bound(envs, workers, busy_us, usable_cpus()),
            "actor": "device (fsrl_collect_step: one call per vector step, library RNG)" if device_actor else "host mirror (torch CPU, torch RNG)",
            "collects": collects, "env_steps_per_s": col.collect_step / dt,

@@ -33,8 +33,10 @@ class OffpolicyAgent(BaseAgent):
         # that geometry.  None = the size the agent was built with (its `buffer_size`, default 100 000 like the
         # reference's learn()); an explicit size must fit that allocation (AssertionError otherwise).
         buffer = HipVectorReplayBuffer(eng, buffer_size, len(train_envs))
-        train_collector = FastCollector(self.policy, train_envs, buffer, exploration_noise=True,
-                                        device_actor=device_actor)   # True: actor + noise on the MI355X
+        # device_actor=True: actor + noise on the MI355X (library RNG); over a worker-process env the collector then also
+        # overlaps the actor with the env workers when that pays (split_phase="auto")
+        train_collector = FastCollector(self.policy, train_envs, buffer, exploration_noise=True, device_actor=device_actor,
+                                        split_phase="auto" if device_actor else False)
         test_collector = FastCollector(self.policy, test_envs) if test_envs is not None else None
 
         def stop_fn(reward, cost):

@@ -16,13 +16,24 @@ from fsrl_amd.data.batch import Batch
 
 class FastCollector:
     def __init__(self, policy, env, buffer=None, preprocess_fn=None, exploration_noise: bool = False,
-                 device_actor: bool = False, fused_step: bool = True):
+                 device_actor: bool = False, fused_step: bool = True, split_phase=False):
         # device_actor=True: actions come from fsrl_actor_sample (actor on the MI355X, library RNG) and rows go
         # straight to fsrl_store_push -- no torch call and no Batch objects per vector step.  False keeps the
         # host mirror of the actor with torch's random stream (what the reference consumes).
         self.device_actor = device_actor and getattr(policy, "engine", None) is not None
         # fused_step (device_actor only): one fsrl_collect_step per vector step instead of fsrl_actor_sample + fsrl_store_push
         self.fused_step = fused_step
+        # split_phase (device_actor + fused_step over an env with step_async / step_wait and two lanes: the worker-process env):
+        # the envs are stepped in two halves, the actor for one half runs while the other half's workers step.  Rows of an
+        # env stay chronological, so sample(0) order and episode-exact collection are as in the plain loop; the ORDER in which
+        # the library's noise stream is consumed changes, so this is a throughput mode like perms=None, not a parity mode.
+        # split_phase="auto": the first collect runs the plain loop and times its two halves; the split loop takes over when
+        # a vector step of the env costs more than the actor call it would hide (an env that costs nothing gains nothing
+        # from two half-width actor launches per vector step).
+        can_split = hasattr(env, "step_async") and getattr(env, "n_lanes", 1) == 2
+        self._split_auto = split_phase == "auto" and can_split
+        self.split_phase = bool(split_phase is True and can_split)
+        self._t_env = self._t_act = 0.0
         self.env = env
         self.env_num = len(env)
         self.policy = policy
@@ -68,6 +79,8 @@ class FastCollector:
         if eng is not None and hasattr(self.policy, "_drain"):
             self.policy._drain()
         if eng is not None and not random and self.buffer is not None and self.fused_step:
+            if self.split_phase:
+                return self._collect_split(eng, n_episode, ready, obs, t0, gym_reset_kwargs)
             return self._collect_fused(eng, n_episode, ready, obs, t0, gym_reset_kwargs)
         while True:
             data = None if eng is not None and not random else Batch(obs=obs, info={})
@@ -139,8 +152,13 @@ class FastCollector:
         ep_rews, ep_lens = [], []
         obs = np.asarray(obs, np.float32)
         act, env_act, _, _ = eng.collect_step(None, obs, det, bound, low, high)
+        clock = time.perf_counter
+        t_env = t_act = 0.0
         while True:
+            tc0 = clock()
             obs_next, rew, terminated, truncated, info = self.env.step(env_act, ready)
+            tc1 = clock()
+            t_env += tc1 - tc0
             terminated, truncated = np.asarray(terminated, bool), np.asarray(truncated, bool)
             done = terminated | truncated
             cost = np.asarray(info.get("cost", np.zeros(len(ready))), np.float64) if isinstance(info, dict) \
@@ -162,14 +180,94 @@ class FastCollector:
                     mask[local[:surplus]] = False
                     nready, nxt = ready[mask], nxt[mask]
                 last = episode_count + n_done >= n_episode
+                tc2 = clock()
                 act, env_act, ep_rew, ep_len = eng.collect_step(prev, None if last else nxt, det, bound, low, high)
+                t_act += clock() - tc2
                 episode_count += n_done
                 ep_lens.append(ep_len[local].copy()); ep_rews.append(ep_rew[local].copy())
                 if last:
                     break
             else:
+                tc2 = clock()
                 act, env_act, _, _ = eng.collect_step(prev, nxt, det, bound, low, high)
+                t_act += clock() - tc2
             obs, ready = np.asarray(nxt, np.float32), nready
+        if self._split_auto and t_act > 0.0:
+            self._t_env, self._t_act = t_env, t_act
+            self.split_phase = t_env > 1.25 * t_act           # decided once per collect of the plain loop; sticks while split
+        self.buffer.sync_sizes()
+        self.collect_step += step_count
+        self.collect_episode += episode_count
+        self.collect_time += max(time.time() - t0, 1e-9)
+        self.reset_env()
+        rews, lens = np.concatenate(ep_rews), np.concatenate(ep_lens)
+        done_count = term_count + trunc_count
+        return {"n/ep": episode_count, "n/st": step_count, "rew": float(rews.mean()),
+                "len": float(lens.mean()), "total_cost": total_cost,
+                "cost": total_cost / episode_count, "truncated": trunc_count / done_count,
+                "terminated": term_count / done_count}
+
+    def _collect_split(self, eng, n_episode, ready, obs, t0, gym_reset_kwargs):
+        """The fused loop over the two lanes of a worker-process env: while lane A's workers step, the collector stores lane
+        B's finished transitions, evaluates the actor on lane B's next observations and starts lane B's step.  Episode
+        accounting is global (envs of either lane are dropped once the remaining envs cover the episodes still needed), so
+        exactly n_episode episodes are collected, as in the reference (fast_collector.py:341-362)."""
+        pol, env = self.policy, self.env
+        det = bool(pol._deterministic_eval and not pol.training)
+        space = pol.action_space
+        bound = {"": 0, "clip": 1, "tanh": 2}[pol.action_bound_method] if space is not None else 0
+        low = np.asarray(space.low, np.float32) if (space is not None and pol.action_scaling) else None
+        high = np.asarray(space.high, np.float32) if low is not None else None
+        step_count, total_cost, episode_count, term_count, trunc_count = 0, 0.0, 0, 0, 0
+        ep_rews, ep_lens = [], []
+        obs = np.asarray(obs, np.float32)
+        lane_of = env.lane_of_env
+        groups = []
+        for lane in range(2):
+            m = lane_of[ready] == lane
+            g = {"ready": ready[m], "obs": obs[m], "act": None, "busy": False}
+            if len(g["ready"]):
+                g["act"], env_act, _, _ = eng.collect_step(None, g["obs"], det, bound, low, high)
+                env.step_async(env_act, g["ready"])
+                g["busy"] = True
+            groups.append(g)
+        while episode_count < n_episode:
+            assert groups[0]["busy"] or groups[1]["busy"], "split-phase collect: no env left but episodes are missing"
+            for g in groups:
+                if not g["busy"]:
+                    continue
+                rdy = g["ready"]
+                obs_next, rew, terminated, truncated, info = env.step_wait(rdy)
+                g["busy"] = False
+                done = terminated | truncated
+                cost = np.asarray(info["cost"], np.float64)
+                total_cost += float(cost.sum())
+                step_count += len(rdy)
+                prev = (rdy, g["obs"], g["act"], rew, cost, terminated, truncated, obs_next)
+                nxt, nready = obs_next, rdy
+                if done.any():
+                    local = np.where(done)[0]
+                    n_done = len(local)
+                    term_count += int(terminated.sum()); trunc_count += int(truncated.sum())
+                    nxt = np.array(obs_next, np.float32)
+                    obs_reset, _ = env.reset(rdy[local], **(gym_reset_kwargs or {}))
+                    nxt[local] = obs_reset
+                    active = len(groups[0]["ready"]) + len(groups[1]["ready"])
+                    surplus = active - (n_episode - episode_count - n_done)
+                    if surplus > 0:      # drop finished envs that are no longer needed (unbiased tail)
+                        mask = np.ones(len(rdy), bool)
+                        mask[local[:surplus]] = False
+                        nready, nxt = rdy[mask], nxt[mask]
+                    act, env_act, ep_rew, ep_len = eng.collect_step(prev, nxt if len(nready) else None, det, bound, low, high)
+                    episode_count += n_done
+                    ep_lens.append(ep_len[local].copy()); ep_rews.append(ep_rew[local].copy())
+                else:
+                    act, env_act, _, _ = eng.collect_step(prev, nxt, det, bound, low, high)
+                g["ready"], g["obs"], g["act"] = nready, np.asarray(nxt, np.float32), act
+                if len(nready):
+                    env.step_async(env_act, nready)
+                    g["busy"] = True
+        assert not (groups[0]["busy"] or groups[1]["busy"])
         self.buffer.sync_sizes()
         self.collect_step += step_count
         self.collect_episode += episode_count

@@ -8,16 +8,21 @@ here, so this is the same ARCHITECTURE around the synthetic dynamics of `Synthet
   * `workers` processes, each owning a contiguous slice of the `env_num` envs (one env per worker when
     workers == env_num, like tianshou; fewer workers batch their slice's steps);
   * obs / act / rew / cost / flags live in ONE `multiprocessing.shared_memory` block: the parent writes the actions of the
-    active envs and bumps each touched worker's `go` sequence number in that block, the workers step their envs in parallel
-    (burning `busy_us` per env step to stand in for a physics step), write results in place and bump their `done` number;
-    the parent polls those -- no pickling, no pipes and no system call on the per-step path.  A worker that sees nothing for
-    `spin_us` (the policy update, ~10 ms) parks on a semaphore and is woken by the next command, so idle workers do not burn
-    their cores (32 semaphore posts + waits per vector step cost ~130 us; the sequence numbers ~2 us);
+    active envs, the workers step their envs in parallel (an env step costs `busy_us` of host time, the stand-in for a
+    physics step) and write the results in place -- no pickling, no pipes;
+  * the per-step handshake is NATIVE (fsrl_amd/env/csrc/fsrl_env.c, libfsrl_env.so): a command is one release store of a
+    generation word + one FUTEX_WAKE for every worker sleeping on it; completion is one counter the workers decrement, the
+    collector sleeps on it once and the last worker wakes it.  Workers block inside the C call, not in the interpreter.
+    (Round 2: a semaphore pair per worker = 32 posts + 32 blocking waits from Python per vector step, ~130 us.)
+  * two LANES: the workers are split in two halves with their own generation / completion words, so the collector can
+    keep one half stepping while it computes the other half's actions (`step_async` / `step_wait`; FastCollector's
+    split-phase loop).  `step()` / `reset()` drive both lanes at once;
   * `cores`: the rank's core slice (fsrl_amd.parallel.pin_rank_cores); worker w is pinned to cores[w % len(cores)].
 
 Calling convention of the collector: `len(env)`, `reset(ids=None) -> (obs, info)`, `step(act, ids) -> (obs, rew, terminated,
 truncated, {"cost": cost})`, `close()`.  With workers == 1 the trajectories are bit-identical to the in-process env of the
 same seed (tests/test_shmem_env.py)."""
+import ctypes as C
 import multiprocessing as mp
 import os
 from multiprocessing import shared_memory
@@ -28,15 +33,30 @@ import numpy as np
 from fsrl_amd.env.synthetic import Box, SyntheticSafetyVectorEnv
 
 _CMD_STEP, _CMD_RESET, _CMD_EXIT = 1, 2, 3
+_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libfsrl_env.so")
 
 
-def _layout(env_num, obs_dim, act_dim):
+def _load_lib():
+    """libfsrl_env.so: the futex handshake.  There is no Python fallback: without the library the env does not start."""
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(f"{_LIB_PATH} not found: build it with fsrl_amd/env/csrc/build.sh (or __graft_entry__.build())")
+    lib = C.CDLL(_LIB_PATH)
+    u32p = C.c_void_p
+    lib.fsrl_env_post.argtypes = [u32p, u32p, C.c_uint32, C.c_uint32]; lib.fsrl_env_post.restype = None
+    lib.fsrl_env_wait_go.argtypes = [u32p, C.c_uint32, C.c_uint32, C.c_int32]; lib.fsrl_env_wait_go.restype = C.c_uint32
+    lib.fsrl_env_done.argtypes = [u32p]; lib.fsrl_env_done.restype = None
+    lib.fsrl_env_wait_done.argtypes = [u32p, C.c_uint32, C.c_int32]; lib.fsrl_env_wait_done.restype = C.c_int32
+    return lib
+
+
+def _layout(env_num, obs_dim, act_dim, workers):
     """name -> (offset, shape, dtype) of the arrays inside the shared block, 64-byte aligned"""
     fields = [("obs", (env_num, obs_dim), np.float32), ("act", (env_num, act_dim), np.float32), ("rew", (env_num, ), np.float64),
               ("cost", (env_num, ), np.float64), ("term", (env_num, ), np.uint8), ("trunc", (env_num, ), np.uint8),
-              ("active", (env_num, ), np.uint8), ("cmd", (64, ), np.int32),
-              # per-worker handshake words, one 64-byte line each (no false sharing between the pollers)
-              ("go", (env_num, 8), np.int64), ("done", (env_num, 8), np.int64), ("parked", (env_num, 8), np.int64)]
+              ("active", (env_num, ), np.uint8),
+              # handshake words, one 64-byte line each: per lane (generation | pending workers | command), per worker the
+              # generation of the last command it takes part in
+              ("hs", (2, 3, 16), np.uint32), ("want", (workers, 16), np.uint32)]
     out, off = {}, 0
     for name, shape, dt in fields:
         out[name] = (off, shape, dt)
@@ -48,53 +68,54 @@ def _views(buf, layout):
     return {name: np.ndarray(shape, dtype=dt, buffer=buf, offset=off) for name, (off, shape, dt) in layout.items()}
 
 
-def _worker(w, lo, hi, shm_name, env_num, obs_dim, act_dim, episode_len, seed, busy_us, wake, done_sem, core, spin_us):
+def _worker(w, lane, lo, hi, shm_name, env_num, workers, obs_dim, act_dim, episode_len, seed, busy_us, core, spin):
     if core is not None:
         try:
             os.sched_setaffinity(0, {core})
         except (AttributeError, OSError):
             pass
+    lib = _load_lib()
     shm = shared_memory.SharedMemory(name=shm_name)
-    layout, _ = _layout(env_num, obs_dim, act_dim)
+    layout, _ = _layout(env_num, obs_dim, act_dim, workers)
     v = _views(shm.buf, layout)
     env = SyntheticSafetyVectorEnv(env_num=hi - lo, obs_dim=obs_dim, act_dim=act_dim, episode_len=episode_len, seed=seed,
                                    busy_us=busy_us)
-    go, done, parked = v["go"][w], v["done"][w], v["parked"][w]
+    gen_p, pend_p = v["hs"][lane, 0].ctypes.data, v["hs"][lane, 1].ctypes.data
+    cmd_w, want_w = v["hs"][lane, 2], v["want"][w]
+    parent = os.getppid()
+    sl, all_local = slice(lo, hi), np.arange(hi - lo)
+    v_active, v_obs, v_act, v_rew, v_cost, v_term, v_trunc = (v[k] for k in ("active", "obs", "act", "rew", "cost", "term", "trunc"))
     seen = 0
-    spins = max(1, int(spin_us / 0.15))          # ~0.15 us per poll of a shared word from Python
     try:
         while True:
-            n = 0
-            while go[0] == seen:                 # poll; park after spin_us of nothing (spin_us = 0: semaphores only)
-                n += 1
-                if n >= spins or done_sem is not None:
-                    parked[0] = 1
-                    while go[0] == seen:         # a post can race the flag: the timeout bounds a missed wake-up to 2 ms
-                        if done_sem is not None:
-                            wake.acquire()       # semaphore mode: the parent posts for every command, nothing to miss
-                        else:
-                            wake.acquire(timeout=0.002)
-                    parked[0] = 0
+            g = lib.fsrl_env_wait_go(gen_p, seen, spin, 1000)
+            if g == seen:                          # a second without a command: is the collector still there?
+                if os.getppid() != parent:
                     break
-            seen = int(go[0])
-            cmd = int(v["cmd"][0])
+                continue
+            seen = g
+            cmd = int(cmd_w[0])
             if cmd == _CMD_EXIT:
                 break
-            local = np.flatnonzero(v["active"][lo:hi])
-            if local.size:
+            if int(want_w[0]) != g:                # this command does not touch my envs
+                continue
+            act_w = v_active[sl]
+            if act_w.all():                        # the whole slice (the steady state): basic slices, no index arrays
+                local, gi = all_local, sl
+            else:
+                local = np.flatnonzero(act_w)
+                gi = lo + local
+            if len(local):
                 if cmd == _CMD_RESET:
                     obs, _ = env.reset(local)
-                    v["obs"][lo + local] = obs
+                    v_obs[gi] = obs
                 else:
-                    obs, rew, term, trunc, info = env.step(v["act"][lo + local], local)
-                    g = lo + local
-                    v["obs"][g] = obs; v["rew"][g] = rew; v["cost"][g] = info["cost"]
-                    v["term"][g] = term; v["trunc"][g] = trunc
-            done[0] = seen
-            if done_sem is not None:
-                done_sem.release()
+                    obs, rew, term, trunc, info = env.step(v_act[gi], local)
+                    v_obs[gi] = obs; v_rew[gi] = rew; v_cost[gi] = info["cost"]
+                    v_term[gi] = term; v_trunc[gi] = trunc
+            lib.fsrl_env_done(pend_p)
     finally:
-        del v
+        del v, cmd_w, want_w, v_active, v_obs, v_act, v_rew, v_cost, v_term, v_trunc
         shm.close()
 
 
@@ -108,96 +129,148 @@ class ShmemVectorEnv:
         self.observation_space = Box(-np.inf, np.inf, (obs_dim, ))
         self.action_space = Box(-1.0, 1.0, (act_dim, ))
         self.spec = SimpleNamespace(id="SyntheticSafety-v0", max_episode_steps=episode_len)
-        self._layout, size = _layout(env_num, obs_dim, act_dim)
+        self._lib = _load_lib()
+        self._layout, size = _layout(env_num, obs_dim, act_dim, workers)
         self._shm = shared_memory.SharedMemory(create=True, size=size)
         self._v = _views(self._shm.buf, self._layout)
         for a in self._v.values():
             a[...] = 0
         ctx = mp.get_context(start_method)
-        # contiguous slices: worker w owns envs [bounds[w], bounds[w + 1])
+        # contiguous slices: worker w owns envs [bounds[w], bounds[w + 1]); lane 0 = the first half of the workers
         self._bounds = [round(w * env_num / workers) for w in range(workers + 1)]
         self._owner = np.zeros(env_num, np.int32)
-        # polling needs a CPU per worker plus one for the collector; on a smaller or quota-limited host (measured on the MI355X
-        # box: 256 CPUs visible, cgroup quota 16: 32 pollers get throttled, 84k vs 110k env-steps/s at 100 us per step) the
-        # workers park on semaphores right away and the parent blocks on theirs -- the classic handshake
+        self.n_lanes = 2 if workers >= 2 else 1
+        half = (workers + 1) // 2 if self.n_lanes == 2 else workers
+        self._lane_of_worker = np.array([0 if w < half else 1 for w in range(workers)], np.int32)
+        # spinning before the futex sleep needs a CPU per worker plus one for the collector; on a smaller or quota-limited
+        # host (the MI355X box: 256 CPUs visible, cgroup quota 16) nobody spins
         if spin_us is None:
             from fsrl_amd.parallel import usable_cpus
             usable = min(usable_cpus(), len(cores)) if cores else usable_cpus()      # affinity AND the cgroup CPU quota
-            spin_us = 500.0 if workers + 1 <= usable else 0.0
+            spin_us = 500.0 if workers + 1 <= usable else 0.0  # longer than the collector's own work between two commands
         self.spin_us = float(spin_us)
-        self._wake = [ctx.Semaphore(0) for _ in range(workers)]
-        self._done = [ctx.Semaphore(0) for _ in range(workers)] if self.spin_us <= 0 else None
-        self._seq = 0
+        self._spin = int(self.spin_us * 30)                   # ~30 ns per pause-and-load
+        self._gen = [0, 0]
+        self._inflight = [None, None]                         # per lane: env ids of the command in flight
         self._procs = []
         for w in range(workers):
             lo, hi = self._bounds[w], self._bounds[w + 1]
             self._owner[lo:hi] = w
             wseed = seed if workers == 1 else seed * 7919 + w
             core = None if not cores else list(cores)[w % len(cores)]
-            p = ctx.Process(target=_worker, args=(w, lo, hi, self._shm.name, env_num, obs_dim, act_dim, episode_len, wseed,
-                                                  busy_us, self._wake[w], self._done[w] if self._done else None, core,
-                                                  self.spin_us), daemon=True)
+            p = ctx.Process(target=_worker, args=(w, int(self._lane_of_worker[w]), lo, hi, self._shm.name, env_num, workers, obs_dim,
+                                                  act_dim, episode_len, wseed, busy_us, core, self._spin), daemon=True)
             p.start()
             self._procs.append(p)
+        self.lane_of_env = self._lane_of_worker[self._owner]
+        self.lanes = [np.flatnonzero(self.lane_of_env == l) for l in range(self.n_lanes)]
+        # lanes are contiguous env / worker ranges: the steady state (a command for a whole lane) uses basic slices
+        self._lane_env = [slice(int(l[0]), int(l[-1]) + 1) for l in self.lanes]
+        self._lane_wrk = [slice(int(np.flatnonzero(self._lane_of_worker == l)[0]), int(np.flatnonzero(self._lane_of_worker == l)[-1]) + 1)
+                          for l in range(self.n_lanes)]
+        hs = self._v["hs"]
+        self._gen_p = [hs[l, 0].ctypes.data for l in range(2)]
+        self._pend_p = [hs[l, 1].ctypes.data for l in range(2)]
         self._closed = False
 
     def __len__(self):
         return self.env_num
 
-    def _run(self, cmd, ids):
+    # ---- the handshake: post a command to a lane, wait for it
+    def _post(self, lane, cmd, ids):
+        assert self._inflight[lane] is None, "a command is already in flight on this lane"
         v = self._v
-        v["active"][:] = 0
-        v["active"][ids] = 1
-        v["cmd"][0] = cmd
-        touched = np.unique(self._owner[ids])
-        self._seq += 1
-        seq = self._seq
-        v["go"][touched, 0] = seq                       # the command is in place: release the pollers
-        for w in (touched if self._done is not None else touched[v["parked"][touched, 0] != 0]):
-            self._wake[w].release()                      # parked workers (first step after an update) need the post
-        if self._done is not None:                       # semaphore mode: every touched worker parked and posts when done
-            for w in touched:
-                if not self._done[w].acquire(timeout=60):
-                    raise RuntimeError(f"env worker {w} did not answer (exitcode {self._procs[w].exitcode})")
-            return
-        done = v["done"]
-        n = 0
-        while not (done[touched, 0] == seq).all():
-            n += 1
-            if n % 4096 == 0:                            # every ~ms: liveness of the workers, and an overall deadline
-                dead = [int(w) for w in touched if not self._procs[w].is_alive()]
-                if dead or n > 4096 * 60000:
-                    raise RuntimeError(f"env workers {dead or list(map(int, touched))} did not answer")
-                for w in touched[v["parked"][touched, 0] != 0]:
-                    self._wake[w].release()
+        self._gen[lane] = (self._gen[lane] + 1) & 0x7FFFFFFF or 1
+        g = self._gen[lane]
+        es = self._lane_env[lane]
+        if len(ids) == es.stop - es.start:               # the whole lane
+            v["active"][es] = 1
+            ws = self._lane_wrk[lane]
+            v["want"][ws, 0] = g
+            n = ws.stop - ws.start
+        else:
+            v["active"][es] = 0
+            v["active"][ids] = 1
+            touched = np.unique(self._owner[ids])
+            v["want"][touched, 0] = g
+            n = len(touched)
+        v["hs"][lane, 2, 0] = cmd
+        self._inflight[lane] = ids
+        self._lib.fsrl_env_post(self._gen_p[lane], self._pend_p[lane], n, g)
+
+    def _wait(self, lane):
+        ids = self._inflight[lane]
+        assert ids is not None, "nothing in flight on this lane"
+        waited = 0
+        while self._lib.fsrl_env_wait_done(self._pend_p[lane], self._spin, 2000) != 0:
+            waited += 2
+            dead = [w for w in np.unique(self._owner[ids]) if not self._procs[w].is_alive()]
+            if dead or waited >= 60:
+                self._inflight[lane] = None
+                raise RuntimeError(f"env workers {dead or 'of lane %d' % lane} did not answer")
+        self._inflight[lane] = None
+        return ids
+
+    def _split(self, ids):
+        """ids (any order) -> [(lane, positions into ids)] for the lanes they touch"""
+        lane = self.lane_of_env[ids]
+        return [(l, np.flatnonzero(lane == l)) for l in range(self.n_lanes) if (lane == l).any()]
+
+    def _run(self, cmd, ids):
+        parts = self._split(ids)
+        for l, pos in parts:
+            self._post(l, cmd, ids[pos])
+        for l, _ in parts:
+            self._wait(l)
 
     def reset(self, ids=None, **kwargs):
         ids = np.arange(self.env_num) if ids is None else np.asarray(ids)
         self._run(_CMD_RESET, ids)
         return self._v["obs"][ids].copy(), {}
 
+    def _results(self, ids):
+        v = self._v
+        if len(ids) and len(ids) == int(ids[-1]) - int(ids[0]) + 1:       # a contiguous range (sorted unique ids): basic slices
+            ids = slice(int(ids[0]), int(ids[-1]) + 1)
+            return (v["obs"][ids].copy(), v["rew"][ids].copy(), v["term"][ids].astype(bool), v["trunc"][ids].astype(bool),
+                    {"cost": v["cost"][ids].copy()})
+        return (v["obs"][ids], v["rew"][ids], v["term"][ids].astype(bool), v["trunc"][ids].astype(bool), {"cost": v["cost"][ids]})
+
     def step(self, act, ids=None):
         ids = np.arange(self.env_num) if ids is None else np.asarray(ids)
         self._v["act"][ids] = np.asarray(act, np.float32).reshape(len(ids), self.act_dim)
         self._run(_CMD_STEP, ids)
-        v = self._v
-        return (v["obs"][ids].copy(), v["rew"][ids].copy(), v["term"][ids].astype(bool), v["trunc"][ids].astype(bool),
-                {"cost": v["cost"][ids].copy()})
+        return self._results(ids)
+
+    # ---- split-phase interface: one lane steps while the collector works on the other
+    def step_async(self, act, ids):
+        """Start a step of `ids` (all in ONE lane) and return at once; `step_wait(ids)` collects it."""
+        ids = np.asarray(ids)
+        lane = int(self.lane_of_env[ids[0]])
+        assert (self.lane_of_env[ids] == lane).all(), "step_async: the ids of one call belong to one lane"
+        self._v["act"][ids] = np.asarray(act, np.float32).reshape(len(ids), self.act_dim)
+        self._post(lane, _CMD_STEP, ids)
+
+    def step_wait(self, ids):
+        ids = np.asarray(ids)
+        got = self._wait(int(self.lane_of_env[ids[0]]))
+        assert len(got) == len(ids)
+        return self._results(ids)
 
     def close(self):
         if self._closed:
             return
         self._closed = True
-        self._v["cmd"][0] = _CMD_EXIT
-        self._seq += 1
-        self._v["go"][:self.workers, 0] = self._seq
-        for g in self._wake:
-            g.release()
+        for l in range(2):
+            self._v["hs"][l, 2, 0] = _CMD_EXIT
+            self._gen[l] = (self._gen[l] + 1) & 0x7FFFFFFF or 1
+            self._lib.fsrl_env_post(self._gen_p[l], self._pend_p[l], 0, self._gen[l])
         for p in self._procs:
             p.join(5)
             if p.is_alive():
                 p.terminate()
         self._v = None
+        self._gen_p = self._pend_p = None
         self._shm.close()
         try:
             self._shm.unlink()

@@ -3,7 +3,7 @@
 not available in the build or GPU images; this env exists so that env-steps/s and the
 collector -> store -> update loop can be exercised end to end.  It is NOT a physics model:
 `obs' = A obs + B act + noise`, reward = progress along a circle, cost = 1 outside a band.
-`busy_us` burns host time per env step to mimic a simulator's cost (0 = free)."""
+`busy_us`: host time one env step takes in total, to mimic a simulator's cost (0 = free)."""
 import time
 
 import numpy as np
@@ -55,12 +55,12 @@ class SyntheticSafetyVectorEnv:
         return self.state[ids].copy(), {}
 
     def step(self, act, ids=None):
+        # an env step costs busy_us of host time IN TOTAL (the few microseconds of numpy below count towards it, like a
+        # simulator's own arithmetic would): the clock is read first, the remainder is burnt at the end
+        t_in = time.perf_counter() if self.busy_us > 0 else 0.0
         ids = np.arange(self.env_num) if ids is None else np.asarray(ids)
         act = np.asarray(act, np.float32).reshape(len(ids), self.act_dim)
-        if self.busy_us > 0:
-            end = time.perf_counter() + self.busy_us * 1e-6 * len(ids)
-            while time.perf_counter() < end:
-                pass
+        end = t_in + self.busy_us * 1e-6 * len(ids) if self.busy_us > 0 else 0.0
         s = self.state[ids] @ self.A + act @ self.B
         s += 0.05 * self.rng.standard_normal(s.shape).astype(np.float32)
         self.state[ids] = s
@@ -69,6 +69,8 @@ class SyntheticSafetyVectorEnv:
         cost = (np.abs(s[:, 1]) > 1.0).astype(np.float64)
         truncated = self.t[ids] >= self.episode_len
         terminated = np.zeros(len(ids), bool)
+        while end and time.perf_counter() < end:
+            pass
         return s.copy(), rew, terminated, truncated, {"cost": cost}
 
     def close(self):

@@ -110,3 +110,51 @@ def test_deterministic_collect_step_rows_equal_host_mirror_collector(which):
     # contracting, so rows stay within 1e-5 over the 23-step episodes
     for k in ("obs", "act", "obs_next", "rew"):
         np.testing.assert_allclose(rows_d[k], rows_h[k], rtol=0, atol=1e-5, err_msg=k)
+
+
+def test_split_phase_collect_stores_the_rows_of_the_plain_fused_loop():
+    """FastCollector(split_phase=True) over the two lanes of the worker-process env against the plain fused loop over the
+    same env (same seed, policy.eval() so that no noise stream is involved): every env's trajectory depends on its own
+    worker's random stream and the actions it is given only, so where both loops keep the SAME envs they must store the
+    SAME rows in the SAME slots.  They keep the same envs whenever nothing or everything is dropped at an episode boundary
+    (n_episode a multiple of the env count, or below it); otherwise the plain loop drops the first finished envs of the whole
+    vector and the split loop the first finished envs of the lane that reports last -- equally exact, different envs -- and
+    only the episode accounting is compared."""
+    from fsrl_amd.agent import PPOLagAgent
+    from fsrl_amd.data import FastCollector, HipVectorReplayBuffer
+    from fsrl_amd.env import ShmemVectorEnv
+
+    def run(split, n_list):
+        env = ShmemVectorEnv(env_num=6, workers=6, obs_dim=8, act_dim=2, episode_len=17, seed=4)
+        try:
+            agent = PPOLagAgent(env, None, cost_limit=10, device="cuda:0", seed=2, hidden_sizes=(64, 64), training_num=6)
+            agent.policy.eval()
+            eng = agent.policy.engine
+            buf = HipVectorReplayBuffer(eng, 6 * 300, 6)
+            col = FastCollector(agent.policy, env, buf, exploration_noise=False, device_actor=True, split_phase=split)
+            assert col.split_phase == split
+            stats = [col.collect(n_episode=n) for n in n_list]
+            idx = eng.sample0()
+            rows = eng.store_read(idx)
+            sizes = buf._sizes.copy()
+            eng.close()
+            return stats, idx, rows, sizes
+        finally:
+            env.close()
+
+    same = (6, 12, 3, 1, 18)
+    st_s, idx_s, rows_s, _ = run(True, same)
+    st_p, idx_p, rows_p, _ = run(False, same)
+    assert np.array_equal(idx_s, idx_p)
+    for a, b in zip(st_s, st_p):
+        assert {k: v for k, v in a.items() if k != "rew"} == {k: v for k, v in b.items() if k != "rew"}, (a, b)
+        assert abs(a["rew"] - b["rew"]) <= 1e-9 * max(1.0, abs(b["rew"]))          # the mean is taken in a different order
+    for k in rows_p:
+        assert np.array_equal(rows_s[k], rows_p[k]), k
+    # episode-exact collection when envs are dropped mid-way: exactly n whole episodes, whole episodes per env
+    ragged = (10, 7, 4, 11)
+    st_s, _, rows_s, sizes = run(True, ragged)
+    assert [s["n/ep"] for s in st_s] == list(ragged) and all(s["len"] == 17.0 and s["truncated"] == 1.0 for s in st_s)
+    assert [s["n/st"] for s in st_s] == [17 * n for n in ragged]
+    assert int(sizes.sum()) == 17 * sum(ragged) and (sizes % 17 == 0).all()
+    assert int(rows_s["truncated"].sum()) == sum(ragged)
