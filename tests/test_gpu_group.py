@@ -202,3 +202,28 @@ def test_destroying_member_zero_first_leaves_the_other_members_usable():
     s_b, _ = engs[1].ppo_update([0.4], 1 / 1.4, 64, 1, seed=12)
     assert np.isfinite(s_b).all()
     engs[1].close(); ref.close()
+
+
+@pytest.mark.parametrize("H,k", [(128, 6), (256, 8)])
+def test_large_groups_match_member_by_member(H, k):
+    """More members than fill the chip in one round (k x 16 tiles x 3 networks > 256 workgroups).  The members' own updates
+    use 4-row tiles at this minibatch size (v_mfma_f32_4x4x1: another K order), so the logged rows agree to fp32 rounding
+    and the parameters to a few 1e-6 after four Adam steps."""
+    from fsrl_amd.engine import EngineGroup
+    T = 300                                                     # 600 rows per member: minibatches of 256 and 344 (merged)
+    engs = [_filled(T, 20 + i, None, H=H) for i in range(k)]
+    solo = [_filled(T, 20 + i, None, H=H) for i in range(k)]
+    grp = EngineGroup(engs)
+    rng = np.random.default_rng(1)
+    perms = [[rng.permutation(2 * T) for _ in range(2)] for _ in range(k)]
+    lags = np.linspace(0.1, 0.9, k).reshape(k, 1)
+    resc = [1.0 / (1.0 + float(l)) for l in lags[:, 0]]
+    st, stop = grp.ppo_update(lags, resc, 256, 2, perms=perms)
+    for i, e in enumerate(solo):
+        s1, _ = e.ppo_update(lags[i], resc[i], 256, 2, perms=perms[i])
+        assert st[i].shape == s1.shape == (4, 11)
+        np.testing.assert_allclose(st[i], s1, rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(engs[i].get_params(), e.get_params(), rtol=0, atol=2e-5)
+    grp.close()
+    for e in engs + solo:
+        e.close()

@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_actor.py -q -x -k split 2>&1 | tail -2
-python tools/bench_shmem.py --seconds 3
+python tools/bench_group.py --ks 4 8 --updates 5 | cut -c1-110
+python tools/bench_group.py --ks 4 8 --updates 5 --xcd | cut -c1-110
+python tools/bench_group.py --ks 4 --updates 5 | cut -c1-110
+python tools/bench_group.py --ks 4 --updates 5 --xcd | cut -c1-110
