@@ -126,6 +126,17 @@ __device__ __forceinline__ f32x4 mfma_4x4x1(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 
+// 16-byte store of data the NEXT launch reads on other XCDs (activation side buffers, freshly stepped parameters): written
+// through (`sc1`), so the line leaves this XCD's L2 at once instead of sitting dirty until the kernel-boundary write-back and
+// the reader's first touch finds it in the Infinity Cache.  Same-box A/B on the headline bench: 112.4 -> 116.6 updates/s, the
+// fused kernel 13.8 -> 12.9 us (MI355X_MICROARCH.md "publish-large"); 4-byte sc1 stores (D1, DO, gradient) added nothing.
+__device__ __forceinline__ void store4_next(float* p, const f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");   // s_nop: the store-data hazard of a >8-byte VMEM store
+}
+// the full-batch / replay kernels' 16-byte spills (A1 / A2 / D2 and the R-op operands, 20 MB arrays at N = 20 000): the same
+// write-through.  A/B: CPO 38.9 -> 38.65 ms, TRPO-Lag 32.4 -> 32.0 ms, SAC-Lag 6 450 -> 6 610 updates/s.
+__device__ __forceinline__ void store4_fb(float* p, const f32x4 v) { store4_next(p, v); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -56,8 +56,8 @@ __device__ __forceinline__ void tile_backward(TileSmem<H, tile_rows(R)>& sm, con
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
     for (int e = tid; e < R * H4; e += NT) {
         const int i = e / H4, c4 = e - i * H4;
-        *reinterpret_cast<f32x4*>(&A1[(size_t)i * H + 4 * c4]) = *reinterpret_cast<const f32x4*>(&sm.h1[i * LD + 4 * c4]);
-        *reinterpret_cast<f32x4*>(&A2[(size_t)i * H + 4 * c4]) = *reinterpret_cast<const f32x4*>(&sm.h2[i * LD + 4 * c4]);
+        store4_fb(&A1[(size_t)i * H + 4 * c4], *reinterpret_cast<const f32x4*>(&sm.h1[i * LD + 4 * c4]));
+        store4_fb(&A2[(size_t)i * H + 4 * c4], *reinterpret_cast<const f32x4*>(&sm.h2[i * LD + 4 * c4]));
     }
     for (int t = tid; t < (R / 4) * H; t += NT) {   // dz2 = (dout @ W3) * relu'(z2); one trip up to 16 rows, two for 32
         const int k = t % H, rg = t / H;
@@ -76,7 +76,7 @@ __device__ __forceinline__ void tile_backward(TileSmem<H, tile_rows(R)>& sm, con
     __syncthreads();
     for (int e = tid; e < R * H4; e += NT) {
         const int i = e / H4, c4 = e - i * H4;
-        *reinterpret_cast<f32x4*>(&D2[(size_t)i * H + 4 * c4]) = *reinterpret_cast<const f32x4*>(&sm.d2[i * LD + 4 * c4]);
+        store4_fb(&D2[(size_t)i * H + 4 * c4], *reinterpret_cast<const f32x4*>(&sm.d2[i * LD + 4 * c4]));
     }
     for (int e = tid; e < R * FSRL_DOW; e += NT) DOb[e] = sm.dout[e];
     // dz1 = (dz2 @ W2) * relu'(z1)
@@ -782,8 +782,8 @@ __device__ __forceinline__ void hvp_tile_body(Hvp32Smem<H>& sm, const float* __r
         const int i = e / H4, c4 = e - i * H4;
         const size_t o = base + (size_t)i * H + 4 * c4;
         const int l = i * LD + 4 * c4;
-        *reinterpret_cast<f32x4*>(a.RA1 + o) = *reinterpret_cast<const f32x4*>(&rh1[l]);
-        if constexpr (!CACHED) *reinterpret_cast<f32x4*>(a.A1 + o) = *reinterpret_cast<const f32x4*>(&h1[l]);
+        store4_fb(a.RA1 + o, *reinterpret_cast<const f32x4*>(&rh1[l]));
+        if constexpr (!CACHED) store4_fb(a.A1 + o, *reinterpret_cast<const f32x4*>(&h1[l]));
     }
     // ---- head pre-activations: out = W3 h2 + b3 ; R{out} = W3 R{h2} + V3 h2 + vb3
     for (int i = wave; i < R; i += WAVES) {
@@ -837,8 +837,8 @@ __device__ __forceinline__ void hvp_tile_body(Hvp32Smem<H>& sm, const float* __r
         const int i = e / H4, c4 = e - i * H4;
         const size_t o = base + (size_t)i * H + 4 * c4;
         const int l = i * LD + 4 * c4;
-        *reinterpret_cast<f32x4*>(a.RA2 + o) = *reinterpret_cast<const f32x4*>(&rh2[l]);
-        if constexpr (!CACHED) *reinterpret_cast<f32x4*>(a.A2 + o) = *reinterpret_cast<const f32x4*>(&h2[l]);
+        store4_fb(a.RA2 + o, *reinterpret_cast<const f32x4*>(&rh2[l]));
+        if constexpr (!CACHED) store4_fb(a.A2 + o, *reinterpret_cast<const f32x4*>(&h2[l]));
     }
     __syncthreads();
     // ---- dz2 = relu'(z2) (dout W3) ; R{dz2} = relu'(z2) (R{dout} W3 + dout V3)      (dz2 -> slot 1, R{dz2} -> slot 3)
@@ -887,8 +887,8 @@ __device__ __forceinline__ void hvp_tile_body(Hvp32Smem<H>& sm, const float* __r
         const int i = e / H4, c4 = e - i * H4;
         const size_t o = base + (size_t)i * H + 4 * c4;
         const int l = i * LD + 4 * c4;
-        *reinterpret_cast<f32x4*>(a.RD2 + o) = *reinterpret_cast<const f32x4*>(&rd2[l]);
-        if constexpr (!CACHED) *reinterpret_cast<f32x4*>(a.D2 + o) = *reinterpret_cast<const f32x4*>(&d2[l]);
+        store4_fb(a.RD2 + o, *reinterpret_cast<const f32x4*>(&rd2[l]));
+        if constexpr (!CACHED) store4_fb(a.D2 + o, *reinterpret_cast<const f32x4*>(&d2[l]));
     }
     for (int e = tid; e < R * FSRL_DOW; e += NT) {
         a.RDO[(size_t)row0 * FSRL_DOW + e] = sm.rdout[e];

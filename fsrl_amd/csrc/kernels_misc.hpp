@@ -334,9 +334,9 @@ __device__ __forceinline__ void adam_clip_body(float* __restrict__ P, float* __r
         }
         *reinterpret_cast<f32x4*>(M + i4) = m;
         *reinterpret_cast<f32x4*>(V + i4) = v;
-        *reinterpret_cast<f32x4*>(P + i4) = p;
+        store4_next(P + i4, p);
         const int mi = w2f_mirror_of(md, i4);           // 4 consecutive k of one W2 row = one mirror float4
-        if (mi >= 0) *reinterpret_cast<f32x4*>(P + mi) = p;
+        if (mi >= 0) store4_next(P + mi, p);
     }
     // pass-level KL early stop (ppo_lag.py:251-255); only after the last minibatch of a pass
     if (sa.last_in_pass && blockIdx.x == 0 && tid == 0 && sa.target_kl > 0.0f) {

@@ -497,10 +497,8 @@ __device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* _
         constexpr int H4 = H / 4;
         for (int e = tid; e < R * H4; e += NT) {
             const int i = e / H4, c4 = e - i * H4;
-            *reinterpret_cast<f32x4*>(&A1[(size_t)i * H + 4 * c4]) =
-                *reinterpret_cast<const f32x4*>(&sm.h1[i * LD + 4 * c4]);
-            *reinterpret_cast<f32x4*>(&A2[(size_t)i * H + 4 * c4]) =
-                *reinterpret_cast<const f32x4*>(&sm.h2[i * LD + 4 * c4]);
+            store4_next(&A1[(size_t)i * H + 4 * c4], *reinterpret_cast<const f32x4*>(&sm.h1[i * LD + 4 * c4]));
+            store4_next(&A2[(size_t)i * H + 4 * c4], *reinterpret_cast<const f32x4*>(&sm.h2[i * LD + 4 * c4]));
         }
     }
 
@@ -639,8 +637,7 @@ __device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* _
         constexpr int H4 = H / 4;
         for (int e = tid; e < R * H4; e += NT) {
             const int i = e / H4, c4 = e - i * H4;
-            *reinterpret_cast<f32x4*>(&D2[(size_t)i * H + 4 * c4]) =
-                *reinterpret_cast<const f32x4*>(&sm.d2[i * LD + 4 * c4]);
+            store4_next(&D2[(size_t)i * H + 4 * c4], *reinterpret_cast<const f32x4*>(&sm.d2[i * LD + 4 * c4]));
         }
         float* __restrict__ DOb = bp.DO + (nb + row0) * FSRL_DOW;
         for (int e = tid; e < R * FSRL_DOW; e += NT) DOb[e] = sm.dout[e];
