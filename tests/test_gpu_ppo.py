@@ -195,9 +195,12 @@ def test_update_is_deterministic_and_idempotent_setup():
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
-def test_full_size_update_vs_oracle():
-    """BASELINE configs[1] shape (obs 8, act 2, 256x256, 20 100 rows = 67 episodes x 300,
-    B 256, repeat 1 to keep the CPU oracle in seconds): stats and parameters vs the oracle."""
+@pytest.mark.parametrize("repeat", [1, 4])
+def test_full_size_update_vs_oracle(repeat):
+    """BASELINE configs[1] shape (obs 8, act 2, 256x256, 20 100 rows = 67 episodes x 300, B 256): stats and parameters vs the
+    oracle.  repeat 1: one pass (78 steps), tight early + envelope.  repeat 4: the headline workload's 312 dependent steps,
+    judged against the float64 run of the same algorithm -- the device must stay as close to it as the reference-equivalent
+    fp32 oracle does (both are fp32 trajectories of a chaotic map; neither can track the other step by step that long)."""
     from oracle.ppo_lag import OnPolicyData, PPOLagConfig, PPOLagOracle
     from fsrl_amd.engine import Engine, EngineConfig
     rng = np.random.default_rng(11)
@@ -228,13 +231,13 @@ def test_full_size_update_vs_oracle():
     data = OnPolicyData(obs=cat["obs"], act=cat["act"], rew=cat["rew"], cost=cat["cost"],
                         terminated=cat["term"], truncated=cat["trunc"], obs_next=cat["obs_next"],
                         end_flag=cat["term"] | cat["trunc"])
-    lag = np.array([0.75]); perm = rng.permutation(len(data))
+    lag = np.array([0.75]); perms = [rng.permutation(len(data)) for _ in range(repeat)]
     torch.set_num_threads(4)
     o64 = PPOLagOracle(ocfg, dtype=torch.float64); o64.set_params(theta)
-    pb, ostats, _ = o.update(data, lag, _rescale(lag), 256, 1, perms=[perm])
-    _, xstats, _ = o64.update(data, lag, _rescale(lag), 256, 1, perms=[perm])
-    stats, _ = eng.ppo_update(lag, _rescale(lag), 256, 1, perms=[perm])
-    assert stats.shape == ostats.shape == (78, 11)
+    pb, ostats, _ = o.update(data, lag, _rescale(lag), 256, repeat, perms=perms)
+    _, xstats, _ = o64.update(data, lag, _rescale(lag), 256, repeat, perms=perms)
+    stats, _ = eng.ppo_update(lag, _rescale(lag), 256, repeat, perms=perms)
+    assert stats.shape == ostats.shape == (78 * repeat, 11)
     np.testing.assert_allclose(eng.batch_get("advs"), pb["advs"].numpy(), rtol=0, atol=2e-5)
     # PPO's objective is discontinuous in theta (ratio clip, ReLU kinks, grad-norm clip), so fp32
     # rounding differences are amplified chaotically over tens of dependent steps in ANY fp32
@@ -245,10 +248,25 @@ def test_full_size_update_vs_oracle():
     scale = np.maximum(np.abs(xstats).max(0), 1e-2)
     early = np.abs(stats[:10] - ostats[:10]).max(0)
     assert (early <= 2e-5 * scale + 1e-6).all(), f"first 10 steps: {early} (scale {scale})"
-    late = np.abs(stats - ostats).max(0)
-    assert (late <= 2e-2 * scale).all(), f"all steps: {late} (scale {scale})"
-    dth = np.abs(eng.get_params() - o.get_params())
-    assert dth.max() <= 5e-2 and dth.mean() <= 2e-4, (dth.max(), dth.mean())
+    if repeat == 1:
+        late = np.abs(stats - ostats).max(0)
+        assert (late <= 2e-2 * scale).all(), f"all steps: {late} (scale {scale})"
+        dth = np.abs(eng.get_params() - o.get_params())
+        assert dth.max() <= 5e-2 and dth.mean() <= 2e-4, (dth.max(), dth.mean())
+    else:
+        # per-pass means of every logged statistic against the float64 run, in units of the statistic's scale: in pass 4 the
+        # fp32 oracle sits 1e-4 .. 7e-3 away and so does the device, but WHICH statistic drifts most differs between two fp32
+        # trajectories, and the device (MFMA k-class sums) leaves the float64 path a pass earlier than the torch fp32 run,
+        # whose summation order is the float64 run's own (pass 2: 2e-3 vs 1e-5; pass 4: 5e-3 vs 7e-3).  The bar is on the
+        # worst statistic of each pass: 3x the fp32 oracle's distance, or 1e-2 of the scale (half the one-pass envelope)
+        pm = lambda a: a.reshape(repeat, 78, 11).mean(1)  # noqa: E731
+        e_dev = (np.abs(pm(stats) - pm(xstats)) / scale).max(1)
+        e_ref = (np.abs(pm(ostats) - pm(xstats)) / scale).max(1)
+        print("worst per-pass statistic vs f64 (units of scale): device", e_dev, " fp32 oracle", e_ref)
+        assert (e_dev <= np.maximum(3.0 * e_ref, 1e-2)).all(), (e_dev, e_ref)
+        d_dev, d_ref = np.abs(eng.get_params() - o64.get_params()), np.abs(o.get_params() - o64.get_params())
+        print("theta vs f64: device max / mean", d_dev.max(), d_dev.mean(), " fp32 oracle max / mean", d_ref.max(), d_ref.mean())
+        assert d_dev.mean() <= 3.0 * d_ref.mean() + 1e-4 and d_dev.max() <= 3.0 * d_ref.max() + 1e-3
     print("fp64 yardstick: |hip-f64| stats", np.abs(stats - xstats).max(), "|f32-f64| stats",
           np.abs(ostats - xstats).max())
     eng.close()

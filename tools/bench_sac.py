@@ -87,6 +87,11 @@ def main():
     out["roofline"] = {"bound": "mfma", "scope": "whole update (12 launches)", "achieved": flops / dev / 1e12, "peak": 157.3,
                        "unit": "TFLOP/s", "frac": flops / dev / 1e12 / 157.3, "flops_per_update": flops,
                        "algorithmic_gather_bytes": B * ((2 * Do + Da) * 4 + 17), "traffic": None}
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from bench_trust import pmc_update_traffic
+    tb, src = pmc_update_traffic("sac")
+    if tb is not None:        # HBM-side bytes per update (PMC, profiles/): the gathered rows are ~0.3 MB of it, the rest is parameters,
+        out["roofline"].update(traffic=tb, traffic_source=src, traffic_gb_per_s=tb / dev / 1e9)   # Adam state and side buffers
     if not a.no_cpu:
         torch.set_num_threads(4)
         o.set_params(th_a, th_c, 0.0)

@@ -17,6 +17,19 @@ from oracle.ppo_lag import OnPolicyData  # noqa: E402
 from oracle.trust_region import CPOConfig, CPOOracle, TRPOConfig, TRPOLagOracle  # noqa: E402
 
 
+def pmc_update_traffic(alg):
+    """HBM-side bytes per update from the committed PMC passes (profiles/rNN_pmc_traffic_updates.json: FETCH_SIZE x 2 +
+    WRITE_SIZE over a whole traced run / its updates); counters cannot be read inside this process.  None without a capture."""
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for tag in ("r05", "r04", "r03"):
+        f = os.path.join(here, "profiles", f"{tag}_pmc_traffic_updates.json")
+        if os.path.exists(f):
+            d = json.load(open(f)).get(alg)
+            if d:
+                return float(d["hbm_bytes_per_update"]), f"profiles/{tag}_pmc_traffic_updates.json"
+    return None, None
+
+
 def inputs(rng, envs, T, obs_dim, act_dim, ep):
     obs = rng.standard_normal((T + 1, envs, obs_dim)).astype(np.float32)
     act = (0.3 * rng.standard_normal((T, envs, act_dim))).astype(np.float32)
@@ -90,6 +103,12 @@ def run(kind, obs_dim, act_dim, hid, envs=20, T=1000, ep=1000, repeat=4, cpu_rep
     roof = {"bound": "mfma", "scope": "whole update (all launches, host line-search control included)",
             "achieved": flops / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / dt / 1e12 / 157.3,
             "flops_per_update": flops, "traffic": None}
+    tb, src = pmc_update_traffic(kind)
+    if tb is not None:
+        # algorithmic: every full-batch pass reads the 60 B/row inputs once + the side buffers it spills for the
+        # weight-side kernel; the figure below is what the memory side actually moved per update
+        roof.update(traffic=tb, traffic_source=src, traffic_gb_per_s=tb / dt / 1e9,
+                    algorithmic_input_bytes_per_pass=60 * N)
     if os.environ.get("FSRL_NO_CPU"):
         print(json.dumps({"bench": kind, "hip_ms_per_update": dt * 1e3, "roofline": roof})); eng.close(); return
     em = lambda a: np.concatenate([a[:, e] for e in range(envs)])

@@ -65,6 +65,33 @@ if out:
     json.dump(out, open(os.path.join(pr, f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps({k: round(v["hbm_bytes_per_launch"]) for k, v in out.items()}, indent=1))
 
+# ---- HBM-side bytes per UPDATE of the full-batch / replay paths: every kernel's FETCH_SIZE x 2 + WRITE_SIZE summed over
+#      the run, divided by the updates the traced command made (bench_trust.py: 1 warm-up + 3 timed; bench_sac.py: 20 + 200)
+upd = {}
+for alg, n_upd in (("cpo", 4), ("trpo", 4), ("sac", 220)):
+    by = defaultdict(lambda: {"launches": 0, "fetch_kib": 0.0, "write_kib": 0.0})
+    ok = False
+    for cname, key in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib")):
+        f = one(f"{tag}_pmc_{cname}_{alg}/**/*_counter_collection.csv")
+        if not f:
+            continue
+        ok = True
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0]
+            by[name][key] += float(r["Counter_Value"])
+            if key == "fetch_kib":
+                by[name]["launches"] += 1
+    if not ok:
+        continue
+    tot = sum((2 * t["fetch_kib"] + t["write_kib"]) * 1024 for t in by.values())
+    upd[alg] = {"updates_in_run": n_upd, "hbm_bytes_per_update": tot / n_upd,
+                "by_kernel_bytes_per_launch": {k: (2 * t["fetch_kib"] + t["write_kib"]) * 1024 / max(t["launches"], 1)
+                                               for k, t in sorted(by.items(), key=lambda kv: -(2 * kv[1]["fetch_kib"] + kv[1]["write_kib"]))[:12]},
+                "launches_per_update": {k: t["launches"] / n_upd for k, t in by.items() if t["launches"] >= n_upd}}
+if upd:
+    json.dump(upd, open(os.path.join(pr, f"{tag}_pmc_traffic_updates.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: round(v["hbm_bytes_per_update"] / 1e6, 1) for k, v in upd.items()}), "MB per update")
+
 # ---- MFMA utilisation per kernel from the SQ counter passes (one dispatch = one row per counter):
 #      util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x SIMDs) -- rocprofv3's own MfmaUtil expression, 256 CUs x 4
 #      SIMDs; SQ_VALU_MFMA_BUSY_CYCLES is the sum over all SIMDs of the cycles their matrix pipe was busy (K1: 192
