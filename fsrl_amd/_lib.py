@@ -22,6 +22,14 @@ class Config(C.Structure):
                 ("unbounded", C.c_int32), ("rew_norm", C.c_int32), ("value_clip", C.c_int32)]
 
 
+class ShmEnv(C.Structure):
+    """struct fsrl_shm_env (include/fsrl_hip.h): the worker-process env's shared block, as fsrl_collect_run sees it"""
+    _fields_ = [("obs", C.c_void_p), ("act", C.c_void_p), ("rew", C.c_void_p), ("cost", C.c_void_p), ("term", C.c_void_p),
+                ("trunc", C.c_void_p), ("active", C.c_void_p), ("hs", C.c_void_p), ("want", C.c_void_p), ("owner", C.c_void_p),
+                ("lane_of_worker", C.c_void_p), ("env_num", C.c_int32), ("obs_dim", C.c_int32), ("act_dim", C.c_int32),
+                ("workers", C.c_int32), ("n_lanes", C.c_int32), ("gen", C.c_uint32 * 2), ("spin", C.c_uint32)]
+
+
 class TrConfig(C.Structure):
     """struct fsrl_tr_config (include/fsrl_hip.h)"""
     _fields_ = [("target_kl", C.c_float), ("backtrack_coeff", C.c_float), ("damping", C.c_float),
@@ -118,6 +126,8 @@ SIGNATURES = {
     "fsrl_actor_sample": (C.c_int, [_ctx, _f, C.c_int32, C.c_int32, C.c_uint64, _f]),
     "fsrl_collect_step": (C.c_int, [_ctx, _i32, C.c_int32, _f, _f, _d, _d, _u8, _u8, _f, _i64, _d, _i32, _i64,
                                     _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, _f, _f]),
+    "fsrl_collect_run": (C.c_int, [_ctx, _P(ShmEnv), _i32, C.c_int32, _f, _f, _f, C.c_int32, C.c_int32, _f, _f, C.c_int32, _i32, _d, _d, _d,
+                                  _u8, _u8, _f]),
     "fsrl_store_sizes": (C.c_int, [_ctx, _i64, C.c_int32]),
     "fsrl_sac_stats_drain": (C.c_int64, [_ctx, _f, C.c_int64]),
     "fsrl_sac_last_sample": (C.c_int, [_ctx, _i64, _f, _f, C.c_int32]),

@@ -973,6 +973,8 @@ extern "C" int fsrl_gae_return(fsrl_ctx* c, const float* v, const float* v_next,
     return 0;
 }
 
+#include "host_collect.inc"
+
 #include "host_ppo.inc"
 
 #include "host_group.inc"

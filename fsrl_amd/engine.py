@@ -72,7 +72,8 @@ class Engine:
         _lib.check(self.lib.fsrl_ctx_create(int(device), C.byref(ccfg), C.byref(self._ctx)))
         self.n_params = int(self.lib.fsrl_param_count(self._ctx))
         self._act_stage = None
-        self._collect_stage = None      # cached staging arrays + ctypes pointers of the collector's hot calls
+        self._collect_stage = None
+        self._run_stage = None      # cached staging arrays + ctypes pointers of the collector's hot calls
         self._push_stage = None
 
     def close(self):
@@ -250,6 +251,35 @@ class Engine:
             p["er"], p["el"], p["ei"], p["oa"], ka, int(deterministic), int(bound_method),
             p["lo"] if low is not None else None, p["hi"] if low is not None else None, p["ao"], p["eo"]))
         return a["ao"][:ka].copy(), a["eo"][:ka].copy(), a["er"][:k], a["el"][:k]
+
+    def collect_run(self, env_desc, ready, obs, act, env_act, deterministic=False, bound_method=1, low=None, high=None,
+                    max_steps=1 << 30):
+        """The collector's inner loop over a worker-process env in one C call (fsrl_collect_run): from the envs `ready` with
+        observations `obs`, policy actions `act` and mapped actions `env_act`, step the env / store / evaluate the actor until
+        a vector step finishes an episode.  -> (steps, cost_sum, obs, act, rew, cost, terminated, truncated, obs_next) where
+        obs / act are the inputs of that last step and rew ... obs_next its (unstored) results."""
+        Do, Da = self.cfg.obs_dim, self.cfg.act_dim
+        n = len(ready)
+        st = self._run_stage
+        if st is None or st["n"] < n:
+            cap = self.cfg.env_num
+            arr = dict(ids=np.empty(cap, np.int32), obs=np.empty((cap, Do), np.float32), act=np.empty((cap, Da), np.float32),
+                       eact=np.empty((cap, Da), np.float32), rew=np.empty(cap, np.float64), cost=np.empty(cap, np.float64),
+                       term=np.empty(cap, np.uint8), trunc=np.empty(cap, np.uint8), nxt=np.empty((cap, Do), np.float32),
+                       lo=np.empty(Da, np.float32), hi=np.empty(Da, np.float32))
+            types = dict(ids=_i32p, obs=_f32p, act=_f32p, eact=_f32p, rew=_f64p, cost=_f64p, term=_u8p, trunc=_u8p, nxt=_f32p,
+                         lo=_f32p, hi=_f32p)
+            st = self._run_stage = dict(n=cap, a=arr, p={k: _ptr(arr[k], types[k]) for k in arr}, steps=C.c_int32(), csum=C.c_double())
+        a, p = st["a"], st["p"]
+        a["ids"][:n] = ready; a["obs"][:n] = obs; a["act"][:n] = act; a["eact"][:n] = env_act
+        if low is not None:
+            a["lo"][:] = low; a["hi"][:] = high
+        _lib.check(self.lib.fsrl_collect_run(
+            self._ctx, C.byref(env_desc), p["ids"], n, p["obs"], p["act"], p["eact"], int(deterministic), int(bound_method),
+            p["lo"] if low is not None else None, p["hi"] if low is not None else None, int(max_steps), C.byref(st["steps"]),
+            C.byref(st["csum"]), p["rew"], p["cost"], p["term"], p["trunc"], p["nxt"]))
+        return (st["steps"].value, st["csum"].value, a["obs"][:n].copy(), a["act"][:n].copy(), a["rew"][:n].copy(),
+                a["cost"][:n].copy(), a["term"][:n].astype(bool), a["trunc"][:n].astype(bool), a["nxt"][:n].copy())
 
     def store_sizes(self, n=None):
         n = self.cfg.env_num if n is None else int(n)

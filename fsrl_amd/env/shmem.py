@@ -242,6 +242,29 @@ class ShmemVectorEnv:
         self._run(_CMD_STEP, ids)
         return self._results(ids)
 
+    # ---- native collector loop (fsrl_collect_run): the shared block as a C struct
+    def native_desc(self):
+        """struct fsrl_shm_env for fsrl_collect_run (include/fsrl_hip.h); the generation counters travel with it (sync_native
+        after the call).  No command may be in flight."""
+        assert self._inflight == [None, None]
+        from fsrl_amd._lib import ShmEnv
+        if getattr(self, "_desc", None) is None:
+            v = self._v
+            self._owner32 = np.ascontiguousarray(self._owner, np.int32)
+            self._low32 = np.ascontiguousarray(self._lane_of_worker, np.int32)
+            d = ShmEnv()
+            for k in ("obs", "act", "rew", "cost", "term", "trunc", "active", "hs", "want"):
+                setattr(d, k, v[k].ctypes.data)
+            d.owner, d.lane_of_worker = self._owner32.ctypes.data, self._low32.ctypes.data
+            d.env_num, d.obs_dim, d.act_dim, d.workers, d.n_lanes = self.env_num, self.obs_dim, self.act_dim, self.workers, self.n_lanes
+            d.spin = self._spin
+            self._desc = d
+        self._desc.gen[0], self._desc.gen[1] = self._gen[0], self._gen[1]
+        return self._desc
+
+    def sync_native(self):
+        self._gen[0], self._gen[1] = int(self._desc.gen[0]), int(self._desc.gen[1])
+
     # ---- split-phase interface: one lane steps while the collector works on the other
     def step_async(self, act, ids):
         """Start a step of `ids` (all in ONE lane) and return at once; `step_wait(ids)` collects it."""
@@ -270,6 +293,7 @@ class ShmemVectorEnv:
             if p.is_alive():
                 p.terminate()
         self._v = None
+        self._desc = None
         self._gen_p = self._pend_p = None
         self._shm.close()
         try:

@@ -158,6 +158,34 @@ int fsrl_collect_step(fsrl_ctx* ctx, const int32_t* env_ids, int32_t k, const fl
                       int64_t* ep_idx_out, const float* obs_act, int32_t k_act, int32_t deterministic,
                       int32_t bound_method, const float* act_low, const float* act_high, float* act_out,
                       float* env_act_out);
+/* The worker-process vector env as the native collector loop sees it: pointers into the env's shared-memory block
+ * (fsrl_amd/env/shmem.py lays it out; tianshou's ShmemVectorEnv is what the reference uses,
+ * examples/mlp/train_ppol_agent.py:120-123) and the geometry of its two handshake lanes.                            */
+typedef struct fsrl_shm_env {
+    float* obs;                 /* [env_num][obs_dim]  written by the workers                          */
+    float* act;                 /* [env_num][act_dim]  written by the collector                        */
+    double* rew; double* cost;  /* [env_num]                                                           */
+    uint8_t* term; uint8_t* trunc; uint8_t* active;     /* [env_num]                                   */
+    uint32_t* hs;               /* [2][3][16]: per lane generation | pending workers | command         */
+    uint32_t* want;             /* [workers][16]: generation of the last command a worker takes part in */
+    const int32_t* owner;       /* [env_num] worker of each env                                        */
+    const int32_t* lane_of_worker;  /* [workers]                                                       */
+    int32_t env_num, obs_dim, act_dim, workers, n_lanes;
+    uint32_t gen[2];            /* in / out: last generation posted per lane                           */
+    uint32_t spin;              /* polls before the collector sleeps on a lane's completion word       */
+} fsrl_shm_env;
+/* FastCollector.collect's inner loop (fast_collector.py:252-340) over that env, in C: starting from the envs `ready`
+ * with observations obs[n], policy actions act[n] and mapped actions env_act[n] (the outputs of the last
+ * fsrl_collect_step), repeat { env.step -> store the transitions, evaluate the actor on the new observations
+ * (= fsrl_collect_step) } until a vector step finishes an episode or max_steps steps were taken.  THAT step's results
+ * come back unstored in rew_out / cost_out / term_out / trunc_out / obs_next_out[n] (the caller resets the finished envs,
+ * drops surplus ones and stores the rows with its next fsrl_collect_step, fast_collector.py:341-362); obs / act /
+ * env_act then hold the inputs of that step.  *steps_out: vector steps taken (>= 1), *cost_sum_out: sum of their costs.
+ * Same random stream and the same stored rows as the per-step calls.                                               */
+int fsrl_collect_run(fsrl_ctx* ctx, fsrl_shm_env* env, const int32_t* ready, int32_t n, float* obs, float* act,
+                     float* env_act, int32_t deterministic, int32_t bound_method, const float* act_low,
+                     const float* act_high, int32_t max_steps, int32_t* steps_out, double* cost_sum_out, double* rew_out,
+                     double* cost_out, uint8_t* term_out, uint8_t* trunc_out, float* obs_next_out);
 /* Fill level of the first n sub-buffers (len(buffer.buffers[e]); ReplayBufferManager.sample_indices weighs by it). */
 int fsrl_store_sizes(const fsrl_ctx* ctx, int64_t* sizes_out, int32_t n);
 

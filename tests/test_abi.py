@@ -66,7 +66,7 @@ def test_ctypes_structs_have_the_layout_the_c_compiler_gives_the_header(tmp_path
     import subprocess
     from fsrl_amd import _lib
     pairs = {"fsrl_config": _lib.Config, "fsrl_tr_config": _lib.TrConfig, "fsrl_sac_config": _lib.SacConfig,
-             "fsrl_focops_config": _lib.FocopsConfig, "fsrl_cvpo_config": _lib.CvpoConfig}
+             "fsrl_focops_config": _lib.FocopsConfig, "fsrl_cvpo_config": _lib.CvpoConfig, "fsrl_shm_env": _lib.ShmEnv}
     lines = ["#include <stddef.h>", "#include <stdio.h>", '#include "fsrl_hip.h"', "int main(void) {"]
     for cname, cls in pairs.items():
         lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')

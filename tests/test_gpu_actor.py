@@ -158,3 +158,39 @@ def test_split_phase_collect_stores_the_rows_of_the_plain_fused_loop():
     assert [s["n/st"] for s in st_s] == [17 * n for n in ragged]
     assert int(sizes.sum()) == 17 * sum(ragged) and (sizes % 17 == 0).all()
     assert int(rows_s["truncated"].sum()) == sum(ragged)
+
+
+@pytest.mark.parametrize("workers", [1, 3, 6])
+def test_native_collector_loop_stores_the_rows_of_the_interpreted_loop(workers):
+    """fsrl_collect_run (the steps in which no episode ends run inside the library: handshake with the env workers, store,
+    actor) against the same loop driven step by step from Python: same library noise stream, same env seeds -> the same
+    rows in the same slots, the same statistics.  Exploration noise ON: the two paths must consume the stream identically."""
+    from fsrl_amd.agent import PPOLagAgent
+    from fsrl_amd.data import FastCollector, HipVectorReplayBuffer
+    from fsrl_amd.env import ShmemVectorEnv
+
+    def run(native):
+        env = ShmemVectorEnv(env_num=6, workers=workers, obs_dim=8, act_dim=2, episode_len=19, seed=4)
+        try:
+            agent = PPOLagAgent(env, None, cost_limit=10, device="cuda:0", seed=2, hidden_sizes=(64, 64), training_num=6)
+            agent.policy.train()
+            eng = agent.policy.engine
+            buf = HipVectorReplayBuffer(eng, 6 * 300, 6)
+            col = FastCollector(agent.policy, env, buf, exploration_noise=True, device_actor=True, native_loop=native)
+            eng.actor_sample(np.zeros((1, 8), np.float32), seed=77)            # key the library stream identically
+            stats = [col.collect(n_episode=n) for n in (6, 10, 3, 1, 7)]
+            idx = eng.sample0()
+            rows = eng.store_read(idx)
+            eng.close()
+            return stats, idx, rows
+        finally:
+            env.close()
+
+    st_n, idx_n, rows_n = run(True)
+    st_p, idx_p, rows_p = run(False)
+    assert np.array_equal(idx_n, idx_p)
+    for a, b in zip(st_n, st_p):
+        assert a == b, (a, b)
+    for k in rows_p:
+        assert np.array_equal(rows_n[k], rows_p[k]), k
+    assert rows_n["act"].std() > 0.1                       # the noise was on
