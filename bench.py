@@ -514,7 +514,9 @@ def main():
         floors_us = LAUNCH_FLOORS_US["fwdbwd"] + LAUNCH_FLOORS_US["wgrad"] + LAUNCH_FLOORS_US["adam"]
         step_flops = fl + flops_wgrad_launch(rows_avg)
         floor_us = floors_us + step_flops / (F32_MFMA_PEAK_TFLOPS * 1e12) * 1e6
-        step_us = learn_ms / prof_steps * 1e3 / grad_steps
+        # per optimiser step in the UN-instrumented timed region: the update minus process_fn (timed here with HIP events; the
+        # event brackets of the profiling mode themselves cost ~8 us per step, so its own learn time is not used)
+        step_us = (dt / args.steps * 1e3 - proc_ms / prof_steps) * 1e3 / grad_steps
         r["latency_floor_us"] = floor_us
         r["latency_floor_parts_us"] = dict(LAUNCH_FLOORS_US, mfma_at_peak=floor_us - floors_us)
         r["step_us"] = step_us

@@ -23,32 +23,29 @@ class BasePolicy(ABC, nn.Module):
                  action_scaling: bool = True, action_bound_method: str = "clip",
                  observation_space=None, action_space=None, lr_scheduler=None) -> None:
         super().__init__()
-        self.actor = actor
-        if isinstance(critics, nn.Module):
-            self.critics = nn.ModuleList([critics])
-        elif isinstance(critics, (list, tuple)):
-            self.critics = nn.ModuleList(critics)
-        else:
-            raise TypeError("critics should not be %s" % (type(critics)))
-        self.critics_num = len(self.critics)
-        self.dist_fn = dist_fn
-        self.logger = logger if logger is not None else DummyLogger()
+        # the attribute names are the drop-in surface: state_dict() keys, the collector and the trainers read them
+        # (fsrl/policy/base_policy.py:96-130)
         assert 0.0 <= gamma <= 1.0, "discount factor should be in [0, 1]."
-        self._rew_norm = bool(reward_normalization)
-        self._gamma = gamma
-        self._deterministic_eval = deterministic_eval
-        self._max_batchsize = max_batchsize
+        assert action_bound_method in self._BOUND
+        self.actor, self.critics = actor, self._as_module_list(critics)
+        self.critics_num = len(self.critics)
         self._actor_critic = ActorCritic(self.actor, self.critics)
-        self.observation_space = observation_space
-        self.action_space = action_space
-        self.action_type = "continuous"
-        self.updating = False
-        self.action_scaling = action_scaling
-        assert action_bound_method in ("", "clip", "tanh")
-        self.action_bound_method = action_bound_method
-        self.lr_scheduler = lr_scheduler
-        self.gradient_steps = 0
+        self.dist_fn, self.lr_scheduler = dist_fn, lr_scheduler
+        self.logger = DummyLogger() if logger is None else logger
+        self._gamma, self._rew_norm, self._max_batchsize = gamma, bool(reward_normalization), max_batchsize
+        self._deterministic_eval = deterministic_eval
+        self.observation_space, self.action_space, self.action_type = observation_space, action_space, "continuous"
+        self.action_scaling, self.action_bound_method = action_scaling, action_bound_method
+        self.updating, self.gradient_steps = False, 0
         self.engine = None  # set by the concrete policy
+
+    @staticmethod
+    def _as_module_list(critics):
+        if isinstance(critics, nn.Module):
+            return nn.ModuleList([critics])
+        if isinstance(critics, (list, tuple)):
+            return nn.ModuleList(critics)
+        raise TypeError("critics should not be %s" % (type(critics)))
 
     # ------------------------------------------------------------------ engine
     def _make_engine(self, device, env_num, buffer_size, optim=None, **cfg_over):
@@ -161,32 +158,44 @@ class BasePolicy(ABC, nn.Module):
     def exploration_noise(self, act, batch):
         return act
 
+    # The two action maps (reference semantics: fsrl/policy/base_policy.py:226-290; the device applies the forward map
+    # itself inside fsrl_collect_step with the same bound codes: 0 none, 1 clip, 2 tanh).
+    _BOUND = {"": 0, "clip": 1, "tanh": 2}
+
+    def _act_range(self):
+        """(low, width) of the env's action box, or None when actions pass through unscaled"""
+        sp = self.action_space
+        if sp is None or not self.action_scaling:
+            return None
+        return sp.low, sp.high - sp.low
+
     def map_action(self, act):
-        """Bound to [-1, 1] then scale to the env's action range (base_policy.py:226-256)."""
-        if self.action_space is not None and isinstance(act, np.ndarray):
-            if self.action_bound_method == "clip":
-                act = np.clip(act, -1.0, 1.0)
-            elif self.action_bound_method == "tanh":
-                act = np.tanh(act)
-            if self.action_scaling:
-                assert np.min(act) >= -1.0 and np.max(act) <= 1.0, \
-                    "action scaling only accepts raw action range = [-1, 1]"
-                low, high = self.action_space.low, self.action_space.high
-                act = low + (high - low) * (act + 1.0) / 2.0
-        return act
+        """policy output -> env action: squash into [-1, 1] (clip or tanh), then stretch onto [low, high]"""
+        if self.action_space is None or not isinstance(act, np.ndarray):
+            return act
+        code = self._BOUND[self.action_bound_method]
+        unit = np.clip(act, -1.0, 1.0) if code == 1 else (np.tanh(act) if code == 2 else act)
+        rng = self._act_range()
+        if rng is None:
+            return unit
+        assert np.min(unit) >= -1.0 and np.max(unit) <= 1.0, "action scaling only accepts raw action range = [-1, 1]"
+        low, width = rng
+        return low + width * (unit + 1.0) / 2.0
 
     def map_action_inverse(self, act):
-        act = np.asarray(act)
-        if self.action_space is not None:
-            if self.action_scaling:
-                low, high = self.action_space.low, self.action_space.high
-                scale = (high - low).copy()
-                eps = np.finfo(np.float32).eps.item()
-                scale[scale < eps] += eps
-                act = (act - low) * 2.0 / scale - 1.0
-            if self.action_bound_method == "tanh":
-                act = (np.log(1.0 + act) - np.log(1.0 - act)) / 2.0
-        return act
+        """env action -> the policy's raw output space (used for random-action collection): undo the stretch, then atanh"""
+        unit = np.asarray(act)
+        if self.action_space is None:
+            return unit
+        rng = self._act_range()
+        if rng is not None:
+            low, width = rng
+            tiny = np.finfo(np.float32).eps.item()
+            width = np.where(width < tiny, width + tiny, width)       # a degenerate dimension must not divide by zero
+            unit = (unit - low) * 2.0 / width - 1.0
+        if self._BOUND[self.action_bound_method] == 2:
+            unit = (np.log(1.0 + unit) - np.log(1.0 - unit)) / 2.0
+        return unit
 
     # ------------------------------------------------------------------ update
     @abstractmethod

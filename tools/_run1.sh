@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_actor.py tests/test_shmem_env.py tests/test_abi.py -q -x 2>&1 | tail -4
-python tools/bench_shmem.py --seconds 3 | cut -c1-60,160-400
-echo no-split; python tools/bench_shmem.py --seconds 3 --no-split | cut -c1-60,160-400
+nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; grep -c processor /proc/cpuinfo; grep "model name" /proc/cpuinfo | head -1
+for i in 1 2 3; do python tools/bench_shmem.py --seconds 2 | cut -c1-40,160-330 | tail -1; done
+cat /sys/fs/cgroup/cpu.stat 2>/dev/null | head -8

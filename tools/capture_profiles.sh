@@ -42,4 +42,7 @@ cd $R
 timeout 600 python tools/bench_trust.py > $O/${TAG}_bench_trust.json 2>/dev/null
 timeout 300 python tools/learning_curves.py > $O/${TAG}_learning_curves.json 2>/dev/null
 timeout 300 python tools/bench_shmem.py > $O/${TAG}_bench_shmem.json 2>/dev/null
+# microbenchmarks the DESIGN notes quote: device-wide barrier flavours, workgroup dispatch rate (prebuilt: tools/ubench/*.bin)
+[ -x tools/ubench/gridsync.bin ] && { timeout 60 tools/ubench/gridsync.bin 217; timeout 60 tools/ubench/gridsync.bin 256; } > $O/${TAG}_ubench_gridsync.txt 2>&1
+[ -x tools/ubench/dispatch.bin ] && timeout 60 tools/ubench/dispatch.bin > $O/${TAG}_ubench_dispatch.txt 2>&1
 ls $O | head -40

@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""Regenerate the measured-numbers tables of README.md and DESIGN.md from the committed profile summaries (profiles/<tag>_*),
+so that no figure in the documents is typed by hand ("docs drift").
+
+    python tools/gen_results_md.py r03          # rewrites the blocks between <!-- BEGIN GENERATED <tag> --> / <!-- END GENERATED <tag> -->
+                                                # in README.md and DESIGN.md, and writes profiles/RESULTS_<tag>.md
+
+Every row names the file it was read from.  Missing inputs leave their rows out."""
+import csv
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PR = os.path.join(ROOT, "profiles")
+
+
+def jl(name):
+    """all JSON objects of a file with one object per line (or one object)"""
+    f = os.path.join(PR, name)
+    if not os.path.exists(f):
+        return []
+    out = []
+    for line in open(f):
+        line = line.strip()
+        if line.startswith("{"):
+            try:
+                out.append(json.loads(line))
+            except ValueError:
+                pass
+    return out
+
+
+def kernels(name, top=6):
+    f = os.path.join(PR, name)
+    if not os.path.exists(f):
+        return []
+    rows = list(csv.DictReader(open(f)))
+    return [(r["Name"].split("(")[0].replace("void ", ""), int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"]))
+            for r in rows[:top]]
+
+
+def fmt(x, d=1):
+    return "n/a" if x is None else f"{x:,.{d}f}"
+
+
+def build(tag):
+    L = []
+    add = L.append
+    b = (jl(f"{tag}_bench.json") or [None])[-1]
+    if b:
+        r = b.get("roofline", {})
+        add(f"### Headline: `bench.py` (`profiles/{tag}_bench.json`)\n")
+        add("| | value |\n|---|---|")
+        add(f"| policy-updates/s (configs[1]: 256x256, N = 20 000, batch 256 x 4 passes, grad-clip 0.5) | **{fmt(b['value'])}** "
+            f"({fmt(b['ms_per_step'], 2)} ms per update, {fmt(b['grad_steps_per_s'], 0)} optimiser steps/s) |")
+        if isinstance(r, dict) and "frac" in r:
+            add(f"| `roofline` of `ppo_fwd_bwd_kernel<256>` | {fmt(r['achieved'], 2)} TFLOP/s of {r['peak']} = **{fmt(r['frac'], 4)}**; "
+                f"{fmt(r['avg_launch_us'], 2)} us per launch ({r['launches_timed']} launches, HIP events); HBM-side traffic "
+                f"{fmt((r.get('traffic') or 0) / 1e6, 1)} MB per launch ({r.get('traffic_source', 'no PMC pass')}) |")
+            if r.get("latency_floor_us"):
+                add(f"| latency floor of an optimiser step (3 launch floors + MFMA work at peak) | {fmt(r['latency_floor_us'], 1)} us vs "
+                    f"{fmt(r['step_us'], 1)} us measured per step = **{fmt(r['frac_of_latency_floor'], 3)}** of the floor |")
+        for key, label in (("cpu_baseline", "CPU port, 4 threads (the reference default)"),
+                           ("cpu_baseline_all_cores", "CPU port, all usable cores"),
+                           ("cpu_baseline_c0", "CPU port at BASELINE configs[0] (128x128, 4 threads)")):
+            c = b.get(key)
+            if isinstance(c, dict) and "value" in c:
+                add(f"| {label} | {fmt(c['value'], 3)} updates/s on {c['cores']} threads |")
+        if isinstance(b.get("gpu_c0"), dict) and "value" in b["gpu_c0"]:
+            add(f"| HIP path at the configs[0] shape (128x128) | {fmt(b['gpu_c0']['value'])} updates/s ({fmt(b['gpu_c0']['us_per_step'], 1)} us per step) |")
+        if "speedup_vs_cpu_port" in b:
+            add(f"| HIP / CPU port (4 threads) | {fmt(b['speedup_vs_cpu_port'], 0)}x |")
+        if isinstance(b.get("no_clip"), dict) and "value" in b["no_clip"]:
+            add(f"| same update without the gradient-norm clip (agent default; 2 launches per step) | {fmt(b['no_clip']['value'])} updates/s |")
+        for key in ("grouped", "grouped_k8"):
+            g = b.get(key)
+            if isinstance(g, dict) and "aggregate_updates_per_s" in g:
+                add(f"| grouped launches, {g['agents_per_gpu']} agents on one GPU | {fmt(g['aggregate_updates_per_s'])} updates/s aggregate "
+                    f"({fmt(g['us_per_agent_step'], 1)} us per agent-step) |")
+        if isinstance(b.get("multi_seed"), dict) and "value" in b["multi_seed"]:
+            add(f"| {b['multi_seed']['seeds_per_gpu']} agents, one host thread + context each | {fmt(b['multi_seed']['value'])} updates/s aggregate |")
+        for key, label in (("end_to_end", "end to end, in-process zero-cost env, 20 envs, device actor"),
+                           ("end_to_end_host_actor", "the same with the host torch actor")):
+            e = b.get(key)
+            if isinstance(e, dict) and "env_steps_per_s" in e:
+                add(f"| {label} | {fmt(e['env_steps_per_s'], 0)} env-steps/s ({fmt(e['update_ms_per_collect'], 2)} ms update per collect) |")
+        for e in b.get("end_to_end_shmem", []) or []:
+            if isinstance(e, dict) and "env_steps_per_s" in e:
+                bound = e.get("env_bound_env_steps_per_s")
+                add(f"| worker-process env: {e['workers']} workers x {e['busy_us']:g} us per env step, 32 envs ({e.get('collector_loop', '')}) | "
+                    f"{fmt(e['env_steps_per_s'], 0)} env-steps/s" + (f" = {fmt(e['frac_of_env_bound'], 2)} of the env bound {fmt(bound, 0)}" if bound else "") + " |")
+        add("")
+    ks = kernels(f"{tag}_kernel_stats.csv")
+    if ks:
+        add(f"Kernel trace of the headline run (`profiles/{tag}_kernel_stats.csv`, rocprofv3 --kernel-trace --stats):\n")
+        add("| kernel | calls | avg us | % |\n|---|---|---|---|")
+        for n, c, us, pc in ks[:5]:
+            add(f"| `{n[:70]}` | {c} | {fmt(us, 2)} | {fmt(pc, 1)} |")
+        add("")
+    tr = jl(f"{tag}_bench_trust.json")
+    upd = {}
+    f = os.path.join(PR, f"{tag}_pmc_traffic_updates.json")
+    if os.path.exists(f):
+        upd = json.load(open(f))
+    if tr or jl(f"{tag}_bench_sac.json"):
+        add(f"### Other update paths (`profiles/{tag}_bench_trust.json`, `_bench_sac.json`, `_bench_cvpo.json`, `_pmc_traffic_updates.json`)\n")
+        add("| update | time | fp32-MFMA fraction (whole update) | HBM-side bytes per update (PMC) | CPU port (4 threads) |\n|---|---|---|---|---|")
+        for t in tr:
+            kind = t.get("bench")
+            rf = t.get("roofline", {})
+            tb = (upd.get(kind) or {}).get("hbm_bytes_per_update")
+            cpu = t.get("cpu_oracle_ms_per_update_4thr")
+            add(f"| {kind.upper()} ({'obs 60, ' if kind == 'cpo' else ''}256x256, N = 20 000) | {fmt(t['hip_ms_per_update'], 1)} ms | {fmt(rf.get('frac'), 3)} | "
+                f"{(fmt(tb / 1e9, 2) + ' GB') if tb else 'n/a'} | {(fmt(cpu / 1e3, 1) + ' s = ' + fmt(t.get('speedup'), 0) + 'x') if cpu else 'n/a'} |")
+        for name, kind in ((f"{tag}_bench_sac.json", "sac"), (f"{tag}_bench_cvpo.json", "cvpo")):
+            for t in jl(name)[-1:]:
+                rf = t.get("roofline", {})
+                us = t.get("ms_per_update", 0) * 1e3 if "ms_per_update" in t else t.get("us_per_update")
+                tb = (upd.get(kind) or {}).get("hbm_bytes_per_update")
+                cb = t.get("cpu_baseline", {})
+                add(f"| {t['config']['workload'][:60]} | {fmt(us, 1)} us = {fmt(t['value'], 0)} updates/s | {fmt(rf.get('frac'), 3)} | "
+                    f"{(fmt(tb / 1e6, 2) + ' MB') if tb else 'n/a'} | {(fmt(cb['value'], 1) + ' updates/s') if 'value' in cb else 'n/a'} |")
+        add("")
+    kt = kernels(f"{tag}_trust_kernel_stats.csv", top=8)
+    if kt:
+        add(f"Kernel trace of `tools/bench_trust.py` (CPO + TRPO-Lag + FOCOPS; `profiles/{tag}_trust_kernel_stats.csv`):\n")
+        add("| kernel | calls | avg us | % |\n|---|---|---|---|")
+        for n, c, us, pc in kt[:7]:
+            add(f"| `{n[:70]}` | {c} | {fmt(us, 1)} | {fmt(pc, 1)} |")
+        add("")
+    f = os.path.join(PR, f"{tag}_pmc_mfma.json")
+    if os.path.exists(f):
+        mf = json.load(open(f))
+        rows = sorted(((k, v) for k, v in mf.items() if v.get("mfma_util_pct") and v.get("mfma_f32_flops_per_launch", 0) > 0),
+                      key=lambda kv: -kv[1]["mfma_util_pct"])
+        if rows:
+            add(f"MFMA utilisation (`SQ_VALU_MFMA_BUSY_CYCLES` / (GPU-active cycles x 1024 SIMDs), own PMC passes; `profiles/{tag}_pmc_mfma.json`):\n")
+            add("| kernel | MFMA-busy % | fp32 MFMA FLOPs per launch (hardware count) |\n|---|---|---|")
+            for k, v in rows[:10]:
+                add(f"| `{k.replace('void ', '')[:70]}` | {fmt(v['mfma_util_pct'], 1)} | {fmt(v['mfma_f32_flops_per_launch'] / 1e6, 1)} M |")
+            add("")
+    g = jl(f"{tag}_bench_group.json")
+    if g:
+        add(f"Grouped launches (`profiles/{tag}_bench_group.json`): " +
+            ", ".join(f"k = {x['agents_per_gpu']}: {fmt(x['aggregate_updates_per_s'])}" for x in g) + " updates/s aggregate.\n")
+    for name, title in ((f"{tag}_ubench_gridsync.txt", "Device-wide barrier inside a kernel (`tools/ubench/gridsync.hip`)"),
+                        (f"{tag}_ubench_dispatch.txt", "Workgroup dispatch rate (`tools/ubench/dispatch.hip`)")):
+        f = os.path.join(PR, name)
+        if os.path.exists(f):
+            add(f"{title}, `profiles/{name}`:\n\n```\n" + open(f).read().strip() + "\n```\n")
+    return "\n".join(L)
+
+
+def splice(path, tag, text):
+    s = open(path).read()
+    a, z = f"<!-- BEGIN GENERATED {tag} -->", f"<!-- END GENERATED {tag} -->"
+    if a not in s:
+        return False
+    s = re.sub(re.escape(a) + r".*?" + re.escape(z), lambda m: a + "\n" + text + "\n" + z, s, flags=re.S)
+    open(path, "w").write(s)
+    return True
+
+
+if __name__ == "__main__":
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    text = build(tag)
+    open(os.path.join(PR, f"RESULTS_{tag}.md"), "w").write(f"# Measured numbers, {tag} (generated by tools/gen_results_md.py from profiles/{tag}_*)\n\n" + text + "\n")
+    for doc in ("README.md", "DESIGN.md"):
+        print(doc, "updated" if splice(os.path.join(ROOT, doc), tag, text) else "has no generated block for " + tag)
