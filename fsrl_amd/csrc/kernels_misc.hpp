@@ -332,8 +332,8 @@ __device__ __forceinline__ void adam_clip_body(float* __restrict__ P, float* __r
             ppo_adam_math(g[e] * coef, me, ve, pe, sa);
             m[e] = me; v[e] = ve; p[e] = pe;
         }
-        *reinterpret_cast<f32x4*>(M + i4) = m;
-        *reinterpret_cast<f32x4*>(V + i4) = v;
+        store4_next(M + i4, m);             // written through as well: nothing of this kernel is left dirty at its boundary
+        store4_next(V + i4, v);             // (same-box A/B: 116.3 -> 116.9 updates/s, every one of three alternations)
         store4_next(P + i4, p);
         const int mi = w2f_mirror_of(md, i4);           // 4 consecutive k of one W2 row = one mirror float4
         if (mi >= 0) store4_next(P + mi, p);
