@@ -26,6 +26,28 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == syms
 
 
+def test_env_library_exports_every_declared_symbol():
+    """include/fsrl_env.h vs libfsrl_env.so (the worker-process env's futex handshake), and one round trip through it on
+    a private word pair: post -> wait_go sees the generation, done -> wait_done sees zero."""
+    src = open(os.path.join(ROOT, "include", "fsrl_env.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(fsrl_env_[a-z0-9_]+)\s*\(", src)))
+    assert len(syms) == 6
+    from fsrl_amd.env import shmem
+    lib = shmem._load_lib()
+    for s_ in syms:
+        assert hasattr(lib, s_), f"{s_} declared in include/fsrl_env.h but not exported"
+    words = (ctypes.c_uint32 * 64)()
+    gen, pend = ctypes.addressof(words), ctypes.addressof(words) + 128
+    lib.fsrl_env_post(gen, pend, 2, 7)
+    assert words[0] == 7 and words[32] == 2
+    assert lib.fsrl_env_wait_go(gen, 6, 10, 50) == 7                 # moved: returns at once
+    assert lib.fsrl_env_wait_go(gen, 7, 10, 20) == 7                 # not moved: times out with the old value
+    assert lib.fsrl_env_wait_done(pend, 10, 30) == -1                # two workers still pending
+    lib.fsrl_env_done(pend); lib.fsrl_env_done(pend)
+    assert lib.fsrl_env_wait_done(pend, 10, 30) == 0
+
+
 def test_config_struct_matches_header_defaults():
     from fsrl_amd import _lib
     lib = _lib.load()
