@@ -315,3 +315,39 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
             assert np.array_equal(ref[k], got[k]), (plan, k, np.abs(np.asarray(ref[k], np.float64) - got[k]).max())
     eng.tr_set_plan(0, 0, 0)
     eng.close()
+
+
+def test_cpo_minibatched_at_full_size():
+    """configs[2] with batch_size below the buffer: N = 20 000 rows, Batch.split(6000, merge_last=True) -> minibatches of
+    6 000 / 6 000 / 8 000 rows of one permutation (cpo.py:357-358).  Every minibatch runs the mixed 32 / 16-row tile plan on
+    a row VIEW of the permuted copy (offsets that are not multiples of 32 rows x obs_dim floats).  First minibatch against
+    the oracle at the full-size bars; the later ones must agree on the dual-solve branch and stay finite."""
+    from oracle.trust_region import CPOConfig, CPOOracle
+    torch.set_num_threads(4)
+    eng, data = _setup_onpolicy(60, 2, 256, 1000, 1e-3)
+    ocfg = CPOConfig(obs_dim=60, act_dim=2, hidden=(256, 256), optim_critic_iters=4, max_backtracks=10, cost_limit=10.0,
+                     l2_reg=0.001, target_kl=0.01)
+    o = CPOOracle(ocfg)
+    theta = _orth_theta(o, 0)
+    o.set_params(theta)
+    eng.set_params(theta); eng.optim_reset()
+    assert eng.tr_begin(target_kl=0.01, l2_reg=0.001, critic_lr=1e-3, max_backtracks=10, optim_critic_iters=4,
+                        cost_limit=10.0) == 20000
+    perm = np.random.default_rng(5).permutation(20000)
+    st = eng.cpo_learn(25.0, 1, batch_size=6000, perms=[perm])
+    _, rows = o.update(data, 25.0, 1, perms=[perm], batch_size=6000)
+    assert st.shape == (3, 17) and len(rows) == 3 and np.isfinite(st).all()
+    keys = ["loss/kl", "loss/entropy", "loss/rew_loss", "loss/cost_loss", "loss/optim_A", "loss/optim_B", "loss/optim_C",
+            "loss/optim_Q", "loss/optim_R", "loss/optim_S", "loss/optim_lam", "loss/optim_nu", "loss/optim_case",
+            "loss/step_size"]
+    for r in range(3):
+        assert int(st[r, 12]) == int(rows[r][0]["loss/optim_case"]), (r, st[r], rows[r][0])
+    sa, sc, _ = rows[0]
+    got = dict(zip(keys, st[0, :14]))
+    np.testing.assert_allclose(got["loss/step_size"], sa["loss/step_size"], rtol=1e-6)
+    assert _rel(st[0, 14], sc["loss/vf0"]) <= 2e-4 and _rel(st[0, 15], sc["loss/vf1"]) <= 2e-4, (st[0, 14:], sc)
+    qs = float(np.sqrt(abs(sa["loss/optim_Q"] * sa["loss/optim_S"])))
+    for k in ("loss/optim_Q", "loss/optim_R", "loss/optim_S", "loss/optim_nu", "loss/cost_loss", "loss/optim_C"):
+        floor = qs if k == "loss/optim_R" else 1e-3
+        assert _rel(got[k], sa[k], floor) <= 3e-3, (k, got[k], sa[k])
+    eng.close()
