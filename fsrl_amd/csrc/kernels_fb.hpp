@@ -369,6 +369,7 @@ struct HvpArgs {
     float* DO; float* RDO;   // [rows_pad][FSRL_DOW]
     int N, rows_pad;
     float max_action;
+    unsigned long long* ts;  // probe builds: [blocks][16] shader-clock stamps of the phase boundaries (else null)
 };
 
 template <int H>
@@ -682,6 +683,7 @@ __device__ __forceinline__ void hvp_tile_body(Hvp32Smem<H>& sm, const float* __r
     float* h1 = sm.s0; float* rh1 = sm.s1; float* h2 = sm.s2; float* rh2 = sm.s3;
     float* d2 = sm.s1; float* rd2 = sm.s3;          // later owners of the two tangent slots
 
+    FSRL_TS(a.ts, 0);                                // in-kernel timeline of probe builds: tools/tstamp_hvp.py
     FwdW2Frag<H> wf;
     wf.load(P + no.W2f, wave, lane);
     if constexpr (CACHED) {                          // h1, h2 of this theta, left by the CACHED = false launch
@@ -700,7 +702,9 @@ __device__ __forceinline__ void hvp_tile_body(Hvp32Smem<H>& sm, const float* __r
         sm.mo[e] = (i < n_valid) ? a.rd[(size_t)(row0 + i) * FSRL_RD + FSRL_RD_MEAN + f] : 0.0f;   // MEAN and STD are adjacent
     }
     for (int e = tid; e < R * FSRL_DOW; e += NT) { sm.dout[e] = 0.0f; sm.rdout[e] = 0.0f; }
+    FSRL_TS(a.ts, 1);
     __syncthreads();
+    FSRL_TS(a.ts, 2);
 
     // ---- layer 1 and its tangent on MFMA: the wave's 16 rows of W1 and of V1 in one load burst, NH row halves
     {
@@ -749,6 +753,7 @@ __device__ __forceinline__ void hvp_tile_body(Hvp32Smem<H>& sm, const float* __r
         }
     }
     __syncthreads();
+    FSRL_TS(a.ts, 3);
     // ---- layer 2:  z2 = W2 h1 + b2 ; R{z2} = W2 R{h1} + V2 h1 + vb2
     {
         f32x4 z[NH], rz[NH];
@@ -756,8 +761,10 @@ __device__ __forceinline__ void hvp_tile_body(Hvp32Smem<H>& sm, const float* __r
         for (int hf = 0; hf < NH; ++hf) z[hf] = rz[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (!CACHED) mma_rows_n<H, NH>(h1, wf, li, q, z);
         mma_rows_n<H, NH>(rh1, wf, li, q, rz);
+        FSRL_TS(a.ts, 4);
         wf.load(V + no.W2f, wave, lane);
         mma_rows_n<H, NH>(h1, wf, li, q, rz);
+        FSRL_TS(a.ts, 5);
         const int j = wave * 16 + li;
         const float bias = P[no.b2 + j], vbias = V[no.b2 + j];
 #pragma unroll
@@ -777,6 +784,7 @@ __device__ __forceinline__ void hvp_tile_body(Hvp32Smem<H>& sm, const float* __r
         }
     }
     __syncthreads();
+    FSRL_TS(a.ts, 6);
     // R{h1} (and h1 on the first product) leave for the weight-side kernel; slot 1 is free after the next barrier
     for (int e = tid; e < R * H4; e += NT) {
         const int i = e / H4, c4 = e - i * H4;
@@ -807,6 +815,7 @@ __device__ __forceinline__ void hvp_tile_body(Hvp32Smem<H>& sm, const float* __r
         }
     }
     __syncthreads();
+    FSRL_TS(a.ts, 7);
     // ---- KL head (per row, per action dim): dout, R{dout}, and the sigma_param rows
     if (tid < 16 * R) {
         const int i = tid >> 4, d = tid & 15;
@@ -841,6 +850,7 @@ __device__ __forceinline__ void hvp_tile_body(Hvp32Smem<H>& sm, const float* __r
         if constexpr (!CACHED) store4_fb(a.A2 + o, *reinterpret_cast<const f32x4*>(&h2[l]));
     }
     __syncthreads();
+    FSRL_TS(a.ts, 8);
     // ---- dz2 = relu'(z2) (dout W3) ; R{dz2} = relu'(z2) (R{dout} W3 + dout V3)      (dz2 -> slot 1, R{dz2} -> slot 3)
     for (int t = tid; t < (R / 4) * H; t += NT) {
         const int k = t % H, rg = t / H;
@@ -864,13 +874,16 @@ __device__ __forceinline__ void hvp_tile_body(Hvp32Smem<H>& sm, const float* __r
         }
     }
     __syncthreads();
+    FSRL_TS(a.ts, 9);
     // ---- R{dz1} = relu'(z1) (R{dz2} W2 + dz2 V2)
     {
         f32x4 acc[NH];
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) acc[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
         mma_cols_n<H, NH>(rd2, P + no.W2, wave, li, q, acc);
+        FSRL_TS(a.ts, 10);
         mma_cols_n<H, NH>(d2, V + no.W2, wave, li, q, acc);
+        FSRL_TS(a.ts, 11);
         float* __restrict__ RD1 = a.RD1 + base;
         const int col = wave * 16 + li;
 #pragma unroll
@@ -894,6 +907,7 @@ __device__ __forceinline__ void hvp_tile_body(Hvp32Smem<H>& sm, const float* __r
         a.RDO[(size_t)row0 * FSRL_DOW + e] = sm.rdout[e];
         if constexpr (!CACHED) a.DO[(size_t)row0 * FSRL_DOW + e] = sm.dout[e];
     }
+    FSRL_TS(a.ts, 12);
 }
 
 // Mixed-height grid: blocks [0, n32) take 32-row tiles, the rest 16-row tiles behind them (host: hvp_plan): the tile
