@@ -31,13 +31,20 @@ def main():
     ap.add_argument("--seed", type=int, default=10)
     ap.add_argument("--device-actor", action="store_true", help="collector actions from fsrl_actor_sample (library RNG)")
     ap.add_argument("--batch-size", type=int, default=256, help="minibatch size of PPO-Lag / FOCOPS and the off-policy agents")
+    ap.add_argument("--tr-batch-size", type=int, default=99999,
+                    help="CPO / TRPO-Lag: Batch.split size inside learn (the reference's default 99999 = the whole buffer)")
+    ap.add_argument("--workers", type=int, default=0, help="> 0: the training envs step in that many worker processes (ShmemVectorEnv)")
     # options of the on-policy agents (the reference's constructor arguments of the same names)
     ap.add_argument("--unbounded", action="store_true", help="actor mean without max_action * tanh")
     ap.add_argument("--reward-normalization", action="store_true", help="critics learn returns / running std")
     ap.add_argument("--value-clip", action="store_true", help="PPO-Lag clipped value loss (needs --reward-normalization)")
     ap.add_argument("--recompute-advantage", action="store_true", help="PPO-Lag / FOCOPS: GAE from the current critics before every pass")
     a = ap.parse_args()
-    env = SyntheticSafetyVectorEnv(env_num=a.envs, obs_dim=8, act_dim=2, episode_len=300, seed=a.seed)
+    if a.workers > 0:
+        from fsrl_amd.env import ShmemVectorEnv
+        env = ShmemVectorEnv(env_num=a.envs, workers=a.workers, obs_dim=8, act_dim=2, episode_len=300, seed=a.seed)
+    else:
+        env = SyntheticSafetyVectorEnv(env_num=a.envs, obs_dim=8, act_dim=2, episode_len=300, seed=a.seed)
     test_env = SyntheticSafetyVectorEnv(env_num=2, obs_dim=8, act_dim=2, episode_len=300, seed=a.seed + 1)
     logger = BaseLogger(tempfile.mkdtemp(prefix="fsrl_amd_"), name=a.algo)
     kw = dict(cost_limit=a.cost_limit, device=a.device, seed=a.seed, hidden_sizes=(a.hidden, a.hidden), training_num=a.envs)
@@ -53,7 +60,7 @@ def main():
                           batch_size=a.batch_size, testing_num=2, device_actor=a.device_actor, verbose=True, save_ckpt=False)
     else:
         out = agent.learn(env, test_env, epoch=a.epoch, episode_per_collect=a.envs, step_per_epoch=6000, repeat_per_collect=4,
-                          batch_size=a.batch_size if a.algo in ("ppol", "focops") else 99999, testing_num=2, device_actor=a.device_actor,
+                          batch_size=a.batch_size if a.algo in ("ppol", "focops") else a.tr_batch_size, testing_num=2, device_actor=a.device_actor,
                           verbose=True, save_ckpt=False)
     print("final:", {k: round(float(v), 4) for k, v in out[1].items() if isinstance(v, (int, float))})
     rew, length, cost = agent.evaluate(test_env, eval_episodes=2)
