@@ -79,6 +79,8 @@ SIGNATURES = {
     "fsrl_params_get": (C.c_int, [_ctx, _f, C.c_int64]),
     "fsrl_grads_get": (C.c_int, [_ctx, _f, C.c_int64]),
     "fsrl_optim_reset": (C.c_int, [_ctx]),
+    "fsrl_state_snapshot": (C.c_int, [_ctx]),
+    "fsrl_state_restore": (C.c_int, [_ctx]),
     "fsrl_ret_rms_get": (C.c_int, [_ctx, _d, C.c_int32]),
     "fsrl_ret_rms_set": (C.c_int, [_ctx, _d, C.c_int32]),
     "fsrl_set_lr": (C.c_int, [_ctx, C.c_int32, C.c_float]),

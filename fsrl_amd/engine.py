@@ -105,6 +105,13 @@ class Engine:
         _lib.check(self.lib.fsrl_grads_get(self._ctx, _ptr(out, _f32p), out.size))
         return out
 
+    def state_snapshot(self):
+        """Checkpoint parameters + Adam state in HBM (device-to-device, asynchronous)."""
+        _lib.check(self.lib.fsrl_state_snapshot(self._ctx))
+
+    def state_restore(self):
+        _lib.check(self.lib.fsrl_state_restore(self._ctx))
+
     def optim_reset(self):
         _lib.check(self.lib.fsrl_optim_reset(self._ctx))
 

@@ -96,6 +96,12 @@ int fsrl_params_set(fsrl_ctx* ctx, const float* flat, int64_t n);
 int fsrl_params_get(fsrl_ctx* ctx, float* flat, int64_t n);
 int fsrl_grads_get(fsrl_ctx* ctx, float* flat, int64_t n);   /* last minibatch gradient  */
 int fsrl_optim_reset(fsrl_ctx* ctx);                /* zero Adam moments and step count  */
+/* Device-resident checkpoint of the training state of an on-policy context (parameters with their W2 mirrors, Adam
+ * moments, step counts), kept in HBM: snapshot / restore are device-to-device copies on the compute stream, no host round
+ * trip and no synchronisation.  The reference has no counterpart (copy.deepcopy(policy.state_dict()) is the host-side
+ * equivalent); bench.py restores the same start state before every timed update with it.                                */
+int fsrl_state_snapshot(fsrl_ctx* ctx);
+int fsrl_state_restore(fsrl_ctx* ctx);
 /* lr_scheduler.step() at the end of BasePolicy.update (fsrl/policy/base_policy.py:352-354): the caller's torch
  * scheduler owns the schedule, this call moves the new rate of one optimiser into the engine; it applies from the next
  * optimiser step.  group: on-policy contexts 0 (the one Adam; for CPO / TRPO-Lag the critics' Adam); FOCOPS 0 actor,

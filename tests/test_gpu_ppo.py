@@ -333,3 +333,27 @@ def test_fused_adam_step_is_bit_identical_to_the_three_launch_step(name):
         eng.close()
     for k, (a, b) in enumerate(zip(out[0], out[1])):
         assert np.array_equal(a, b), (k, float(np.abs(a - b).max()), int((a != b).sum()), a.size)
+
+
+def test_state_snapshot_restore_reproduces_an_update_bit_for_bit():
+    """fsrl_state_snapshot / _restore (device-resident checkpoint of parameters, W2 mirrors, Adam moments and step counts):
+    an update from the restored state equals the update from the same state set through the host (set_params +
+    optim_reset), bit for bit -- also after other updates have moved the parameters and the Adam step count in between."""
+    cfg, g = ppo_case("c1")
+    eng = _engine(cfg)
+    _start(eng, g)
+    _push_golden(eng, g)
+    lag = g["lagrangian"]
+    run = lambda: eng.ppo_update(lag, _rescale(lag), cfg["batch_size"], cfg["repeat"], perms=g["perms"])[0]  # noqa: E731
+    eng.optim_reset()
+    eng.state_snapshot()
+    s0 = run(); th0 = eng.get_params()
+    run()                                                            # moves theta, the moments and adam_t further
+    eng.state_restore()
+    s1 = run(); th1 = eng.get_params()
+    assert np.array_equal(s0, s1) and np.array_equal(th0, th1)
+    eng.set_params(g["theta0"]); eng.optim_reset()
+    s2 = run()
+    assert np.array_equal(s0, s2) and np.array_equal(th0, eng.get_params())
+    np.testing.assert_allclose(s0, g["stats"], rtol=2e-5, atol=2e-5)
+    eng.close()
