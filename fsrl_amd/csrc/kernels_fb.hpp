@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
     constexpr int TPD = H / 64;             // dW2 tiles of 64 x 64 outputs
     constexpr int NT2 = TPD * TPD;
     constexpr int NA = H / 32;
-    constexpr int BU = 2;                   // k-steps per load burst
+    constexpr int BU = 1;                   // k-steps per load burst (A/B at N = 20 000: 1 -> CPO 37.9 ms, 2 -> 38.6, 3 -> 39.6, 4 -> 41.5)
     constexpr int SLOT = 64 * 65;           // one 64 x 64 partial tile (+1 column of padding)
     __shared__ float red[4 * SLOT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
