@@ -958,6 +958,7 @@ template <int H, bool PAIR2, bool FIRST, int NCH>
 __device__ __forceinline__ void wgrad_aux_pass(const FbWgradArgs& wa, const FbWgradNet& wn, const NetOff& no, float* red,
                                                float* __restrict__ gout, const int j0, const int k0, const int KS0,
                                                const int KS, const int Do, const int out, const int tid) {
+    constexpr int AUXU = 4;                      // k-steps per load burst (A/B: 1, 2 and 4 equal within noise, 8 slower)
     const int lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
     {
         {
@@ -967,11 +968,11 @@ __device__ __forceinline__ void wgrad_aux_pass(const FbWgradArgs& wa, const FbWg
             for (int ch = 0; ch < NCH; ++ch) ax[ch][0] = ax[ch][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             f32x4 ad0 = {0, 0, 0, 0}, ad1 = {0, 0, 0, 0};
             f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
-            for (int sb = KS0 + wave; sb < KS; sb += 16 * 4) {
-                f32x2 y1[4], xa3[4], xb3[4], b1v[4], b2v[4];
-                float bx[4][NCH], bda[4], bdb[4];
+            for (int sb = KS0 + wave; sb < KS; sb += 16 * AUXU) {
+                f32x2 y1[AUXU], xa3[AUXU], xb3[AUXU], b1v[AUXU], b2v[AUXU];
+                float bx[AUXU][NCH], bda[AUXU], bdb[AUXU];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < AUXU; ++u) {
                     const int s = sb + 16 * u;
                     y1[u] = xa3[u] = xb3[u] = b1v[u] = b2v[u] = f32x2{0.f, 0.f};
                     bda[u] = bdb[u] = 0.f;
@@ -996,7 +997,7 @@ __device__ __forceinline__ void wgrad_aux_pass(const FbWgradArgs& wa, const FbWg
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < AUXU; ++u) {
 #pragma unroll
                     for (int ch = 0; ch < NCH; ++ch) {
                         if (k0 + 16 * ch < Do) {           // block-uniform: chunks past Do cost nothing
