@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--batch-size", type=int, default=256, help="minibatch size of PPO-Lag / FOCOPS and the off-policy agents")
     ap.add_argument("--tr-batch-size", type=int, default=99999,
                     help="CPO / TRPO-Lag: Batch.split size inside learn (the reference's default 99999 = the whole buffer)")
+    ap.add_argument("--task", choices=["synthetic", "point-circle"], default="synthetic",
+                    help="synthetic: the vectorised stand-in dynamics; point-circle: per-instance gym-style envs built from factories")
     ap.add_argument("--workers", type=int, default=0, help="> 0: the training envs step in that many worker processes (ShmemVectorEnv)")
     # options of the on-policy agents (the reference's constructor arguments of the same names)
     ap.add_argument("--unbounded", action="store_true", help="actor mean without max_action * tanh")
@@ -40,12 +42,19 @@ def main():
     ap.add_argument("--value-clip", action="store_true", help="PPO-Lag clipped value loss (needs --reward-normalization)")
     ap.add_argument("--recompute-advantage", action="store_true", help="PPO-Lag / FOCOPS: GAE from the current critics before every pass")
     a = ap.parse_args()
-    if a.workers > 0:
+    if a.task == "point-circle":
+        # the reference's own construction (train_ppol_agent.py:120-123): one factory per env, in process or in worker processes
+        from fsrl_amd.env import DummyVectorEnv, PointCircleEnv, ShmemVectorEnv
+        fns = [lambda: PointCircleEnv(max_episode_steps=100) for _ in range(a.envs)]
+        env = ShmemVectorEnv(fns, workers=a.workers, seed=a.seed) if a.workers > 0 else DummyVectorEnv(fns, seed=a.seed)
+        test_env = DummyVectorEnv(fns[:2], seed=a.seed + 1000)
+    elif a.workers > 0:
         from fsrl_amd.env import ShmemVectorEnv
         env = ShmemVectorEnv(env_num=a.envs, workers=a.workers, obs_dim=8, act_dim=2, episode_len=300, seed=a.seed)
     else:
         env = SyntheticSafetyVectorEnv(env_num=a.envs, obs_dim=8, act_dim=2, episode_len=300, seed=a.seed)
-    test_env = SyntheticSafetyVectorEnv(env_num=2, obs_dim=8, act_dim=2, episode_len=300, seed=a.seed + 1)
+    if a.task != "point-circle":
+        test_env = SyntheticSafetyVectorEnv(env_num=2, obs_dim=8, act_dim=2, episode_len=300, seed=a.seed + 1)
     logger = BaseLogger(tempfile.mkdtemp(prefix="fsrl_amd_"), name=a.algo)
     kw = dict(cost_limit=a.cost_limit, device=a.device, seed=a.seed, hidden_sizes=(a.hidden, a.hidden), training_num=a.envs)
     if a.algo in ("ppol", "cpo", "trpol", "focops"):

@@ -49,6 +49,8 @@ class OnpolicyAgent(BaseAgent):
         assert self.policy is not None, "The policy is not initialized"
         self.policy.train()
         eng = self.policy.engine
+        from fsrl_amd.env.venv import as_vector_env
+        train_envs = as_vector_env(train_envs)                 # a single env: one sub-buffer (base_agent.py:160-163)
         assert eng.cfg.env_num >= len(train_envs), \
             f"agent built for {eng.cfg.env_num} env sub-buffers, got {len(train_envs)} envs (pass training_num)"
         # VectorReplayBuffer(buffer_size, len(train_envs)) of the reference (base_agent.py:279): the store is re-cut to

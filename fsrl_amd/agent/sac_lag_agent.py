@@ -28,6 +28,8 @@ class OffpolicyAgent(BaseAgent):
         assert self.policy is not None, "The policy is not initialized"
         self.policy.train()
         eng = self.policy.engine
+        from fsrl_amd.env.venv import as_vector_env
+        train_envs = as_vector_env(train_envs)                 # a single env: one sub-buffer (base_agent.py:160-163)
         assert eng.cfg.env_num >= len(train_envs)
         # VectorReplayBuffer(buffer_size, len(train_envs)) of the reference (base_agent.py:279): the store is re-cut to
         # that geometry.  None = the size the agent was built with (its `buffer_size`, default 100 000 like the

@@ -33,6 +33,8 @@ class FastCollector:
         # split_phase="auto": the first collect runs the plain loop and times its two halves; the split loop takes over when
         # a vector step of the env costs more than the actor call it would hide (an env that costs nothing gains nothing
         # from two half-width actor launches per vector step).
+        from fsrl_amd.env.venv import as_vector_env
+        env = as_vector_env(env)             # a single env is wrapped like the reference does (fast_collector.py:55-58)
         can_split = hasattr(env, "step_async") and getattr(env, "n_lanes", 1) == 2
         self._split_auto = split_phase == "auto" and can_split
         self.split_phase = bool(split_phase is True and can_split)

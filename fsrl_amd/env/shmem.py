@@ -3,7 +3,8 @@
 north_star: "vectorized rollout collection (FastCollector over ShmemVectorEnv) stays on the host CPUs"; the reference builds
 `ShmemVectorEnv([lambda: gym.make(task) for _ in range(training_num)])` (examples/mlp/train_ppol_agent.py:120-123), i.e.
 tianshou's worker processes with the observations in shared memory.  tianshou, gymnasium and the simulators are absent
-here, so this is the same ARCHITECTURE around the synthetic dynamics of `SyntheticSafetyVectorEnv`:
+here, so this is the same ARCHITECTURE around either the synthetic dynamics of `SyntheticSafetyVectorEnv` (the bench) or the
+caller's own env factories (`ShmemVectorEnv([lambda: make(task) for _ in range(n)])`, duck-typed gym envs, fsrl_amd/env/venv.py):
 
   * `workers` processes, each owning a contiguous slice of the `env_num` envs (one env per worker when
     workers == env_num, like tianshou; fewer workers batch their slice's steps);
@@ -68,7 +69,17 @@ def _views(buf, layout):
     return {name: np.ndarray(shape, dtype=dt, buffer=buf, offset=off) for name, (off, shape, dt) in layout.items()}
 
 
-def _worker(w, lane, lo, hi, shm_name, env_num, workers, obs_dim, act_dim, episode_len, seed, busy_us, core, spin):
+def _make_env(spec, lo, hi):
+    """the worker's own envs: the synthetic dynamics, or the user's factories for envs [lo, hi)"""
+    if spec["kind"] == "synthetic":
+        return SyntheticSafetyVectorEnv(env_num=hi - lo, obs_dim=spec["obs_dim"], act_dim=spec["act_dim"], episode_len=spec["episode_len"],
+                                        seed=spec["seed"], busy_us=spec["busy_us"])
+    import cloudpickle
+    from fsrl_amd.env.venv import EnvList
+    return EnvList([cloudpickle.loads(b)() for b in spec["fns"]], seed=spec["seed"], first_index=lo)
+
+
+def _worker(w, lane, lo, hi, shm_name, env_num, workers, obs_dim, act_dim, spec, core, spin):
     if core is not None:
         try:
             os.sched_setaffinity(0, {core})
@@ -78,8 +89,7 @@ def _worker(w, lane, lo, hi, shm_name, env_num, workers, obs_dim, act_dim, episo
     shm = shared_memory.SharedMemory(name=shm_name)
     layout, _ = _layout(env_num, obs_dim, act_dim, workers)
     v = _views(shm.buf, layout)
-    env = SyntheticSafetyVectorEnv(env_num=hi - lo, obs_dim=obs_dim, act_dim=act_dim, episode_len=episode_len, seed=seed,
-                                   busy_us=busy_us)
+    env = _make_env(spec, lo, hi)
     gen_p, pend_p = v["hs"][lane, 0].ctypes.data, v["hs"][lane, 1].ctypes.data
     cmd_w, want_w = v["hs"][lane, 2], v["want"][w]
     parent = os.getppid()
@@ -115,20 +125,43 @@ def _worker(w, lane, lo, hi, shm_name, env_num, workers, obs_dim, act_dim, episo
                     v_term[gi] = term; v_trunc[gi] = trunc
             lib.fsrl_env_done(pend_p)
     finally:
+        env.close()
         del v, cmd_w, want_w, v_active, v_obs, v_act, v_rew, v_cost, v_term, v_trunc
         shm.close()
 
 
 class ShmemVectorEnv:
     def __init__(self, env_num=32, workers=None, obs_dim=8, act_dim=2, episode_len=300, seed=0, busy_us=0.0, cores=None,
-                 start_method="spawn", spin_us=None):
+                 start_method="spawn", spin_us=None, env_fns=None):
+        """Two ways to say what the workers step: the synthetic dynamics (`env_num`, `obs_dim`, ... ; the bench), or
+        `env_fns` -- one factory per env, the reference's `ShmemVectorEnv([lambda: gym.make(task) for _ in range(n)])`
+        (also accepted as the first positional argument).  Factories travel to the spawned workers with cloudpickle, so
+        lambdas and closures work; the envs are duck-typed (fsrl_amd/env/venv.py).  `seed` in this mode follows tianshou's
+        `venv.seed(s)`: env i is reset with seed s + i the first time (None = the env's own default)."""
+        if env_fns is None and not isinstance(env_num, (int, np.integer)):
+            env_fns, env_num = env_num, None
+        fns_pickled = None
+        if env_fns is not None:
+            import cloudpickle
+            env_fns = list(env_fns)
+            env_num = len(env_fns)
+            fns_pickled = [cloudpickle.dumps(fn) for fn in env_fns]
+            probe = env_fns[0]()                              # like tianshou: one throw-away instance for the spaces
+            self.observation_space, self.action_space = probe.observation_space, probe.action_space
+            self.spec = getattr(probe, "spec", None)
+            obs_dim, act_dim = int(np.prod(self.observation_space.shape)), int(np.prod(self.action_space.shape))
+            if hasattr(probe, "close"):
+                probe.close()
+            del probe
+            episode_len = getattr(self.spec, "max_episode_steps", None)
+        else:
+            self.observation_space = Box(-np.inf, np.inf, (obs_dim, ))
+            self.action_space = Box(-1.0, 1.0, (act_dim, ))
+            self.spec = SimpleNamespace(id="SyntheticSafety-v0", max_episode_steps=episode_len)
         workers = env_num if workers is None else int(workers)
         assert 1 <= workers <= env_num
         self.env_num, self.obs_dim, self.act_dim, self.workers = env_num, obs_dim, act_dim, workers
         self.episode_len, self.busy_us = episode_len, busy_us
-        self.observation_space = Box(-np.inf, np.inf, (obs_dim, ))
-        self.action_space = Box(-1.0, 1.0, (act_dim, ))
-        self.spec = SimpleNamespace(id="SyntheticSafety-v0", max_episode_steps=episode_len)
         self._lib = _load_lib()
         self._layout, size = _layout(env_num, obs_dim, act_dim, workers)
         self._shm = shared_memory.SharedMemory(create=True, size=size)
@@ -156,10 +189,14 @@ class ShmemVectorEnv:
         for w in range(workers):
             lo, hi = self._bounds[w], self._bounds[w + 1]
             self._owner[lo:hi] = w
-            wseed = seed if workers == 1 else seed * 7919 + w
+            if fns_pickled is None:
+                spec = dict(kind="synthetic", obs_dim=obs_dim, act_dim=act_dim, episode_len=episode_len, busy_us=busy_us,
+                            seed=seed if workers == 1 else seed * 7919 + w)
+            else:
+                spec = dict(kind="fns", fns=fns_pickled[lo:hi], seed=seed)
             core = None if not cores else list(cores)[w % len(cores)]
             p = ctx.Process(target=_worker, args=(w, int(self._lane_of_worker[w]), lo, hi, self._shm.name, env_num, workers, obs_dim,
-                                                  act_dim, episode_len, wseed, busy_us, core, self._spin), daemon=True)
+                                                  act_dim, spec, core, self._spin), daemon=True)
             p.start()
             self._procs.append(p)
         self.lane_of_env = self._lane_of_worker[self._owner]

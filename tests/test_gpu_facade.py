@@ -520,3 +520,29 @@ def test_agents_accept_the_on_policy_options_of_the_reference(kind, tmp_path):
     mu = agent.policy.engine.actor_forward(np.full((1, 8), 3.0, np.float32))[0]
     assert np.isfinite(mu).all()
     agent.policy.engine.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workers", [0, 3])
+def test_agent_learns_over_env_factories(workers, tmp_path):
+    """The reference's own construction (train_ppol_agent.py:120-123): a list of env factories wrapped in DummyVectorEnv /
+    ShmemVectorEnv.  Per-instance gym-style envs (obs 6, act 2, info["cost"]) -- in process, and in 3 worker processes with the
+    device actor (native collector loop over the shared block)."""
+    from fsrl_amd.agent import PPOLagAgent
+    from fsrl_amd.env import DummyVectorEnv, PointCircleEnv, ShmemVectorEnv
+    from fsrl_amd.utils import BaseLogger
+    fns = [lambda: PointCircleEnv(max_episode_steps=40) for _ in range(6)]
+    train = ShmemVectorEnv(fns, workers=workers, seed=1) if workers else DummyVectorEnv(fns, seed=1)
+    test = DummyVectorEnv(fns[:2], seed=100)
+    try:
+        agent = PPOLagAgent(train, BaseLogger(str(tmp_path), name="t"), cost_limit=5, device="cuda:0", seed=3,
+                            hidden_sizes=(64, 64), max_grad_norm=0.5, training_num=6)
+        theta0 = agent.policy.engine.get_params()
+        ep, stat, info = agent.learn(train, test, epoch=2, episode_per_collect=6, step_per_epoch=480, repeat_per_collect=2,
+                                     batch_size=64, testing_num=2, verbose=False, save_ckpt=False, device_actor=bool(workers))
+        assert ep == 2 and stat["train/length"] <= 40 and np.isfinite(list(stat.values())).all()
+        assert np.abs(agent.policy.engine.get_params() - theta0).max() > 1e-4
+        rew, length, cost = agent.evaluate(PointCircleEnv(max_episode_steps=40), eval_episodes=2)      # a bare env is wrapped
+        assert 0 < length <= 40 and np.isfinite(rew) and cost >= 0
+    finally:
+        train.close()

@@ -132,3 +132,121 @@ def test_a_dead_worker_is_reported_not_waited_for_forever():
             env.step(np.zeros((4, 2), np.float32))
     finally:
         env.close()
+
+
+# ---- env factories: the reference's `ShmemVectorEnv([lambda: gym.make(task) ...])` / `DummyVectorEnv` (train_ppol_agent.py:120-123)
+def _fns(n, horizon=9):
+    from fsrl_amd.env import PointCircleEnv
+    return [lambda: PointCircleEnv(max_episode_steps=horizon) for _ in range(n)]
+
+
+def _rollout_fns(env, steps, n, seed):
+    rng = np.random.default_rng(seed)
+    obs, _ = env.reset()
+    out = [obs.copy()]
+    for t in range(steps):
+        ids = np.arange(n) if t % 3 else np.arange(0, n, 2)
+        act = rng.uniform(-1, 1, (len(ids), 2)).astype(np.float32)
+        o, r, term, trunc, info = env.step(act, ids)
+        out += [o.copy(), r.copy(), term.copy(), trunc.copy(), info["cost"].copy()]
+        done = np.flatnonzero(term | trunc)
+        if done.size:
+            ro, _ = env.reset(ids[done])
+            out.append(ro.copy())
+    return out
+
+
+def test_dummy_vector_env_steps_each_instance():
+    from fsrl_amd.env import DummyVectorEnv, PointCircleEnv
+    env = DummyVectorEnv(_fns(3), seed=5)
+    singles = [PointCircleEnv(max_episode_steps=9) for _ in range(3)]
+    o, _ = env.reset()
+    assert o.shape == (3, 6) and o.dtype == np.float32 and len(env) == 3
+    for i, e in enumerate(singles):
+        assert np.array_equal(o[i], e.reset(seed=5 + i)[0])           # tianshou's venv.seed(s): env i gets s + i
+    act = np.array([[0.5, -1.0], [1.0, 1.0]], np.float32)
+    o, r, term, trunc, info = env.step(act, np.array([0, 2]))
+    for j, i in enumerate((0, 2)):
+        so, sr, st, stc, si = singles[i].step(act[j])
+        assert np.array_equal(o[j], so) and r[j] == sr and term[j] == st and trunc[j] == stc and info["cost"][j] == si["cost"]
+    assert r.dtype == np.float64 and term.dtype == bool
+
+
+def test_old_gym_api_and_missing_cost():
+    """4-tuple step / bare-obs reset envs (old gym) and envs without a cost signal go through the same adapter"""
+    from fsrl_amd.env import Box, DummyVectorEnv
+
+    class Old:
+        observation_space, action_space = Box(-1, 1, (3, )), Box(-1, 1, (1, ))
+        def __init__(self): self.t = 0
+        def seed(self, s): self.s = s
+        def reset(self): self.t = 0; return np.full(3, getattr(self, "s", -1), np.float32)
+        def step(self, a):
+            self.t += 1
+            return np.full(3, self.t, np.float32), 1.0, self.t >= 2, {"TimeLimit.truncated": self.t >= 2}
+
+    env = DummyVectorEnv([Old, Old], seed=7)
+    o, _ = env.reset()
+    assert np.array_equal(o[:, 0], [7, 8])
+    env.step(np.zeros((2, 1)))
+    o, r, term, trunc, info = env.step(np.zeros((2, 1)))
+    assert trunc.all() and not term.any() and np.array_equal(info["cost"], [0.0, 0.0]) and np.array_equal(o[:, 0], [2, 2])
+
+
+@pytest.mark.parametrize("workers", [1, 2, 5])
+def test_shmem_env_over_factories_matches_the_in_process_env(workers):
+    """worker processes stepping the caller's own envs (factories sent with cloudpickle) == the same instances stepped in
+    process, whatever the worker count: every env has its own state and seed"""
+    from fsrl_amd.env import DummyVectorEnv, ShmemVectorEnv
+    a = DummyVectorEnv(_fns(5), seed=11)
+    b = ShmemVectorEnv(_fns(5), workers=workers, seed=11)
+    try:
+        assert len(b) == 5 and b.observation_space.shape == (6, ) and b.action_space.shape == (2, )
+        assert b.spec.max_episode_steps == 9
+        ra, rb = _rollout_fns(a, 40, 5, 0), _rollout_fns(b, 40, 5, 0)
+        assert len(ra) == len(rb)
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y)
+    finally:
+        b.close()
+
+
+def test_collector_over_factory_envs():
+    """FastCollector over DummyVectorEnv / ShmemVectorEnv(env_fns): n episodes, the cost from info["cost"]"""
+    from fsrl_amd.data import FastCollector
+    from fsrl_amd.env import DummyVectorEnv, ShmemVectorEnv
+
+    class _Pol:
+        action_space = None
+        def map_action(self, a): return a
+        def map_action_inverse(self, a): return a
+
+    stats = []
+    for make in (lambda: DummyVectorEnv(_fns(4), seed=3), lambda: ShmemVectorEnv(env_fns=_fns(4), workers=2, seed=3)):
+        env = make()
+        try:
+            np.random.seed(0)
+            env.action_space.seed(0)
+            col = FastCollector(_Pol(), env, None)
+            st = col.collect(n_episode=8, random=True)
+            stats.append(st)
+            assert st["n/ep"] == 8 and st["n/st"] == 8 * 9 and st["len"] == 9
+        finally:
+            env.close()
+    assert stats[0]["rew"] == stats[1]["rew"] and stats[0]["cost"] == stats[1]["cost"]
+
+
+def test_collector_wraps_a_single_env():
+    """fast_collector.py:55-58: a bare env is wrapped into a one-env vector env, with the reference's warning"""
+    from fsrl_amd.data import FastCollector
+    from fsrl_amd.env import PointCircleEnv
+
+    class _Pol:
+        action_space = None
+        def map_action(self, a): return a
+        def map_action_inverse(self, a): return a
+
+    with pytest.warns(UserWarning, match="Single environment"):
+        col = FastCollector(_Pol(), PointCircleEnv(max_episode_steps=7), None)
+    st = col.collect(n_episode=3, random=True)
+    assert col.env_num == 1 and st["n/ep"] == 3 and st["n/st"] == 21
