@@ -19,7 +19,8 @@ class Config(C.Structure):
                 ("vf_coef", C.c_float), ("max_grad_norm", C.c_float), ("target_kl", C.c_float),
                 ("norm_adv", C.c_int32), ("use_lagrangian", C.c_int32), ("lr", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float), ("recompute_adv", C.c_int32),
-                ("unbounded", C.c_int32), ("rew_norm", C.c_int32), ("value_clip", C.c_int32)]
+                ("unbounded", C.c_int32), ("rew_norm", C.c_int32), ("value_clip", C.c_int32),
+                ("hidden1", C.c_int32), ("hidden2", C.c_int32)]
 
 
 class ShmEnv(C.Structure):

@@ -40,8 +40,6 @@ class PPOLagAgent(OnpolicyAgent):
         self.logger = logger if logger is not None else DummyLogger()
         self.cost_limit = cost_limit
         cost_dim = 1 if np.isscalar(cost_limit) else len(cost_limit)
-        assert len(hidden_sizes) == 2 and hidden_sizes[0] == hidden_sizes[1], \
-            "the HIP path supports two equal hidden layers (64/128/256)"
         seed_all(seed)
         torch.set_num_threads(thread)
         actor, critic, actor_critic = onpolicy_nets(env, hidden_sizes, 1 + cost_dim, last_layer_scale, unbounded)

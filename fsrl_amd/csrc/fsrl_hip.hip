@@ -47,7 +47,21 @@ extern "C" const char* fsrl_last_error(void) { return g_err.c_str(); }
 // ------------------------------------------------------------------------------ context
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-struct TensorMap { int api_off, dev_off, n; };   // one parameter tensor: flat API offset -> device
+// One parameter tensor: `rows x cols` values, dense at the flat API offset, rows `dev_ld` apart on the device.  The device
+// layout is that of two hidden layers of the kernels' width H (64 / 128 / 256); the API layout is the caller's network with
+// its own widths h1, h2 <= H (fsrl_config.hidden1 / hidden2).  Padded units have zero weights and biases: their
+// pre-activation is 0, relu' is taken off h > 0, so every gradient entry of a padded weight is exactly 0 and Adam (also
+// with an L2 term), Polyak averaging and the flat-vector algebra of the trust-region path leave it 0 for ever.
+struct TensorMap {
+    int api_off, dev_off, rows, cols, dev_ld;
+    int n() const { return rows * cols; }
+    void to_dev(float* dev, const float* api) const {
+        for (int r = 0; r < rows; ++r) memcpy(dev + dev_off + (size_t)r * dev_ld, api + api_off + (size_t)r * cols, (size_t)cols * 4);
+    }
+    void to_api(float* api, const float* dev) const {
+        for (int r = 0; r < rows; ++r) memcpy(api + api_off + (size_t)r * cols, dev + dev_off + (size_t)r * dev_ld, (size_t)cols * 4);
+    }
+};
 
 struct EnvBook {           // tianshou ReplayBuffer bookkeeping of one sub-buffer (host side)
     int64_t index = 0, size = 0, last_index = 0;
@@ -76,6 +90,7 @@ struct fsrl_ctx {
     hipStream_t compute = nullptr, side = nullptr;
     ModelDesc md{};
     std::vector<TensorMap> tmap;
+    int h1 = 0, h2 = 0;    // widths of the caller's two hidden layers (<= cfg.hidden, the padded width the kernels run at)
     int64_t n_api = 0;     // flat parameter count (API)
     int n_dev = 0;         // padded device parameter count (main vector: what Adam / clip / copies see)
     int n_alloc = 0;       // n_dev + the forward-fragment mirrors of every W2 (P only)
@@ -272,12 +287,14 @@ static void build_layout(fsrl_ctx* c) {
     ModelDesc& md = c->md;
     md.Do = Do; md.Da = Da; md.H = H; md.n_nets = 1 + c->cfg.n_critics;
     md.unbounded = (c->cfg.unbounded && c->cfg.algo != FSRL_ALGO_SAC_LAG) ? 1 : 0;     // replay actors have their own (raw mu | log sigma) head
+    const int h1 = c->h1, h2 = c->h2;
     int api = 0, dev = 0;
-    auto add = [&](int n) {
-        TensorMap t{api, dev, n};
+    // rows x cols API values inside a device tensor of `dev_n` floats whose rows are dev_ld apart
+    auto add = [&](int rows, int cols, int dev_ld, int dev_n) {
+        TensorMap t{api, dev, rows, cols, dev_ld};
         c->tmap.push_back(t);
-        api += n;
-        dev = round_up(dev + n, 64);  // every tensor starts 256-byte aligned on the device
+        api += rows * cols;
+        dev = round_up(dev + dev_n, 64);  // every tensor starts 256-byte aligned on the device
         return t.dev_off;
     };
     for (int net = 0; net < md.n_nets; ++net) {
@@ -285,10 +302,10 @@ static void build_layout(fsrl_ctx* c) {
         no.begin = dev;
         const int out = (net == 0) ? Da : 1;
         no.out = out;
-        no.sigma = (net == 0) ? add(Da) : -1;
-        no.W1 = add(H * Do); no.b1 = add(H);
-        no.W2 = add(H * H);  no.b2 = add(H);
-        no.W3 = add(out * H); no.b3 = add(out);
+        no.sigma = (net == 0) ? add(1, Da, Da, Da) : -1;
+        no.W1 = add(h1, Do, Do, H * Do); no.b1 = add(1, h1, H, H);
+        no.W2 = add(h2, h1, H, H * H);   no.b2 = add(1, h2, H, H);
+        no.W3 = add(out, h2, H, out * H); no.b3 = add(1, out, out, out);
         no.end = dev;
     }
     c->n_api = api;
@@ -355,8 +372,13 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
                   cfg->algo == FSRL_ALGO_TRPO_LAG || cfg->algo == FSRL_ALGO_FOCOPS, "unknown algo %d", cfg->algo);
     CHECK_ARG(cfg->obs_dim >= 1 && cfg->obs_dim <= FSRL_MAX_OBS, "obs_dim must be in [1,%d]", FSRL_MAX_OBS);
     CHECK_ARG(cfg->act_dim >= 1 && cfg->act_dim <= FSRL_MAX_ACT, "act_dim must be in [1,%d]", FSRL_MAX_ACT);
-    CHECK_ARG(cfg->hidden == 64 || cfg->hidden == 128 || cfg->hidden == 256,
-              "hidden must be 64, 128 or 256 (two equal hidden layers)");
+    // two hidden layers of any widths up to 256: the kernels run at H = 64 / 128 / 256, narrower layers are zero-padded
+    const int h1_ = cfg->hidden1 > 0 ? cfg->hidden1 : cfg->hidden, h2_ = cfg->hidden2 > 0 ? cfg->hidden2 : cfg->hidden;
+    CHECK_ARG((cfg->hidden1 > 0) == (cfg->hidden2 > 0), "hidden1 and hidden2 are given together (0, 0 = two layers of `hidden`)");
+    CHECK_ARG(h1_ >= 1 && h1_ <= 256 && h2_ >= 1 && h2_ <= 256, "hidden layer widths must be in [1, 256] (two hidden layers)");
+    const int Hpad_ = std::max(h1_, h2_) <= 64 ? 64 : std::max(h1_, h2_) <= 128 ? 128 : 256;
+    CHECK_ARG(cfg->hidden1 == 0 || cfg->hidden == 0 || cfg->hidden == Hpad_ ,
+              "hidden = %d does not fit hidden1 / hidden2 = %d / %d (leave hidden 0 or give %d)", cfg->hidden, h1_, h2_, Hpad_);
     CHECK_ARG(cfg->n_critics >= 1 && cfg->n_critics <= 2,
               "n_critics must be 1 or 2 (reward [+ one cost], get_metrics base_policy.py:377-382)");
     CHECK_ARG(cfg->env_num >= 1 && cfg->buffer_size >= cfg->env_num, "bad env_num/buffer_size");
@@ -376,6 +398,8 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     (void)hipDeviceGetAttribute(&n_cus_probe, hipDeviceAttributeMultiprocessorCount, device_id);
     fsrl_ctx* c = new fsrl_ctx();
     c->cfg = *cfg;
+    c->cfg.hidden = Hpad_;                 // from here on `hidden` is the kernels' width; h1 / h2 are the caller's layers
+    c->h1 = h1_; c->h2 = h2_;
     c->device = device_id;
     c->n_cus = n_cus_probe > 0 ? n_cus_probe : 256;
 #ifdef FSRL_PROBES
@@ -466,7 +490,7 @@ static int copy_flat(fsrl_ctx* c, float* dev, float* host_out, const float* host
     HIPCHK(hipSetDevice(c->device));
     std::vector<float> tmp((size_t)c->n_dev, 0.0f);
     if (host_in) {                              // only P is ever written from the host
-        for (const TensorMap& t : c->tmap) memcpy(&tmp[t.dev_off], host_in + t.api_off, (size_t)t.n * 4);
+        for (const TensorMap& t : c->tmap) t.to_dev(tmp.data(), host_in);
         HIPCHK(hipStreamSynchronize(c->compute));
         HIPCHK(hipMemcpy(dev, tmp.data(), (size_t)c->n_dev * 4, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(w2f_sync_kernel, dim3(192), dim3(256), 0, c->compute, dev, c->md);   // W2 mirrors
@@ -474,7 +498,7 @@ static int copy_flat(fsrl_ctx* c, float* dev, float* host_out, const float* host
     } else {
         HIPCHK(hipStreamSynchronize(c->compute));
         HIPCHK(hipMemcpy(tmp.data(), dev, (size_t)c->n_dev * 4, hipMemcpyDeviceToHost));
-        for (const TensorMap& t : c->tmap) memcpy(host_out + t.api_off, &tmp[t.dev_off], (size_t)t.n * 4);
+        for (const TensorMap& t : c->tmap) t.to_api(host_out, tmp.data());
     }
     return 0;
 }

@@ -23,7 +23,8 @@ class EngineConfig:
     """Mirror of struct fsrl_config; defaults = PPOLagAgent defaults (ppo_lag_agent.py:82-116)."""
     obs_dim: int = 8
     act_dim: int = 2
-    hidden: int = 128
+    hidden: int = 128                 # two hidden layers of this width ...
+    hidden_sizes: Optional[Sequence[int]] = None   # ... or (h1, h2), any widths in [1, 256] (agents' hidden_sizes); wins over `hidden`
     n_critics: int = 2
     env_num: int = 20
     buffer_size: int = 100000
@@ -50,6 +51,10 @@ class EngineConfig:
     def to_c(self):
         c = _lib.Config()
         c.algo, c.obs_dim, c.act_dim, c.hidden = self.algo, self.obs_dim, self.act_dim, self.hidden
+        if self.hidden_sizes is not None:
+            if len(self.hidden_sizes) != 2:
+                raise ValueError(f"the HIP path runs MLPs with two hidden layers, got hidden_sizes={tuple(self.hidden_sizes)}")
+            c.hidden, c.hidden1, c.hidden2 = 0, int(self.hidden_sizes[0]), int(self.hidden_sizes[1])
         c.n_critics, c.env_num, c.buffer_size = self.n_critics, self.env_num, self.buffer_size
         c.max_action, c.gamma, c.gae_lambda = self.max_action, self.gamma, self.gae_lambda
         c.eps_clip, c.dual_clip = self.eps_clip, (self.dual_clip or 0.0)

@@ -51,11 +51,11 @@ class BasePolicy(ABC, nn.Module):
     def _make_engine(self, device, env_num, buffer_size, optim=None, **cfg_over):
         """Create the HIP context with the geometry of the host networks."""
         from fsrl_amd.engine import Engine, EngineConfig
-        w1 = self.actor.preprocess.model.model[0].weight
-        hidden, obs_dim = w1.shape
+        from fsrl_amd.utils.net import mlp_geometry
+        obs_dim, hidden_sizes = mlp_geometry(self.actor.preprocess)
         act_dim = self.actor.mu.model[0].weight.shape[0]
         dev = device if isinstance(device, int) else (int(str(device).split(":")[-1]) if ":" in str(device) else 0)
-        kw = dict(obs_dim=int(obs_dim), act_dim=int(act_dim), hidden=int(hidden), n_critics=self.critics_num,
+        kw = dict(obs_dim=int(obs_dim), act_dim=int(act_dim), hidden_sizes=hidden_sizes, n_critics=self.critics_num,
                   env_num=int(env_num), buffer_size=int(buffer_size),
                   max_action=float(getattr(self.actor, "_max", 1.0)), gamma=self._gamma,
                   unbounded=bool(getattr(self.actor, "_unbounded", False)), rew_norm=self._rew_norm)

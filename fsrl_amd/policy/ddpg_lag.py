@@ -37,12 +37,12 @@ class DDPGLagrangian(LagrangianPolicy):
         self.critics_old = deepcopy(self.critics)
         self.critics_old.eval()
         self.tau, self._noise, self._n_step = tau, exploration_noise, n_step
-        w1 = actor.preprocess.model.model[0].weight
-        hidden, obs_dim = w1.shape
+        from fsrl_amd.utils.net import mlp_geometry
+        obs_dim, hidden_sizes = mlp_geometry(actor.preprocess)
         act_dim = actor.last.model[0].weight.shape[0]
         dev = device if isinstance(device, int) else (int(str(device).split(":")[-1]) if ":" in str(device) else 0)
         self.engine = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=int(obs_dim), act_dim=int(act_dim),
-                                          hidden=int(hidden), n_critics=2, env_num=int(env_num),
+                                          hidden_sizes=hidden_sizes, n_critics=2, env_num=int(env_num),
                                           buffer_size=int(buffer_size), gamma=gamma, max_action=float(actor._max),
                                           target_kl=None), device=dev)
         self.engine.sac_init(actor_lr=actor_optim.param_groups[0]["lr"], critic_lr=critic_optim.param_groups[0]["lr"],

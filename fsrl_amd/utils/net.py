@@ -40,6 +40,17 @@ class Net(nn.Module):
         return self.model(obs), state
 
 
+def mlp_geometry(preprocess_net):
+    """(input_dim, (h1, h2)) of a preprocess Net, the way the HIP engine needs it: exactly two Linear + ReLU hidden layers
+    of any widths up to 256 (the kernels run at 64 / 128 / 256 and zero-pad narrower layers, include/fsrl_hip.h
+    fsrl_config.hidden1 / hidden2).  Other depths / widths raise a ValueError that says so."""
+    lin = [m for m in preprocess_net.model.model if isinstance(m, nn.Linear)]
+    widths = tuple(int(m.out_features) for m in lin)
+    if len(lin) != 2 or max(widths) > 256:
+        raise ValueError(f"the HIP path runs MLPs with two hidden layers of at most 256 units, got hidden_sizes={widths}")
+    return int(lin[0].in_features), widths
+
+
 SIGMA_MIN, SIGMA_MAX = -20, 2
 
 

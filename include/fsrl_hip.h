@@ -55,7 +55,7 @@ typedef struct fsrl_config {
     int32_t algo;            /* FSRL_ALGO_*                                              */
     int32_t obs_dim;         /* Do  (1..128)                                             */
     int32_t act_dim;         /* Da  (1..16)                                              */
-    int32_t hidden;          /* H1 == H2 == hidden, one of 64 / 128 / 256                */
+    int32_t hidden;          /* two hidden layers of this width; with hidden1 / hidden2 set: 0, or the padded width       */
     int32_t n_critics;       /* 1 + number of cost constraints (2 for one cost)          */
     int32_t env_num;         /* number of per-env sub-buffers (VectorReplayBuffer)       */
     int64_t buffer_size;     /* total rows requested; sub-buffers get ceil(total/env_num)*/
@@ -78,6 +78,10 @@ typedef struct fsrl_config {
     int32_t rew_norm;        /* reward_normalization (base_policy.py:114, 430-444): critics learn returns divided by the
                                 running std of the returns; on-policy contexts                                        */
     int32_t value_clip;      /* PPO: clipped value loss (ppo_lag.py:158-164); needs rew_norm like the reference      */
+    int32_t hidden1, hidden2; /* hidden_sizes = (hidden1, hidden2) of the agents (fsrl/agent/ppo_lag_agent.py:91,136), any
+                                widths in [1, 256]; 0, 0 = (hidden, hidden).  Every flat parameter vector of the API (set /
+                                get, gradients, trust-region vectors, the replay agents' actor / critic vectors) has the
+                                caller's layout; the kernels run at 64 / 128 / 256 with zero-padded units               */
 } fsrl_config;
 
 const char* fsrl_last_error(void);

@@ -358,6 +358,17 @@ def gen_ppo_options():
                  max_grad_norm=0.5, target_kl=1e9, unbounded=True)
 
 
+def gen_ppo_widths():
+    # hidden_sizes of two DIFFERENT widths, neither one of the kernels' 64 / 128 / 256 (fsrl/agent/ppo_lag_agent.py:91,136:
+    # `hidden_sizes: Tuple[int, ...]`): the HIP path zero-pads them
+    gen_ppo_case("widths", obs_dim=7, act_dim=3, hidden=(96, 40), env_num=3,
+                 ep_lens=[[60, 45, -11], [70, 50], [40, 40, -20]], batch_size=64, repeat=3, seed=41,
+                 max_grad_norm=0.5, target_kl=1e9)
+    gen_ppo_case("widths_wide", obs_dim=8, act_dim=2, hidden=(100, 200), env_num=2,
+                 ep_lens=[[90, 70], [100, -50]], batch_size=128, repeat=2, seed=42,
+                 max_grad_norm=None, target_kl=1e9)
+
+
 def gen_manifest():
     policy, _, _ = build_ppo(8, 2, (128, 128), 0, logger=CaptureLogger(), cost_limit=10.0)
     sd = policy.state_dict()
@@ -372,4 +383,4 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["gae", "nstep", "pid", "ppo", "manifest"]
     for w in which:
         {"gae": gen_gae, "nstep": gen_nstep, "pid": gen_pid, "ppo": gen_ppo, "recompute": gen_ppo_recompute, "options": gen_ppo_options,
-         "manifest": gen_manifest}[w]()
+         "widths": gen_ppo_widths, "manifest": gen_manifest}[w]()

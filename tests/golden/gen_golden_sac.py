@@ -133,6 +133,10 @@ def gen(name, obs_dim, act_dim, hidden, env_num, ep_lens, batch_size, n_updates,
 if __name__ == "__main__":
     torch.set_num_threads(4)
     eps = [[60, 50, -17], [70, 55], [40, 40, 40, -9]]
+    if sys.argv[1:] == ["widths"]:
+        # two hidden layers of different widths that are not 64 / 128 / 256 (zero-padded on the device)
+        gen("widths", 6, 3, (80, 48), 3, eps, batch_size=64, n_updates=5, seed=35, n_step=2)
+        sys.exit(0)
     gen("small", 6, 3, (64, 64), 3, eps, batch_size=64, n_updates=6, seed=30, n_step=2)
     gen("nstep3", 8, 2, (64, 64), 3, eps, batch_size=128, n_updates=4, seed=31, n_step=3, auto_alpha=False,
         alpha=0.2)

@@ -258,6 +258,13 @@ if __name__ == "__main__":
         gen_trpo("options", 8, 2, (64, 64), 3, eps, repeat=2, seed=22, cost_stat=25.0, cost_limit=10.0,
                  optim_critic_iters=5, unbounded=True, reward_normalization=True, ret_rms0=rms0)
         sys.exit(0)
+    if sys.argv[1:] == ["widths"]:
+        # two hidden layers of different widths that are not 64 / 128 / 256 (zero-padded on the device)
+        gen_cpo("widths", 8, 2, (100, 50), 3, eps, repeat=2, seed=33, cost_stat=25.0, cost_limit=10.0,
+                optim_critic_iters=3, max_backtracks=10)
+        gen_trpo("widths", 8, 2, (48, 80), 3, eps, repeat=2, seed=34, cost_stat=25.0, cost_limit=10.0,
+                 optim_critic_iters=3)
+        sys.exit(0)
     if sys.argv[1:] == ["minibatch"]:
         # batch_size below the buffer: Batch.split(batch_size, merge_last=True) inside learn (cpo.py:357-358,
         # trpo_lag.py:178).  N = 560 rows, batch 150 -> minibatches of 150 / 150 / 260 (the remainder merged into the last)

@@ -13,13 +13,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("hidden,obs_dim,act_dim", [(64, 8, 2), (128, 8, 2), (256, 8, 2), (256, 60, 2), (128, 33, 8)])
+@pytest.mark.parametrize("hidden,obs_dim,act_dim", [(64, 8, 2), (128, 8, 2), (256, 8, 2), (256, 60, 2), (128, 33, 8),
+                                                    ((100, 50), 8, 2), ((24, 200), 17, 3)])      # zero-padded widths
 def test_actor_forward_equals_host_mirror(hidden, obs_dim, act_dim, tmp_path):
     from fsrl_amd.agent import PPOLagAgent
     from fsrl_amd.data.batch import Batch
     from fsrl_amd.env import SyntheticSafetyVectorEnv
     env = SyntheticSafetyVectorEnv(env_num=4, obs_dim=obs_dim, act_dim=act_dim, episode_len=20, seed=1)
-    agent = PPOLagAgent(env, None, cost_limit=10, device="cuda:0", seed=3, hidden_sizes=(hidden, hidden), training_num=4)
+    agent = PPOLagAgent(env, None, cost_limit=10, device="cuda:0", seed=3,
+                        hidden_sizes=hidden if isinstance(hidden, tuple) else (hidden, hidden), training_num=4)
     pol, eng = agent.policy, agent.policy.engine
     with torch.no_grad():                       # move sigma_param and the head off their init so every term is exercised
         pol.actor.sigma_param.add_(0.1 * torch.randn_like(pol.actor.sigma_param))

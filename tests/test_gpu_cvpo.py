@@ -15,7 +15,7 @@ def _engine(cfg, g, ocfg):
     from fsrl_amd import _lib
     from fsrl_amd.engine import Engine, EngineConfig
     eng = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"],
-                              hidden=cfg["hidden"][0], n_critics=2, env_num=cfg["env_num"], buffer_size=cfg["buffer_size"],
+                              hidden_sizes=tuple(cfg["hidden"]), n_critics=2, env_num=cfg["env_num"], buffer_size=cfg["buffer_size"],
                               gamma=cfg["gamma"], max_action=cfg["max_action"], target_kl=None))
     eng.cvpo_init(ocfg.qc_thres, **{k: cfg[k] for k in (
         "actor_lr", "critic_lr", "tau", "n_step", "double_critic", "sample_act_num", "estep_iter_num", "mstep_iter_num",

@@ -16,7 +16,7 @@ def _engine(cfg, g):
     from fsrl_amd import _lib
     from fsrl_amd.engine import Engine, EngineConfig
     eng = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"],
-                              hidden=cfg["hidden"][0], n_critics=2, env_num=cfg["env_num"], buffer_size=cfg["buffer_size"],
+                              hidden_sizes=tuple(cfg["hidden"]), n_critics=2, env_num=cfg["env_num"], buffer_size=cfg["buffer_size"],
                               gamma=cfg["gamma"], max_action=cfg["max_action"], target_kl=None))
     eng.sac_init(actor_lr=cfg["actor_lr"], critic_lr=cfg["critic_lr"], tau=cfg["tau"], n_step=cfg["n_step"],
                  use_lagrangian=cfg["use_lagrangian"], deterministic=True)

@@ -546,3 +546,45 @@ def test_agent_learns_over_env_factories(workers, tmp_path):
         assert 0 < length <= 40 and np.isfinite(rew) and cost >= 0
     finally:
         train.close()
+
+
+@pytest.mark.parametrize("kind", ["ppol", "cpo", "sacl", "ddpgl", "cvpo", "focops"])
+def test_agents_with_two_hidden_layers_of_any_width(kind, tmp_path):
+    """`hidden_sizes: Tuple[int, ...]` of the agents (fsrl/agent/ppo_lag_agent.py:91,136): any two widths up to 256 run on the
+    HIP path (the kernels' width is the next of 64 / 128 / 256, narrower layers are zero-padded: include/fsrl_hip.h hidden1 /
+    hidden2).  Train a little, then: the state_dict has the caller's shapes, the device parameters round-trip through it, and
+    three hidden layers / a 300-wide layer fail with a message instead of an assert somewhere below."""
+    from fsrl_amd import agent as A
+    from fsrl_amd.env import SyntheticSafetyVectorEnv
+    from fsrl_amd.utils import BaseLogger
+    cls = {"ppol": A.PPOLagAgent, "cpo": A.CPOAgent, "sacl": A.SACLagAgent, "ddpgl": A.DDPGLagAgent, "cvpo": A.CVPOAgent,
+           "focops": A.FOCOPSAgent}[kind]
+    env = SyntheticSafetyVectorEnv(env_num=4, episode_len=40, seed=1)
+    kw = dict(buffer_size=4000) if kind in ("sacl", "ddpgl", "cvpo") else {}
+    agent = cls(env, BaseLogger(str(tmp_path), name="t"), cost_limit=10, device="cuda:0", seed=3, hidden_sizes=(100, 50),
+                training_num=4, **kw)
+    pol = agent.policy
+    w = {k: tuple(v.shape) for k, v in pol.state_dict().items() if k.startswith("actor.preprocess")}
+    assert w["actor.preprocess.model.model.0.weight"] == (100, 8) and w["actor.preprocess.model.model.2.weight"] == (50, 100)
+    if kind in ("sacl", "ddpgl", "cvpo"):
+        agent.learn(env, None, epoch=1, episode_per_collect=4, step_per_epoch=320, update_per_step=0.2, batch_size=64,
+                    verbose=False, save_ckpt=False)
+    else:
+        agent.learn(env, None, epoch=1, episode_per_collect=4, step_per_epoch=320, repeat_per_collect=2,
+                    batch_size=64 if kind in ("ppol", "focops") else 99999, verbose=False, save_ckpt=False)
+    import copy
+    sd = copy.deepcopy(pol.state_dict())
+    assert all(torch.isfinite(v).all() for v in sd.values() if torch.is_tensor(v) and v.is_floating_point())
+    pol.load_state_dict(sd)                                    # host -> device -> host: the padding is invisible
+    if kind in ("sacl", "ddpgl", "cvpo"):
+        pol._dirty = pol._rest_dirty = True                   # the next state_dict() reads the device back
+    else:
+        pol._mark_stale()
+    for k, v in pol.state_dict().items():
+        if torch.is_tensor(v):
+            assert torch.equal(v, sd[k]), k
+    rew, length, cost = agent.evaluate(env, eval_episodes=2)
+    assert length == 40.0 and np.isfinite(rew)
+    for bad in ((64, 64, 64), (300, 64)):
+        with pytest.raises(ValueError, match="two hidden layers"):
+            cls(env, None, cost_limit=10, device="cuda:0", seed=3, hidden_sizes=bad, training_num=4, **kw)

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def _engine(cfg, g):
     from fsrl_amd import _lib
     from fsrl_amd.engine import Engine, EngineConfig
-    eng = Engine(EngineConfig(algo=_lib.ALGO_FOCOPS, obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"], hidden=cfg["hidden"][0],
+    eng = Engine(EngineConfig(algo=_lib.ALGO_FOCOPS, obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"], hidden_sizes=tuple(cfg["hidden"]),
                               n_critics=2, env_num=cfg["env_num"], max_action=cfg["max_action"], gamma=cfg["gamma"],
                               gae_lambda=cfg["gae_lambda"], norm_adv=cfg["advantage_normalization"], target_kl=None,
                               unbounded=bool(cfg.get("unbounded", False)),

@@ -16,7 +16,7 @@ def _engine(cfg, g):
     from fsrl_amd import _lib
     from fsrl_amd.engine import Engine, EngineConfig
     eng = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"],
-                              hidden=cfg["hidden"][0], n_critics=2, env_num=cfg["env_num"],
+                              hidden_sizes=tuple(cfg["hidden"]), n_critics=2, env_num=cfg["env_num"],
                               buffer_size=cfg["buffer_size"], gamma=cfg["gamma"], target_kl=None))
     eng.sac_init(actor_lr=cfg["actor_lr"], critic_lr=cfg["critic_lr"], alpha_lr=cfg["alpha_lr"], tau=cfg["tau"],
                  alpha=cfg["alpha"], n_step=cfg["n_step"], auto_alpha=cfg["auto_alpha"])
@@ -32,7 +32,7 @@ def _engine(cfg, g):
     return eng
 
 
-@pytest.mark.parametrize("name", ["small", "nstep3", "c4"])
+@pytest.mark.parametrize("name", ["small", "nstep3", "c4", "widths"])
 def test_sac_updates_vs_golden(name):
     g, cfg, ocfg, store, index = sac_setup(name)
     eng = _engine(cfg, g)

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 def _engine(cfg, **over):
     from fsrl_amd.engine import Engine, EngineConfig
-    ec = EngineConfig(obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"], hidden=cfg["hidden"][0], n_critics=2,
+    ec = EngineConfig(obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"], hidden_sizes=tuple(cfg["hidden"]), n_critics=2,
                       env_num=cfg["env_num"], gamma=cfg["gamma"], gae_lambda=cfg["gae_lambda"],
                       max_action=cfg["max_action"], lr=cfg["lr"], target_kl=None,
                       unbounded=bool(cfg.get("unbounded", False)), rew_norm=bool(cfg.get("reward_normalization", False)))
@@ -126,7 +126,7 @@ def _cpo_f64_yardstick(name):
     return _YARD[name]
 
 
-@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options"])
+@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options", "widths"])
 def test_cpo_learn_vs_golden(name):
     g = load_npz(f"cpo_{name}.npz")
     cfg = json.loads(str(g["cfg_json"]))
@@ -175,7 +175,7 @@ TRPO_KEYS = ["loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss/act
              "loss/vf0", "loss/vf1", "loss/vf_total", "loss/kl", "loss/step_size", "loss/entropy"]
 
 
-@pytest.mark.parametrize("name", ["small", "c1", "options"])
+@pytest.mark.parametrize("name", ["small", "c1", "options", "widths"])
 def test_trpo_learn_vs_golden(name):
     g = load_npz(f"trpo_{name}.npz")
     cfg = json.loads(str(g["cfg_json"]))

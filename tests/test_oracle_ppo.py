@@ -11,7 +11,7 @@ from oracle.pid import rescaling_factor
 from oracle.ppo_lag import PPOLagOracle, split_chunks
 
 CASES = ["tiny", "c1", "c2", "earlystop", "dualclip", "recompute", "rewnorm", "rewnorm_first", "rewnorm_recompute",
-         "unbounded"]
+         "unbounded", "widths", "widths_wide"]
 
 
 def test_split_chunks_matches_tianshou_semantics():
