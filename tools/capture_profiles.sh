@@ -45,4 +45,5 @@ timeout 300 python tools/bench_shmem.py > $O/${TAG}_bench_shmem.json 2>/dev/null
 # microbenchmarks the DESIGN notes quote: device-wide barrier flavours, workgroup dispatch rate (prebuilt: tools/ubench/*.bin)
 [ -x tools/ubench/gridsync.bin ] && { timeout 60 tools/ubench/gridsync.bin 217; timeout 60 tools/ubench/gridsync.bin 256; } > $O/${TAG}_ubench_gridsync.txt 2>&1
 [ -x tools/ubench/dispatch.bin ] && timeout 60 tools/ubench/dispatch.bin > $O/${TAG}_ubench_dispatch.txt 2>&1
+[ -x tools/ubench/chain.bin ] && timeout 120 tools/ubench/chain.bin 78 > $O/${TAG}_ubench_chain.txt 2>&1
 ls $O | head -40

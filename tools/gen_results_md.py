@@ -146,7 +146,8 @@ def build(tag):
         add(f"Grouped launches (`profiles/{tag}_bench_group.json`): " +
             ", ".join(f"k = {x['agents_per_gpu']}: {fmt(x['aggregate_updates_per_s'])}" for x in g) + " updates/s aggregate.\n")
     for name, title in ((f"{tag}_ubench_gridsync.txt", "Device-wide barrier inside a kernel (`tools/ubench/gridsync.hip`)"),
-                        (f"{tag}_ubench_dispatch.txt", "Workgroup dispatch rate (`tools/ubench/dispatch.hip`)")):
+                        (f"{tag}_ubench_dispatch.txt", "Workgroup dispatch rate (`tools/ubench/dispatch.hip`)"),
+                        (f"{tag}_ubench_chain.txt", "Three launches per step vs ONE launch whose blocks wait for lower-numbered blocks (`tools/ubench/chain.hip`)")):
         f = os.path.join(PR, name)
         if os.path.exists(f):
             add(f"{title}, `profiles/{name}`:\n\n```\n" + open(f).read().strip() + "\n```\n")
