@@ -1131,31 +1131,38 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s0 = KS0 + wave; s0 < KS; s0 += 16 * BU) {       // bursts of BU k-steps per wave
-            f32x4 ya[BU], xa[BU], yb[BU], xb[BU];
-#pragma unroll
-            for (int b = 0; b < BU; ++b) {
-                const int s = s0 + 16 * b;
-                ya[b] = xa[b] = yb[b] = xb[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (s < KS) {
-                    const size_t r = (size_t)(4 * s + q) * H;
-                    ya[b] = *reinterpret_cast<const f32x4*>(wn.w2_ya + r + tj * 64 + 4 * c);
-                    xa[b] = *reinterpret_cast<const f32x4*>(wn.w2_xa + r + tk * 64 + 4 * c);
-                    if constexpr (PAIR2) {
-                        yb[b] = *reinterpret_cast<const f32x4*>(wn.w2_yb + r + tj * 64 + 4 * c);
-                        xb[b] = *reinterpret_cast<const f32x4*>(wn.w2_xb + r + tk * 64 + 4 * c);
-                    }
-                }
+        // Software-pipelined: the operands of the wave's NEXT k-step are requested before the 16 (32) MFMAs of the current one
+        // issue, so a wave's own MFMA time hides part of its load latency too (load -> wait -> MFMAs left that to the other
+        // three waves of the SIMD).  Same k order per wave, same accumulation order: bit-identical to the loop it replaces.
+        auto fetch = [&](const int s, f32x4& ya, f32x4& xa, f32x4& yb, f32x4& xb) {
+            const size_t r = (size_t)(4 * s + q) * H;
+            ya = *reinterpret_cast<const f32x4*>(wn.w2_ya + r + tj * 64 + 4 * c);
+            xa = *reinterpret_cast<const f32x4*>(wn.w2_xa + r + tk * 64 + 4 * c);
+            if constexpr (PAIR2) {
+                yb = *reinterpret_cast<const f32x4*>(wn.w2_yb + r + tj * 64 + 4 * c);
+                xb = *reinterpret_cast<const f32x4*>(wn.w2_xb + r + tk * 64 + 4 * c);
             }
+        };
+        auto fma16 = [&](const f32x4& ya, const f32x4& xa, const f32x4& yb, const f32x4& xb) {
 #pragma unroll
-            for (int b = 0; b < BU; ++b) {
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        acc[t][u] = mfma_16x16x4(ya[b][t], xa[b][u], acc[t][u]);
-                        if constexpr (PAIR2) acc[t][u] = mfma_16x16x4(yb[b][t], xb[b][u], acc[t][u]);
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    acc[t][u] = mfma_16x16x4(ya[t], xa[u], acc[t][u]);
+                    if constexpr (PAIR2) acc[t][u] = mfma_16x16x4(yb[t], xb[u], acc[t][u]);
+                }
+        };
+        static_assert(BU == 1, "the pipelined loop replaces the burst loop");
+        {
+            f32x4 ya, xa, yb, xb;
+            ya = xa = yb = xb = f32x4{0.f, 0.f, 0.f, 0.f};
+            int s0 = KS0 + wave;
+            if (s0 < KS) fetch(s0, ya, xa, yb, xb);
+            for (; s0 < KS; s0 += 16) {
+                f32x4 nya = ya, nxa = xa, nyb = yb, nxb = xb;
+                if (s0 + 16 < KS) fetch(s0 + 16, nya, nxa, nyb, nxb);
+                fma16(ya, xa, yb, xb);
+                ya = nya; xa = nxa; yb = nyb; xb = nxb;
             }
         }
         // four partial-tile slots, four rounds: waves 4k..4k+3 add into slot (wave & 3) in round k
