@@ -119,6 +119,7 @@ SIGNATURES = {
     "fsrl_tr_eval": (C.c_int, [_ctx, _d]),
     "fsrl_tr_set_plan": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32]),
     "fsrl_focops_init": (C.c_int, [_ctx, _P(FocopsConfig)]),
+    "fsrl_focops_set_plan": (C.c_int, [_ctx, C.c_int32]),
     "fsrl_focops_set_nu": (C.c_int, [_ctx, C.c_double, C.c_double]),
     "fsrl_sac_init": (C.c_int, [_ctx, _P(SacConfig)]),
     "fsrl_sac_param_count": (C.c_int64, [_ctx, C.c_int32]),

@@ -1572,6 +1572,11 @@ struct FocopsStepArgs {
     float* gsq;                              // [nb_a] per-block sums of squares of the actor gradient
     float* psq;                              // [nb_c0 + nb_c1] per-block sums of squares of the critics' PRE-update parameters
     float* sig_stash;                        // [Da] sigma_param before the step (entropy of the pre-update policy)
+    // three-launch step (ppo_wgrad_kernel instead of fb_wgrad_kernel + focops_prep_kernel): G holds the final gradient of all
+    // three networks, the actor's squared norm comes as ppo_wgrad's per-block sums + its extra block's per-network share, and
+    // the step leaves sum(theta^2) of the critics / sigma_param AFTER the update for the next step's logged row
+    const float* gsq_part; int n_gsq_part; const float* gsq_net;
+    float* psq_next; float* sig_next;
     int nb_a, nb_c0, nb_c1;
     float max_norm, l2;
     float one_minus_b1, beta2, one_minus_b2, adam_eps;
@@ -1593,10 +1598,12 @@ __global__ __launch_bounds__(256) void focops_prep_kernel(const ModelDesc md, co
     float q = 0.0f;
     if (i < md.net[net].end) {
         if (net == 0) {
-            float v = a.parts[i];
-            for (int z = 1; z < a.nparts; ++z) v += a.parts[(size_t)z * a.stride + i];
-            a.G[i] = v;
-            q = v * v;
+            if (a.nparts > 0) {                   // nparts == 0: called for the parameter sums only (start of a three-launch pass)
+                float v = a.parts[i];
+                for (int z = 1; z < a.nparts; ++z) v += a.parts[(size_t)z * a.stride + i];
+                a.G[i] = v;
+                q = v * v;
+            }
         } else {
             const float p = a.P[i];
             q = p * p;
@@ -1616,6 +1623,7 @@ __global__ __launch_bounds__(256) void focops_prep_kernel(const ModelDesc md, co
 __global__ __launch_bounds__(256) void focops_step_kernel(const ModelDesc md, const FocopsStepArgs a) {
     __shared__ double shd[4];
     __shared__ float coef_s;
+    __shared__ float shq[4];
     if ((int)blockIdx.x == a.nb_a + a.nb_c0 + a.nb_c1) {
         if (threadIdx.x < 64) focops_finalize_row(a.fin, threadIdx.x);
         return;
@@ -1625,6 +1633,10 @@ __global__ __launch_bounds__(256) void focops_step_kernel(const ModelDesc md, co
     float coef = 1.0f;
     if (net == 0 && a.max_norm > 0.0f) {     // same reduction order as adam_range_kernel's clip
         double sq = 0.0;
+        if (a.gsq_part) {                    // the actor's blocks of ppo_wgrad_kernel come first, then its share of the extra block
+            for (int k = threadIdx.x; k < a.n_gsq_part; k += 256) sq += (double)a.gsq_part[k];
+            if (threadIdx.x == 0) sq += (double)a.gsq_net[0];
+        } else
         for (int k = threadIdx.x; k < a.nb_a; k += 256) sq += (double)a.gsq[k];
         sq = wave_sum_d(sq);
         if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = sq;
@@ -1633,18 +1645,28 @@ __global__ __launch_bounds__(256) void focops_step_kernel(const ModelDesc md, co
         __syncthreads();
         coef = coef_s;
     }
-    if (i >= md.net[net].end) return;
-    const float p = a.P[i];
-    float gs;
-    if (net == 0) gs = a.G[i];
-    else {
-        gs = a.parts[i];
-        for (int z = 1; z < a.nparts; ++z) gs += a.parts[(size_t)z * a.stride + i];
+    float pn = 0.0f;
+    if (i < md.net[net].end) {
+        const float p = a.P[i];
+        float gs;
+        if (net == 0 || a.nparts == 0) gs = a.G[i];
+        else {
+            gs = a.parts[i];
+            for (int z = 1; z < a.nparts; ++z) gs += a.parts[(size_t)z * a.stride + i];
+        }
+        if (net == 0) adam_element(a.P, a.M, a.V, i, p, gs, coef, 0.0f, a.one_minus_b1, a.beta2, a.one_minus_b2, a.step_a, a.bc2s_a,
+                                   a.adam_eps, md, nullptr, 0.0f, 0.0f);
+        else adam_element(a.P, a.M, a.V, i, p, gs, coef, a.l2, a.one_minus_b1, a.beta2, a.one_minus_b2, a.step_c, a.bc2s_c, a.adam_eps,
+                          md, nullptr, 0.0f, 0.0f);
+        pn = a.P[i];                          // what this thread just wrote
+        if (net == 0 && a.sig_next && (unsigned)(i - md.net[0].sigma) < (unsigned)md.Da) a.sig_next[i - md.net[0].sigma] = pn;
     }
-    if (net == 0) adam_element(a.P, a.M, a.V, i, p, gs, coef, 0.0f, a.one_minus_b1, a.beta2, a.one_minus_b2, a.step_a, a.bc2s_a,
-                               a.adam_eps, md, nullptr, 0.0f, 0.0f);
-    else adam_element(a.P, a.M, a.V, i, p, gs, coef, a.l2, a.one_minus_b1, a.beta2, a.one_minus_b2, a.step_c, a.bc2s_c, a.adam_eps,
-                      md, nullptr, 0.0f, 0.0f);
+    if (net != 0 && a.psq_next) {             // sum(theta^2) of this block AFTER the step: the next step's pre-update value
+        float q = wave_sum(pn * pn);
+        if ((threadIdx.x & 63) == 0) shq[threadIdx.x >> 6] = q;
+        __syncthreads();
+        if (threadIdx.x == 0) a.psq_next[blockIdx.x - a.nb_a] = (shq[0] + shq[1]) + (shq[2] + shq[3]);
+    }
 }
 
 // full-batch advantage normalisation (CPO cpo.py:127-131, TRPO trpo_lag.py:129-133): per critic

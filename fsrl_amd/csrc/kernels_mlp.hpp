@@ -724,6 +724,8 @@ struct WgradPtrs {
     float* stats;      // [steps][FSRL_PPO_NSTATS]
     int mbp_max;
     float* Pw; float* M; float* V;   // fused-Adam instantiation (FUSE): parameters and Adam moments, updated in place
+    float* gsq_net;    // optional [n_nets]: the extra block's share of the squared norm (db3, dsigma) PER NETWORK -- FOCOPS clips the
+                       // actor alone (focops.py:205-213); with `stats` null the extra block skips the PPO row
 };
 
 // torch.optim.Adam single-tensor update of ONE element with an unclipped gradient -- the same operations in the same
@@ -816,7 +818,7 @@ __device__ __forceinline__ void ppo_wgrad_body(const ModelDesc& md, const WgradP
     if (FSRL_PROBE(sa, 20)) return;
     if ((int)blockIdx.x == md.n_nets * PB) {  // the stats block
         if (FSRL_PROBE(sa, 21) || FSRL_PROBE(sa, 22)) return;
-        if (wave == 0) {
+        if (wave == 0 && wp.stats) {
             ppo_stats_finalize(md, wp, sa, n_stat_tiles, lane);
             // fused mode: the pass-level KL stop that adam_clip_kernel's first block decides otherwise (ppo_lag.py:251-255)
             if (FUSE && lane == 0 && sa.last_in_pass && sa.target_kl > 0.0f) {
@@ -826,7 +828,7 @@ __device__ __forceinline__ void ppo_wgrad_body(const ModelDesc& md, const WgradP
         }
         // db3[o] / dsigma[d] = column sums of DO over the minibatch rows, for every network:
         // thread (col = tid & 31, row phase = tid >> 5); all loads of a thread in one burst
-        float sqs = 0.0f;
+        float sqs = 0.0f, sqs_prev = 0.0f;
         for (int net = 0; net < md.n_nets; ++net) {
             const NetOff no = md.net[net];
             const float* __restrict__ DOn = wp.DO + (size_t)net * wp.mbp_max * FSRL_DOW;
@@ -857,6 +859,11 @@ __device__ __forceinline__ void ppo_wgrad_body(const ModelDesc& md, const WgradP
                     wp.grad[no.sigma + tid - 16] = tot; sqs = fmaf(tot, tot, sqs);
                     if constexpr (FUSE) ppo_adam_elem(wp, sa, no.sigma + tid - 16, tot);   // wave 0 logged the entropy first
                 }
+            }
+            if (wp.gsq_net && wave == 0) {           // this network's share on its own (lanes >= 32 of wave 0 hold 0)
+                const float d = wave_sum(sqs - sqs_prev);
+                if (lane == 0) wp.gsq_net[net] = d;
+                sqs_prev = sqs;
             }
         }
         if (wave == 0) {

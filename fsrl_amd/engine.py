@@ -305,6 +305,10 @@ class Engine:
         cfg = _lib.FocopsConfig(actor_lr, critic_lr, l2_reg, delta, eta, tem_lambda, float(max_grad_norm or 0.0))
         _lib.check(self.lib.fsrl_focops_init(self._ctx, C.byref(cfg)))
 
+    def focops_set_plan(self, four_launch: int = 0):
+        """A/B and tests: 1 = the four-launch minibatch step (split-K weight gradients), 0 = three launches (default)"""
+        _lib.check(self.lib.fsrl_focops_set_plan(self._ctx, int(four_launch)))
+
     def focops_update(self, nu, nu_loss, batch_size, repeat, perms=None, seed=0):
         """-> (stats [steps, 8]: nu_loss, nu_value, actor_loss, kl, entropy, vf0, vf1, vf_total; stopped pass or -1)."""
         _lib.check(self.lib.fsrl_focops_set_nu(self._ctx, float(nu), float(nu_loss)))

@@ -334,6 +334,10 @@ typedef struct fsrl_focops_config {
 } fsrl_focops_config;
 #define FSRL_FOCOPS_NSTATS 8
 int fsrl_focops_init(fsrl_ctx* ctx, const fsrl_focops_config* cfg);
+/* A/B and tests only: 1 = every FOCOPS minibatch step as the four-launch sequence (split-K weight gradients + their sum); 0 =
+ * three launches whenever the minibatch has at most 512 rows (the default).  Same arithmetic per element, different
+ * summation order of the weight gradients. */
+int fsrl_focops_set_plan(fsrl_ctx* ctx, int32_t four_launch);
 int fsrl_focops_set_nu(fsrl_ctx* ctx, double nu, double nu_loss);
 
 /* ---- SAC-Lagrangian (fsrl/policy/sac_lag.py), off-policy on the HIP-resident replay store.

@@ -31,11 +31,13 @@ def _engine(cfg, g):
     return eng
 
 
+@pytest.mark.parametrize("four_launch", [0, 1])     # 0: three launches per step (ppo_wgrad_kernel), 1: split-K weight gradients + their sum
 @pytest.mark.parametrize("name", ["small", "c1", "earlystop", "unbounded", "recompute"])
-def test_focops_update_vs_golden(name):
+def test_focops_update_vs_golden(name, four_launch):
     g = load_npz(f"focops_{name}.npz")
     cfg = json.loads(str(g["cfg_json"]))
     eng = _engine(cfg, g)
+    eng.focops_set_plan(four_launch)
     nu = float(g["stats_nu"][0][1]); nu_loss = float(g["stats_nu"][0][0])       # the host-side nu step (focops.py:154-159)
     perms = list(g["perms"]) + [np.arange(len(g["indices"]))] * (cfg["repeat"] - len(g["perms"]))
     stats, stopped = eng.focops_update(nu, nu_loss, cfg["batch_size"], cfg["repeat"], perms=perms)
