@@ -122,6 +122,7 @@ SIGNATURES = {
     "fsrl_focops_set_plan": (C.c_int, [_ctx, C.c_int32]),
     "fsrl_focops_set_nu": (C.c_int, [_ctx, C.c_double, C.c_double]),
     "fsrl_sac_init": (C.c_int, [_ctx, _P(SacConfig)]),
+    "fsrl_sac_set_plan": (C.c_int, [_ctx, C.c_int32]),
     "fsrl_sac_param_count": (C.c_int64, [_ctx, C.c_int32]),
     "fsrl_sac_params_set": (C.c_int, [_ctx, _f, C.c_int64, _f, C.c_int64, C.c_float]),
     "fsrl_sac_params_put": (C.c_int, [_ctx, C.c_int32, _f, C.c_int64]),

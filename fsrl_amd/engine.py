@@ -467,6 +467,10 @@ class Engine:
         self.n_sac_actor = int(self.lib.fsrl_sac_param_count(self._ctx, 0))
         self.n_sac_critics = int(self.lib.fsrl_sac_param_count(self._ctx, 1))
 
+    def sac_set_plan(self, wgrad_splitk: int = 0):
+        """A/B and tests: 1 = split-K weight gradients at every batch size, 0 = the one-workgroup-per-tile kernel up to 512 rows"""
+        _lib.check(self.lib.fsrl_sac_set_plan(self._ctx, int(wgrad_splitk)))
+
     def sac_set_params(self, actor_flat, critics_flat, log_alpha=0.0):
         a = np.ascontiguousarray(actor_flat, np.float32); c = np.ascontiguousarray(critics_flat, np.float32)
         _lib.check(self.lib.fsrl_sac_params_set(self._ctx, _ptr(a, _f32p), a.size, _ptr(c, _f32p), c.size,

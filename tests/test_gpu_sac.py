@@ -32,10 +32,12 @@ def _engine(cfg, g):
     return eng
 
 
+@pytest.mark.parametrize("splitk", [0, 1])      # weight gradients: 0 = one workgroup per output tile (batches <= 512 rows), 1 = split-K
 @pytest.mark.parametrize("name", ["small", "nstep3", "c4", "widths"])
-def test_sac_updates_vs_golden(name):
+def test_sac_updates_vs_golden(name, splitk):
     g, cfg, ocfg, store, index = sac_setup(name)
     eng = _engine(cfg, g)
+    eng.sac_set_plan(splitk)
     a0, _ = eng.sac_get_params(0)
     c0, _ = eng.sac_get_params(1)
     assert np.array_equal(a0, g["theta_actor0"]) and np.array_equal(c0, g["theta_critics0"])

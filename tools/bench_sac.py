@@ -35,6 +35,8 @@ def main():
     eng = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=Do, act_dim=Da, hidden=H, n_critics=2, env_num=E,
                               buffer_size=a.rows, gamma=0.99, target_kl=None))
     eng.sac_init()
+    if os.environ.get("FSRL_SAC_SPLITK"):      # A/B: split-K weight gradients at every batch size (fsrl_sac_set_plan)
+        eng.sac_set_plan(1)
     cfg = SACConfig(obs_dim=Do, act_dim=Da, hidden=(H, H))
     o = SACLagOracle(cfg)
     torch.manual_seed(0)
