@@ -1310,16 +1310,29 @@ __global__ __launch_bounds__(256) void cg_init_kernel(const float* __restrict__ 
 }
 
 // z = H p + damping p (in place in hz) ; partial p.z
+// parts != null: H p arrives as the split-K partials of fb_wgrad_kernel and is summed here exactly as fb_sum_parts_kernel would
+// (float64, z ascending, rounded once): one launch less per conjugate-gradient iteration
 __global__ __launch_bounds__(256) void cg_pz_kernel(float* __restrict__ hz, const float* __restrict__ p,
                                                    const CgScal* __restrict__ sc, double* __restrict__ part, int n,
-                                                   float damping) {
+                                                   float damping, const float* __restrict__ parts = nullptr, int nparts = 0,
+                                                   int stride = 0) {
     __shared__ double sh[4];
     const int tid = threadIdx.x;
     if (sc->done) return;
     double acc = 0.0;
     for (int i4 = (blockIdx.x * 256 + tid) * 4; i4 < n; i4 += CG_NB * 1024) {
         const f32x4 pi = *reinterpret_cast<const f32x4*>(p + i4);
-        f32x4 z = *reinterpret_cast<const f32x4*>(hz + i4);
+        f32x4 z;
+        if (parts) {
+            const f32x4 z0 = *reinterpret_cast<const f32x4*>(parts + i4);
+            double a0 = (double)z0[0], a1 = (double)z0[1], a2 = (double)z0[2], a3 = (double)z0[3];
+            for (int k = 1; k < nparts; ++k) {
+                const f32x4 zk = *reinterpret_cast<const f32x4*>(parts + (size_t)k * stride + i4);
+                a0 += (double)zk[0]; a1 += (double)zk[1]; a2 += (double)zk[2]; a3 += (double)zk[3];
+            }
+            z = f32x4{(float)a0, (float)a1, (float)a2, (float)a3};
+        } else
+            z = *reinterpret_cast<const f32x4*>(hz + i4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) z[e] = z[e] + pi[e] * damping;
         *reinterpret_cast<f32x4*>(hz + i4) = z;
