@@ -18,7 +18,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VAL
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_pmc_mfma_trust -- env FSRL_NO_CPU=1 python $R/tools/bench_trust.py > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_pmc_mfma_sac -- python $R/tools/bench_sac.py --rows 200000 --updates 200 --no-cpu > /dev/null 2>&1
 # HBM-side traffic of the full-batch and replay updates: FETCH_SIZE / WRITE_SIZE in their own passes,
-# one algorithm per run (bench_trust.py runs 1 warm-up + 3 timed updates; bench_sac.py 20 + 200)
+# one algorithm per run (bench_trust.py runs 1 warm-up + 5 timed updates; bench_sac.py 20 + 200)
 for ALG in cpo trpo; do
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/${TAG}_pmc_${C}_${ALG} -- env FSRL_NO_CPU=1 FSRL_ONLY=$ALG python $R/tools/bench_trust.py > /dev/null 2>&1

@@ -68,9 +68,9 @@ if out:
     print(json.dumps({k: round(v["hbm_bytes_per_launch"]) for k, v in out.items()}, indent=1))
 
 # ---- HBM-side bytes per UPDATE of the full-batch / replay paths: every kernel's FETCH_SIZE x 2 + WRITE_SIZE summed over
-#      the run, divided by the updates the traced command made (bench_trust.py: 1 warm-up + 3 timed; bench_sac.py: 20 + 200)
+#      the run, divided by the updates the traced command made (bench_trust.py: 1 warm-up + 5 timed; bench_sac.py: 20 + 200)
 upd = {}
-for alg, n_upd in (("cpo", 4), ("trpo", 4), ("sac", 220)):
+for alg, n_upd in (("cpo", 6), ("trpo", 6), ("sac", 220)):
     by = defaultdict(lambda: {"launches": 0, "fetch_kib": 0.0, "write_kib": 0.0})
     ok = False
     for cname, key in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib")):
