@@ -41,6 +41,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_pr
 cd $R
 timeout 600 python tools/bench_trust.py > $O/${TAG}_bench_trust.json 2>/dev/null
 timeout 300 python tools/learning_curves.py > $O/${TAG}_learning_curves.json 2>/dev/null
+timeout 300 python tools/learning_curves.py --task point-circle --agents ppol,cpo,sacl --epochs 25 > $O/${TAG}_learning_curves_pointcircle.json 2>/dev/null
 timeout 300 python tools/bench_shmem.py > $O/${TAG}_bench_shmem.json 2>/dev/null
 # microbenchmarks the DESIGN notes quote: device-wide barrier flavours, workgroup dispatch rate (prebuilt: tools/ubench/*.bin)
 [ -x tools/ubench/gridsync.bin ] && { timeout 60 tools/ubench/gridsync.bin 217; timeout 60 tools/ubench/gridsync.bin 256; } > $O/${TAG}_ubench_gridsync.txt 2>&1

@@ -21,6 +21,10 @@ def main():
     ap.add_argument("--epochs", type=int, default=20)
     ap.add_argument("--agents", default="ppol,focops,cpo,trpol,sacl,ddpgl,cvpo")
     ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--task", choices=["synthetic", "point-circle"], default="synthetic",
+                    help="point-circle: per-instance gym-style envs (fsrl_amd.env.PointCircleEnv) built from factories and stepped in "
+                         "worker processes, hidden_sizes (100, 50): the env-factory path and the zero-padded widths end to end")
+    ap.add_argument("--cost-limit", type=float, default=20.0)
     a = ap.parse_args()
     from fsrl_amd.agent import CPOAgent, CVPOAgent, DDPGLagAgent, FOCOPSAgent, PPOLagAgent, SACLagAgent, TRPOLagAgent
     from fsrl_amd.env import SyntheticSafetyVectorEnv
@@ -33,10 +37,18 @@ def main():
              "ddpgl": (DDPGLagAgent, dict(buffer_size=50000), off), "cvpo": (CVPOAgent, dict(buffer_size=50000), off)}
     for name in a.agents.split(","):
         cls, akw, lkw = table[name]
-        env = SyntheticSafetyVectorEnv(env_num=10, episode_len=100, seed=0)
-        test = SyntheticSafetyVectorEnv(env_num=4, episode_len=100, seed=5)
-        agent = cls(env, BaseLogger(tempfile.mkdtemp(), name=name), cost_limit=20, device="cuda:0", seed=1,
-                    hidden_sizes=(a.hidden, a.hidden), training_num=10, **akw)
+        if a.task == "point-circle":
+            from fsrl_amd.env import DummyVectorEnv, PointCircleEnv, ShmemVectorEnv
+            fns = [lambda: PointCircleEnv(max_episode_steps=100) for _ in range(10)]
+            env = ShmemVectorEnv(fns, workers=5, seed=0)
+            test = DummyVectorEnv(fns[:4], seed=500)
+            hidden = (100, 50)
+        else:
+            env = SyntheticSafetyVectorEnv(env_num=10, episode_len=100, seed=0)
+            test = SyntheticSafetyVectorEnv(env_num=4, episode_len=100, seed=5)
+            hidden = (a.hidden, a.hidden)
+        agent = cls(env, BaseLogger(tempfile.mkdtemp(), name=name), cost_limit=a.cost_limit, device="cuda:0", seed=1,
+                    hidden_sizes=hidden, training_num=10, **akw)
         before = agent.evaluate(test, eval_episodes=8)
         curve, t0, steps = [], time.time(), 0
         for ep in range(a.epochs):          # one epoch per learn() call: the statistics of that epoch come back
@@ -48,12 +60,13 @@ def main():
                           round(float(stat.get("loss/lagrangian", stat.get("loss/optim_nu", stat.get("loss/nu_value", 0.0)))), 4)])
         wall = time.time() - t0
         after = agent.evaluate(test, eval_episodes=8)
-        print(json.dumps({"agent": name, "hidden": a.hidden, "epochs": a.epochs, "cost_limit": 20,
+        print(json.dumps({"agent": name, "task": a.task, "hidden": list(hidden), "epochs": a.epochs, "cost_limit": a.cost_limit,
                           "eval_before_reward_len_cost": [round(float(x), 2) for x in before],
                           "eval_after_reward_len_cost": [round(float(x), 2) for x in after],
                           "curve_train_reward_cost_multiplier": curve, "wall_s": round(wall, 3),
                           "env_steps_per_s_incl_updates": round(steps / wall)}), flush=True)
         agent.policy.engine.close()
+        env.close()
 
 
 if __name__ == "__main__":
