@@ -251,15 +251,20 @@ static int ensure_parts(fsrl_ctx* c, int stride, int nsplit) {
 template <bool PAIR2>
 static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int ny, int stride, int* nsplit) {
     const int H_ = c->cfg.hidden;
-    const WgradPlan pl = wgrad_plan(wa.rows, ((H_ / 64) * (H_ / 64) + H_ / 32 + 1) * ny, c->n_cus);
+    // blocks of one split and network: 64x64 dW2 tiles + one block per (64-column group, pass over the rows) + the db3 block.
+    // Passes: the first carries NCH0 16-column chunks of dW1 (+ dW3, db1, db2), every further one four chunks.
+    const int nch0 = PAIR2 ? 1 : 2;
+    const int passes = 1 + std::max(0, (md.Do - 16 * nch0 + 63) / 64);
+    const int NB = (H_ / 64) * (H_ / 64) + (H_ / FB_AUX_COLS) * passes + 1;
+    const WgradPlan pl = wgrad_plan(wa.rows, NB * ny, c->n_cus);
     int rc = ensure_parts(c, stride, pl.nsplit);
     if (rc) return rc;
     wa.out = c->wg_parts; wa.ks_per_split = pl.ks_per_split; wa.split_stride = stride;
     wa.dbg_skip = c->probe_wgrad_skip;
+    wa.aux_passes = passes;
     *nsplit = pl.nsplit;
     return dispatch_H(c->cfg.hidden, [&](auto hc) {
         constexpr int HH = decltype(hc)::value;
-        constexpr int NB = (HH / 64) * (HH / 64) + HH / 32 + 1;   // 64x64 dW2 tiles + 32-column aux blocks + db3 block
         if (c->wgrad_xcd) {
             wa.remap_total = NB * ny * pl.nsplit; wa.remap_ny = ny;
             hipLaunchKernelGGL((fb_wgrad_kernel<HH, PAIR2>), dim3(round_up(wa.remap_total, 8)), dim3(1024), 0, c->compute, md, wa);

@@ -949,138 +949,150 @@ struct FbWgradArgs {
     // (observed placement, used for speed only), so logical block (L % 8) * (grid / 8) + L / 8 puts CONSECUTIVE logical
     // blocks -- the blocks of one split, which stream the same rows -- behind one L2.
     int remap_total, remap_ny;
+    int aux_passes;     // passes over the rows an aux column block needs (1 + the dW1 chunks beyond the first pass): one BLOCK per pass
 };
 
 // one pass of an aux block of fb_wgrad_kernel over its rows: NCH 16-column chunks of dW1 (columns k0 ..), and with FIRST the
-// dW3 / db1 / db2 outputs of the block's 32 hidden columns.  Accumulation order per output = row order: the result does not
-// depend on NCH.
+// dW3 / db1 / db2 outputs of the block's FB_AUX_COLS hidden columns.  Accumulation order per output = row order: the result
+// does not depend on NCH.
+//
+// 64 hidden columns per aux block (round 3, late; 32 before).  The role is bound by its load REQUESTS, not by bytes in flight
+// or MFMA time (probe build, CPO at N = 20 000: the aux blocks alone took 93 of the critic steps' 98 us and 68 of the R-op
+// product's 82 us while doing 1/16 of the FLOPs; 1, 2 or 4 k-steps of loads in flight made no difference): a lane now loads
+// one float4 per operand and k-step instead of a float2, the observation columns a block reads serve twice the outputs, the
+// db1 sums reuse the dW1 operand (the same array in every caller: b1_src == w1_y), and a split has 21 blocks instead of 25, so
+// the same chip takes more splits with fewer rows each.
+#define FB_AUX_COLS 64
+#define FB_AUX_SLOT (FB_AUX_COLS * 34)       // [CW x 16 dW1 chunk][CW x 16 dW3^T][CW db1][CW db2] floats per partial slot
 template <int H, bool PAIR2, bool FIRST, int NCH>
 __device__ __forceinline__ void wgrad_aux_pass(const FbWgradArgs& wa, const FbWgradNet& wn, const NetOff& no, float* red,
                                                float* __restrict__ gout, const int j0, const int k0, const int KS0,
                                                const int KS, const int Do, const int out, const int tid) {
-    constexpr int AUXU = 4;                      // k-steps per load burst (A/B: 1, 2 and 4 equal within noise, 8 slower)
+    constexpr int AUXU = 2;                      // k-steps per load burst
+    constexpr int CW = FB_AUX_COLS, T = CW / 16; // T = 4 columns per lane: lane (c, q) holds columns j0 + 4c .. + 3 of row q
+    constexpr int SL = FB_AUX_SLOT;
     const int lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
-    {
-        {
-            constexpr bool first = FIRST;
-            f32x4 ax[NCH][2];
+    constexpr bool first = FIRST;
+    f32x4 ax[NCH][T];
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) ax[ch][0] = ax[ch][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 ad0 = {0, 0, 0, 0}, ad1 = {0, 0, 0, 0};
-            f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
-            for (int sb = KS0 + wave; sb < KS; sb += 16 * AUXU) {
-                f32x2 y1[AUXU], xa3[AUXU], xb3[AUXU], b1v[AUXU], b2v[AUXU];
-                float bx[AUXU][NCH], bda[AUXU], bdb[AUXU];
+    for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-                for (int u = 0; u < AUXU; ++u) {
-                    const int s = sb + 16 * u;
-                    y1[u] = xa3[u] = xb3[u] = b1v[u] = b2v[u] = f32x2{0.f, 0.f};
-                    bda[u] = bdb[u] = 0.f;
+        for (int t = 0; t < T; ++t) ax[ch][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 ad[T];
 #pragma unroll
-                    for (int ch = 0; ch < NCH; ++ch) bx[u][ch] = 0.f;
-                    if (s < KS) {
-                        const size_t r = (size_t)(4 * s + q);
-                        y1[u] = *reinterpret_cast<const f32x2*>(wn.w1_y + r * H + j0 + 2 * c);
+    for (int t = 0; t < T; ++t) ad[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    for (int sb = KS0 + wave; sb < KS; sb += 16 * AUXU) {
+        f32x4 y1[AUXU], xa3[AUXU], xb3[AUXU], b2v[AUXU];
+        float bx[AUXU][NCH], bda[AUXU], bdb[AUXU];
 #pragma unroll
-                        for (int ch = 0; ch < NCH; ++ch)
-                            if (k0 + 16 * ch + c < Do && r < (size_t)wa.N) bx[u][ch] = wa.obs[r * Do + k0 + 16 * ch + c];
-                        if (first) {
-                            xa3[u] = *reinterpret_cast<const f32x2*>(wn.w3_xa + r * H + j0 + 2 * c);
-                            bda[u] = wn.w3_ya[r * FSRL_DOW + c];
-                            if constexpr (PAIR2) {
-                                xb3[u] = *reinterpret_cast<const f32x2*>(wn.w3_xb + r * H + j0 + 2 * c);
-                                bdb[u] = wn.w3_yb[r * FSRL_DOW + c];
-                            }
-                            b1v[u] = *reinterpret_cast<const f32x2*>(wn.b1_src + r * H + j0 + 2 * c);
-                            b2v[u] = *reinterpret_cast<const f32x2*>(wn.b2_src + r * H + j0 + 2 * c);
-                        }
+        for (int u = 0; u < AUXU; ++u) {
+            const int s = sb + 16 * u;
+            y1[u] = xa3[u] = xb3[u] = b2v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bda[u] = bdb[u] = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) bx[u][ch] = 0.f;
+            if (s < KS) {
+                const size_t r = (size_t)(4 * s + q);
+                y1[u] = *reinterpret_cast<const f32x4*>(wn.w1_y + r * H + j0 + T * c);
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch)
+                    if (k0 + 16 * ch + c < Do && r < (size_t)wa.N) bx[u][ch] = wa.obs[r * Do + k0 + 16 * ch + c];
+                if (first) {
+                    xa3[u] = *reinterpret_cast<const f32x4*>(wn.w3_xa + r * H + j0 + T * c);
+                    bda[u] = wn.w3_ya[r * FSRL_DOW + c];
+                    if constexpr (PAIR2) {
+                        xb3[u] = *reinterpret_cast<const f32x4*>(wn.w3_xb + r * H + j0 + T * c);
+                        bdb[u] = wn.w3_yb[r * FSRL_DOW + c];
                     }
+                    b2v[u] = *reinterpret_cast<const f32x4*>(wn.b2_src + r * H + j0 + T * c);
                 }
+            }
+        }
 #pragma unroll
-                for (int u = 0; u < AUXU; ++u) {
+        for (int u = 0; u < AUXU; ++u) {
 #pragma unroll
-                    for (int ch = 0; ch < NCH; ++ch) {
-                        if (k0 + 16 * ch < Do) {           // block-uniform: chunks past Do cost nothing
-                            ax[ch][0] = mfma_16x16x4(y1[u][0], bx[u][ch], ax[ch][0]);
-                            ax[ch][1] = mfma_16x16x4(y1[u][1], bx[u][ch], ax[ch][1]);
-                        }
-                    }
-                    if (first) {
-                        ad0 = mfma_16x16x4(xa3[u][0], bda[u], ad0);
-                        ad1 = mfma_16x16x4(xa3[u][1], bda[u], ad1);
-                        if constexpr (PAIR2) {
-                            ad0 = mfma_16x16x4(xb3[u][0], bdb[u], ad0);
-                            ad1 = mfma_16x16x4(xb3[u][1], bdb[u], ad1);
-                        }
-                        s1 += b1v[u];
-                        s2 += b2v[u];
-                    }
+            for (int ch = 0; ch < NCH; ++ch) {
+                if (k0 + 16 * ch < Do) {           // block-uniform: chunks past Do cost nothing
+#pragma unroll
+                    for (int t = 0; t < T; ++t) ax[ch][t] = mfma_16x16x4(y1[u][t], bx[u][ch], ax[ch][t]);
                 }
             }
             if (first) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    s1[t] += __shfl_xor(s1[t], 16, 64); s1[t] += __shfl_xor(s1[t], 32, 64);
-                    s2[t] += __shfl_xor(s2[t], 16, 64); s2[t] += __shfl_xor(s2[t], 32, 64);
+                for (int t = 0; t < T; ++t) {
+                    ad[t] = mfma_16x16x4(xa3[u][t], bda[u], ad[t]);
+                    if constexpr (PAIR2) ad[t] = mfma_16x16x4(xb3[u][t], bdb[u], ad[t]);
                 }
+                s1 += y1[u];                       // db1: column sums of the dW1 operand itself (b1_src == w1_y)
+                s2 += b2v[u];
             }
-            float* slot = red + (wave & 7) * 1088;
+        }
+    }
+    if (first) {
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                if (k0 + 16 * ch >= Do) continue;             // block-uniform
-                const bool f0 = first && ch == 0;           // dW3 and the bias sums ride with the first chunk
-                const f32x4 ax0 = ax[ch][0], ax1 = ax[ch][1];
-                __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            s1[t] += __shfl_xor(s1[t], 16, 64); s1[t] += __shfl_xor(s1[t], 32, 64);
+            s2[t] += __shfl_xor(s2[t], 16, 64); s2[t] += __shfl_xor(s2[t], 32, 64);
+        }
+    }
+    // acc register r of MFMA tile t in lane (c, q) is output (j = j0 + T (4 q + r) + t, k = chunk column c).  Eight partial slots,
+    // two rounds: waves 0-7 store, waves 8-15 add into the same slot; the final sum walks the slots in order.
+    float* slot = red + (wave & 7) * SL;
 #pragma unroll
-                for (int round = 0; round < 2; ++round) {
-                    if ((wave >> 3) == round) {
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (k0 + 16 * ch >= Do) continue;             // block-uniform
+        const bool f0 = first && ch == 0;           // dW3 and the bias sums ride with the first chunk
+        __syncthreads();
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int jl = 2 * (4 * q + r);
-                            if (round == 0) {
-                                slot[(jl + 0) * 16 + c] = ax0[r]; slot[(jl + 1) * 16 + c] = ax1[r];
-                                if (f0) { slot[512 + (jl + 0) * 16 + c] = ad0[r]; slot[512 + (jl + 1) * 16 + c] = ad1[r]; }
-                            } else {
-                                slot[(jl + 0) * 16 + c] += ax0[r]; slot[(jl + 1) * 16 + c] += ax1[r];
-                                if (f0) { slot[512 + (jl + 0) * 16 + c] += ad0[r]; slot[512 + (jl + 1) * 16 + c] += ad1[r]; }
-                            }
-                        }
-                        if (f0 && q == 0) {
-                            if (round == 0) {
-                                slot[1024 + 2 * c] = s1[0]; slot[1024 + 2 * c + 1] = s1[1];
-                                slot[1056 + 2 * c] = s2[0]; slot[1056 + 2 * c + 1] = s2[1];
-                            } else {
-                                slot[1024 + 2 * c] += s1[0]; slot[1024 + 2 * c + 1] += s1[1];
-                                slot[1056 + 2 * c] += s2[0]; slot[1056 + 2 * c + 1] += s2[1];
-                            }
+        for (int round = 0; round < 2; ++round) {
+            if ((wave >> 3) == round) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jl = T * (4 * q + r);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        if (round == 0) {
+                            slot[(jl + t) * 16 + c] = ax[ch][t][r];
+                            if (f0) slot[CW * 16 + (jl + t) * 16 + c] = ad[t][r];
+                        } else {
+                            slot[(jl + t) * 16 + c] += ax[ch][t][r];
+                            if (f0) slot[CW * 16 + (jl + t) * 16 + c] += ad[t][r];
                         }
                     }
-                    __syncthreads();
                 }
-                const int e = tid & 511;
-                float v = 0.0f;
-                const int off = (tid < 512) ? e : 512 + e;
-                if (tid < 512 || f0) {
+                if (f0 && q == 0) {
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) v += red[w * 1088 + off];
-                }
-                const int jl = e >> 4, kk = e & 15;
-                const int kc0 = k0 + 16 * ch;
-                if (tid < 512) {
-                    if (kc0 + kk < Do) gout[no.W1 + (size_t)(j0 + jl) * Do + kc0 + kk] = v;
-                } else if (f0 && kk < out) {
-                    gout[no.W3 + (size_t)kk * H + j0 + jl] = v;
-                }
-                if (f0 && tid < 64) {
-                    float bsum = 0.0f;
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) bsum += red[w * 1088 + 1024 + tid];
-                    if (tid < 32) gout[no.b1 + j0 + tid] = bsum;
-                    else gout[no.b2 + j0 + tid - 32] = bsum;
+                    for (int t = 0; t < T; ++t) {
+                        if (round == 0) { slot[2 * CW * 16 + T * c + t] = s1[t]; slot[2 * CW * 16 + CW + T * c + t] = s2[t]; }
+                        else { slot[2 * CW * 16 + T * c + t] += s1[t]; slot[2 * CW * 16 + CW + T * c + t] += s2[t]; }
+                    }
                 }
             }
             __syncthreads();
         }
+        const int kc0 = k0 + 16 * ch;
+        {
+            const int jl = tid >> 4, kk = tid & 15;          // 1024 threads = CW x 16 outputs of the dW1 chunk
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[w * SL + tid];
+            if (kc0 + kk < Do) gout[no.W1 + (size_t)(j0 + jl) * Do + kc0 + kk] = v;
+            if (f0) {
+                float v3 = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v3 += red[w * SL + CW * 16 + tid];
+                if (kk < out) gout[no.W3 + (size_t)kk * H + j0 + jl] = v3;
+                if (tid < 2 * CW) {
+                    float bsum = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) bsum += red[w * SL + 2 * CW * 16 + tid];
+                    if (tid < CW) gout[no.b1 + j0 + tid] = bsum;
+                    else gout[no.b2 + j0 + tid - CW] = bsum;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1092,17 +1104,17 @@ template <int H, bool PAIR2>
 __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, const FbWgradArgs wa) {
     constexpr int TPD = H / 64;             // dW2 tiles of 64 x 64 outputs
     constexpr int NT2 = TPD * TPD;
-    constexpr int NA = H / 32;
+    constexpr int NA = H / FB_AUX_COLS;
     constexpr int BU = 1;                   // k-steps per load burst (A/B at N = 20 000: 1 -> CPO 37.9 ms, 2 -> 38.6, 3 -> 39.6, 4 -> 41.5)
     constexpr int SLOT = 64 * 65;           // one 64 x 64 partial tile (+1 column of padding)
-    __shared__ float red[4 * SLOT];
+    __shared__ float red[(4 * SLOT > 8 * FB_AUX_SLOT) ? 4 * SLOT : 8 * FB_AUX_SLOT];     // tile role: 4 partial tiles; aux role: 8 partial slots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int rb = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (wa.remap_total) {
         const int L = blockIdx.x, per = gridDim.x >> 3;
         const int Lp = (L & 7) * per + (L >> 3);
         if (Lp >= wa.remap_total) return;
-        constexpr int NB = (H / 64) * (H / 64) + H / 32 + 1;
+        const int NB = NT2 + NA * wa.aux_passes + 1;
         rb = Lp % NB;
         const int g = Lp / NB;
         by = g % wa.remap_ny; bz = g / wa.remap_ny;
@@ -1116,8 +1128,8 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
     const int Do = md.Do, out = no.out;
 
 #ifdef FSRL_PROBES
-    if (wa.dbg_skip && ((rb < NT2 && (wa.dbg_skip & 1)) || (rb >= NT2 && rb < NT2 + NA && (wa.dbg_skip & 2)) ||
-                        (rb >= NT2 + NA && (wa.dbg_skip & 4)))) return;
+    if (wa.dbg_skip && ((rb < NT2 && (wa.dbg_skip & 1)) || (rb >= NT2 && rb < NT2 + NA * wa.aux_passes && (wa.dbg_skip & 2)) ||
+                        (rb >= NT2 + NA * wa.aux_passes && (wa.dbg_skip & 4)))) return;
 #endif
     if (rb < NT2) {
         // ---- dW2[j][k] += sum_r Ya[r][j] Xa[r][k] (+ Yb Xb): a 64 x 64 tile per block, 16-way split-K over
@@ -1187,17 +1199,18 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
             const float v = (red[jl * 65 + kl] + red[SLOT + jl * 65 + kl]) + (red[2 * SLOT + jl * 65 + kl] + red[3 * SLOT + jl * 65 + kl]);
             gout[no.W2 + (size_t)(tj * 64 + jl) * H + tk * 64 + kl] = v;
         }
-    } else if (rb < NT2 + NA) {
+    } else if (rb < NT2 + NA * wa.aux_passes) {
         // dW1 is [H][Do]: the obs columns go through the MFMA 16 at a time, several 16-column chunks per pass over the rows (one
-        // read of the dz1 column block serves them all).  With a pass per chunk the aux block of a Do = 60 network walked its
-        // rows four times and took as long as a dW2 tile block while doing 1/16 of its FLOPs (probe build, CPO at N = 20 000:
-        // the 184 aux blocks alone 49 us, the 368 tile blocks alone 85 us, together 121 us on 256 CUs).  The first pass also
-        // carries dW3 and the bias sums (more operands in flight), so it takes two chunks (one in the R-op instantiation), the later ones four.
-        const int j0 = (rb - NT2) * 32;
+        // read of the dz1 column block serves them all).  The first pass also carries dW3 and the bias sums (more operands in
+        // flight), so it takes two chunks (one in the R-op instantiation), the later ones four.  Every pass of a column block is
+        // its own workgroup (grid.x = NT2 + NA * passes + 1): with one workgroup walking its rows once per pass, the aux blocks
+        // of a Do = 60 network were the critical path of the launch (probe build, CPO critic steps at N = 20 000: aux blocks
+        // alone 93 us, tile blocks alone 69 us, together 98 us).
+        const int ai = rb - NT2;
+        const int j0 = (ai % NA) * FB_AUX_COLS, pass = ai / NA;
         constexpr int NCH0 = PAIR2 ? 1 : 2;          // the R-op instantiation has two more operands in flight in its first pass
-        wgrad_aux_pass<H, PAIR2, true, NCH0>(wa, wn, no, red, gout, j0, 0, KS0, KS, Do, out, tid);
-        for (int k0 = 16 * NCH0; k0 < Do; k0 += 64)
-            wgrad_aux_pass<H, PAIR2, false, 4>(wa, wn, no, red, gout, j0, k0, KS0, KS, Do, out, tid);
+        if (pass == 0) wgrad_aux_pass<H, PAIR2, true, NCH0>(wa, wn, no, red, gout, j0, 0, KS0, KS, Do, out, tid);
+        else wgrad_aux_pass<H, PAIR2, false, 4>(wa, wn, no, red, gout, j0, 16 * NCH0 + 64 * (pass - 1), KS0, KS, Do, out, tid);
     } else {
         // db3[o] / dsigma[d]: column sums of the dout-like buffer over all rows
         const int col = tid & 31, php = tid >> 5;
