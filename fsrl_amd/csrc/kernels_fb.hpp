@@ -981,7 +981,10 @@ __device__ __forceinline__ void wgrad_aux_pass(const FbWgradArgs& wa, const FbWg
     f32x4 ad[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) ad[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f};
+    // a head with ONE output (every critic / Q-net): dW3 = A2^T dout is a matrix-vector product -- four FMAs per lane and
+    // k-step instead of four 16-wide MFMAs that would carry one useful column (a third of this pass's matrix-pipe time)
+    const bool vec3 = first && !PAIR2 && out == 1;
     for (int sb = KS0 + wave; sb < KS; sb += 16 * AUXU) {
         f32x4 y1[AUXU], xa3[AUXU], xb3[AUXU], b2v[AUXU];
         float bx[AUXU][NCH], bda[AUXU], bdb[AUXU];
@@ -1000,7 +1003,7 @@ __device__ __forceinline__ void wgrad_aux_pass(const FbWgradArgs& wa, const FbWg
                     if (k0 + 16 * ch + c < Do && r < (size_t)wa.N) bx[u][ch] = wa.obs[r * Do + k0 + 16 * ch + c];
                 if (first) {
                     xa3[u] = *reinterpret_cast<const f32x4*>(wn.w3_xa + r * H + j0 + T * c);
-                    bda[u] = wn.w3_ya[r * FSRL_DOW + c];
+                    bda[u] = wn.w3_ya[r * FSRL_DOW + (vec3 ? 0 : c)];
                     if constexpr (PAIR2) {
                         xb3[u] = *reinterpret_cast<const f32x4*>(wn.w3_xb + r * H + j0 + T * c);
                         bdb[u] = wn.w3_yb[r * FSRL_DOW + c];
@@ -1019,10 +1022,15 @@ __device__ __forceinline__ void wgrad_aux_pass(const FbWgradArgs& wa, const FbWg
                 }
             }
             if (first) {
+                if (vec3) {
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    ad[t] = mfma_16x16x4(xa3[u][t], bda[u], ad[t]);
-                    if constexpr (PAIR2) ad[t] = mfma_16x16x4(xb3[u][t], bdb[u], ad[t]);
+                    for (int t = 0; t < T; ++t) s3[t] = fmaf(xa3[u][t], bda[u], s3[t]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        ad[t] = mfma_16x16x4(xa3[u][t], bda[u], ad[t]);
+                        if constexpr (PAIR2) ad[t] = mfma_16x16x4(xb3[u][t], bdb[u], ad[t]);
+                    }
                 }
                 s1 += y1[u];                       // db1: column sums of the dW1 operand itself (b1_src == w1_y)
                 s2 += b2v[u];
@@ -1034,6 +1042,7 @@ __device__ __forceinline__ void wgrad_aux_pass(const FbWgradArgs& wa, const FbWg
         for (int t = 0; t < T; ++t) {
             s1[t] += __shfl_xor(s1[t], 16, 64); s1[t] += __shfl_xor(s1[t], 32, 64);
             s2[t] += __shfl_xor(s2[t], 16, 64); s2[t] += __shfl_xor(s2[t], 32, 64);
+            s3[t] += __shfl_xor(s3[t], 16, 64); s3[t] += __shfl_xor(s3[t], 32, 64);
         }
     }
     // acc register r of MFMA tile t in lane (c, q) is output (j = j0 + T (4 q + r) + t, k = chunk column c).  Eight partial slots,
@@ -1054,10 +1063,10 @@ __device__ __forceinline__ void wgrad_aux_pass(const FbWgradArgs& wa, const FbWg
                     for (int t = 0; t < T; ++t) {
                         if (round == 0) {
                             slot[(jl + t) * 16 + c] = ax[ch][t][r];
-                            if (f0) slot[CW * 16 + (jl + t) * 16 + c] = ad[t][r];
+                            if (f0 && !vec3) slot[CW * 16 + (jl + t) * 16 + c] = ad[t][r];
                         } else {
                             slot[(jl + t) * 16 + c] += ax[ch][t][r];
-                            if (f0) slot[CW * 16 + (jl + t) * 16 + c] += ad[t][r];
+                            if (f0 && !vec3) slot[CW * 16 + (jl + t) * 16 + c] += ad[t][r];
                         }
                     }
                 }
@@ -1066,6 +1075,10 @@ __device__ __forceinline__ void wgrad_aux_pass(const FbWgradArgs& wa, const FbWg
                     for (int t = 0; t < T; ++t) {
                         if (round == 0) { slot[2 * CW * 16 + T * c + t] = s1[t]; slot[2 * CW * 16 + CW + T * c + t] = s2[t]; }
                         else { slot[2 * CW * 16 + T * c + t] += s1[t]; slot[2 * CW * 16 + CW + T * c + t] += s2[t]; }
+                        if (vec3) {          // output column 0 of hidden column T c + t; the other 15 slots of the row are never read
+                            if (round == 0) slot[CW * 16 + (T * c + t) * 16] = s3[t];
+                            else slot[CW * 16 + (T * c + t) * 16] += s3[t];
+                        }
                     }
                 }
             }
