@@ -265,6 +265,11 @@ if __name__ == "__main__":
         gen_trpo("widths", 8, 2, (48, 80), 3, eps, repeat=2, seed=34, cost_stat=25.0, cost_limit=10.0,
                  optim_critic_iters=3)
         sys.exit(0)
+    if sys.argv[1:] == ["wideobs"]:
+        # 100 observation columns: the first layer's weight gradient takes three passes of the weight-side kernel's aux blocks
+        gen_cpo("wideobs", 100, 4, (64, 64), 3, eps, repeat=2, seed=36, cost_stat=25.0, cost_limit=10.0,
+                optim_critic_iters=3, max_backtracks=10)
+        sys.exit(0)
     if sys.argv[1:] == ["minibatch"]:
         # batch_size below the buffer: Batch.split(batch_size, merge_last=True) inside learn (cpo.py:357-358,
         # trpo_lag.py:178).  N = 560 rows, batch 150 -> minibatches of 150 / 150 / 260 (the remainder merged into the last)

@@ -1,6 +1,6 @@
 """Seeded random sweep of PPO-Lagrangian option combinations (the flags the fixtures cover one at a time: dual clip, no
 advantage normalisation, no Lagrangian, grad-norm clip on / off, unbounded head, reward_normalization, value_clip,
-recompute_advantage) x shapes (widths 64 / 128 / 256, ragged sub-buffers, merged last minibatch, 4-row and 16-row tiles)
+recompute_advantage) x shapes (widths 64 / 128 / 256 and, for the last seeds, two unrelated widths; ragged sub-buffers, merged last minibatch, 4-row and 16-row tiles)
 against the CPU oracle on the same inputs and permutations.  Tolerances as in test_gpu_shapes.py."""
 import numpy as np
 import pytest
@@ -27,19 +27,24 @@ def _case(seed):
                 vf_coef=float(r.choice([0.25, 1.0])), lr=float(r.choice([5e-4, 2e-3])))
 
 
-@pytest.mark.parametrize("seed", range(14))
+@pytest.mark.parametrize("seed", range(19))
 def test_random_option_combination_vs_oracle(seed):
     from fsrl_amd.engine import Engine, EngineConfig
     from oracle.ppo_lag import OnPolicyData, PPOLagConfig, PPOLagOracle
     c = _case(seed)
+    hidden = (c["H"], c["H"])
+    if seed >= 14:            # two hidden layers of unrelated widths (zero-padded to 64 / 128 / 256 on the device)
+        rw = np.random.default_rng(5000 + seed)
+        hidden = (int(rw.integers(5, 257)), int(rw.integers(5, 257))) if seed > 14 else (40, 24)      # seed 14: pads to 64
+        c["hidden"] = hidden
     rng = np.random.default_rng(seed)
     cols = _synthetic(rng, c["rows"], c["Do"], c["Da"], c["ep"])
-    eng = Engine(EngineConfig(obs_dim=c["Do"], act_dim=c["Da"], hidden=c["H"], env_num=len(c["rows"]), buffer_size=len(c["rows"]) * 512,
+    eng = Engine(EngineConfig(obs_dim=c["Do"], act_dim=c["Da"], hidden_sizes=hidden, env_num=len(c["rows"]), buffer_size=len(c["rows"]) * 512,
                               max_grad_norm=c["max_grad_norm"], target_kl=None, max_action=c["max_action"], dual_clip=c["dual_clip"],
                               norm_adv=c["norm_adv"], use_lagrangian=c["use_lagrangian"], unbounded=c["unbounded"],
                               rew_norm=c["rew_norm"], value_clip=c["value_clip"], recompute_adv=c["recompute"], eps_clip=c["eps_clip"],
                               vf_coef=c["vf_coef"], lr=c["lr"]))
-    o = PPOLagOracle(PPOLagConfig(obs_dim=c["Do"], act_dim=c["Da"], hidden=(c["H"], c["H"]), max_grad_norm=c["max_grad_norm"],
+    o = PPOLagOracle(PPOLagConfig(obs_dim=c["Do"], act_dim=c["Da"], hidden=hidden, max_grad_norm=c["max_grad_norm"],
                                   target_kl=1e9, max_action=c["max_action"], dual_clip=c["dual_clip"],
                                   advantage_normalization=c["norm_adv"], use_lagrangian=c["use_lagrangian"], unbounded=c["unbounded"],
                                   reward_normalization=c["rew_norm"], value_clip=c["value_clip"], recompute_advantage=c["recompute"],

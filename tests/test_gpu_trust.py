@@ -54,7 +54,8 @@ def _close(a, b, rel):
         (float(np.abs(np.asarray(a) - np.asarray(b)).max()), scale)
 
 
-@pytest.mark.parametrize("name,perturbed", [("infeasible", False), ("perturbed", True), ("options", False)])
+@pytest.mark.parametrize("name,perturbed", [("infeasible", False), ("perturbed", True), ("options", False), ("widths", False),
+                                            ("wideobs", False)])
 def test_gradients_and_hvp_vs_autograd(name, perturbed):
     from oracle.trust_region import CPOOracle
     from torch.distributions import Independent, Normal, kl_divergence
@@ -126,7 +127,7 @@ def _cpo_f64_yardstick(name):
     return _YARD[name]
 
 
-@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options", "widths"])
+@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options", "widths", "wideobs"])
 def test_cpo_learn_vs_golden(name):
     g = load_npz(f"cpo_{name}.npz")
     cfg = json.loads(str(g["cfg_json"]))

@@ -36,7 +36,7 @@ def trpo_cfg(cfg):
                       reward_normalization=bool(cfg.get("reward_normalization", False)))
 
 
-@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options", "minibatch", "widths"])
+@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options", "minibatch", "widths", "wideobs"])
 def test_cpo_update(name):
     torch.set_num_threads(4)
     g = load_npz(f"cpo_{name}.npz")
