@@ -1791,7 +1791,7 @@ __global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ P, 
                                                         int n_gsq = 0, float max_norm = 0.0f,
                                                         float* __restrict__ psq_part = nullptr,
                                                         float* __restrict__ tgt = nullptr, float tau = 0.0f,
-                                                        float one_minus_tau = 0.0f) {
+                                                        float one_minus_tau = 0.0f, int sum64 = 0) {
     __shared__ double shd[4];
     __shared__ float coef_s, shf[4];
     const int i = begin + blockIdx.x * 256 + threadIdx.x;
@@ -1811,6 +1811,11 @@ __global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ P, 
         const float p = P[i];
         psq = p * p;
         float gs = G[i];                                   // split-K partials of fb_wgrad_kernel, z order
+        if (sum64) {                                       // ... combined in float64 and rounded once, as fb_sum_parts_kernel does
+            double acc = (double)gs;
+            for (int z = 1; z < nparts; ++z) acc += (double)G[(size_t)z * stride + i];
+            gs = (float)acc;
+        } else
         for (int z = 1; z < nparts; ++z) gs += G[(size_t)z * stride + i];
         adam_element(P, M, V, i, p, gs, coef, l2, one_minus_b1, beta2, one_minus_b2, step_size, bc2_sqrt, eps, md, tgt, tau,
                      one_minus_tau);
