@@ -204,7 +204,8 @@ def end_to_end(local_rank, seed, seconds=6.0, device_actor=False, workers=0, bus
            "handshake": (("futex generation word + completion counter per lane (libfsrl_env.so), spin "
                           f"{getattr(env, 'spin_us', 0):g} us before sleeping") if workers > 0 else None),
            "split_phase": bool(col.split_phase),
-           "collector_loop": ("native (fsrl_collect_run: Python sees episode boundaries only)"
+           "collector_loop": (("native (fsrl_collect_episodes: one library call per collect)" if col.native_loop is True
+                               else "native (fsrl_collect_run: Python sees episode boundaries only)")
                               if (device_actor and col.native_loop and hasattr(env, "native_desc") and not col.split_phase)
                               else "interpreted, one library call per vector step" if device_actor else "interpreted, host actor"),
            "env_bound_env_steps_per_s": env_bound(envs, workers, busy_us, usable_cpus()),

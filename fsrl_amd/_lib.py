@@ -131,6 +131,8 @@ SIGNATURES = {
     "fsrl_actor_sample": (C.c_int, [_ctx, _f, C.c_int32, C.c_int32, C.c_uint64, _f]),
     "fsrl_collect_step": (C.c_int, [_ctx, _i32, C.c_int32, _f, _f, _d, _d, _u8, _u8, _f, _i64, _d, _i32, _i64,
                                     _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, _f, _f]),
+    "fsrl_collect_episodes": (C.c_int, [_ctx, _P(ShmEnv), _i32, C.c_int32, _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, _i64, _d, _i32,
+                                        _i32, _d, _i32, _i32]),
     "fsrl_collect_run": (C.c_int, [_ctx, _P(ShmEnv), _i32, C.c_int32, _f, _f, _f, C.c_int32, C.c_int32, _f, _f, C.c_int32, _i32, _d, _d, _d,
                                   _u8, _u8, _f]),
     "fsrl_store_sizes": (C.c_int, [_ctx, _i64, C.c_int32]),

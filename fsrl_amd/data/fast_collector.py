@@ -23,8 +23,10 @@ class FastCollector:
         self.device_actor = device_actor and getattr(policy, "engine", None) is not None
         # fused_step (device_actor only): one fsrl_collect_step per vector step instead of fsrl_actor_sample + fsrl_store_push
         self.fused_step = fused_step
-        # native_loop (device_actor + fused_step over the worker-process env): the vector steps in which no episode ends run
-        # inside the library (fsrl_collect_run: handshake with the env workers, store, actor); Python sees episode boundaries only
+        # native_loop (device_actor + fused_step over the worker-process env).  True: a collect(n_episode) is ONE library call
+        # (fsrl_collect_episodes: handshake with the env workers, store, actor, resets, episode accounting).  "run": the vector
+        # steps in which no episode ends run inside the library (fsrl_collect_run), Python sees the episode boundaries.  False:
+        # one fsrl_collect_step per vector step from Python.
         self.native_loop = native_loop
         # split_phase (device_actor + fused_step over an env with step_async / step_wait and two lanes: the worker-process env):
         # the envs are stepped in two halves, the actor for one half runs while the other half's workers step.  Rows of an
@@ -157,6 +159,21 @@ class FastCollector:
         step_count, total_cost, episode_count, term_count, trunc_count = 0, 0.0, 0, 0, 0
         ep_rews, ep_lens = [], []
         obs = np.asarray(obs, np.float32)
+        if self.native_loop is True and hasattr(self.env, "native_desc") and not gym_reset_kwargs:
+            # worker-process env: the WHOLE collect -- steps, store, actor, resets, episode accounting, surplus envs -- in one
+            # library call (fsrl_collect_episodes); native_loop="run" keeps the episode boundaries in this loop (fsrl_collect_run)
+            r = eng.collect_episodes(self.env.native_desc(), ready, obs, n_episode, det, bound, low, high)
+            self.env.sync_native()
+            self.buffer.sync_sizes()
+            self.collect_step += r["steps"]
+            self.collect_episode += len(r["ep_rews"])
+            self.collect_time += max(time.time() - t0, 1e-9)
+            self.reset_env()
+            done_count = r["terminated"] + r["truncated"]
+            return {"n/ep": len(r["ep_rews"]), "n/st": r["steps"], "rew": float(r["ep_rews"].mean()),
+                    "len": float(r["ep_lens"].mean()), "total_cost": r["total_cost"],
+                    "cost": r["total_cost"] / len(r["ep_rews"]), "truncated": r["truncated"] / done_count,
+                    "terminated": r["terminated"] / done_count}
         act, env_act, _, _ = eng.collect_step(None, obs, det, bound, low, high)
         clock = time.perf_counter
         t_env = t_act = 0.0

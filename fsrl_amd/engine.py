@@ -293,6 +293,26 @@ class Engine:
         return (st["steps"].value, st["csum"].value, a["obs"][:n].copy(), a["act"][:n].copy(), a["rew"][:n].copy(),
                 a["cost"][:n].copy(), a["term"][:n].astype(bool), a["trunc"][:n].astype(bool), a["nxt"][:n].copy())
 
+    def collect_episodes(self, env_desc, ready, obs, n_episode, deterministic=False, bound_method=1, low=None, high=None):
+        """FastCollector.collect(n_episode) over a worker-process env in ONE C call (fsrl_collect_episodes): vector steps, store,
+        actor, resets, episode accounting, surplus envs.  -> dict(steps, total_cost, terminated, truncated, ep_rews, ep_lens)"""
+        Do, Da = self.cfg.obs_dim, self.cfg.act_dim
+        n = len(ready)
+        ids = np.ascontiguousarray(ready, np.int32)
+        ob = np.ascontiguousarray(obs, np.float32).reshape(n, Do)
+        lo = np.ascontiguousarray(low, np.float32) if low is not None else None
+        hi = np.ascontiguousarray(high, np.float32) if low is not None else None
+        steps, cost = C.c_int64(), C.c_double()
+        nt, ntr, nep = C.c_int32(), C.c_int32(), C.c_int32()
+        ep_rew, ep_len = np.zeros(int(n_episode), np.float64), np.zeros(int(n_episode), np.int32)
+        _lib.check(self.lib.fsrl_collect_episodes(
+            self._ctx, C.byref(env_desc), _ptr(ids, _i32p), n, _ptr(ob, _f32p), int(n_episode), int(deterministic), int(bound_method),
+            _ptr(lo, _f32p) if lo is not None else None, _ptr(hi, _f32p) if hi is not None else None, C.byref(steps), C.byref(cost),
+            C.byref(nt), C.byref(ntr), _ptr(ep_rew, _f64p), _ptr(ep_len, _i32p), C.byref(nep)))
+        k = nep.value
+        return dict(steps=int(steps.value), total_cost=float(cost.value), terminated=int(nt.value), truncated=int(ntr.value),
+                    ep_rews=ep_rew[:k], ep_lens=ep_len[:k])
+
     def store_sizes(self, n=None):
         n = self.cfg.env_num if n is None else int(n)
         out = np.empty(n, np.int64)

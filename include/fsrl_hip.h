@@ -196,6 +196,17 @@ int fsrl_collect_run(fsrl_ctx* ctx, fsrl_shm_env* env, const int32_t* ready, int
                      float* env_act, int32_t deterministic, int32_t bound_method, const float* act_low,
                      const float* act_high, int32_t max_steps, int32_t* steps_out, double* cost_sum_out, double* rew_out,
                      double* cost_out, uint8_t* term_out, uint8_t* trunc_out, float* obs_next_out);
+/* replaces: FastCollector.collect(n_episode=...) as a whole over the worker-process env (fsrl/data/fast_collector.py:283-368): the
+ * loop of fsrl_collect_run PLUS the episode boundaries -- reset of the finished envs (a reset command to their workers), episode
+ * accounting, dropping of surplus envs (fast_collector.py:341-362).  ready / obs: the envs to start from and their current
+ * observations.  Outputs: env steps taken, the summed cost, terminated / truncated counts, and per finished episode its
+ * reward and length ([n_episode] each, in the order the loop met them); *episodes_out == n_episode on success.  The same
+ * fsrl_collect_step calls in the same order as the interpreted loop: same rows in the same slots, same noise stream. */
+int fsrl_collect_episodes(fsrl_ctx* ctx, fsrl_shm_env* env, const int32_t* ready, int32_t n, const float* obs, int32_t n_episode,
+                          int32_t deterministic, int32_t bound_method, const float* act_low, const float* act_high,
+                          int64_t* steps_out, double* total_cost_out, int32_t* term_count_out, int32_t* trunc_count_out,
+                          double* ep_rew_out, int32_t* ep_len_out, int32_t* episodes_out);
+
 /* Fill level of the first n sub-buffers (len(buffer.buffers[e]); ReplayBufferManager.sample_indices weighs by it). */
 int fsrl_store_sizes(const fsrl_ctx* ctx, int64_t* sizes_out, int32_t n);
 

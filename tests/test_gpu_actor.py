@@ -164,9 +164,10 @@ def test_split_phase_collect_stores_the_rows_of_the_plain_fused_loop():
 
 @pytest.mark.parametrize("workers", [1, 3, 6])
 def test_native_collector_loop_stores_the_rows_of_the_interpreted_loop(workers):
-    """fsrl_collect_run (the steps in which no episode ends run inside the library: handshake with the env workers, store,
-    actor) against the same loop driven step by step from Python: same library noise stream, same env seeds -> the same
-    rows in the same slots, the same statistics.  Exploration noise ON: the two paths must consume the stream identically."""
+    """fsrl_collect_episodes (a whole collect(n_episode) inside the library: handshake with the env workers, store, actor,
+    resets, episode accounting, surplus envs) and fsrl_collect_run (Python keeps the episode boundaries) against the same loop
+    driven step by step from Python: same library noise stream, same env seeds -> the same rows in the same slots, the same
+    statistics.  Exploration noise ON: the paths must consume the stream identically."""
     from fsrl_amd.agent import PPOLagAgent
     from fsrl_amd.data import FastCollector, HipVectorReplayBuffer
     from fsrl_amd.env import ShmemVectorEnv
@@ -188,11 +189,12 @@ def test_native_collector_loop_stores_the_rows_of_the_interpreted_loop(workers):
         finally:
             env.close()
 
-    st_n, idx_n, rows_n = run(True)
     st_p, idx_p, rows_p = run(False)
-    assert np.array_equal(idx_n, idx_p)
-    for a, b in zip(st_n, st_p):
-        assert a == b, (a, b)
-    for k in rows_p:
-        assert np.array_equal(rows_n[k], rows_p[k]), k
-    assert rows_n["act"].std() > 0.1                       # the noise was on
+    for mode in (True, "run"):
+        st_n, idx_n, rows_n = run(mode)
+        assert np.array_equal(idx_n, idx_p), mode
+        for a, b in zip(st_n, st_p):
+            assert a == b, (mode, a, b)
+        for k in rows_p:
+            assert np.array_equal(rows_n[k], rows_p[k]), (mode, k)
+    assert rows_p["act"].std() > 0.1                       # the noise was on
