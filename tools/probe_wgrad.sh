@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
 for SK in 0 1 2; do
   rm -rf /tmp/pw_$SK
-  FSRL_WGRAD_SKIP=$SK FSRL_HIP_LIB=$R/fsrl_amd/libfsrl_hip_probe.so FSRL_NO_CPU=1 FSRL_ONLY=cpo timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pw_$SK -- python $R/tools/bench_trust.py > /dev/null 2>&1
+  FSRL_WGRAD_SKIP=$SK FSRL_HIP_LIB=$R/fsrl_amd/libfsrl_hip_probe.so FSRL_NO_CPU=1 FSRL_ONLY=${ALG:-cpo} timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pw_$SK -- python $R/tools/bench_trust.py > /dev/null 2>&1
   f=$(ls /tmp/pw_$SK/*/*kernel_stats.csv 2>/dev/null | head -1)
   echo "skip=$SK"; python3 -c "
 import csv,sys
