@@ -107,6 +107,7 @@ SIGNATURES = {
     "fsrl_group_ppo_update": (C.c_int, [_ctx, _d, _d, C.c_int32, C.c_int32, _P(_i64), C.c_uint64, _P(_f), C.c_int64, _i64,
                                         _i32]),
     "fsrl_gae_return": (C.c_int, [_ctx, _f, _f, _d, _u8, C.c_int64, C.c_double, C.c_double, _d]),
+    "fsrl_nstep_return": (C.c_int, [_ctx, _d, _u8, C.c_int64, _f, _i64, C.c_int64, C.c_int64, C.c_double, C.c_int32, _d]),
     "fsrl_tr_begin": (C.c_int, [_ctx, _P(TrConfig), _i64]),
     "fsrl_cpo_learn": (C.c_int, [_ctx, C.c_double, C.c_int32, _f]),
     "fsrl_trpo_learn": (C.c_int, [_ctx, _d, C.c_double, C.c_int32, _f]),

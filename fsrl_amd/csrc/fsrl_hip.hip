@@ -1045,6 +1045,42 @@ extern "C" int fsrl_gae_return(fsrl_ctx* c, const float* v, const float* v_next,
     return 0;
 }
 
+// ------------------------------------------------------------------------------ n-step return (standalone)
+// nstep_return (base_policy.py:543-567) on the device: the twin of fsrl_gae_return.  Host arrays in, host array out.
+extern "C" int fsrl_nstep_return(fsrl_ctx* c, const double* metric, const uint8_t* end_flag, int64_t len,
+                                 const float* target_q, const int64_t* indices, int64_t bsz, int64_t q, double gamma,
+                                 int32_t n_step, double* out) {
+    CHECK_ARG(c && out, "null argument");
+    CHECK_ARG(n_step >= 1, "n_step should be greater than 0");          /* base_policy.py:472 */
+    CHECK_ARG(bsz >= 0 && q >= 1 && len >= 0 && bsz < INT_MAX / 8 && q < 65536, "bad sizes");
+    if (bsz == 0) return 0;
+    CHECK_ARG(metric && end_flag && target_q && indices && len > 0, "null argument");
+    for (int64_t i = 0; i < (int64_t)n_step * bsz; ++i)
+        CHECK_ARG(indices[i] >= 0 && indices[i] < len, "index out of range");
+    HIPCHK(hipSetDevice(c->device));
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t L = (size_t)len, B = (size_t)bsz, Q = (size_t)q;
+    const size_t o_m = 0, o_e = o_m + al(L * 8), o_t = o_e + al(L), o_i = o_t + al(B * Q * 4),
+                 o_o = o_i + al((size_t)n_step * B * 8), total = o_o + al(B * Q * 8);
+    int rc = ensure_scratch(c, total);
+    if (rc) return rc;
+    char* base = (char*)c->scratch;
+    hipStream_t s = c->compute;
+    HIPCHK(hipMemcpyAsync(base + o_m, metric, L * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(base + o_e, end_flag, L, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(base + o_t, target_q, B * Q * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(base + o_i, indices, (size_t)n_step * B * 8, hipMemcpyHostToDevice, s));
+    NstepArgs na{};
+    na.metric = (const double*)(base + o_m); na.end_flag = (const uint8_t*)(base + o_e);
+    na.target_q = (const float*)(base + o_t); na.indices = (const int64_t*)(base + o_i);
+    na.out = (double*)(base + o_o); na.len = len; na.bsz = (int)bsz; na.q = (int)q; na.n_step = n_step; na.gamma = gamma;
+    hipLaunchKernelGGL(nstep_return_kernel, dim3((unsigned)((bsz + 255) / 256)), dim3(256), 0, s, na);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, base + o_o, B * Q * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
 #include "host_collect.inc"
 
 #include "host_ppo.inc"

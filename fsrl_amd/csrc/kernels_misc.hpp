@@ -353,3 +353,37 @@ __global__ __launch_bounds__(ADAM_NT) void adam_clip_kernel(float* __restrict__ 
                                                        CtrlBlock* ctrl, const ModelDesc md) {
     adam_clip_body(P, M, V, G, gsq_part, nparts, n, sa, ctrl, md);
 }
+
+// ---- the stand-alone n-step return (nstep_return, base_policy.py:543-567) behind fsrl_nstep_return: one lane per batch
+// row, the reference's float64 operations in its order (gamma * returns rounded before the add, gamma_buffer built by
+// repeated multiplication): bit-exact with the sequential numba loop for any n_step / q.
+struct NstepArgs {
+    const double* metric;    // [len] rew or info.cost of the WHOLE buffer (base_policy.py:481)
+    const uint8_t* end_flag; // [len] done | unfinished
+    const float* target_q;   // [bsz][q] value-masked targets (float32, as torch hands them over)
+    const int64_t* indices;  // [n_step][bsz] the buffer.next chain
+    double* out;             // [bsz][q]
+    int64_t len;
+    int bsz, q, n_step;
+    double gamma;
+};
+__global__ __launch_bounds__(256) void nstep_return_kernel(const NstepArgs a) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.bsz) return;
+    int gammas = a.n_step;
+    double ret = 0.0;
+    for (int n = a.n_step - 1; n >= 0; --n) {
+        const int64_t now = a.indices[(size_t)n * a.bsz + b];
+        if (a.end_flag[now]) { gammas = n + 1; ret = 0.0; }
+        const double t = a.gamma * ret;
+        ret = a.metric[now] + t;
+    }
+    double gpow = 1.0;
+    for (int i = 0; i < gammas; ++i) gpow = gpow * a.gamma;          // gamma_buffer[gammas]
+    for (int j = 0; j < a.q; ++j) {
+        const double prod = (double)a.target_q[(size_t)b * a.q + j] * gpow;
+        a.out[(size_t)b * a.q + j] = prod + ret;
+    }
+}
+

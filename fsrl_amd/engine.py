@@ -403,6 +403,21 @@ class Engine:
                                             float(gae_lambda), _ptr(out, _f64p)))
         return out
 
+    def nstep_return(self, metric, end_flag, target_q, indices, gamma, n_step):
+        """nstep_return (base_policy.py:543-567) on the device; target_q [bsz, ...] float32, indices [n_step, bsz]."""
+        metric = np.ascontiguousarray(metric, np.float64)
+        end = np.ascontiguousarray(end_flag).astype(np.uint8)
+        tq = np.ascontiguousarray(target_q, np.float32)
+        shape = tq.shape
+        bsz = shape[0] if tq.ndim else 0
+        tq2 = tq.reshape(bsz, -1) if bsz else tq.reshape(0, 1)
+        idx = np.ascontiguousarray(indices, np.int64).reshape(int(n_step), bsz) if n_step >= 1 else np.zeros((0, bsz), np.int64)
+        out = np.empty(tq2.shape, np.float64)
+        _lib.check(self.lib.fsrl_nstep_return(self._ctx, _ptr(metric, _f64p), _ptr(end, _u8p), metric.size,
+                                              _ptr(tq2, _f32p), _ptr(idx, _i64p), bsz, tq2.shape[1], float(gamma),
+                                              int(n_step), _ptr(out, _f64p)))
+        return out.reshape(shape)
+
     # ---------------------------------------------------------------- CPO / TRPO-Lagrangian
     def tr_begin(self, target_kl=0.01, backtrack_coeff=0.8, damping=0.1, l2_reg=0.0, critic_lr=1e-3,
                  max_backtracks=10, optim_critic_iters=10, cg_iters=10, norm_adv=True,

@@ -266,6 +266,14 @@ int fsrl_gae_return(fsrl_ctx* ctx, const float* v, const float* v_next, const do
                     const uint8_t* end_flag, int64_t n, double gamma, double gae_lambda,
                     double* adv_out);
 
+/* ---- stand-alone float64 n-step return on the device (nstep_return, base_policy.py:543-567; called from
+ *      compute_nstep_returns :453-512 with metric = rew / info.cost of the WHOLE buffer :481, end_flag = done | unfinished,
+ *      target_q already value-masked, indices = the buffer.next chain [n_step][bsz]).  out[bsz][q] float64.
+ *      Bit-exact with the sequential reference.  n_step < 1 -> FSRL_EINVAL (the reference asserts, :472).   */
+int fsrl_nstep_return(fsrl_ctx* ctx, const double* metric, const uint8_t* end_flag, int64_t len,
+                      const float* target_q, const int64_t* indices, int64_t bsz, int64_t q, double gamma,
+                      int32_t n_step, double* out);
+
 /* ---- trust-region policy updates: CPO (fsrl/policy/cpo.py) and TRPO-Lagrangian
  *      (fsrl/policy/trpo_lag.py).  Same context / store / parameter layout as PPO-Lag;
  *      full batch (the reference runs them with batch_size = 99999).                       */

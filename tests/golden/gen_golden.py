@@ -369,6 +369,93 @@ def gen_ppo_widths():
                  max_grad_norm=None, target_kl=1e9)
 
 
+def gen_ppo_full_case(name, env_num, ep_lens, seed=2, hidden=(256, 256), batch_size=256, repeat=4, theta0_from=None):
+    """BASELINE-size fixtures (configs[1]: 20 envs x 1000 rows; configs[4] per rank: 32 envs x 625 rows), 256x256, grad clip
+    0.5 (ppol_cfg.py:21), repeat 4 = 312 steps of the UNMODIFIED PPOLagrangian.update.  20 000 rows of random floats do not
+    compress, so the rollout is NOT stored: tests/helpers.synth_rollout(seed) regenerates it (checksum stored), and the file
+    keeps theta0, the recorded permutations (uint16), advs / logp_old of process_fn, stats[312, 11], theta after pass 1 and
+    after pass 4."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import rollout_checksum, synth_rollout
+    obs_dim, act_dim = 8, 2
+    logger = CaptureLogger()
+    kw = dict(max_grad_norm=0.5, target_kl=1e9)
+    policy, actor_critic, optim = build_ppo(obs_dim, act_dim, hidden, seed, logger=logger, cost_limit=10.0, **kw)
+    policy.train()
+    steps = synth_rollout(seed + 1000, env_num, ep_lens, obs_dim, act_dim)
+    buf = VectorReplayBuffer(100000, env_num)
+    for ids, obs, act, rew, cost, term, trunc, nxt in steps:
+        buf.add({"obs": obs, "act": act, "rew": rew, "terminated": term, "truncated": trunc, "done": term | trunc,
+                 "obs_next": nxt, "info.cost": cost}, ids)
+    out = {"rollout_seed": np.array(seed + 1000), "rollout_checksum": rollout_checksum(steps),
+           "ep_lens": np.array(ep_lens[0]), "env_num": np.array(env_num)}
+    assert all(list(e) == list(ep_lens[0]) for e in ep_lens)
+    theta0 = flat_params(actor_critic)
+    if theta0_from is None:
+        out["theta0"] = theta0
+    else:
+        assert np.array_equal(theta0, np.load(os.path.join(HERE, theta0_from))["theta0"])
+        out["theta0_from"] = np.array(theta0_from)
+    policy.pre_update_fn(stats_train={"cost": 25.0})
+    out["lagrangian"] = np.array([o.get_lag() for o in policy.lag_optims], np.float64)
+    batch, indices = buf.sample(0)
+    out["n_rows"] = np.array(len(indices))
+    pb = policy.process_fn(batch, buf, indices)
+    out["advs"], out["logp_old"] = pb.advs.numpy().copy(), pb.logp_old.numpy().copy()
+    perms, snaps, counter = [], {}, {"n": 0}
+    orig_perm, orig_step = np.random.permutation, optim.step
+    n_per_pass = max(1, len(indices) // batch_size)          # Batch.split(merge_last=True): a remainder joins the last chunk
+
+    def rec_perm(n):
+        p = orig_perm(n)
+        perms.append(np.asarray(p).copy())
+        return p
+
+    def rec_step(*a, **k):
+        r = orig_step(*a, **k)
+        counter["n"] += 1
+        if counter["n"] == n_per_pass:
+            snaps["theta_pass1"] = flat_params(actor_critic)
+        return r
+
+    optim.step = rec_step
+    np.random.permutation = rec_perm
+    try:
+        seed_all(seed + 7)
+        policy.update(0, buf, batch_size=batch_size, repeat=repeat)
+    finally:
+        np.random.permutation = orig_perm
+    assert len(perms) == repeat and max(p.max() for p in perms) < 65536
+    out["perms"] = np.stack(perms).astype(np.uint16)
+    out["theta_final"] = flat_params(actor_critic)
+    out.update(snaps)
+    rows = [r for r in logger.rows if "update/gradient_steps" not in r]
+    keys = ["loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss/actor_rew", "loss/actor_total", "loss/kl",
+            "loss/vf0", "loss/vf1", "loss/vf_total", "loss/total", "loss/entropy"]
+    stats = []
+    for i in range(0, len(rows), 3):
+        merged = {}
+        for r in rows[i:i + 3]:
+            merged.update(r)
+        stats.append([merged[k] for k in keys])
+    out["stats"] = np.array(stats, np.float64)
+    assert out["stats"].shape == (n_per_pass * repeat, 11) and "theta_pass1" in out
+    cfg = dict(obs_dim=obs_dim, act_dim=act_dim, hidden=list(hidden), env_num=env_num, batch_size=batch_size, repeat=repeat,
+               seed=seed, cost_stat=25.0, cost_limit=10.0, max_action=1.0, target_kl=1e9, vf_coef=0.25, max_grad_norm=0.5,
+               gae_lambda=0.95, eps_clip=0.2, dual_clip=None, gamma=0.99, lr=5e-4, advantage_normalization=True,
+               lagrangian_pid=(0.05, 0.0005, 0.1), rescaling=True, use_lagrangian=True)
+    out["cfg_json"] = np.array(json.dumps(cfg))
+    np.savez_compressed(os.path.join(HERE, f"ppo_{name}.npz"), **out)
+    print(f"G4 ppo_{name}.npz  N={len(indices)} steps={len(stats)} size={os.path.getsize(os.path.join(HERE, f'ppo_{name}.npz')) / 1e6:.2f} MB")
+
+
+def gen_ppo_full():
+    # configs[1]: 20 envs x 1000 rows, episodes of 250 steps (SURVEY 8d "N = 20 000 variant")
+    gen_ppo_full_case("c2full", 20, [[250, 250, 250, 250]] * 20)
+    # configs[4], one rank: 32 envs x 625 rows (two episodes of 250 and an unfinished tail of 125 each), same theta0
+    gen_ppo_full_case("c5rank", 32, [[250, 250, -125]] * 32, theta0_from="ppo_c2full.npz")
+
+
 def gen_manifest():
     policy, _, _ = build_ppo(8, 2, (128, 128), 0, logger=CaptureLogger(), cost_limit=10.0)
     sd = policy.state_dict()
@@ -383,4 +470,4 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["gae", "nstep", "pid", "ppo", "manifest"]
     for w in which:
         {"gae": gen_gae, "nstep": gen_nstep, "pid": gen_pid, "ppo": gen_ppo, "recompute": gen_ppo_recompute, "options": gen_ppo_options,
-         "widths": gen_ppo_widths, "manifest": gen_manifest}[w]()
+         "widths": gen_ppo_widths, "full": gen_ppo_full, "manifest": gen_manifest}[w]()

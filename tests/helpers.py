@@ -42,3 +42,74 @@ def oracle_cfg_and_data(cfg, g):
                         terminated=g["buf_terminated"], truncated=g["buf_truncated"],
                         obs_next=g["buf_obs_next"], end_flag=end_flag_of(g))
     return ocfg, data
+
+
+def synth_rollout(seed, env_num, ep_lens_per_env, obs_dim, act_dim, term_prob=0.3, cost_prob=0.1):
+    """Seeded synthetic rollouts as lock-step vector steps [(ids, obs, act, rew, cost, term, trunc, obs_next)], the way
+    FastCollector pushes them (fast_collector.py:333).  ep_lens_per_env[e] = episode lengths of env e; a negative last entry
+    -k = k steps left unfinished.  The full-size fixtures (tests/golden/gen_golden.py `full`) store only the seed and a
+    checksum of what this function returns; the generator script and the GPU tests both call it."""
+    rng = np.random.default_rng(seed)
+    plan = []
+    for e in range(env_num):
+        steps = []
+        for L in ep_lens_per_env[e]:
+            unfinished = L < 0
+            L = abs(L)
+            terminated_end = rng.random() < term_prob
+            for t in range(L):
+                last = (t == L - 1) and not unfinished
+                steps.append((last and terminated_end, last and not terminated_end))
+        plan.append(steps)
+    T = max(len(p) for p in plan)
+    cur = rng.standard_normal((env_num, obs_dim)).astype(np.float32)
+    out = []
+    for t in range(T):
+        ids = [e for e in range(env_num) if t < len(plan[e])]
+        k = len(ids)
+        obs = cur[ids].copy()
+        nxt = rng.standard_normal((k, obs_dim)).astype(np.float32)
+        act = (0.3 * rng.standard_normal((k, act_dim))).astype(np.float32)
+        rew = rng.normal(0.5, 0.5, k)
+        cost = (rng.random(k) < cost_prob).astype(np.float64)
+        term = np.array([plan[e][t][0] for e in ids])
+        trunc = np.array([plan[e][t][1] for e in ids])
+        out.append((ids, obs, act, rew, cost, term, trunc, nxt))
+        cur[ids] = nxt
+        for j, e in enumerate(ids):
+            if term[j] or trunc[j]:
+                cur[e] = rng.standard_normal(obs_dim).astype(np.float32)
+    return out
+
+
+def rollout_checksum(steps):
+    """float64 sums of every column of synth_rollout's output: guards the fixture against a drift of numpy's generators"""
+    return np.array([sum(float(np.asarray(s[c], np.float64).sum()) for s in steps) for c in range(1, 8)])
+
+
+def rollout_env_major(steps, env_num):
+    """the rows in sample(0) order (env-major, time-ordered inside each env) + end_flag = done | unfinished tail"""
+    cols = [[[] for _ in range(env_num)] for _ in range(7)]
+    for ids, *rest in steps:
+        for j, e in enumerate(ids):
+            for c, a in enumerate(rest):
+                cols[c][e].append(a[j])
+    cat = [np.concatenate([np.asarray(cols[c][e]) for e in range(env_num)]) for c in range(7)]
+    obs, act, rew, cost, term, trunc, nxt = cat
+    end = term | trunc
+    off = np.cumsum([len(cols[0][e]) for e in range(env_num)])
+    end[off - 1] = True                       # unfinished tails (base_policy.py:409-411); finished ones are set already
+    return dict(obs=obs, act=act, rew=rew, cost=cost, terminated=term, truncated=trunc, obs_next=nxt, end_flag=end)
+
+
+def ppo_full_case(name):
+    """tests/golden/ppo_{c2full,c5rank}.npz: BASELINE-size PPO-Lagrangian updates of the unmodified reference (256x256, clip 0.5,
+    N = 20 000, 4 passes).  -> (cfg, golden arrays incl. theta0 and int64 perms, the regenerated rollout steps)"""
+    cfg, g = ppo_case(name)
+    if "theta0" not in g:
+        g["theta0"] = load_npz(str(g["theta0_from"]))["theta0"]
+    g["perms"] = g["perms"].astype(np.int64)
+    env_num = int(g["env_num"])
+    steps = synth_rollout(int(g["rollout_seed"]), env_num, [list(g["ep_lens"])] * env_num, cfg["obs_dim"], cfg["act_dim"])
+    assert np.array_equal(rollout_checksum(steps), g["rollout_checksum"]), "numpy's generators no longer reproduce the fixture's rollout"
+    return cfg, g, steps

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import oracle_cfg_and_data, ppo_case
+from helpers import oracle_cfg_and_data, ppo_case, ppo_full_case, rollout_env_major
 from oracle.pid import rescaling_factor
 from oracle.ppo_lag import PPOLagOracle, split_chunks
 
@@ -72,3 +72,25 @@ def test_two_updates_under_an_lr_schedule():
         np.testing.assert_allclose(stats, g[f"stats{u}"], rtol=2e-5, atol=2e-5)
         np.testing.assert_allclose(o.get_params(), g[f"theta_after{u}"], rtol=0, atol=2e-6)
     assert g["lrs"][1] == 0.5 * g["lrs"][0] and g["lrs"][2] == 0.25 * g["lrs"][0]
+
+
+@pytest.mark.parametrize("name", ["c2full", "c5rank"])
+def test_full_size_update_vs_reference(name):
+    """The headline workload itself (BASELINE configs[1] / one rank of configs[4]: obs 8, act 2, 256x256, N = 20 000, batch 256,
+    4 passes = 312 steps, max_grad_norm 0.5 as in ppol_cfg.py:21) recorded from the unmodified reference (ppo_lag.py:214-257):
+    process_fn, every logged statistic of the first pass at the fixture tolerances, theta after pass 1 and after pass 4."""
+    from oracle.ppo_lag import OnPolicyData, PPOLagConfig
+    torch.set_num_threads(4)
+    cfg, g, steps = ppo_full_case(name)
+    d = rollout_env_major(steps, cfg["env_num"])
+    assert len(d["obs"]) == int(g["n_rows"]) == 20000
+    ocfg = PPOLagConfig(obs_dim=8, act_dim=2, hidden=(256, 256), max_grad_norm=0.5, target_kl=1e9)
+    o = PPOLagOracle(ocfg)
+    o.set_params(g["theta0"])
+    lag = g["lagrangian"]
+    pb, stats, _ = o.update(OnPolicyData(**d), lag, rescaling_factor(lag), 256, 4, perms=g["perms"])
+    np.testing.assert_allclose(pb["advs"].numpy(), g["advs"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(pb["logp_old"].numpy(), g["logp_old"], rtol=1e-5, atol=1e-5)
+    assert stats.shape == g["stats"].shape == (312, 11)
+    np.testing.assert_allclose(stats, g["stats"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(o.get_params(), g["theta_final"], rtol=0, atol=2e-6)
