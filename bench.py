@@ -27,9 +27,18 @@ sys.path.insert(0, ROOT)
 
 OBS, ACT, HID, NROWS, ENVS, EPLEN, BATCH, REPEAT = 8, 2, 256, 20000, 20, 250, 256, 4
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix = vector peak
-# Duration of an EMPTY launch of each of the optimiser step's three grids behind its predecessor on the same stream (probe
-# build, every role returning at once: DESIGN.md section 3, "role timing"): the part of a step no kernel work can remove.
-LAUNCH_FLOORS_US = {"fwdbwd": 3.5, "wgrad": 4.2, "adam": 4.8}
+
+
+def csrc_sha16():
+    """hash of the kernel / host sources the library was built from: the committed PMC files carry the hash they were captured
+    at (tools/collect_profiles.py), so a traffic figure read from a stale capture says so in the bench line"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fsrl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".inc")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def make_inputs(seed):
@@ -199,19 +208,23 @@ def end_to_end(local_rank, seed, seconds=6.0, device_actor=False, workers=0, bus
     from fsrl_amd.parallel import usable_cpus
     kind = (f"shared-memory multi-process vector env: {workers} worker processes, {busy_us:g} us of host time per env step"
             if workers > 0 else "in-process vector env, zero-cost step")
+    procs = int(getattr(env, "workers", workers)) if workers > 0 else 0      # worker PROCESSES (capped at the usable CPUs)
     out = {"env": "synthetic SafetyCarCircle-shaped dynamics (not PyBullet); " + kind, "envs": envs, "workers": workers,
-           "busy_us": busy_us, "host_cpus_usable": usable_cpus(),
+           "worker_processes": procs, "busy_us": busy_us, "host_cpus_usable": usable_cpus(),
            "handshake": (("futex generation word + completion counter per lane (libfsrl_env.so), spin "
                           f"{getattr(env, 'spin_us', 0):g} us before sleeping") if workers > 0 else None),
            "split_phase": bool(col.split_phase),
-           "collector_loop": (("native (fsrl_collect_episodes: one library call per collect)" if col.native_loop is True
+           "collector_loop": ((("native split-phase (fsrl_collect_episodes_split: one library call per collect, the two lanes "
+                                 "alternate)" if col.split_phase else "native (fsrl_collect_episodes: one library call per collect)")
+                               if col.native_loop is True
                                else "native (fsrl_collect_run: Python sees episode boundaries only)")
-                              if (device_actor and col.native_loop and hasattr(env, "native_desc") and not col.split_phase)
+                              if (device_actor and col.native_loop and hasattr(env, "native_desc")
+                                  and (col.native_loop is True or not col.split_phase))
                               else "interpreted, one library call per vector step" if device_actor else "interpreted, host actor"),
-           "env_bound_env_steps_per_s": env_bound(envs, workers, busy_us, usable_cpus()),
+           "env_bound_env_steps_per_s": env_bound(envs, procs, busy_us, usable_cpus()),
            "actor": "device (fsrl_collect_step: one call per vector step, library RNG)" if device_actor else "host mirror (torch CPU, torch RNG)",
            "collects": collects, "env_steps_per_s": col.collect_step / dt,
-           "frac_of_env_bound": (col.collect_step / dt / env_bound(envs, workers, busy_us, usable_cpus())
+           "frac_of_env_bound": (col.collect_step / dt / env_bound(envs, procs, busy_us, usable_cpus())
                                  if busy_us > 0 else None),
            "collector_only_env_steps_per_s": col.collect_step / col.collect_time,
            "update_ms_per_collect": update_s / collects * 1e3,
@@ -312,10 +325,70 @@ def pmc_traffic():
     for tag in ("r05", "r04", "r03", "r02", "r01"):
         f = os.path.join(here, "profiles", f"{tag}_pmc_traffic.json")
         if os.path.exists(f):
-            for name, v in json.load(open(f)).items():
+            j = json.load(open(f))
+            meta = j.get("_meta", {})
+            for name, v in j.items():
                 if name.startswith("void ppo_fwd_bwd_kernel<256"):
-                    return float(v["hbm_bytes_per_launch"]), f"profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc, separate pass)"
+                    return (float(v["hbm_bytes_per_launch"]), f"profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc, separate pass)",
+                            meta.get("head"), meta.get("csrc_sha16"))
     return None
+
+
+def kl_on_variant(theta, inputs, seed, steps=10):
+    """"disable [the KL early stop] for throughput runs; report both".  The same workload with the reference's
+    default target_kl = 0.02 (ppo_lag_agent.py:95): the pass-level check (ppo_lag.py:251-255) costs one 24-byte read-back per
+    pass, and an update whose pass-mean KL exceeds 1.5 x target_kl ends early (fewer gradient steps: both are reported)."""
+    from fsrl_amd.engine import Engine, EngineConfig
+    eng = Engine(EngineConfig(obs_dim=OBS, act_dim=ACT, hidden=HID, env_num=ENVS, buffer_size=100000, max_grad_norm=0.5,
+                              target_kl=0.02))
+    obs, act, rew, cost, term, trunc = inputs
+    ids = np.arange(ENVS)
+    for t in range(NROWS // ENVS):
+        eng.push(ids, obs[t], act[t], rew[t], cost[t], term[t], trunc[t], obs[t + 1])
+    eng.sync()
+    lag, resc = np.array([0.75]), 1.0 / 1.75
+    eng.set_params(theta); eng.optim_reset(); eng.state_snapshot()
+
+    def one(k):
+        eng.state_restore()
+        return eng.ppo_update(lag, resc, BATCH, REPEAT, perms=None, seed=1000 * seed + k + 1)
+    one(0)
+    eng.sync()
+    n_steps, stopped = [], 0
+    t0 = time.perf_counter()
+    for k in range(steps):
+        st, sp = one(k + 1)
+        n_steps.append(int(st.shape[0])); stopped += int(sp >= 0)
+    eng.sync()
+    dt = (time.perf_counter() - t0) / steps
+    eng.close()
+    return {"value": 1.0 / dt, "unit": "updates/s", "ms_per_update": dt * 1e3, "target_kl": 0.02,
+            "grad_steps_per_update_mean": float(np.mean(n_steps)), "updates_stopped_early": stopped, "updates": steps,
+            "us_per_step": dt * 1e6 / max(float(np.mean(n_steps)), 1.0),
+            "note": "the headline workload with the KL early stop ON (reference default 0.02); the headline value has it off"}
+
+
+def cpo_c2_leg():
+    """BASELINE configs[2]: CPO on the SafetyPointGoal shape (obs 60, act 2, 256x256, N = 20 000 full batch, CG 10, 4 repeats)
+    -- the body of tools/bench_trust.py; roofline of the whole update + the oracle on 1 of its 4 repeats as cpu_baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_trust
+    return bench_trust.run("cpo", 60, 2, 256, timed=5, emit=False, no_cpu=False)
+
+
+def trpo_c1_leg():
+    """TRPO-Lagrangian on the configs[1] shape (obs 8, 256x256, N = 20 000 full batch): the FVP + line-search path's other user."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_trust
+    return bench_trust.run("trpo", 8, 2, 256, ep=250, timed=5, emit=False, no_cpu=False)
+
+
+def sac_c3_leg():
+    """BASELINE configs[3]: SAC-Lagrangian, SafetyAntRun shape, 1 M-row replay store resident in HBM, batch 1024, n_step 2:
+    1 000 consecutive updates -- the body of tools/bench_sac.py."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_sac
+    return bench_sac.main(["--updates", "1000", "--cpu-updates", "10"], emit=False)
 
 
 class Legs:
@@ -516,23 +589,34 @@ def main():
              "avg_launch_us": avg_launch_s * 1e6, "avg_launch_us_raw_event_bracket": k_raw / max(k_n, 1) * 1e3,
              "launches_timed": int(k_n), "flops_per_launch": fl}
         # the bound that actually applies to a chain of dependent ~0.2 GFLOP launches ("report the achieved
-        # fraction of the latency floor as well"): per optimiser step, the floors of its dependent launches (an empty
-        # launch of each grid, measured with the probe build: DESIGN section 3) + the step's MFMA work at the chip's peak
-        floors_us = LAUNCH_FLOORS_US["fwdbwd"] + LAUNCH_FLOORS_US["wgrad"] + LAUNCH_FLOORS_US["adam"]
+        # fraction of the latency floor as well"): per optimiser step, the floors of its dependent launches -- MEASURED HERE,
+        # in this run, on this device (fsrl_launch_floors: empty kernels with the step's three grids, block sizes and LDS
+        # footprints, 300 triples back to back, ~5 ms) -- + the step's MFMA work at the chip's peak
+        floors = eng.launch_floors(BATCH, 300)
+        floors_us = floors["triple"]
         step_flops = fl + flops_wgrad_launch(rows_avg)
         floor_us = floors_us + step_flops / (F32_MFMA_PEAK_TFLOPS * 1e12) * 1e6
         # per optimiser step in the UN-instrumented timed region: the update minus process_fn (timed here with HIP events; the
         # event brackets of the profiling mode themselves cost ~8 us per step, so its own learn time is not used)
         step_us = (dt / args.steps * 1e3 - proc_ms / prof_steps) * 1e3 / grad_steps
         r["latency_floor_us"] = floor_us
-        r["latency_floor_parts_us"] = dict(LAUNCH_FLOORS_US, mfma_at_peak=floor_us - floors_us)
+        r["latency_floor_parts_us"] = {"three_empty_launches_measured_in_this_run": floors_us, "each_grid_behind_itself": floors,
+                                       "mfma_at_peak": floor_us - floors_us}
         r["step_us"] = step_us
         r["frac_of_latency_floor"] = floor_us / step_us if step_us > 0 else None
         pmc = pmc_traffic()
         if pmc is not None:
-            r["traffic"], r["traffic_source"] = pmc
+            r["traffic"], r["traffic_source"], r["traffic_profile_head"], r["traffic_profile_csrc_sha16"] = pmc
+            r["csrc_sha16"] = csrc_sha16()
+            r["traffic_profile_current"] = (r["traffic_profile_csrc_sha16"] == r["csrc_sha16"]) if r["traffic_profile_csrc_sha16"] else None
+            if r["traffic_profile_current"] is not True:
+                r["traffic_warning"] = ("the PMC capture was taken on other kernel sources than this run's (or carries no source "
+                                        "hash): the traffic figure may be stale")
         if out is not None:
-            out["phase_ms"] = {"process_fn": proc_ms / prof_steps, "learn": learn_ms / prof_steps}
+            out["phase_ms_instrumented"] = {
+                "process_fn": proc_ms / prof_steps, "learn": learn_ms / prof_steps,
+                "note": "profiling mode: three event records per optimiser step inside learn (~8 us each step), so learn here "
+                        "exceeds the un-instrumented ms_per_step; only process_fn is used (step_us above)"}
         return r
 
     legs.run("roofline", roofline_leg, 60.0)
@@ -543,7 +627,8 @@ def main():
         #      -> update) side by side for a few seconds on its own slice of the host cores; job env-steps/s = sum over ranks.
         #      A rank whose loop fails contributes NaNs, so the gather below is still joined by every rank.
         cores = parallel.pin_rank_cores(local_rank if not args.share_gpu else rank, world)
-        e2e = legs.run("end_to_end_rank", lambda: end_to_end(local_rank, seed, seconds=4.0, device_actor=True), 90.0, store=False)
+        # BASELINE configs[4]: 32 envs per rank (one seed per GPU)
+        e2e = legs.run("end_to_end_rank", lambda: end_to_end(local_rank, seed, seconds=4.0, device_actor=True, envs=32), 90.0, store=False)
         mine = {"rank": float(rank), "cores": float(len(cores)),
                 "env_steps_per_s": e2e["env_steps_per_s"] if e2e else float("nan"),
                 "policy_updates_per_s": e2e["policy_updates_per_s"] if e2e else float("nan")}
@@ -597,6 +682,12 @@ def main():
             allc = max(1, int(usable_cpus()))          # "... and with all host cores" (the cgroup quota counts)
             if allc > 4:
                 legs.run("cpu_baseline_all_cores", lambda: cpu_baseline(theta, inputs, seconds=6.0, threads=allc), 60.0)
+        # every other BASELINE configuration, each with its own roofline + cpu_baseline (configs[2], the TRPO-Lag user of the
+        # same path, configs[3]) and the headline with the KL early stop on ("report both")
+        legs.run("kl_on", lambda: kl_on_variant(theta, inputs, seed), 60.0)
+        legs.run("cpo_c2", cpo_c2_leg, 90.0)
+        legs.run("trpo_c1", trpo_c1_leg, 90.0)
+        legs.run("sac_c3", sac_c3_leg, 120.0)
         legs.run("no_clip", lambda: no_clip_variant(theta, inputs), 60.0)
         legs.run("end_to_end", lambda: end_to_end(local_rank, seed, device_actor=True), 60.0)
         legs.run("end_to_end_host_actor", lambda: end_to_end(local_rank, seed, seconds=4.0, device_actor=False), 60.0)

@@ -28,7 +28,8 @@ class ShmEnv(C.Structure):
     _fields_ = [("obs", C.c_void_p), ("act", C.c_void_p), ("rew", C.c_void_p), ("cost", C.c_void_p), ("term", C.c_void_p),
                 ("trunc", C.c_void_p), ("active", C.c_void_p), ("hs", C.c_void_p), ("want", C.c_void_p), ("owner", C.c_void_p),
                 ("lane_of_worker", C.c_void_p), ("env_num", C.c_int32), ("obs_dim", C.c_int32), ("act_dim", C.c_int32),
-                ("workers", C.c_int32), ("n_lanes", C.c_int32), ("gen", C.c_uint32 * 2), ("spin", C.c_uint32)]
+                ("workers", C.c_int32), ("n_lanes", C.c_int32), ("gen", C.c_uint32 * 2), ("spin", C.c_uint32),
+                ("err", C.c_void_p), ("pids", C.c_void_p)]
 
 
 class TrConfig(C.Structure):
@@ -108,6 +109,7 @@ SIGNATURES = {
                                         _i32]),
     "fsrl_gae_return": (C.c_int, [_ctx, _f, _f, _d, _u8, C.c_int64, C.c_double, C.c_double, _d]),
     "fsrl_nstep_return": (C.c_int, [_ctx, _d, _u8, C.c_int64, _f, _i64, C.c_int64, C.c_int64, C.c_double, C.c_int32, _d]),
+    "fsrl_launch_floors": (C.c_int, [_ctx, C.c_int32, C.c_int32, _d]),
     "fsrl_tr_begin": (C.c_int, [_ctx, _P(TrConfig), _i64]),
     "fsrl_cpo_learn": (C.c_int, [_ctx, C.c_double, C.c_int32, _f]),
     "fsrl_trpo_learn": (C.c_int, [_ctx, _d, C.c_double, C.c_int32, _f]),
@@ -134,6 +136,9 @@ SIGNATURES = {
                                     _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, _f, _f]),
     "fsrl_collect_episodes": (C.c_int, [_ctx, _P(ShmEnv), _i32, C.c_int32, _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, _i64, _d, _i32,
                                         _i32, _d, _i32, _i32]),
+    "fsrl_collect_episodes_split": (C.c_int, [_ctx, _P(ShmEnv), _i32, C.c_int32, _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, _i64, _d, _i32,
+                                              _i32, _d, _i32, _i32]),
+    "fsrl_collect_timing": (C.c_int, [_ctx, _d]),
     "fsrl_collect_run": (C.c_int, [_ctx, _P(ShmEnv), _i32, C.c_int32, _f, _f, _f, C.c_int32, C.c_int32, _f, _f, C.c_int32, _i32, _d, _d, _d,
                                   _u8, _u8, _f]),
     "fsrl_store_sizes": (C.c_int, [_ctx, _i64, C.c_int32]),

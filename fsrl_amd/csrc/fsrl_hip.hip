@@ -71,15 +71,17 @@ struct EnvBook {           // tianshou ReplayBuffer bookkeeping of one sub-buffe
     int64_t ep_idx = 0;
 };
 
-struct Staging {           // pinned host staging + its device mirror (one of two)
-    int* slot = nullptr; float* obs = nullptr; float* obs_next = nullptr; float* act = nullptr;
-    double* rew = nullptr; double* cost = nullptr; uint8_t* flags = nullptr;
-    int* d_slot = nullptr; float* d_obs = nullptr; float* d_obs_next = nullptr; float* d_act = nullptr;
-    double* d_rew = nullptr; double* d_cost = nullptr; uint8_t* d_flags = nullptr;
+// Pinned host staging window + its device mirror (one of two).  Rows are PACKED records -- rew f64 | cost f64 | slot i32 |
+// flags u32 | obs[Do] | obs_next[Do] | act[Da] -- so that a flush is ONE hipMemcpyAsync of count x rec bytes on the side
+// stream (it was seven, one per column: at one flush per vector step the copies' submission cost more than the bytes).
+struct Staging {
+    uint8_t* h = nullptr;      // pinned, STAGE_CAP x rec bytes
+    uint8_t* d = nullptr;      // device mirror
     int count = 0;
     hipEvent_t done = nullptr;
     bool in_flight = false;
 };
+static inline size_t stage_rec_bytes(int Do, int Da) { return ((size_t)24 + 4 * (size_t)(2 * Do + Da) + 7) / 8 * 8; }
 
 struct fsrl_group;
 struct fsrl_ctx {
@@ -150,7 +152,8 @@ struct fsrl_ctx {
     size_t k_ev_used = 0;
     double t_process_ms = 0, t_learn_ms = 0, t_fwdbwd_ms = 0, t_fwdbwd_raw_ms = 0;
     int64_t n_fwdbwd = 0;
-    uint64_t rng[4] = {0x9E3779B97F4A7C15ull, 0xBF58476D1CE4E5B9ull, 0x94D049BB133111EBull, 1};
+    uint64_t rng[4] = {0x9E3779B97F4A7C15ull, 0xBF58476D1CE4E5B9ull, 0x94D049BB133111EBull, 1};          // the collector's action noise
+    uint64_t shuffle_rng[4] = {0xD6E8FEB86659FD93ull, 0xA0761D6478BD642Full, 0xE7037ED1A0B428DBull, 2};  // the library's own minibatch shuffles (perm == NULL): a stream of its own
     // split-K partial gradients of fb_wgrad_kernel, one buffer per parameter layout (keyed by its
     // padded size) so that the never-written inter-tensor padding stays zero
     struct Parts { int stride = 0; float* p = nullptr; size_t floats = 0; } parts[3];
@@ -176,11 +179,13 @@ struct fsrl_ctx {
     hipEvent_t perm_copied = nullptr; bool perm_in_flight = false;
     uint64_t store_version = 1;     // bumped by every push / reset (device copies of the bookkeeping)
     uint64_t joined_version = 0;    // store_version at the last side -> compute stream join (join_store)
+    double t_collect_env = 0.0, t_collect_act = 0.0;   // fsrl_collect_timing
     float* snap = nullptr;          // fsrl_state_snapshot: P (with mirrors) | M | V
     int64_t snap_adam_t = 0, snap_critic_t = 0, snap_foc_a = 0, snap_foc_c = 0; bool snap_valid = false;
     struct TrState* tr = nullptr;   // trust-region (CPO / TRPO-Lag) working set, owned
     void* sac = nullptr;            // SacState, owned
 };
+static bool ctx_is_replay(const fsrl_ctx* c);
 static void sac_free(fsrl_ctx* c);
 static void tr_free(fsrl_ctx* c);
 static void foc_free(fsrl_ctx* c);
@@ -357,10 +362,8 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
     void* hptrs[] = {c->h_ctrl, c->h_indices, c->h_end, c->h_seg, c->h_perm, c->h_mbplan};
     for (void* p : hptrs) if (p) (void)hipHostFree(p);
     for (auto& s : c->stage) {
-        void* hp[] = {s.slot, s.obs, s.obs_next, s.act, s.rew, s.cost, s.flags};
-        for (void* p : hp) if (p) (void)hipHostFree(p);
-        void* dp[] = {s.d_slot, s.d_obs, s.d_obs_next, s.d_act, s.d_rew, s.d_cost, s.d_flags};
-        for (void* p : dp) if (p) (void)hipFree(p);
+        if (s.h) (void)hipHostFree(s.h);
+        if (s.d) (void)hipFree(s.d);
         if (s.done) (void)hipEventDestroy(s.done);
     }
     for (hipEvent_t e : {c->store_ready, c->ev_a, c->ev_b, c->ev_c, c->perm_copied}) if (e) (void)hipEventDestroy(e);
@@ -461,12 +464,8 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     TRY(hipStreamSynchronize(c->compute));     // zero fills have landed before any other stream touches them
     for (auto& s : c->stage) {
         const size_t k = fsrl_ctx::STAGE_CAP;
-        TRY(hipHostMalloc(&s.slot, k * 4)); TRY(hipHostMalloc(&s.obs, k * Do * 4));
-        TRY(hipHostMalloc(&s.obs_next, k * Do * 4)); TRY(hipHostMalloc(&s.act, k * Da * 4));
-        TRY(hipHostMalloc(&s.rew, k * 8)); TRY(hipHostMalloc(&s.cost, k * 8)); TRY(hipHostMalloc(&s.flags, k));
-        TRY(hipMalloc(&s.d_slot, k * 4)); TRY(hipMalloc(&s.d_obs, k * Do * 4));
-        TRY(hipMalloc(&s.d_obs_next, k * Do * 4)); TRY(hipMalloc(&s.d_act, k * Da * 4));
-        TRY(hipMalloc(&s.d_rew, k * 8)); TRY(hipMalloc(&s.d_cost, k * 8)); TRY(hipMalloc(&s.d_flags, k));
+        TRY(hipHostMalloc(&s.h, k * stage_rec_bytes(Do, Da)));
+        TRY(hipMalloc(&s.d, k * stage_rec_bytes(Do, Da)));
         TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     }
     TRY(hipEventCreateWithFlags(&c->store_ready, hipEventDisableTiming));
@@ -541,14 +540,20 @@ extern "C" int fsrl_optim_reset(fsrl_ctx* c) {
 extern "C" int fsrl_state_snapshot(fsrl_ctx* c) {
     CHECK_ARG(c, "null ctx");
     CHECK_ARG(!c->in_update, "fsrl_state_snapshot inside an update");
+    // replay agents keep their training state elsewhere (SacState: actor / Q / target stores, log alpha, three Adam states): a
+    // snapshot of c->P / M / V would restore nothing of it
+    CHECK_ARG(!ctx_is_replay(c), "fsrl_state_snapshot covers on-policy contexts (PPO-Lag, FOCOPS, CPO, TRPO-Lag) only");
     HIPCHK(hipSetDevice(c->device));
     if (!c->snap) {
-        HIPCHK(hipMalloc(&c->snap, ((size_t)c->n_alloc + 2 * (size_t)c->n_dev) * 4));
+        HIPCHK(hipMalloc(&c->snap, ((size_t)c->n_alloc + 2 * (size_t)c->n_dev) * 4 + 3 * FSRL_MAX_CRITICS * sizeof(double)));
     }
     hipStream_t st = c->compute;
     HIPCHK(hipMemcpyAsync(c->snap, c->P, (size_t)c->n_alloc * 4, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(c->snap + c->n_alloc, c->M, (size_t)c->n_dev * 4, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(c->snap + c->n_alloc + c->n_dev, c->V, (size_t)c->n_dev * 4, hipMemcpyDeviceToDevice, st));
+    if (c->d_rms)       // reward_normalization: the running return statistics are training state too
+        HIPCHK(hipMemcpyAsync(c->snap + c->n_alloc + 2 * (size_t)c->n_dev, c->d_rms, 3 * FSRL_MAX_CRITICS * sizeof(double),
+                              hipMemcpyDeviceToDevice, st));
     c->snap_adam_t = c->adam_t;
     c->snap_critic_t = tr_critic_steps_taken(c);
     foc_steps(c, &c->snap_foc_a, &c->snap_foc_c, false);
@@ -564,6 +569,9 @@ extern "C" int fsrl_state_restore(fsrl_ctx* c) {
     HIPCHK(hipMemcpyAsync(c->P, c->snap, (size_t)c->n_alloc * 4, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(c->M, c->snap + c->n_alloc, (size_t)c->n_dev * 4, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(c->V, c->snap + c->n_alloc + c->n_dev, (size_t)c->n_dev * 4, hipMemcpyDeviceToDevice, st));
+    if (c->d_rms)
+        HIPCHK(hipMemcpyAsync(c->d_rms, c->snap + c->n_alloc + 2 * (size_t)c->n_dev, 3 * FSRL_MAX_CRITICS * sizeof(double),
+                              hipMemcpyDeviceToDevice, st));
     c->adam_t = c->snap_adam_t;
     tr_set_critic_steps(c, c->snap_critic_t);
     foc_steps(c, &c->snap_foc_a, &c->snap_foc_c, true);
@@ -575,17 +583,11 @@ static int flush_stage(fsrl_ctx* c) {
     Staging& s = c->stage[c->cur_stage];
     if (s.count == 0) return 0;
     const int k = s.count, Do = c->cfg.obs_dim, Da = c->cfg.act_dim;
-    HIPCHK(hipMemcpyAsync(s.d_slot, s.slot, (size_t)k * 4, hipMemcpyHostToDevice, c->side));
-    HIPCHK(hipMemcpyAsync(s.d_obs, s.obs, (size_t)k * Do * 4, hipMemcpyHostToDevice, c->side));
-    HIPCHK(hipMemcpyAsync(s.d_obs_next, s.obs_next, (size_t)k * Do * 4, hipMemcpyHostToDevice, c->side));
-    HIPCHK(hipMemcpyAsync(s.d_act, s.act, (size_t)k * Da * 4, hipMemcpyHostToDevice, c->side));
-    HIPCHK(hipMemcpyAsync(s.d_rew, s.rew, (size_t)k * 8, hipMemcpyHostToDevice, c->side));
-    HIPCHK(hipMemcpyAsync(s.d_cost, s.cost, (size_t)k * 8, hipMemcpyHostToDevice, c->side));
-    HIPCHK(hipMemcpyAsync(s.d_flags, s.flags, (size_t)k, hipMemcpyHostToDevice, c->side));
+    const size_t rec = stage_rec_bytes(Do, Da);
+    HIPCHK(hipMemcpyAsync(s.d, s.h, (size_t)k * rec, hipMemcpyHostToDevice, c->side));      // the pinned side-stream ingest: ONE copy
     const int per = 2 * Do + Da + 1;
     const int blocks = std::min(1024, (k * per + 255) / 256);
-    hipLaunchKernelGGL(store_scatter_kernel, dim3(blocks), dim3(256), 0, c->side, c->st, s.d_slot, s.d_obs,
-                       s.d_obs_next, s.d_act, s.d_rew, s.d_cost, s.d_flags, k, Do, Da);
+    hipLaunchKernelGGL(store_scatter_kernel, dim3(blocks), dim3(256), 0, c->side, c->st, s.d, (int)rec, k, Do, Da);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s.done, c->side));
     s.in_flight = true;
@@ -610,6 +612,7 @@ extern "C" int fsrl_store_push(fsrl_ctx* c, const int32_t* env_ids, int32_t k, c
     HIPCHK(hipSetDevice(c->device));
     c->store_version += 1;
     const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim;
+    const size_t rec = stage_rec_bytes(Do, Da);
     for (int j = 0; j < k; ++j) {
         const int e = env_ids[j];
         CHECK_ARG(e >= 0 && e < c->active_envs, "buffer id %d out of range", e);
@@ -626,14 +629,16 @@ extern "C" int fsrl_store_push(fsrl_ctx* c, const int32_t* env_ids, int32_t k, c
         const int64_t ptr = eb.index;
         const int64_t gptr = ptr + (int64_t)e * c->sub_size;
         const int i = s.count++;
-        s.slot[i] = (int)gptr;
-        memcpy(s.obs + (size_t)i * Do, obs + (size_t)j * Do, (size_t)Do * 4);
-        memcpy(s.obs_next + (size_t)i * Do, obs_next + (size_t)j * Do, (size_t)Do * 4);
-        memcpy(s.act + (size_t)i * Da, act + (size_t)j * Da, (size_t)Da * 4);
-        s.rew[i] = rew[j];
-        s.cost[i] = cost ? cost[j] : 0.0;
         const uint8_t fl = (uint8_t)((terminated[j] ? 1 : 0) | (truncated[j] ? 2 : 0));
-        s.flags[i] = fl;
+        {
+            uint8_t* r = s.h + (size_t)i * rec;
+            const double rw = rew[j], cs = cost ? cost[j] : 0.0;
+            const int32_t sl = (int32_t)gptr; const uint32_t f32 = fl;
+            memcpy(r, &rw, 8); memcpy(r + 8, &cs, 8); memcpy(r + 16, &sl, 4); memcpy(r + 20, &f32, 4);
+            memcpy(r + 24, obs + (size_t)j * Do, (size_t)Do * 4);
+            memcpy(r + 24 + (size_t)Do * 4, obs_next + (size_t)j * Do, (size_t)Do * 4);
+            memcpy(r + 24 + (size_t)Do * 8, act + (size_t)j * Da, (size_t)Da * 4);
+        }
         c->h_flags[(size_t)gptr] = fl;
         // ReplayBuffer.add bookkeeping (ptr, ep_rew, ep_len, ep_idx)
         eb.last_index = ptr;
@@ -1107,6 +1112,72 @@ extern "C" int fsrl_last_timing(fsrl_ctx* c, double* out, int32_t n) {
     CHECK_ARG(c && out && n >= 4, "need room for 4 doubles");
     out[0] = c->t_process_ms; out[1] = c->t_learn_ms; out[2] = c->t_fwdbwd_ms; out[3] = (double)c->n_fwdbwd;
     if (n >= 5) out[4] = c->t_fwdbwd_raw_ms;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ launch floors (measured, bench.py)
+// What no kernel work can remove from one PPO optimiser step: its three dependent launches.  Three EMPTY kernels with the grids,
+// block sizes and LDS footprints of the step's kernels (fused forward/backward, weight gradients, clip + Adam) for a minibatch
+// of `mb_rows` rows run `iters` times back to back on the compute stream, bracketed by events: out_us[0..2] = one launch of each
+// grid behind itself, out_us[3] = the triple behind itself (what a step's launches cost with nothing in them).
+template <int NT>
+__global__ __launch_bounds__(NT) void floor_kernel(int* sink) {
+    extern __shared__ float floor_lds[];
+    if (sink && threadIdx.x == 4095) sink[0] = (int)floor_lds[0];          // never true: keeps the LDS allocation alive
+}
+extern "C" int fsrl_launch_floors(fsrl_ctx* c, int32_t mb_rows, int32_t iters, double* out_us) {
+    CHECK_ARG(c && out_us && mb_rows >= 1 && iters >= 1 && iters <= 100000, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    const int H = c->cfg.hidden, nn = c->md.n_nets;
+    const int tiles = (mb_rows + 15) / 16;
+    const bool rows4 = tiles * 4 * nn <= c->n_cus, rows8 = !rows4 && tiles * 2 * nn <= c->n_cus;
+    const int g_fb = rows4 ? tiles * 4 * nn : rows8 ? tiles * 2 * nn : tiles * nn;
+    const int g_wg = nn * ((H / 32) * (H / 32) + H / 32) + 1;
+    const int g_ad = (c->n_dev + 4 * ADAM_NT - 1) / (4 * ADAM_NT);
+    size_t lds_fb = 0, lds_wg = 0;
+    int rc = dispatch_H(H, [&](auto hc) {
+        constexpr int HH = decltype(hc)::value;
+        hipFuncAttributes fa{};
+        const void* f = rows4 ? (const void*)ppo_fwd_bwd_kernel<HH, 4> : rows8 ? (const void*)ppo_fwd_bwd_kernel<HH, 8>
+                                                                              : (const void*)ppo_fwd_bwd_kernel<HH, 16>;
+        HIPCHK(hipFuncGetAttributes(&fa, f));
+        lds_fb = fa.sharedSizeBytes;
+        HIPCHK(hipFuncGetAttributes(&fa, (const void*)ppo_wgrad_kernel<HH, false, false>));
+        lds_wg = fa.sharedSizeBytes;
+        return 0;
+    });
+    if (rc) return rc;
+    const int nt_fb = 4 * H;
+    auto launch = [&](int which) {
+        hipStream_t s = c->compute;
+        if (which == 0) {
+            if (nt_fb == 1024) hipLaunchKernelGGL(floor_kernel<1024>, dim3(g_fb), dim3(1024), lds_fb, s, (int*)nullptr);
+            else if (nt_fb == 512) hipLaunchKernelGGL(floor_kernel<512>, dim3(g_fb), dim3(512), lds_fb, s, (int*)nullptr);
+            else hipLaunchKernelGGL(floor_kernel<256>, dim3(g_fb), dim3(256), lds_fb, s, (int*)nullptr);
+        } else if (which == 1) hipLaunchKernelGGL(floor_kernel<1024>, dim3(g_wg), dim3(1024), lds_wg, s, (int*)nullptr);
+        else hipLaunchKernelGGL(floor_kernel<ADAM_NT>, dim3(g_ad), dim3(ADAM_NT), 0, s, (int*)nullptr);
+    };
+    const size_t lds_max = std::max(lds_fb, lds_wg);
+    HIPCHK(hipFuncSetAttribute((const void*)floor_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    HIPCHK(hipFuncSetAttribute((const void*)floor_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    HIPCHK(hipFuncSetAttribute((const void*)floor_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    for (int m = 0; m < 4; ++m) {
+        for (int w = 0; w < 8; ++w) launch(m < 3 ? m : w % 3);                       // warm the code objects
+        HIPCHK(hipEventRecord(e0, c->compute));
+        for (int i = 0; i < iters; ++i) {
+            if (m < 3) launch(m);
+            else { launch(0); launch(1); launch(2); }
+        }
+        HIPCHK(hipEventRecord(e1, c->compute));
+        HIPCHK(hipEventSynchronize(e1));
+        HIPCHK(hipGetLastError());
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        out_us[m] = (double)ms * 1e3 / iters;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return 0;
 }
 

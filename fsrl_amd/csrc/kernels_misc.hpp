@@ -16,19 +16,22 @@ struct StorePtrs {
     uint8_t* flags;   // [maxsize] bit0 terminated, bit1 truncated
 };
 
-__global__ void store_scatter_kernel(StorePtrs st, const int* __restrict__ slot,
-                                     const float* __restrict__ obs, const float* __restrict__ obs_next,
-                                     const float* __restrict__ act, const double* __restrict__ rew,
-                                     const double* __restrict__ cost, const uint8_t* __restrict__ flags,
-                                     int k, int Do, int Da) {
+// rows arrive as packed records (host: struct Staging): rew f64 | cost f64 | slot i32 | flags u32 | obs[Do] | obs_next[Do] | act[Da]
+__global__ void store_scatter_kernel(StorePtrs st, const uint8_t* __restrict__ recs, const int rec, int k, int Do, int Da) {
     const int per = 2 * Do + Da + 1;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < k * per; e += gridDim.x * blockDim.x) {
         const int row = e / per, f = e - row * per;
-        const size_t dst = (size_t)slot[row];
-        if (f < Do) st.obs[dst * Do + f] = obs[(size_t)row * Do + f];
-        else if (f < 2 * Do) st.obs_next[dst * Do + (f - Do)] = obs_next[(size_t)row * Do + (f - Do)];
-        else if (f < 2 * Do + Da) st.act[dst * Da + (f - 2 * Do)] = act[(size_t)row * Da + (f - 2 * Do)];
-        else { st.rew[dst] = rew[row]; st.cost[dst] = cost[row]; st.flags[dst] = flags[row]; }
+        const uint8_t* r = recs + (size_t)row * rec;
+        const size_t dst = (size_t)*reinterpret_cast<const int*>(r + 16);
+        const float* x = reinterpret_cast<const float*>(r + 24);
+        if (f < Do) st.obs[dst * Do + f] = x[f];
+        else if (f < 2 * Do) st.obs_next[dst * Do + (f - Do)] = x[f];
+        else if (f < 2 * Do + Da) st.act[dst * Da + (f - 2 * Do)] = x[f];
+        else {
+            st.rew[dst] = *reinterpret_cast<const double*>(r);
+            st.cost[dst] = *reinterpret_cast<const double*>(r + 8);
+            st.flags[dst] = (uint8_t)*reinterpret_cast<const uint32_t*>(r + 20);
+        }
     }
 }
 

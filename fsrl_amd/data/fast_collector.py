@@ -160,20 +160,7 @@ class FastCollector:
         ep_rews, ep_lens = [], []
         obs = np.asarray(obs, np.float32)
         if self.native_loop is True and hasattr(self.env, "native_desc") and not gym_reset_kwargs:
-            # worker-process env: the WHOLE collect -- steps, store, actor, resets, episode accounting, surplus envs -- in one
-            # library call (fsrl_collect_episodes); native_loop="run" keeps the episode boundaries in this loop (fsrl_collect_run)
-            r = eng.collect_episodes(self.env.native_desc(), ready, obs, n_episode, det, bound, low, high)
-            self.env.sync_native()
-            self.buffer.sync_sizes()
-            self.collect_step += r["steps"]
-            self.collect_episode += len(r["ep_rews"])
-            self.collect_time += max(time.time() - t0, 1e-9)
-            self.reset_env()
-            done_count = r["terminated"] + r["truncated"]
-            return {"n/ep": len(r["ep_rews"]), "n/st": r["steps"], "rew": float(r["ep_rews"].mean()),
-                    "len": float(r["ep_lens"].mean()), "total_cost": r["total_cost"],
-                    "cost": r["total_cost"] / len(r["ep_rews"]), "truncated": r["truncated"] / done_count,
-                    "terminated": r["terminated"] / done_count}
+            return self._collect_native(eng, n_episode, ready, obs, t0, det, bound, low, high, split=False)
         act, env_act, _, _ = eng.collect_step(None, obs, det, bound, low, high)
         clock = time.perf_counter
         t_env = t_act = 0.0
@@ -190,9 +177,11 @@ class FastCollector:
                 self._t_env, self._t_act = t_env, t_act
                 self.split_phase = t_env > 1.25 * t_act           # takes over from the next collect() on
             if native and not probing:
-                k_steps, csum, obs, act, rew, cost, terminated, truncated, obs_next = eng.collect_run(
-                    self.env.native_desc(), ready, obs, act, env_act, det, bound, low, high)
-                self.env.sync_native()
+                try:
+                    k_steps, csum, obs, act, rew, cost, terminated, truncated, obs_next = eng.collect_run(
+                        self.env.native_desc(), ready, obs, act, env_act, det, bound, low, high)
+                finally:
+                    self.env.sync_native()
                 done = terminated | truncated
                 total_cost += csum
                 step_count += len(ready) * k_steps
@@ -247,6 +236,32 @@ class FastCollector:
                 "cost": total_cost / episode_count, "truncated": trunc_count / done_count,
                 "terminated": term_count / done_count}
 
+    def _collect_native(self, eng, n_episode, ready, obs, t0, det, bound, low, high, split):
+        """worker-process env: the WHOLE collect -- steps, store, actor, resets, episode accounting, surplus envs -- in one library
+        call (fsrl_collect_episodes, or its two-lane split-phase form).  The env's generation counters travel through the call:
+        they are read back even when it fails, so the env object stays consistent with its shared block (a worker that raised
+        or died fails the call within half a second; the env itself is then unusable and says so on its next command)."""
+        try:
+            r = eng.collect_episodes(self.env.native_desc(), ready, obs, n_episode, det, bound, low, high, split=split)
+        finally:
+            self.env.sync_native()
+        self.buffer.sync_sizes()
+        self.collect_step += r["steps"]
+        self.collect_episode += len(r["ep_rews"])
+        self.collect_time += max(time.time() - t0, 1e-9)
+        if self._split_auto and not self._split_decided:
+            # the first collect ran single-phase and timed its two halves in C: the split loop takes over when the env's vector
+            # step outweighs the store + actor call it can hide behind the other lane's step
+            self._split_decided = True
+            self._t_env, self._t_act = r["t_env"], r["t_act"]
+            self.split_phase = r["t_env"] > 1.25 * r["t_act"]
+        self.reset_env()
+        done_count = r["terminated"] + r["truncated"]
+        return {"n/ep": len(r["ep_rews"]), "n/st": r["steps"], "rew": float(r["ep_rews"].mean()),
+                "len": float(r["ep_lens"].mean()), "total_cost": r["total_cost"],
+                "cost": r["total_cost"] / len(r["ep_rews"]), "truncated": r["truncated"] / done_count,
+                "terminated": r["terminated"] / done_count}
+
     def _collect_split(self, eng, n_episode, ready, obs, t0, gym_reset_kwargs):
         """The fused loop over the two lanes of a worker-process env: while lane A's workers step, the collector stores lane
         B's finished transitions, evaluates the actor on lane B's next observations and starts lane B's step.  Episode
@@ -258,6 +273,8 @@ class FastCollector:
         bound = {"": 0, "clip": 1, "tanh": 2}[pol.action_bound_method] if space is not None else 0
         low = np.asarray(space.low, np.float32) if (space is not None and pol.action_scaling) else None
         high = np.asarray(space.high, np.float32) if low is not None else None
+        if self.native_loop is True and hasattr(env, "native_desc") and not gym_reset_kwargs:
+            return self._collect_native(eng, n_episode, ready, np.asarray(obs, np.float32), t0, det, bound, low, high, split=True)
         step_count, total_cost, episode_count, term_count, trunc_count = 0, 0.0, 0, 0, 0
         ep_rews, ep_lens = [], []
         obs = np.asarray(obs, np.float32)

@@ -293,9 +293,10 @@ class Engine:
         return (st["steps"].value, st["csum"].value, a["obs"][:n].copy(), a["act"][:n].copy(), a["rew"][:n].copy(),
                 a["cost"][:n].copy(), a["term"][:n].astype(bool), a["trunc"][:n].astype(bool), a["nxt"][:n].copy())
 
-    def collect_episodes(self, env_desc, ready, obs, n_episode, deterministic=False, bound_method=1, low=None, high=None):
+    def collect_episodes(self, env_desc, ready, obs, n_episode, deterministic=False, bound_method=1, low=None, high=None, split=False):
         """FastCollector.collect(n_episode) over a worker-process env in ONE C call (fsrl_collect_episodes): vector steps, store,
-        actor, resets, episode accounting, surplus envs.  -> dict(steps, total_cost, terminated, truncated, ep_rews, ep_lens)"""
+        actor, resets, episode accounting, surplus envs.  split: the two-lane split-phase form (fsrl_collect_episodes_split).
+        -> dict(steps, total_cost, terminated, truncated, ep_rews, ep_lens, t_env, t_act)"""
         Do, Da = self.cfg.obs_dim, self.cfg.act_dim
         n = len(ready)
         ids = np.ascontiguousarray(ready, np.int32)
@@ -305,13 +306,16 @@ class Engine:
         steps, cost = C.c_int64(), C.c_double()
         nt, ntr, nep = C.c_int32(), C.c_int32(), C.c_int32()
         ep_rew, ep_len = np.zeros(int(n_episode), np.float64), np.zeros(int(n_episode), np.int32)
-        _lib.check(self.lib.fsrl_collect_episodes(
+        fn = self.lib.fsrl_collect_episodes_split if split else self.lib.fsrl_collect_episodes
+        _lib.check(fn(
             self._ctx, C.byref(env_desc), _ptr(ids, _i32p), n, _ptr(ob, _f32p), int(n_episode), int(deterministic), int(bound_method),
             _ptr(lo, _f32p) if lo is not None else None, _ptr(hi, _f32p) if hi is not None else None, C.byref(steps), C.byref(cost),
             C.byref(nt), C.byref(ntr), _ptr(ep_rew, _f64p), _ptr(ep_len, _i32p), C.byref(nep)))
         k = nep.value
+        tm = np.zeros(2, np.float64)
+        _lib.check(self.lib.fsrl_collect_timing(self._ctx, _ptr(tm, _f64p)))
         return dict(steps=int(steps.value), total_cost=float(cost.value), terminated=int(nt.value), truncated=int(ntr.value),
-                    ep_rews=ep_rew[:k], ep_lens=ep_len[:k])
+                    ep_rews=ep_rew[:k], ep_lens=ep_len[:k], t_env=float(tm[0]), t_act=float(tm[1]))
 
     def store_sizes(self, n=None):
         n = self.cfg.env_num if n is None else int(n)
@@ -402,6 +406,12 @@ class Engine:
                                             _ptr(rew, _f64p), _ptr(end, _u8p), rew.size, float(gamma),
                                             float(gae_lambda), _ptr(out, _f64p)))
         return out
+
+    def launch_floors(self, mb_rows=256, iters=200):
+        """fsrl_launch_floors: {"fwdbwd", "wgrad", "adam", "triple"} in microseconds, measured now on this device."""
+        out = np.zeros(4, np.float64)
+        _lib.check(self.lib.fsrl_launch_floors(self._ctx, int(mb_rows), int(iters), _ptr(out, _f64p)))
+        return dict(zip(("fwdbwd", "wgrad", "adam", "triple"), out.tolist()))
 
     def nstep_return(self, metric, end_flag, target_q, indices, gamma, n_step):
         """nstep_return (base_policy.py:543-567) on the device; target_q [bsz, ...] float32, indices [n_step, bsz]."""

@@ -57,7 +57,9 @@ def _layout(env_num, obs_dim, act_dim, workers):
               ("active", (env_num, ), np.uint8),
               # handshake words, one 64-byte line each: per lane (generation | pending workers | command), per worker the
               # generation of the last command it takes part in
-              ("hs", (2, 3, 16), np.uint32), ("want", (workers, 16), np.uint32)]
+              ("hs", (2, 3, 16), np.uint32), ("want", (workers, 16), np.uint32),
+              # per worker: non-zero once it raised inside its env (the collector checks it after every wait)
+              ("err", (workers, 16), np.uint32)]
     out, off = {}, 0
     for name, shape, dt in fields:
         out[name] = (off, shape, dt)
@@ -96,8 +98,10 @@ def _worker(w, lane, lo, hi, shm_name, env_num, workers, obs_dim, act_dim, spec,
     sl, all_local = slice(lo, hi), np.arange(hi - lo)
     v_active, v_obs, v_act, v_rew, v_cost, v_term, v_trunc = (v[k] for k in ("active", "obs", "act", "rew", "cost", "term", "trunc"))
     seen = 0
+    in_cmd = False
     try:
         while True:
+            in_cmd = False
             g = lib.fsrl_env_wait_go(gen_p, seen, spin, 1000)
             if g == seen:                          # a second without a command: is the collector still there?
                 if os.getppid() != parent:
@@ -109,6 +113,7 @@ def _worker(w, lane, lo, hi, shm_name, env_num, workers, obs_dim, act_dim, spec,
                 break
             if int(want_w[0]) != g:                # this command does not touch my envs
                 continue
+            in_cmd = True
             act_w = v_active[sl]
             if act_w.all():                        # the whole slice (the steady state): basic slices, no index arrays
                 local, gi = all_local, sl
@@ -124,6 +129,13 @@ def _worker(w, lane, lo, hi, shm_name, env_num, workers, obs_dim, act_dim, spec,
                     v_obs[gi] = obs; v_rew[gi] = rew; v_cost[gi] = info["cost"]
                     v_term[gi] = term; v_trunc[gi] = trunc
             lib.fsrl_env_done(pend_p)
+    except BaseException:
+        # an exception inside the user's env: say so in the shared block and release the collector (it checks the error
+        # words after every wait and raises), then let the traceback reach stderr
+        v["err"][w, 0] = 1
+        if in_cmd:
+            lib.fsrl_env_done(pend_p)
+        raise
     finally:
         env.close()
         del v, cmd_w, want_w, v_active, v_obs, v_act, v_rew, v_cost, v_term, v_trunc
@@ -131,8 +143,8 @@ def _worker(w, lane, lo, hi, shm_name, env_num, workers, obs_dim, act_dim, spec,
 
 
 class ShmemVectorEnv:
-    def __init__(self, env_num=32, workers=None, obs_dim=8, act_dim=2, episode_len=300, seed=0, busy_us=0.0, cores=None,
-                 start_method="spawn", spin_us=None, env_fns=None):
+    def __init__(self, env_num=32, workers=None, obs_dim=8, act_dim=2, episode_len=300, seed=None, busy_us=0.0, cores=None,
+                 start_method="spawn", spin_us=None, env_fns=None, cap_workers=True):
         """Two ways to say what the workers step: the synthetic dynamics (`env_num`, `obs_dim`, ... ; the bench), or
         `env_fns` -- one factory per env, the reference's `ShmemVectorEnv([lambda: gym.make(task) for _ in range(n)])`
         (also accepted as the first positional argument).  Factories travel to the spawned workers with cloudpickle, so
@@ -141,6 +153,8 @@ class ShmemVectorEnv:
         if env_fns is None and not isinstance(env_num, (int, np.integer)):
             env_fns, env_num = env_num, None
         fns_pickled = None
+        if env_fns is None and seed is None:
+            seed = 0                                          # the synthetic dynamics are always seeded (the bench's default)
         if env_fns is not None:
             import cloudpickle
             env_fns = list(env_fns)
@@ -160,6 +174,16 @@ class ShmemVectorEnv:
             self.spec = SimpleNamespace(id="SyntheticSafety-v0", max_episode_steps=episode_len)
         workers = env_num if workers is None else int(workers)
         assert 1 <= workers <= env_num
+        # cap_workers: never more worker PROCESSES than CPUs this process may use (affinity and cgroup quota; the rank's core
+        # slice when `cores` is given) -- the surplus envs are spread over the workers, several envs per process.  32 processes
+        # on 16 CPUs run in two rounds either way; half the processes do it without the context switches and with half the
+        # wake-ups per vector step (measured: 32 envs x 0 us, 32 requested workers: 352 k -> the 16-process figure).  tianshou
+        # always runs one process per env; cap_workers=False restores that.
+        self.workers_requested = workers
+        if cap_workers:
+            from fsrl_amd.parallel import usable_cpus
+            cap = max(1, int(min(usable_cpus(), len(cores)) if cores else usable_cpus()))
+            workers = max(1, min(workers, cap))
         self.env_num, self.obs_dim, self.act_dim, self.workers = env_num, obs_dim, act_dim, workers
         self.episode_len, self.busy_us = episode_len, busy_us
         self._lib = _load_lib()
@@ -199,6 +223,7 @@ class ShmemVectorEnv:
                                                   act_dim, spec, core, self._spin), daemon=True)
             p.start()
             self._procs.append(p)
+        self._pids = np.array([p.pid for p in self._procs], np.int32)
         self.lane_of_env = self._lane_of_worker[self._owner]
         self.lanes = [np.flatnonzero(self.lane_of_env == l) for l in range(self.n_lanes)]
         # lanes are contiguous env / worker ranges: the steady state (a command for a whole lane) uses basic slices
@@ -246,6 +271,9 @@ class ShmemVectorEnv:
                 self._inflight[lane] = None
                 raise RuntimeError(f"env workers {dead or 'of lane %d' % lane} did not answer")
         self._inflight[lane] = None
+        if self._v["err"][:, 0].any():
+            bad = np.flatnonzero(self._v["err"][:, 0]).tolist()
+            raise RuntimeError(f"env workers {bad} raised inside their env (traceback on their stderr); the vector env cannot be used any more")
         return ids
 
     def _split(self, ids):
@@ -261,13 +289,17 @@ class ShmemVectorEnv:
             self._wait(l)
 
     def reset(self, ids=None, **kwargs):
+        if kwargs:                    # the workers call env.reset(local): nothing carries keyword arguments to them
+            raise TypeError(f"ShmemVectorEnv.reset does not forward reset kwargs to its workers: {sorted(kwargs)}")
         ids = np.arange(self.env_num) if ids is None else np.asarray(ids)
         self._run(_CMD_RESET, ids)
         return self._v["obs"][ids].copy(), {}
 
     def _results(self, ids):
         v = self._v
-        if len(ids) and len(ids) == int(ids[-1]) - int(ids[0]) + 1:       # a contiguous range (sorted unique ids): basic slices
+        # a contiguous ascending range: basic slices.  The length test alone also holds for a permuted range like [0, 2, 1, 3]
+        # (step(act, ids) accepts any order), so the order is checked as well
+        if len(ids) and len(ids) == int(ids[-1]) - int(ids[0]) + 1 and (len(ids) == 1 or bool((np.diff(ids) == 1).all())):
             ids = slice(int(ids[0]), int(ids[-1]) + 1)
             return (v["obs"][ids].copy(), v["rew"][ids].copy(), v["term"][ids].astype(bool), v["trunc"][ids].astype(bool),
                     {"cost": v["cost"][ids].copy()})
@@ -293,6 +325,7 @@ class ShmemVectorEnv:
             for k in ("obs", "act", "rew", "cost", "term", "trunc", "active", "hs", "want"):
                 setattr(d, k, v[k].ctypes.data)
             d.owner, d.lane_of_worker = self._owner32.ctypes.data, self._low32.ctypes.data
+            d.err, d.pids = v["err"].ctypes.data, self._pids.ctypes.data
             d.env_num, d.obs_dim, d.act_dim, d.workers, d.n_lanes = self.env_num, self.obs_dim, self.act_dim, self.workers, self.n_lanes
             d.spin = self._spin
             self._desc = d

@@ -14,11 +14,22 @@ and the safety cost of a step is `info["cost"]` (Bullet-Safety-Gym / Safety-Gymn
 import numpy as np
 
 
+def _accepts_seed(env):
+    """does env.reset take a `seed` keyword (gymnasium / gym >= 0.22)?  Decided from the signature, not by catching the
+    TypeError of a trial call -- a TypeError raised INSIDE a user's reset must reach the user."""
+    import inspect
+    try:
+        params = inspect.signature(env.reset).parameters
+    except (TypeError, ValueError):
+        return True
+    return "seed" in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+
+
 def _reset_one(env, seed, kwargs):
     if seed is not None:
-        try:
+        if _accepts_seed(env):
             out = env.reset(seed=int(seed), **kwargs)
-        except TypeError:                                   # old gym: env.seed(s); env.reset()
+        else:                                               # old gym: env.seed(s); env.reset()
             if hasattr(env, "seed"):
                 env.seed(int(seed))
             out = env.reset(**kwargs)

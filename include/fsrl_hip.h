@@ -100,8 +100,10 @@ int fsrl_params_set(fsrl_ctx* ctx, const float* flat, int64_t n);
 int fsrl_params_get(fsrl_ctx* ctx, float* flat, int64_t n);
 int fsrl_grads_get(fsrl_ctx* ctx, float* flat, int64_t n);   /* last minibatch gradient  */
 int fsrl_optim_reset(fsrl_ctx* ctx);                /* zero Adam moments and step count  */
-/* Device-resident checkpoint of the training state of an on-policy context (parameters with their W2 mirrors, Adam
- * moments, step counts), kept in HBM: snapshot / restore are device-to-device copies on the compute stream, no host round
+/* Device-resident checkpoint of the training state of an ON-POLICY context (PPO-Lag, FOCOPS, CPO, TRPO-Lag: parameters with
+ * their W2 mirrors, Adam moments, step counts, and with reward_normalization the running return statistics), kept in HBM; the
+ * collector's noise stream and the library's shuffle stream are NOT part of it.  Replay contexts (SAC / DDPG / CVPO keep actor,
+ * Q, target and alpha state of their own) are refused with FSRL_EINVAL. snapshot / restore are device-to-device copies on the compute stream, no host round
  * trip and no synchronisation.  The reference has no counterpart (copy.deepcopy(policy.state_dict()) is the host-side
  * equivalent); bench.py restores the same start state before every timed update with it.                                */
 int fsrl_state_snapshot(fsrl_ctx* ctx);
@@ -183,6 +185,9 @@ typedef struct fsrl_shm_env {
     int32_t env_num, obs_dim, act_dim, workers, n_lanes;
     uint32_t gen[2];            /* in / out: last generation posted per lane                           */
     uint32_t spin;              /* polls before the collector sleeps on a lane's completion word       */
+    const uint32_t* err;        /* [workers][16] or NULL: non-zero once a worker raised inside its env */
+    const int32_t* pids;        /* [workers] or NULL: the workers' process ids (children of the caller): a killed worker
+                                 * fails the native collect within 0.5 s instead of after the 60 s handshake timeout */
 } fsrl_shm_env;
 /* FastCollector.collect's inner loop (fast_collector.py:252-340) over that env, in C: starting from the envs `ready`
  * with observations obs[n], policy actions act[n] and mapped actions env_act[n] (the outputs of the last
@@ -206,6 +211,16 @@ int fsrl_collect_episodes(fsrl_ctx* ctx, fsrl_shm_env* env, const int32_t* ready
                           int32_t deterministic, int32_t bound_method, const float* act_low, const float* act_high,
                           int64_t* steps_out, double* total_cost_out, int32_t* term_count_out, int32_t* trunc_count_out,
                           double* ep_rew_out, int32_t* ep_len_out, int32_t* episodes_out);
+
+/* The same collect, split-phase over the env's two lanes (needs n_lanes == 2): one lane's workers step while the collector stores
+ * the other lane's transitions and evaluates the actor on its next observations; exactly n_episode episodes, global surplus rule
+ * (fast_collector.py:341-362).  Rows and noise stream equal the interpreted split loop's (FastCollector._collect_split).   */
+int fsrl_collect_episodes_split(fsrl_ctx* ctx, fsrl_shm_env* env, const int32_t* ready, int32_t n, const float* obs, int32_t n_episode,
+                                int32_t deterministic, int32_t bound_method, const float* act_low, const float* act_high,
+                                int64_t* steps_out, double* total_cost_out, int32_t* term_count_out, int32_t* trunc_count_out,
+                                double* ep_rew_out, int32_t* ep_len_out, int32_t* episodes_out);
+/* out2[0] = seconds the last fsrl_collect_episodes[_split] waited for the env workers, out2[1] = seconds in its store + actor calls */
+int fsrl_collect_timing(fsrl_ctx* ctx, double* out2);
 
 /* Fill level of the first n sub-buffers (len(buffer.buffers[e]); ReplayBufferManager.sample_indices weighs by it). */
 int fsrl_store_sizes(const fsrl_ctx* ctx, int64_t* sizes_out, int32_t n);
@@ -465,6 +480,12 @@ int fsrl_cvpo_last_particles(fsrl_ctx* ctx, float* eps_particles, int64_t n);
  * overhead correction).                                                                   */
 int fsrl_set_profiling(fsrl_ctx* ctx, int enable);
 int fsrl_last_timing(fsrl_ctx* ctx, double* out, int32_t n);
+
+/* The part of a PPO optimiser step (ppo_lag.py:224-243: forward/backward, clip, Adam = three dependent launches here) that no
+ * kernel work can remove, measured on this device: empty kernels with the step's grids, block sizes and LDS footprints for a
+ * minibatch of mb_rows rows, `iters` times back to back on the compute stream.  out_us[0..2] = one launch of the forward/backward,
+ * weight-gradient and Adam grid behind itself, out_us[3] = the three behind each other (microseconds per launch / per triple). */
+int fsrl_launch_floors(fsrl_ctx* ctx, int32_t mb_rows, int32_t iters, double* out_us);
 
 /* ---- the one collective of the multi-GPU layout: independent agents, one process per GPU; once per epoch the
  *      ranks sum a short float64 metric vector [n_st, n_ep, sum rew, sum cost, ...] (fsrl_amd/parallel.py EPOCH_KEYS).  The

@@ -198,3 +198,66 @@ def test_native_collector_loop_stores_the_rows_of_the_interpreted_loop(workers):
         for k in rows_p:
             assert np.array_equal(rows_n[k], rows_p[k]), (mode, k)
     assert rows_p["act"].std() > 0.1                       # the noise was on
+
+
+@pytest.mark.parametrize("workers", [2, 6])
+def test_native_split_phase_collect_stores_the_rows_of_the_interpreted_split_loop(workers):
+    """fsrl_collect_episodes_split (the two-lane split-phase collect as ONE library call) against FastCollector._collect_split
+    driven from Python: the same library calls in the same order -> the same rows in the same slots, the same noise stream
+    (exploration noise ON), the same statistics -- also for episode counts at which envs are dropped mid-way."""
+    from fsrl_amd.agent import PPOLagAgent
+    from fsrl_amd.data import FastCollector, HipVectorReplayBuffer
+    from fsrl_amd.env import ShmemVectorEnv
+
+    def run(native):
+        env = ShmemVectorEnv(env_num=6, workers=workers, obs_dim=8, act_dim=2, episode_len=19, seed=4)
+        try:
+            agent = PPOLagAgent(env, None, cost_limit=10, device="cuda:0", seed=2, hidden_sizes=(64, 64), training_num=6)
+            agent.policy.train()
+            eng = agent.policy.engine
+            buf = HipVectorReplayBuffer(eng, 6 * 300, 6)
+            col = FastCollector(agent.policy, env, buf, exploration_noise=True, device_actor=True, split_phase=True, native_loop=native)
+            assert col.split_phase
+            eng.actor_sample(np.zeros((1, 8), np.float32), seed=77)            # key the library stream identically
+            stats = [col.collect(n_episode=n) for n in (6, 10, 3, 1, 7, 12)]
+            idx = eng.sample0()
+            rows = eng.store_read(idx)
+            eng.close()
+            return stats, idx, rows
+        finally:
+            env.close()
+
+    st_p, idx_p, rows_p = run(False)
+    st_n, idx_n, rows_n = run(True)
+    assert np.array_equal(idx_n, idx_p)
+    for a, b in zip(st_n, st_p):
+        assert a == b, (a, b)
+    for k in rows_p:
+        assert np.array_equal(rows_n[k], rows_p[k]), k
+    assert rows_p["act"].std() > 0.1 and [s["n/ep"] for s in st_n] == [6, 10, 3, 1, 7, 12]
+
+
+def test_native_collect_fails_fast_on_a_dead_worker_and_leaves_the_env_object_consistent():
+    """A worker that dies mid-collect fails the native collect within seconds (the C wait looks at the workers between 0.5 s
+    sleeps instead of waiting out the 60 s handshake timeout), and the env's generation counters are read back even though
+    the call raised (FastCollector wraps it in try / finally)."""
+    import time
+    from fsrl_amd.agent import PPOLagAgent
+    from fsrl_amd.data import FastCollector, HipVectorReplayBuffer
+    from fsrl_amd.env import ShmemVectorEnv
+    env = ShmemVectorEnv(env_num=4, workers=2, obs_dim=8, act_dim=2, episode_len=50, seed=1)
+    try:
+        agent = PPOLagAgent(env, None, cost_limit=10, device="cuda:0", seed=2, hidden_sizes=(64, 64), training_num=4)
+        eng = agent.policy.engine
+        buf = HipVectorReplayBuffer(eng, 4 * 300, 4)
+        col = FastCollector(agent.policy, env, buf, exploration_noise=True, device_actor=True)
+        col.collect(n_episode=4)
+        env._procs[1].terminate(); env._procs[1].join(5)
+        t0 = time.time()
+        with pytest.raises(Exception, match="worker"):
+            col.collect(n_episode=4)
+        assert time.time() - t0 < 10.0
+        assert env._gen[0] == int(env._desc.gen[0]) and env._gen[1] == int(env._desc.gen[1])
+        eng.close()
+    finally:
+        env.close()

@@ -250,3 +250,95 @@ def test_collector_wraps_a_single_env():
         col = FastCollector(_Pol(), PointCircleEnv(max_episode_steps=7), None)
     st = col.collect(n_episode=3, random=True)
     assert col.env_num == 1 and st["n/ep"] == 3 and st["n/st"] == 21
+
+
+def test_step_with_permuted_ids_returns_rows_in_the_requested_order():
+    """step(act, ids) takes ids in any order; a permuted contiguous range like [0, 2, 1, 3] must not take the slice shortcut."""
+    from fsrl_amd.env import ShmemVectorEnv
+    a = ShmemVectorEnv(env_num=4, workers=2, episode_len=50, seed=5)
+    b = ShmemVectorEnv(env_num=4, workers=2, episode_len=50, seed=5)
+    try:
+        a.reset(); b.reset()
+        rng = np.random.default_rng(0)
+        for _ in range(5):
+            act = rng.standard_normal((4, 2)).astype(np.float32)
+            perm = np.array([0, 2, 1, 3])
+            oa, ra, ta, ua, ia = a.step(act, np.arange(4))
+            ob, rb, tb, ub, ib = b.step(act[perm], perm)
+            assert np.array_equal(ob, oa[perm]) and np.array_equal(rb, ra[perm]) and np.array_equal(ib["cost"], ia["cost"][perm])
+    finally:
+        a.close(); b.close()
+
+
+class _Raises:
+    """an env whose third step raises (picklable: module level)"""
+    class _Space:
+        shape = (3, )
+        low = -np.ones(3, np.float32); high = np.ones(3, np.float32)
+    observation_space = action_space = _Space()
+
+    def __init__(self):
+        self.t = 0
+
+    def reset(self, seed=None):
+        self.t = 0
+        return np.zeros(3, np.float32), {}
+
+    def step(self, a):
+        self.t += 1
+        if self.t == 3:
+            raise ValueError("boom inside the user's env")
+        return np.zeros(3, np.float32), 0.0, False, False, {}
+
+
+def test_an_exception_inside_a_workers_env_reaches_the_collector_quickly():
+    import time
+    from fsrl_amd.env import ShmemVectorEnv
+    env = ShmemVectorEnv([_Raises, _Raises], workers=2, seed=None)
+    try:
+        env.reset()
+        act = np.zeros((2, 3), np.float32)
+        env.step(act); env.step(act)
+        t0 = time.time()
+        with pytest.raises(RuntimeError, match="raised inside"):
+            env.step(act)
+        assert time.time() - t0 < 5.0
+    finally:
+        env.close()
+
+
+def test_reset_kwargs_are_refused_not_dropped_and_typeerrors_of_a_users_reset_are_not_masked():
+    from fsrl_amd.env import DummyVectorEnv, ShmemVectorEnv
+    env = ShmemVectorEnv(env_num=2, workers=1, episode_len=5, seed=1)
+    try:
+        with pytest.raises(TypeError, match="reset kwargs"):
+            env.reset(options={"x": 1})
+    finally:
+        env.close()
+
+    class Bad(_Raises):
+        def reset(self, seed=None):
+            raise TypeError("a bug in the user's reset")
+
+    with pytest.raises(TypeError, match="user's reset"):
+        DummyVectorEnv([Bad], seed=3).reset()
+
+
+def test_worker_processes_are_capped_at_the_usable_cpus():
+    from fsrl_amd.env import ShmemVectorEnv
+    from fsrl_amd.parallel import usable_cpus
+    cap = max(1, int(usable_cpus()))
+    env = ShmemVectorEnv(env_num=2 * cap + 3, workers=2 * cap + 3, episode_len=5, seed=1)
+    try:
+        assert env.workers == cap and env.workers_requested == 2 * cap + 3 and len(env._procs) == cap
+        obs, _ = env.reset()
+        assert obs.shape == (2 * cap + 3, 8)
+        o, r, t, u, i = env.step(np.zeros((2 * cap + 3, 2), np.float32))
+        assert o.shape == (2 * cap + 3, 8) and len(i["cost"]) == 2 * cap + 3
+    finally:
+        env.close()
+    env = ShmemVectorEnv(env_num=cap + 2, workers=cap + 2, episode_len=5, seed=1, cap_workers=False)
+    try:
+        assert env.workers == cap + 2
+    finally:
+        env.close()

@@ -19,7 +19,8 @@ from fsrl_amd.engine import Engine, EngineConfig  # noqa: E402
 from oracle.sac_lag import ReplayIndex, SACConfig, SACLagOracle  # noqa: E402
 
 
-def main():
+def main(argv=None, emit=True):
+    """emit: print the JSON line (command line use); bench.py's leg calls main([...], emit=False) and takes the dict."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--envs", type=int, default=10)
@@ -28,7 +29,7 @@ def main():
     ap.add_argument("--updates", type=int, default=1000)
     ap.add_argument("--cpu-updates", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     Do, Da, H, E, B = 33, 8, a.hidden, a.envs, a.batch
     T = a.rows // E
     rng = np.random.default_rng(0)
@@ -113,7 +114,10 @@ def main():
         out["cpu_baseline"] = {"value": 1.0 / cpu, "unit": "updates/s", "cores": 4, "kind": "port",
                                "sample": f"{a.cpu_updates} updates of the same store/batch (oracle, torch fp32)"}
         out["speedup_vs_cpu"] = cpu / dev
-    print(json.dumps(out))
+    eng.close()
+    if emit:
+        print(json.dumps(out))
+    return out
 
 
 if __name__ == "__main__":

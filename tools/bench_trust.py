@@ -24,9 +24,14 @@ def pmc_update_traffic(alg):
     for tag in ("r05", "r04", "r03"):
         f = os.path.join(here, "profiles", f"{tag}_pmc_traffic_updates.json")
         if os.path.exists(f):
-            d = json.load(open(f)).get(alg)
+            j = json.load(open(f))
+            d = j.get(alg)
             if d:
-                return float(d["hbm_bytes_per_update"]), f"profiles/{tag}_pmc_traffic_updates.json"
+                meta = j.get("_meta", {})
+                src = f"profiles/{tag}_pmc_traffic_updates.json"
+                if meta:          # which sources the capture ran (tools/collect_profiles.py): a stale file says so
+                    src += f" (captured at {meta.get('head', '?')}, csrc {meta.get('csrc_sha16', '?')})"
+                return float(d["hbm_bytes_per_update"]), src
     return None, None
 
 
@@ -52,7 +57,9 @@ def orth_theta(o, seed):
     return torch.cat(parts).numpy()
 
 
-def run(kind, obs_dim, act_dim, hid, envs=20, T=1000, ep=1000, repeat=4, cpu_repeat=1):
+def run(kind, obs_dim, act_dim, hid, envs=20, T=1000, ep=1000, repeat=4, cpu_repeat=1, timed=5, emit=True, no_cpu=None):
+    """emit: print the JSON line (command line use); bench.py's legs call with emit=False and take the returned dict."""
+    no_cpu = bool(os.environ.get("FSRL_NO_CPU")) if no_cpu is None else no_cpu
     rng = np.random.default_rng(0)
     obs, act, rew, cost, term, trunc = inputs(rng, envs, T, obs_dim, act_dim, ep)
     eng = Engine(EngineConfig(obs_dim=obs_dim, act_dim=act_dim, hidden=hid, env_num=envs, target_kl=None,
@@ -88,7 +95,7 @@ def run(kind, obs_dim, act_dim, hid, envs=20, T=1000, ep=1000, repeat=4, cpu_rep
 
     device_update()
     times = []
-    for _ in range(5):          # the median of five: the box's CPU quota throttles a process for tens of ms now and then
+    for _ in range(timed):      # the median of five: the box's CPU quota throttles a process for tens of ms now and then
         t0 = time.perf_counter()
         stats = device_update()
         times.append(time.perf_counter() - t0)
@@ -111,8 +118,12 @@ def run(kind, obs_dim, act_dim, hid, envs=20, T=1000, ep=1000, repeat=4, cpu_rep
         # weight-side kernel; the figure below is what the memory side actually moved per update
         roof.update(traffic=tb, traffic_source=src, traffic_gb_per_s=tb / dt / 1e9,
                     algorithmic_input_bytes_per_pass=60 * N)
-    if os.environ.get("FSRL_NO_CPU"):
-        print(json.dumps({"bench": kind, "hip_ms_per_update": dt * 1e3, "roofline": roof})); eng.close(); return
+    if no_cpu:
+        res = {"bench": kind, "hip_ms_per_update": dt * 1e3, "roofline": roof}
+        if emit:
+            print(json.dumps(res))
+        eng.close()
+        return res
     em = lambda a: np.concatenate([a[:, e] for e in range(envs)])
     data = OnPolicyData(obs=em(obs[:-1]), act=em(act), rew=em(rew), cost=em(cost), terminated=em(term),
                         truncated=em(trunc), obs_next=em(obs[1:]), end_flag=em(term | trunc))
@@ -126,14 +137,17 @@ def run(kind, obs_dim, act_dim, hid, envs=20, T=1000, ep=1000, repeat=4, cpu_rep
         _, rows = o.update(data, [0.75], 1 / 1.75, cpu_repeat)
         ostat = rows[0][0]
     cdt = (time.perf_counter() - t0) / cpu_repeat * repeat
-    print(json.dumps({"bench": kind, "obs": obs_dim, "act": act_dim, "hidden": hid, "N": envs * T,
-                      "repeat": repeat, "hip_ms_per_update": dt * 1e3, "hip_updates_per_s": 1 / dt,
-                      "cpu_oracle_ms_per_update_4thr": cdt * 1e3, "speedup": cdt / dt,
-                      "roofline": roof, "cpu_baseline": {"value": 1.0 / cdt, "unit": "updates/s", "cores": 4, "kind": "port",
-                                                         "sample": f"{cpu_repeat} of {repeat} repeats of the same update (oracle, torch fp32)"},
-                      "hip_first_repeat": [float(x) for x in stats[0]],
-                      "oracle_first_repeat": {k: float(v) for k, v in ostat.items()}}))
+    res = {"bench": kind, "obs": obs_dim, "act": act_dim, "hidden": hid, "N": envs * T,
+           "repeat": repeat, "hip_ms_per_update": dt * 1e3, "hip_updates_per_s": 1 / dt,
+           "cpu_oracle_ms_per_update_4thr": cdt * 1e3, "speedup": cdt / dt,
+           "roofline": roof, "cpu_baseline": {"value": 1.0 / cdt, "unit": "updates/s", "cores": 4, "kind": "port",
+                                              "sample": f"{cpu_repeat} of {repeat} repeats of the same update (oracle, torch fp32)"},
+           "hip_first_repeat": [float(x) for x in stats[0]],
+           "oracle_first_repeat": {k: float(v) for k, v in ostat.items()}}
+    if emit:
+        print(json.dumps(res))
     eng.close()
+    return res
 
 
 def run_focops(obs_dim=8, act_dim=2, hid=256, envs=20, T=1000, ep=250, batch=256, repeat=4):

@@ -46,6 +46,20 @@ f = one(f"{tag}_prof_bench/**/*_domain_stats.csv")
 if f:
     shutil.copy(f, os.path.join(pr, f"{tag}_domain_stats.csv"))
 
+# what the capture ran: the source hash written next to it by capture_profiles.sh (bench.csrc_sha16) and this checkout's HEAD
+meta = {}
+try:
+    import subprocess
+    meta["head"] = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+except Exception:          # noqa: BLE001
+    pass
+hf = os.path.join(go, f"{tag}_csrc_sha16.txt")
+if os.path.exists(hf):
+    meta["csrc_sha16"] = open(hf).read().strip()
+    sys.path.insert(0, root)
+    from bench import csrc_sha16
+    meta["csrc_sha16_of_this_checkout"] = csrc_sha16()
+
 traffic = defaultdict(lambda: {"launches": 0, "fetch_kib": 0.0, "write_kib": 0.0})
 for sub, key in ((f"{tag}_pmc_fetch", "fetch_kib"), (f"{tag}_pmc_write", "write_kib")):
     f = one(f"{sub}/**/*_counter_collection.csv")
@@ -65,8 +79,9 @@ for name, t in traffic.items():
                  "write_bytes_per_launch_reported": t["write_kib"] * 1024 / wl,
                  "hbm_bytes_per_launch": (2 * t["fetch_kib"] + t["write_kib"]) * 1024 / n}
 if out:
-    json.dump(out, open(os.path.join(pr, f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps({k: round(v["hbm_bytes_per_launch"]) for k, v in out.items()}, indent=1))
+    out["_meta"] = meta
+    json.dump(out, open(os.path.join(pr, f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 
 # ---- HBM-side bytes per UPDATE of the full-batch / replay paths: every kernel's FETCH_SIZE x 2 + WRITE_SIZE summed over
 #      the run, divided by the updates the traced command made (bench_trust.py: 1 warm-up + 5 timed; bench_sac.py: 20 + 200)
@@ -92,8 +107,9 @@ for alg, n_upd in (("cpo", 6), ("trpo", 6), ("sac", 220)):
                                                for k, t in sorted(by.items(), key=lambda kv: -(2 * kv[1]["fetch_kib"] + kv[1]["write_kib"]))[:12]},
                 "launches_per_update": {k: t["launches"] / n_upd for k, t in by.items() if t["launches"] >= n_upd}}
 if upd:
-    json.dump(upd, open(os.path.join(pr, f"{tag}_pmc_traffic_updates.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps({k: round(v["hbm_bytes_per_update"] / 1e6, 1) for k, v in upd.items()}), "MB per update")
+    upd["_meta"] = meta
+    json.dump(upd, open(os.path.join(pr, f"{tag}_pmc_traffic_updates.json"), "w"), indent=1, sort_keys=True)
 
 # ---- MFMA utilisation per kernel from the SQ counter passes (one dispatch = one row per counter):
 #      util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x SIMDs) -- rocprofv3's own MfmaUtil expression, 256 CUs x 4
