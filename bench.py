@@ -171,7 +171,7 @@ def env_bound(envs, workers, busy_us, cpus):
     return envs / (-(-envs // lanes) * busy_us * 1e-6)
 
 
-def end_to_end(local_rank, seed, seconds=6.0, device_actor=False, workers=0, busy_us=0.0, envs=ENVS):
+def end_to_end(local_rank, seed, seconds=6.0, device_actor=False, workers=0, busy_us=0.0, envs=ENVS, cap_workers=False):
     """Secondary figure (outside the timed region): the whole training loop of
     OnpolicyAgent.learn -- host collector over a SYNTHETIC SafetyCarCircle-shaped vector env
     (300-step episodes, one episode per env and collect) feeding the HIP-resident store, one
@@ -184,7 +184,8 @@ def end_to_end(local_rank, seed, seconds=6.0, device_actor=False, workers=0, bus
     from fsrl_amd.env import ShmemVectorEnv, SyntheticSafetyVectorEnv
     from fsrl_amd.trainer import OnpolicyTrainer
     if workers > 0:
-        env = ShmemVectorEnv(env_num=envs, workers=workers, obs_dim=OBS, act_dim=ACT, episode_len=300, seed=seed, busy_us=busy_us)
+        env = ShmemVectorEnv(env_num=envs, workers=workers, obs_dim=OBS, act_dim=ACT, episode_len=300, seed=seed, busy_us=busy_us,
+                             cap_workers=cap_workers)
     else:
         env = SyntheticSafetyVectorEnv(env_num=envs, obs_dim=OBS, act_dim=ACT, episode_len=300, seed=seed, busy_us=busy_us)
     agent = PPOLagAgent(env, cost_limit=10, device=f"cuda:{local_rank}", seed=seed, hidden_sizes=(HID, HID),
@@ -700,6 +701,11 @@ def main():
                              lambda: end_to_end(local_rank, seed, seconds=3.0, device_actor=True, workers=w, busy_us=b, envs=32),
                              60.0, store=False)
                 shm.append(r if r is not None else {"workers": w, "busy_us": b, "error": "leg failed or timed out"})
+        # 32 envs at zero step cost with the worker processes capped at the usable CPUs (ShmemVectorEnv(cap_workers=True))
+        r = legs.run("end_to_end_shmem_w32_b0_capped",
+                     lambda: end_to_end(local_rank, seed, seconds=3.0, device_actor=True, workers=32, busy_us=0.0, envs=32, cap_workers=True),
+                     60.0, store=False)
+        shm.append(r if r is not None else {"workers": 32, "busy_us": 0.0, "cap_workers": True, "error": "leg failed or timed out"})
         legs.run("grouped", lambda: grouped(4), 90.0)
         legs.run("grouped_k8", lambda: grouped(8), 90.0)
         legs.run("multi_seed", multi_seed, 90.0)

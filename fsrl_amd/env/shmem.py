@@ -144,7 +144,7 @@ def _worker(w, lane, lo, hi, shm_name, env_num, workers, obs_dim, act_dim, spec,
 
 class ShmemVectorEnv:
     def __init__(self, env_num=32, workers=None, obs_dim=8, act_dim=2, episode_len=300, seed=None, busy_us=0.0, cores=None,
-                 start_method="spawn", spin_us=None, env_fns=None, cap_workers=True):
+                 start_method="spawn", spin_us=None, env_fns=None, cap_workers=False):
         """Two ways to say what the workers step: the synthetic dynamics (`env_num`, `obs_dim`, ... ; the bench), or
         `env_fns` -- one factory per env, the reference's `ShmemVectorEnv([lambda: gym.make(task) for _ in range(n)])`
         (also accepted as the first positional argument).  Factories travel to the spawned workers with cloudpickle, so
@@ -174,11 +174,13 @@ class ShmemVectorEnv:
             self.spec = SimpleNamespace(id="SyntheticSafety-v0", max_episode_steps=episode_len)
         workers = env_num if workers is None else int(workers)
         assert 1 <= workers <= env_num
-        # cap_workers: never more worker PROCESSES than CPUs this process may use (affinity and cgroup quota; the rank's core
-        # slice when `cores` is given) -- the surplus envs are spread over the workers, several envs per process.  32 processes
-        # on 16 CPUs run in two rounds either way; half the processes do it without the context switches and with half the
-        # wake-ups per vector step (measured: 32 envs x 0 us, 32 requested workers: 352 k -> the 16-process figure).  tianshou
-        # always runs one process per env; cap_workers=False restores that.
+        # cap_workers=True: never more worker PROCESSES than CPUs this process may use (affinity and cgroup quota; the rank's core
+        # slice when `cores` is given) -- the envs are spread over the workers, several per process.  It pays for envs that cost
+        # (almost) nothing per step, where a vector step is the wake-up of the sleeping workers; it LOSES for envs with a real
+        # step cost: one process per env on fewer CPUs runs in rounds either way, but with a process per env the two lanes of the
+        # split-phase collect keep every CPU busy while the other lane's actor call is in flight (MI355X box, 16 usable CPUs,
+        # 32 envs x 100 us: 0.68 of the env bound with 16 processes, 0.83-0.89 with 32).  Default off = tianshou's one process
+        # per env.
         self.workers_requested = workers
         if cap_workers:
             from fsrl_amd.parallel import usable_cpus

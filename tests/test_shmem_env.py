@@ -324,11 +324,11 @@ def test_reset_kwargs_are_refused_not_dropped_and_typeerrors_of_a_users_reset_ar
         DummyVectorEnv([Bad], seed=3).reset()
 
 
-def test_worker_processes_are_capped_at_the_usable_cpus():
+def test_worker_processes_can_be_capped_at_the_usable_cpus():
     from fsrl_amd.env import ShmemVectorEnv
     from fsrl_amd.parallel import usable_cpus
     cap = max(1, int(usable_cpus()))
-    env = ShmemVectorEnv(env_num=2 * cap + 3, workers=2 * cap + 3, episode_len=5, seed=1)
+    env = ShmemVectorEnv(env_num=2 * cap + 3, workers=2 * cap + 3, episode_len=5, seed=1, cap_workers=True)
     try:
         assert env.workers == cap and env.workers_requested == 2 * cap + 3 and len(env._procs) == cap
         obs, _ = env.reset()
@@ -337,7 +337,7 @@ def test_worker_processes_are_capped_at_the_usable_cpus():
         assert o.shape == (2 * cap + 3, 8) and len(i["cost"]) == 2 * cap + 3
     finally:
         env.close()
-    env = ShmemVectorEnv(env_num=cap + 2, workers=cap + 2, episode_len=5, seed=1, cap_workers=False)
+    env = ShmemVectorEnv(env_num=cap + 2, workers=cap + 2, episode_len=5, seed=1)
     try:
         assert env.workers == cap + 2
     finally:
