@@ -20,6 +20,7 @@
 #include "kernels_misc.hpp"
 #include "kernels_mlp.hpp"
 #include "kernels_fb.hpp"
+#include "kernels_wgrad2.hpp"
 
 // ------------------------------------------------------------------------------ errors
 static thread_local std::string g_err;
@@ -160,6 +161,7 @@ struct fsrl_ctx {
     float* wg_parts = nullptr;      // the buffer the last wgrad_launch wrote
     int n_cus = 256;                // compute units of the device (tile-shape heuristic)
     bool wgrad_xcd = false;         // fb_wgrad_kernel: XCD-aware placement of the splits (fsrl_tr_set_plan)
+    bool wgrad_stream = false;      // fsrl_tr_set_plan(wgrad = 3): fb_wgrad2_kernel (one streaming pass per workgroup) where it applies
     struct FocState* foc = nullptr; // FOCOPS working set, owned
     float* mu_old = nullptr;        // [maxsize][Da] actor means at process time (FOCOPS)
     float* sigma_old = nullptr;     // [FSRL_MAX_ACT] sigma_param at process time (FOCOPS)
@@ -256,6 +258,27 @@ static int ensure_parts(fsrl_ctx* c, int stride, int nsplit) {
 template <bool PAIR2>
 static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int ny, int stride, int* nsplit) {
     const int H_ = c->cfg.hidden;
+    // fsrl_tr_set_plan(wgrad = 3), 256-wide layers over a few thousand rows or more: the one-pass streaming form
+    // (kernels_wgrad2.hpp) -- a workgroup per (network, output quarter, row slice), ONE round of workgroups, slices of a multiple
+    // of 32 rows.  It moves 2.6x fewer bytes (160 vs 413-430 MB per launch at N = 20 000) in the same time (80 vs 82 us for the
+    // R-op product, 80 vs 78 us plain), and its 32-64 partials cost the consumers 3 us more per launch than the <= 24 of the
+    // split-K kernel: CPO 36.5 vs 36.0 ms, TRPO-Lag 29.7 vs 29.0 ms same box -- so it is NOT the default.
+    if (H_ == 256 && wa.rows >= 4096 && wa.rows % 16 == 0 && c->wgrad_stream) {
+        for (int y = 0; y < ny; ++y)
+            CHECK_ARG(wa.nets[y].b1_src == wa.nets[y].w1_y && wa.nets[y].b2_src == wa.nets[y].w2_ya && wa.nets[y].do_src == wa.nets[y].w3_ya,
+                      "fb_wgrad2_kernel takes the bias sums off the operands of the matrix products");
+        int ns = std::max(1, c->n_cus / (WG2_Q * ny));
+        ns = std::min(ns, std::max(1, wa.rows / 128));
+        const int rps = round_up((wa.rows + ns - 1) / ns, 32);
+        ns = (wa.rows + rps - 1) / rps;
+        int rc = ensure_parts(c, stride, ns);
+        if (rc) return rc;
+        wa.out = c->wg_parts; wa.split_stride = stride; wa.ks_per_split = rps / 4;
+        *nsplit = ns;
+        hipLaunchKernelGGL((fb_wgrad2_kernel<256, PAIR2>), dim3(8 * WG2_Q * ((ns + 7) / 8), ny), dim3(1024), 0, c->compute, md, wa, ns, rps);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     // blocks of one split and network: 64x64 dW2 tiles + one block per (64-column group, pass over the rows) + the db3 block.
     // Passes: the first carries NCH0 16-column chunks of dW1 (+ dW3, db1, db2), every further one four chunks.
     const int nch0 = PAIR2 ? 1 : 2;

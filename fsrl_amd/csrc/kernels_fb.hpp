@@ -1251,6 +1251,39 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
     }
 }
 
+// sum of the split partials of one element (or four adjacent ones) in float64, z ascending: the loads of EIGHT partials are
+// issued before the first add (the one-pass weight-gradient kernel leaves 32-64 partials; one dependent load per add took
+// cg_pz_kernel from 5 to 18 us).  Same additions in the same order as the plain loop.
+__device__ __forceinline__ double sum_parts1(const float* __restrict__ parts, const size_t stride, const int nparts, const size_t i) {
+    double acc = 0.0;
+    int z = 0;
+    for (; z + 8 <= nparts; z += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = parts[(size_t)(z + u) * stride + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; z < nparts; ++z) acc += (double)parts[(size_t)z * stride + i];
+    return acc;
+}
+__device__ __forceinline__ void sum_parts4(const float* __restrict__ parts, const size_t stride, const int nparts, const size_t i4,
+                                           double (&a)[4]) {
+    a[0] = a[1] = a[2] = a[3] = 0.0;
+    int z = 0;
+    for (; z + 8 <= nparts; z += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(parts + (size_t)(z + u) * stride + i4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a[0] += (double)v[u][0]; a[1] += (double)v[u][1]; a[2] += (double)v[u][2]; a[3] += (double)v[u][3]; }
+    }
+    for (; z < nparts; ++z) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(parts + (size_t)z * stride + i4);
+        a[0] += (double)v[0]; a[1] += (double)v[1]; a[2] += (double)v[2]; a[3] += (double)v[3];
+    }
+}
+
 // out[i] = sum_z parts[z * stride + i], z ascending (fixed order), i in [begin, end)
 __global__ __launch_bounds__(256) void fb_sum_parts_kernel(float* __restrict__ out, const float* __restrict__ parts,
                                                           int begin, int end, int nparts, int stride,
@@ -1261,9 +1294,7 @@ __global__ __launch_bounds__(256) void fb_sum_parts_kernel(float* __restrict__ o
     if (i < end) {
         // the split-K partials (each an fp32 MFMA chain over >= 256 rows) are combined in float64, z ascending, and rounded
         // once: at N = 20 000 that is up to 24 terms -- the summation-order noise fp32 conjugate gradients amplify
-        double acc = (double)parts[i];
-        for (int z = 1; z < nparts; ++z) acc += (double)parts[(size_t)z * stride + i];
-        v = (float)acc;
+        v = (float)sum_parts1(parts, (size_t)stride, nparts, (size_t)i);
         out[i] = v;
     }
     if (gsq_part) {                          // per-block sum of squares (clip_grad_norm_ of the consumer)
@@ -1350,13 +1381,9 @@ __global__ __launch_bounds__(256) void cg_pz_kernel(float* __restrict__ hz, cons
         const f32x4 pi = *reinterpret_cast<const f32x4*>(p + i4);
         f32x4 z;
         if (parts) {
-            const f32x4 z0 = *reinterpret_cast<const f32x4*>(parts + i4);
-            double a0 = (double)z0[0], a1 = (double)z0[1], a2 = (double)z0[2], a3 = (double)z0[3];
-            for (int k = 1; k < nparts; ++k) {
-                const f32x4 zk = *reinterpret_cast<const f32x4*>(parts + (size_t)k * stride + i4);
-                a0 += (double)zk[0]; a1 += (double)zk[1]; a2 += (double)zk[2]; a3 += (double)zk[3];
-            }
-            z = f32x4{(float)a0, (float)a1, (float)a2, (float)a3};
+            double a[4];
+            sum_parts4(parts, (size_t)stride, nparts, (size_t)i4, a);
+            z = f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
         } else
             z = *reinterpret_cast<const f32x4*>(hz + i4);
 #pragma unroll
@@ -1812,9 +1839,7 @@ __global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ P, 
         psq = p * p;
         float gs = G[i];                                   // split-K partials of fb_wgrad_kernel, z order
         if (sum64) {                                       // ... combined in float64 and rounded once, as fb_sum_parts_kernel does
-            double acc = (double)gs;
-            for (int z = 1; z < nparts; ++z) acc += (double)G[(size_t)z * stride + i];
-            gs = (float)acc;
+            gs = (float)sum_parts1(G, (size_t)stride, nparts, (size_t)i);
         } else
         for (int z = 1; z < nparts; ++z) gs += G[(size_t)z * stride + i];
         adam_element(P, M, V, i, p, gs, coef, l2, one_minus_b1, beta2, one_minus_b2, step_size, bc2_sqrt, eps, md, tgt, tau,

@@ -348,8 +348,12 @@ int fsrl_tr_eval(fsrl_ctx* ctx, double* stats8);
  * workgroups), 16 = 16-row tiles only.  hvp: 0 = automatic (mixed tiles; the theta-only activations of the KL Hessian
  * product are computed by the first product of a conjugate-gradient solve and read back by the others: cpo.py:184-204
  * calls _MVP 10 + 1 times per right-hand side at one theta), 1 = the 16-row kernel that recomputes everything,
- * 2 = mixed tiles without the cache.  wgrad: 1 = XCD-aware placement of the split-K weight-gradient blocks (the blocks
- * of one row split behind one L2).  All plans give bit-identical results.                                          */
+ * 2 = mixed tiles without the cache.  wgrad: 0 = the split-K weight-gradient kernel (default), 1 = the same with XCD-aware
+ * placement of its blocks, 3 = the one-pass streaming kernel for 256-wide layers over >= 4096 rows (one workgroup per network,
+ * output quarter and row slice; operands by LDS-DMA; 2.6x less memory traffic, the same time: not the default).  The
+ * tile_rows / hvp / wgrad 0-1 plans give bit-identical results; the streaming kernel adds the rows up in another order (fp32
+ * MFMA chains of different lengths, partials in float64): its results agree to rounding (tests/test_gpu_fullsize.py states
+ * the tolerance).                                                                                                   */
 int fsrl_tr_set_plan(fsrl_ctx* ctx, int32_t tile_rows, int32_t hvp, int32_t wgrad);
 
 /* ---- FOCOPS (fsrl/policy/focops.py:126-251), on the PPO entry points: create the context

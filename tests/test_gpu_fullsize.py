@@ -272,7 +272,7 @@ def test_hessian_vector_product_properties_at_full_size():
 
 @pytest.mark.parametrize("obs_dim,hid,T", [(60, 256, 1000), (8, 256, 300), (24, 128, 700)])
 def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
-    """The full-batch path's three kernel plans (fsrl_tr_set_plan) must agree BIT FOR BIT: 16-row tiles + the HVP kernel
+    """The full-batch path's three tile / HVP kernel plans (fsrl_tr_set_plan) must agree BIT FOR BIT: 16-row tiles + the HVP kernel
     that recomputes everything (round 2's path) | mixed 32- / 16-row tiles without the HVP cache | mixed tiles + the
     theta-only activations of the KL Hessian product computed once per conjugate-gradient solve and read back (default).
     A row's arithmetic does not depend on its tile's height, relu'(z) is read off h > 0, and the per-tile statistics keep
@@ -307,12 +307,91 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
         out["theta_trpo"] = eng.get_params().copy()
         return out
 
-    ref = run(16, 1)
-    assert np.isfinite(ref["cpo"]).all() and np.isfinite(ref["trpo"]).all() and np.abs(ref["hvp"]).max() > 0
-    for plan in ((0, 2), (0, 0), (16, 0), (0, 0, 1)):
-        got = run(*plan)
-        for k in ref:
-            assert np.array_equal(ref[k], got[k]), (plan, k, np.abs(np.asarray(ref[k], np.float64) - got[k]).max())
+    # the tile / HVP plans are bit-identical under EITHER weight-gradient kernel (wgrad 0: the split-K kernel, the default;
+    # wgrad 3: the one-pass streaming kernel where it applies -- 256-wide layers, >= 4096 rows)
+    refs = {}
+    for wg in (3, 0):
+        ref = refs[wg] = run(16, 1, wg)
+        assert np.isfinite(ref["cpo"]).all() and np.isfinite(ref["trpo"]).all() and np.abs(ref["hvp"]).max() > 0
+        for plan in ((0, 2, wg), (0, 0, wg), (16, 0, wg)) + (((0, 0, 1), ) if wg == 0 else ()):
+            got = run(*plan)
+            for k in ref:
+                assert np.array_equal(ref[k], got[k]), (plan, k, np.abs(np.asarray(ref[k], np.float64) - got[k]).max())
+    # the two weight-gradient kernels add the rows up in different orders (fp32 MFMA chains over 4 vs 16 interleaved row
+    # classes, 32-64 vs <= 24 partials in float64): the building blocks agree to 2e-5 of the vector's largest entry (the
+    # tolerance of the autograd comparison in test_gpu_trust.py); whole updates -- conjugate gradients amplify summation
+    # order, DESIGN "conditioning note" -- at the fixture tolerances of test_gpu_trust.py (2e-2 on what is downstream of CG)
+    a, b = refs[3], refs[0]
+    if hid == 256 and envs * T >= 4096:
+        for k in ("grad0", "grad1", "grad2", "hvp"):
+            scale = max(float(np.abs(b[k]).max()), 1e-12)
+            assert float(np.abs(a[k] - b[k]).max()) <= 2e-5 * scale, (k, float(np.abs(a[k] - b[k]).max()), scale)
+        assert not np.array_equal(a["hvp"], b["hvp"])                    # the new kernel did run
+        np.testing.assert_allclose(a["eval"], b["eval"], rtol=0, atol=0)
+        # first repeat: same branch of the dual solve, same number of backtracks, everything else within 2e-2 of its scale (the
+        # reference's own error band on quantities downstream of conjugate gradients); the second repeat starts from thetas
+        # that differ at the 1e-4 level and is only required to stay finite and to take the same branch
+        assert a["cpo"][0, 12] == b["cpo"][0, 12] and a["cpo"][1, 12] == b["cpo"][1, 12]          # loss/optim_case
+        np.testing.assert_allclose(a["cpo"][0, 13], b["cpo"][0, 13], rtol=1e-6)                   # loss/step_size
+        for k in ("cpo", "trpo"):
+            sc = np.maximum(np.abs(b[k][0]), 1e-3 * np.abs(b[k][0]).max())
+            bad = np.abs(a[k][0] - b[k][0]) > 2e-2 * sc
+            assert not bad.any(), (k, np.flatnonzero(bad), a[k][0], b[k][0])
+            assert np.isfinite(a[k]).all()
+        for k in ("theta_cpo", "theta_trpo"):
+            d = np.abs(a[k] - b[k])
+            assert d.max() <= 5e-3 and d.mean() <= 5e-5, (k, d.max(), d.mean())
+    else:
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k                         # below the new kernel's range nothing changes
+    eng.tr_set_plan(0, 0, 0)
+    eng.close()
+
+
+def test_streaming_weight_gradients_vs_autograd_at_full_size():
+    """fb_wgrad2_kernel (256-wide layers, N = 20 000, obs 60: four 16-column chunks of dW1 with a ragged last one) against torch
+    autograd of the oracle's losses on the same batch: the two surrogate gradients, the KL gradient away from theta_old, and
+    three Hessian-vector products of the mean KL (cpo.py:177-182, 206-220), for both weight-gradient kernels.  2e-5 / 5e-5 of
+    the vector's largest entry, the bars of the small-fixture test (tests/test_gpu_trust.py).  The critics' gradients take the
+    same kernel with two networks per launch: test_cpo_configs2_full_size / test_trpo_full_size compare their losses after
+    the Adam steps with the oracle's."""
+    from oracle.trust_region import CPOConfig, CPOOracle
+    from torch.distributions import Independent, Normal, kl_divergence
+    torch.set_num_threads(4)
+    eng, data = _setup_onpolicy(60, 2, 256, 1000, 1e-3)
+    o = CPOOracle(CPOConfig(obs_dim=60, act_dim=2, hidden=(256, 256), cost_limit=10.0))
+    theta = _orth_theta(o, 0)
+    rng = np.random.default_rng(5)
+    theta = theta + (0.02 * rng.standard_normal(theta.size)).astype(np.float32)      # sigma, biases and W3 away from their init
+    o.set_params(theta); eng.set_params(theta); eng.optim_reset()
+    assert eng.tr_begin(target_kl=0.01, norm_adv=True, cost_limit=10.0) == 20000
+    pb = o.process(data)
+    moved = theta.copy()
+    na = eng.n_actor_params
+    moved[:na] += (0.01 * rng.standard_normal(na)).astype(np.float32)                # theta != theta_old: exact Hessian
+    o.set_params(moved); eng.set_params(moved)
+    dist = o.actor_dist(pb["obs"])
+    ratio = torch.exp(dist.log_prob(pb["act"]) - pb["logp_old"])
+    obj = torch.mean(ratio * pb["advs"][..., 0])
+    csur = torch.mean(ratio * pb["advs"][..., 1])
+    kl = kl_divergence(Independent(Normal(pb["mean_old"], pb["std_old"]), 1), dist).mean()
+    og = o.flat_grad(obj, retain_graph=True).numpy()
+    ob = o.flat_grad(-csur, retain_graph=True).numpy()
+    klg = o.flat_grad(kl, create_graph=True)
+
+    def close(a, b, rel):
+        scale = max(float(np.abs(b).max()), 1e-12)
+        err = float(np.abs(np.asarray(a) - np.asarray(b)).max())
+        assert err <= rel * scale, (err, scale)
+    for plan in (3, 0):
+        eng.tr_set_plan(0, 0, plan)
+        close(eng.tr_grad(0), og, 2e-5)
+        close(eng.tr_grad(1), ob, 2e-5)
+        close(eng.tr_grad(2), klg.detach().numpy(), 2e-5)
+        for k in range(3):
+            v = np.random.default_rng(k).standard_normal(og.size).astype(np.float32)
+            hv = o.flat_grad(torch.dot(klg, torch.from_numpy(v)), retain_graph=True).numpy()
+            close(eng.tr_hvp(v), hv, 5e-5)
     eng.tr_set_plan(0, 0, 0)
     eng.close()
 
