@@ -22,6 +22,54 @@
 #define FB_MODE_FOCOPS 7  // actor: d/dtheta mean((KL(new||old) - cr * ratio * (A_r - cc * A_c)) * [KL <= eta])  (focops.py:179-203)
 #define FB_NSTAT 8
 
+// ---- SAC / DDPG-Lag n-step regression target of one batch row and one metric (0 = reward, 1 = cost), float64 in the
+//      reference's order (base_policy.py:453-512 + nstep_return :543-567; sac_lag.py:136-145 for the entropy term).  Called by
+//      the Q-networks' training tile (FB_MODE_Q_TRAIN with FbArgs::ns_on) and by the stand-alone sac_nstep_kernel.
+// ---- scalars that live on the device between updates
+struct SacScalars {
+    float alpha, log_alpha;         // temperature
+    float m, v;                     // Adam moments of log_alpha
+    int t;                          // Adam step count of log_alpha
+    int pad;
+};
+
+struct SacNstepArgs {
+    const float* QT;        // [4][B] target-net Q(s', a')
+    const float* lpn;       // [B] log pi(a'|s')
+    const int* chain;       // [n_step][B] index chain (host: buffer.next)
+    const uint8_t* endbits; // [n_step][B] end_flag (done | unfinished) at each chain element
+    const double* rew; const double* cost; const uint8_t* flags;   // store columns
+    const SacScalars* sc;
+    float* Y;               // [2][B]
+    int B, n_step;
+    double gamma;
+    int auto_alpha; float alpha_fixed;
+    int single;             // DDPG-Lag: one target critic per metric, no entropy term (ddpg_lag.py:125-131)
+};
+__device__ __forceinline__ float sac_nstep_target(const SacNstepArgs& a, const int b, const int metric) {
+#pragma clang fp contract(off)
+    const float alpha = a.auto_alpha ? a.sc->alpha : a.alpha_fixed;
+    const double* __restrict__ m = metric == 0 ? a.rew : a.cost;
+    double gpow = 1.0;
+    int gammas = a.n_step;
+    double ret = 0.0;
+    for (int n = a.n_step - 1; n >= 0; --n) {
+        const int now = a.chain[(size_t)n * a.B + b];
+        if (a.endbits[(size_t)n * a.B + b]) { gammas = n + 1; ret = 0.0; }
+        const double t = a.gamma * ret;
+        ret = m[now] + t;
+    }
+    for (int i = 0; i < gammas; ++i) gpow = gpow * a.gamma;          // gamma_buffer[gammas]
+    const int terminal = a.chain[(size_t)(a.n_step - 1) * a.B + b];
+    const bool term = (a.flags[terminal] & 1) != 0;
+    const float lp = a.single ? 0.0f : alpha * a.lpn[b];
+    float tq = a.single ? a.QT[(size_t)metric * a.B + b]
+                        : fminf(a.QT[(size_t)(2 * metric) * a.B + b], a.QT[(size_t)(2 * metric + 1) * a.B + b]) - lp;
+    if (term) tq = 0.0f;
+    const double prod = (double)tq * gpow;
+    return (float)(prod + ret);
+}
+
 struct FbArgs {
     const float* obs;     // [N][Do]  batch, store order
     const float* rd;      // [N][FSRL_RD] act | logp_old | adv_n | ret | mean_old | std_old
@@ -39,6 +87,8 @@ struct FbArgs {
     int act_cols;         // number of action columns at the end of x
     float eta;            // FOCOPS: rows whose KL(new||old) exceeds eta drop out of the loss
     int pair_shift;       // Q_TRAIN target of net n is tgt[n >> pair_shift]: 1 = double critics (SAC), 0 = single (DDPG)
+    int ns_on;            // Q_TRAIN: the regression targets are computed HERE (sac_nstep_target) instead of read from tgt: one
+    SacNstepArgs ns;      //   launch less per update; the same float64 operations, so the same bits
 };
 
 // Activation backward of one tile given sm.dout: spills relu(z1), relu(z2), dz2, dout, dz1 for the
@@ -159,6 +209,8 @@ __device__ __forceinline__ void fb_tile_body(TileSmem<H, tile_rows(R)>& sm, cons
 
     TileStage<H, ROWS> stg;
     stg.issue(P, no, Do, Da, a.obs + (size_t)row0 * Do, a.rd ? a.rd + (size_t)row0 * FSRL_RD : nullptr, n_valid, tid);
+    if (a.mode == FB_MODE_Q_TRAIN && a.ns_on && tid < n_valid)       // its loads travel underneath the forward pass; read by the head
+        sm.st[tid] = sac_nstep_target(a.ns, row0 + tid, net >> a.pair_shift);
     FwdW2Frag<H> wf;
     wf.load(P + no.W2f, wave, lane);
     for (int e = tid; e < ROWS * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
@@ -253,7 +305,7 @@ __device__ __forceinline__ void fb_tile_body(TileSmem<H, tile_rows(R)>& sm, cons
             const int r = row0 + i;
             if (valid && d == 0) {
                 if (a.mode == FB_MODE_Q_TRAIN) {
-                    const float td = qv - a.tgt[(size_t)(net >> a.pair_shift) * a.N + r];
+                    const float td = qv - (a.ns_on ? sm.st[i] : a.tgt[(size_t)(net >> a.pair_shift) * a.N + r]);
                     sm.dout[i * FSRL_DOW] = 2.0f * td * invN;
                     st[0] = td * td;
                     a.qout[(size_t)net * a.N + r] = qv;

@@ -64,6 +64,41 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
     sincospif(2.0f * u2, &sn, &cs);
     n0 = rad * cs; n1 = rad * sn;
 }
+// one sampled row: the uniform index, its n-step chain with the end flags, the two rsample noise rows.  -> (index, terminal index)
+__device__ __forceinline__ void sac_sample_row(const SacSampleArgs& a, const SacBook* __restrict__ book, const int b,
+                                               const uint32_t k0, const uint32_t k1, int* idx_out = nullptr, int* term_out = nullptr) {
+    uint32_t c[4] = {(uint32_t)b, 0u, (uint32_t)a.counter, (uint32_t)(a.counter >> 32)};
+    philox4x32_10(c, k0, k1);
+    unsigned long long k = ((unsigned long long)c[0] * a.stored) >> 32;    // uniform over the stored rows
+    int e = 0;
+    while (e < a.env_num - 1 && k >= (unsigned long long)book[e].size) { k -= book[e].size; ++e; }
+    int cur = e * a.sub_size + (int)k;
+    a.idx[b] = cur;
+    if (idx_out) *idx_out = cur;
+    for (int n = 0; n < a.n_step; ++n) {
+        const int env = cur / a.sub_size, local = cur - env * a.sub_size;
+        const SacBook bk = book[env];
+        if (n > 0) {                                   // indices[n] = buffer.next(indices[n-1])
+            const bool end = a.flags[cur] != 0 || local == bk.last_index;
+            if (!end && bk.size > 0) cur = env * a.sub_size + (local + 1) % bk.size;
+        }
+        const int loc2 = cur - env * a.sub_size;
+        a.chain[(size_t)n * a.B + b] = cur;
+        a.endbits[(size_t)n * a.B + b] =
+            (a.flags[cur] != 0 || (bk.size > 0 && loc2 == (bk.index - 1 + bk.size) % bk.size)) ? 1 : 0;
+    }
+    if (term_out) *term_out = cur;                     // the chain's last element
+    for (int d0 = 0; d0 < a.Da; d0 += 2) {             // 4 normals per Philox block: 2 for each stream
+        uint32_t r[4] = {(uint32_t)b, 1u + (uint32_t)(d0 >> 1), (uint32_t)a.counter, (uint32_t)(a.counter >> 32)};
+        philox4x32_10(r, k0, k1);
+        float t0, t1, p0, p1;
+        box_muller(r[0], r[1], t0, t1);
+        box_muller(r[2], r[3], p0, p1);
+        a.eps_t[(size_t)b * a.Da + d0] = t0; a.eps_p[(size_t)b * a.Da + d0] = p0;
+        if (d0 + 1 < a.Da) { a.eps_t[(size_t)b * a.Da + d0 + 1] = t1; a.eps_p[(size_t)b * a.Da + d0 + 1] = p1; }
+    }
+}
+
 __global__ __launch_bounds__(256) void sac_sample_kernel(const SacSampleArgs a) {
     // SAC / DDPG: one thread per sampled row.  CVPO (eps_k != NULL): B * K threads, thread (b, kp) also draws particle
     // kp's noise for row b; the row work is done by the kp == 0 threads.
@@ -93,43 +128,41 @@ __global__ __launch_bounds__(256) void sac_sample_kernel(const SacSampleArgs a) 
         }
         if (kp != 0) return;
     }
-    uint32_t c[4] = {(uint32_t)b, 0u, (uint32_t)a.counter, (uint32_t)(a.counter >> 32)};
-    philox4x32_10(c, k0, k1);
-    unsigned long long k = ((unsigned long long)c[0] * a.stored) >> 32;    // uniform over the stored rows
-    int e = 0;
-    while (e < a.env_num - 1 && k >= (unsigned long long)book[e].size) { k -= book[e].size; ++e; }
-    int cur = e * a.sub_size + (int)k;
-    a.idx[b] = cur;
-    for (int n = 0; n < a.n_step; ++n) {
-        const int env = cur / a.sub_size, local = cur - env * a.sub_size;
-        const SacBook bk = book[env];
-        if (n > 0) {                                   // indices[n] = buffer.next(indices[n-1])
-            const bool end = a.flags[cur] != 0 || local == bk.last_index;
-            if (!end && bk.size > 0) cur = env * a.sub_size + (local + 1) % bk.size;
-        }
-        const int loc2 = cur - env * a.sub_size;
-        a.chain[(size_t)n * a.B + b] = cur;
-        a.endbits[(size_t)n * a.B + b] =
-            (a.flags[cur] != 0 || (bk.size > 0 && loc2 == (bk.index - 1 + bk.size) % bk.size)) ? 1 : 0;
-    }
-    for (int d0 = 0; d0 < a.Da; d0 += 2) {             // 4 normals per Philox block: 2 for each stream
-        uint32_t r[4] = {(uint32_t)b, 1u + (uint32_t)(d0 >> 1), (uint32_t)a.counter, (uint32_t)(a.counter >> 32)};
-        philox4x32_10(r, k0, k1);
-        float t0, t1, p0, p1;
-        box_muller(r[0], r[1], t0, t1);
-        box_muller(r[2], r[3], p0, p1);
-        a.eps_t[(size_t)b * a.Da + d0] = t0; a.eps_p[(size_t)b * a.Da + d0] = p0;
-        if (d0 + 1 < a.Da) { a.eps_t[(size_t)b * a.Da + d0 + 1] = t1; a.eps_p[(size_t)b * a.Da + d0 + 1] = p1; }
-    }
+    sac_sample_row(a, book, b, k0, k1);
 }
 
-// ---- scalars that live on the device between updates
-struct SacScalars {
-    float alpha, log_alpha;         // temperature
-    float m, v;                     // Adam moments of log_alpha
-    int t;                          // Adam step count of log_alpha
-    int pad;
-};
+// ---- sample + gather in ONE launch (SAC / DDPG-Lag, library RNG): a workgroup draws SG_ROWS rows (one thread each: index,
+//      chain, noise -- the same Philox counters as sac_sample_kernel, so the same sample) and then gathers exactly those rows with
+//      all its threads.  Two dependent ~5-7 us launches at their floors become one.
+#define SG_ROWS 16
+__global__ __launch_bounds__(256) void sac_sample_gather_kernel(const SacSampleArgs a, const SacGatherArgs g) {
+    constexpr int BOOK_LDS = 512;
+    __shared__ SacBook book_s[BOOK_LDS];
+    __shared__ int idx_s[SG_ROWS], term_s[SG_ROWS];
+    const bool in_lds = a.env_num <= BOOK_LDS;
+    if (in_lds) {
+        for (int e = threadIdx.x; e < a.env_num; e += blockDim.x) book_s[e] = a.book[e];
+        __syncthreads();
+    }
+    const SacBook* __restrict__ book = in_lds ? book_s : a.book;
+    const int b0 = blockIdx.x * SG_ROWS;
+    if (threadIdx.x < SG_ROWS && b0 + threadIdx.x < a.B)
+        sac_sample_row(a, book, b0 + threadIdx.x, (uint32_t)a.key, (uint32_t)(a.key >> 32), &idx_s[threadIdx.x], &term_s[threadIdx.x]);
+    __syncthreads();
+    const int Din = g.Do + g.Da, nrow = min(SG_ROWS, a.B - b0);
+    for (int e = threadIdx.x; e < nrow * Din; e += blockDim.x) {
+        const int rl = e / Din, f = e - rl * Din, r = b0 + rl;
+        const size_t s_ = (size_t)idx_s[rl], t_ = (size_t)term_s[rl];
+        const size_t o = (size_t)r * Din + f;
+        if (f < g.Do) {
+            const float ob = g.st.obs[s_ * g.Do + f], on = g.st.obs_next[t_ * g.Do + f];
+            g.XQ[o] = ob; g.XP[o] = ob; g.XN[o] = on;
+            g.OBS[(size_t)r * g.Do + f] = ob; g.OBSN[(size_t)r * g.Do + f] = on;
+        } else {
+            g.XQ[o] = g.st.act[s_ * g.Da + (f - g.Do)];
+        }
+    }
+}
 
 // ---- actor tile: a = tanh(mu + sigma*eps), log pi with the tanh correction; optional backward
 #define SAC_A_FWD 0      // write action into X[:, Do:], log pi into lp_out
@@ -272,47 +305,13 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
                      a.D2 + (size_t)row0 * H, a.DO + (size_t)row0 * FSRL_DOW, tid, false);
 }
 
-// ---- n-step target (float64), base_policy.py:453-512 + nstep_return :543-567
-struct SacNstepArgs {
-    const float* QT;        // [4][B] target-net Q(s', a')
-    const float* lpn;       // [B] log pi(a'|s')
-    const int* chain;       // [n_step][B] index chain (host: buffer.next)
-    const uint8_t* endbits; // [n_step][B] end_flag (done | unfinished) at each chain element
-    const double* rew; const double* cost; const uint8_t* flags;   // store columns
-    const SacScalars* sc;
-    float* Y;               // [2][B]
-    int B, n_step;
-    double gamma;
-    int auto_alpha; float alpha_fixed;
-    int single;             // DDPG-Lag: one target critic per metric, no entropy term (ddpg_lag.py:125-131)
-};
+// ---- n-step target (float64), base_policy.py:453-512 + nstep_return :543-567: the stand-alone launch (CVPO; SAC / DDPG-Lag fold
+//      sac_nstep_target into the critics' tile launch, kernels_fb.hpp)
 __global__ void sac_nstep_kernel(const SacNstepArgs a) {
-#pragma clang fp contract(off)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.B) return;
-    const float alpha = a.auto_alpha ? a.sc->alpha : a.alpha_fixed;
-    double gpow = 1.0;
-    int gammas = a.n_step;
-    double ret_r = 0.0, ret_c = 0.0;
-    for (int n = a.n_step - 1; n >= 0; --n) {
-        const int now = a.chain[(size_t)n * a.B + b];
-        if (a.endbits[(size_t)n * a.B + b]) { gammas = n + 1; ret_r = 0.0; ret_c = 0.0; }
-        const double tr = a.gamma * ret_r, tc = a.gamma * ret_c;
-        ret_r = a.rew[now] + tr;
-        ret_c = a.cost[now] + tc;
-    }
-    for (int i = 0; i < gammas; ++i) gpow = gpow * a.gamma;          // gamma_buffer[gammas]
-    const int terminal = a.chain[(size_t)(a.n_step - 1) * a.B + b];
-    const bool term = (a.flags[terminal] & 1) != 0;
-    const float lp = a.single ? 0.0f : alpha * a.lpn[b];
-    for (int i = 0; i < 2; ++i) {
-        float tq = a.single ? a.QT[(size_t)i * a.B + b]
-                            : fminf(a.QT[(size_t)(2 * i) * a.B + b], a.QT[(size_t)(2 * i + 1) * a.B + b]) - lp;
-        if (term) tq = 0.0f;
-        const double prod = (double)tq * gpow;
-        const double y = prod + (i == 0 ? ret_r : ret_c);
-        a.Y[(size_t)i * a.B + b] = (float)y;
-    }
+    a.Y[b] = sac_nstep_target(a, b, 0);
+    a.Y[(size_t)a.B + b] = sac_nstep_target(a, b, 1);
 }
 
 // ---- scalar bookkeeping of one update: logged stats, alpha loss + Adam on log_alpha

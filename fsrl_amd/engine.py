@@ -512,9 +512,10 @@ class Engine:
         self.n_sac_actor = int(self.lib.fsrl_sac_param_count(self._ctx, 0))
         self.n_sac_critics = int(self.lib.fsrl_sac_param_count(self._ctx, 1))
 
-    def sac_set_plan(self, wgrad_splitk: int = 0):
-        """A/B and tests: 1 = split-K weight gradients at every batch size, 0 = the one-workgroup-per-tile kernel up to 512 rows"""
-        _lib.check(self.lib.fsrl_sac_set_plan(self._ctx, int(wgrad_splitk)))
+    def sac_set_plan(self, plan: int = 0):
+        """A/B and tests: bit 0 = split-K weight gradients at every batch size (default: the one-workgroup-per-tile kernel up to
+        512 rows); bit 1 = sample / gather / n-step targets as launches of their own (default: 10 launches per update, not 12)"""
+        _lib.check(self.lib.fsrl_sac_set_plan(self._ctx, int(plan)))
 
     def sac_set_params(self, actor_flat, critics_flat, log_alpha=0.0):
         a = np.ascontiguousarray(actor_flat, np.float32); c = np.ascontiguousarray(critics_flat, np.float32)

@@ -455,3 +455,43 @@ def test_state_snapshot_restore_reproduces_an_update_bit_for_bit():
     assert np.array_equal(s0, s2) and np.array_equal(th0, eng.get_params())
     np.testing.assert_allclose(s0, g["stats"], rtol=2e-5, atol=2e-5)
     eng.close()
+
+
+def test_state_snapshot_covers_the_return_statistics_and_refuses_replay_contexts():
+    """With reward_normalization the running return statistics are training state: a restore puts them back (two updates from
+    the restored state give the same statistics bit for bit).  Replay agents keep their training state in stores of their own
+    (actor / Q / target parameters, log alpha, three Adam states): the call refuses them instead of restoring nothing relevant."""
+    from fsrl_amd import _lib
+    from fsrl_amd.engine import Engine, EngineConfig
+    cfg, g = ppo_case("rewnorm")
+    eng = _engine(cfg)
+    _start(eng, g)
+    _push_golden(eng, g)
+    lag = g["lagrangian"]
+    run = lambda: eng.ppo_update(lag, _rescale(lag), cfg["batch_size"], cfg["repeat"], perms=g["perms"])[0]  # noqa: E731
+    eng.optim_reset()
+    eng.state_snapshot()
+    rms0 = eng.ret_rms_get().copy()
+    s0 = run(); rms1 = eng.ret_rms_get().copy()
+    assert not np.array_equal(rms0, rms1)                            # the update moved the statistics
+    eng.state_restore()
+    assert np.array_equal(eng.ret_rms_get(), rms0)
+    s1 = run()
+    assert np.array_equal(s0, s1) and np.array_equal(eng.ret_rms_get(), rms1)
+    eng.close()
+    sac = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=5, act_dim=2, hidden=64, n_critics=2, env_num=2, buffer_size=100, target_kl=None))
+    sac.sac_init()
+    with pytest.raises(Exception, match="on-policy"):
+        sac.state_snapshot()
+    sac.close()
+
+
+def test_launch_floors_are_measured_and_plausible():
+    """fsrl_launch_floors (bench.py's latency floor, measured in the run): three empty kernels with the PPO step's grids; every
+    figure is a few microseconds, and the three behind each other cost no more than the sum of each behind itself (+ slack)."""
+    cfg, _ = ppo_case("c2")
+    eng = _engine(cfg)
+    f = eng.launch_floors(256, 200)
+    assert all(0.5 < f[k] < 30.0 for k in ("fwdbwd", "wgrad", "adam")), f
+    assert f["triple"] <= 1.5 * (f["fwdbwd"] + f["wgrad"] + f["adam"]) + 2.0, f
+    eng.close()

@@ -38,6 +38,8 @@ def main(argv=None, emit=True):
     eng.sac_init()
     if os.environ.get("FSRL_SAC_SPLITK"):      # A/B: split-K weight gradients at every batch size (fsrl_sac_set_plan)
         eng.sac_set_plan(1)
+    if os.environ.get("FSRL_SAC_PLAN"):        # A/B: plan bits (2 = sample / gather / n-step as launches of their own)
+        eng.sac_set_plan(int(os.environ["FSRL_SAC_PLAN"]))
     cfg = SACConfig(obs_dim=Do, act_dim=Da, hidden=(H, H))
     o = SACLagOracle(cfg)
     torch.manual_seed(0)
