@@ -66,13 +66,13 @@ def test_sac_updates_vs_golden(name, splitk):
 
 @pytest.mark.parametrize("batch", [256, 1024])
 def test_fused_launch_plan_is_bit_identical_to_the_separate_launches(batch):
-    """fsrl_sac_set_plan bit 1: the sampler, the row gather and the float64 n-step targets as launches of their own (12 launches
-    per update) against the default (sample + gather in one launch, the critics' tile launch computing its targets itself: 10).
+    """fsrl_sac_set_plan bits 1 and 2: the sampler and the row gather / the float64 n-step targets as launches of their own (12
+    launches per update) against the default (sample + gather in one launch, the critics' tile launch computing its targets itself: 10).
     The same Philox counters, the same rows, the same float64 operations: statistics and parameters must agree BIT FOR BIT over
     a run of library-RNG updates; with the caller's indices (parity mode) only the n-step fold differs, also bit for bit."""
     g, cfg, ocfg, store, index = sac_setup("c4")
     outs = []
-    for plan in (0, 2):
+    for plan in (0, 6, 2):
         eng = _engine(cfg, g)
         eng.sac_set_plan(plan)
         rows = [eng.sac_update(batch, [0.5], 1 / 1.5, seed=7 if u == 0 else 0).copy() for u in range(12)]
@@ -82,8 +82,9 @@ def test_fused_launch_plan_is_bit_identical_to_the_separate_launches(batch):
         outs.append((np.stack(rows), eng.sac_get_params(0)[0], eng.sac_get_params(1)[0], eng.sac_get_params(2)[0],
                      eng.sac_last_sample(cfg["batch_size"])[0].copy()))
         eng.close()
-    for a, b in zip(outs[0], outs[1]):
-        assert np.array_equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
     assert np.isfinite(outs[0][0]).all()
 
 
