@@ -25,6 +25,10 @@ for ALG in cpo trpo; do
     timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/${TAG}_pmc_${C}_${ALG} -- env FSRL_NO_CPU=1 FSRL_ONLY=$ALG python $R/tools/bench_trust.py > /dev/null 2>&1
   done
 done
+# the same for CPO with the one-pass streaming weight-gradient kernel (fsrl_tr_set_plan(wgrad = 3): not the default)
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/${TAG}_pmc_${C}_cpo_stream -- env FSRL_NO_CPU=1 FSRL_ONLY=cpo FSRL_TR_PLAN=0,0,3 python $R/tools/bench_trust.py > /dev/null 2>&1
+done
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/${TAG}_pmc_${C}_sac -- python $R/tools/bench_sac.py --rows 200000 --updates 200 --no-cpu > /dev/null 2>&1
 done

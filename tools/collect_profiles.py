@@ -84,9 +84,10 @@ if out:
     json.dump(out, open(os.path.join(pr, f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 
 # ---- HBM-side bytes per UPDATE of the full-batch / replay paths: every kernel's FETCH_SIZE x 2 + WRITE_SIZE summed over
-#      the run, divided by the updates the traced command made (bench_trust.py: 1 warm-up + 5 timed; bench_sac.py: 20 + 200)
+#      the run, divided by the updates the traced command made (bench_trust.py: 1 warm-up + 5 timed; bench_sac.py: 200 + 3 x 200;
+#      cpo_stream = CPO with the one-pass streaming weight-gradient kernel, fsrl_tr_set_plan(wgrad = 3))
 upd = {}
-for alg, n_upd in (("cpo", 6), ("trpo", 6), ("sac", 220)):
+for alg, n_upd in (("cpo", 6), ("trpo", 6), ("sac", 800), ("cpo_stream", 6)):     # bench_sac.py: 200 warm-up + 3 blocks of --updates 200
     by = defaultdict(lambda: {"launches": 0, "fetch_kib": 0.0, "write_kib": 0.0})
     ok = False
     for cname, key in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib")):

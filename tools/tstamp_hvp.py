@@ -51,6 +51,23 @@ def main():
               f"total median {np.median(x[:, 12] - x[:, 0]):.0f} cycles")
         for k in range(1, 13):
             print(f"{k:2d} {LABELS[k]:58s} +{np.median(x[:, k] - x[:, k - 1]):7.0f}   (since entry {np.median(x[:, k] - x[:, 0]):7.0f})")
+    # the launch's schedule.  The shader clock is per XCD (eight unrelated bases): workgroups are clustered by base, and each
+    # cluster (= one XCD, 32 CUs) gets its own timeline: when its workgroups enter and leave relative to the cluster's first entry
+    order = np.argsort(ts[used, 0])
+    u = used[order]
+    cuts = np.flatnonzero(np.diff(ts[u, 0]) > 10**9)
+    clusters = np.split(u, cuts + 1)
+    print(f"--- schedule: {len(clusters)} clock domains (XCDs)")
+    for ci, cl in enumerate(clusters):
+        base = ts[cl, 0].min()
+        ent, end = ts[cl, 0] - base, ts[cl, 12] - base
+        big = cl < 512
+        line = f"XCD {ci}: {len(cl)} workgroups ({int(big.sum())} x 32 rows), span {end.max()} cycles = {end.max() / 2400:.1f} us; busy sum / 32 CUs = {(end - ent).sum() / 32:.0f}"
+        print(line)
+        if ci == 0:
+            o = np.argsort(ent)
+            print("   entry -> exit (rows) of every 4th workgroup in entry order:")
+            print("   " + "  ".join(f"{int(ent[k])}->{int(end[k])}({32 if big[k] else 16})" for k in o[::4]))
     eng.close()
 
 
