@@ -72,6 +72,28 @@ def build(tag):
             add(f"| HIP path at the configs[0] shape (128x128) | {fmt(b['gpu_c0']['value'])} updates/s ({fmt(b['gpu_c0']['us_per_step'], 1)} us per step) |")
         if "speedup_vs_cpu_port" in b:
             add(f"| HIP / CPU port (4 threads) | {fmt(b['speedup_vs_cpu_port'], 0)}x |")
+        k = b.get("kl_on")
+        if isinstance(k, dict) and "value" in k:
+            add(f"| the same update with the KL early stop ON (target_kl 0.02, the reference default; SURVEY 8d \"report both\") | "
+                f"{fmt(k['value'])} updates/s, {fmt(k['grad_steps_per_update_mean'], 0)} optimiser steps per update, "
+                f"{k['updates_stopped_early']} of {k['updates']} updates stopped early |")
+        for key, label in (("cpo_c2", "leg `cpo_c2`: CPO, BASELINE configs[2] (obs 60, 256x256, N = 20 000, CG 10, 4 repeats)"),
+                           ("trpo_c1", "leg `trpo_c1`: TRPO-Lag on the configs[1] shape (N = 20 000 full batch)")):
+            t = b.get(key)
+            if isinstance(t, dict) and "hip_ms_per_update" in t:
+                rf, cb = t.get("roofline", {}), t.get("cpu_baseline", {})
+                add(f"| {label} | {fmt(t['hip_ms_per_update'], 1)} ms per update = {fmt(rf.get('frac'), 3)} of the fp32 MFMA peak over the whole update; "
+                    f"CPU port {fmt(cb.get('value'), 3)} updates/s on {cb.get('cores')} threads ({fmt(t.get('speedup'), 0)}x) |")
+        t = b.get("sac_c3")
+        if isinstance(t, dict) and "value" in t:
+            rf, cb = t.get("roofline", {}), t.get("cpu_baseline", {})
+            add(f"| leg `sac_c3`: SAC-Lag, BASELINE configs[3] (1 M-row store in HBM, batch 1024, n_step 2) | {fmt(t['ms_per_update'] * 1e3, 1)} us per update = "
+                f"{fmt(t['value'], 0)} updates/s, {fmt(rf.get('frac'), 3)} of the fp32 MFMA peak; CPU port {fmt(cb.get('value'), 1)} updates/s on {cb.get('cores')} threads |")
+        lf = (r.get("latency_floor_parts_us") or {}) if isinstance(r, dict) else {}
+        if "three_empty_launches_measured_in_this_run" in lf:
+            e = lf.get("each_grid_behind_itself", {})
+            add(f"| launch floors measured in this run (`fsrl_launch_floors`) | three empty launches of the step's grids behind each other "
+                f"{fmt(lf['three_empty_launches_measured_in_this_run'], 2)} us (each grid behind itself: {fmt(e.get('fwdbwd'), 2)} / {fmt(e.get('wgrad'), 2)} / {fmt(e.get('adam'), 2)} us) |")
         if isinstance(b.get("no_clip"), dict) and "value" in b["no_clip"]:
             add(f"| same update without the gradient-norm clip (agent default; 2 launches per step) | {fmt(b['no_clip']['value'])} updates/s |")
         for key in ("grouped", "grouped_k8"):
@@ -89,7 +111,8 @@ def build(tag):
         for e in b.get("end_to_end_shmem", []) or []:
             if isinstance(e, dict) and "env_steps_per_s" in e:
                 bound = e.get("env_bound_env_steps_per_s")
-                add(f"| worker-process env: {e['workers']} workers x {e['busy_us']:g} us per env step, 32 envs ({e.get('collector_loop', '')}) | "
+                procs = e.get("worker_processes", e["workers"])
+                add(f"| worker-process env: {e['workers']} workers{'' if procs == e['workers'] else f' (capped: {procs} processes)'} x {e['busy_us']:g} us per env step, 32 envs ({e.get('collector_loop', '')}) | "
                     f"{fmt(e['env_steps_per_s'], 0)} env-steps/s" + (f" = {fmt(e['frac_of_env_bound'], 2)} of the env bound {fmt(bound, 0)}" if bound else "") + " |")
         add("")
     ks = kernels(f"{tag}_kernel_stats.csv")
@@ -114,6 +137,10 @@ def build(tag):
             cpu = t.get("cpu_oracle_ms_per_update_4thr")
             add(f"| {kind.upper()} ({'obs 60, ' if kind == 'cpo' else ''}256x256, N = 20 000) | {fmt(t['hip_ms_per_update'], 1)} ms | {fmt(rf.get('frac'), 3)} | "
                 f"{(fmt(tb / 1e9, 2) + ' GB') if tb else 'n/a'} | {(fmt(cpu / 1e3, 1) + ' s = ' + fmt(t.get('speedup'), 0) + 'x') if cpu else 'n/a'} |")
+        cs = (upd.get("cpo_stream") or {}).get("hbm_bytes_per_update")
+        if cs:
+            add(f"| CPO with the one-pass streaming weight-gradient kernel (`fsrl_tr_set_plan(wgrad = 3)`, not the default) | same time within 1-2 % "
+                f"(profiles/{tag}_wgrad2_ab_*.csv) | | {fmt(cs / 1e9, 2)} GB | |")
         for name, kind in ((f"{tag}_bench_sac.json", "sac"), (f"{tag}_bench_cvpo.json", "cvpo")):
             for t in jl(name)[-1:]:
                 rf = t.get("roofline", {})
