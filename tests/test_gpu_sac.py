@@ -67,15 +67,20 @@ def test_sac_updates_vs_golden(name, splitk):
 @pytest.mark.parametrize("batch", [256, 1024])
 def test_fused_launch_plan_is_bit_identical_to_the_separate_launches(batch):
     """fsrl_sac_set_plan bits 1 and 2: the sampler and the row gather / the float64 n-step targets as launches of their own (12
-    launches per update) against the default (sample + gather in one launch, the critics' tile launch computing its targets itself: 10).
+    launches per update) against the default (sample + gather in one launch, the critics' tile launch computing its targets itself: 10);
+    bit 3: the next update's sample drawn on the side stream while this update runs (rows pushed in between invalidate it).
     The same Philox counters, the same rows, the same float64 operations: statistics and parameters must agree BIT FOR BIT over
     a run of library-RNG updates; with the caller's indices (parity mode) only the n-step fold differs, also bit for bit."""
     g, cfg, ocfg, store, index = sac_setup("c4")
     outs = []
-    for plan in (0, 6, 2):
+    for plan in (0, 6, 2, 8, 14):
         eng = _engine(cfg, g)
         eng.sac_set_plan(plan)
         rows = [eng.sac_update(batch, [0.5], 1 / 1.5, seed=7 if u == 0 else 0).copy() for u in range(12)]
+        k = cfg["env_num"]                                  # new rows: the store changed, the prefetched sample must be dropped
+        eng.push(np.arange(k), g["st_obs"][:k], g["st_act"][:k], np.ones(k), np.zeros(k), np.zeros(k, bool), np.zeros(k, bool), g["st_obs"][:k])
+        rows += [eng.sac_update(batch, [0.5], 1 / 1.5, sync=(u % 2 == 0)) for u in range(6)]
+        rows = [r.copy() for r in rows if r is not None]
         lag = g["lagrangian"]
         rows.append(eng.sac_update(cfg["batch_size"], lag, 1.0 / (lag.sum() + 1.0), indices=g["indices"][0],
                                    eps_target=g["eps_target"][0], eps_pi=g["eps_pi"][0]).copy())
