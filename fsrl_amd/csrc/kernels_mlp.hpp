@@ -800,23 +800,13 @@ __device__ __forceinline__ void ppo_stats_finalize(const ModelDesc& md, const Wg
     }
 }
 
-// BIG = false: mbp <= 512, every role is one straight-line load burst (the common case: batch <= 256).
-// BIG = true: the same code inside a loop over 512-row chunks (merged last minibatch of batch 512: 1023).
-// FUSE: apply Adam to every gradient element as soon as it is reduced (max_grad_norm off); a separate instantiation so
-// that the clipped path keeps its register budget (one kernel with a runtime switch spilled 42 VGPRs).
-template <int H, bool BIG, bool FUSE>
-__device__ __forceinline__ void ppo_wgrad_body(const ModelDesc& md, const WgradPtrs& wp, const int mbp,
-                                               const PpoStepArgs& sa, const int n_stat_tiles) {
-    const int CH = BIG ? (mbp + 511) / 512 : 1;      // row chunks
-    constexpr int TPD = H / 32;          // tiles per dimension
-    constexpr int NT2 = TPD * TPD;
-    constexpr int NA = H / 32;
-    constexpr int PB = NT2 + NA;
-    __shared__ float red[1024 * 9];      // 8 split-K partial slots of a 32x32 tile / aux reduce scratch
-    __shared__ float wsum[16];
+// The extra block of a weight-gradient launch: the step's logged row, and db3 / dsigma (column sums of the dout side buffer)
+// of every network with their share of the squared gradient norm.  `red`: at least 32 x 33 floats of LDS.
+template <bool BIG, bool FUSE>
+__device__ __forceinline__ void ppo_wgrad_extra_block(const ModelDesc& md, const WgradPtrs& wp, const int mbp, const PpoStepArgs& sa,
+                                                      const int n_stat_tiles, float* red) {
+    const int CH = BIG ? (mbp + 511) / 512 : 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (FSRL_PROBE(sa, 20)) return;
-    if ((int)blockIdx.x == md.n_nets * PB) {  // the stats block
         if (FSRL_PROBE(sa, 21) || FSRL_PROBE(sa, 22)) return;
         if (wave == 0 && wp.stats) {
             ppo_stats_finalize(md, wp, sa, n_stat_tiles, lane);
@@ -870,6 +860,26 @@ __device__ __forceinline__ void ppo_wgrad_body(const ModelDesc& md, const WgradP
             sqs = wave_sum(sqs);
             if (lane == 0) wp.gsq_part[blockIdx.x] = sqs;
         }
+}
+
+// BIG = false: mbp <= 512, every role is one straight-line load burst (the common case: batch <= 256).
+// BIG = true: the same code inside a loop over 512-row chunks (merged last minibatch of batch 512: 1023).
+// FUSE: apply Adam to every gradient element as soon as it is reduced (max_grad_norm off); a separate instantiation so
+// that the clipped path keeps its register budget (one kernel with a runtime switch spilled 42 VGPRs).
+template <int H, bool BIG, bool FUSE>
+__device__ __forceinline__ void ppo_wgrad_body(const ModelDesc& md, const WgradPtrs& wp, const int mbp,
+                                               const PpoStepArgs& sa, const int n_stat_tiles) {
+    const int CH = BIG ? (mbp + 511) / 512 : 1;      // row chunks
+    constexpr int TPD = H / 32;          // tiles per dimension
+    constexpr int NT2 = TPD * TPD;
+    constexpr int NA = H / 32;
+    constexpr int PB = NT2 + NA;
+    __shared__ float red[1024 * 9];      // 8 split-K partial slots of a 32x32 tile / aux reduce scratch
+    __shared__ float wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (FSRL_PROBE(sa, 20)) return;
+    if ((int)blockIdx.x == md.n_nets * PB) {  // the stats block
+        ppo_wgrad_extra_block<BIG, FUSE>(md, wp, mbp, sa, n_stat_tiles, red);
         return;
     }
     const int net = blockIdx.x / PB, rb = blockIdx.x % PB;
