@@ -238,7 +238,9 @@ class FastCollector:
 
     def _collect_native(self, eng, n_episode, ready, obs, t0, det, bound, low, high, split):
         """worker-process env: the WHOLE collect -- steps, store, actor, resets, episode accounting, surplus envs -- in one library
-        call (fsrl_collect_episodes, or its two-lane split-phase form).  The env's generation counters travel through the call:
+        call (fsrl_collect_episodes, or its two-lane split-phase form).  The interpreter is not entered while the call runs: a
+        KeyboardInterrupt is delivered when the collect returns (a collect of n_episode episodes; native_loop="run" or False
+        returns to Python at every episode boundary / vector step instead).  The env's generation counters travel through the call:
         they are read back even when it fails, so the env object stays consistent with its shared block (a worker that raised
         or died fails the call within half a second; the env itself is then unusable and says so on its next command)."""
         try:
