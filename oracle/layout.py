@@ -4,10 +4,10 @@ The flat float32 vector is the concatenation, in `torch.nn.Module.parameters()` 
 the reference's networks as instantiated at fsrl/agent/ppo_lag_agent.py:136-153 (tianshou
 0.5 `Net` + `ActorProb` / `Critic`):
 
-  gaussian actor (state-independent sigma):
-      sigma_param[Da]  W1[H1,Do] b1[H1]  W2[H2,H1] b2[H2]  Wmu[Da,H2] bmu[Da]
+  gaussian actor (state-independent sigma), hidden_sizes = (H1, ..., HL):
+      sigma_param[Da]  W1[H1,Do] b1[H1]  W2[H2,H1] b2[H2] ... W{L+1}[Da,HL] b{L+1}[Da]      (the last pair is `mu`)
   V critic:
-      W1[H1,Do] b1[H1]  W2[H2,H1] b2[H2]  W3[1,H2] b3[1]
+      W1[H1,Do] b1[H1]  W2[H2,H1] b2[H2] ... W{L+1}[1,HL] b{L+1}[1]                          (the last pair is `last`)
   on-policy policy (PPO-Lag / TRPO-Lag / CPO):  actor ++ critic_0 (reward) ++ critic_1 (cost) ...
 
 All weights are row-major [out_features, in_features] exactly like `nn.Linear.weight`.
@@ -17,17 +17,22 @@ from collections import OrderedDict
 import numpy as np
 
 
+def _trunk_spec(obs_dim, out_dim, hidden):
+    """W1 b1 ... W{L+1} b{L+1}: L hidden Linear + ReLU layers of the given widths, then the head (tianshou 0.5 `Net` with
+    `hidden_sizes` of any length + the `mu` / `last` MLP, fsrl/agent/ppo_lag_agent.py:91,136-145)."""
+    sizes = [int(obs_dim)] + [int(h) for h in hidden] + [int(out_dim)]
+    items = []
+    for l in range(1, len(sizes)):
+        items += [(f"W{l}", (sizes[l], sizes[l - 1])), (f"b{l}", (sizes[l], ))]
+    return items
+
+
 def gauss_actor_spec(obs_dim, act_dim, hidden):
-    h1, h2 = hidden
-    return OrderedDict([("sigma_param", (act_dim, )), ("W1", (h1, obs_dim)), ("b1", (h1, )),
-                        ("W2", (h2, h1)), ("b2", (h2, )), ("W3", (act_dim, h2)),
-                        ("b3", (act_dim, ))])
+    return OrderedDict([("sigma_param", (act_dim, ))] + _trunk_spec(obs_dim, act_dim, hidden))
 
 
 def v_critic_spec(obs_dim, hidden):
-    h1, h2 = hidden
-    return OrderedDict([("W1", (h1, obs_dim)), ("b1", (h1, )), ("W2", (h2, h1)),
-                        ("b2", (h2, )), ("W3", (1, h2)), ("b3", (1, ))])
+    return OrderedDict(_trunk_spec(obs_dim, 1, hidden))
 
 
 def spec_size(spec):

@@ -36,7 +36,7 @@ STAT_KEYS = ("loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss/act
 class PPOLagConfig:
     obs_dim: int
     act_dim: int
-    hidden: Tuple[int, int] = (128, 128)
+    hidden: Tuple[int, ...] = (128, 128)     # hidden_sizes of the agents: any depth (fsrl/agent/ppo_lag_agent.py:91)
     n_critics: int = 2
     max_action: float = 1.0
     gamma: float = 0.99
@@ -131,9 +131,11 @@ class PPOLagOracle:
     # ------------------------------------------------------------------ nets
     @staticmethod
     def _trunk(p, x):
-        h = torch.relu(F.linear(x, p["W1"], p["b1"]))
-        h = torch.relu(F.linear(h, p["W2"], p["b2"]))
-        return F.linear(h, p["W3"], p["b3"])
+        n_lin = sum(1 for k in p if k[0] == "W")        # hidden layers + the head
+        h = x
+        for l in range(1, n_lin):
+            h = torch.relu(F.linear(h, p[f"W{l}"], p[f"b{l}"]))
+        return F.linear(h, p[f"W{n_lin}"], p[f"b{n_lin}"])
 
     def actor_dist(self, obs):
         p = self.nets[0]

@@ -369,6 +369,25 @@ def gen_ppo_widths():
                  max_grad_norm=None, target_kl=1e9)
 
 
+def gen_ppo_depths():
+    # hidden_sizes that are NOT two layers of at most 256 units (fsrl/agent/ppo_lag_agent.py:91,136: any tuple): the HIP library
+    # runs these through its layer-by-layer kernels (include/fsrl_hip.h fsrl_config.n_hidden)
+    gen_ppo_case("deep3", obs_dim=7, act_dim=3, hidden=(64, 48, 32), env_num=3,
+                 ep_lens=[[60, 45, -11], [70, 50], [40, 40, -20]], batch_size=64, repeat=3, seed=51,
+                 max_grad_norm=0.5, target_kl=1e9)
+    gen_ppo_case("wide", obs_dim=8, act_dim=2, hidden=(300, 260), env_num=2,
+                 ep_lens=[[90, 70], [100, -50]], batch_size=128, repeat=2, seed=52,
+                 max_grad_norm=None, target_kl=1e9)
+    gen_ppo_case("one_layer", obs_dim=6, act_dim=2, hidden=(96, ), env_num=3,
+                 ep_lens=[[70, 60, -25], [80, 75], [50, 50, 50]], batch_size=64, repeat=3, seed=53,
+                 max_grad_norm=0.5, target_kl=0.01, lr=3e-3)          # the KL early stop fires
+    rms0 = [(2.9, 6.5, 1500.0), (0.35, 0.8, 1500.0)]
+    gen_ppo_case("deep4_options", obs_dim=6, act_dim=2, hidden=(40, 72, 72, 24), env_num=3,
+                 ep_lens=[[70, 60, -25], [80, 75], [50, 50, 50]], batch_size=64, repeat=3, seed=54,
+                 max_grad_norm=0.5, target_kl=1e9, reward_normalization=True, value_clip=True, ret_rms0=rms0,
+                 recompute_advantage=True, dual_clip=3.0, eps_clip=0.05, lr=2e-3)
+
+
 def gen_ppo_full_case(name, env_num, ep_lens, seed=2, hidden=(256, 256), batch_size=256, repeat=4, theta0_from=None):
     """BASELINE-size fixtures (configs[1]: 20 envs x 1000 rows; configs[4] per rank: 32 envs x 625 rows), 256x256, grad clip
     0.5 (ppol_cfg.py:21), repeat 4 = 312 steps of the UNMODIFIED PPOLagrangian.update.  20 000 rows of random floats do not
@@ -470,4 +489,4 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["gae", "nstep", "pid", "ppo", "manifest"]
     for w in which:
         {"gae": gen_gae, "nstep": gen_nstep, "pid": gen_pid, "ppo": gen_ppo, "recompute": gen_ppo_recompute, "options": gen_ppo_options,
-         "widths": gen_ppo_widths, "full": gen_ppo_full, "manifest": gen_manifest}[w]()
+         "widths": gen_ppo_widths, "depths": gen_ppo_depths, "full": gen_ppo_full, "manifest": gen_manifest}[w]()

@@ -11,7 +11,8 @@ from oracle.pid import rescaling_factor
 from oracle.ppo_lag import PPOLagOracle, split_chunks
 
 CASES = ["tiny", "c1", "c2", "earlystop", "dualclip", "recompute", "rewnorm", "rewnorm_first", "rewnorm_recompute",
-         "unbounded", "widths", "widths_wide"]
+         "unbounded", "widths", "widths_wide",
+         "deep3", "wide", "one_layer", "deep4_options"]     # hidden_sizes of other depths / widths above 256
 
 
 def test_split_chunks_matches_tianshou_semantics():
