@@ -317,6 +317,44 @@ def no_clip_variant(theta, inputs, steps=6):
             "note": "max_grad_norm=None (agent default): Adam fused into the weight-gradient kernel; not the headline config"}
 
 
+def layered_variant(inputs, steps=3):
+    """The headline workload (N 20 000, batch 256, 4 passes, clip 0.5) on networks the fused kernels do not hold: the layered
+    contexts of include/fsrl_hip.h fsrl_config.n_hidden (one MFMA GEMM launch per Linear, 2 L + 5 launches per step).  The
+    (256, 256) row runs the headline network itself through those kernels (force_layered) -- what the fusion is worth."""
+    import torch
+    from fsrl_amd.engine import Engine, EngineConfig
+    obs, act, rew, cost, term, trunc = inputs
+    ids = np.arange(ENVS)
+    lag, resc = np.array([0.75]), 1.0 / 1.75
+    out = {}
+    for hid in ((256, 256), (256, 256, 256), (512, 512), (1024, 1024)):
+        eng = Engine(EngineConfig(obs_dim=OBS, act_dim=ACT, hidden_sizes=hid, force_layered=True, env_num=ENVS, buffer_size=100000,
+                                  max_grad_norm=0.5, target_kl=None))
+        for t in range(NROWS // ENVS):
+            eng.push(ids, obs[t], act[t], rew[t], cost[t], term[t], trunc[t], obs[t + 1])
+        torch.manual_seed(1)
+        eng.set_params((0.05 * torch.randn(eng.n_params)).numpy()); eng.optim_reset(); eng.state_snapshot()
+
+        def one(k):
+            eng.state_restore()
+            return eng.ppo_update(lag, resc, BATCH, REPEAT, perms=None, seed=k + 1)[0]
+        one(0)
+        eng.sync()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            st = one(k + 1)
+        eng.sync()
+        dt = (time.perf_counter() - t0) / steps
+        eng.close()
+        L = len(hid)
+        out["x".join(map(str, hid))] = {"value": 1.0 / dt, "unit": "updates/s", "ms_per_update": dt * 1e3,
+                                        "us_per_step": dt * 1e6 / st.shape[0], "launches_per_step": 2 * L + 5,
+                                        "n_params": int(eng.n_params)}
+    out["note"] = ("hidden_sizes outside the fused kernels' reach (PPO-Lagrangian only): layer-by-layer GEMM launches, activations in "
+                   "HBM; 256x256 = the headline network through the same kernels")
+    return out
+
+
 def pmc_traffic():
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE, separate runs; tools/capture_profiles.sh + tools/collect_profiles.py apply
@@ -709,6 +747,7 @@ def main():
         legs.run("grouped", lambda: grouped(4), 90.0)
         legs.run("grouped_k8", lambda: grouped(8), 90.0)
         legs.run("multi_seed", multi_seed, 90.0)
+        legs.run("layered", lambda: layered_variant(inputs), 90.0)
     legs.emit()
     try:
         eng.close()

@@ -20,7 +20,8 @@ class Config(C.Structure):
                 ("norm_adv", C.c_int32), ("use_lagrangian", C.c_int32), ("lr", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float), ("recompute_adv", C.c_int32),
                 ("unbounded", C.c_int32), ("rew_norm", C.c_int32), ("value_clip", C.c_int32),
-                ("hidden1", C.c_int32), ("hidden2", C.c_int32)]
+                ("hidden1", C.c_int32), ("hidden2", C.c_int32),
+                ("n_hidden", C.c_int32), ("hidden_sizes", C.c_int32 * 8), ("force_layered", C.c_int32)]
 
 
 class ShmEnv(C.Structure):

@@ -21,6 +21,7 @@
 #include "kernels_mlp.hpp"
 #include "kernels_fb.hpp"
 #include "kernels_wgrad2.hpp"
+#include "kernels_layered.hpp"
 
 // ------------------------------------------------------------------------------ errors
 static thread_local std::string g_err;
@@ -184,6 +185,7 @@ struct fsrl_ctx {
     double t_collect_env = 0.0, t_collect_act = 0.0;   // fsrl_collect_timing
     float* snap = nullptr;          // fsrl_state_snapshot: P (with mirrors) | M | V
     int64_t snap_adam_t = 0, snap_critic_t = 0, snap_foc_a = 0, snap_foc_c = 0; bool snap_valid = false;
+    struct LayState* lay = nullptr; // layered PPO-Lag context (hidden_sizes of other depths / widths, host_layered.inc), owned
     struct TrState* tr = nullptr;   // trust-region (CPO / TRPO-Lag) working set, owned
     void* sac = nullptr;            // SacState, owned
 };
@@ -197,6 +199,12 @@ static void tr_set_critic_steps(fsrl_ctx* c, int64_t t);
 static void foc_steps(fsrl_ctx* c, int64_t* t_actor, int64_t* t_critic, bool set);
 static void foc_reset_optim(fsrl_ctx* c);
 static void group_detach(fsrl_ctx* c);
+static void lay_free(fsrl_ctx* c);
+static void lay_build_layout(fsrl_ctx* c, const int* widths, int L);
+static int lay_ensure_mb(fsrl_ctx* c, int B);
+static int lay_ppo_steps(fsrl_ctx* c);
+struct InferArgs;
+static int lay_infer(fsrl_ctx* c, const InferArgs& ia, int jobs_y, hipStream_t s);
 static void comm_free(fsrl_ctx* c);
 static int focops_pass(fsrl_ctx* c, int32_t* stopped_out);
 static int pass_verdict(fsrl_ctx* c, int32_t* stopped_out);
@@ -366,6 +374,7 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
     tr_free(c);
     sac_free(c);
     foc_free(c);
+    lay_free(c);
     if (c->h_actor) (void)hipHostFree(c->h_actor);
     if (c->h_done) (void)hipHostFree(c->h_done);
     if (c->mbstat) (void)hipFree(c->mbstat);
@@ -403,12 +412,34 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
                   cfg->algo == FSRL_ALGO_TRPO_LAG || cfg->algo == FSRL_ALGO_FOCOPS, "unknown algo %d", cfg->algo);
     CHECK_ARG(cfg->obs_dim >= 1 && cfg->obs_dim <= FSRL_MAX_OBS, "obs_dim must be in [1,%d]", FSRL_MAX_OBS);
     CHECK_ARG(cfg->act_dim >= 1 && cfg->act_dim <= FSRL_MAX_ACT, "act_dim must be in [1,%d]", FSRL_MAX_ACT);
-    // two hidden layers of any widths up to 256: the kernels run at H = 64 / 128 / 256, narrower layers are zero-padded
-    const int h1_ = cfg->hidden1 > 0 ? cfg->hidden1 : cfg->hidden, h2_ = cfg->hidden2 > 0 ? cfg->hidden2 : cfg->hidden;
-    CHECK_ARG((cfg->hidden1 > 0) == (cfg->hidden2 > 0), "hidden1 and hidden2 are given together (0, 0 = two layers of `hidden`)");
-    CHECK_ARG(h1_ >= 1 && h1_ <= 256 && h2_ >= 1 && h2_ <= 256, "hidden layer widths must be in [1, 256] (two hidden layers)");
-    const int Hpad_ = std::max(h1_, h2_) <= 64 ? 64 : std::max(h1_, h2_) <= 128 ? 128 : 256;
-    CHECK_ARG(cfg->hidden1 == 0 || cfg->hidden == 0 || cfg->hidden == Hpad_ ,
+    // hidden_sizes (fsrl/agent/ppo_lag_agent.py:91,136): n_hidden > 0 names them.  Two layers of at most 256 units run on the
+    // fused kernels (H = 64 / 128 / 256, narrower layers zero-padded); any other depth / width is a LAYERED context
+    // (host_layered.inc), PPO-Lagrangian only
+    CHECK_ARG(cfg->n_hidden >= 0 && cfg->n_hidden <= FSRL_MAX_HIDDEN, "n_hidden must be in [0, %d]", FSRL_MAX_HIDDEN);
+    bool layered = false;
+    int n_hid1 = cfg->hidden1, n_hid2 = cfg->hidden2;
+    if (cfg->n_hidden > 0) {
+        CHECK_ARG(cfg->hidden1 == 0 && cfg->hidden2 == 0, "give hidden_sizes[n_hidden] or hidden1 / hidden2, not both");
+        for (int l = 0; l < cfg->n_hidden; ++l)
+            CHECK_ARG(cfg->hidden_sizes[l] >= 1 && cfg->hidden_sizes[l] <= FSRL_MAX_WIDTH, "hidden_sizes[%d] = %d outside [1, %d]", l,
+                      cfg->hidden_sizes[l], FSRL_MAX_WIDTH);
+        if (cfg->n_hidden == 2 && cfg->hidden_sizes[0] <= 256 && cfg->hidden_sizes[1] <= 256 && !cfg->force_layered) {
+            n_hid1 = cfg->hidden_sizes[0]; n_hid2 = cfg->hidden_sizes[1];
+        } else {
+            layered = true;
+            CHECK_ARG(cfg->algo == FSRL_ALGO_PPO_LAG,
+                      "hidden_sizes other than two layers of at most 256 units: PPO-Lagrangian contexts only (algo %d)", cfg->algo);
+        }
+    } else {
+        CHECK_ARG(!cfg->force_layered, "force_layered needs hidden_sizes[n_hidden]");
+    }
+    const int h1_ = layered ? 0 : (n_hid1 > 0 ? n_hid1 : cfg->hidden), h2_ = layered ? 0 : (n_hid2 > 0 ? n_hid2 : cfg->hidden);
+    if (!layered) {
+        CHECK_ARG((n_hid1 > 0) == (n_hid2 > 0), "hidden1 and hidden2 are given together (0, 0 = two layers of `hidden`)");
+        CHECK_ARG(h1_ >= 1 && h1_ <= 256 && h2_ >= 1 && h2_ <= 256, "hidden layer widths must be in [1, 256] (two hidden layers)");
+    }
+    const int Hpad_ = layered ? 0 : std::max(h1_, h2_) <= 64 ? 64 : std::max(h1_, h2_) <= 128 ? 128 : 256;
+    CHECK_ARG(layered || n_hid1 == 0 || cfg->hidden == 0 || cfg->hidden == Hpad_ ,
               "hidden = %d does not fit hidden1 / hidden2 = %d / %d (leave hidden 0 or give %d)", cfg->hidden, h1_, h2_, Hpad_);
     CHECK_ARG(cfg->n_critics >= 1 && cfg->n_critics <= 2,
               "n_critics must be 1 or 2 (reward [+ one cost], get_metrics base_policy.py:377-382)");
@@ -444,7 +475,8 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
         (void)hipMemset(c->probe_ts, 0, 1024 * 16 * sizeof(unsigned long long));
     }
 #endif
-    build_layout(c);
+    if (layered) lay_build_layout(c, cfg->hidden_sizes, cfg->n_hidden);
+    else build_layout(c);
 #define TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { fail(FSRL_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); fsrl_ctx_destroy(c); return FSRL_EHIP; } } while (0)
     TRY(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
     TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
@@ -829,6 +861,7 @@ static int dispatch_H(int H, F&& f) {
 static int launch_infer(fsrl_ctx* c, const InferArgs& ia, int jobs_y, hipStream_t s) {
     const int tiles = (ia.N + 15) / 16;
     if (tiles == 0) return 0;
+    if (c->lay) return lay_infer(c, ia, jobs_y, s);
     return dispatch_H(c->cfg.hidden, [&](auto hc) {
         constexpr int H = decltype(hc)::value;
         // persistent over tiles: about one workgroup per CU in total (their LDS footprint allows no more)
@@ -1113,6 +1146,8 @@ extern "C" int fsrl_nstep_return(fsrl_ctx* c, const double* metric, const uint8_
 
 #include "host_ppo.inc"
 
+#include "host_layered.inc"
+
 #include "host_group.inc"
 
 // abandon an update that began with fsrl_ppo_begin and cannot reach fsrl_ppo_end (an exception between the calls on the
@@ -1150,6 +1185,7 @@ __global__ __launch_bounds__(NT) void floor_kernel(int* sink) {
 }
 extern "C" int fsrl_launch_floors(fsrl_ctx* c, int32_t mb_rows, int32_t iters, double* out_us) {
     CHECK_ARG(c && out_us && mb_rows >= 1 && iters >= 1 && iters <= 100000, "bad argument");
+    CHECK_ARG(!c->lay, "launch floors describe the fused three-launch step, not a layered context");
     HIPCHK(hipSetDevice(c->device));
     const int H = c->cfg.hidden, nn = c->md.n_nets;
     const int tiles = (mb_rows + 15) / 16;

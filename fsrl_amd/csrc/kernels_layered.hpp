@@ -1,0 +1,312 @@
+// kernels_layered.hpp -- layer-by-layer kernels of the PPO-Lagrangian update for networks the fused kernels do not cover:
+// `hidden_sizes` of any depth (1 .. FSRL_MAX_HIDDEN hidden layers) and any width (fsrl/agent/ppo_lag_agent.py:91,136-145:
+// tianshou `Net(hidden_sizes=...)` under ActorProb / Critic).  The fused path (kernels_mlp.hpp) keeps a whole two-layer
+// network of at most 256 units in one workgroup; here every Linear is its own MFMA GEMM launch over the minibatch (or, at
+// process_fn time, over the whole batch), all networks of the policy in one launch (grid.z), activations in HBM between
+// launches:
+//     forward   Z_l = relu(Z_{l-1} W_l^T + b_l)             lin_kernel<LIN_F>   one launch per layer (+ the head)
+//     loss      the PPO-Lag / value heads on the head outputs lay_ppo_head_kernel (the arithmetic of the fused kernel's head)
+//     backward  dZ_{l-1} = (dZ_l W_l) * relu'(Z_{l-1})        lin_kernel<LIN_X>   one launch per layer
+//               dW_l = dZ_l^T Z_{l-1}, db_l = colsum(dZ_l)    lin_kernel<LIN_W>   ONE launch for every layer of every network
+//     then the shared ppo_stats_kernel and adam_clip_kernel.
+// 2 L + 5 launches per minibatch step for L hidden layers (the fused path: 3).  fp32 on v_mfma_f32_16x16x4_f32; every
+// reduction has a fixed order (no atomics), so an update is reproducible run to run.
+#pragma once
+#include "common.hpp"
+#include "kernels_mlp.hpp"
+
+#define LAY_MAX_JOBS 32
+#define LIN_F 0     // C[m][n] = act(sum_k A[m][k] B[n][k] + bias[n])            A: M x K,  B: N x K   (both k-contiguous)
+#define LIN_X 1     // C[m][n] = (sum_k A[m][k] B[k][n]) * (mask[m][n] > 0)      A: M x K,  B: K x N
+#define LIN_W 2     // C[m][n] = sum_k A[k][m] B[k][n];  bias_out[m] = sum_k A[k][m]   A: K x M,  B: K x N   (k = batch row)
+
+struct LinJob {
+    const float* A; const float* B; float* C;
+    const float* aux;     // LIN_F: bias [N] ; LIN_X: the activations whose relu' masks the result, M x N with row stride ldaux
+    float* bias_out;      // LIN_W: column sums of A (the bias gradient), length M; may be null
+    int lda, ldb, ldc, ldaux;
+    int M, N, K;
+    int relu;             // LIN_F
+};
+struct LinJobs { int n; int pad; LinJob j[LAY_MAX_JOBS]; };
+
+// offsets of one network inside the flat parameter vector (API layout == device layout: no padding, no mirrors)
+struct LayLayer { int W, b, in, out; };
+struct LayNet { int sigma; int nl; LayLayer l[FSRL_MAX_HIDDEN + 1]; };      // l[0 .. nl-2] hidden layers, l[nl-1] the head
+struct LayModel { int Do, Da, n_nets, unbounded; LayNet net[FSRL_MAX_NETS]; };
+
+#define LIN_LDK 20      // floats per row of a k-minor LDS tile   [64 rows][16 k]   (read as one ds_read_b128 per lane)
+#define LIN_LDJ 68      // floats per row of a k-major LDS tile   [16 k][64 cols]   (4 x ds_read_b32: banks 16 q + li, each twice)
+
+// One 64 x 16 (k-minor) or 16 x 64 (k-major) operand tile of a k-chunk: 256 threads, one float4 each.  Out-of-range elements
+// are zeros, so ragged M / N / K need no special case further down.
+template <bool KMAJOR>
+__device__ __forceinline__ f32x4 lin_load(const float* __restrict__ base, const int ld, const int rows, const int cols,
+                                          const int r0, const int c0, const int tid) {
+    // k-minor: tile row = operand row r0 + (tid >> 2), 4 consecutive k from c0 + 4 (tid & 3)      (rows x cols = R x K)
+    // k-major: tile row = k index     r0 + (tid >> 4), 4 consecutive columns from c0 + 4 (tid & 15)   (rows x cols = K x R)
+    const int r = r0 + (KMAJOR ? (tid >> 4) : (tid >> 2));
+    const int c = c0 + 4 * (KMAJOR ? (tid & 15) : (tid & 3));
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows && c < cols) {
+        const float* p = base + (size_t)r * ld + c;
+        if (c + 3 < cols && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) v = *reinterpret_cast<const f32x4*>(p);
+        else {
+            v[0] = p[0];
+            if (c + 1 < cols) v[1] = p[1];
+            if (c + 2 < cols) v[2] = p[2];
+            if (c + 3 < cols) v[3] = p[3];
+        }
+    }
+    return v;
+}
+template <bool KMAJOR>
+__device__ __forceinline__ void lin_stage(float* __restrict__ s, const f32x4 v, const int tid) {
+    if (KMAJOR) *reinterpret_cast<f32x4*>(&s[(tid >> 4) * LIN_LDJ + 4 * (tid & 15)]) = v;
+    else *reinterpret_cast<f32x4*>(&s[(tid >> 2) * LIN_LDK + 4 * (tid & 3)]) = v;
+}
+// the four k-values (k = 4 q + s) of operand row / column `i` of the staged tile, as the MFMA wants them
+template <bool KMAJOR>
+__device__ __forceinline__ f32x4 lin_frag(const float* __restrict__ s, const int i, const int q) {
+    if (KMAJOR) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = s[(4 * q + e) * LIN_LDJ + i];
+        return v;
+    }
+    return *reinterpret_cast<const f32x4*>(&s[i * LIN_LDK + 4 * q]);
+}
+
+// grid = (max column tiles, max row tiles, jobs); 256 threads = 4 waves; workgroup tile 64 x 64, wave w owns rows 16 w .. 16 w + 15
+// of it (4 MFMA column tiles), k-chunks of 16 staged through LDS with the next chunk's global loads in flight.
+// LIN_W additionally: the workgroups of column tile 0 reduce the bias gradient (ascending batch row), and EVERY workgroup of
+// the grid writes its share of the squared gradient norm to gsq_part[linear block index] (0 for idle ones).
+template <int FORM>
+__global__ __launch_bounds__(256) void lin_kernel(const LinJobs jobs, float* __restrict__ gsq_part) {
+    constexpr bool AKJ = (FORM == LIN_W), BKJ = (FORM != LIN_F);
+    __shared__ __attribute__((aligned(16))) float sA[AKJ ? 16 * LIN_LDJ : 64 * LIN_LDK];
+    __shared__ __attribute__((aligned(16))) float sB[BKJ ? 16 * LIN_LDJ : 64 * LIN_LDK];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, q = lane >> 4;
+    const LinJob& jb = jobs.j[blockIdx.z];
+    const int M = jb.M, N = jb.N, K = jb.K;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const bool bias_role = (FORM == LIN_W) && blockIdx.x == 0 && jb.bias_out != nullptr;
+    if (m0 >= M || (n0 >= N && !bias_role)) {
+        if (FORM == LIN_W && gsq_part && tid == 0) gsq_part[blk] = 0.0f;
+        return;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.0f;
+    // operand geometry: A rows are output rows (k-minor) or batch rows (k-major); the same for B and the output columns
+    auto loadA = [&](int k0) {
+        return AKJ ? lin_load<true>(jb.A, jb.lda, K, M, k0, m0, tid) : lin_load<false>(jb.A, jb.lda, M, K, m0, k0, tid);
+    };
+    auto loadB = [&](int k0) {
+        return BKJ ? lin_load<true>(jb.B, jb.ldb, K, N, k0, n0, tid) : lin_load<false>(jb.B, jb.ldb, N, K, n0, k0, tid);
+    };
+    f32x4 ga = loadA(0), gb = loadB(0);
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        __syncthreads();                       // everybody is done with the previous chunk's tiles
+        lin_stage<AKJ>(sA, ga, tid);
+        lin_stage<BKJ>(sB, gb, tid);
+        __syncthreads();
+        if (k0 + 16 < K) { ga = loadA(k0 + 16); gb = loadB(k0 + 16); }
+        const f32x4 a = lin_frag<AKJ>(sA, 16 * wave + li, q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 b = lin_frag<BKJ>(sB, 16 * t + li, q);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[t] = mfma_16x16x4(a[s], b[s], acc[t]);
+        }
+        if (FORM == LIN_W) {
+            if (bias_role && tid < 64) {
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) bsum += sA[kk * LIN_LDJ + tid];
+            }
+        }
+    }
+    // ---- epilogue: acc[t][r] = C[m0 + 16 wave + 4 q + r][n0 + 16 t + li]
+    float sq = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int n = n0 + 16 * t + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * wave + 4 * q + r;
+            if (m < M && n < N) {
+                float v = acc[t][r];
+                if (FORM == LIN_F) {
+                    v += jb.aux[n];
+                    if (jb.relu) v = fmaxf(v, 0.0f);
+                } else if (FORM == LIN_X) {
+                    v = (jb.aux[(size_t)m * jb.ldaux + n] > 0.0f) ? v : 0.0f;
+                } else {
+                    sq = fmaf(v, v, sq);
+                }
+                jb.C[(size_t)m * jb.ldc + n] = v;
+            }
+        }
+    }
+    if (FORM == LIN_W) {
+        if (bias_role && tid < 64 && m0 + tid < M) {
+            jb.bias_out[m0 + tid] = bsum;
+            sq = fmaf(bsum, bsum, sq);
+        }
+        if (gsq_part) {
+            sq = wave_sum(sq);
+            if (lane == 0) red[wave] = sq;
+            __syncthreads();
+            if (tid == 0) gsq_part[blk] = (red[0] + red[1]) + (red[2] + red[3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- loss heads of one minibatch step
+// grid = (ceil(mb_size / 16), n_nets), 256 threads = (row i = tid >> 4, action dim d = tid & 15): the head arithmetic of
+// ppo_fwd_bwd_body (kernels_mlp.hpp; fsrl/policy/ppo_lag.py:152-212, lagrangian_base.py:145-166) on head outputs that a
+// lin_kernel<LIN_F> launch left in `out` ([net][mbp][16]).  Writes dL/d(head) | dL/d(log sigma) rows to `dout`
+// ([net][mbp][FSRL_DOW]) and the per-16-row partial sums of the logged quantities to statp, like the fused kernel.
+struct LayHeadArgs {
+    const float* out; float* dout; const float* rd; float* statp;
+    const float* P; int sigma;      // the actor's sigma_param inside P
+    int mbp, n_nets, Da, unbounded;
+};
+__global__ __launch_bounds__(256) void lay_ppo_head_kernel(const LayHeadArgs h, const PpoStepArgs sa) {
+    __shared__ float st[16 * 4];
+    const int tid = threadIdx.x, i = tid >> 4, d = tid & 15, lane = tid & 63;
+    const int net = blockIdx.y, tile = blockIdx.x, C = h.n_nets - 1, Da = h.Da;
+    const int row = tile * 16 + i;
+    const bool valid = row < sa.mb_size;
+    const float* rd = h.rd + (size_t)(sa.mb_start + (valid ? row : 0)) * FSRL_RD;
+    const float* o = h.out + ((size_t)net * h.mbp + (valid ? row : 0)) * FSRL_MAX_ACT;
+    float* dO = h.dout + ((size_t)net * h.mbp + row) * FSRL_DOW;
+    const float invB = 1.0f / (float)sa.mb_size;
+    float st0 = 0.f, st1 = 0.f, st2 = 0.f;
+    if (net == 0) {
+        float th = 0.f, var = 1.f, df = 0.f, lp = 0.f;
+        float hs = sa.max_action;
+        if (d < Da) {
+            const float x = o[d];
+            th = tanhf(x);
+            const float sig = expf(h.P[h.sigma + d]);
+            var = sig * sig;
+            df = rd[d] - sa.max_action * th;
+            if (h.unbounded) { df = rd[d] - x; th = 0.0f; hs = 1.0f; }
+            lp = -(df * df) / (2.0f * var) - logf(sig) - LOG_SQRT_2PI;
+        }
+        float logp = 0.0f;
+        for (int dd = 0; dd < Da; ++dd) logp += __shfl(lp, (lane & 48) + dd, 64);
+        const float lpo = rd[FSRL_RD_LOGP];
+        const float ratio = expf(logp - lpo);
+        const float ar = rd[FSRL_RD_ADV];
+        const float s1 = ratio * ar;
+        const float rc = fminf(fmaxf(ratio, 1.0f - sa.eps_clip), 1.0f + sa.eps_clip);
+        const float s2 = rc * ar;
+        const bool inrange = (ratio >= 1.0f - sa.eps_clip) && (ratio <= 1.0f + sa.eps_clip);
+        const float g_c1 = inrange ? ar : (s1 < s2 ? ar : (s1 == s2 ? 0.5f * ar : 0.0f));
+        float term = fminf(s1, s2);
+        float g_term = g_c1;
+        if (sa.dual_clip > 0.0f) {
+            const float c1 = term;
+            const float lim = sa.dual_clip * ar;
+            if (ar < 0.0f) {
+                term = fmaxf(c1, lim);
+                g_term = (c1 > lim) ? g_c1 : (c1 == lim ? 0.5f * g_c1 : 0.0f);
+            }
+        }
+        float dL_dratio = -g_term * invB;
+        float safety_sum = 0.0f;
+        if (sa.use_lagrangian) {
+#pragma unroll
+            for (int c = 1; c < FSRL_MAX_CRITICS; ++c) {
+                if (c < C) {
+                    const float ac = rd[FSRL_RD_ADV + c];
+                    dL_dratio += sa.lam[c - 1] * ac * invB;
+                    safety_sum += ratio * ac * sa.lam[c - 1];
+                }
+            }
+        }
+        const float dL_dlogp = sa.rescale * dL_dratio * ratio;
+        if (valid) {
+            dO[d] = (d < Da) ? dL_dlogp * (df / var) * hs * (1.0f - th * th) : 0.0f;
+            dO[16 + d] = (d < Da) ? dL_dlogp * (df * df / var - 1.0f) : 0.0f;
+            st0 = term; st1 = safety_sum; st2 = lpo - logp;
+        }
+    } else {
+        const int c = net - 1;
+        const float v = o[0];
+        const float dd = rd[FSRL_RD_RET + c] - v;
+        float g = -2.0f * dd, vf = dd * dd;
+        if (sa.value_clip) {
+            const float vo = rd[FSRL_RD_VOLD + c];
+            const float dv = v - vo;
+            const float vc = vo + fminf(fmaxf(dv, -sa.eps_clip), sa.eps_clip);
+            const float d2 = rd[FSRL_RD_RET + c] - vc;
+            const float vf2 = d2 * d2;
+            const float g2 = (dv >= -sa.eps_clip && dv <= sa.eps_clip) ? -2.0f * d2 : 0.0f;
+            g = (vf > vf2) ? g : (vf == vf2 ? 0.5f * g + 0.5f * g2 : g2);
+            vf = fmaxf(vf, vf2);
+        }
+        if (valid) {
+            dO[d] = (d == 0) ? sa.vf_coef * g * invB : 0.0f;
+            dO[16 + d] = 0.0f;
+            st0 = vf;
+        }
+    }
+    if (d == 0) { st[i * 4 + 0] = st0; st[i * 4 + 1] = st1; st[i * 4 + 2] = st2; }
+    __syncthreads();
+    if (tid < 4) {       // rows summed in ascending order
+        float t = 0.0f;
+        if (tid < 3)
+            for (int r = 0; r < 16; ++r) t += st[r * 4 + tid];
+        h.statp[((size_t)tile * h.n_nets + net) * 4 + tid] = t;
+    }
+}
+
+// ---------------------------------------------------------------- process_fn / collector inference: the tail of mlp_infer_kernel
+// grid = (ceil(N / 16), jobs), 64 threads: lane r < 16 finishes row 16 blockIdx.x + r of the job from its head outputs
+// (`out`: [job][N][16]).  Job numbering and semantics are InferArgs' (kernels_mlp.hpp).
+__global__ __launch_bounds__(64) void lay_infer_out_kernel(const float* __restrict__ out, const float* __restrict__ P,
+                                                          const int sigma, const int Da, const int unbounded,
+                                                          const InferArgs a) {
+    const int job = blockIdx.y, C = a.C, tid = threadIdx.x;
+    const bool is_actor = (job == 2 * C);
+    const bool use_next = (!is_actor) && job >= C;
+    const int r = blockIdx.x * 16 + tid;
+    if (a.sigma_param_out && is_actor && blockIdx.x == 0 && tid < Da) a.sigma_param_out[tid] = P[sigma + tid];
+    if (tid < 16 && r < a.N) {
+        const float* o = out + ((size_t)job * a.N + r) * FSRL_MAX_ACT;
+        if (!is_actor) {
+            float v = o[0];
+            const int c = (C > 0) ? job % C : 0;
+            if (use_next) {
+                if (a.flags[r] & 1) v = 0.0f;
+                a.vnext[(size_t)c * a.N + r] = v;
+            } else {
+                a.values[(size_t)c * a.N + r] = v;
+            }
+        } else {
+            float logp = 0.0f;
+            for (int d = 0; d < Da; ++d) {
+                const float x = o[d];
+                const float mu = unbounded ? x : a.max_action * tanhf(x);
+                const float sig = expf(P[sigma + d]);
+                if (a.mu_out) a.mu_out[(size_t)r * Da + d] = mu;
+                if (a.act) {
+                    const float diff = a.act[(size_t)r * Da + d] - mu;
+                    logp += -(diff * diff) / (2.0f * sig * sig) - logf(sig) - LOG_SQRT_2PI;
+                }
+            }
+            if (a.logp_old) a.logp_old[r] = logp;
+        }
+    }
+    if (a.done) {
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.done + blockIdx.x, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}

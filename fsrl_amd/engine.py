@@ -24,7 +24,10 @@ class EngineConfig:
     obs_dim: int = 8
     act_dim: int = 2
     hidden: int = 128                 # two hidden layers of this width ...
-    hidden_sizes: Optional[Sequence[int]] = None   # ... or (h1, h2), any widths in [1, 256] (agents' hidden_sizes); wins over `hidden`
+    hidden_sizes: Optional[Sequence[int]] = None   # ... or the agents' hidden_sizes (wins over `hidden`): two layers of at most 256
+                                                   # units run on the fused kernels; any other tuple (1 .. 8 layers, any width)
+                                                   # makes a layered PPO-Lag context (include/fsrl_hip.h fsrl_config.n_hidden)
+    force_layered: bool = False       # tests: a two-layer network through the layered kernels too
     n_critics: int = 2
     env_num: int = 20
     buffer_size: int = 100000
@@ -52,9 +55,17 @@ class EngineConfig:
         c = _lib.Config()
         c.algo, c.obs_dim, c.act_dim, c.hidden = self.algo, self.obs_dim, self.act_dim, self.hidden
         if self.hidden_sizes is not None:
-            if len(self.hidden_sizes) != 2:
-                raise ValueError(f"the HIP path runs MLPs with two hidden layers, got hidden_sizes={tuple(self.hidden_sizes)}")
-            c.hidden, c.hidden1, c.hidden2 = 0, int(self.hidden_sizes[0]), int(self.hidden_sizes[1])
+            hs = [int(h) for h in self.hidden_sizes]
+            if not 1 <= len(hs) <= 8:
+                raise ValueError(f"the HIP path runs MLPs with 1 to 8 hidden layers, got hidden_sizes={tuple(hs)}")
+            fused = len(hs) == 2 and max(hs) <= 256
+            if not fused and self.algo != _lib.ALGO_PPO_LAG:
+                raise ValueError("this algorithm's HIP path runs MLPs with two hidden layers of at most 256 units, got "
+                                 f"hidden_sizes={tuple(hs)} (other depths / widths: PPO-Lagrangian only)")
+            c.hidden, c.n_hidden = 0, len(hs)
+            for i, h in enumerate(hs):
+                c.hidden_sizes[i] = h
+            c.force_layered = int(self.force_layered)
         c.n_critics, c.env_num, c.buffer_size = self.n_critics, self.env_num, self.buffer_size
         c.max_action, c.gamma, c.gae_lambda = self.max_action, self.gamma, self.gae_lambda
         c.eps_clip, c.dual_clip = self.eps_clip, (self.dual_clip or 0.0)

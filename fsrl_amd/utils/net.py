@@ -41,13 +41,14 @@ class Net(nn.Module):
 
 
 def mlp_geometry(preprocess_net):
-    """(input_dim, (h1, h2)) of a preprocess Net, the way the HIP engine needs it: exactly two Linear + ReLU hidden layers
-    of any widths up to 256 (the kernels run at 64 / 128 / 256 and zero-pad narrower layers, include/fsrl_hip.h
-    fsrl_config.hidden1 / hidden2).  Other depths / widths raise a ValueError that says so."""
+    """(input_dim, hidden_sizes) of a preprocess Net, the way the HIP engine needs it: its Linear + ReLU hidden layers.  Two
+    layers of at most 256 units run on the fused kernels (64 / 128 / 256 wide, narrower layers zero-padded); any other tuple
+    makes a layered PPO-Lagrangian context (include/fsrl_hip.h fsrl_config.n_hidden) -- the other algorithms' contexts refuse
+    it with the library's message."""
     lin = [m for m in preprocess_net.model.model if isinstance(m, nn.Linear)]
     widths = tuple(int(m.out_features) for m in lin)
-    if len(lin) != 2 or max(widths) > 256:
-        raise ValueError(f"the HIP path runs MLPs with two hidden layers of at most 256 units, got hidden_sizes={widths}")
+    if not 1 <= len(lin) <= 8:
+        raise ValueError(f"the HIP path runs MLPs with 1 to 8 hidden layers, got hidden_sizes={widths}")
     return int(lin[0].in_features), widths
 
 

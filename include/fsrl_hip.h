@@ -42,6 +42,8 @@ extern "C" {
 #define FSRL_ALGO_FOCOPS 4
 
 #define FSRL_MAX_CRITICS 4
+#define FSRL_MAX_HIDDEN 8      /* hidden layers of a layered context (fsrl_config.n_hidden)                          */
+#define FSRL_MAX_WIDTH 4096    /* widest hidden layer of a layered context                                            */
 #define FSRL_PPO_NSTATS 11  /* rescaling, lagrangian, actor_safety, actor_rew, actor_total,
                                kl, vf0, vf1, vf_total, total, entropy  (logger keys of
                                fsrl/policy/ppo_lag.py:169-170,204-211,245-247 and
@@ -82,6 +84,17 @@ typedef struct fsrl_config {
                                 widths in [1, 256]; 0, 0 = (hidden, hidden).  Every flat parameter vector of the API (set /
                                 get, gradients, trust-region vectors, the replay agents' actor / critic vectors) has the
                                 caller's layout; the kernels run at 64 / 128 / 256 with zero-padded units               */
+    int32_t n_hidden;        /* 0, or the length of hidden_sizes[] below: `hidden_sizes` of the agents as ANY tuple
+                                (fsrl/agent/ppo_lag_agent.py:91,136-145; tianshou Net(hidden_sizes=...)), 1 .. FSRL_MAX_HIDDEN
+                                layers of 1 .. FSRL_MAX_WIDTH units; leave hidden1 / hidden2 0 with it.  Two layers of at most
+                                256 units select the fused kernels exactly like hidden1 / hidden2.  Anything else makes a
+                                LAYERED context, PPO-Lagrangian only: the same entry points (store, collector actor,
+                                fsrl_ppo_*, parameters, snapshot, lr), the same float64 scans and logged rows, but the network
+                                math runs one MFMA GEMM launch per Linear (2 L + 5 launches per minibatch step instead of 3)
+                                on activations kept in HBM.  Grouped updates, fsrl_launch_floors and the other algorithms
+                                refuse such a context with FSRL_EINVAL.                                                   */
+    int32_t hidden_sizes[FSRL_MAX_HIDDEN];
+    int32_t force_layered;   /* tests: run a two-layer network of at most 256 units through the layered kernels as well   */
 } fsrl_config;
 
 const char* fsrl_last_error(void);

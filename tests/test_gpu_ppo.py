@@ -14,7 +14,8 @@ from helpers import load_npz, oracle_cfg_and_data, ppo_case, ppo_full_case, roll
 pytestmark = pytest.mark.gpu
 
 CASES = ["tiny", "dualclip", "earlystop", "c1", "c2", "recompute", "rewnorm", "rewnorm_first", "rewnorm_recompute", "unbounded",
-         "widths", "widths_wide"]      # two hidden layers of different widths, none of them 64 / 128 / 256 (zero-padded on the device)
+         "widths", "widths_wide",      # two hidden layers of different widths, none of them 64 / 128 / 256 (zero-padded on the device)
+         "deep3", "wide", "one_layer", "deep4_options"]     # other depths / widths above 256: layered contexts (host_layered.inc)
 
 
 def _engine(cfg, **over):
