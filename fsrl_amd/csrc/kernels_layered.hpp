@@ -14,6 +14,7 @@
 #pragma once
 #include "common.hpp"
 #include "kernels_mlp.hpp"
+#include "kernels_fb.hpp"
 
 #define LAY_MAX_JOBS 32
 #define LIN_F 0     // C[m][n] = act(sum_k A[m][k] B[n][k] + bias[n])            A: M x K,  B: N x K   (both k-contiguous)
@@ -264,6 +265,87 @@ __global__ __launch_bounds__(256) void lay_ppo_head_kernel(const LayHeadArgs h, 
         if (tid < 3)
             for (int r = 0; r < 16; ++r) t += st[r * 4 + tid];
         h.statp[((size_t)tile * h.n_nets + net) * 4 + tid] = t;
+    }
+}
+
+// ---------------------------------------------------------------- heads of the FOCOPS minibatch step (and the regression critics)
+// The head arithmetic of fb_tile_body (kernels_fb.hpp) for FB_MODE_FOCOPS on the actor and the plain value regression on the
+// critics (focops.py:161-203), same thread layout and statistics slots ([tile][net][FB_NSTAT]) as lay_ppo_head_kernel.
+struct LayFbHeadArgs {
+    const float* out; float* dout; const float* rd; float* statp;      // rd: row data of THIS minibatch (already offset)
+    const float* P; int sigma;
+    int mbp, n_nets, Da, unbounded, N;
+    float max_action, cr, cc, eta;
+};
+__global__ __launch_bounds__(256) void lay_focops_head_kernel(const LayFbHeadArgs h) {
+    __shared__ float stl[16 * FB_NSTAT];
+    const int tid = threadIdx.x, i = tid >> 4, d = tid & 15, lane = tid & 63;
+    const int net = blockIdx.y, tile = blockIdx.x, Da = h.Da;
+    const int row = tile * 16 + i;
+    const bool valid = row < h.N;
+    const float* rd = h.rd + (size_t)(valid ? row : 0) * FSRL_RD;
+    const float* o = h.out + ((size_t)net * h.mbp + (valid ? row : 0)) * FSRL_MAX_ACT;
+    float* dO = h.dout + ((size_t)net * h.mbp + row) * FSRL_DOW;
+    const float invN = 1.0f / (float)h.N;
+    float st[FB_NSTAT];
+#pragma unroll
+    for (int k = 0; k < FB_NSTAT; ++k) st[k] = 0.0f;
+    if (net == 0) {
+        float th = 0.f, var = 1.f, df = 0.f, lp = 0.f, klp = 0.f, dmu = 0.f, so2 = 0.f;
+        float hs = h.max_action;
+        if (d < Da) {
+            const float x = o[d];
+            th = tanhf(x);
+            const float sig = expf(h.P[h.sigma + d]);
+            var = sig * sig;
+            const float mu = h.max_action * th;
+            df = rd[d] - mu;
+            dmu = mu - rd[FSRL_RD_MEAN + d];
+            if (h.unbounded) { df = rd[d] - x; dmu = x - rd[FSRL_RD_MEAN + d]; th = 0.0f; hs = 1.0f; }
+            lp = -(df * df) / (2.0f * var) - logf(sig) - LOG_SQRT_2PI;
+            const float so = rd[FSRL_RD_STD + d];
+            // KL(new || old): torch.distributions.kl._kl_normal_normal(p = new, q = old)
+            const float vr = (sig / so) * (sig / so);
+            const float t1n = (dmu / so) * (dmu / so);
+            klp = 0.5f * (vr + t1n - 1.0f - logf(vr));
+            so2 = vr;                             // d KL / d log sigma_new = vr - 1
+            dmu = dmu / (so * so);                // d KL / d mu_new
+        }
+        float logp = 0.0f, klrow = 0.0f;
+        for (int dd = 0; dd < Da; ++dd) {
+            logp += __shfl(lp, (lane & 48) + dd, 64);
+            klrow += __shfl(klp, (lane & 48) + dd, 64);
+        }
+        const float lpo = rd[FSRL_RD_LOGP];
+        const float ratio = expf(logp - lpo);
+        const float ar = rd[FSRL_RD_ADV], ac = rd[FSRL_RD_ADV + 1];
+        if (valid) {
+            // loss_row = (KL - cr * ratio * (A_r - cc * A_c)) * mask ; cr = 1 / lambda, cc = nu
+            const float mask = (klrow <= h.eta) ? invN : 0.0f;
+            const float dL_dlogp = -h.cr * (ar - h.cc * ac) * ratio;
+            dO[d] = (d < Da) ? (dL_dlogp * (df / var) + dmu) * hs * (1.0f - th * th) * mask : 0.0f;
+            dO[16 + d] = (d < Da) ? (dL_dlogp * (df * df / var - 1.0f) + (so2 - 1.0f)) * mask : 0.0f;
+            st[0] = (klrow <= h.eta) ? (klrow - h.cr * ratio * (ar - h.cc * ac)) : 0.0f;
+            st[1] = ratio * ac; st[2] = klrow; st[3] = lpo - logp; st[4] = ar; st[5] = ac;
+        }
+    } else {
+        const int c = net - 1;
+        const float dd = rd[FSRL_RD_RET + c] - o[0];
+        if (valid) {
+            dO[d] = (d == 0) ? -2.0f * dd * invN : 0.0f;
+            dO[16 + d] = 0.0f;
+            st[0] = dd * dd;
+        }
+    }
+    if (d == 0) {
+#pragma unroll
+        for (int k = 0; k < FB_NSTAT; ++k) stl[i * FB_NSTAT + k] = st[k];
+    }
+    __syncthreads();
+    if (tid < FB_NSTAT) {        // rows summed in ascending order
+        float t = 0.0f;
+        for (int r = 0; r < 16; ++r) t += stl[r * FB_NSTAT + tid];
+        h.statp[((size_t)tile * h.n_nets + net) * FB_NSTAT + tid] = t;
     }
 }
 

@@ -86,6 +86,11 @@ if __name__ == "__main__":
         # recompute_advantage (focops.py:223-226): GAE from the current critics before passes 2 and 3
         gen("recompute", 6, 2, (64, 64), 3, eps, batch_size=64, repeat=3, seed=54, cost_stat=25.0, recompute_advantage=True)
         sys.exit(0)
+    if sys.argv[1:] == ["depths"]:
+        # hidden_sizes the fused kernels do not hold (focops_agent.py: any tuple): layered contexts on the HIP side
+        gen("deep3", 6, 2, (48, 64, 32), 3, eps, batch_size=64, repeat=3, seed=55, cost_stat=25.0)
+        gen("wide1", 7, 3, (272, ), 3, eps, batch_size=64, repeat=2, seed=56, cost_stat=12.0, nu=0.4, unbounded=True)
+        sys.exit(0)
     gen("small", 6, 2, (64, 64), 3, eps, batch_size=64, repeat=3, seed=50, cost_stat=25.0)
     gen("c1", 8, 2, (128, 128), 4, [[150, 150], [300], [200, -60], [120, 120, -40]], batch_size=256, repeat=4, seed=51,
         cost_stat=4.0, nu=0.3)

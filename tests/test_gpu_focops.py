@@ -32,7 +32,7 @@ def _engine(cfg, g):
 
 
 @pytest.mark.parametrize("four_launch", [0, 1])     # 0: three launches per step (ppo_wgrad_kernel), 1: split-K weight gradients + their sum
-@pytest.mark.parametrize("name", ["small", "c1", "earlystop", "unbounded", "recompute"])
+@pytest.mark.parametrize("name", ["small", "c1", "earlystop", "unbounded", "recompute", "deep3", "wide1"])
 def test_focops_update_vs_golden(name, four_launch):
     g = load_npz(f"focops_{name}.npz")
     cfg = json.loads(str(g["cfg_json"]))

@@ -20,7 +20,7 @@ def focops_cfg(cfg):
                         recompute_advantage=bool(cfg.get("recompute_advantage", False)))
 
 
-@pytest.mark.parametrize("name", ["small", "c1", "earlystop", "unbounded", "recompute"])
+@pytest.mark.parametrize("name", ["small", "c1", "earlystop", "unbounded", "recompute", "deep3", "wide1"])
 def test_focops_update(name):
     torch.set_num_threads(4)
     g = load_npz(f"focops_{name}.npz")
