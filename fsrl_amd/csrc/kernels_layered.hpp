@@ -28,6 +28,9 @@ struct LinJob {
     int lda, ldb, ldc, ldaux;
     int M, N, K;
     int relu;             // LIN_F
+    int a_len;            // 0, or the READABLE length of A's contiguous dimension (K of a k-minor A, M of a k-major one) when the
+                          // buffer is zero-padded beyond the logical length (head-gradient rows: FSRL_DOW wide, zeros past the head
+                          // width) -- lets a 2-wide head share the float4 instantiation with the wide layers of the same launch
 };
 struct LinJobs { int n; int pad; LinJob j[LAY_MAX_JOBS]; };
 
@@ -36,60 +39,86 @@ struct LayLayer { int W, b, in, out; };
 struct LayNet { int sigma; int nl; LayLayer l[FSRL_MAX_HIDDEN + 1]; };      // l[0 .. nl-2] hidden layers, l[nl-1] the head
 struct LayModel { int Do, Da, n_nets, unbounded; LayNet net[FSRL_MAX_NETS]; };
 
-#define LIN_LDK 20      // floats per row of a k-minor LDS tile   [64 rows][16 k]   (read as one ds_read_b128 per lane)
-#define LIN_LDJ 68      // floats per row of a k-major LDS tile   [16 k][64 cols]   (4 x ds_read_b32: banks 16 q + li, each twice)
+#define LIN_KC 64       // k-chunk staged per round trip (a 16-deep chunk made every round trip ~0.7 us of load latency for 16 MFMAs)
+#define LIN_LD 68       // floats per row of a staged 64 x 64 operand tile, either orientation:
+                        //   k-minor [64 operand rows][64 k]: fragment = one ds_read_b128 at row i, k = 16 kc + 4 q
+                        //   k-major [64 k][64 operand cols]: fragment = 4 x ds_read_b32 (banks 16 q + l, every bank exactly twice)
 
-// One 64 x 16 (k-minor) or 16 x 64 (k-major) operand tile of a k-chunk: 256 threads, one float4 each.  Out-of-range elements
-// are zeros, so ragged M / N / K need no special case further down.
-template <bool KMAJOR>
-__device__ __forceinline__ f32x4 lin_load(const float* __restrict__ base, const int ld, const int rows, const int cols,
-                                          const int r0, const int c0, const int tid) {
-    // k-minor: tile row = operand row r0 + (tid >> 2), 4 consecutive k from c0 + 4 (tid & 3)      (rows x cols = R x K)
-    // k-major: tile row = k index     r0 + (tid >> 4), 4 consecutive columns from c0 + 4 (tid & 15)   (rows x cols = K x R)
-    const int r = r0 + (KMAJOR ? (tid >> 4) : (tid >> 2));
-    const int c = c0 + 4 * (KMAJOR ? (tid & 15) : (tid & 3));
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r < rows && c < cols) {
-        const float* p = base + (size_t)r * ld + c;
-        if (c + 3 < cols && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) v = *reinterpret_cast<const f32x4*>(p);
-        else {
-            v[0] = p[0];
-            if (c + 1 < cols) v[1] = p[1];
-            if (c + 2 < cols) v[2] = p[2];
-            if (c + 3 < cols) v[3] = p[3];
+// One 64 x 64 operand tile of a k-chunk: 256 threads x 4 float4, rows of 256 contiguous bytes.  `rows` x `cols` is the extent
+// of the matrix the tile is cut from (k-minor: operand rows x K; k-major: K x operand columns).  Out-of-range elements are
+// zeros, so ragged M / N / K need no special case further down.
+// The loads are STRAIGHT-LINE (addresses clamped into the matrix, no lane-divergent branch around a load: a predicated load
+// costs its whole latency on the spot, kernels_wgrad2.hpp) and the zero-fill is applied when the tile is written to LDS, two
+// chunks later; `ok` carries one bit per element.  VEC (chosen by the host per launch): every operand row is 16-byte aligned
+// and 4 | its length, so a float4 is all in or all out; otherwise four dword loads per slot.
+struct LinTile { f32x4 v[4]; unsigned ok; };
+// One operand's view for this thread: slot j = tid + 256 j covers tile row tr = slot >> 4, tile columns tc .. tc + 3 (tc = 4 (slot & 15)).
+//   k-minor: tile row = operand row (fixed), tile column = k (advances by 64 per chunk)
+//   k-major: tile row = k (advances),        tile column = operand column (fixed)
+template <bool KMAJOR, bool VEC>
+struct LinOperand {
+    const float* base; int ld, fixed_n, K, fixed0;     // fixed_n: extent of the operand dimension (rows of a k-minor operand, columns of a k-major one)
+    int tid;
+    __device__ __forceinline__ LinTile load(const int k0) const {
+        LinTile t;
+        t.ok = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int slot = tid + 256 * j, tr = slot >> 4, tc = 4 * (slot & 15);
+            const int f = fixed0 + (KMAJOR ? tc : tr);        // operand index (fixed over the chunks)
+            const int k = k0 + (KMAJOR ? tr : tc);
+            if (VEC) {
+                // (max(0, .): an operand the job does not have -- the sigma_param job's B -- has extent 0 and reads element 0, masked)
+                const size_t off = KMAJOR ? (size_t)min(k, K - 1) * ld + max(0, min(f, fixed_n - 4)) : (size_t)max(0, min(f, fixed_n - 1)) * ld + min(k, K - 4);
+                t.v[j] = *reinterpret_cast<const f32x4*>(base + off);
+                if (f < fixed_n && k < K) t.ok |= 0xFu << (4 * j);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int fe = KMAJOR ? f + e : f, ke = KMAJOR ? k : k + e;
+                    const size_t off = KMAJOR ? (size_t)min(ke, K - 1) * ld + max(0, min(fe, fixed_n - 1)) : (size_t)max(0, min(fe, fixed_n - 1)) * ld + min(ke, K - 1);
+                    t.v[j][e] = base[off];
+                    if (fe < fixed_n && ke < K) t.ok |= 1u << (4 * j + e);
+                }
+            }
         }
+        return t;
     }
-    return v;
+};
+__device__ __forceinline__ void lin_stage(float* __restrict__ s, const LinTile& t, const int tid) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = tid + 256 * j;
+        f32x4 v = t.v[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ((t.ok >> (4 * j + e)) & 1u) ? v[e] : 0.0f;
+        *reinterpret_cast<f32x4*>(&s[(idx >> 4) * LIN_LD + 4 * (idx & 15)]) = v;
+    }
 }
+// the four k-values (k = 16 kc + 4 q + s) of operand row / column `i` of the staged tile, as the MFMA wants them
 template <bool KMAJOR>
-__device__ __forceinline__ void lin_stage(float* __restrict__ s, const f32x4 v, const int tid) {
-    if (KMAJOR) *reinterpret_cast<f32x4*>(&s[(tid >> 4) * LIN_LDJ + 4 * (tid & 15)]) = v;
-    else *reinterpret_cast<f32x4*>(&s[(tid >> 2) * LIN_LDK + 4 * (tid & 3)]) = v;
-}
-// the four k-values (k = 4 q + s) of operand row / column `i` of the staged tile, as the MFMA wants them
-template <bool KMAJOR>
-__device__ __forceinline__ f32x4 lin_frag(const float* __restrict__ s, const int i, const int q) {
+__device__ __forceinline__ f32x4 lin_frag(const float* __restrict__ s, const int i, const int kc, const int q) {
     if (KMAJOR) {
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = s[(4 * q + e) * LIN_LDJ + i];
+        for (int e = 0; e < 4; ++e) v[e] = s[(16 * kc + 4 * q + e) * LIN_LD + i];
         return v;
     }
-    return *reinterpret_cast<const f32x4*>(&s[i * LIN_LDK + 4 * q]);
+    return *reinterpret_cast<const f32x4*>(&s[i * LIN_LD + 16 * kc + 4 * q]);
 }
 
 // grid = (max column tiles, max row tiles, jobs); 256 threads = 4 waves; workgroup tile 64 x 64, wave w owns rows 16 w .. 16 w + 15
-// of it (4 MFMA column tiles), k-chunks of 16 staged through LDS with the next chunk's global loads in flight.
+// of it (4 MFMA column tiles), k-chunks of 64 staged through LDS (34 KB) with the next two chunks' global loads in flight.
 // LIN_W additionally: the workgroups of column tile 0 reduce the bias gradient (ascending batch row), and EVERY workgroup of
 // the grid writes its share of the squared gradient norm to gsq_part[linear block index] (0 for idle ones).
-template <int FORM>
+template <int FORM, bool VEC>
 __global__ __launch_bounds__(256) void lin_kernel(const LinJobs jobs, float* __restrict__ gsq_part) {
     constexpr bool AKJ = (FORM == LIN_W), BKJ = (FORM != LIN_F);
-    __shared__ __attribute__((aligned(16))) float sA[AKJ ? 16 * LIN_LDJ : 64 * LIN_LDK];
-    __shared__ __attribute__((aligned(16))) float sB[BKJ ? 16 * LIN_LDJ : 64 * LIN_LDK];
+    __shared__ __attribute__((aligned(16))) float sA[64 * LIN_LD];
+    __shared__ __attribute__((aligned(16))) float sB[64 * LIN_LD];
     __shared__ float red[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, q = lane >> 4;
-    const LinJob& jb = jobs.j[blockIdx.z];
+    const LinJob jb = jobs.j[blockIdx.z];        // by value: the fields live in SGPRs, not re-read from the kernel arguments per chunk
     const int M = jb.M, N = jb.N, K = jb.K;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -103,32 +132,53 @@ __global__ __launch_bounds__(256) void lin_kernel(const LinJobs jobs, float* __r
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.0f;
     // operand geometry: A rows are output rows (k-minor) or batch rows (k-major); the same for B and the output columns
-    auto loadA = [&](int k0) {
-        return AKJ ? lin_load<true>(jb.A, jb.lda, K, M, k0, m0, tid) : lin_load<false>(jb.A, jb.lda, M, K, m0, k0, tid);
-    };
-    auto loadB = [&](int k0) {
-        return BKJ ? lin_load<true>(jb.B, jb.ldb, K, N, k0, n0, tid) : lin_load<false>(jb.B, jb.ldb, N, K, n0, k0, tid);
-    };
-    f32x4 ga = loadA(0), gb = loadB(0);
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    const LinOperand<AKJ, VEC> opA{jb.A, jb.lda, (AKJ && jb.a_len) ? jb.a_len : M, (!AKJ && jb.a_len) ? jb.a_len : K, m0, tid};
+    const LinOperand<BKJ, VEC> opB{jb.B, jb.ldb, N, K, n0, tid};
+    // register prefetch two chunks ahead: one chunk's MFMA work (~0.85 us) is shorter than a cold round trip to L2 / HBM.
+    // Two named tile pairs (a dynamically indexed register array would go to scratch); a load past K is clamped and unused.
+    LinTile a0 = opA.load(0), b0 = opB.load(0), a1 = opA.load(LIN_KC), b1 = opB.load(LIN_KC);
+    auto chunk = [&](const int k0, LinTile& ta, LinTile& tb) __attribute__((always_inline)) {
         __syncthreads();                       // everybody is done with the previous chunk's tiles
-        lin_stage<AKJ>(sA, ga, tid);
-        lin_stage<BKJ>(sB, gb, tid);
+        lin_stage(sA, ta, tid);
+        lin_stage(sB, tb, tid);
         __syncthreads();
-        if (k0 + 16 < K) { ga = loadA(k0 + 16); gb = loadB(k0 + 16); }
-        const f32x4 a = lin_frag<AKJ>(sA, 16 * wave + li, q);
+        ta = opA.load(k0 + 2 * LIN_KC); tb = opB.load(k0 + 2 * LIN_KC);
+        // fragments of sub-chunk kc + 1 are read while the 16 MFMAs of sub-chunk kc issue; the MFMAs of one k-step go round the
+        // four accumulators, so consecutive ones are independent
+        f32x4 fa = lin_frag<AKJ>(sA, 16 * wave + li, 0, q), fb[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f32x4 b = lin_frag<BKJ>(sB, 16 * t + li, q);
+        for (int t = 0; t < 4; ++t) fb[t] = lin_frag<BKJ>(sB, 16 * t + li, 0, q);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc[t] = mfma_16x16x4(a[s], b[s], acc[t]);
-        }
-        if (FORM == LIN_W) {
-            if (bias_role && tid < 64) {
+        for (int kc = 0; kc < LIN_KC / 16; ++kc) {
+            const f32x4 a = fa;
+            f32x4 b[4];
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) bsum += sA[kk * LIN_LDJ + tid];
+            for (int t = 0; t < 4; ++t) b[t] = fb[t];
+            if (kc + 1 < LIN_KC / 16) {
+                fa = lin_frag<AKJ>(sA, 16 * wave + li, kc + 1, q);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fb[t] = lin_frag<BKJ>(sB, 16 * t + li, kc + 1, q);
+            }
+            if (k0 + 16 * kc < K) {            // uniform; the rest of the chunk is zeros
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = mfma_16x16x4(a[s], b[t][s], acc[t]);
+                if (FORM == LIN_W) {
+                    if (bias_role && tid < 64) {   // ascending batch row; the 16 LDS reads of a sub-chunk issued together
+                        float v[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) v[u] = sA[(16 * kc + u) * LIN_LD + tid];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) bsum += v[u];
+                    }
+                }
             }
         }
+    };
+    for (int k0 = 0; k0 < K; k0 += 2 * LIN_KC) {
+        chunk(k0, a0, b0);
+        if (k0 + LIN_KC < K) chunk(k0 + LIN_KC, a1, b1);
     }
     // ---- epilogue: acc[t][r] = C[m0 + 16 wave + 4 q + r][n0 + 16 t + li]
     float sq = 0.0f;
