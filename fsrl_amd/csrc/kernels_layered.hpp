@@ -28,11 +28,19 @@ struct LinJob {
     int lda, ldb, ldc, ldaux;
     int M, N, K;
     int relu;             // LIN_F
+    // the R-operator products of the trust-region path (Hessian-vector products, host_trust.inc); null / 0 everywhere else
+    const float* acc;     // LIN_F / LIN_X: added to the product before bias / relu / mask, M x N with row stride ldacc (may be C itself)
+    const float* mask;    // LIN_F: result := (mask[m][n] > 0) ? result : 0 after the bias, M x N with row stride ldmask
+    const float* A2; const float* B2;     // LIN_W: a second operand pair accumulated into the same output (same shapes and strides)
+    int ldacc, ldmask;
     int a_len;            // 0, or the READABLE length of A's contiguous dimension (K of a k-minor A, M of a k-major one) when the
                           // buffer is zero-padded beyond the logical length (head-gradient rows: FSRL_DOW wide, zeros past the head
                           // width) -- lets a 2-wide head share the float4 instantiation with the wide layers of the same launch
 };
-struct LinJobs { int n; int pad; LinJob j[LAY_MAX_JOBS]; };
+// ksplit > 1 (LIN_W only): the reduction over K (the batch rows) is cut into ksplit contiguous ranges of kchunk rows, range s
+// writing its own partial at C + s * part_stride / bias_out + s * part_stride; the consumer adds the partials in float64 in
+// ascending order (fb_sum_parts_kernel, adam_range_kernel, cg_pz_kernel: the split-K convention of fb_wgrad_kernel).
+struct LinJobs { int n; int ksplit; int kchunk; int part_stride; LinJob j[LAY_MAX_JOBS]; };
 
 // offsets of one network inside the flat parameter vector (API layout == device layout: no padding, no mirrors)
 struct LayLayer { int W, b, in, out; };
@@ -118,9 +126,20 @@ __global__ __launch_bounds__(256) void lin_kernel(const LinJobs jobs, float* __r
     __shared__ __attribute__((aligned(16))) float sB[64 * LIN_LD];
     __shared__ float red[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, q = lane >> 4;
-    const LinJob jb = jobs.j[blockIdx.z];        // by value: the fields live in SGPRs, not re-read from the kernel arguments per chunk
+    LinJob jb = jobs.j[blockIdx.z];              // by value: the fields live in SGPRs, not re-read from the kernel arguments per chunk
+    int by = blockIdx.y;
+    if (FORM == LIN_W && jobs.ksplit > 1) {      // this workgroup's range of batch rows and its partial
+        const int row_tiles = gridDim.y / jobs.ksplit, sp = by / row_tiles;
+        by -= sp * row_tiles;
+        const int kb = min(sp * jobs.kchunk, jb.K);
+        jb.K = min(jb.K - kb, jobs.kchunk);
+        jb.A += (size_t)kb * jb.lda; jb.B += (size_t)kb * jb.ldb;
+        if (jb.A2) { jb.A2 += (size_t)kb * jb.lda; jb.B2 += (size_t)kb * jb.ldb; }
+        jb.C += (size_t)sp * jobs.part_stride;
+        if (jb.bias_out) jb.bias_out += (size_t)sp * jobs.part_stride;
+    }
     const int M = jb.M, N = jb.N, K = jb.K;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = by * 64, n0 = blockIdx.x * 64;
     const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const bool bias_role = (FORM == LIN_W) && blockIdx.x == 0 && jb.bias_out != nullptr;
     if (m0 >= M || (n0 >= N && !bias_role)) {
@@ -132,8 +151,10 @@ __global__ __launch_bounds__(256) void lin_kernel(const LinJobs jobs, float* __r
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.0f;
     // operand geometry: A rows are output rows (k-minor) or batch rows (k-major); the same for B and the output columns
-    const LinOperand<AKJ, VEC> opA{jb.A, jb.lda, (AKJ && jb.a_len) ? jb.a_len : M, (!AKJ && jb.a_len) ? jb.a_len : K, m0, tid};
-    const LinOperand<BKJ, VEC> opB{jb.B, jb.ldb, N, K, n0, tid};
+    // one pass over K for an operand pair; LIN_W may run a second pair into the same accumulators (R{dW} = R{dz}^T a + dz^T R{a})
+    auto k_pass = [&](const float* Ap, const float* Bp, const bool with_bias) __attribute__((always_inline)) {
+    const LinOperand<AKJ, VEC> opA{Ap, jb.lda, (AKJ && jb.a_len) ? jb.a_len : M, (!AKJ && jb.a_len) ? jb.a_len : K, m0, tid};
+    const LinOperand<BKJ, VEC> opB{Bp, jb.ldb, N, K, n0, tid};
     // register prefetch two chunks ahead: one chunk's MFMA work (~0.85 us) is shorter than a cold round trip to L2 / HBM.
     // Two named tile pairs (a dynamically indexed register array would go to scratch); a load past K is clamped and unused.
     LinTile a0 = opA.load(0), b0 = opB.load(0), a1 = opA.load(LIN_KC), b1 = opB.load(LIN_KC);
@@ -165,7 +186,7 @@ __global__ __launch_bounds__(256) void lin_kernel(const LinJobs jobs, float* __r
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc[t] = mfma_16x16x4(a[s], b[t][s], acc[t]);
                 if (FORM == LIN_W) {
-                    if (bias_role && tid < 64) {   // ascending batch row; the 16 LDS reads of a sub-chunk issued together
+                    if (with_bias && bias_role && tid < 64) {   // ascending batch row; the 16 LDS reads of a sub-chunk issued together
                         float v[16];
 #pragma unroll
                         for (int u = 0; u < 16; ++u) v[u] = sA[(16 * kc + u) * LIN_LD + tid];
@@ -180,6 +201,11 @@ __global__ __launch_bounds__(256) void lin_kernel(const LinJobs jobs, float* __r
         chunk(k0, a0, b0);
         if (k0 + LIN_KC < K) chunk(k0 + LIN_KC, a1, b1);
     }
+    };
+    k_pass(jb.A, jb.B, true);
+    if (FORM == LIN_W) {
+        if (jb.A2) k_pass(jb.A2, jb.B2, false);     // uniform
+    }
     // ---- epilogue: acc[t][r] = C[m0 + 16 wave + 4 q + r][n0 + 16 t + li]
     float sq = 0.0f;
 #pragma unroll
@@ -191,10 +217,13 @@ __global__ __launch_bounds__(256) void lin_kernel(const LinJobs jobs, float* __r
             if (m < M && n < N) {
                 float v = acc[t][r];
                 if (FORM == LIN_F) {
-                    v += jb.aux[n];
+                    if (jb.acc) v += jb.acc[(size_t)m * jb.ldacc + n];
+                    if (jb.aux) v += jb.aux[n];
                     if (jb.relu) v = fmaxf(v, 0.0f);
+                    if (jb.mask) v = (jb.mask[(size_t)m * jb.ldmask + n] > 0.0f) ? v : 0.0f;
                 } else if (FORM == LIN_X) {
-                    v = (jb.aux[(size_t)m * jb.ldaux + n] > 0.0f) ? v : 0.0f;
+                    if (jb.acc) v += jb.acc[(size_t)m * jb.ldacc + n];
+                    if (jb.aux) v = (jb.aux[(size_t)m * jb.ldaux + n] > 0.0f) ? v : 0.0f;
                 } else {
                     sq = fmaf(v, v, sq);
                 }
@@ -318,21 +347,23 @@ __global__ __launch_bounds__(256) void lay_ppo_head_kernel(const LayHeadArgs h, 
     }
 }
 
-// ---------------------------------------------------------------- heads of the FOCOPS minibatch step (and the regression critics)
-// The head arithmetic of fb_tile_body (kernels_fb.hpp) for FB_MODE_FOCOPS on the actor and the plain value regression on the
-// critics (focops.py:161-203), same thread layout and statistics slots ([tile][net][FB_NSTAT]) as lay_ppo_head_kernel.
+// ---------------------------------------------------------------- heads of the full-batch family (FOCOPS step, CPO / TRPO-Lag)
+// The head arithmetic of fb_tile_body (kernels_fb.hpp) on head outputs a lin_kernel<LIN_F> launch left in `out`: actor modes
+// FB_MODE_SUR / _KL / _FOCOPS / _EVAL (cpo.py:184-214, trpo_lag.py:134-171, focops.py:161-203), the plain value regression on
+// the critics.  grid = (ceil(N / 16), ny): network net0 + blockIdx.y; statistics slots [tile][ny][FB_NSTAT] like fb_tile_kernel.
 struct LayFbHeadArgs {
-    const float* out; float* dout; const float* rd; float* statp;      // rd: row data of THIS minibatch (already offset)
+    const float* out; float* dout; const float* rd; float* statp;      // rd: row data of THESE rows (already offset)
     const float* P; int sigma;
-    int mbp, n_nets, Da, unbounded, N;
+    int mbp, net0, ny, Da, unbounded, N, mode;
     float max_action, cr, cc, eta;
 };
-__global__ __launch_bounds__(256) void lay_focops_head_kernel(const LayFbHeadArgs h) {
+__global__ __launch_bounds__(256) void lay_fb_head_kernel(const LayFbHeadArgs h) {
     __shared__ float stl[16 * FB_NSTAT];
     const int tid = threadIdx.x, i = tid >> 4, d = tid & 15, lane = tid & 63;
-    const int net = blockIdx.y, tile = blockIdx.x, Da = h.Da;
+    const int y = blockIdx.y, net = h.net0 + y, tile = blockIdx.x, Da = h.Da;
     const int row = tile * 16 + i;
     const bool valid = row < h.N;
+    const bool backward = h.mode != FB_MODE_EVAL;
     const float* rd = h.rd + (size_t)(valid ? row : 0) * FSRL_RD;
     const float* o = h.out + ((size_t)net * h.mbp + (valid ? row : 0)) * FSRL_MAX_ACT;
     float* dO = h.dout + ((size_t)net * h.mbp + row) * FSRL_DOW;
@@ -353,13 +384,19 @@ __global__ __launch_bounds__(256) void lay_focops_head_kernel(const LayFbHeadArg
             dmu = mu - rd[FSRL_RD_MEAN + d];
             if (h.unbounded) { df = rd[d] - x; dmu = x - rd[FSRL_RD_MEAN + d]; th = 0.0f; hs = 1.0f; }
             lp = -(df * df) / (2.0f * var) - logf(sig) - LOG_SQRT_2PI;
+            // KL(old || new), torch.distributions.kl._kl_normal_normal
             const float so = rd[FSRL_RD_STD + d];
-            // KL(new || old): torch.distributions.kl._kl_normal_normal(p = new, q = old)
-            const float vr = (sig / so) * (sig / so);
-            const float t1n = (dmu / so) * (dmu / so);
-            klp = 0.5f * (vr + t1n - 1.0f - logf(vr));
-            so2 = vr;                             // d KL / d log sigma_new = vr - 1
-            dmu = dmu / (so * so);                // d KL / d mu_new
+            so2 = so * so;
+            const float var_ratio = (so / sig) * (so / sig);
+            const float t1 = (dmu / sig) * (dmu / sig);
+            klp = 0.5f * (var_ratio + t1 - 1.0f - logf(var_ratio));
+            if (h.mode == FB_MODE_FOCOPS) {          // KL(new || old): _kl_normal_normal(p = new, q = old)
+                const float vr = (sig / so) * (sig / so);
+                const float t1n = (dmu / so) * (dmu / so);
+                klp = 0.5f * (vr + t1n - 1.0f - logf(vr));
+                so2 = vr;                             // d KL / d log sigma_new = vr - 1
+                dmu = dmu / (so * so);                // d KL / d mu_new
+            }
         }
         float logp = 0.0f, klrow = 0.0f;
         for (int dd = 0; dd < Da; ++dd) {
@@ -369,21 +406,34 @@ __global__ __launch_bounds__(256) void lay_focops_head_kernel(const LayFbHeadArg
         const float lpo = rd[FSRL_RD_LOGP];
         const float ratio = expf(logp - lpo);
         const float ar = rd[FSRL_RD_ADV], ac = rd[FSRL_RD_ADV + 1];
+        if (valid && backward) {
+            float g0 = 0.0f, g1 = 0.0f;
+            if (d < Da) {
+                if (h.mode == FB_MODE_SUR) {
+                    const float dL_dlogp = (h.cr * ar + h.cc * ac) * ratio * invN;
+                    g0 = dL_dlogp * (df / var) * hs * (1.0f - th * th);
+                    g1 = dL_dlogp * (df * df / var - 1.0f);
+                } else if (h.mode == FB_MODE_KL) {
+                    g0 = (dmu / var) * invN * hs * (1.0f - th * th);
+                    g1 = (1.0f - (so2 + dmu * dmu) / var) * invN;
+                } else {                              // FB_MODE_FOCOPS: (KL - cr * ratio * (A_r - cc * A_c)) * mask ; cr = 1 / lambda, cc = nu
+                    const float mask = (klrow <= h.eta) ? invN : 0.0f;
+                    const float dL_dlogp = -h.cr * (ar - h.cc * ac) * ratio;
+                    g0 = (dL_dlogp * (df / var) + dmu) * hs * (1.0f - th * th) * mask;
+                    g1 = (dL_dlogp * (df * df / var - 1.0f) + (so2 - 1.0f)) * mask;
+                }
+            }
+            dO[d] = g0; dO[16 + d] = g1;
+        }
         if (valid) {
-            // loss_row = (KL - cr * ratio * (A_r - cc * A_c)) * mask ; cr = 1 / lambda, cc = nu
-            const float mask = (klrow <= h.eta) ? invN : 0.0f;
-            const float dL_dlogp = -h.cr * (ar - h.cc * ac) * ratio;
-            dO[d] = (d < Da) ? (dL_dlogp * (df / var) + dmu) * hs * (1.0f - th * th) * mask : 0.0f;
-            dO[16 + d] = (d < Da) ? (dL_dlogp * (df * df / var - 1.0f) + (so2 - 1.0f)) * mask : 0.0f;
-            st[0] = (klrow <= h.eta) ? (klrow - h.cr * ratio * (ar - h.cc * ac)) : 0.0f;
-            st[1] = ratio * ac; st[2] = klrow; st[3] = lpo - logp; st[4] = ar; st[5] = ac;
+            st[0] = ratio * ar; st[1] = ratio * ac; st[2] = klrow; st[3] = lpo - logp; st[4] = ar; st[5] = ac;
+            if (h.mode == FB_MODE_FOCOPS) st[0] = (klrow <= h.eta) ? (klrow - h.cr * ratio * (ar - h.cc * ac)) : 0.0f;
         }
     } else {
         const int c = net - 1;
         const float dd = rd[FSRL_RD_RET + c] - o[0];
         if (valid) {
-            dO[d] = (d == 0) ? -2.0f * dd * invN : 0.0f;
-            dO[16 + d] = 0.0f;
+            if (backward) { dO[d] = (d == 0) ? -2.0f * dd * invN : 0.0f; dO[16 + d] = 0.0f; }
             st[0] = dd * dd;
         }
     }
@@ -395,8 +445,49 @@ __global__ __launch_bounds__(256) void lay_focops_head_kernel(const LayFbHeadArg
     if (tid < FB_NSTAT) {        // rows summed in ascending order
         float t = 0.0f;
         for (int r = 0; r < 16; ++r) t += stl[r * FB_NSTAT + tid];
-        h.statp[((size_t)tile * h.n_nets + net) * FB_NSTAT + tid] = t;
+        h.statp[((size_t)tile * h.ny + y) * FB_NSTAT + tid] = t;
     }
+}
+
+// KL head of a Hessian-vector product (the head of fb_hvp_body, kernels_fb.hpp; cpo.py:169-182): from the head outputs x and their
+// tangent R{x} (`rout`), the tangent of log sigma (v's sigma_param block) -> dout = dKLbar / d(head | log sigma) and R{dout}.
+// grid = ceil(N / 16), 256 threads = (row, action dim).
+struct LayHvpHeadArgs {
+    const float* out; const float* rout; float* dout; float* rdout; const float* rd;
+    const float* P; const float* V; int sigma;
+    int Da, unbounded, N;
+    float max_action;
+};
+__global__ __launch_bounds__(256) void lay_hvp_head_kernel(const LayHvpHeadArgs h) {
+    const int tid = threadIdx.x, i = tid >> 4, d = tid & 15;
+    const int row = blockIdx.x * 16 + i;
+    if (row >= h.N) return;
+    float g0 = 0.f, g1 = 0.f, r0 = 0.f, r1 = 0.f;
+    if (d < h.Da) {
+        const float invN = 1.0f / (float)h.N;
+        const float* rd = h.rd + (size_t)row * FSRL_RD;
+        const float x = h.out[(size_t)row * FSRL_MAX_ACT + d];
+        const float t = h.unbounded ? 0.0f : tanhf(x);
+        const float hs = h.unbounded ? 1.0f : h.max_action;
+        const float ro = h.rout[(size_t)row * FSRL_MAX_ACT + d];
+        const float sp = h.P[h.sigma + d], rls = h.V[h.sigma + d];      // R{log sigma} = v_sigma
+        const float sig = expf(sp), var = sig * sig;
+        const float dt = hs * (1.0f - t * t);                           // dmu / dout
+        const float rmu = dt * ro;
+        const float dmu_b = h.max_action * t - rd[FSRL_RD_MEAN + d];
+        const float dmu = h.unbounded ? x - rd[FSRL_RD_MEAN + d] : dmu_b;
+        const float so = rd[FSRL_RD_STD + d], so2 = so * so;
+        const float gmu = dmu / var;                                    // dKL / dmu
+        const float rgmu = rmu / var - 2.0f * gmu * rls;
+        const float rgls = -2.0f * dmu * rmu / var + 2.0f * (so2 + dmu * dmu) / var * rls;
+        const float rdt = hs * (-2.0f * t) * (1.0f - t * t) * ro;       // R{dmu / dout}
+        g0 = invN * gmu * dt;
+        r0 = invN * (rgmu * dt + gmu * rdt);
+        g1 = invN * (1.0f - (so2 + dmu * dmu) / var);
+        r1 = invN * rgls;
+    }
+    h.dout[(size_t)row * FSRL_DOW + d] = g0; h.dout[(size_t)row * FSRL_DOW + 16 + d] = g1;
+    h.rdout[(size_t)row * FSRL_DOW + d] = r0; h.rdout[(size_t)row * FSRL_DOW + 16 + d] = r1;
 }
 
 // ---------------------------------------------------------------- process_fn / collector inference: the tail of mlp_infer_kernel

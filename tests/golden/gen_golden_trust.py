@@ -265,6 +265,15 @@ if __name__ == "__main__":
         gen_trpo("widths", 8, 2, (48, 80), 3, eps, repeat=2, seed=34, cost_stat=25.0, cost_limit=10.0,
                  optim_critic_iters=3)
         sys.exit(0)
+    if sys.argv[1:] == ["depths"]:
+        # hidden_sizes the fused kernels do not hold (cpo_agent.py / trpol_agent.py: any tuple): layered contexts on the HIP side
+        gen_cpo("deep3", 8, 2, (48, 64, 40), 3, eps, repeat=2, seed=41, cost_stat=25.0, cost_limit=10.0,
+                optim_critic_iters=3, max_backtracks=10)
+        gen_trpo("deep3", 8, 2, (40, 56, 32), 3, eps, repeat=2, seed=38, cost_stat=25.0, cost_limit=10.0,
+                 optim_critic_iters=3)
+        gen_cpo("wide1", 8, 2, (272, ), 3, eps, repeat=2, seed=39, cost_stat=3.0, cost_limit=10.0,
+                optim_critic_iters=3, max_backtracks=10)
+        sys.exit(0)
     if sys.argv[1:] == ["wideobs"]:
         # 100 observation columns: the first layer's weight gradient takes three passes of the weight-side kernel's aux blocks
         gen_cpo("wideobs", 100, 4, (64, 64), 3, eps, repeat=2, seed=36, cost_stat=25.0, cost_limit=10.0,

@@ -134,18 +134,23 @@ def test_what_a_layered_context_refuses():
         Engine(EngineConfig(obs_dim=6, act_dim=2, hidden_sizes=(64, 5000), env_num=2))
 
 
-def test_agent_with_three_hidden_layers_trains_and_round_trips(tmp_path):
-    """PPOLagAgent(hidden_sizes=(64, 64, 32)): collect with the device actor, update, checkpoint shapes, evaluate."""
+@pytest.mark.parametrize("kind", ["ppol", "focops", "cpo", "trpol", "cpo_minibatch"])
+def test_agent_with_three_hidden_layers_trains_and_round_trips(kind, tmp_path):
+    """The on-policy agents with hidden_sizes=(64, 64, 32): collect with the device actor, update (CPO also with Batch.split
+    minibatches inside learn), checkpoint shapes, evaluate."""
     import copy
     from fsrl_amd import agent as A
     from fsrl_amd.env import SyntheticSafetyVectorEnv
     from fsrl_amd.utils import BaseLogger
     env = SyntheticSafetyVectorEnv(env_num=4, episode_len=40, seed=1)
-    agent = A.PPOLagAgent(env, BaseLogger(str(tmp_path), name="t"), cost_limit=10, device="cuda:0", seed=3,
-                          hidden_sizes=(64, 64, 32), training_num=4, max_grad_norm=0.5)
+    cls = {"ppol": A.PPOLagAgent, "focops": A.FOCOPSAgent, "cpo": A.CPOAgent, "trpol": A.TRPOLagAgent, "cpo_minibatch": A.CPOAgent}[kind]
+    kw = dict(max_grad_norm=0.5) if kind == "ppol" else {}
+    agent = cls(env, BaseLogger(str(tmp_path), name="t"), cost_limit=10, device="cuda:0", seed=3,
+                hidden_sizes=(64, 64, 32), training_num=4, **kw)
     pol = agent.policy
     theta0 = pol.engine.get_params().copy()
-    agent.learn(env, None, epoch=2, episode_per_collect=4, step_per_epoch=320, repeat_per_collect=2, batch_size=64, verbose=False,
+    bs = {"ppol": 64, "focops": 64, "cpo": 99999, "trpol": 99999, "cpo_minibatch": 100}[kind]
+    agent.learn(env, None, epoch=2, episode_per_collect=4, step_per_epoch=320, repeat_per_collect=2, batch_size=bs, verbose=False,
                 save_ckpt=False)
     sd = copy.deepcopy(pol.state_dict())
     assert tuple(sd["actor.preprocess.model.model.4.weight"].shape) == (32, 64)

@@ -55,7 +55,7 @@ def _close(a, b, rel):
 
 
 @pytest.mark.parametrize("name,perturbed", [("infeasible", False), ("perturbed", True), ("options", False), ("widths", False),
-                                            ("wideobs", False)])
+                                            ("wideobs", False), ("deep3", False), ("wide1", False)])      # the last two: layered contexts
 def test_gradients_and_hvp_vs_autograd(name, perturbed):
     from oracle.trust_region import CPOOracle
     from torch.distributions import Independent, Normal, kl_divergence
@@ -127,7 +127,7 @@ def _cpo_f64_yardstick(name):
     return _YARD[name]
 
 
-@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options", "widths", "wideobs"])
+@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options", "widths", "wideobs", "deep3", "wide1"])
 def test_cpo_learn_vs_golden(name):
     g = load_npz(f"cpo_{name}.npz")
     cfg = json.loads(str(g["cfg_json"]))
@@ -176,7 +176,7 @@ TRPO_KEYS = ["loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss/act
              "loss/vf0", "loss/vf1", "loss/vf_total", "loss/kl", "loss/step_size", "loss/entropy"]
 
 
-@pytest.mark.parametrize("name", ["small", "c1", "options", "widths"])
+@pytest.mark.parametrize("name", ["small", "c1", "options", "widths", "deep3"])
 def test_trpo_learn_vs_golden(name):
     g = load_npz(f"trpo_{name}.npz")
     cfg = json.loads(str(g["cfg_json"]))

@@ -36,7 +36,7 @@ def trpo_cfg(cfg):
                       reward_normalization=bool(cfg.get("reward_normalization", False)))
 
 
-@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options", "minibatch", "widths", "wideobs"])
+@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options", "minibatch", "widths", "wideobs", "deep3", "wide1"])
 def test_cpo_update(name):
     torch.set_num_threads(4)
     g = load_npz(f"cpo_{name}.npz")
@@ -79,7 +79,7 @@ def test_cpo_policy_loss_away_from_theta_old():
     np.testing.assert_allclose(o.get_params(), g["theta_after_pl"], rtol=0, atol=2e-6)
 
 
-@pytest.mark.parametrize("name", ["small", "c1", "options", "minibatch", "widths"])
+@pytest.mark.parametrize("name", ["small", "c1", "options", "minibatch", "widths", "deep3"])
 def test_trpo_update(name):
     torch.set_num_threads(4)
     g = load_npz(f"trpo_{name}.npz")
