@@ -427,8 +427,8 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
             n_hid1 = cfg->hidden_sizes[0]; n_hid2 = cfg->hidden_sizes[1];
         } else {
             layered = true;
-            CHECK_ARG(cfg->algo == FSRL_ALGO_PPO_LAG || cfg->algo == FSRL_ALGO_FOCOPS,
-                      "hidden_sizes other than two layers of at most 256 units: PPO-Lagrangian and FOCOPS contexts only (algo %d)", cfg->algo);
+            CHECK_ARG(cfg->algo != FSRL_ALGO_SAC_LAG,
+                      "hidden_sizes other than two layers of at most 256 units: on-policy contexts only (algo %d is a replay context)", cfg->algo);
         }
     } else {
         CHECK_ARG(!cfg->force_layered, "force_layered needs hidden_sizes[n_hidden]");
