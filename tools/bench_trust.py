@@ -62,14 +62,18 @@ def run(kind, obs_dim, act_dim, hid, envs=20, T=1000, ep=1000, repeat=4, cpu_rep
     no_cpu = bool(os.environ.get("FSRL_NO_CPU")) if no_cpu is None else no_cpu
     rng = np.random.default_rng(0)
     obs, act, rew, cost, term, trunc = inputs(rng, envs, T, obs_dim, act_dim, ep)
-    eng = Engine(EngineConfig(obs_dim=obs_dim, act_dim=act_dim, hidden=hid, env_num=envs, target_kl=None,
+    hs = (hid, hid)
+    lay = os.environ.get("FSRL_TR_LAYERED")                # "256x256x256": the same workload on a layered context
+    if lay:
+        hs = tuple(int(x) for x in lay.split("x"))
+    eng = Engine(EngineConfig(obs_dim=obs_dim, act_dim=act_dim, hidden_sizes=hs, force_layered=bool(lay), env_num=envs, target_kl=None,
                               lr=1e-3 if kind == "cpo" else 5e-4))
     if kind == "cpo":
-        ocfg = CPOConfig(obs_dim=obs_dim, act_dim=act_dim, hidden=(hid, hid), optim_critic_iters=10,
+        ocfg = CPOConfig(obs_dim=obs_dim, act_dim=act_dim, hidden=hs, optim_critic_iters=10,
                          max_backtracks=10, cost_limit=10.0)
         o = CPOOracle(ocfg)
     else:
-        ocfg = TRPOConfig(obs_dim=obs_dim, act_dim=act_dim, hidden=(hid, hid), optim_critic_iters=20)
+        ocfg = TRPOConfig(obs_dim=obs_dim, act_dim=act_dim, hidden=hs, optim_critic_iters=20)
         o = TRPOLagOracle(ocfg)
     theta = orth_theta(o, 0)
     ids = np.arange(envs)
