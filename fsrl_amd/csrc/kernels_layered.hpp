@@ -41,6 +41,7 @@ struct LinJob {
 // writing its own partial at C + s * part_stride / bias_out + s * part_stride; the consumer adds the partials in float64 in
 // ascending order (fb_sum_parts_kernel, adam_range_kernel, cg_pz_kernel: the split-K convention of fb_wgrad_kernel).
 struct LinJobs { int n; int ksplit; int kchunk; int part_stride; LinJob j[LAY_MAX_JOBS]; };
+static_assert(sizeof(LinJobs) + 16 <= 4096, "LinJobs travels as a kernel argument: keep it under the 4 KB kernarg segment");
 
 // offsets of one network inside the flat parameter vector (API layout == device layout: no padding, no mirrors)
 struct LayLayer { int W, b, in, out; };
