@@ -350,8 +350,8 @@ def layered_variant(inputs, steps=3):
         out["x".join(map(str, hid))] = {"value": 1.0 / dt, "unit": "updates/s", "ms_per_update": dt * 1e3,
                                         "us_per_step": dt * 1e6 / st.shape[0], "launches_per_step": 2 * L + 5,
                                         "n_params": int(eng.n_params)}
-    out["note"] = ("hidden_sizes outside the fused kernels' reach (PPO-Lagrangian only): layer-by-layer GEMM launches, activations in "
-                   "HBM; 256x256 = the headline network through the same kernels")
+    out["note"] = ("hidden_sizes outside the fused kernels' reach (layered contexts: PPO-Lag here; FOCOPS, CPO, TRPO-Lag run them too): "
+                   "layer-by-layer GEMM launches, activations in HBM; 256x256 = the headline network through the same kernels")
     return out
 
 
