@@ -58,10 +58,6 @@ class EngineConfig:
             hs = [int(h) for h in self.hidden_sizes]
             if not 1 <= len(hs) <= 8:
                 raise ValueError(f"the HIP path runs MLPs with 1 to 8 hidden layers, got hidden_sizes={tuple(hs)}")
-            fused = len(hs) == 2 and max(hs) <= 256
-            if not fused and self.algo == _lib.ALGO_SAC_LAG:
-                raise ValueError("the replay agents' HIP path runs MLPs with two hidden layers of at most 256 units, got "
-                                 f"hidden_sizes={tuple(hs)} (other depths / widths: the on-policy agents only)")
             c.hidden, c.n_hidden = 0, len(hs)
             for i, h in enumerate(hs):
                 c.hidden_sizes[i] = h

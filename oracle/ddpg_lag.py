@@ -31,7 +31,7 @@ from .scans import nstep_return_np
 class DDPGConfig:
     obs_dim: int
     act_dim: int
-    hidden: Tuple[int, int] = (128, 128)
+    hidden: Tuple[int, ...] = (128, 128)
     max_action: float = 1.0
     gamma: float = 0.99
     n_step: int = 3
@@ -42,14 +42,20 @@ class DDPGConfig:
 
 
 def mlp_spec(d_in, d_out, hidden):
-    h1, h2 = hidden
-    return OrderedDict([("W1", (h1, d_in)), ("b1", (h1, )), ("W2", (h2, h1)), ("b2", (h2, )), ("W3", (d_out, h2)),
-                        ("b3", (d_out, ))])
+    """W1 b1 ... W{L+1} b{L+1}: hidden_sizes of any length (ddpg_lag_agent.py takes a tuple), then the output Linear"""
+    sizes = [int(d_in)] + [int(h) for h in hidden] + [int(d_out)]
+    items = []
+    for l in range(1, len(sizes)):
+        items += [(f"W{l}", (sizes[l], sizes[l - 1])), (f"b{l}", (sizes[l], ))]
+    return OrderedDict(items)
 
 
 def mlp(p, x):
-    h = torch.relu(F.linear(torch.relu(F.linear(x, p["W1"], p["b1"])), p["W2"], p["b2"]))
-    return F.linear(h, p["W3"], p["b3"])
+    n_lin = sum(1 for k in p if k[0] == "W")
+    h = x
+    for l in range(1, n_lin):
+        h = torch.relu(F.linear(h, p[f"W{l}"], p[f"b{l}"]))
+    return F.linear(h, p[f"W{n_lin}"], p[f"b{n_lin}"])
 
 
 class DDPGLagOracle:

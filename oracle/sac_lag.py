@@ -34,7 +34,7 @@ F32_EPS = float(np.finfo(np.float32).eps)
 class SACConfig:
     obs_dim: int
     act_dim: int
-    hidden: Tuple[int, int] = (128, 128)
+    hidden: Tuple[int, ...] = (128, 128)
     gamma: float = 0.99
     n_step: int = 2
     tau: float = 0.05
@@ -47,20 +47,35 @@ class SACConfig:
     use_lagrangian: bool = True
 
 
+def _hidden_items(d_in, hidden, suffix=""):
+    """W1 b1 ... WL bL of the preprocess MLP (tianshou Net, hidden_sizes of any length: sac_lag_agent.py takes a tuple)"""
+    sizes = [int(d_in)] + [int(h) for h in hidden]
+    items = []
+    for l in range(1, len(sizes)):
+        items += [(f"W{l}{suffix}", (sizes[l], sizes[l - 1])), (f"b{l}{suffix}", (sizes[l], ))]
+    return items
+
+
 def actor_spec(Do, Da, hidden):
-    h1, h2 = hidden
-    return OrderedDict([("W1", (h1, Do)), ("b1", (h1, )), ("W2", (h2, h1)), ("b2", (h2, )),
-                        ("Wmu", (Da, h2)), ("bmu", (Da, )), ("Wsig", (Da, h2)), ("bsig", (Da, ))])
+    hl = int(hidden[-1])
+    return OrderedDict(_hidden_items(Do, hidden) + [("Wmu", (Da, hl)), ("bmu", (Da, )), ("Wsig", (Da, hl)), ("bsig", (Da, ))])
 
 
 def double_critic_spec(Do, Da, hidden):
-    h1, h2 = hidden
+    L, hl = len(hidden), int(hidden[-1])
     s = OrderedDict()
     for j in (1, 2):
-        s.update({f"W1_{j}": (h1, Do + Da), f"b1_{j}": (h1, ), f"W2_{j}": (h2, h1), f"b2_{j}": (h2, )})
+        s.update(_hidden_items(Do + Da, hidden, f"_{j}"))
     for j in (1, 2):
-        s.update({f"W3_{j}": (1, h2), f"b3_{j}": (1, )})
+        s.update({f"W{L + 1}_{j}": (1, hl), f"b{L + 1}_{j}": (1, )})
     return s
+
+
+def _trunk(p, x, n_hidden, suffix=""):
+    h = x
+    for l in range(1, n_hidden + 1):
+        h = torch.relu(F.linear(h, p[f"W{l}{suffix}"], p[f"b{l}{suffix}"]))
+    return h
 
 
 def _leaves(flat, spec, off):
@@ -126,7 +141,7 @@ class SACLagOracle:
     # ------------------------------------------------------------------ nets
     def pi(self, obs, eps):
         p = self.actor
-        h = torch.relu(F.linear(torch.relu(F.linear(obs, p["W1"], p["b1"])), p["W2"], p["b2"]))
+        h = _trunk(p, obs, len(self.cfg.hidden))
         mu = F.linear(h, p["Wmu"], p["bmu"])
         sigma = torch.clamp(F.linear(h, p["Wsig"], p["bsig"]), min=SIGMA_MIN, max=SIGMA_MAX).exp()
         u = mu + eps * sigma                                          # Normal.rsample
@@ -141,8 +156,9 @@ class SACLagOracle:
         x = torch.cat([obs, act], dim=1)
         out = []
         for j in (1, 2):
-            h = torch.relu(F.linear(torch.relu(F.linear(x, cr[f"W1_{j}"], cr[f"b1_{j}"])), cr[f"W2_{j}"], cr[f"b2_{j}"]))
-            out.append(F.linear(h, cr[f"W3_{j}"], cr[f"b3_{j}"]))
+            L = sum(1 for k in cr if k.startswith("W") and k.endswith("_1")) - 1      # hidden layers
+            h = _trunk(cr, x, L, f"_{j}")
+            out.append(F.linear(h, cr[f"W{L + 1}_{j}"], cr[f"b{L + 1}_{j}"]))
         return out
 
     # ------------------------------------------------------------------ update

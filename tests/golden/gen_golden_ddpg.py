@@ -103,6 +103,10 @@ def gen(name, obs_dim, act_dim, hidden, env_num, ep_lens, batch_size, n_updates,
 if __name__ == "__main__":
     torch.set_num_threads(4)
     eps = [[60, 50, -17], [70, 55], [40, 40, 40, -9]]
+    if sys.argv[1:] == ["depths"]:
+        # hidden_sizes the fused kernels do not hold (ddpg_lag_agent.py: any tuple): layered contexts on the HIP side
+        gen("deep3", 6, 3, (40, 56, 32), 3, eps, batch_size=64, n_updates=5, seed=43, n_step=2)
+        sys.exit(0)
     gen("small", 6, 3, (64, 64), 3, eps, batch_size=64, n_updates=6, seed=40, n_step=3)
     gen("scaled", 8, 2, (128, 128), 3, eps, batch_size=100, n_updates=5, seed=41, n_step=1, max_action=2.0)
     gen("nolag", 17, 4, (256, 256), 2, [[90, -30], [100]], batch_size=256, n_updates=4, seed=42, n_step=2,

@@ -137,6 +137,11 @@ if __name__ == "__main__":
         # two hidden layers of different widths that are not 64 / 128 / 256 (zero-padded on the device)
         gen("widths", 6, 3, (80, 48), 3, eps, batch_size=64, n_updates=5, seed=35, n_step=2)
         sys.exit(0)
+    if sys.argv[1:] == ["depths"]:
+        # hidden_sizes the fused kernels do not hold (sac_lag_agent.py: any tuple): layered contexts on the HIP side
+        gen("deep3", 6, 3, (48, 64, 40), 3, eps, batch_size=64, n_updates=5, seed=36, n_step=2)
+        gen("wide1", 8, 2, (272, ), 3, eps, batch_size=100, n_updates=4, seed=37, n_step=3, auto_alpha=False, alpha=0.2)
+        sys.exit(0)
     gen("small", 6, 3, (64, 64), 3, eps, batch_size=64, n_updates=6, seed=30, n_step=2)
     gen("nstep3", 8, 2, (64, 64), 3, eps, batch_size=128, n_updates=4, seed=31, n_step=3, auto_alpha=False,
         alpha=0.2)

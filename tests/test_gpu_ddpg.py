@@ -30,7 +30,7 @@ def _engine(cfg, g):
     return eng
 
 
-@pytest.mark.parametrize("name", ["small", "scaled", "nolag"])
+@pytest.mark.parametrize("name", ["small", "scaled", "nolag", "deep3"])
 def test_ddpg_updates_vs_golden(name):
     g, cfg, ocfg, store, index = ddpg_setup(name)
     eng = _engine(cfg, g)

@@ -124,8 +124,10 @@ def test_what_a_layered_context_refuses():
     with pytest.raises(AssertionError, match="fused"):
         eng.launch_floors(256, 10)
     eng.close()
-    with pytest.raises(ValueError, match="two hidden layers"):
-        Engine(EngineConfig(obs_dim=6, act_dim=2, hidden_sizes=(300, 300), env_num=2, algo=_lib.ALGO_SAC_LAG))
+    rep = Engine(EngineConfig(obs_dim=6, act_dim=2, hidden_sizes=(300, 300), env_num=2, algo=_lib.ALGO_SAC_LAG))
+    with pytest.raises(AssertionError, match="CVPO runs the fused kernels"):      # SAC-Lag / DDPG-Lag take a layered replay context, CVPO does not
+        rep.cvpo_init(qc_thres=1.0)
+    rep.close()
     for bad in ((), (1, ) * 9):
         with pytest.raises(ValueError, match="1 to 8 hidden layers"):
             Engine(EngineConfig(obs_dim=6, act_dim=2, hidden_sizes=bad, env_num=2))
@@ -133,7 +135,7 @@ def test_what_a_layered_context_refuses():
         Engine(EngineConfig(obs_dim=6, act_dim=2, hidden_sizes=(64, 5000), env_num=2))
 
 
-@pytest.mark.parametrize("kind", ["ppol", "focops", "cpo", "trpol", "cpo_minibatch"])
+@pytest.mark.parametrize("kind", ["ppol", "focops", "cpo", "trpol", "cpo_minibatch", "sacl", "ddpgl"])
 def test_agent_with_three_hidden_layers_trains_and_round_trips(kind, tmp_path):
     """The on-policy agents with hidden_sizes=(64, 64, 32): collect with the device actor, update (CPO also with Batch.split
     minibatches inside learn), checkpoint shapes, evaluate."""
@@ -142,21 +144,31 @@ def test_agent_with_three_hidden_layers_trains_and_round_trips(kind, tmp_path):
     from fsrl_amd.env import SyntheticSafetyVectorEnv
     from fsrl_amd.utils import BaseLogger
     env = SyntheticSafetyVectorEnv(env_num=4, episode_len=40, seed=1)
-    cls = {"ppol": A.PPOLagAgent, "focops": A.FOCOPSAgent, "cpo": A.CPOAgent, "trpol": A.TRPOLagAgent, "cpo_minibatch": A.CPOAgent}[kind]
-    kw = dict(max_grad_norm=0.5) if kind == "ppol" else {}
+    cls = {"ppol": A.PPOLagAgent, "focops": A.FOCOPSAgent, "cpo": A.CPOAgent, "trpol": A.TRPOLagAgent, "cpo_minibatch": A.CPOAgent,
+           "sacl": A.SACLagAgent, "ddpgl": A.DDPGLagAgent}[kind]
+    replay = kind in ("sacl", "ddpgl")
+    kw = dict(max_grad_norm=0.5) if kind == "ppol" else dict(buffer_size=4000) if replay else {}
     agent = cls(env, BaseLogger(str(tmp_path), name="t"), cost_limit=10, device="cuda:0", seed=3,
                 hidden_sizes=(64, 64, 32), training_num=4, **kw)
     pol = agent.policy
-    theta0 = pol.engine.get_params().copy()
-    bs = {"ppol": 64, "focops": 64, "cpo": 99999, "trpol": 99999, "cpo_minibatch": 100}[kind]
-    agent.learn(env, None, epoch=2, episode_per_collect=4, step_per_epoch=320, repeat_per_collect=2, batch_size=bs, verbose=False,
-                save_ckpt=False)
+    theta0 = (pol.engine.sac_get_params(0)[0] if replay else pol.engine.get_params()).copy()
+    bs = {"ppol": 64, "focops": 64, "cpo": 99999, "trpol": 99999, "cpo_minibatch": 100, "sacl": 64, "ddpgl": 64}[kind]
+    if replay:
+        agent.learn(env, None, epoch=2, episode_per_collect=4, step_per_epoch=320, update_per_step=0.2, batch_size=bs, verbose=False,
+                    save_ckpt=False)
+    else:
+        agent.learn(env, None, epoch=2, episode_per_collect=4, step_per_epoch=320, repeat_per_collect=2, batch_size=bs, verbose=False,
+                    save_ckpt=False)
     sd = copy.deepcopy(pol.state_dict())
     assert tuple(sd["actor.preprocess.model.model.4.weight"].shape) == (32, 64)
     assert all(torch.isfinite(v).all() for v in sd.values() if torch.is_tensor(v) and v.is_floating_point())
-    assert np.abs(pol.engine.get_params() - theta0).max() > 1e-4          # it did learn something
+    theta1 = pol.engine.sac_get_params(0)[0] if replay else pol.engine.get_params()
+    assert np.abs(theta1 - theta0).max() > 1e-4          # it did learn something
     pol.load_state_dict(sd)
-    pol._mark_stale()
+    if replay:
+        pol._dirty = pol._rest_dirty = True              # the next state_dict() reads the device back
+    else:
+        pol._mark_stale()
     for kk, v in pol.state_dict().items():
         if torch.is_tensor(v):
             assert torch.equal(v, sd[kk]), kk

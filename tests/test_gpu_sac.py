@@ -33,7 +33,7 @@ def _engine(cfg, g):
 
 
 @pytest.mark.parametrize("splitk", [0, 1])      # weight gradients: 0 = one workgroup per output tile (batches <= 512 rows), 1 = split-K
-@pytest.mark.parametrize("name", ["small", "nstep3", "c4", "widths"])
+@pytest.mark.parametrize("name", ["small", "nstep3", "c4", "widths", "deep3", "wide1"])      # the last two: layered contexts
 def test_sac_updates_vs_golden(name, splitk):
     g, cfg, ocfg, store, index = sac_setup(name)
     eng = _engine(cfg, g)

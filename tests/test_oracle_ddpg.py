@@ -26,7 +26,7 @@ def ddpg_setup(name):
     return g, cfg, ocfg, store, ReplayIndex(g["env_rows"], sub, store["terminated"] | store["truncated"])
 
 
-@pytest.mark.parametrize("name", ["small", "scaled", "nolag"])
+@pytest.mark.parametrize("name", ["small", "scaled", "nolag", "deep3"])
 def test_ddpg_updates(name):
     torch.set_num_threads(4)
     g, cfg, ocfg, store, index = ddpg_setup(name)

@@ -28,7 +28,7 @@ def sac_setup(name):
     return g, cfg, ocfg, store, ReplayIndex(g["env_rows"], sub, done)
 
 
-@pytest.mark.parametrize("name", ["small", "nstep3", "c4", "widths"])
+@pytest.mark.parametrize("name", ["small", "nstep3", "c4", "widths", "deep3", "wide1"])
 def test_sac_updates(name):
     torch.set_num_threads(4)
     g, cfg, ocfg, store, index = sac_setup(name)
