@@ -53,9 +53,6 @@ class CVPO(BasePolicy):
         double = hasattr(self.critics[0], "preprocess2")
         from fsrl_amd.utils.net import mlp_geometry
         obs_dim, hidden_sizes = mlp_geometry(actor.preprocess)
-        if not (len(hidden_sizes) == 2 and max(hidden_sizes) <= 256):
-            raise ValueError("CVPO: the HIP path runs MLPs with two hidden layers of at most 256 units, got "
-                             f"hidden_sizes={tuple(hidden_sizes)} (other depths / widths: every agent but CVPO)")
         act_dim = actor.mu.model[0].weight.shape[0]
         dev = device if isinstance(device, int) else (int(str(device).split(":")[-1]) if ":" in str(device) else 0)
         self.engine = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=int(obs_dim), act_dim=int(act_dim),

@@ -47,7 +47,7 @@ LOG_SQRT_2PI = float(np.log(np.sqrt(2 * np.pi)))
 class CVPOConfig:
     obs_dim: int
     act_dim: int
-    hidden: Tuple[int, int] = (128, 128)
+    hidden: Tuple[int, ...] = (128, 128)
     max_action: float = 1.0
     gamma: float = 0.98
     n_step: int = 2
@@ -75,9 +75,10 @@ class CVPOConfig:
 
 
 def single_critic_spec(Do, Da, hidden):
-    h1, h2 = hidden
-    return OrderedDict([("W1_1", (h1, Do + Da)), ("b1_1", (h1, )), ("W2_1", (h2, h1)), ("b2_1", (h2, )),
-                        ("W3_1", (1, h2)), ("b3_1", (1, ))])
+    """SingleCritic: the preprocess MLP (hidden_sizes of any length) then the last Linear"""
+    from .sac_lag import _hidden_items
+    L = len(hidden)
+    return OrderedDict(_hidden_items(Do + Da, hidden, "_1") + [(f"W{L + 1}_1", (1, int(hidden[-1]))), (f"b{L + 1}_1", (1, ))])
 
 
 class CVPOOracle:
@@ -126,7 +127,8 @@ class CVPOOracle:
 
     # ------------------------------------------------------------------ nets
     def pi(self, p, obs):
-        h = torch.relu(F.linear(torch.relu(F.linear(obs, p["W1"], p["b1"])), p["W2"], p["b2"]))
+        from .sac_lag import _trunk
+        h = _trunk(p, obs, len(self.cfg.hidden))
         mu = self.cfg.max_action * torch.tanh(F.linear(h, p["Wmu"], p["bmu"]))
         sigma = torch.clamp(F.linear(h, p["Wsig"], p["bsig"]), min=SIGMA_MIN, max=SIGMA_MAX).exp()
         return mu, sigma
@@ -135,8 +137,10 @@ class CVPOOracle:
         x = torch.cat([obs, act], dim=1)
         out = []
         for j in range(1, self.n_q + 1):
-            h = torch.relu(F.linear(torch.relu(F.linear(x, cr[f"W1_{j}"], cr[f"b1_{j}"])), cr[f"W2_{j}"], cr[f"b2_{j}"]))
-            out.append(F.linear(h, cr[f"W3_{j}"], cr[f"b3_{j}"]))
+            from .sac_lag import _trunk
+            L = len(self.cfg.hidden)
+            h = _trunk(cr, x, L, f"_{j}")
+            out.append(F.linear(h, cr[f"W{L + 1}_{j}"], cr[f"b{L + 1}_{j}"]))
         return out
 
     def q_predict(self, cr, obs, act):

@@ -173,6 +173,13 @@ def gen(name, obs_dim, act_dim, hidden, env_num, ep_lens, batch_size, cycles, up
 if __name__ == "__main__":
     torch.set_num_threads(4)
     eps = [[60, 50, -17], [70, 55], [40, 40, 40, -9]]
+    if sys.argv[1:] == ["depths"]:
+        # hidden_sizes the fused kernels do not hold (cvpo_agent.py: any tuple): layered contexts on the HIP side
+        gen("deep3", 6, 3, (48, 64, 40), 3, eps, batch_size=64, cycles=2, updates_per_cycle=4, seed=53, cost_limit=0.3,
+            mstep_kl_mu=2e-4, mstep_kl_std=2e-6, actor_lr=2e-3)
+        gen("wide1_double", 8, 2, (272, ), 3, eps, batch_size=100, cycles=2, updates_per_cycle=3, seed=54, n_step=3, max_action=2.0,
+            cost_limit=0.5, mstep_kl_mu=1e-3, double_critic=True, mstep_iter_num=2, estep_iter_num=2, sample_act_num=8)
+        sys.exit(0)
     # small: cost threshold below Qc (lambda grows) and tight KL bounds (the M-step duals turn positive)
     gen("small", 6, 3, (64, 64), 3, eps, batch_size=64, cycles=2, updates_per_cycle=6, seed=50, cost_limit=0.3,
         mstep_kl_mu=2e-4, mstep_kl_std=2e-6, actor_lr=2e-3)

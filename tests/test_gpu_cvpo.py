@@ -34,7 +34,7 @@ def _close(d, q99, mx):
     return np.quantile(d, 0.99) <= q99 and d.max() <= mx
 
 
-@pytest.mark.parametrize("name", ["small", "default", "double"])
+@pytest.mark.parametrize("name", ["small", "default", "double", "deep3", "wide1_double"])
 def test_cvpo_updates_vs_golden(name):
     g, cfg, ocfg, store, index = cvpo_setup(name)
     eng = _engine(cfg, g, ocfg)

@@ -553,7 +553,7 @@ def test_agents_with_two_hidden_layers_of_any_width(kind, tmp_path):
     """`hidden_sizes: Tuple[int, ...]` of the agents (fsrl/agent/ppo_lag_agent.py:91,136): any two widths up to 256 run on the
     HIP path (the kernels' width is the next of 64 / 128 / 256, narrower layers are zero-padded: include/fsrl_hip.h hidden1 /
     hidden2).  Train a little, then: the state_dict has the caller's shapes, the device parameters round-trip through it, and
-    three hidden layers / a 300-wide layer make a layered context for every agent but CVPO, which fails with a message."""
+    three hidden layers / a 300-wide layer make a layered context for every agent."""
     from fsrl_amd import agent as A
     from fsrl_amd.env import SyntheticSafetyVectorEnv
     from fsrl_amd.utils import BaseLogger
@@ -586,10 +586,7 @@ def test_agents_with_two_hidden_layers_of_any_width(kind, tmp_path):
     rew, length, cost = agent.evaluate(env, eval_episodes=2)
     assert length == 40.0 and np.isfinite(rew)
     for other in ((64, 64, 64), (300, 64)):
-        if kind != "cvpo":      # every agent but CVPO takes any tuple: a layered context (include/fsrl_hip.h fsrl_config.n_hidden)
-            a2 = cls(env, None, cost_limit=10, device="cuda:0", seed=3, hidden_sizes=other, training_num=4, **kw)
-            if kind in ("ppol", "focops", "cpo"):
-                assert a2.policy.engine.n_params == sum(p.numel() for p in a2.policy._actor_critic.parameters())
-        else:
-            with pytest.raises(ValueError, match="two hidden layers"):
-                cls(env, None, cost_limit=10, device="cuda:0", seed=3, hidden_sizes=other, training_num=4, **kw)
+        # every agent takes any tuple: a layered context (include/fsrl_hip.h fsrl_config.n_hidden)
+        a2 = cls(env, None, cost_limit=10, device="cuda:0", seed=3, hidden_sizes=other, training_num=4, **kw)
+        if kind in ("ppol", "focops", "cpo"):
+            assert a2.policy.engine.n_params == sum(p.numel() for p in a2.policy._actor_critic.parameters())

@@ -124,10 +124,6 @@ def test_what_a_layered_context_refuses():
     with pytest.raises(AssertionError, match="fused"):
         eng.launch_floors(256, 10)
     eng.close()
-    rep = Engine(EngineConfig(obs_dim=6, act_dim=2, hidden_sizes=(300, 300), env_num=2, algo=_lib.ALGO_SAC_LAG))
-    with pytest.raises(AssertionError, match="CVPO runs the fused kernels"):      # SAC-Lag / DDPG-Lag take a layered replay context, CVPO does not
-        rep.cvpo_init(qc_thres=1.0)
-    rep.close()
     for bad in ((), (1, ) * 9):
         with pytest.raises(ValueError, match="1 to 8 hidden layers"):
             Engine(EngineConfig(obs_dim=6, act_dim=2, hidden_sizes=bad, env_num=2))
@@ -135,7 +131,7 @@ def test_what_a_layered_context_refuses():
         Engine(EngineConfig(obs_dim=6, act_dim=2, hidden_sizes=(64, 5000), env_num=2))
 
 
-@pytest.mark.parametrize("kind", ["ppol", "focops", "cpo", "trpol", "cpo_minibatch", "sacl", "ddpgl"])
+@pytest.mark.parametrize("kind", ["ppol", "focops", "cpo", "trpol", "cpo_minibatch", "sacl", "ddpgl", "cvpo"])
 def test_agent_with_three_hidden_layers_trains_and_round_trips(kind, tmp_path):
     """The on-policy agents with hidden_sizes=(64, 64, 32): collect with the device actor, update (CPO also with Batch.split
     minibatches inside learn), checkpoint shapes, evaluate."""
@@ -145,14 +141,14 @@ def test_agent_with_three_hidden_layers_trains_and_round_trips(kind, tmp_path):
     from fsrl_amd.utils import BaseLogger
     env = SyntheticSafetyVectorEnv(env_num=4, episode_len=40, seed=1)
     cls = {"ppol": A.PPOLagAgent, "focops": A.FOCOPSAgent, "cpo": A.CPOAgent, "trpol": A.TRPOLagAgent, "cpo_minibatch": A.CPOAgent,
-           "sacl": A.SACLagAgent, "ddpgl": A.DDPGLagAgent}[kind]
-    replay = kind in ("sacl", "ddpgl")
+           "sacl": A.SACLagAgent, "ddpgl": A.DDPGLagAgent, "cvpo": A.CVPOAgent}[kind]
+    replay = kind in ("sacl", "ddpgl", "cvpo")
     kw = dict(max_grad_norm=0.5) if kind == "ppol" else dict(buffer_size=4000) if replay else {}
     agent = cls(env, BaseLogger(str(tmp_path), name="t"), cost_limit=10, device="cuda:0", seed=3,
                 hidden_sizes=(64, 64, 32), training_num=4, **kw)
     pol = agent.policy
     theta0 = (pol.engine.sac_get_params(0)[0] if replay else pol.engine.get_params()).copy()
-    bs = {"ppol": 64, "focops": 64, "cpo": 99999, "trpol": 99999, "cpo_minibatch": 100, "sacl": 64, "ddpgl": 64}[kind]
+    bs = {"ppol": 64, "focops": 64, "cpo": 99999, "trpol": 99999, "cpo_minibatch": 100, "sacl": 64, "ddpgl": 64, "cvpo": 64}[kind]
     if replay:
         agent.learn(env, None, epoch=2, episode_per_collect=4, step_per_epoch=320, update_per_step=0.2, batch_size=bs, verbose=False,
                     save_ckpt=False)

@@ -30,7 +30,7 @@ def cvpo_setup(name):
     return g, cfg, ocfg, store, ReplayIndex(g["env_rows"], sub, done)
 
 
-@pytest.mark.parametrize("name", ["small", "default", "double"])
+@pytest.mark.parametrize("name", ["small", "default", "double", "deep3", "wide1_double"])
 def test_cvpo_updates(name):
     torch.set_num_threads(4)
     g, cfg, ocfg, store, index = cvpo_setup(name)
