@@ -26,7 +26,7 @@ class EngineConfig:
     hidden: int = 128                 # two hidden layers of this width ...
     hidden_sizes: Optional[Sequence[int]] = None   # ... or the agents' hidden_sizes (wins over `hidden`): two layers of at most 256
                                                    # units run on the fused kernels; any other tuple (1 .. 8 layers, any width)
-                                                   # makes a layered PPO-Lag context (include/fsrl_hip.h fsrl_config.n_hidden)
+                                                   # makes a layered context (include/fsrl_hip.h fsrl_config.n_hidden)
     force_layered: bool = False       # tests: a two-layer network through the layered kernels too
     n_critics: int = 2
     env_num: int = 20

@@ -48,15 +48,12 @@ class BasePolicy(ABC, nn.Module):
         raise TypeError("critics should not be %s" % (type(critics)))
 
     # ------------------------------------------------------------------ engine
-    def _make_engine(self, device, env_num, buffer_size, optim=None, layered_ok=False, **cfg_over):
-        """Create the HIP context with the geometry of the host networks.  layered_ok: the policy's update runs on networks of
-        any depth / width (the on-policy agents: PPO-Lag, FOCOPS, CPO, TRPO-Lag); the replay agents need two hidden layers of at most 256 units."""
+    def _make_engine(self, device, env_num, buffer_size, optim=None, **cfg_over):
+        """Create the HIP context with the geometry of the host networks (hidden_sizes of any depth / width: two layers of at
+        most 256 units run on the fused kernels, anything else as a layered context)."""
         from fsrl_amd.engine import Engine, EngineConfig
         from fsrl_amd.utils.net import mlp_geometry
         obs_dim, hidden_sizes = mlp_geometry(self.actor.preprocess)
-        if not layered_ok and not (len(hidden_sizes) == 2 and max(hidden_sizes) <= 256):
-            raise ValueError(f"{type(self).__name__}: the HIP path runs MLPs with two hidden layers of at most 256 units, got "
-                             f"hidden_sizes={tuple(hidden_sizes)} (other depths / widths: the on-policy agents only)")
         act_dim = self.actor.mu.model[0].weight.shape[0]
         dev = device if isinstance(device, int) else (int(str(device).split(":")[-1]) if ":" in str(device) else 0)
         kw = dict(obs_dim=int(obs_dim), act_dim=int(act_dim), hidden_sizes=hidden_sizes, n_critics=self.critics_num,

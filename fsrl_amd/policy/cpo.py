@@ -44,7 +44,7 @@ class CPO(BasePolicy):
         self._l2_reg, self._delta = l2_reg, target_kl
         self._backtrack_coeff, self._damping_coeff = backtrack_coeff, damping_coeff
         self._ave_cost_return = 0.0
-        self._make_engine(device, env_num, buffer_size, optim, layered_ok=True, gae_lambda=gae_lambda, target_kl=None)
+        self._make_engine(device, env_num, buffer_size, optim, gae_lambda=gae_lambda, target_kl=None)
 
     def pre_update_fn(self, stats_train: Dict, **kwarg) -> Any:
         self._ave_cost_return = stats_train["cost"]

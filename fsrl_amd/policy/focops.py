@@ -36,7 +36,7 @@ class FOCOPS(BasePolicy):
         self._is_auto_nu = True
         self._ave_cost_return = 0.0
         self._reference_rng = reference_rng     # burn the torch draws the reference's forward() wastes in update()
-        self._make_engine(device, env_num, buffer_size, actor_optim, layered_ok=True, algo=_lib.ALGO_FOCOPS, gae_lambda=gae_lambda,
+        self._make_engine(device, env_num, buffer_size, actor_optim, algo=_lib.ALGO_FOCOPS, gae_lambda=gae_lambda,
                           norm_adv=advantage_normalization, target_kl=None, recompute_adv=bool(recompute_advantage))
         self.engine.focops_init(actor_lr=actor_optim.param_groups[0]["lr"], critic_lr=critic_optim.param_groups[0]["lr"],
                                 l2_reg=l2_reg, delta=delta, eta=eta, tem_lambda=tem_lambda, max_grad_norm=max_grad_norm)

@@ -62,7 +62,7 @@ class PPOLagrangian(LagrangianPolicy):
         # (process_fn: ppo_lag.py:146-148; learn: :225 via policy_loss :175) -- so that a whole collect/update
         # loop stays on the reference's random streams (tests/test_gpu_loop.py).  Costs ~N*Da normals per update.
         self._reference_rng = reference_rng
-        self._make_engine(device, env_num, buffer_size, optim, layered_ok=True, gae_lambda=gae_lambda, eps_clip=eps_clip,
+        self._make_engine(device, env_num, buffer_size, optim, gae_lambda=gae_lambda, eps_clip=eps_clip,
                           dual_clip=dual_clip, vf_coef=vf_coef, max_grad_norm=max_grad_norm,
                           target_kl=target_kl, norm_adv=advantage_normalization,
                           use_lagrangian=use_lagrangian, recompute_adv=bool(recompute_advantage),

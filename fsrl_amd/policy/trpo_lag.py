@@ -53,7 +53,7 @@ class TRPOLagrangian(LagrangianPolicy):
         self._max_backtracks, self._delta = max_backtracks, target_kl
         self._backtrack_coeff, self._optim_critic_iters = backtrack_coeff, optim_critic_iters
         self._damping = 0.1
-        self._make_engine(device, env_num, buffer_size, optim, layered_ok=True, gae_lambda=gae_lambda, target_kl=None,
+        self._make_engine(device, env_num, buffer_size, optim, gae_lambda=gae_lambda, target_kl=None,
                           use_lagrangian=use_lagrangian)
 
     def _burn(self, n_rows: int, forwards: int) -> None:

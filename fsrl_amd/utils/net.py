@@ -43,8 +43,7 @@ class Net(nn.Module):
 def mlp_geometry(preprocess_net):
     """(input_dim, hidden_sizes) of a preprocess Net, the way the HIP engine needs it: its Linear + ReLU hidden layers.  Two
     layers of at most 256 units run on the fused kernels (64 / 128 / 256 wide, narrower layers zero-padded); any other tuple
-    makes a layered PPO-Lagrangian context (include/fsrl_hip.h fsrl_config.n_hidden) -- the other algorithms' contexts refuse
-    it with the library's message."""
+    makes a layered context (include/fsrl_hip.h fsrl_config.n_hidden)."""
     lin = [m for m in preprocess_net.model.model if isinstance(m, nn.Linear)]
     widths = tuple(int(m.out_features) for m in lin)
     if not 1 <= len(lin) <= 8:

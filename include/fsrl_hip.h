@@ -88,11 +88,11 @@ typedef struct fsrl_config {
                                 (fsrl/agent/ppo_lag_agent.py:91,136-145; tianshou Net(hidden_sizes=...)), 1 .. FSRL_MAX_HIDDEN
                                 layers of 1 .. FSRL_MAX_WIDTH units; leave hidden1 / hidden2 0 with it.  Two layers of at most
                                 256 units select the fused kernels exactly like hidden1 / hidden2.  Anything else makes a
-                                LAYERED context, on-policy algorithms only (PPO-Lagrangian, FOCOPS, and CPO / TRPO-Lag through fsrl_tr_*): the same entry points (store, collector actor,
-                                fsrl_ppo_*, parameters, snapshot, lr), the same float64 scans and logged rows, but the network
+                                LAYERED context (every algorithm): the same entry points (store, collector actor,
+                                fsrl_ppo_* / fsrl_tr_* / fsrl_sac_* / fsrl_cvpo_*, parameters, snapshot, lr), the same float64 scans and logged rows, but the network
                                 math runs one MFMA GEMM launch per Linear (2 L + 5 launches per minibatch step instead of 3)
-                                on activations kept in HBM.  Grouped updates, fsrl_launch_floors and the replay algorithms
-                                refuse such a context with FSRL_EINVAL.                                                   */
+                                on activations kept in HBM.  Grouped updates and fsrl_launch_floors refuse such a
+                                context with FSRL_EINVAL.                                                   */
     int32_t hidden_sizes[FSRL_MAX_HIDDEN];
     int32_t force_layered;   /* tests: run a two-layer network of at most 256 units through the layered kernels as well   */
 } fsrl_config;
