@@ -176,6 +176,8 @@ CVPO_VARIANTS = [  # Do, Da, H, rows per env, batch, K, n_step, double_critic, e
     (20, 8, 128, [64, 64, 64], 16, 64, 3, True, 1, 2, 2.0),   # widest action head, most particles, DoubleCritic, scaled actions
     (9, 2, 256, [33], 1, 1, 2, False, 3, 1, 1.0),             # one row, one particle (weights == 1), three E-step iterations
     (41, 1, 64, [90, 45], 333, 5, 2, False, 1, 1, 0.5),       # batch larger than the store, K not a power of two
+    (7, 3, (40, 24, 56), [40, 17], 100, 16, 2, False, 1, 1, 1.0),    # layered context: three ragged hidden layers
+    (12, 4, (300, ), [64, 64], 50, 8, 3, True, 2, 2, 2.0),            # layered context: one wide layer, DoubleCritic, scaled actions
 ]
 
 
@@ -188,10 +190,11 @@ def test_cvpo_variants_vs_oracle(Do, Da, H, rows, B, K, n_step, double, eit, mit
     from oracle.sac_lag import ReplayIndex
     rng = np.random.default_rng(Do + 10 * Da)
     E, sub = len(rows), 128
-    ocfg = CVPOConfig(obs_dim=Do, act_dim=Da, hidden=(H, H), max_action=amax, gamma=0.97, n_step=n_step, tau=0.1,
+    hs = (H, H) if isinstance(H, int) else tuple(H)
+    ocfg = CVPOConfig(obs_dim=Do, act_dim=Da, hidden=hs, max_action=amax, gamma=0.97, n_step=n_step, tau=0.1,
                       double_critic=double, sample_act_num=K, estep_iter_num=eit, mstep_iter_num=mit, cost_limit=0.5,
                       max_episode_steps=50, mstep_kl_mu=1e-4, mstep_kl_std=1e-5, actor_lr=1e-3)
-    eng = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=Do, act_dim=Da, hidden=H, n_critics=2, env_num=E,
+    eng = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=Do, act_dim=Da, hidden_sizes=hs, n_critics=2, env_num=E,
                               buffer_size=E * sub, gamma=0.97, max_action=amax, target_kl=None))
     eng.cvpo_init(ocfg.qc_thres, actor_lr=1e-3, tau=0.1, n_step=n_step, double_critic=double, sample_act_num=K,
                   estep_iter_num=eit, mstep_iter_num=mit, mstep_kl_mu=1e-4, mstep_kl_std=1e-5)
