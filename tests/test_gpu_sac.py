@@ -93,13 +93,14 @@ def test_fused_launch_plan_is_bit_identical_to_the_separate_launches(batch):
     assert np.isfinite(outs[0][0]).all()
 
 
-def test_sac_perf_mode_runs_and_is_finite():
+@pytest.mark.parametrize("name", ["c4", "deep3"])      # deep3: a layered context
+def test_sac_perf_mode_runs_and_is_finite(name):
     """indices / noise drawn by the library (perf mode): finite stats, parameters move."""
-    g, cfg, ocfg, store, index = sac_setup("c4")
+    g, cfg, ocfg, store, index = sac_setup(name)
     eng = _engine(cfg, g)
     a0, _ = eng.sac_get_params(0)
     for u in range(20):
-        st = eng.sac_update(256, [0.5], 1 / 1.5, seed=u + 1)
+        st = eng.sac_update(256 if name == "c4" else 64, [0.5], 1 / 1.5, seed=u + 1)
         assert np.isfinite(st).all()
     a1, alpha = eng.sac_get_params(0)
     assert np.abs(a1 - a0).max() > 1e-4 and 0.9 < alpha < 1.0
