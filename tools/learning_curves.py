@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--epochs", type=int, default=20)
     ap.add_argument("--agents", default="ppol,focops,cpo,trpol,sacl,ddpgl,cvpo")
     ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--hidden-sizes", default="", help="e.g. 64x48x32: hidden_sizes as a tuple (layered contexts when it is not two "
+                                                       "layers of at most 256 units); overrides --hidden")
     ap.add_argument("--task", choices=["synthetic", "point-circle"], default="synthetic",
                     help="point-circle: per-instance gym-style envs (fsrl_amd.env.PointCircleEnv) built from factories and stepped in "
                          "worker processes, hidden_sizes (100, 50): the env-factory path and the zero-padded widths end to end")
@@ -47,6 +49,8 @@ def main():
             env = SyntheticSafetyVectorEnv(env_num=10, episode_len=100, seed=0)
             test = SyntheticSafetyVectorEnv(env_num=4, episode_len=100, seed=5)
             hidden = (a.hidden, a.hidden)
+        if a.hidden_sizes:
+            hidden = tuple(int(x) for x in a.hidden_sizes.split("x"))
         agent = cls(env, BaseLogger(tempfile.mkdtemp(), name=name), cost_limit=a.cost_limit, device="cuda:0", seed=1,
                     hidden_sizes=hidden, training_num=10, **akw)
         before = agent.evaluate(test, eval_episodes=8)
