@@ -414,7 +414,7 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     CHECK_ARG(cfg->act_dim >= 1 && cfg->act_dim <= FSRL_MAX_ACT, "act_dim must be in [1,%d]", FSRL_MAX_ACT);
     // hidden_sizes (fsrl/agent/ppo_lag_agent.py:91,136): n_hidden > 0 names them.  Two layers of at most 256 units run on the
     // fused kernels (H = 64 / 128 / 256, narrower layers zero-padded); any other depth / width is a LAYERED context
-    // (host_layered.inc): every algorithm but CVPO
+    // (host_layered.inc): every algorithm
     CHECK_ARG(cfg->n_hidden >= 0 && cfg->n_hidden <= FSRL_MAX_HIDDEN, "n_hidden must be in [0, %d]", FSRL_MAX_HIDDEN);
     bool layered = false;
     int n_hid1 = cfg->hidden1, n_hid2 = cfg->hidden2;

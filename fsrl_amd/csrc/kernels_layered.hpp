@@ -1,4 +1,5 @@
-// kernels_layered.hpp -- layer-by-layer kernels of the PPO-Lagrangian update for networks the fused kernels do not cover:
+// kernels_layered.hpp -- layer-by-layer kernels for networks the fused kernels do not cover (all seven agents; written first for
+// the PPO-Lagrangian update, whose launch sequence is listed here):
 // `hidden_sizes` of any depth (1 .. FSRL_MAX_HIDDEN hidden layers) and any width (fsrl/agent/ppo_lag_agent.py:91,136-145:
 // tianshou `Net(hidden_sizes=...)` under ActorProb / Critic).  The fused path (kernels_mlp.hpp) keeps a whole two-layer
 // network of at most 256 units in one workgroup; here every Linear is its own MFMA GEMM launch over the minibatch (or, at
