@@ -61,20 +61,21 @@ struct LayModel { int Do, Da, n_nets, unbounded; LayNet net[FSRL_MAX_NETS]; };
 // costs its whole latency on the spot, kernels_wgrad2.hpp) and the zero-fill is applied when the tile is written to LDS, two
 // chunks later; `ok` carries one bit per element.  VEC (chosen by the host per launch): every operand row is 16-byte aligned
 // and 4 | its length, so a float4 is all in or all out; otherwise four dword loads per slot.
-struct LinTile { f32x4 v[4]; unsigned ok; };
-// One operand's view for this thread: slot j = tid + 256 j covers tile row tr = slot >> 4, tile columns tc .. tc + 3 (tc = 4 (slot & 15)).
+template <int SLOTS> struct LinTile { f32x4 v[SLOTS]; unsigned ok; };     // SLOTS float4 per thread: 1024 / threads of the workgroup
+// One operand's view for this thread: slot j = tid + NT j (NT threads per workgroup) covers tile row tr = slot >> 4, tile columns tc .. tc + 3 (tc = 4 (slot & 15)).
 //   k-minor: tile row = operand row (fixed), tile column = k (advances by 64 per chunk)
 //   k-major: tile row = k (advances),        tile column = operand column (fixed)
-template <bool KMAJOR, bool VEC>
+template <bool KMAJOR, bool VEC, int SLOTS>
 struct LinOperand {
+    static constexpr int NT = 1024 / SLOTS;
     const float* base; int ld, fixed_n, K, fixed0;     // fixed_n: extent of the operand dimension (rows of a k-minor operand, columns of a k-major one)
     int tid;
-    __device__ __forceinline__ LinTile load(const int k0) const {
-        LinTile t;
+    __device__ __forceinline__ LinTile<SLOTS> load(const int k0) const {
+        LinTile<SLOTS> t;
         t.ok = 0u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int slot = tid + 256 * j, tr = slot >> 4, tc = 4 * (slot & 15);
+        for (int j = 0; j < SLOTS; ++j) {
+            const int slot = tid + NT * j, tr = slot >> 4, tc = 4 * (slot & 15);
             const int f = fixed0 + (KMAJOR ? tc : tr);        // operand index (fixed over the chunks)
             const int k = k0 + (KMAJOR ? tr : tc);
             if (VEC) {
@@ -95,10 +96,11 @@ struct LinOperand {
         return t;
     }
 };
-__device__ __forceinline__ void lin_stage(float* __restrict__ s, const LinTile& t, const int tid) {
+template <int SLOTS>
+__device__ __forceinline__ void lin_stage(float* __restrict__ s, const LinTile<SLOTS>& t, const int tid) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int idx = tid + 256 * j;
+    for (int j = 0; j < SLOTS; ++j) {
+        const int idx = tid + (1024 / SLOTS) * j;
         f32x4 v = t.v[j];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ((t.ok >> (4 * j + e)) & 1u) ? v[e] : 0.0f;
@@ -121,13 +123,18 @@ __device__ __forceinline__ f32x4 lin_frag(const float* __restrict__ s, const int
 // of it (4 MFMA column tiles), k-chunks of 64 staged through LDS (34 KB) with the next two chunks' global loads in flight.
 // LIN_W additionally: the workgroups of column tile 0 reduce the bias gradient (ascending batch row), and EVERY workgroup of
 // the grid writes its share of the squared gradient norm to gsq_part[linear block index] (0 for idle ones).
-template <int FORM, bool VEC>
-__global__ __launch_bounds__(256) void lin_kernel(const LinJobs jobs, float* __restrict__ gsq_part) {
+// NW = waves along the 64 output columns (1, 2 or 4): 256 NW threads, wave (wm = w & 3, wn = w >> 2) owns rows 16 wm .. + 15 and
+// the 4 / NW column tiles from 16 (4 / NW) wn.  A minibatch-sized product has only a few hundred workgroups: with NW = 1 that is
+// less than one wave per SIMD and every load, LDS read and barrier is exposed; NW = 4 puts up to four waves on each SIMD of the
+// workgroup's CU (the host picks NW from the number of workgroups of the launch).
+template <int FORM, bool VEC, int NW>
+__global__ __launch_bounds__(256 * NW) void lin_kernel(const LinJobs jobs, float* __restrict__ gsq_part) {
     constexpr bool AKJ = (FORM == LIN_W), BKJ = (FORM != LIN_F);
+    constexpr int T = 4 / NW, SLOTS = 4 / NW;
     __shared__ __attribute__((aligned(16))) float sA[64 * LIN_LD];
     __shared__ __attribute__((aligned(16))) float sB[64 * LIN_LD];
-    __shared__ float red[4];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, q = lane >> 4;
+    __shared__ float red[4 * NW];
+    const int tid = threadIdx.x, wv = tid >> 6, wave = wv & 3, wn = wv >> 2, lane = tid & 63, li = lane & 15, q = lane >> 4;
     LinJob jb = jobs.j[blockIdx.z];              // by value: the fields live in SGPRs, not re-read from the kernel arguments per chunk
     int by = blockIdx.y;
     if (FORM == LIN_W && jobs.ksplit > 1) {      // this workgroup's range of batch rows and its partial
@@ -148,19 +155,19 @@ __global__ __launch_bounds__(256) void lin_kernel(const LinJobs jobs, float* __r
         if (FORM == LIN_W && gsq_part && tid == 0) gsq_part[blk] = 0.0f;
         return;
     }
-    f32x4 acc[4];
+    f32x4 acc[T];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.0f;
     // operand geometry: A rows are output rows (k-minor) or batch rows (k-major); the same for B and the output columns
     // one pass over K for an operand pair; LIN_W may run a second pair into the same accumulators (R{dW} = R{dz}^T a + dz^T R{a})
     auto k_pass = [&](const float* Ap, const float* Bp, const bool with_bias) __attribute__((always_inline)) {
-    const LinOperand<AKJ, VEC> opA{Ap, jb.lda, (AKJ && jb.a_len) ? jb.a_len : M, (!AKJ && jb.a_len) ? jb.a_len : K, m0, tid};
-    const LinOperand<BKJ, VEC> opB{Bp, jb.ldb, N, K, n0, tid};
+    const LinOperand<AKJ, VEC, SLOTS> opA{Ap, jb.lda, (AKJ && jb.a_len) ? jb.a_len : M, (!AKJ && jb.a_len) ? jb.a_len : K, m0, tid};
+    const LinOperand<BKJ, VEC, SLOTS> opB{Bp, jb.ldb, N, K, n0, tid};
     // register prefetch two chunks ahead: one chunk's MFMA work (~0.85 us) is shorter than a cold round trip to L2 / HBM.
     // Two named tile pairs (a dynamically indexed register array would go to scratch); a load past K is clamped and unused.
-    LinTile a0 = opA.load(0), b0 = opB.load(0), a1 = opA.load(LIN_KC), b1 = opB.load(LIN_KC);
-    auto chunk = [&](const int k0, LinTile& ta, LinTile& tb) __attribute__((always_inline)) {
+    LinTile<SLOTS> a0 = opA.load(0), b0 = opB.load(0), a1 = opA.load(LIN_KC), b1 = opB.load(LIN_KC);
+    auto chunk = [&](const int k0, LinTile<SLOTS>& ta, LinTile<SLOTS>& tb) __attribute__((always_inline)) {
         __syncthreads();                       // everybody is done with the previous chunk's tiles
         lin_stage(sA, ta, tid);
         lin_stage(sB, tb, tid);
@@ -168,25 +175,25 @@ __global__ __launch_bounds__(256) void lin_kernel(const LinJobs jobs, float* __r
         ta = opA.load(k0 + 2 * LIN_KC); tb = opB.load(k0 + 2 * LIN_KC);
         // fragments of sub-chunk kc + 1 are read while the 16 MFMAs of sub-chunk kc issue; the MFMAs of one k-step go round the
         // four accumulators, so consecutive ones are independent
-        f32x4 fa = lin_frag<AKJ>(sA, 16 * wave + li, 0, q), fb[4];
+        f32x4 fa = lin_frag<AKJ>(sA, 16 * wave + li, 0, q), fb[T];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) fb[t] = lin_frag<BKJ>(sB, 16 * t + li, 0, q);
+        for (int t = 0; t < T; ++t) fb[t] = lin_frag<BKJ>(sB, 16 * (T * wn + t) + li, 0, q);
 #pragma unroll
         for (int kc = 0; kc < LIN_KC / 16; ++kc) {
             const f32x4 a = fa;
-            f32x4 b[4];
+            f32x4 b[T];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) b[t] = fb[t];
+            for (int t = 0; t < T; ++t) b[t] = fb[t];
             if (kc + 1 < LIN_KC / 16) {
                 fa = lin_frag<AKJ>(sA, 16 * wave + li, kc + 1, q);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) fb[t] = lin_frag<BKJ>(sB, 16 * t + li, kc + 1, q);
+                for (int t = 0; t < T; ++t) fb[t] = lin_frag<BKJ>(sB, 16 * (T * wn + t) + li, kc + 1, q);
             }
             if (k0 + 16 * kc < K) {            // uniform; the rest of the chunk is zeros
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = mfma_16x16x4(a[s], b[t][s], acc[t]);
+                    for (int t = 0; t < T; ++t) acc[t] = mfma_16x16x4(a[s], b[t][s], acc[t]);
                 if (FORM == LIN_W) {
                     if (with_bias && bias_role && tid < 64) {   // ascending batch row; the 16 LDS reads of a sub-chunk issued together
                         float v[16];
@@ -199,9 +206,9 @@ __global__ __launch_bounds__(256) void lin_kernel(const LinJobs jobs, float* __r
             }
         }
     };
-    for (int k0 = 0; k0 < K; k0 += 2 * LIN_KC) {
-        chunk(k0, a0, b0);
-        if (k0 + LIN_KC < K) chunk(k0 + LIN_KC, a1, b1);
+    for (int k0 = 0; k0 < K; k0 += 2 * LIN_KC) {       // both halves unconditionally: a load inside a branch makes the compiler wait for
+        chunk(k0, a0, b0);                             // every outstanding load at the join; a half past K stages zeros and skips
+        chunk(k0 + LIN_KC, a1, b1);                    // its MFMAs
     }
     };
     k_pass(jb.A, jb.B, true);
@@ -211,8 +218,8 @@ __global__ __launch_bounds__(256) void lin_kernel(const LinJobs jobs, float* __r
     // ---- epilogue: acc[t][r] = C[m0 + 16 wave + 4 q + r][n0 + 16 t + li]
     float sq = 0.0f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int n = n0 + 16 * t + li;
+    for (int t = 0; t < T; ++t) {
+        const int n = n0 + 16 * (T * wn + t) + li;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + 16 * wave + 4 * q + r;
@@ -240,9 +247,14 @@ __global__ __launch_bounds__(256) void lin_kernel(const LinJobs jobs, float* __r
         }
         if (gsq_part) {
             sq = wave_sum(sq);
-            if (lane == 0) red[wave] = sq;
+            if (lane == 0) red[wv] = sq;
             __syncthreads();
-            if (tid == 0) gsq_part[blk] = (red[0] + red[1]) + (red[2] + red[3]);
+            if (tid == 0) {
+                float tot = 0.0f;
+#pragma unroll
+                for (int g = 0; g < NW; ++g) tot += (red[4 * g] + red[4 * g + 1]) + (red[4 * g + 2] + red[4 * g + 3]);
+                gsq_part[blk] = tot;
+            }
         }
     }
 }
