@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--epoch", type=int, default=3)
     ap.add_argument("--envs", type=int, default=20)
     ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--hidden-sizes", default="", help="hidden_sizes as a tuple, e.g. 64x48x32 or 512x512 (the reference's agents take any tuple); "
+                                                       "two layers of at most 256 units run on the fused kernels, anything else on the layered ones")
     ap.add_argument("--cost-limit", type=float, default=10.0)
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--seed", type=int, default=10)
@@ -56,7 +58,8 @@ def main():
     if a.task != "point-circle":
         test_env = SyntheticSafetyVectorEnv(env_num=2, obs_dim=8, act_dim=2, episode_len=300, seed=a.seed + 1)
     logger = BaseLogger(tempfile.mkdtemp(prefix="fsrl_amd_"), name=a.algo)
-    kw = dict(cost_limit=a.cost_limit, device=a.device, seed=a.seed, hidden_sizes=(a.hidden, a.hidden), training_num=a.envs)
+    kw = dict(cost_limit=a.cost_limit, device=a.device, seed=a.seed, hidden_sizes=(tuple(int(x) for x in a.hidden_sizes.split("x")) if a.hidden_sizes else (a.hidden, a.hidden)),
+              training_num=a.envs)
     if a.algo in ("ppol", "cpo", "trpol", "focops"):
         kw.update(unbounded=a.unbounded, reward_normalization=a.reward_normalization)
     if a.algo == "ppol":
