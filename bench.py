@@ -430,6 +430,45 @@ def sac_c3_leg():
     return bench_sac.main(["--updates", "1000", "--cpu-updates", "10"], emit=False)
 
 
+def configs_summary(out):
+    """Every BASELINE configuration's figures in one compact object (<= 600 characters), written as the LAST key of the
+    line so that a record which keeps only the tail of stdout still carries them: time, whole-update fp32-MFMA fraction,
+    memory-side traffic (committed PMC pass) and the CPU port's rate on this box."""
+    def g(d, *ks):
+        for k in ks:
+            d = d.get(k) if isinstance(d, dict) else None
+        return d
+
+    def r(x, n=3):
+        return None if not isinstance(x, (int, float)) else round(float(x), n)
+    c = {}
+    roof = out.get("roofline") if isinstance(out.get("roofline"), dict) else {}
+    c["c1_ppo"] = {"ms": r(out.get("ms_per_step")), "step_us": r(roof.get("step_us"), 2), "frac": r(roof.get("frac"), 4),
+                   "cpu_updates_s": r(g(out, "cpu_baseline", "value"))}
+    c0 = out.get("gpu_c0")
+    if isinstance(c0, dict) and "ms_per_update" in c0:
+        c["c0_ppo128"] = {"ms": r(c0["ms_per_update"]), "cpu_updates_s": r(g(out, "cpu_baseline_c0", "value"))}
+    for key, name in (("cpo_c2", "c2_cpo"), ("trpo_c1", "c1_trpo")):
+        d = out.get(key)
+        if isinstance(d, dict):
+            tb = g(d, "roofline", "traffic")
+            c[name] = ({"err": 1} if "error" in d else
+                       {"ms": r(d.get("hip_ms_per_update"), 2), "frac": r(g(d, "roofline", "frac")),
+                        "traffic_gb": r(tb / 1e9 if tb else None, 1), "cpu_updates_s": r(g(d, "cpu_baseline", "value"), 4)})
+    d = out.get("sac_c3")
+    if isinstance(d, dict):
+        tb = g(d, "roofline", "traffic")
+        c["c3_sac"] = ({"err": 1} if "error" in d else
+                       {"us": r(d["ms_per_update"] * 1e3 if "ms_per_update" in d else None, 1), "frac": r(g(d, "roofline", "frac")),
+                        "traffic_mb": r(tb / 1e6 if tb else None, 1), "launches": d.get("launches_per_update"),
+                        "cpu_updates_s": r(g(d, "cpu_baseline", "value"), 2)})
+    d = out.get("kl_on")
+    if isinstance(d, dict) and "ms_per_update" in d:
+        c["kl_on"] = {"ms": r(d["ms_per_update"]), "steps": r(d.get("grad_steps_per_update_mean"), 1),
+                      "stopped": d.get("updates_stopped_early"), "of": d.get("updates")}
+    return c
+
+
 class Legs:
     """Secondary legs of the bench line.  The headline dict is complete BEFORE any of them runs; every leg runs inside
     try/except (its key becomes {"error": ...} on failure) under a watchdog thread with a per-leg deadline: when a leg
@@ -468,6 +507,8 @@ class Legs:
                 return
             self.printed = True
         if self.rank == 0 and self.out is not None:
+            self.out.pop("configs", None)
+            self.out["configs"] = configs_summary(self.out)       # LAST key: the stored tail of the line always holds it
             print(json.dumps(self.out), flush=True)
 
     def remaining(self):
@@ -593,9 +634,10 @@ def main():
             "value": ups * world, "unit": "updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: PPO-Lag update, obs 8 / act 2, 256x256, N=20000 rows "
-                                   "(20 envs x 1000, 250-step episodes), batch 256, repeat 4, grad-clip 0.5, "
-                                   "KL early stop off", "seeds_per_gpu": 1, "parallelism": f"independent agents x{world}"},
+            # < 120 characters (the driver's record cuts the string): what is timed first, the shape after it
+            "config": {"workload": "configs[1] PPO-Lag update: repeat 4, clip 0.5, KL stop off, batch 256, N=20000 (20x1000), "
+                                   "obs 8/act 2, 256x256",
+                       "seeds_per_gpu": 1, "parallelism": f"independent agents x{world}"},
             "grad_steps_per_update": int(grad_steps),
             "grad_steps_per_s": ups * grad_steps * world,
             "buffer_rows_per_s": ups * NROWS * world,

@@ -245,8 +245,12 @@ class FastCollector:
         or died fails the call within half a second; the env itself is then unusable and says so on its next command)."""
         try:
             r = eng.collect_episodes(self.env.native_desc(), ready, obs, n_episode, det, bound, low, high, split=split)
-        finally:
+        except BaseException:
+            # a failed native collect may have left a command half-handled on a lane: the env refuses every later command
             self.env.sync_native()
+            self.env.mark_broken("a native collect failed while env commands were in flight")
+            raise
+        self.env.sync_native()
         self.buffer.sync_sizes()
         self.collect_step += r["steps"]
         self.collect_episode += len(r["ep_rews"])

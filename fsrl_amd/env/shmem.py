@@ -225,7 +225,9 @@ class ShmemVectorEnv:
                                                   act_dim, spec, core, self._spin), daemon=True)
             p.start()
             self._procs.append(p)
-        self._pids = np.array([p.pid for p in self._procs], np.int32)
+        # the native collector probes these with waitid(): only meaningful when this process IS the workers' parent (spawn / fork).
+        # A fork server's children are not ours -- pass no pids then (the error words and the 60 s timeout remain)
+        self._pids = np.array([p.pid if start_method in ("spawn", "fork") else 0 for p in self._procs], np.int32)
         self.lane_of_env = self._lane_of_worker[self._owner]
         self.lanes = [np.flatnonzero(self.lane_of_env == l) for l in range(self.n_lanes)]
         # lanes are contiguous env / worker ranges: the steady state (a command for a whole lane) uses basic slices
@@ -241,7 +243,13 @@ class ShmemVectorEnv:
         return self.env_num
 
     # ---- the handshake: post a command to a lane, wait for it
+    def mark_broken(self, why):
+        """sticky: every later command raises (the handshake words can no longer be trusted)"""
+        self._broken = str(why)
+
     def _post(self, lane, cmd, ids):
+        if getattr(self, "_broken", None):
+            raise RuntimeError(f"ShmemVectorEnv is unusable: {self._broken}")
         assert self._inflight[lane] is None, "a command is already in flight on this lane"
         v = self._v
         self._gen[lane] = (self._gen[lane] + 1) & 0x7FFFFFFF or 1
@@ -317,6 +325,8 @@ class ShmemVectorEnv:
     def native_desc(self):
         """struct fsrl_shm_env for fsrl_collect_run (include/fsrl_hip.h); the generation counters travel with it (sync_native
         after the call).  No command may be in flight."""
+        if getattr(self, "_broken", None):
+            raise RuntimeError(f"ShmemVectorEnv is unusable: {self._broken}")
         assert self._inflight == [None, None]
         from fsrl_amd._lib import ShmEnv
         if getattr(self, "_desc", None) is None:

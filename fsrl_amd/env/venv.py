@@ -18,11 +18,26 @@ def _accepts_seed(env):
     """does env.reset take a `seed` keyword (gymnasium / gym >= 0.22)?  Decided from the signature, not by catching the
     TypeError of a trial call -- a TypeError raised INSIDE a user's reset must reach the user."""
     import inspect
-    try:
-        params = inspect.signature(env.reset).parameters
-    except (TypeError, ValueError):
-        return True
-    return "seed" in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+    # a wrapper's `reset(self, **kwargs)` says nothing (old-gym Wrapper / TimeLimit forward to an inner reset() that may take no
+    # seed): walk .env / .unwrapped down to the first explicit signature
+    seen = 0
+    while env is not None and seen < 32:
+        try:
+            params = inspect.signature(env.reset).parameters
+        except (TypeError, ValueError):
+            return True
+        if "seed" in params:
+            return True
+        if not any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values()):
+            return False
+        inner = getattr(env, "env", None)
+        if inner is None or inner is env:
+            un = getattr(env, "unwrapped", None)
+            inner = un if (un is not None and un is not env) else None
+        if inner is None:
+            return True                                     # a bare reset(**kwargs): nothing below it to ask
+        env, seen = inner, seen + 1
+    return True
 
 
 def _reset_one(env, seed, kwargs):

@@ -245,7 +245,7 @@ class CPOOracle(_TrustRegionBase):
                             cs_n - cs0 <= max(-c_value.item(), 0):
                         break
                     beta *= c.backtrack_coeff
-        f = lambda t: float(torch.as_tensor(t).reshape(-1)[0])  # noqa: E731
+        f = lambda t: float(torch.as_tensor(t).detach().reshape(-1)[0])  # noqa: E731
         stats = {"loss/kl": kl.item(), "loss/entropy": ent.item(), "loss/rew_loss": objective.item(),
                  "loss/cost_loss": cost_sur.item(), "loss/optim_A": f(A), "loss/optim_B": f(B),
                  "loss/optim_C": c_value.item(), "loss/optim_Q": f(s_q), "loss/optim_R": f(s_r),

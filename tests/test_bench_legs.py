@@ -59,3 +59,30 @@ def test_nonzero_rank_watchdog_exits_quietly():
             "legs.run('stuck', lambda: time.sleep(3600), 1.0)\n") % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and r.stdout.strip() == ""
+
+
+def test_configs_summary_is_the_last_key_and_compact(capsys):
+    """the record keeps only the tail of the line: every BASELINE configuration's figures sit in ONE last key of <= 600 characters
+    (built here from a bench line this repo recorded on an MI355X: profiles/r04_bench.json)"""
+    import bench
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    rec.pop("configs", None)
+    legs = bench.Legs(rec, 0, 30.0)
+    legs.emit()
+    line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][0]
+    d = json.loads(line)
+    assert list(d)[-1] == "configs"
+    c = d["configs"]
+    assert len(json.dumps(c)) <= 600, len(json.dumps(c))
+    assert {"c1_ppo", "c2_cpo", "c1_trpo", "c3_sac", "kl_on"} <= set(c)
+    assert abs(c["c2_cpo"]["ms"] - rec["cpo_c2"]["hip_ms_per_update"]) < 0.01 and c["c2_cpo"]["frac"] > 0 and c["c2_cpo"]["cpu_updates_s"] > 0
+    assert abs(c["c3_sac"]["us"] - rec["sac_c3"]["ms_per_update"] * 1e3) < 0.06 and c["c3_sac"]["cpu_updates_s"] > 0
+    assert c["c1_trpo"]["traffic_gb"] > 1 and c["c1_ppo"]["frac"] > 0
+
+
+def test_headline_workload_string_survives_the_records_cut():
+    import bench, inspect
+    src = inspect.getsource(bench.main)
+    i = src.index('"config": {"workload": ')
+    txt = "".join(__import__("re").findall(r'"([^"]*)"', src[i + 22:src.index('"seeds_per_gpu"', i)]))
+    assert len(txt) < 120 and txt.startswith("configs[1] PPO-Lag update: repeat 4, clip 0.5"), (len(txt), txt)

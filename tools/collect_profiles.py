@@ -133,11 +133,17 @@ for sub in (f"{tag}_pmc_mfma", f"{tag}_pmc_mfma_trust", f"{tag}_pmc_mfma_sac"):
     for name, c in acc.items():
         n = max(len(disp[name]), 1)
         gui = c.get("GRBM_GUI_ACTIVE", 0.0) / XCDS
-        mf[name] = {"launches": n, "mfma_busy_cycles_per_launch": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / n,
+        row = {"launches": n, "mfma_busy_cycles_per_launch": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / n,
                     "gpu_active_cycles_per_launch": gui / n,
                     "mfma_util_pct": 100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * SIMDS) if gui else None,
                     "mfma_f32_flops_per_launch": c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512 / n,
                     "sq_busy_cycles_per_launch": c.get("SQ_BUSY_CYCLES", 0.0) / n, "source": sub}
+        # one row per (kernel, source run): `name@headline` / `name@trust` / `name@sac` -- the same kernel template runs at other
+        # shapes in other updates (fb_wgrad_kernel<256,false>: CPO's critic step over 20 000 rows vs SAC's 1 024-row batch);
+        # the bare name keeps the first source that has it (what earlier rounds' files held)
+        short = sub[len(tag) + 1:].replace("pmc_mfma_", "").replace("pmc_mfma", "headline")
+        mf[f"{name}@{short}"] = row
+        mf.setdefault(name, row)
 if mf:
     json.dump(mf, open(os.path.join(pr, f"{tag}_pmc_mfma.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps({k: (round(v["mfma_util_pct"], 2) if v["mfma_util_pct"] is not None else None) for k, v in mf.items()
