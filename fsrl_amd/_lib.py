@@ -120,8 +120,10 @@ SIGNATURES = {
     "fsrl_actor_param_count": (C.c_int64, [_ctx]),
     "fsrl_tr_grad": (C.c_int, [_ctx, C.c_int32, _f, C.c_int64]),
     "fsrl_tr_hvp": (C.c_int, [_ctx, _f, _f, C.c_int64]),
+    "fsrl_tr_hvp_cached": (C.c_int, [_ctx, _f, _f, C.c_int64]),
     "fsrl_tr_eval": (C.c_int, [_ctx, _d]),
     "fsrl_tr_set_plan": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32]),
+    "fsrl_tr_set_tile_split": (C.c_int, [_ctx, C.c_int32, C.c_int32]),
     "fsrl_focops_init": (C.c_int, [_ctx, _P(FocopsConfig)]),
     "fsrl_focops_set_plan": (C.c_int, [_ctx, C.c_int32]),
     "fsrl_focops_set_nu": (C.c_int, [_ctx, C.c_double, C.c_double]),

@@ -20,6 +20,7 @@
 #include "kernels_misc.hpp"
 #include "kernels_mlp.hpp"
 #include "kernels_fb.hpp"
+#include "kernels_fbco.hpp"
 #include "kernels_wgrad2.hpp"
 #include "kernels_layered.hpp"
 

@@ -467,9 +467,20 @@ class Engine:
         _lib.check(self.lib.fsrl_tr_hvp(self._ctx, _ptr(v, _f32p), _ptr(out, _f32p), v.size))
         return out
 
+    def tr_hvp_cached(self, v):
+        """H v again at the theta / batch of the previous tr_hvp call: the cached-activation kernel of the CG solves."""
+        v = np.ascontiguousarray(v, np.float32)
+        out = np.empty_like(v)
+        _lib.check(self.lib.fsrl_tr_hvp_cached(self._ctx, _ptr(v, _f32p), _ptr(out, _f32p), v.size))
+        return out
+
     def tr_set_plan(self, tile_rows: int = 0, hvp: int = 0, wgrad: int = 0):
         """Kernel plan of the full-batch path (A/B timing, bit-identity tests); 0 / 0 = automatic."""
         _lib.check(self.lib.fsrl_tr_set_plan(self._ctx, int(tile_rows), int(hvp), int(wgrad)))
+
+    def tr_set_tile_split(self, n32_tile: int = -1, n32_hvp: int = -1):
+        """A/B only: forced 32-row tile counts of the co-resident tile / cached-HVP launches (-1 = the dispatch simulation)."""
+        _lib.check(self.lib.fsrl_tr_set_tile_split(self._ctx, int(n32_tile), int(n32_hvp)))
 
     def tr_eval(self):
         out = np.zeros(8, np.float64)

@@ -354,20 +354,31 @@ int64_t fsrl_actor_param_count(const fsrl_ctx* ctx);
 int fsrl_tr_grad(fsrl_ctx* ctx, int32_t which, float* out, int64_t n);
 /* out = H v (no damping), H = Hessian of mean KL(N(mean_old,std_old) || pi_theta) at the current theta */
 int fsrl_tr_hvp(fsrl_ctx* ctx, const float* v, float* out, int64_t n);
+/* the same product for a caller that promises that theta, the batch and mean_old / std_old are those of its previous
+ * fsrl_tr_hvp / fsrl_tr_hvp_cached call: the theta-only activations (h1, h2, dout, dz2) are read back instead of recomputed --
+ * the kernel the conjugate-gradient solves inside fsrl_cpo_learn / fsrl_trpo_learn run for their 2nd .. 11th product
+ * (cpo.py:184-204).  Bit-identical to fsrl_tr_hvp.                                                                     */
+int fsrl_tr_hvp_cached(fsrl_ctx* ctx, const float* v, float* out, int64_t n);
 /* stats8: mean(ratio*A_r), mean(ratio*A_c), mean KL, mean(logp_old - logp), mean A_r, mean A_c, 0, 0 */
 int fsrl_tr_eval(fsrl_ctx* ctx, double* stats8);
 /* Kernel plan of the full-batch path, for A/B timing and the bit-identity tests (no reference counterpart: the reference
- * has one code path).  tile_rows: 0 = automatic (mixed 32- / 16-row tiles where the batch spans more than one round of
- * workgroups), 16 = 16-row tiles only.  hvp: 0 = automatic (mixed tiles; the theta-only activations of the KL Hessian
- * product are computed by the first product of a conjugate-gradient solve and read back by the others: cpo.py:184-204
- * calls _MVP 10 + 1 times per right-hand side at one theta), 1 = the 16-row kernel that recomputes everything,
- * 2 = mixed tiles without the cache.  wgrad: 0 = the split-K weight-gradient kernel (default), 1 = the same with XCD-aware
- * placement of its blocks, 3 = the one-pass streaming kernel for 256-wide layers over >= 4096 rows (one workgroup per network,
- * output quarter and row slice; operands by LDS-DMA; 2.6x less memory traffic, the same time: not the default).  The
- * tile_rows / hvp / wgrad 0-1 plans give bit-identical results; the streaming kernel adds the rows up in another order (fp32
- * MFMA chains of different lengths, partials in float64): its results agree to rounding (tests/test_gpu_fullsize.py states
- * the tolerance).                                                                                                   */
+ * has one code path).  tile_rows: 0 = automatic (mixed 32- / 16-row tiles; at 256-wide layers, obs_dim <= 64 and act_dim <= 4
+ * as TWO co-resident 512-thread workgroups per CU: fb_tile_co_kernel), 16 = 16-row tiles only, 32 = mixed tiles with one
+ * 1024-thread workgroup per CU (round 4's kernel).  hvp: 0 = automatic (mixed tiles; the theta-only activations of the KL
+ * Hessian product are computed by the first product of a conjugate-gradient solve and read back by the others: cpo.py:184-204
+ * calls _MVP 10 + 1 times per right-hand side at one theta; the cached products run as two co-resident workgroups per CU at
+ * 256-wide layers: fb_hvp_co_kernel), 1 = the 16-row kernel that recomputes everything, 2 = mixed tiles without the cache,
+ * 3 = mixed tiles + cache with one 1024-thread workgroup per CU (round 4's kernel).  wgrad: 0 = the split-K weight-gradient
+ * kernel (default), 1 = the same with XCD-aware placement of its blocks, 3 = the one-pass streaming kernel for 256-wide layers
+ * over >= 4096 rows (one workgroup per network, output quarter and row slice; operands by LDS-DMA; 2.6x less memory traffic,
+ * the same time: not the default).  The tile_rows / hvp / wgrad 0-1 plans give bit-identical results; the streaming kernel adds
+ * the rows up in another order (fp32 MFMA chains of different lengths, partials in float64): its results agree to rounding
+ * (tests/test_gpu_fullsize.py states the tolerance).                                                                   */
 int fsrl_tr_set_plan(fsrl_ctx* ctx, int32_t tile_rows, int32_t hvp, int32_t wgrad);
+/* A/B only: force how many 32-row tiles (per network) the co-resident launches of the tile kernel / of the cached Hessian
+ * product start with, the remaining rows going to 16-row tiles behind them; -1 = automatic (the dispatch simulation).  The
+ * split does not change a result (a row's arithmetic does not depend on its tile's height).                           */
+int fsrl_tr_set_tile_split(fsrl_ctx* ctx, int32_t n32_tile, int32_t n32_hvp);
 
 /* ---- FOCOPS (fsrl/policy/focops.py:126-251), on the PPO entry points: create the context
  *      with algo = FSRL_ALGO_FOCOPS (same networks and parameter vector as PPO-Lag), call fsrl_focops_init once,

@@ -299,6 +299,7 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
             out[f"grad{w}"] = eng.tr_grad(w)
         out["eval"] = eng.tr_eval()
         out["hvp"] = eng.tr_hvp(v)
+        out["hvp_cached"] = eng.tr_hvp_cached(v[::-1].copy())        # the cached-activation kernel (r5: co-resident at 256 wide)
         out["cpo"] = eng.cpo_learn(25.0, 2).copy()
         out["theta_cpo"] = eng.get_params().copy()
         eng.set_params(theta); eng.optim_reset()
@@ -313,7 +314,8 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
     for wg in (3, 0):
         ref = refs[wg] = run(16, 1, wg)
         assert np.isfinite(ref["cpo"]).all() and np.isfinite(ref["trpo"]).all() and np.abs(ref["hvp"]).max() > 0
-        for plan in ((0, 2, wg), (0, 0, wg), (16, 0, wg)) + (((0, 0, 1), ) if wg == 0 else ()):
+        # (32, 3): round 4's one-workgroup-per-CU kernels; (0, 0): round 5's co-resident pairs where they apply (256 wide)
+        for plan in ((0, 2, wg), (0, 0, wg), (16, 0, wg), (32, 3, wg), (32, 0, wg), (0, 3, wg)) + (((0, 0, 1), ) if wg == 0 else ()):
             got = run(*plan)
             for k in ref:
                 assert np.array_equal(ref[k], got[k]), (plan, k, np.abs(np.asarray(ref[k], np.float64) - got[k]).max())
@@ -346,6 +348,58 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
             assert np.array_equal(a[k], b[k]), k                         # below the new kernel's range nothing changes
     eng.tr_set_plan(0, 0, 0)
     eng.close()
+
+
+@pytest.mark.parametrize("obs_dim,T", [(60, 1000), (8, 1000), (33, 163)])
+def test_co_resident_kernels_match_one_workgroup_per_cu(obs_dim, T):
+    """Round 5's co-resident tile kernels (two 512-thread workgroups per CU, two time-multiplexed LDS slots; kernels_fbco.hpp)
+    against round 4's one-1024-thread-workgroup-per-CU kernels on the building blocks, BIT FOR BIT, for the automatic tile mix and
+    for forced mixes (all 32-row tiles incl. a ragged last one, all 16-row tiles, one 32-row tile): the three gradients (SUR,
+    SUR, KL heads), the line-search statistics (EVAL), the critics' regression step (VF, through one CPO repeat) and the cached
+    Hessian-vector product.  N = 20 000 (BASELINE configs[2] / configs[1] shapes) and N = 3 260 (partial tiles, one round)."""
+    from fsrl_amd.engine import Engine, EngineConfig
+    envs = 20
+    rng = np.random.default_rng(21)
+    obs, act, rew, cost, term, trunc = _inputs(rng, envs, T, obs_dim, 2, 250)
+    eng = Engine(EngineConfig(obs_dim=obs_dim, act_dim=2, hidden=256, env_num=envs, target_kl=None, lr=1e-3))
+    ids = np.arange(envs)
+    for t in range(T):
+        eng.push(ids, obs[t], act[t], rew[t], cost[t], term[t], trunc[t], obs[t + 1])
+    theta = (0.1 * np.random.default_rng(3).standard_normal(eng.n_params)).astype(np.float32)
+    moved = theta.copy()
+    moved[:eng.n_actor_params] += (0.01 * np.random.default_rng(5).standard_normal(eng.n_actor_params)).astype(np.float32)
+    v = np.random.default_rng(4).standard_normal(eng.n_actor_params).astype(np.float32)
+    N = envs * T
+
+    def run(tile_rows, hvp, split=(-1, -1)):
+        out = {}
+        eng.tr_set_plan(tile_rows, hvp, 0)
+        eng.tr_set_tile_split(*split)
+        eng.set_params(theta); eng.optim_reset()
+        assert eng.tr_begin(target_kl=0.01, l2_reg=0.001, critic_lr=1e-3, max_backtracks=10, optim_critic_iters=2, cost_limit=10.0) == N
+        eng.set_params(moved)                                   # theta != theta_old: every term of the R-op is live
+        for w in range(3):
+            out[f"grad{w}"] = eng.tr_grad(w)
+        out["eval"] = eng.tr_eval()
+        out["hvp"] = eng.tr_hvp(v)
+        out["hvp_cached"] = eng.tr_hvp_cached(v)
+        out["hvp_cached2"] = eng.tr_hvp_cached(v[::-1].copy())
+        out["cpo"] = eng.cpo_learn(25.0, 1).copy()
+        out["theta"] = eng.get_params().copy()
+        return out
+    ref = run(32, 3)
+    assert np.array_equal(ref["hvp"], ref["hvp_cached"]) and np.abs(ref["hvp"]).max() > 0 and np.isfinite(ref["cpo"]).all()
+    bad = []
+    for split in ((-1, -1), (N // 32, N // 32), (0, 0), (1, 1), (300, 100)):
+        got = run(0, 0, split)
+        for k in ref:
+            if not np.array_equal(ref[k], got[k]):
+                d = np.abs(np.asarray(ref[k], np.float64) - got[k])
+                bad.append((split, k, float(d.max()), int((d > 0).sum()), int(np.size(d))))
+    eng.tr_set_tile_split(-1, -1)
+    eng.tr_set_plan(0, 0, 0)
+    eng.close()
+    assert not bad, bad
 
 
 def test_streaming_weight_gradients_vs_autograd_at_full_size():

@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Same-box A/B of the full-batch kernel plans (round 5): round 4's one-1024-thread-workgroup-per-CU tile / cached-HVP kernels
+against the co-resident pairs of kernels_fbco.hpp, CPO on BASELINE configs[2] and TRPO-Lag on the configs[1] shape, alternated
+`--rounds` times so that box drift shows.  One JSON line per (algorithm, plan, round) + a summary.
+
+    python tools/ab_trust_co.py [--rounds 2] [--splits]      (under rocprofv3 --kernel-trace --stats for per-kernel times)
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bench_trust  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--splits", action="store_true", help="also sweep forced 32-row tile counts of the co-resident launches")
+    ap.add_argument("--only", default="cpo,trpo")
+    a = ap.parse_args()
+    plans = {"r4 (32,3)": "32,3,0", "co tile only (0,3)": "0,3,0", "co hvp only (32,0)": "32,0,0", "co both (0,0)": "0,0,0"}
+    res = {}
+    for rnd in range(a.rounds):
+        for kind, od, ep in (("cpo", 60, 1000), ("trpo", 8, 250)):
+            if kind not in a.only.split(","):
+                continue
+            for name, plan in plans.items():
+                os.environ["FSRL_TR_PLAN"] = plan
+                os.environ.pop("FSRL_TR_SPLIT", None)
+                r = bench_trust.run(kind, od, 2, 256, ep=ep, timed=5, emit=False, no_cpu=True)
+                res.setdefault((kind, name), []).append(r["hip_ms_per_update"])
+                print(json.dumps({"alg": kind, "plan": name, "round": rnd, "ms": round(r["hip_ms_per_update"], 3)}), flush=True)
+    if a.splits:
+        os.environ["FSRL_TR_PLAN"] = "0,0,0"
+        for kind, od, ep in (("cpo", 60, 1000), ("trpo", 8, 250)):
+            if kind not in a.only.split(","):
+                continue
+            for n32 in (0, 256, 384, 448, 512, 576, 625):
+                os.environ["FSRL_TR_SPLIT"] = f"{n32},{n32}"
+                r = bench_trust.run(kind, od, 2, 256, ep=ep, timed=5, emit=False, no_cpu=True)
+                res.setdefault((kind, f"co split n32={n32}"), []).append(r["hip_ms_per_update"])
+                print(json.dumps({"alg": kind, "plan": f"co split n32={n32}", "ms": round(r["hip_ms_per_update"], 3)}), flush=True)
+    print(json.dumps({"summary_ms_median": {f"{k[0]} | {k[1]}": round(float(np.median(v)), 3) for k, v in res.items()}}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

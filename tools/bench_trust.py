@@ -85,6 +85,10 @@ def run(kind, obs_dim, act_dim, hid, envs=20, T=1000, ep=1000, repeat=4, cpu_rep
     if plan:
         eng.tr_set_plan(*[int(x) for x in plan.split(",")])
 
+    split = os.environ.get("FSRL_TR_SPLIT")                # "n32_tile,n32_hvp" (fsrl_tr_set_tile_split): A/B of the co-resident launches' tile mix
+    if split:
+        eng.tr_set_tile_split(*[int(x) for x in split.split(",")])
+
     def device_update():
         # every timed update is the same workload: initial weights AND a fresh optimiser state -- round 1 restored the
         # weights only, so the critics' Adam moments of the previous update leaked into the next one and the reported
