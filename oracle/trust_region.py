@@ -263,7 +263,7 @@ class CPOOracle(_TrustRegionBase):
                 for _ in range(self.tcfg.optim_critic_iters):
                     sc = self.critics_step(mb)
                 sa, hg, hb = self.policy_step(mb, ave_cost_return)
-                rows.append((sa, sc, hg))
+                rows.append((sa, sc, hg, hb))
         return pb, rows
 
 

@@ -32,7 +32,10 @@ def flat(mods):
 
 def gen(name, obs_dim, act_dim, hidden, env_num, ep_lens, batch_size, n_updates, seed, n_step=2,
         cost_stat=25.0, cost_limit=10.0, auto_alpha=True, alpha=0.005, tau=0.05, actor_lr=5e-4,
-        critic_lr=1e-3, alpha_lr=3e-4, gamma=0.99, buffer_size=None):
+        critic_lr=1e-3, alpha_lr=3e-4, gamma=0.99, buffer_size=None, full=False):
+    """full: a BASELINE-size case -- the rollout (tests/helpers.synth_rollout) and the initial parameters (synth_theta) are
+    regenerated from seeds by the tests, the fixture keeps their checksums, the sampled indices, both noise blocks of every
+    update, the logged rows and the parameters after the updates (the target critics as every 8th element)."""
     seed_all(seed)
     actor = ActorProb(Net((obs_dim, ), hidden_sizes=hidden), (act_dim, ), max_action=1.0,
                       conditioned_sigma=True, unbounded=True)
@@ -54,6 +57,22 @@ def gen(name, obs_dim, act_dim, hidden, env_num, ep_lens, batch_size, n_updates,
         for p in ac.parameters():
             if p.ndim == 1:
                 p.add_(0.05 * torch.randn(p.shape, generator=g))
+    out = {}
+    if full:
+        sys.path.insert(0, os.path.dirname(HERE))
+        from helpers import rollout_checksum, synth_rollout, synth_theta, theta_checksum
+        for key, mods, sd in (("actor", [actor], seed + 500), ("critics", critics, seed + 501)):
+            shapes = [tuple(p.shape) for m in mods for p in m.parameters()]
+            th = synth_theta(sd, shapes)
+            o = 0
+            with torch.no_grad():
+                for m in mods:
+                    for p in m.parameters():
+                        p.copy_(torch.from_numpy(th[o:o + p.numel()]).reshape(p.shape)); o += p.numel()
+            assert o == th.size
+            out[f"theta_{key}_seed"] = np.array(sd)
+            out[f"theta_{key}_shapes_json"] = np.array(json.dumps([list(s_) for s_ in shapes]))
+            out[f"theta_{key}0_checksum"] = theta_checksum(th)
     alpha_arg = alpha
     if auto_alpha:
         target_entropy = -float(act_dim)
@@ -67,17 +86,28 @@ def gen(name, obs_dim, act_dim, hidden, env_num, ep_lens, batch_size, n_updates,
                            action_space=_Box(-1, 1, (act_dim, )))
     policy.train()
     rng = np.random.default_rng(seed + 1000)
-    buf = fill_buffer(rng, env_num, ep_lens, obs_dim, act_dim, buffer_size=buffer_size or 100000)
+    if full:
+        from ref_shim import VectorReplayBuffer
+        steps = synth_rollout(seed + 1000, env_num, [list(ep_lens)] * env_num, obs_dim, act_dim)
+        buf = VectorReplayBuffer(buffer_size or 100000, env_num)
+        for ids, obs, act, rew, cost, term, trunc, nxt in steps:
+            buf.add({"obs": obs, "act": act, "rew": rew, "terminated": term, "truncated": trunc, "done": term | trunc,
+                     "obs_next": nxt, "info.cost": cost}, ids)
+        out.update(rollout_seed=np.array(seed + 1000), rollout_checksum=rollout_checksum(steps), ep_lens=np.array(ep_lens),
+                   env_num=np.array(env_num))
+    else:
+        buf = fill_buffer(rng, env_num, ep_lens, obs_dim, act_dim, buffer_size=buffer_size or 100000)
     # stored actions of a tanh policy live in (-1, 1)
     buf._meta["act"][:] = np.tanh(buf._meta["act"])
-    out = {"theta_actor0": flat([actor]), "theta_critics0": flat(critics)}
     meta = buf._meta
     used = np.concatenate([np.arange(o, o + len(b)) for o, b in zip(buf._offset, buf.buffers)])
-    out["slots"] = used
-    for k in ("obs", "act", "rew", "terminated", "truncated", "obs_next"):
-        out["st_" + k] = meta[k][used]
-    out["st_cost"] = meta["info.cost"][used]
-    out["env_rows"] = np.array([len(b) for b in buf.buffers])
+    if not full:
+        out.update(theta_actor0=flat([actor]), theta_critics0=flat(critics))
+        out["slots"] = used
+        for k in ("obs", "act", "rew", "terminated", "truncated", "obs_next"):
+            out["st_" + k] = meta[k][used]
+        out["st_cost"] = meta["info.cost"][used]
+        out["env_rows"] = np.array([len(b) for b in buf.buffers])
     out["sub_size"] = np.array(buf.buffers[0].maxsize)
     policy.pre_update_fn(stats_train={"cost": cost_stat})
     out["lagrangian"] = np.array([o.get_lag() for o in policy.lag_optims], np.float64)
@@ -118,6 +148,8 @@ def gen(name, obs_dim, act_dim, hidden, env_num, ep_lens, batch_size, n_updates,
     out["theta_actor_final"] = flat([actor])
     out["theta_critics_final"] = flat(critics)
     out["theta_critics_old_final"] = flat(list(policy.critics_old))
+    if full:
+        out["theta_critics_old_final"] = out["theta_critics_old_final"][::8].copy()
     out["alpha_final"] = np.array(float(policy._alpha))
     cfg = dict(obs_dim=obs_dim, act_dim=act_dim, hidden=list(hidden), env_num=env_num, batch_size=batch_size,
                n_updates=n_updates, seed=seed, n_step=n_step, cost_stat=cost_stat, cost_limit=cost_limit,
@@ -133,6 +165,11 @@ def gen(name, obs_dim, act_dim, hidden, env_num, ep_lens, batch_size, n_updates,
 if __name__ == "__main__":
     torch.set_num_threads(4)
     eps = [[60, 50, -17], [70, 55], [40, 40, 40, -9]]
+    if sys.argv[1:] == ["full"]:
+        # BASELINE configs[3]'s shape (SafetyAntRun: obs 33, act 8; 256x256; batch 1024; n_step 2, sacl_cfg.py:21) over a
+        # 97 000-row store (10 envs x nine 1000-step episodes + an unfinished tail of 700)
+        gen("c4full", 33, 8, (256, 256), 10, [1000] * 9 + [-700], batch_size=1024, n_updates=3, seed=62, n_step=2, full=True)
+        sys.exit(0)
     if sys.argv[1:] == ["widths"]:
         # two hidden layers of different widths that are not 64 / 128 / 256 (zero-padded on the device)
         gen("widths", 6, 3, (80, 48), 3, eps, batch_size=64, n_updates=5, seed=35, n_step=2)

@@ -181,6 +181,85 @@ def gen_cpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cost
               f"steps={np.round(out['stats_actor'][:, isz], 4)}")
 
 
+def set_flat(module, theta):
+    """module.parameters() <- the flat vector, in order"""
+    o = 0
+    with torch.no_grad():
+        for p in module.parameters():
+            n = p.numel()
+            p.copy_(torch.from_numpy(theta[o:o + n]).reshape(p.shape))
+            o += n
+    assert o == theta.size
+
+
+def gen_cpo_full(name="c3full", obs_dim=60, act_dim=2, hidden=(256, 256), env_num=20, ep_lens=(1000, ), seed=61,
+                 cost_stat=25.0, cost_limit=10.0, lr=1e-3, optim_critic_iters=10, max_backtracks=10):
+    """BASELINE configs[2] at full size: CPO (cpo.py:234-351) on obs 60 / act 2 / 256x256, N = 20 000 rows as ONE full batch
+    (cpo_cfg.py:84-90), CG 10, 10 critic steps, ONE repeat of the UNMODIFIED CPO.update.  Neither the rollout nor theta0 is
+    stored (tests/helpers.synth_rollout / synth_theta regenerate them; checksums here).  Kept: process_fn's advs / logp_old /
+    mean_old, the permutation Batch.split drew, both logger rows, H^-1 g and H^-1 b, theta after the update."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import rollout_checksum, synth_rollout, synth_theta, theta_checksum
+    from ref_shim import VectorReplayBuffer
+    actor, critic, ac = build_nets(obs_dim, act_dim, hidden, seed)
+    shapes = [tuple(p.shape) for p in ac.parameters()]
+    theta0 = synth_theta(seed + 500, shapes)
+    set_flat(ac, theta0)
+    optim = torch.optim.Adam(nn.ModuleList(critic).parameters(), lr=lr)
+    logger = CaptureLogger()
+    kw = dict(optim_critic_iters=optim_critic_iters, max_backtracks=max_backtracks)
+    policy = CPO(actor, critic, optim, dist, logger=logger, cost_limit=cost_limit,
+                 observation_space=_Box(-np.inf, np.inf, (obs_dim, )), action_space=_Box(-1, 1, (act_dim, )), **kw)
+    policy.train()
+    steps = synth_rollout(seed + 1000, env_num, [list(ep_lens)] * env_num, obs_dim, act_dim)
+    buf = VectorReplayBuffer(100000, env_num)
+    for ids, obs, act, rew, cost, term, trunc, nxt in steps:
+        buf.add({"obs": obs, "act": act, "rew": rew, "terminated": term, "truncated": trunc, "done": term | trunc,
+                 "obs_next": nxt, "info.cost": cost}, ids)
+    out = {"rollout_seed": np.array(seed + 1000), "rollout_checksum": rollout_checksum(steps), "ep_lens": np.array(ep_lens),
+           "env_num": np.array(env_num), "sub_size": np.array(buf.buffers[0].maxsize), "theta_seed": np.array(seed + 500),
+           "theta_shapes_json": np.array(json.dumps([list(s) for s in shapes])), "theta0_checksum": theta_checksum(theta0)}
+    policy.pre_update_fn(stats_train={"cost": cost_stat})
+    cap = {"cg": []}
+    orig_cg = policy._conjugate_gradients
+
+    def cg(g, fkg, *a, **k):
+        x = orig_cg(g, fkg, *a, **k)
+        cap["cg"].append(x.detach().numpy().copy())
+        return x
+    policy._conjugate_gradients = cg
+    batch, indices = buf.sample(0)
+    import copy
+    rms_keep = copy.deepcopy(policy.ret_rms)
+    pbatch = policy.process_fn(batch, buf, indices)
+    policy.ret_rms = rms_keep
+    out["advs_norm"] = pbatch.advs.numpy().copy()
+    out["logp_old"] = pbatch.logp_old.numpy().copy()
+    out["mean_old"] = pbatch.mean_old.numpy().copy()
+    with PermRecorder() as pr:
+        seed_all(seed + 7)
+        policy.update(0, buf, batch_size=99999, repeat=1)
+    assert len(pr.perms) == 1 and pr.perms[0].max() < 65536
+    out["perms"] = np.stack(pr.perms).astype(np.uint16)
+    rows = [r for r in logger.rows if "update/gradient_steps" not in r]
+    assert len(rows) == 2 and len(cap["cg"]) == 2
+    keys_a, keys_c = list(rows[0].keys()), list(rows[1].keys())
+    out["stats_actor_keys"], out["stats_critic_keys"] = np.array(keys_a), np.array(keys_c)
+    out["stats_actor"] = np.array([[rows[0][k] for k in keys_a]])
+    out["stats_critic"] = np.array([[rows[1][k] for k in keys_c]])
+    out["H_inv_g_first"], out["H_inv_b_first"] = cap["cg"][0], cap["cg"][1]
+    out["theta_final"] = flat_params(ac)
+    cfg = dict(obs_dim=obs_dim, act_dim=act_dim, hidden=list(hidden), env_num=env_num, repeat=1, seed=seed, cost_stat=cost_stat,
+               cost_limit=cost_limit, lr=lr, max_action=1.0, perturb_actor=0.0, target_kl=0.01, backtrack_coeff=0.8,
+               damping_coeff=0.1, l2_reg=0.001, gae_lambda=0.95, advantage_normalization=True, gamma=0.99, **kw)
+    out["cfg_json"] = np.array(json.dumps(cfg))
+    f = os.path.join(HERE, f"cpo_{name}.npz")
+    np.savez_compressed(f, **out)
+    ic, isz = keys_a.index("loss/optim_case"), keys_a.index("loss/step_size")
+    print(f"G5 cpo_{name}.npz N={len(indices)} case={out['stats_actor'][0, ic]} step={out['stats_actor'][0, isz]:.4f} "
+          f"size={os.path.getsize(f) / 1e6:.2f} MB")
+
+
 def gen_trpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cost_stat, cost_limit,
              lr=5e-4, unbounded=False, ret_rms0=None, batch_size=99999, **kw):
     actor, critic, ac = build_nets(obs_dim, act_dim, hidden, seed, unbounded)
@@ -245,6 +324,9 @@ def gen_trpo(name, obs_dim, act_dim, hidden, env_num, ep_lens, repeat, seed, cos
 if __name__ == "__main__":
     torch.set_num_threads(4)
     eps = [[100, 100], [100, -60], [120, 80]]
+    if sys.argv[1:] == ["full"]:
+        gen_cpo_full()
+        sys.exit(0)
     if sys.argv[1:] == ["case4"]:
         # the vanishing-cost-gradient branch: zero cost signal, no advantage normalisation (0 / 0 otherwise), c < 0
         gen_cpo("case4", 8, 2, (64, 64), 3, eps, repeat=2, seed=16, cost_stat=0.0, cost_limit=10.0,

@@ -113,3 +113,73 @@ def ppo_full_case(name):
     steps = synth_rollout(int(g["rollout_seed"]), env_num, [list(g["ep_lens"])] * env_num, cfg["obs_dim"], cfg["act_dim"])
     assert np.array_equal(rollout_checksum(steps), g["rollout_checksum"]), "numpy's generators no longer reproduce the fixture's rollout"
     return cfg, g, steps
+
+
+def synth_theta(seed, shapes, bias_scale=0.05):
+    """A seeded parameter vector for the full-size fixtures (NOT stored in them: regenerated here, checksum in the fixture):
+    `shapes` = the shapes of a module's parameters() in order; matrices ~ N(0, 1 / fan_in), vectors ~ bias_scale * N(0, 1);
+    a (Da, 1) tensor is the on-policy actor's sigma_param (= -0.5, ppo_lag_agent.py:147)."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for sh in shapes:
+        sh = tuple(int(x) for x in sh)
+        if len(sh) == 2 and sh[1] == 1 and sh[0] <= 16:
+            parts.append(np.full(sh[0], -0.5, np.float32))
+        elif len(sh) == 2:
+            parts.append((rng.standard_normal(sh) / np.sqrt(sh[1])).astype(np.float32).reshape(-1))
+        else:
+            parts.append((bias_scale * rng.standard_normal(sh)).astype(np.float32).reshape(-1))
+    return np.concatenate(parts)
+
+
+def theta_checksum(theta):
+    th = np.asarray(theta, np.float64)
+    return np.array([th.sum(), np.abs(th).sum(), (th * np.arange(1, th.size + 1)).sum()])
+
+
+def full_rollout_arrays(g, obs_dim, act_dim):
+    """the regenerated rollout of a full-size fixture as the arrays the small fixtures store: env-major rows (sample(0) order)
+    under the small fixtures' keys (buf_* and st_*), env_rows, slots, indices, unfinished_index"""
+    env_num = int(g["env_num"])
+    ep_lens = [int(x) for x in g["ep_lens"]]
+    steps = synth_rollout(int(g["rollout_seed"]), env_num, [ep_lens] * env_num, obs_dim, act_dim)
+    assert np.array_equal(rollout_checksum(steps), g["rollout_checksum"]), "numpy's generators no longer reproduce the fixture's rollout"
+    em = rollout_env_major(steps, env_num)
+    rows = sum(abs(x) for x in ep_lens)
+    sub = int(g["sub_size"])
+    slots = np.concatenate([e * sub + np.arange(rows) for e in range(env_num)])
+    out = {"env_rows": np.full(env_num, rows), "slots": slots, "indices": slots.copy(),
+           "unfinished_index": np.array([e * sub + rows - 1 for e in range(env_num) if ep_lens[-1] < 0], np.int64)}
+    for k in ("obs", "act", "rew", "cost", "terminated", "truncated", "obs_next"):
+        out["buf_" + k] = out["st_" + k] = em[k]
+    return out, steps
+
+
+def trust_full_case(name):
+    """tests/golden/cpo_c3full.npz: BASELINE configs[2] (obs 60, act 2, 256x256, N = 20 000 full batch) through one repeat of the
+    unmodified CPO.update; rollout and theta0 regenerated from seeds.  -> the dict the small-fixture tests take"""
+    g = load_npz(f"cpo_{name}.npz")
+    cfg = json.loads(str(g["cfg_json"]))
+    arr, _ = full_rollout_arrays(g, cfg["obs_dim"], cfg["act_dim"])
+    g.update(arr)
+    shapes = [tuple(s) for s in json.loads(str(g["theta_shapes_json"]))]
+    g["theta0"] = synth_theta(int(g["theta_seed"]), shapes)
+    assert np.array_equal(theta_checksum(g["theta0"]), g["theta0_checksum"])
+    g["perms"] = g["perms"].astype(np.int64)
+    return g
+
+
+def sac_full_case(name):
+    """tests/golden/sac_c4full.npz: BASELINE configs[3]'s shape (obs 33, act 8, 256x256, batch 1024, n_step 2) over a 97 000-row
+    store regenerated from a seed; parameters regenerated from seeds; the tanh of the rollout's raw actions is what is stored"""
+    g = load_npz(f"sac_{name}.npz")
+    cfg = json.loads(str(g["cfg_json"]))
+    arr, _ = full_rollout_arrays(g, cfg["obs_dim"], cfg["act_dim"])
+    arr["st_act"] = arr["buf_act"] = np.tanh(arr["st_act"])
+    del arr["indices"]                                   # the fixture's own `indices` are the recorded buffer.sample draws
+    g.update(arr)
+    for key in ("actor", "critics"):
+        shapes = [tuple(s) for s in json.loads(str(g[f"theta_{key}_shapes_json"]))]
+        g[f"theta_{key}0"] = synth_theta(int(g[f"theta_{key}_seed"]), shapes)
+        assert np.array_equal(theta_checksum(g[f"theta_{key}0"]), g[f"theta_{key}0_checksum"])
+    return g

@@ -16,7 +16,7 @@ import pytest
 import torch
 
 from helpers import end_flag_of, load_npz
-from test_oracle_trust import _data, cpo_cfg, trpo_cfg
+from test_oracle_trust import _data, cpo_case, cpo_cfg, trpo_cfg
 
 pytestmark = pytest.mark.gpu
 
@@ -112,7 +112,7 @@ def _cpo_f64_yardstick(name):
         from oracle.ppo_lag import OnPolicyData
         from oracle.trust_region import CPOOracle
         torch.set_num_threads(4)
-        g = load_npz(f"cpo_{name}.npz")
+        g = cpo_case(name)
         cfg = json.loads(str(g["cfg_json"]))
         o = CPOOracle(cpo_cfg(cfg), dtype=torch.float64)
         o.set_params(g["theta0"])
@@ -127,9 +127,10 @@ def _cpo_f64_yardstick(name):
     return _YARD[name]
 
 
-@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options", "widths", "wideobs", "deep3", "wide1"])
+# c3full: BASELINE configs[2] at full size from the unmodified reference (obs 60, 256x256, N = 20 000, one repeat; r5)
+@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options", "widths", "wideobs", "deep3", "wide1", "c3full"])
 def test_cpo_learn_vs_golden(name):
-    g = load_npz(f"cpo_{name}.npz")
+    g = cpo_case(name)
     cfg = json.loads(str(g["cfg_json"]))
     eng = _engine(cfg); _start(eng, g); _push(eng, g)
     eng.tr_begin(target_kl=cfg["target_kl"], backtrack_coeff=cfg["backtrack_coeff"],

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import end_flag_of, load_npz
+from helpers import end_flag_of, load_npz, trust_full_case
 from oracle.ppo_lag import OnPolicyData
 from oracle.trust_region import CPOConfig, CPOOracle, TRPOConfig, TRPOLagOracle
 
@@ -36,10 +36,15 @@ def trpo_cfg(cfg):
                       reward_normalization=bool(cfg.get("reward_normalization", False)))
 
 
-@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options", "minibatch", "widths", "wideobs", "deep3", "wide1"])
+def cpo_case(name):
+    """c3full: BASELINE configs[2] at full size (rollout and theta0 regenerated from seeds, helpers.trust_full_case)"""
+    return trust_full_case(name) if name.endswith("full") else load_npz(f"cpo_{name}.npz")
+
+
+@pytest.mark.parametrize("name", ["infeasible", "feasible", "edge", "case1", "case2", "case4", "options", "minibatch", "widths", "wideobs", "deep3", "wide1", "c3full"])
 def test_cpo_update(name):
     torch.set_num_threads(4)
-    g = load_npz(f"cpo_{name}.npz")
+    g = cpo_case(name)
     cfg = json.loads(str(g["cfg_json"]))
     o = CPOOracle(cpo_cfg(cfg))
     o.set_params(g["theta0"])
@@ -57,6 +62,8 @@ def test_cpo_update(name):
     np.testing.assert_allclose(got_a, g["stats_actor"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(got_c, g["stats_critic"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(rows[0][2].numpy(), g["H_inv_g_first"], rtol=1e-4, atol=1e-6)
+    if "H_inv_b_first" in g:
+        np.testing.assert_allclose(rows[0][3].numpy(), g["H_inv_b_first"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(o.get_params(), g["theta_final"], rtol=0, atol=2e-6)
 
 
