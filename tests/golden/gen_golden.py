@@ -388,7 +388,8 @@ def gen_ppo_depths():
                  recompute_advantage=True, dual_clip=3.0, eps_clip=0.05, lr=2e-3)
 
 
-def gen_ppo_full_case(name, env_num, ep_lens, seed=2, hidden=(256, 256), batch_size=256, repeat=4, theta0_from=None):
+def gen_ppo_full_case(name, env_num, ep_lens, seed=2, hidden=(256, 256), batch_size=256, repeat=4, theta0_from=None,
+                      target_kl=1e9, lr=5e-4, keep_pass1=True):
     """BASELINE-size fixtures (configs[1]: 20 envs x 1000 rows; configs[4] per rank: 32 envs x 625 rows), 256x256, grad clip
     0.5 (ppol_cfg.py:21), repeat 4 = 312 steps of the UNMODIFIED PPOLagrangian.update.  20 000 rows of random floats do not
     compress, so the rollout is NOT stored: tests/helpers.synth_rollout(seed) regenerates it (checksum stored), and the file
@@ -398,7 +399,7 @@ def gen_ppo_full_case(name, env_num, ep_lens, seed=2, hidden=(256, 256), batch_s
     from helpers import rollout_checksum, synth_rollout
     obs_dim, act_dim = 8, 2
     logger = CaptureLogger()
-    kw = dict(max_grad_norm=0.5, target_kl=1e9)
+    kw = dict(max_grad_norm=0.5, target_kl=target_kl, lr=lr)
     policy, actor_critic, optim = build_ppo(obs_dim, act_dim, hidden, seed, logger=logger, cost_limit=10.0, **kw)
     policy.train()
     steps = synth_rollout(seed + 1000, env_num, ep_lens, obs_dim, act_dim)
@@ -444,10 +445,13 @@ def gen_ppo_full_case(name, env_num, ep_lens, seed=2, hidden=(256, 256), batch_s
         policy.update(0, buf, batch_size=batch_size, repeat=repeat)
     finally:
         np.random.permutation = orig_perm
-    assert len(perms) == repeat and max(p.max() for p in perms) < 65536
+    assert len(perms) <= repeat and (len(perms) == repeat or target_kl < 1e8) and max(p.max() for p in perms) < 65536
     out["perms"] = np.stack(perms).astype(np.uint16)
     out["theta_final"] = flat_params(actor_critic)
-    out.update(snaps)
+    if keep_pass1:
+        out.update(snaps)
+    out["passes_run"] = np.array(len(perms))           # < repeat: the KL early stop fired (ppo_lag.py:251-255)
+    out["early_stop_msgs"] = np.array(len(logger.msgs))
     rows = [r for r in logger.rows if "update/gradient_steps" not in r]
     keys = ["loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss/actor_rew", "loss/actor_total", "loss/kl",
             "loss/vf0", "loss/vf1", "loss/vf_total", "loss/total", "loss/entropy"]
@@ -458,14 +462,17 @@ def gen_ppo_full_case(name, env_num, ep_lens, seed=2, hidden=(256, 256), batch_s
             merged.update(r)
         stats.append([merged[k] for k in keys])
     out["stats"] = np.array(stats, np.float64)
-    assert out["stats"].shape == (n_per_pass * repeat, 11) and "theta_pass1" in out
+    assert out["stats"].shape == (n_per_pass * len(perms), 11) and ("theta_pass1" in out or not keep_pass1)
     cfg = dict(obs_dim=obs_dim, act_dim=act_dim, hidden=list(hidden), env_num=env_num, batch_size=batch_size, repeat=repeat,
-               seed=seed, cost_stat=25.0, cost_limit=10.0, max_action=1.0, target_kl=1e9, vf_coef=0.25, max_grad_norm=0.5,
-               gae_lambda=0.95, eps_clip=0.2, dual_clip=None, gamma=0.99, lr=5e-4, advantage_normalization=True,
+               seed=seed, cost_stat=25.0, cost_limit=10.0, max_action=1.0, target_kl=target_kl, vf_coef=0.25, max_grad_norm=0.5,
+               gae_lambda=0.95, eps_clip=0.2, dual_clip=None, gamma=0.99, lr=lr, advantage_normalization=True,
                lagrangian_pid=(0.05, 0.0005, 0.1), rescaling=True, use_lagrangian=True)
     out["cfg_json"] = np.array(json.dumps(cfg))
     np.savez_compressed(os.path.join(HERE, f"ppo_{name}.npz"), **out)
     print(f"G4 ppo_{name}.npz  N={len(indices)} steps={len(stats)} size={os.path.getsize(os.path.join(HERE, f'ppo_{name}.npz')) / 1e6:.2f} MB")
+
+
+LR_KLSTOP = float(os.environ.get("LR_KLSTOP", "1.5e-4"))
 
 
 def gen_ppo_full():
@@ -473,6 +480,13 @@ def gen_ppo_full():
     gen_ppo_full_case("c2full", 20, [[250, 250, 250, 250]] * 20)
     # configs[4], one rank: 32 envs x 625 rows (two episodes of 250 and an unfinished tail of 125 each), same theta0
     gen_ppo_full_case("c5rank", 32, [[250, 250, -125]] * 32, theta0_from="ppo_c2full.npz")
+
+
+def gen_ppo_full_klstop():
+    # configs[1] with the reference's default target_kl = 0.02 (ppo_lag_agent.py:95) and a learning rate at which the pass-mean
+    # KL crosses 1.5 x target_kl: the early stop (ppo_lag.py:251-255) fires at full size
+    gen_ppo_full_case("c2full_klstop", 20, [[250, 250, 250, 250]] * 20, theta0_from="ppo_c2full.npz", target_kl=0.02, lr=LR_KLSTOP,
+                      keep_pass1=False)
 
 
 def gen_manifest():
@@ -489,4 +503,4 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["gae", "nstep", "pid", "ppo", "manifest"]
     for w in which:
         {"gae": gen_gae, "nstep": gen_nstep, "pid": gen_pid, "ppo": gen_ppo, "recompute": gen_ppo_recompute, "options": gen_ppo_options,
-         "widths": gen_ppo_widths, "depths": gen_ppo_depths, "full": gen_ppo_full, "manifest": gen_manifest}[w]()
+         "widths": gen_ppo_widths, "depths": gen_ppo_depths, "full": gen_ppo_full, "full_klstop": gen_ppo_full_klstop, "manifest": gen_manifest}[w]()

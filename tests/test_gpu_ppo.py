@@ -319,13 +319,18 @@ def test_full_size_update_vs_oracle(repeat):
     eng.close()
 
 
+# observed on MI355X (deterministic kernels; three boxes, profiles/r05_fullsize_bars.txt) -> asserted at 3x
+FULL_BARS = {"c2full": dict(tight_steps=10, pass1_stat=1.6e-2, theta_max=8.4e-3, theta_mean=6.8e-5),       # 5.32e-3 / 2.80e-3 / 2.24e-5
+             "c5rank": dict(tight_steps=10, pass1_stat=4.3e-5, theta_max=1.1e-6, theta_mean=1.6e-8)}       # 1.42e-5 / 3.35e-7 / 5.33e-9
+
+
 @pytest.mark.parametrize("name", ["c2full", "c5rank"])
 def test_full_size_update_vs_reference(name):
     """The headline workload pinned to the reference ITSELF (not only to the oracle): BASELINE configs[1] (20 envs x 1000 rows)
     and one rank of configs[4] (32 envs x 625 rows, unfinished tails), obs 8 / act 2 / 256x256 / batch 256 / 4 passes / grad
     clip 0.5 (ppol_cfg.py:21), recorded from the unmodified PPOLagrangian.update (ppo_lag.py:214-257) by
-    tests/golden/gen_golden.py full.  process_fn at 5e-6 of scale; the first 10 optimiser steps at the fixture tolerance
-    (2e-5); the whole FIRST pass and theta after it at the tolerances below; passes 2-4 under the float64-yardstick rule of
+    tests/golden/gen_golden.py full.  process_fn at 5e-6 of scale; the leading optimiser steps at the fixture tolerance
+    (2e-5; FULL_BARS: how many); the whole FIRST pass and theta after it at 3x the device's measured distance; passes 2-4 under the float64-yardstick rule of
     test_full_size_update_vs_oracle (the device may sit at most 3x as far from the float64 run as the reference does)."""
     from oracle.ppo_lag import OnPolicyData, PPOLagConfig, PPOLagOracle
     cfg, g, steps = ppo_full_case(name)
@@ -348,13 +353,20 @@ def test_full_size_update_vs_reference(name):
     ref = g["stats"]
     scale = np.maximum(np.abs(ref).max(0), 1e-2)
     s1, th1 = outs[1]
-    early = np.abs(s1[:10] - ref[:10]).max(0)
-    assert (early <= 2e-5 * scale + 2e-5).all(), f"first 10 steps: {early}"
+    # r5: the bars are 3x what the device does (the kernels are deterministic: every box measured the same figures,
+    # profiles/r05_fullsize_bars.txt), not round 2's envelopes (2e-2 of scale, theta 5e-2 max / 2e-4 mean).  PPO's objective is
+    # discontinuous in theta (ratio clip, ReLU kinks, grad-norm clip): c2full's fp32 trajectories separate inside pass 1,
+    # c5rank's stay together through all 78 steps.
+    tight = (np.abs(s1 - ref[:78]) <= 2e-5 * scale + 2e-5).all(1)
+    n_tight = int(np.argmin(tight)) if not tight.all() else 78
     p1 = (np.abs(s1 - ref[:78]) / scale).max(0)
     d1 = np.abs(th1 - g["theta_pass1"])
-    print(f"{name}: pass 1 worst statistic / scale {p1.max():.3g}; theta after pass 1 max {d1.max():.3g} mean {d1.mean():.3g}")
-    assert (p1 <= 2e-2).all(), p1                      # the one-pass envelope of test_full_size_update_vs_oracle
-    assert d1.max() <= 5e-2 and d1.mean() <= 2e-4, (d1.max(), d1.mean())
+    print(f"{name}: steps inside 2e-5 from the start: {n_tight}; pass 1 worst statistic / scale {p1.max():.3g}; "
+          f"theta after pass 1 max {d1.max():.3g} mean {d1.mean():.3g}")
+    bars = FULL_BARS[name]
+    assert n_tight >= bars["tight_steps"], (n_tight, np.abs(s1 - ref[:78]).max(1)[:bars["tight_steps"] + 2])
+    assert (p1 <= bars["pass1_stat"]).all(), p1
+    assert d1.max() <= bars["theta_max"] and d1.mean() <= bars["theta_mean"], (d1.max(), d1.mean())
     assert np.array_equal(outs[4][0][:78], s1)         # the first pass of the 4-pass update is the 1-pass update
     # passes 2-4: the float64 run of the same algorithm is the yardstick for both fp32 trajectories
     torch.set_num_threads(4)
@@ -495,4 +507,32 @@ def test_launch_floors_are_measured_and_plausible():
     f = eng.launch_floors(256, 200)
     assert all(0.5 < f[k] < 30.0 for k in ("fwdbwd", "wgrad", "adam")), f
     assert f["triple"] <= 1.5 * (f["fwdbwd"] + f["wgrad"] + f["adam"]) + 2.0, f
+    eng.close()
+
+
+def test_full_size_kl_early_stop_vs_reference():
+    """BASELINE configs[1] with the KL early stop ON at full size (target_kl 0.02 = the reference default, ppo_lag_agent.py:95; lr
+    1.5e-4): the unmodified reference runs 2 of its 4 passes (pass-mean KL 0.0262, then 0.0366 > 1.5 x 0.02; ppo_lag.py:251-255).
+    The device must stop after the same pass (its one 24-byte read-back per pass decides), log the same 156 rows and land on
+    the same parameters: statistics at 3x the one-pass figures of c2full, the pass-mean KL that decides at 1e-3 relative."""
+    cfg, g, steps = ppo_full_case("c2full_klstop")
+    assert int(g["passes_run"]) == 2
+    eng = _engine(cfg)
+    eng.set_params(g["theta0"])
+    for ids, obs, act, rew, cost, term, trunc, nxt in steps:
+        eng.push(ids, obs, act, rew, cost, term, trunc, nxt)
+    lag = g["lagrangian"]
+    perms = np.concatenate([g["perms"], np.tile(np.arange(20000), (2, 1))])      # passes 3, 4 must never run
+    stats, stopped = eng.ppo_update(lag, _rescale(lag), 256, 4, perms=perms)
+    ref = g["stats"]
+    assert stopped == 1 and stats.shape == ref.shape == (156, 11), (stopped, stats.shape)
+    scale = np.maximum(np.abs(ref).max(0), 1e-2)
+    early = np.abs(stats[:10] - ref[:10]).max(0)
+    assert (early <= 2e-5 * scale + 2e-5).all(), f"first 10 steps: {early}"
+    kl = stats[:, 5].reshape(2, 78).mean(1); kl_ref = ref[:, 5].reshape(2, 78).mean(1)
+    print("klstop: pass-mean KL device", kl, "reference", kl_ref, "worst statistic / scale", (np.abs(stats - ref) / scale).max())
+    np.testing.assert_allclose(kl, kl_ref, rtol=1e-3)
+    assert ((np.abs(stats - ref) / scale).max(0) <= 1.6e-2).all(), (np.abs(stats - ref) / scale).max(0)
+    d = np.abs(eng.get_params() - g["theta_final"])
+    assert d.max() <= 8.4e-3 and d.mean() <= 6.8e-5, (d.max(), d.mean())
     eng.close()

@@ -95,3 +95,21 @@ def test_full_size_update_vs_reference(name):
     assert stats.shape == g["stats"].shape == (312, 11)
     np.testing.assert_allclose(stats, g["stats"], rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(o.get_params(), g["theta_final"], rtol=0, atol=2e-6)
+
+
+def test_full_size_kl_early_stop_vs_reference():
+    """BASELINE configs[1] with the KL early stop ON at full size (target_kl 0.02 = the reference default, ppo_lag_agent.py:95; lr
+    1.5e-4): the pass-mean KL stays below 1.5 x target_kl in pass 1 (0.0262) and crosses it in pass 2 (0.0366), so the
+    unmodified reference runs 2 of its 4 passes (ppo_lag.py:251-255).  Fixture: tests/golden/gen_golden.py full_klstop."""
+    from oracle.ppo_lag import OnPolicyData, PPOLagConfig
+    torch.set_num_threads(4)
+    cfg, g, steps = ppo_full_case("c2full_klstop")
+    assert int(g["passes_run"]) == 2 and int(g["early_stop_msgs"]) == 1 and cfg["target_kl"] == 0.02
+    o = PPOLagOracle(PPOLagConfig(obs_dim=8, act_dim=2, hidden=(256, 256), max_grad_norm=0.5, target_kl=cfg["target_kl"], lr=cfg["lr"]))
+    o.set_params(g["theta0"])
+    lag = g["lagrangian"]
+    perms = list(g["perms"]) + [np.arange(20000)] * 2                  # passes 3, 4 must never be drawn on
+    _, stats, stopped = o.update(OnPolicyData(**rollout_env_major(steps, cfg["env_num"])), lag, rescaling_factor(lag), 256, 4, perms=perms)
+    assert stopped == 1 and stats.shape == g["stats"].shape == (156, 11)
+    np.testing.assert_allclose(stats, g["stats"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(o.get_params(), g["theta_final"], rtol=0, atol=2e-6)
