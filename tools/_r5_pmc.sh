@@ -2,9 +2,9 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 cd /tmp; export TMPDIR=/tmp
-rocprofv3-avail list > $R/gpurun_out/counters_full.txt 2>&1
 for SET in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU" "SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_ACTIVE_INST_MISC"; do
   T=$(echo $SET | tr ' ' '_' | cut -c1-40)
-  timeout 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $R/gpurun_out/pmc2_$T -- python $R/tools/ab_trust_co.py --rounds 1 --only cpo > /dev/null 2>$R/gpurun_out/pmc2_$T.err
+  timeout 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d /tmp/pmc2/$T -- python $R/tools/ab_trust_co.py --rounds 1 --only cpo > /dev/null 2>/tmp/pmc2_$T.err
 done
-ls $R/gpurun_out | grep pmc2
+python $R/tools/pmc_summary.py $R/gpurun_out/pmc2_summary.json /tmp/pmc2/*
+tail -2 /tmp/pmc2_*.err | tail -20
