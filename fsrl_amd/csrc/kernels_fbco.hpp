@@ -19,6 +19,26 @@
 #pragma once
 #include "kernels_fb.hpp"
 
+// Persistent scheduling of the co-resident kernels: the grid is 2 x (number of CUs) workgroups that stay resident and DRAW their
+// tiles from a device counter (32-row tiles first, 16-row tiles behind them), so that every CU keeps a pair of tiles in flight
+// until the batch runs out.  With one workgroup per tile (static grid) 625 tile units on 256 CUs end in a round that fills
+// 44 % of the chip -- and a workgroup that is alone on its CU has nobody to overlap with: r5's PMC passes show the pair at
+// ~75 % MFMA-busy while both are resident and the launch as a whole at 48 %.  The counter is never reset: launches on the
+// stream are ordered, launch s starts at base_s = sum over earlier launches of (tiles + workgroups) -- every workgroup draws
+// once more than it processes -- and unsigned wrap-around is harmless.  Which workgroup computes a tile does not change a bit of it.
+struct CoSched {
+    unsigned* counter;      // nullptr: static grid, blockIdx.x is the tile
+    unsigned base;
+    int total;
+};
+// first tile of this workgroup (static grid: its block index), or -1 / >= total when there is none
+__device__ __forceinline__ int co_first_tile(const CoSched& cs, int* s_next) {
+    if (cs.counter == nullptr) return (int)blockIdx.x;
+    if (threadIdx.x == 0) *s_next = (int)(atomicAdd(cs.counter, 1u) - cs.base);
+    __syncthreads();
+    return *s_next;
+}
+
 template <int H>
 struct HvpCoSmem {
     static constexpr int LD = H + 4;
@@ -273,11 +293,21 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
 // 2 H threads, <= 128 VGPRs (4 waves per SIMD) and 78.8 KB of LDS: two workgroups per CU.
 template <int H>
 __global__ __launch_bounds__(2 * H, 4) void fb_hvp_co_kernel(const float* __restrict__ P, const ModelDesc md, const HvpArgs a,
-                                                            const int n32) {
+                                                            const int n32, const CoSched cs) {
     __shared__ HvpCoSmem<H> sm;
-    const int b = blockIdx.x;
-    if (b < n32) hvp_co_body<H, 2>(sm, P, md, a, 32 * b);
-    else hvp_co_body<H, 1>(sm, P, md, a, 32 * n32 + 16 * (b - n32));
+    __shared__ int s_next;
+    int b = co_first_tile(cs, &s_next);
+    while (b < cs.total) {
+        unsigned nxt = 0u;
+        if (cs.counter != nullptr && threadIdx.x == 0) nxt = atomicAdd(cs.counter, 1u) - cs.base;   // in flight under this tile
+        if (b < n32) hvp_co_body<H, 2>(sm, P, md, a, 32 * b);
+        else hvp_co_body<H, 1>(sm, P, md, a, 32 * n32 + 16 * (b - n32));
+        if (cs.counter == nullptr) break;
+        __syncthreads();                               // the slots and s_next are free
+        if (threadIdx.x == 0) s_next = (int)nxt;
+        __syncthreads();
+        b = s_next;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -556,15 +586,25 @@ __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __r
 // The grid of fb_tile_mixed_kernel: ny * n32 32-row tiles first, ny * n16 16-row tiles behind them.
 template <int H>
 __global__ __launch_bounds__(2 * H, 4) void fb_tile_co_kernel(const float* __restrict__ P, const ModelDesc md, const FbArgs a,
-                                                             const int n32, const int n16, const int ny) {
+                                                             const int n32, const int n16, const int ny, const CoSched cs) {
     __shared__ TileCoSmem<H> sm;
-    int b = blockIdx.x;
-    if (b < ny * n32) {
-        const int y = b / n32, t = b - y * n32;
-        tile_co_body<H, 2>(sm, P, md, a, 32 * t, 2 * t, y, ny);
-    } else {
-        b -= ny * n32;
-        const int y = b / n16, t = b - y * n16;
-        tile_co_body<H, 1>(sm, P, md, a, 32 * n32 + 16 * t, 2 * n32 + t, y, ny);
+    __shared__ int s_next;
+    int b = co_first_tile(cs, &s_next);
+    while (b < cs.total) {
+        unsigned nxt = 0u;
+        if (cs.counter != nullptr && threadIdx.x == 0) nxt = atomicAdd(cs.counter, 1u) - cs.base;
+        if (b < ny * n32) {
+            const int y = b / n32, t = b - y * n32;
+            tile_co_body<H, 2>(sm, P, md, a, 32 * t, 2 * t, y, ny);
+        } else {
+            const int b2 = b - ny * n32;
+            const int y = b2 / n16, t = b2 - y * n16;
+            tile_co_body<H, 1>(sm, P, md, a, 32 * n32 + 16 * t, 2 * n32 + t, y, ny);
+        }
+        if (cs.counter == nullptr) break;
+        __syncthreads();
+        if (threadIdx.x == 0) s_next = (int)nxt;
+        __syncthreads();
+        b = s_next;
     }
 }

@@ -376,8 +376,11 @@ int fsrl_tr_eval(fsrl_ctx* ctx, double* stats8);
  * (tests/test_gpu_fullsize.py states the tolerance).                                                                   */
 int fsrl_tr_set_plan(fsrl_ctx* ctx, int32_t tile_rows, int32_t hvp, int32_t wgrad);
 /* A/B only: force how many 32-row tiles (per network) the co-resident launches of the tile kernel / of the cached Hessian
- * product start with, the remaining rows going to 16-row tiles behind them; -1 = automatic (the dispatch simulation).  The
- * split does not change a result (a row's arithmetic does not depend on its tile's height).                           */
+ * product start with, the remaining rows going to 16-row tiles behind them; -1 = automatic.  The co-resident launches are
+ * PERSISTENT: 2 x (number of CUs) workgroups draw their tiles from a device counter, so every CU keeps a pair of tiles in
+ * flight until the batch runs out; -2 in either argument = automatic tile mix with one workgroup per tile instead (the static
+ * grid, for A/B).  Neither the split nor the scheduling changes a result (a row's arithmetic does not depend on its tile's
+ * height or on the workgroup that computes it).                                                                        */
 int fsrl_tr_set_tile_split(fsrl_ctx* ctx, int32_t n32_tile, int32_t n32_hvp);
 
 /* ---- FOCOPS (fsrl/policy/focops.py:126-251), on the PPO entry points: create the context

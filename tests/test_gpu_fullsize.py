@@ -353,8 +353,9 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
 @pytest.mark.parametrize("obs_dim,T", [(60, 1000), (8, 1000), (33, 163)])
 def test_co_resident_kernels_match_one_workgroup_per_cu(obs_dim, T):
     """Round 5's co-resident tile kernels (two 512-thread workgroups per CU, two time-multiplexed LDS slots; kernels_fbco.hpp)
-    against round 4's one-1024-thread-workgroup-per-CU kernels on the building blocks, BIT FOR BIT, for the automatic tile mix and
-    for forced mixes (all 32-row tiles incl. a ragged last one, all 16-row tiles, one 32-row tile): the three gradients (SUR,
+    against round 4's one-1024-thread-workgroup-per-CU kernels on the building blocks, BIT FOR BIT, for the persistent launches
+    (tiles drawn from a device counter), for the static grid and for forced tile mixes (all whole 32-row tiles, all 16-row
+    tiles, one 32-row tile, different mixes for the two kernels): the three gradients (SUR,
     SUR, KL heads), the line-search statistics (EVAL), the critics' regression step (VF, through one CPO repeat) and the cached
     Hessian-vector product.  N = 20 000 (BASELINE configs[2] / configs[1] shapes) and N = 3 260 (partial tiles, one round)."""
     from fsrl_amd.engine import Engine, EngineConfig
@@ -390,7 +391,8 @@ def test_co_resident_kernels_match_one_workgroup_per_cu(obs_dim, T):
     ref = run(32, 3)
     assert np.array_equal(ref["hvp"], ref["hvp_cached"]) and np.abs(ref["hvp"]).max() > 0 and np.isfinite(ref["cpo"]).all()
     bad = []
-    for split in ((-1, -1), (N // 32, N // 32), (0, 0), (1, 1), (300, 100)):
+    # (-1, -1): persistent workgroups drawing tiles from the device counter, automatic tile mix; (-2, -2): one workgroup per tile
+    for split in ((-1, -1), (-2, -2), (N // 32, N // 32), (0, 0), (1, 1), (300, 100)):
         got = run(0, 0, split)
         for k in ref:
             if not np.array_equal(ref[k], got[k]):

@@ -24,15 +24,18 @@ def main():
     ap.add_argument("--splits", action="store_true", help="also sweep forced 32-row tile counts of the co-resident launches")
     ap.add_argument("--only", default="cpo,trpo")
     a = ap.parse_args()
-    plans = {"r4 (32,3)": "32,3,0", "co tile only (0,3)": "0,3,0", "co hvp only (32,0)": "32,0,0", "co both (0,0)": "0,0,0"}
+    plans = {"r4 (32,3)": ("32,3,0", None), "co static grid": ("0,0,0", "-2,-2"), "co persistent tile only": ("0,3,0", None),
+             "co persistent hvp only": ("32,0,0", None), "co persistent both": ("0,0,0", None)}
     res = {}
     for rnd in range(a.rounds):
         for kind, od, ep in (("cpo", 60, 1000), ("trpo", 8, 250)):
             if kind not in a.only.split(","):
                 continue
-            for name, plan in plans.items():
+            for name, (plan, split) in plans.items():
                 os.environ["FSRL_TR_PLAN"] = plan
                 os.environ.pop("FSRL_TR_SPLIT", None)
+                if split:
+                    os.environ["FSRL_TR_SPLIT"] = split
                 r = bench_trust.run(kind, od, 2, 256, ep=ep, timed=5, emit=False, no_cpu=True)
                 res.setdefault((kind, name), []).append(r["hip_ms_per_update"])
                 print(json.dumps({"alg": kind, "plan": name, "round": rnd, "ms": round(r["hip_ms_per_update"], 3)}), flush=True)
@@ -41,7 +44,7 @@ def main():
         for kind, od, ep in (("cpo", 60, 1000), ("trpo", 8, 250)):
             if kind not in a.only.split(","):
                 continue
-            for n32 in (0, 256, 384, 448, 512, 576, 625):
+            for n32 in (0, 300, 400, 450, 497, 530, 560, 590, 625):
                 os.environ["FSRL_TR_SPLIT"] = f"{n32},{n32}"
                 r = bench_trust.run(kind, od, 2, 256, ep=ep, timed=5, emit=False, no_cpu=True)
                 res.setdefault((kind, f"co split n32={n32}"), []).append(r["hip_ms_per_update"])
