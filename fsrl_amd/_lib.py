@@ -124,6 +124,7 @@ SIGNATURES = {
     "fsrl_tr_eval": (C.c_int, [_ctx, _d]),
     "fsrl_tr_set_plan": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32]),
     "fsrl_tr_set_tile_split": (C.c_int, [_ctx, C.c_int32, C.c_int32]),
+    "fsrl_tr_set_co_delay": (C.c_int, [_ctx, C.c_int32, C.c_int32]),
     "fsrl_focops_init": (C.c_int, [_ctx, _P(FocopsConfig)]),
     "fsrl_focops_set_plan": (C.c_int, [_ctx, C.c_int32]),
     "fsrl_focops_set_nu": (C.c_int, [_ctx, C.c_double, C.c_double]),

@@ -233,6 +233,7 @@ __device__ __forceinline__ void fb_tile_body(TileSmem<H, tile_rows(R)>& sm, cons
     // ---- head: thread (row i = tid>>4, dim d = tid&15)
     static_assert(16 * R <= NT, "one head thread per (row, dim): a 32-row tile needs H >= 128");
     if (tid < 16 * R) {
+#pragma clang fp contract(off)       // r5: one rounding of this head in every instantiation (tile heights, co-resident kernels: bit-identical plans)
         const int i = tid >> 4, d = tid & 15;
         const bool valid = i < n_valid;
         const float* rd = &sm.rd[i * FSRL_RD];
@@ -574,6 +575,7 @@ __global__ __launch_bounds__(4 * H) void fb_hvp_tile_kernel(const float* __restr
     __syncthreads();
     // ---- KL head (per row, per action dim): dout, R{dout}, and the sigma_param rows
     if (tid < 256) {
+#pragma clang fp contract(off)       // r5: see fb_tile_body
         const int i = tid >> 4, d = tid & 15;
         if (i < n_valid && d < Da) {
             const float x = sm.out[i * FSRL_MAX_ACT + d];
@@ -870,6 +872,7 @@ __device__ __forceinline__ void hvp_tile_body(Hvp32Smem<H>& sm, const float* __r
     FSRL_TS(a.ts, 7);
     // ---- KL head (per row, per action dim): dout, R{dout}, and the sigma_param rows
     if (tid < 16 * R) {
+#pragma clang fp contract(off)       // r5: see fb_tile_body
         const int i = tid >> 4, d = tid & 15;
         if (i < n_valid && d < Da) {
             const float x = sm.out[i * FSRL_MAX_ACT + d];

@@ -30,10 +30,22 @@ struct CoSched {
     unsigned* counter;      // nullptr: static grid, blockIdx.x is the tile
     unsigned base;
     int total;
+    int first_round;        // workgroups [0, first_round) are the ones resident when the launch starts
+    int delay;              // s_sleep(127) periods (8 128 cycles each) the SECOND resident of a CU waits before its first tile
 };
+// Two workgroups that start on a CU in the same cycle run in LOCKSTEP: same phases at the same time, both waiting for the matrix
+// pipe or both away from it -- and lockstep is stable, because the successor of each starts when its predecessor ends.  So the
+// second resident of every CU (its waves sit in wave slots >= 2 of their SIMDs: HW_ID.WAVE_ID) starts half a tile late, once per
+// launch; from then on the pair stays out of phase.  Only wave 0 sleeps: the others wait for it at the first barrier.
+__device__ __forceinline__ void co_desync(const CoSched& cs) {
+    if (cs.delay > 0 && (int)blockIdx.x < cs.first_round && threadIdx.x < 64) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID, all 32 bits
+        if ((hw & 0xFu) >= 2u)
+            for (int i = 0; i < cs.delay; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+}
 // first tile of this workgroup (static grid: its block index), or -1 / >= total when there is none
 __device__ __forceinline__ int co_first_tile(const CoSched& cs, int* s_next) {
-    if (cs.counter == nullptr) return (int)blockIdx.x;
     if (threadIdx.x == 0) *s_next = (int)(atomicAdd(cs.counter, 1u) - cs.base);
     __syncthreads();
     return *s_next;
@@ -206,6 +218,7 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
     __syncthreads();
     // ---- KL head (per row, per action dim): dout, R{dout}, and the sigma_param rows   (hvp_tile_body's arithmetic)
     if (tid < 16 * R) {
+#pragma clang fp contract(off)       // the head's arithmetic is the four-slot kernels' to the bit in every instantiation
         const int i = tid >> 4, d = tid & 15;
         if (i < n_valid && d < Da) {
             const float x = sm.out[i * FSRL_MAX_ACT + d];
@@ -291,22 +304,29 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
 
 // Mixed-height grid like fb_hvp_mixed_kernel: blocks [0, n32) take 32-row tiles, the rest 16-row tiles behind them.
 // 2 H threads, <= 128 VGPRs (4 waves per SIMD) and 78.8 KB of LDS: two workgroups per CU.
-template <int H>
+// PERSIST = false: one workgroup per tile (straight-line: 116 VGPRs, no scratch); true: persistent workgroups (A/B)
+template <int H, bool PERSIST>
 __global__ __launch_bounds__(2 * H, 4) void fb_hvp_co_kernel(const float* __restrict__ P, const ModelDesc md, const HvpArgs a,
                                                             const int n32, const CoSched cs) {
     __shared__ HvpCoSmem<H> sm;
-    __shared__ int s_next;
-    int b = co_first_tile(cs, &s_next);
-    while (b < cs.total) {
-        unsigned nxt = 0u;
-        if (cs.counter != nullptr && threadIdx.x == 0) nxt = atomicAdd(cs.counter, 1u) - cs.base;   // in flight under this tile
+    co_desync(cs);
+    if constexpr (!PERSIST) {
+        const int b = blockIdx.x;
         if (b < n32) hvp_co_body<H, 2>(sm, P, md, a, 32 * b);
         else hvp_co_body<H, 1>(sm, P, md, a, 32 * n32 + 16 * (b - n32));
-        if (cs.counter == nullptr) break;
-        __syncthreads();                               // the slots and s_next are free
-        if (threadIdx.x == 0) s_next = (int)nxt;
-        __syncthreads();
-        b = s_next;
+    } else {
+        __shared__ int s_next;
+        int b = co_first_tile(cs, &s_next);
+        while (b < cs.total) {
+            unsigned nxt = 0u;
+            if (threadIdx.x == 0) nxt = atomicAdd(cs.counter, 1u) - cs.base;   // in flight under this tile
+            if (b < n32) hvp_co_body<H, 2>(sm, P, md, a, 32 * b);
+            else hvp_co_body<H, 1>(sm, P, md, a, 32 * n32 + 16 * (b - n32));
+            __syncthreads();                               // the slots and s_next are free
+            if (threadIdx.x == 0) s_next = (int)nxt;
+            __syncthreads();
+            b = s_next;
+        }
     }
 }
 
@@ -457,6 +477,7 @@ __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __r
     const bool backward = (a.mode != FB_MODE_EVAL);
     // ---- loss head: thread (row i = tid >> 4, dim d = tid & 15)       (fb_tile_body's arithmetic, actor and V-critic cases)
     if (tid < 16 * R) {
+#pragma clang fp contract(off)       // as in fb_tile_body: no instantiation may fuse a multiply-add the other one keeps apart
         const int i = tid >> 4, d = tid & 15;
         const bool valid = i < n_valid;
         const float* rd = &sm.rd[i * TC_RD];
@@ -584,15 +605,12 @@ __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __r
 }
 
 // The grid of fb_tile_mixed_kernel: ny * n32 32-row tiles first, ny * n16 16-row tiles behind them.
-template <int H>
+template <int H, bool PERSIST>
 __global__ __launch_bounds__(2 * H, 4) void fb_tile_co_kernel(const float* __restrict__ P, const ModelDesc md, const FbArgs a,
                                                              const int n32, const int n16, const int ny, const CoSched cs) {
     __shared__ TileCoSmem<H> sm;
-    __shared__ int s_next;
-    int b = co_first_tile(cs, &s_next);
-    while (b < cs.total) {
-        unsigned nxt = 0u;
-        if (cs.counter != nullptr && threadIdx.x == 0) nxt = atomicAdd(cs.counter, 1u) - cs.base;
+    co_desync(cs);
+    auto one = [&](int b) {
         if (b < ny * n32) {
             const int y = b / n32, t = b - y * n32;
             tile_co_body<H, 2>(sm, P, md, a, 32 * t, 2 * t, y, ny);
@@ -601,10 +619,20 @@ __global__ __launch_bounds__(2 * H, 4) void fb_tile_co_kernel(const float* __res
             const int y = b2 / n16, t = b2 - y * n16;
             tile_co_body<H, 1>(sm, P, md, a, 32 * n32 + 16 * t, 2 * n32 + t, y, ny);
         }
-        if (cs.counter == nullptr) break;
-        __syncthreads();
-        if (threadIdx.x == 0) s_next = (int)nxt;
-        __syncthreads();
-        b = s_next;
+    };
+    if constexpr (!PERSIST) {
+        one((int)blockIdx.x);
+    } else {
+        __shared__ int s_next;
+        int b = co_first_tile(cs, &s_next);
+        while (b < cs.total) {
+            unsigned nxt = 0u;
+            if (threadIdx.x == 0) nxt = atomicAdd(cs.counter, 1u) - cs.base;
+            one(b);
+            __syncthreads();
+            if (threadIdx.x == 0) s_next = (int)nxt;
+            __syncthreads();
+            b = s_next;
+        }
     }
 }

@@ -482,6 +482,10 @@ class Engine:
         """A/B only: forced 32-row tile counts of the co-resident tile / cached-HVP launches (-1 = the dispatch simulation)."""
         _lib.check(self.lib.fsrl_tr_set_tile_split(self._ctx, int(n32_tile), int(n32_hvp)))
 
+    def tr_set_co_delay(self, tile_periods: int = -1, hvp_periods: int = -1):
+        """A/B only: start offset of every CU's second co-resident workgroup (periods of 8 128 cycles; -1 = default)."""
+        _lib.check(self.lib.fsrl_tr_set_co_delay(self._ctx, int(tile_periods), int(hvp_periods)))
+
     def tr_eval(self):
         out = np.zeros(8, np.float64)
         _lib.check(self.lib.fsrl_tr_eval(self._ctx, _ptr(out, _f64p)))

@@ -376,12 +376,16 @@ int fsrl_tr_eval(fsrl_ctx* ctx, double* stats8);
  * (tests/test_gpu_fullsize.py states the tolerance).                                                                   */
 int fsrl_tr_set_plan(fsrl_ctx* ctx, int32_t tile_rows, int32_t hvp, int32_t wgrad);
 /* A/B only: force how many 32-row tiles (per network) the co-resident launches of the tile kernel / of the cached Hessian
- * product start with, the remaining rows going to 16-row tiles behind them; -1 = automatic.  The co-resident launches are
- * PERSISTENT: 2 x (number of CUs) workgroups draw their tiles from a device counter, so every CU keeps a pair of tiles in
- * flight until the batch runs out; -2 in either argument = automatic tile mix with one workgroup per tile instead (the static
- * grid, for A/B).  Neither the split nor the scheduling changes a result (a row's arithmetic does not depend on its tile's
+ * product start with, the remaining rows going to 16-row tiles behind them; -1 = automatic.  A PERSISTENT form exists:
+ * 2 x (number of CUs) workgroups draw their tiles from a device counter, so every CU keeps a pair of tiles in
+ * flight until the batch runs out -- that is the A/B form, selected by -2 in either argument; the default is one workgroup per
+ * tile (the hardware dispatcher already hands tiles out dynamically, and 1 250 draws on one counter cost ~50 us per launch).  Neither the split nor the scheduling changes a result (a row's arithmetic does not depend on its tile's
  * height or on the workgroup that computes it).                                                                        */
 int fsrl_tr_set_tile_split(fsrl_ctx* ctx, int32_t n32_tile, int32_t n32_hvp);
+/* A/B only: how late the SECOND co-resident workgroup of every CU starts its first tile, in periods of 8 128 shader cycles
+ * (s_sleep 127), for the tile kernel / the cached Hessian product; -1 = the built-in default.  Two workgroups that start in
+ * the same cycle run their phases in lockstep and never overlap; the offset is created once per launch.  No effect on a result. */
+int fsrl_tr_set_co_delay(fsrl_ctx* ctx, int32_t tile_periods, int32_t hvp_periods);
 
 /* ---- FOCOPS (fsrl/policy/focops.py:126-251), on the PPO entry points: create the context
  *      with algo = FSRL_ALGO_FOCOPS (same networks and parameter vector as PPO-Lag), call fsrl_focops_init once,

@@ -23,9 +23,10 @@ def main():
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--splits", action="store_true", help="also sweep forced 32-row tile counts of the co-resident launches")
     ap.add_argument("--only", default="cpo,trpo")
+    ap.add_argument("--delays", action="store_true", help="sweep the start offset of every CU's second resident workgroup")
     a = ap.parse_args()
-    plans = {"r4 (32,3)": ("32,3,0", None), "co static grid": ("0,0,0", "-2,-2"), "co persistent tile only": ("0,3,0", None),
-             "co persistent hvp only": ("32,0,0", None), "co persistent both": ("0,0,0", None)}
+    plans = {"r4 (32,3)": ("32,3,0", None), "co tile only": ("0,3,0", None), "co hvp only": ("32,0,0", None), "co both": ("0,0,0", None),
+             "co both, persistent workgroups": ("0,0,0", "-2,-2")}
     res = {}
     for rnd in range(a.rounds):
         for kind, od, ep in (("cpo", 60, 1000), ("trpo", 8, 250)):
@@ -49,6 +50,18 @@ def main():
                 r = bench_trust.run(kind, od, 2, 256, ep=ep, timed=5, emit=False, no_cpu=True)
                 res.setdefault((kind, f"co split n32={n32}"), []).append(r["hip_ms_per_update"])
                 print(json.dumps({"alg": kind, "plan": f"co split n32={n32}", "ms": round(r["hip_ms_per_update"], 3)}), flush=True)
+    if a.delays:
+        os.environ["FSRL_TR_PLAN"] = "0,0,0"
+        os.environ.pop("FSRL_TR_SPLIT", None)
+        for kind, od, ep in (("cpo", 60, 1000), ("trpo", 8, 250)):
+            if kind not in a.only.split(","):
+                continue
+            for dt, dh in ((0, 0), (2, 0), (4, 0), (6, 0), (0, 3), (0, 5), (0, 7), (0, 9), (4, 7), (3, 5), (5, 9)):
+                os.environ["FSRL_TR_DELAY"] = f"{dt},{dh}"
+                r = bench_trust.run(kind, od, 2, 256, ep=ep, timed=5, emit=False, no_cpu=True)
+                res.setdefault((kind, f"co delay tile={dt} hvp={dh}"), []).append(r["hip_ms_per_update"])
+                print(json.dumps({"alg": kind, "plan": f"co delay tile={dt} hvp={dh}", "ms": round(r["hip_ms_per_update"], 3)}), flush=True)
+        os.environ.pop("FSRL_TR_DELAY", None)
     print(json.dumps({"summary_ms_median": {f"{k[0]} | {k[1]}": round(float(np.median(v)), 3) for k, v in res.items()}}, indent=1))
 
 

@@ -89,6 +89,10 @@ def run(kind, obs_dim, act_dim, hid, envs=20, T=1000, ep=1000, repeat=4, cpu_rep
     if split:
         eng.tr_set_tile_split(*[int(x) for x in split.split(",")])
 
+    delay = os.environ.get("FSRL_TR_DELAY")                # "tile,hvp" (fsrl_tr_set_co_delay): start offset of the second resident workgroup
+    if delay:
+        eng.tr_set_co_delay(*[int(x) for x in delay.split(",")])
+
     def device_update():
         # every timed update is the same workload: initial weights AND a fresh optimiser state -- round 1 restored the
         # weights only, so the critics' Adam moments of the previous update leaked into the next one and the reported
