@@ -211,7 +211,7 @@ def end_to_end(local_rank, seed, seconds=6.0, device_actor=False, workers=0, bus
             if workers > 0 else "in-process vector env, zero-cost step")
     procs = int(getattr(env, "workers", workers)) if workers > 0 else 0      # worker PROCESSES (capped at the usable CPUs)
     out = {"env": "synthetic SafetyCarCircle-shaped dynamics (not PyBullet); " + kind, "envs": envs, "workers": workers,
-           "worker_processes": procs, "busy_us": busy_us, "host_cpus_usable": usable_cpus(),
+           "worker_processes": procs, "worker_mode": getattr(env, "worker_mode", None), "busy_us": busy_us, "host_cpus_usable": usable_cpus(),
            "handshake": (("futex generation word + completion counter per lane (libfsrl_env.so), spin "
                           f"{getattr(env, 'spin_us', 0):g} us before sleeping") if workers > 0 else None),
            "split_phase": bool(col.split_phase),
@@ -780,14 +780,15 @@ def main():
         for w in (4, 32):
             for b in (0.0, 100.0):
                 r = legs.run(f"end_to_end_shmem_w{w}_b{int(b)}",
-                             lambda: end_to_end(local_rank, seed, seconds=3.0, device_actor=True, workers=w, busy_us=b, envs=32),
+                             lambda: end_to_end(local_rank, seed, seconds=3.0, device_actor=True, workers=w, busy_us=b, envs=32,
+                                                cap_workers="auto"),
                              60.0, store=False)
                 shm.append(r if r is not None else {"workers": w, "busy_us": b, "error": "leg failed or timed out"})
-        # 32 envs at zero step cost with the worker processes capped at the usable CPUs (ShmemVectorEnv(cap_workers=True))
-        r = legs.run("end_to_end_shmem_w32_b0_capped",
-                     lambda: end_to_end(local_rank, seed, seconds=3.0, device_actor=True, workers=32, busy_us=0.0, envs=32, cap_workers=True),
+        # 32 envs at zero step cost with one process per env, as requested (cap_workers=False: the reference's layout) -- what "auto" avoids
+        r = legs.run("end_to_end_shmem_w32_b0_uncapped",
+                     lambda: end_to_end(local_rank, seed, seconds=3.0, device_actor=True, workers=32, busy_us=0.0, envs=32, cap_workers=False),
                      60.0, store=False)
-        shm.append(r if r is not None else {"workers": 32, "busy_us": 0.0, "cap_workers": True, "error": "leg failed or timed out"})
+        shm.append(r if r is not None else {"workers": 32, "busy_us": 0.0, "cap_workers": False, "error": "leg failed or timed out"})
         legs.run("grouped", lambda: grouped(4), 90.0)
         legs.run("grouped_k8", lambda: grouped(8), 90.0)
         legs.run("multi_seed", multi_seed, 90.0)

@@ -135,7 +135,11 @@ __device__ __forceinline__ void store4_next(float* p, const f32x4 v) {
 }
 // the full-batch / replay kernels' 16-byte spills (A1 / A2 / D2 and the R-op operands, 20 MB arrays at N = 20 000): the same
 // write-through.  A/B: CPO 38.9 -> 38.65 ms, TRPO-Lag 32.4 -> 32.0 ms, SAC-Lag 6 450 -> 6 610 updates/s.
+#ifdef FSRL_FB_PLAIN_STORES   // A/B build only (tools/ab_trust_co.py): the spills as plain stores (ack from the XCD's L2, not from the memory side)
+__device__ __forceinline__ void store4_fb(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+#else
 __device__ __forceinline__ void store4_fb(float* p, const f32x4 v) { store4_next(p, v); }
+#endif
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -142,6 +142,32 @@ def _worker(w, lane, lo, hi, shm_name, env_num, workers, obs_dim, act_dim, spec,
         shm.close()
 
 
+AUTO_CHEAP_US = 25.0        # cap_workers="auto": an env step below this is all handshake
+AUTO_CHEAP_WORKERS = 4
+
+
+def _probe_step_cost_us(env, act_dim, steps=8):
+    """host time of one env.step on a throw-away instance (median of a few steps from a reset state); None when the env cannot be
+    stepped here"""
+    import time
+    from fsrl_amd.env.venv import _reset_one, _step_one
+    try:
+        _reset_one(env, None, {})
+        sp = getattr(env, "action_space", None)
+        lo, hi = np.asarray(getattr(sp, "low", -1.0), np.float64), np.asarray(getattr(sp, "high", 1.0), np.float64)
+        act = np.where(np.isfinite(lo + hi), 0.5 * (lo + hi), 0.0).astype(np.float32).reshape(-1)[:act_dim]
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            out = _step_one(env, act)
+            ts.append(time.perf_counter() - t0)
+            if out[2] or out[3]:
+                _reset_one(env, None, {})
+        return float(np.median(ts)) * 1e6
+    except Exception:                                       # noqa: BLE001 -- a probe must never take the construction down
+        return None
+
+
 class ShmemVectorEnv:
     def __init__(self, env_num=32, workers=None, obs_dim=8, act_dim=2, episode_len=300, seed=None, busy_us=0.0, cores=None,
                  start_method="spawn", spin_us=None, env_fns=None, cap_workers=False):
@@ -164,6 +190,7 @@ class ShmemVectorEnv:
             self.observation_space, self.action_space = probe.observation_space, probe.action_space
             self.spec = getattr(probe, "spec", None)
             obs_dim, act_dim = int(np.prod(self.observation_space.shape)), int(np.prod(self.action_space.shape))
+            step_cost_us = _probe_step_cost_us(probe, act_dim) if cap_workers == "auto" else None
             if hasattr(probe, "close"):
                 probe.close()
             del probe
@@ -181,11 +208,27 @@ class ShmemVectorEnv:
         # split-phase collect keep every CPU busy while the other lane's actor call is in flight (MI355X box, 16 usable CPUs,
         # 32 envs x 100 us: 0.68 of the env bound with 16 processes, 0.83-0.89 with 32).  Default off = tianshou's one process
         # per env.
+        # cap_workers="auto" (r5): decided by what ONE env step costs -- measured on the throw-away probe instance (env_fns) or known
+        # (the synthetic dynamics: busy_us).  An env cheaper than AUTO_CHEAP_US per step is all handshake: it runs on
+        # AUTO_CHEAP_WORKERS processes (32 envs x 0 us on this box: 4 processes 600-680 k env-steps/s, 16 processes 290-420 k, 32
+        # processes 240-330 k); every other env keeps the requested process count (one per env: the reference's layout, and what
+        # fills the CPUs at a real step cost).  `worker_mode` says what was chosen and why.
         self.workers_requested = workers
-        if cap_workers:
+        self.worker_mode = f"as requested: {workers} processes"
+        if cap_workers == "auto":
+            cost = float(busy_us) if env_fns is None else step_cost_us
+            if cost is not None and cost < AUTO_CHEAP_US and workers > AUTO_CHEAP_WORKERS:
+                self.worker_mode = (f"auto: an env step costs {cost:.1f} us (< {AUTO_CHEAP_US:g}): {AUTO_CHEAP_WORKERS} processes "
+                                    f"instead of {workers}")
+                workers = AUTO_CHEAP_WORKERS
+            else:
+                self.worker_mode = (f"auto: an env step costs {cost if cost is not None else float('nan'):.1f} us: "
+                                    f"{workers} processes as requested")
+        elif cap_workers:
             from fsrl_amd.parallel import usable_cpus
             cap = max(1, int(min(usable_cpus(), len(cores)) if cores else usable_cpus()))
             workers = max(1, min(workers, cap))
+            self.worker_mode = f"capped at the usable CPUs: {workers} processes"
         self.env_num, self.obs_dim, self.act_dim, self.workers = env_num, obs_dim, act_dim, workers
         self.episode_len, self.busy_us = episode_len, busy_us
         self._lib = _load_lib()

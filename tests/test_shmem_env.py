@@ -342,3 +342,53 @@ def test_worker_processes_can_be_capped_at_the_usable_cpus():
         assert env.workers == cap + 2
     finally:
         env.close()
+
+
+class _SlowEnv:
+    """a duck-typed env whose step burns ~200 us (a real simulator's order of magnitude)"""
+
+    def __init__(self):
+        from types import SimpleNamespace
+        self.observation_space = SimpleNamespace(shape=(3, ))
+        self.action_space = SimpleNamespace(shape=(2, ), low=-np.ones(2, np.float32), high=np.ones(2, np.float32))
+        self.t = 0
+
+    def reset(self, seed=None):
+        self.t = 0
+        return np.zeros(3, np.float32), {}
+
+    def step(self, a):
+        import time
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 200e-6:
+            pass
+        self.t += 1
+        return np.full(3, self.t, np.float32), 1.0, False, self.t >= 4, {"cost": 0.0}
+
+
+def test_auto_worker_count_follows_the_env_step_cost():
+    """cap_workers="auto" (r5): an env that costs (almost) nothing per step runs on 4 processes whatever was requested -- a vector
+    step of such an env is the wake-up of its workers -- and an env with a real step cost keeps one process per env (the
+    reference's layout).  The cost is known for the synthetic dynamics (busy_us) and measured on the probe instance for factories."""
+    from fsrl_amd.env import ShmemVectorEnv
+    env = ShmemVectorEnv(env_num=12, workers=12, episode_len=5, seed=1, busy_us=0.0, cap_workers="auto")
+    try:
+        assert env.workers == 4 and env.workers_requested == 12 and "4 processes instead of 12" in env.worker_mode
+        obs, _ = env.reset()
+        o, r, t, u, i = env.step(np.zeros((12, 2), np.float32))
+        assert o.shape == (12, 8)
+    finally:
+        env.close()
+    env = ShmemVectorEnv(env_num=6, workers=6, episode_len=5, seed=1, busy_us=100.0, cap_workers="auto")
+    try:
+        assert env.workers == 6 and "as requested" in env.worker_mode
+    finally:
+        env.close()
+    env = ShmemVectorEnv(env_fns=[_SlowEnv for _ in range(5)], cap_workers="auto")
+    try:
+        assert env.workers == 5 and "as requested" in env.worker_mode, env.worker_mode
+        obs, _ = env.reset()
+        o, r, t, u, i = env.step(np.zeros((5, 2), np.float32))
+        assert np.array_equal(o, np.ones((5, 3), np.float32))
+    finally:
+        env.close()
