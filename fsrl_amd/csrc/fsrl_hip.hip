@@ -188,6 +188,9 @@ struct fsrl_ctx {
     int64_t snap_adam_t = 0, snap_critic_t = 0, snap_foc_a = 0, snap_foc_c = 0; bool snap_valid = false;
     struct LayState* lay = nullptr; // layered PPO-Lag context (hidden_sizes of other depths / widths, host_layered.inc), owned
     struct TrState* tr = nullptr;   // trust-region (CPO / TRPO-Lag) working set, owned
+    uint64_t theta_version = 1;     // bumped by everything that may write the actor's parameters (uploads, restores, optimiser
+                                    // steps, line-search steps): TrState::rd_version == theta_version <=> mean_old / std_old of the
+                                    // trust-region batch were computed at the CURRENT theta (the Gauss-Newton form of the KL product)
     void* sac = nullptr;            // SacState, owned
 };
 static bool ctx_is_replay(const fsrl_ctx* c);
@@ -563,6 +566,7 @@ static int copy_flat(fsrl_ctx* c, float* dev, float* host_out, const float* host
 
 extern "C" int fsrl_params_set(fsrl_ctx* c, const float* flat, int64_t n) {
     CHECK_ARG(c && flat, "null argument");
+    c->theta_version += 1;
     return copy_flat(c, c->P, nullptr, flat, n);
 }
 extern "C" int fsrl_params_get(fsrl_ctx* c, float* flat, int64_t n) {
@@ -620,6 +624,7 @@ extern "C" int fsrl_state_restore(fsrl_ctx* c) {
     if (!c->snap_valid) return fail(FSRL_ESTATE, "fsrl_state_restore before fsrl_state_snapshot");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->compute;
+    c->theta_version += 1;
     HIPCHK(hipMemcpyAsync(c->P, c->snap, (size_t)c->n_alloc * 4, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(c->M, c->snap + c->n_alloc, (size_t)c->n_dev * 4, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(c->V, c->snap + c->n_alloc + c->n_dev, (size_t)c->n_dev * 4, hipMemcpyDeviceToDevice, st));

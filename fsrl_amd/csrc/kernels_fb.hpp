@@ -423,6 +423,11 @@ struct HvpArgs {
     int N, rows_pad;
     float max_action;
     unsigned long long* ts;  // probe builds: [blocks][16] shader-clock stamps of the phase boundaries (else null)
+    int gn;                  // r5: mean_old / std_old of the batch ARE the policy at this theta (TRPO-Lag always: trpo_lag.py:189-190;
+                             // CPO until its first accepted step): the KL gradient is identically zero, the product is the
+                             // Gauss-Newton one.  The heads then use mu - mean_old = 0 and std_old = sigma EXACTLY (what the reference's
+                             // autograd sees: old_dist is a detached copy of the same forward), so dout, dz2 and every term they
+                             // multiply are exact zeros; kernels_fbco.hpp and the weight-side launch skip them
 };
 
 template <int H>
@@ -587,8 +592,8 @@ __global__ __launch_bounds__(4 * H) void fb_hvp_tile_kernel(const float* __restr
             const float dt = hs * (1.0f - t * t);                       // dmu/dout
             const float rmu = dt * ro;
             const float dmu_b = a.max_action * t - sm.rd[i * FSRL_RD + FSRL_RD_MEAN + d];
-            const float dmu = md.unbounded ? x - sm.rd[i * FSRL_RD + FSRL_RD_MEAN + d] : dmu_b;
-            const float so = sm.rd[i * FSRL_RD + FSRL_RD_STD + d], so2 = so * so;
+            const float dmu = a.gn ? 0.0f : (md.unbounded ? x - sm.rd[i * FSRL_RD + FSRL_RD_MEAN + d] : dmu_b);
+            const float so = sm.rd[i * FSRL_RD + FSRL_RD_STD + d], so2 = a.gn ? var : so * so;
             const float gmu = dmu / var;                                // dKL/dmu
             const float rgmu = rmu / var - 2.0f * gmu * rls;
             const float rgls = -2.0f * dmu * rmu / var + 2.0f * (so2 + dmu * dmu) / var * rls;
@@ -884,8 +889,8 @@ __device__ __forceinline__ void hvp_tile_body(Hvp32Smem<H>& sm, const float* __r
             const float dt = hs * (1.0f - t * t);                       // dmu/dout
             const float rmu = dt * ro;
             const float dmu_b = a.max_action * t - sm.mo[i * 32 + d];
-            const float dmu = md.unbounded ? x - sm.mo[i * 32 + d] : dmu_b;
-            const float so = sm.mo[i * 32 + 16 + d], so2 = so * so;
+            const float dmu = a.gn ? 0.0f : (md.unbounded ? x - sm.mo[i * 32 + d] : dmu_b);
+            const float so = sm.mo[i * 32 + 16 + d], so2 = a.gn ? var : so * so;
             const float gmu = dmu / var;                                // dKL/dmu
             const float rgmu = rmu / var - 2.0f * gmu * rls;
             const float rgls = -2.0f * dmu * rmu / var + 2.0f * (so2 + dmu * dmu) / var * rls;

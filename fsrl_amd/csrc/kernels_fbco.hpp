@@ -67,7 +67,7 @@ static_assert(sizeof(HvpCoSmem<256>) <= 80 * 1024, "two workgroups per CU");
 // the other, keeping 2-4 fragment sets alive through scratch (400-1000 spilled dwords per lane, measured); as runtime loops the
 // kernel needs 116 VGPRs and no scratch, and the fragment loads travel a chunk or two ahead of the MFMAs that consume them.
 // One tile of 16 NH rows starting at row0 of the CACHED product (h1 / h2 / dout / dz2 of this theta are in A1 / A2 / DO / D2).
-template <int H, int NH>
+template <int H, int NH, bool GN>
 __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __restrict__ P, const ModelDesc& md,
                                             const HvpArgs& a, const int row0) {
     constexpr int LD = HvpCoSmem<H>::LD;
@@ -148,11 +148,12 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
     }
     __syncthreads();                                  // R{h1} complete; the observation tile is dead
     for (int e = tid; e < R * FSRL_DOW; e += NT) { dout[e] = 0.0f; rdout[e] = 0.0f; }
-    // R{h1} leaves for the weight-side kernel
-    for (int e = tid; e < R * H4; e += NT) {
-        const int i = e / H4, c4 = e - i * H4;
-        store4_fb(a.RA1 + base + (size_t)i * H + 4 * c4, *reinterpret_cast<const f32x4*>(&rh1[i * LD + 4 * c4]));
-    }
+    // R{h1} leaves for the weight-side kernel (dz2^T R{h1}: not in the Gauss-Newton form, where dz2 = 0)
+    if constexpr (!GN)
+        for (int e = tid; e < R * H4; e += NT) {
+            const int i = e / H4, c4 = e - i * H4;
+            store4_fb(a.RA1 + base + (size_t)i * H + 4 * c4, *reinterpret_cast<const f32x4*>(&rh1[i * LD + 4 * c4]));
+        }
     // ---- layer 2 tangent:  R{z2} = W2 R{h1} + V2 h1   (per column group: W2 fragments, then V2 fragments, same registers)
     f32x4 rz[2][NH];
 #pragma unroll 1
@@ -210,11 +211,12 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
             }
         }
     }
-    // R{h2} leaves; slot 1 is free after the barrier
-    for (int e = tid; e < R * H4; e += NT) {
-        const int i = e / H4, c4 = e - i * H4;
-        store4_fb(a.RA2 + base + (size_t)i * H + 4 * c4, *reinterpret_cast<const f32x4*>(&rh2[i * LD + 4 * c4]));
-    }
+    // R{h2} leaves (dout^T R{h2}: not in the Gauss-Newton form); slot 1 is free after the barrier
+    if constexpr (!GN)
+        for (int e = tid; e < R * H4; e += NT) {
+            const int i = e / H4, c4 = e - i * H4;
+            store4_fb(a.RA2 + base + (size_t)i * H + 4 * c4, *reinterpret_cast<const f32x4*>(&rh2[i * LD + 4 * c4]));
+        }
     __syncthreads();
     // ---- KL head (per row, per action dim): dout, R{dout}, and the sigma_param rows   (hvp_tile_body's arithmetic)
     if (tid < 16 * R) {
@@ -230,8 +232,8 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
             const float dt = hs * (1.0f - t * t);
             const float rmu = dt * ro;
             const float dmu_b = a.max_action * t - mo_mean;
-            const float dmu = md.unbounded ? x - mo_mean : dmu_b;
-            const float so = mo_std, so2 = so * so;
+            const float dmu = GN ? 0.0f : (md.unbounded ? x - mo_mean : dmu_b);
+            const float so = mo_std, so2 = GN ? var : so * so;
             const float gmu = dmu / var;
             const float rgmu = rmu / var - 2.0f * gmu * rls;
             const float rgls = -2.0f * dmu * rmu / var + 2.0f * (so2 + dmu * dmu) / var * rls;
@@ -282,7 +284,7 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
         for (int hf = 0; hf < NH; ++hf) acc[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
         mma_cols_n<H, NH>(rd2, P + no.W2, cg, li, q, acc);
         __builtin_amdgcn_sched_barrier(0);
-        mma_cols_n<H, NH>(d2, V + no.W2, cg, li, q, acc);
+        if constexpr (!GN) mma_cols_n<H, NH>(d2, V + no.W2, cg, li, q, acc);         // dz2 V2: dz2 = 0 in the Gauss-Newton form
         float* __restrict__ RD1 = a.RD1 + base;
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
@@ -305,23 +307,23 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
 // Mixed-height grid like fb_hvp_mixed_kernel: blocks [0, n32) take 32-row tiles, the rest 16-row tiles behind them.
 // 2 H threads, <= 128 VGPRs (4 waves per SIMD) and 78.8 KB of LDS: two workgroups per CU.
 // PERSIST = false: one workgroup per tile (straight-line: 116 VGPRs, no scratch); true: persistent workgroups (A/B)
-template <int H, bool PERSIST>
+template <int H, bool PERSIST, bool GN>
 __global__ __launch_bounds__(2 * H, 4) void fb_hvp_co_kernel(const float* __restrict__ P, const ModelDesc md, const HvpArgs a,
                                                             const int n32, const CoSched cs) {
     __shared__ HvpCoSmem<H> sm;
     co_desync(cs);
     if constexpr (!PERSIST) {
         const int b = blockIdx.x;
-        if (b < n32) hvp_co_body<H, 2>(sm, P, md, a, 32 * b);
-        else hvp_co_body<H, 1>(sm, P, md, a, 32 * n32 + 16 * (b - n32));
+        if (b < n32) hvp_co_body<H, 2, GN>(sm, P, md, a, 32 * b);
+        else hvp_co_body<H, 1, GN>(sm, P, md, a, 32 * n32 + 16 * (b - n32));
     } else {
         __shared__ int s_next;
         int b = co_first_tile(cs, &s_next);
         while (b < cs.total) {
             unsigned nxt = 0u;
             if (threadIdx.x == 0) nxt = atomicAdd(cs.counter, 1u) - cs.base;   // in flight under this tile
-            if (b < n32) hvp_co_body<H, 2>(sm, P, md, a, 32 * b);
-            else hvp_co_body<H, 1>(sm, P, md, a, 32 * n32 + 16 * (b - n32));
+            if (b < n32) hvp_co_body<H, 2, GN>(sm, P, md, a, 32 * b);
+            else hvp_co_body<H, 1, GN>(sm, P, md, a, 32 * n32 + 16 * (b - n32));
             __syncthreads();                               // the slots and s_next are free
             if (threadIdx.x == 0) s_next = (int)nxt;
             __syncthreads();

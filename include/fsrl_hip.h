@@ -368,7 +368,11 @@ int fsrl_tr_eval(fsrl_ctx* ctx, double* stats8);
  * Hessian product are computed by the first product of a conjugate-gradient solve and read back by the others: cpo.py:184-204
  * calls _MVP 10 + 1 times per right-hand side at one theta; the cached products run as two co-resident workgroups per CU at
  * 256-wide layers: fb_hvp_co_kernel), 1 = the 16-row kernel that recomputes everything, 2 = mixed tiles without the cache,
- * 3 = mixed tiles + cache with one 1024-thread workgroup per CU (round 4's kernel).  wgrad: 0 = the split-K weight-gradient
+ * 3 = mixed tiles + cache with one 1024-thread workgroup per CU (round 4's kernel); adding 4 to any of them switches the
+ * Gauss-Newton form of the product off (A/B): by default, whenever mean_old / std_old of the batch were computed at the present
+ * theta -- every TRPO-Lag product (trpo_lag.py:189-190), CPO's products until its first line-search step -- the KL gradient
+ * is identically zero and the heads use mu - mean_old = 0, std_old = sigma exactly (as the reference's autograd does on its
+ * detached copy of the same forward), so the dz2 / dout terms vanish and are not computed.  wgrad: 0 = the split-K weight-gradient
  * kernel (default), 1 = the same with XCD-aware placement of its blocks, 3 = the one-pass streaming kernel for 256-wide layers
  * over >= 4096 rows (one workgroup per network, output quarter and row slice; operands by LDS-DMA; 2.6x less memory traffic,
  * the same time: not the default).  The tile_rows / hvp / wgrad 0-1 plans give bit-identical results; the streaming kernel adds

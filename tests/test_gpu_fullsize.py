@@ -350,14 +350,18 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
     eng.close()
 
 
+@pytest.mark.parametrize("at_theta_old", [False, True])
 @pytest.mark.parametrize("obs_dim,T", [(60, 1000), (8, 1000), (33, 163)])
-def test_co_resident_kernels_match_one_workgroup_per_cu(obs_dim, T):
+def test_co_resident_kernels_match_one_workgroup_per_cu(obs_dim, T, at_theta_old):
     """Round 5's co-resident tile kernels (two 512-thread workgroups per CU, two time-multiplexed LDS slots; kernels_fbco.hpp)
     against round 4's one-1024-thread-workgroup-per-CU kernels on the building blocks, BIT FOR BIT, for the persistent launches
     (tiles drawn from a device counter), for the static grid and for forced tile mixes (all whole 32-row tiles, all 16-row
     tiles, one 32-row tile, different mixes for the two kernels): the three gradients (SUR,
     SUR, KL heads), the line-search statistics (EVAL), the critics' regression step (VF, through one CPO repeat) and the cached
-    Hessian-vector product.  N = 20 000 (BASELINE configs[2] / configs[1] shapes) and N = 3 260 (partial tiles, one round)."""
+    Hessian-vector product.  N = 20 000 (BASELINE configs[2] / configs[1] shapes) and N = 3 260 (partial tiles, one round).
+    at_theta_old: the products are taken at the theta of tr_begin -- the Gauss-Newton form (r5: the co-resident kernel skips the
+    dz2 / dout terms, round 4's kernel computes them as exact zeros: the same bits) -- and once more with that form switched off
+    (hvp plan + 4), which must agree to rounding: the terms it drops are the device's own 1e-7 noise around an exact zero."""
     from fsrl_amd.engine import Engine, EngineConfig
     envs = 20
     rng = np.random.default_rng(21)
@@ -378,7 +382,8 @@ def test_co_resident_kernels_match_one_workgroup_per_cu(obs_dim, T):
         eng.tr_set_tile_split(*split)
         eng.set_params(theta); eng.optim_reset()
         assert eng.tr_begin(target_kl=0.01, l2_reg=0.001, critic_lr=1e-3, max_backtracks=10, optim_critic_iters=2, cost_limit=10.0) == N
-        eng.set_params(moved)                                   # theta != theta_old: every term of the R-op is live
+        if not at_theta_old:
+            eng.set_params(moved)                               # theta != theta_old: every term of the R-op is live
         for w in range(3):
             out[f"grad{w}"] = eng.tr_grad(w)
         out["eval"] = eng.tr_eval()
@@ -398,6 +403,13 @@ def test_co_resident_kernels_match_one_workgroup_per_cu(obs_dim, T):
             if not np.array_equal(ref[k], got[k]):
                 d = np.abs(np.asarray(ref[k], np.float64) - got[k])
                 bad.append((split, k, float(d.max()), int((d > 0).sum()), int(np.size(d))))
+    if at_theta_old:
+        full = run(0, 4)                                        # the same co-resident kernels, Gauss-Newton form off
+        for k in ("hvp", "hvp_cached", "hvp_cached2"):
+            scale = float(np.abs(full[k]).max())
+            err = float(np.abs(full[k] - ref[k]).max())
+            assert 0 < scale and err <= 2e-5 * scale, (k, err, scale)
+        assert not np.array_equal(full["hvp_cached"], ref["hvp_cached"])        # the switch does switch
     eng.tr_set_tile_split(-1, -1)
     eng.tr_set_plan(0, 0, 0)
     eng.close()

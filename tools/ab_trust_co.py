@@ -25,8 +25,8 @@ def main():
     ap.add_argument("--only", default="cpo,trpo")
     ap.add_argument("--delays", action="store_true", help="sweep the start offset of every CU's second resident workgroup")
     a = ap.parse_args()
-    plans = {"r4 (32,3)": ("32,3,0", None), "co tile only": ("0,3,0", None), "co hvp only": ("32,0,0", None), "co both": ("0,0,0", None),
-             "co both, persistent workgroups": ("0,0,0", "-2,-2")}
+    plans = {"r4 kernels, full R-op (32,7)": ("32,7,0", None), "r4 kernels + Gauss-Newton (32,3)": ("32,3,0", None),
+             "co both, full R-op (0,4)": ("0,4,0", None), "co both + Gauss-Newton (0,0) = default": ("0,0,0", None)}
     res = {}
     for rnd in range(a.rounds):
         for kind, od, ep in (("cpo", 60, 1000), ("trpo", 8, 250)):
