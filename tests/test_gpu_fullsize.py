@@ -82,7 +82,7 @@ def test_cpo_configs2_full_size():
     assert n == 20000
     st = eng.cpo_learn(25.0, 1)[0]
     pb, rows = o.update(data, 25.0, 1)
-    sa, sc, _ = rows[0]
+    sa, sc = rows[0][:2]
     # process_fn products at N = 20 000 (float64 GAE, full-batch normalisation): 2e-5 abs on normalised advantages
     np.testing.assert_allclose(eng.batch_get("advs"), pb["advs"].numpy(), rtol=0, atol=2e-5)
     keys = ["loss/kl", "loss/entropy", "loss/rew_loss", "loss/cost_loss", "loss/optim_A", "loss/optim_B", "loss/optim_C",
@@ -489,7 +489,7 @@ def test_cpo_minibatched_at_full_size():
             "loss/step_size"]
     for r in range(3):
         assert int(st[r, 12]) == int(rows[r][0]["loss/optim_case"]), (r, st[r], rows[r][0])
-    sa, sc, _ = rows[0]
+    sa, sc = rows[0][:2]
     got = dict(zip(keys, st[0, :14]))
     np.testing.assert_allclose(got["loss/step_size"], sa["loss/step_size"], rtol=1e-6)
     assert _rel(st[0, 14], sc["loss/vf0"]) <= 2e-4 and _rel(st[0, 15], sc["loss/vf1"]) <= 2e-4, (st[0, 14:], sc)
