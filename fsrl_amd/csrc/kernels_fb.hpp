@@ -91,6 +91,61 @@ struct FbArgs {
     SacNstepArgs ns;      //   launch less per update; the same float64 operations, so the same bits
 };
 
+// ---- the actor's loss head of the trust-region modes (SUR, KL, EVAL): ONE definition with floating-point contraction off, called
+// by fb_tile_body (every tile height) and by the co-resident kernel (kernels_fbco.hpp), so that the kernel plans agree bit for bit
+// whatever the compiler would fuse in one inlining context and not in another (r5: `cr * ar + cc * ac` came out as an fma in one
+// instantiation only).  Thread = (row, action dim d) of a 16-lane row group; dout_mu / dout_sig are this thread's entries of the
+// row's dL/dout | dL/dsigma_param (0 in EVAL mode), st[0..5] the row statistics (valid rows only; every d holds the same).
+__device__ __forceinline__ void fb_tr_actor_head(const float x, const float sigma_param, const float act_d, const float mean_old_d,
+                                                 const float std_old_d, const float lpo, const float ar, const float ac, const int d,
+                                                 const int Da, const int lane, const bool valid, const int mode, const float cr,
+                                                 const float cc, const float max_action, const float invN, const int unbounded,
+                                                 float& dout_mu, float& dout_sig, float (&st)[FB_NSTAT]) {
+#pragma clang fp contract(off)
+    float th = 0.f, var = 1.f, df = 0.f, lp = 0.f, klp = 0.f, dmu = 0.f, so2 = 0.f;
+    float hs = max_action;
+    if (d < Da) {
+        th = tanhf(x);
+        const float sig = expf(sigma_param);
+        var = sig * sig;
+        const float mu = max_action * th;
+        df = act_d - mu;
+        dmu = mu - mean_old_d;
+        if (unbounded) {
+            df = act_d - x;
+            dmu = x - mean_old_d;
+            th = 0.0f; hs = 1.0f;
+        }
+        lp = -(df * df) / (2.0f * var) - logf(sig) - LOG_SQRT_2PI;
+        const float so = std_old_d;                      // KL(old || new), torch.distributions.kl._kl_normal_normal
+        so2 = so * so;
+        const float var_ratio = (so / sig) * (so / sig);
+        const float t1 = (dmu / sig) * (dmu / sig);
+        klp = 0.5f * (var_ratio + t1 - 1.0f - logf(var_ratio));
+    }
+    float logp = 0.0f, klrow = 0.0f;
+    for (int dd = 0; dd < Da; ++dd) {
+        logp += __shfl(lp, (lane & 48) + dd, 64);
+        klrow += __shfl(klp, (lane & 48) + dd, 64);
+    }
+    const float ratio = expf(logp - lpo);
+    dout_mu = 0.0f; dout_sig = 0.0f;
+    if (valid && d < Da) {
+        if (mode == FB_MODE_SUR) {
+            const float dL_dlogp = (cr * ar + cc * ac) * ratio * invN;
+            dout_mu = dL_dlogp * (df / var) * hs * (1.0f - th * th);
+            dout_sig = dL_dlogp * (df * df / var - 1.0f);
+        } else if (mode == FB_MODE_KL) {
+            dout_mu = (dmu / var) * invN * hs * (1.0f - th * th);
+            dout_sig = (1.0f - (so2 + dmu * dmu) / var) * invN;
+        }
+    }
+    if (valid) {
+        st[0] = ratio * ar; st[1] = ratio * ac; st[2] = klrow; st[3] = lpo - logp;
+        st[4] = ar; st[5] = ac;
+    }
+}
+
 // Activation backward of one tile given sm.dout: spills relu(z1), relu(z2), dz2, dout, dz1 for the
 // weight-gradient kernel.  wb = this wave's column slice of W2 (lane (li,q): W2[16jc+4q+s][16w+li]).
 // keep_dz1: also leave dz1 in sm.d2 (used for input gradients).  Always leaves dz1 in sm.d2 when
@@ -233,14 +288,23 @@ __device__ __forceinline__ void fb_tile_body(TileSmem<H, tile_rows(R)>& sm, cons
     // ---- head: thread (row i = tid>>4, dim d = tid&15)
     static_assert(16 * R <= NT, "one head thread per (row, dim): a 32-row tile needs H >= 128");
     if (tid < 16 * R) {
-#pragma clang fp contract(off)       // r5: one rounding of this head in every instantiation (tile heights, co-resident kernels: bit-identical plans)
         const int i = tid >> 4, d = tid & 15;
         const bool valid = i < n_valid;
         const float* rd = &sm.rd[i * FSRL_RD];
         float st[FB_NSTAT];
 #pragma unroll
         for (int k = 0; k < FB_NSTAT; ++k) st[k] = 0.0f;
-        if (net == 0 && !qmode) {
+        if (net == 0 && !qmode && a.mode != FB_MODE_FOCOPS) {
+            // the trust-region modes: the shared, contraction-free head (also the co-resident kernel's)
+            float dmu_ = 0.0f, dsg_ = 0.0f;
+            fb_tr_actor_head(d < Da ? sm.out[i * FSRL_MAX_ACT + d] : 0.0f, d < Da ? sm.sig[d] : 0.0f, rd[d], rd[FSRL_RD_MEAN + d],
+                             rd[FSRL_RD_STD + d], rd[FSRL_RD_LOGP], rd[FSRL_RD_ADV], rd[FSRL_RD_ADV + 1], d, Da, lane, valid, a.mode,
+                             a.cr, a.cc, a.max_action, invN, md.unbounded, dmu_, dsg_, st);
+            if (valid && d < Da && (a.mode == FB_MODE_SUR || a.mode == FB_MODE_KL)) {
+                sm.dout[i * FSRL_DOW + d] = dmu_;
+                sm.dout[i * FSRL_DOW + 16 + d] = dsg_;
+            }
+        } else if (net == 0 && !qmode) {
             float th = 0.f, var = 1.f, df = 0.f, lp = 0.f, klp = 0.f, dmu = 0.f, so2 = 0.f;
             float hs = a.max_action;       // d mu / d head = hs * (1 - th * th); an unbounded head: th = 0, hs = 1
             if (d < Da) {

@@ -479,7 +479,6 @@ __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __r
     const bool backward = (a.mode != FB_MODE_EVAL);
     // ---- loss head: thread (row i = tid >> 4, dim d = tid & 15)       (fb_tile_body's arithmetic, actor and V-critic cases)
     if (tid < 16 * R) {
-#pragma clang fp contract(off)       // as in fb_tile_body: no instantiation may fuse a multiply-add the other one keeps apart
         const int i = tid >> 4, d = tid & 15;
         const bool valid = i < n_valid;
         const float* rd = &sm.rd[i * TC_RD];
@@ -487,49 +486,13 @@ __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __r
 #pragma unroll
         for (int k = 0; k < FB_NSTAT; ++k) st[k] = 0.0f;
         if (net == 0) {
-            float th = 0.f, var = 1.f, df = 0.f, lp = 0.f, klp = 0.f, dmu = 0.f, so2 = 0.f;
-            float hs = a.max_action;
-            if (d < Da) {
-                const float x = sm.out[i * FSRL_MAX_ACT + d];
-                th = tanhf(x);
-                const float sig = expf(P[no.sigma + d]);
-                var = sig * sig;
-                const float mu = a.max_action * th;
-                df = rd[d] - mu;
-                dmu = mu - rd[TC_MEAN + d];
-                if (md.unbounded) {
-                    df = rd[d] - x;
-                    dmu = x - rd[TC_MEAN + d];
-                    th = 0.0f; hs = 1.0f;
-                }
-                lp = -(df * df) / (2.0f * var) - logf(sig) - LOG_SQRT_2PI;
-                const float so = rd[TC_STD + d];
-                so2 = so * so;
-                const float var_ratio = (so / sig) * (so / sig);
-                const float t1 = (dmu / sig) * (dmu / sig);
-                klp = 0.5f * (var_ratio + t1 - 1.0f - logf(var_ratio));
-            }
-            float logp = 0.0f, klrow = 0.0f;
-            for (int dd = 0; dd < Da; ++dd) {
-                logp += __shfl(lp, (lane & 48) + dd, 64);
-                klrow += __shfl(klp, (lane & 48) + dd, 64);
-            }
-            const float lpo = rd[TC_LOGP];
-            const float ratio = expf(logp - lpo);
-            const float ar = rd[TC_ADV], ac = rd[TC_ADV + 1];
-            if (valid && d < Da) {
-                if (a.mode == FB_MODE_SUR) {
-                    const float dL_dlogp = (a.cr * ar + a.cc * ac) * ratio * invN;
-                    sm.dout[i * FSRL_DOW + d] = dL_dlogp * (df / var) * hs * (1.0f - th * th);
-                    sm.dout[i * FSRL_DOW + 16 + d] = dL_dlogp * (df * df / var - 1.0f);
-                } else if (a.mode == FB_MODE_KL) {
-                    sm.dout[i * FSRL_DOW + d] = (dmu / var) * invN * hs * (1.0f - th * th);
-                    sm.dout[i * FSRL_DOW + 16 + d] = (1.0f - (so2 + dmu * dmu) / var) * invN;
-                }
-            }
-            if (valid) {
-                st[0] = ratio * ar; st[1] = ratio * ac; st[2] = klrow; st[3] = lpo - logp;
-                st[4] = ar; st[5] = ac;
+            float dmu_ = 0.0f, dsg_ = 0.0f;
+            fb_tr_actor_head(d < Da ? sm.out[i * FSRL_MAX_ACT + d] : 0.0f, d < Da ? P[no.sigma + d] : 0.0f, rd[d & 3], rd[TC_MEAN + (d & 3)],
+                             rd[TC_STD + (d & 3)], rd[TC_LOGP], rd[TC_ADV], rd[TC_ADV + 1], d, Da, lane, valid, a.mode, a.cr, a.cc,
+                             a.max_action, invN, md.unbounded, dmu_, dsg_, st);
+            if (valid && d < Da && (a.mode == FB_MODE_SUR || a.mode == FB_MODE_KL)) {
+                sm.dout[i * FSRL_DOW + d] = dmu_;
+                sm.dout[i * FSRL_DOW + 16 + d] = dsg_;
             }
         } else {
             const int c = net - 1;
