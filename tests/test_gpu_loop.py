@@ -355,10 +355,12 @@ def test_closed_trust_region_loop_tracks_the_reference_learning_curve(kind):
     else:
         assert np.mean([d[0] for d in diffs]) <= 0.25 * span, ([d[0] for d in diffs], span)
         assert max(d[1] for d in diffs) <= 12.0 and np.mean([d[1] for d in diffs]) <= 6.0, [d[1] for d in diffs]
-        # line search: the same outcome while the runs are still correlated (cycle 0), and afterwards never more than four
-        # backtracks (0.8^4) apart -- both runs sit between 6 and 10 backtracks in every cycle (observed: equal in 3..5 of 8)
+        # line search: the same outcome while the runs are still correlated (r5: cycles 0-3), and afterwards -- two decorrelated
+        # trajectories of a chaotic loop -- never further apart than the range both runs cover: 5 to 10 backtracks in every cycle
+        # (r4 build: 6 to 10, bar four; r5's Gauss-Newton first repeat and contraction-free loss head moved the device's
+        # trajectory, not its distribution: equal in 4 of 8 cycles)
         backs = [abs(np.log(d[2] / d[3]) / np.log(0.8)) for d in diffs]
-        assert backs[0] < 1e-3 and max(backs) <= 4.05, backs
+        assert backs[0] < 1e-3 and max(backs) <= 5.05, backs
         ref_fall = float(g["curve"][0][1] - g["curve"][-1][1])
         assert diffs[0][4] - diffs[-1][4] >= 0.5 * ref_fall, (diffs[0][4], diffs[-1][4], ref_fall)
     pol.engine.close()
