@@ -320,8 +320,8 @@ def test_full_size_update_vs_oracle(repeat):
 
 
 # observed on MI355X (deterministic kernels; three boxes, profiles/r05_fullsize_bars.txt) -> asserted at 3x
-FULL_BARS = {"c2full": dict(tight_steps=10, pass1_stat=1.6e-2, theta_max=8.4e-3, theta_mean=6.8e-5),       # 5.32e-3 / 2.80e-3 / 2.24e-5
-             "c5rank": dict(tight_steps=10, pass1_stat=4.3e-5, theta_max=1.1e-6, theta_mean=1.6e-8)}       # 1.42e-5 / 3.35e-7 / 5.33e-9
+FULL_BARS = {"c2full": dict(tight_steps=50, pass1_stat=1.6e-2, theta_max=8.4e-3, theta_mean=6.8e-5),       # 53 steps / 5.32e-3 / 2.80e-3 / 2.24e-5
+             "c5rank": dict(tight_steps=78, pass1_stat=4.3e-5, theta_max=1.1e-6, theta_mean=1.6e-8)}       # all 78 / 1.42e-5 / 3.35e-7 / 5.33e-9
 
 
 @pytest.mark.parametrize("name", ["c2full", "c5rank"])
@@ -514,7 +514,8 @@ def test_full_size_kl_early_stop_vs_reference():
     """BASELINE configs[1] with the KL early stop ON at full size (target_kl 0.02 = the reference default, ppo_lag_agent.py:95; lr
     1.5e-4): the unmodified reference runs 2 of its 4 passes (pass-mean KL 0.0262, then 0.0366 > 1.5 x 0.02; ppo_lag.py:251-255).
     The device must stop after the same pass (its one 24-byte read-back per pass decides), log the same 156 rows and land on
-    the same parameters: statistics at 3x the one-pass figures of c2full, the pass-mean KL that decides at 1e-3 relative."""
+    the same parameters: statistics at 3x the device's measured distance (3.6e-5 of scale over all 156 steps), the pass-mean KL
+    that decides at 1e-5 relative."""
     cfg, g, steps = ppo_full_case("c2full_klstop")
     assert int(g["passes_run"]) == 2
     eng = _engine(cfg)
@@ -530,9 +531,10 @@ def test_full_size_kl_early_stop_vs_reference():
     early = np.abs(stats[:10] - ref[:10]).max(0)
     assert (early <= 2e-5 * scale + 2e-5).all(), f"first 10 steps: {early}"
     kl = stats[:, 5].reshape(2, 78).mean(1); kl_ref = ref[:, 5].reshape(2, 78).mean(1)
-    print("klstop: pass-mean KL device", kl, "reference", kl_ref, "worst statistic / scale", (np.abs(stats - ref) / scale).max())
-    np.testing.assert_allclose(kl, kl_ref, rtol=1e-3)
-    assert ((np.abs(stats - ref) / scale).max(0) <= 1.6e-2).all(), (np.abs(stats - ref) / scale).max(0)
     d = np.abs(eng.get_params() - g["theta_final"])
-    assert d.max() <= 8.4e-3 and d.mean() <= 6.8e-5, (d.max(), d.mean())
+    print("klstop: pass-mean KL device", kl, "reference", kl_ref, "worst statistic / scale", (np.abs(stats - ref) / scale).max(),
+          "theta max / mean", d.max(), d.mean())
+    np.testing.assert_allclose(kl, kl_ref, rtol=1e-5)                  # observed: equal to 7 digits
+    assert ((np.abs(stats - ref) / scale).max(0) <= 1.2e-4).all(), (np.abs(stats - ref) / scale).max(0)     # observed 3.6e-5 (lr 1.5e-4: the
+    assert d.max() <= 8.4e-3 and d.mean() <= 6.8e-5, (d.max(), d.mean())                                    # trajectories stay together)
     eng.close()
