@@ -51,6 +51,13 @@ __device__ __forceinline__ int co_first_tile(const CoSched& cs, int* s_next) {
     return *s_next;
 }
 
+// A/B build only (-DFSRL_CO_SETPRIO): waves raise their issue priority while they run a GEMM phase
+#ifdef FSRL_CO_SETPRIO
+#define CO_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define CO_PRIO(n) do { } while (0)
+#endif
+
 template <int H>
 struct HvpCoSmem {
     static constexpr int LD = H + 4;
@@ -156,6 +163,7 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
         }
     // ---- layer 2 tangent:  R{z2} = W2 R{h1} + V2 h1   (per column group: W2 fragments, then V2 fragments, same registers)
     f32x4 rz[2][NH];
+    CO_PRIO(2);
 #pragma unroll 1
     for (int g = 0; g < 2; ++g) {
         const int cg = wave + g * WAVES;
@@ -169,6 +177,7 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
         mma_rows_n<H, NH>(h1, wf, li, q, rz[g]);
         __builtin_amdgcn_sched_barrier(0);            // the next group's fragment loads stay behind this group's MFMAs (64 VGPRs each)
     }
+    CO_PRIO(0);
     __syncthreads();                                  // both slots have been read by every wave; the R{h1} spill is out
     // ---- h2 of this theta -> slot 0
     for (int e = tid; e < R * H4; e += NT) {
@@ -269,6 +278,7 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
     }
     __syncthreads();
     // ---- R{dz1} = relu'(z1) (R{dz2} W2 + dz2 V2), the wave's two column groups; relu'(z1) off the cached h1 (the lane's own elements)
+    CO_PRIO(2);
 #pragma unroll 1
     for (int g = 0; g < 2; ++g) {
         const int cg = wave + g * WAVES;
@@ -296,6 +306,7 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    CO_PRIO(0);
     // ---- the remaining operands of the weight-side products
     for (int e = tid; e < R * H4; e += NT) {
         const int i = e / H4, c4 = e - i * H4;
@@ -444,6 +455,7 @@ __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __r
     __syncthreads();                                  // h1 complete; x^T / W1 in slot 1 are dead
 
     // ---- layer 2 -> h2 (slot 1)
+    CO_PRIO(2);
 #pragma unroll 1
     for (int g = 0; g < 2; ++g) {
         const int cg = wave + g * WAVES;
@@ -462,6 +474,7 @@ __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __r
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    CO_PRIO(0);
     __syncthreads();
 
     // ---- head pre-activations: one wave per (row, output)
@@ -549,6 +562,7 @@ __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __r
     }
     for (int e = tid; e < R * FSRL_DOW; e += NT) DOb[e] = sm.dout[e];
     // ---- dz1 = (dz2 @ W2) * relu'(z1), the wave's two column groups
+    CO_PRIO(2);
 #pragma unroll 1
     for (int g = 0; g < 2; ++g) {
         const int cg = wave + g * WAVES;

@@ -364,7 +364,9 @@ int fsrl_tr_eval(fsrl_ctx* ctx, double* stats8);
 /* Kernel plan of the full-batch path, for A/B timing and the bit-identity tests (no reference counterpart: the reference
  * has one code path).  tile_rows: 0 = automatic (mixed 32- / 16-row tiles; at 256-wide layers, obs_dim <= 64 and act_dim <= 4
  * as TWO co-resident 512-thread workgroups per CU: fb_tile_co_kernel), 16 = 16-row tiles only, 32 = mixed tiles with one
- * 1024-thread workgroup per CU (round 4's kernel).  hvp: 0 = automatic (mixed tiles; the theta-only activations of the KL
+ * 1024-thread workgroup per CU (round 4's kernel); adding 64 runs the critics' regression steps on the compute stream, one
+ * launch after the other, instead of on a stream of their own beside the actor's step (r5; same launches, same order inside
+ * each chain: identical results).  hvp: 0 = automatic (mixed tiles; the theta-only activations of the KL
  * Hessian product are computed by the first product of a conjugate-gradient solve and read back by the others: cpo.py:184-204
  * calls _MVP 10 + 1 times per right-hand side at one theta; the cached products run as two co-resident workgroups per CU at
  * 256-wide layers: fb_hvp_co_kernel), 1 = the 16-row kernel that recomputes everything, 2 = mixed tiles without the cache,

@@ -25,8 +25,10 @@ def main():
     ap.add_argument("--only", default="cpo,trpo")
     ap.add_argument("--delays", action="store_true", help="sweep the start offset of every CU's second resident workgroup")
     a = ap.parse_args()
-    plans = {"r4 kernels, full R-op (32,7)": ("32,7,0", None), "r4 kernels + Gauss-Newton (32,3)": ("32,3,0", None),
-             "co both, full R-op (0,4)": ("0,4,0", None), "co both + Gauss-Newton (0,0) = default": ("0,0,0", None)}
+    plans = {"r4: one workgroup per CU, full R-op, one stream (96,7)": ("96,7,0", None),
+             "co + Gauss-Newton, one stream (64,0)": ("64,0,0", None),
+             "r4 kernels, critics beside the actor (32,7)": ("32,7,0", None),
+             "co + Gauss-Newton + critics beside the actor (0,0) = default": ("0,0,0", None)}
     res = {}
     for rnd in range(a.rounds):
         for kind, od, ep in (("cpo", 60, 1000), ("trpo", 8, 250)):
