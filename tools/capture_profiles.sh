@@ -45,11 +45,25 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_cvpo -- python $R/tools/bench_cvpo.py --updates 300 --no-cpu > /dev/null 2>&1
 cd $R
 timeout 600 python tools/bench_trust.py > $O/${TAG}_bench_trust.json 2>/dev/null
-timeout 300 python tools/learning_curves.py > $O/${TAG}_learning_curves.json 2>/dev/null
+[ -z "${FSRL_CAPTURE_FAST:-}" ] && timeout 300 python tools/learning_curves.py > $O/${TAG}_learning_curves.json 2>/dev/null
+if [ -z "${FSRL_CAPTURE_FAST:-}" ]; then       # FSRL_CAPTURE_FAST=1: skip what did not change this round (the r04 files stay the record)
 timeout 300 python tools/learning_curves.py --task point-circle --agents ppol,cpo,sacl --epochs 25 > $O/${TAG}_learning_curves_pointcircle.json 2>/dev/null
 timeout 300 python tools/bench_shmem.py > $O/${TAG}_bench_shmem.json 2>/dev/null
 # microbenchmarks the DESIGN notes quote: device-wide barrier flavours, workgroup dispatch rate (prebuilt: tools/ubench/*.bin)
 [ -x tools/ubench/gridsync.bin ] && { timeout 60 tools/ubench/gridsync.bin 217; timeout 60 tools/ubench/gridsync.bin 256; } > $O/${TAG}_ubench_gridsync.txt 2>&1
 [ -x tools/ubench/dispatch.bin ] && timeout 60 tools/ubench/dispatch.bin > $O/${TAG}_ubench_dispatch.txt 2>&1
 [ -x tools/ubench/chain.bin ] && timeout 120 tools/ubench/chain.bin 78 > $O/${TAG}_ubench_chain.txt 2>&1
+fi
+# r5: the GEMM inner loops in isolation (16x16x4 vs 32x32x2), where a 2-per-CU launch lands, the full-batch kernel plans side by side
+[ -x tools/ubench/mfma_pat.bin ] && timeout 60 tools/ubench/mfma_pat.bin > $O/${TAG}_ubench_mfma_pat.txt 2>&1
+[ -x tools/ubench/hwid.bin ] && timeout 60 tools/ubench/hwid.bin > $O/${TAG}_ubench_hwid.txt 2>&1
+timeout 600 python tools/ab_trust_co.py --rounds 2 > $O/${TAG}_ab_trust_plans.json 2>/dev/null
+# per-kernel counter means of the trust-region run (co-resident kernels beside round 4's): summarised here, the raw files are large
+cd /tmp
+for SET in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum"; do
+  T=$(echo $SET | tr ' ' '_' | cut -c1-40)
+  timeout 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d /tmp/${TAG}_pmcx/$T -- python $R/tools/ab_trust_co.py --rounds 1 --only cpo > /dev/null 2>&1
+done
+python $R/tools/pmc_summary.py $O/${TAG}_pmc_trust_plans.json /tmp/${TAG}_pmcx/* > /dev/null 2>&1
+cd $R
 ls $O | head -40

@@ -33,7 +33,9 @@ for src, dst in ((f"{tag}_bench.json", f"{tag}_bench.json"), (f"{tag}_bench_prof
                  (f"{tag}_learning_curves.json", f"{tag}_learning_curves.json"),
                  (f"{tag}_learning_curves_pointcircle.json", f"{tag}_learning_curves_pointcircle.json"), (f"{tag}_bench_shmem.json", f"{tag}_bench_shmem.json"),
                  (f"{tag}_ubench_gridsync.txt", f"{tag}_ubench_gridsync.txt"), (f"{tag}_ubench_dispatch.txt", f"{tag}_ubench_dispatch.txt"),
-                 (f"{tag}_ubench_chain.txt", f"{tag}_ubench_chain.txt")):
+                 (f"{tag}_ubench_chain.txt", f"{tag}_ubench_chain.txt"), (f"{tag}_ubench_mfma_pat.txt", f"{tag}_ubench_mfma_pat.txt"),
+                 (f"{tag}_ubench_hwid.txt", f"{tag}_ubench_hwid.txt"), (f"{tag}_ab_trust_plans.json", f"{tag}_ab_trust_plans.json"),
+                 (f"{tag}_pmc_trust_plans.json", f"{tag}_pmc_trust_plans.json")):
     if os.path.exists(os.path.join(go, src)):
         shutil.copy(os.path.join(go, src), os.path.join(pr, dst))
 for sub, dst in ((f"{tag}_prof_bench", f"{tag}_kernel_stats.csv"), (f"{tag}_prof_sac", f"{tag}_sac_kernel_stats.csv"),
