@@ -172,12 +172,56 @@ def build(tag):
     if g:
         add(f"Grouped launches (`profiles/{tag}_bench_group.json`): " +
             ", ".join(f"k = {x['agents_per_gpu']}: {fmt(x['aggregate_updates_per_s'])}" for x in g) + " updates/s aggregate.\n")
-    for name, title in ((f"{tag}_ubench_gridsync.txt", "Device-wide barrier inside a kernel (`tools/ubench/gridsync.hip`)"),
-                        (f"{tag}_ubench_dispatch.txt", "Workgroup dispatch rate (`tools/ubench/dispatch.hip`)"),
-                        (f"{tag}_ubench_chain.txt", "Three launches per step vs ONE launch whose blocks wait for lower-numbered blocks (`tools/ubench/chain.hip`)")):
-        f = os.path.join(PR, name)
-        if os.path.exists(f):
-            add(f"{title}, `profiles/{name}`:\n\n```\n" + open(f).read().strip() + "\n```\n")
+    # ---- r5: the full-batch kernel plans side by side (same box, alternated), the co-resident kernels' counters, the GEMM loops alone
+    ab = [x for x in jl(f"{tag}_ab_trust_plans.json") if "alg" in x]
+    f = os.path.join(PR, f"{tag}_ab_trust_plans.json")
+    if ab:
+        med = {}
+        for x in ab:
+            med.setdefault((x["alg"], x["plan"]), []).append(x["ms"])
+        add(f"Full-batch kernel plans on one box, alternated (`tools/ab_trust_co.py`, `profiles/{tag}_ab_trust_plans.json`; ms per update, median):\n")
+        plans = []
+        for (alg, plan) in med:
+            if plan not in plans:
+                plans.append(plan)
+        add("| plan (fsrl_tr_set_plan tile_rows, hvp) | CPO configs[2] | TRPO-Lag |\n|---|---|---|")
+        for plan in plans:
+            c_ = sorted(med.get(("cpo", plan), [float("nan")])); t_ = sorted(med.get(("trpo", plan), [float("nan")]))
+            add(f"| {plan} | {fmt(c_[len(c_) // 2], 2)} | {fmt(t_[len(t_) // 2], 2)} |")
+        add("")
+    f = os.path.join(PR, f"{tag}_pmc_trust_plans.json")
+    if os.path.exists(f):
+        pj = json.load(open(f))
+        names = [n for n in pj if any(k in n for k in ("fb_hvp_co", "fb_hvp_mixed_kernel<256, true", "fb_tile_co", "fb_tile_mixed", "fb_wgrad_kernel"))]
+        if names:
+            add(f"Counter means per launch of the full-batch kernels (own PMC passes over `tools/ab_trust_co.py --only cpo`; `profiles/{tag}_pmc_trust_plans.json`; "
+                "cycles per SIMD = SQ_VALU_MFMA_BUSY_CYCLES / 1024, GPU cycles = GRBM_GUI_ACTIVE / 8 XCDs, LDS cycles per CU = SQ_LDS_IDX_ACTIVE / 256):\n")
+            add("| kernel | launches | GPU cycles | MFMA-busy cycles per SIMD | busy % | LDS-active cycles per CU | of them bank conflicts | wave residency (cycles, mean) |\n|---|---|---|---|---|---|---|---|")
+            for n in sorted(names):
+                v = pj[n]
+                g = lambda k: (v.get(k) or {}).get("mean")     # noqa: E731
+                gui = (g("GRBM_GUI_ACTIVE") or 0) / 8; mf = (g("SQ_VALU_MFMA_BUSY_CYCLES") or 0) / 1024
+                lds = (g("SQ_LDS_IDX_ACTIVE") or 0) / 256; bc = (g("SQ_LDS_BANK_CONFLICT") or 0) / 256
+                wc = g("SQ_WAVE_CYCLES"); wv = g("SQ_WAVES")
+                add(f"| `{n[:60]}` | {int((v.get('GRBM_GUI_ACTIVE') or {}).get('launches', 0))} | {fmt(gui, 0)} | {fmt(mf, 0)} | "
+                    f"{fmt(100 * mf / gui if gui else None, 1)} | {fmt(lds, 0)} | {fmt(bc, 0)} | {fmt(4 * wc / wv if wc and wv else None, 0)} |")
+            add("")
+
+    def newest(name):
+        """this tag's file, or the newest earlier round's (a fast capture does not repeat what did not change)"""
+        n0 = int(tag[1:])
+        for n in range(n0, 0, -1):
+            cand = f"r{n:02d}_{name}"
+            if os.path.exists(os.path.join(PR, cand)):
+                return cand
+        return None
+    for name, title in (("ubench_mfma_pat.txt", "The GEMM inner loops in isolation: 16x16x4 dependent chains vs 32x32x2 (`tools/ubench/mfma_pat.hip`)"),
+                        ("ubench_gridsync.txt", "Device-wide barrier inside a kernel (`tools/ubench/gridsync.hip`)"),
+                        ("ubench_dispatch.txt", "Workgroup dispatch rate (`tools/ubench/dispatch.hip`)"),
+                        ("ubench_chain.txt", "Three launches per step vs ONE launch whose blocks wait for lower-numbered blocks (`tools/ubench/chain.hip`)")):
+        cand = newest(name)
+        if cand:
+            add(f"{title}, `profiles/{cand}`:\n\n```\n" + open(os.path.join(PR, cand)).read().strip() + "\n```\n")
     return "\n".join(L)
 
 
