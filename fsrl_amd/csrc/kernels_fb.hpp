@@ -460,9 +460,9 @@ __global__ __launch_bounds__(4 * H) void fb_tile_kernel(const float* __restrict_
 // to fb_tile_kernel<H, 16>.
 template <int H>
 __global__ __launch_bounds__(4 * H) void fb_tile_mixed_kernel(const float* __restrict__ P, const ModelDesc md, const FbArgs a,
-                                                             const int n32, const int n16, const int ny, const int b0) {
+                                                             const int n32, const int n16, const int ny) {
     __shared__ TileSmem<H, 32> sm;
-    int b = blockIdx.x + b0;          // b0 > 0: this launch takes the tail of the tile list only (r5: behind a co-resident launch)
+    int b = blockIdx.x;
     if (b < ny * n32) {
         const int y = b / n32, t = b - y * n32;
         fb_tile_body<H, 32>(sm, P, md, a, 32 * t, 2 * t, y, ny);
@@ -1039,9 +1039,9 @@ __device__ __forceinline__ void hvp_tile_body(Hvp32Smem<H>& sm, const float* __r
 // rows = two full rounds, then 226 x 16 rows, instead of 625 x 32 rows = two rounds and a 44 %-full third).
 template <int H, bool CACHED>
 __global__ __launch_bounds__(4 * H) void fb_hvp_mixed_kernel(const float* __restrict__ P, const ModelDesc md, const HvpArgs a,
-                                                            const int n32, const int b0) {
+                                                            const int n32) {
     __shared__ Hvp32Smem<H> sm;
-    const int b = blockIdx.x + b0;    // b0 > 0: the tail of the tile list only
+    const int b = blockIdx.x;
     if (b < n32) hvp_tile_body<H, CACHED, 2>(sm, P, md, a, 32 * b);
     else hvp_tile_body<H, CACHED, 1>(sm, P, md, a, 32 * n32 + 16 * (b - n32));
 }

@@ -366,8 +366,7 @@ int fsrl_tr_eval(fsrl_ctx* ctx, double* stats8);
  * as TWO co-resident 512-thread workgroups per CU: fb_tile_co_kernel), 16 = 16-row tiles only, 32 = mixed tiles with one
  * 1024-thread workgroup per CU (round 4's kernel); adding 64 runs the critics' regression steps on the compute stream, one
  * launch after the other, instead of on a stream of their own beside the actor's step (r5; same launches, same order inside
- * each chain: identical results); adding 128 keeps the trailing 16-row tiles inside the co-resident launches (by default they
- * go to the 1024-thread kernel in a small launch of their own: a workgroup alone on its CU is slow).  hvp: 0 = automatic (mixed tiles; the theta-only activations of the KL
+ * each chain: identical results).  hvp: 0 = automatic (mixed tiles; the theta-only activations of the KL
  * Hessian product are computed by the first product of a conjugate-gradient solve and read back by the others: cpo.py:184-204
  * calls _MVP 10 + 1 times per right-hand side at one theta; the cached products run as two co-resident workgroups per CU at
  * 256-wide layers: fb_hvp_co_kernel), 1 = the 16-row kernel that recomputes everything, 2 = mixed tiles without the cache,

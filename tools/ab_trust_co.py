@@ -28,7 +28,6 @@ def main():
     plans = {"r4: one workgroup per CU, full R-op, one stream (96,7)": ("96,7,0", None),
              "co + Gauss-Newton, one stream (64,0)": ("64,0,0", None),
              "r4 kernels, critics beside the actor (32,7)": ("32,7,0", None),
-             "co + Gauss-Newton + critics beside the actor, 16-row tail inside the co launches (128,0)": ("128,0,0", None),
              "co + Gauss-Newton + critics beside the actor (0,0) = default": ("0,0,0", None)}
     res = {}
     for rnd in range(a.rounds):
