@@ -1,4 +1,5 @@
-"""clean per-tile timings: the cached HVP and the tile kernel on batches of exactly k x 256 32-row tiles (and 16-row ones)"""
+"""Per-tile timings of the full-batch kernels: the cached HVP and the tile kernel on batches of exactly k x 256 32-row tiles (and
+16-row ones) under every kernel plan; run under `rocprofv3 --kernel-trace` and reduce with tools/trace_by_grid.py."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
