@@ -73,11 +73,8 @@ static_assert(sizeof(HvpCoSmem<256>) <= 80 * 1024, "two workgroups per CU");
 // the machine scheduler hoists the second group's fragment loads over the first group's MFMAs and runs the two row halves one after
 // the other, keeping 2-4 fragment sets alive through scratch (400-1000 spilled dwords per lane, measured); as runtime loops the
 // kernel needs 116 VGPRs and no scratch, and the fragment loads travel a chunk or two ahead of the MFMAs that consume them.
-// One tile of 16 NH rows starting at row0.  CACHED: h1 / h2 / dout / dz2 of this theta are in A1 / A2 / DO / D2 (a conjugate-gradient
-// solve's 2nd .. 11th product); else this is the first product at a theta: layer 1 and the z GEMM run too and leave those four
-// behind.  (Round 4's first-product kernel needs a whole CU: beside the critic lane's launches it waited for one to drain --
-// 316 us on average instead of 172.)
-template <int H, int NH, bool GN, bool CACHED>
+// One tile of 16 NH rows starting at row0 of the CACHED product (h1 / h2 / dout / dz2 of this theta are in A1 / A2 / DO / D2).
+template <int H, int NH, bool GN>
 __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __restrict__ P, const ModelDesc& md,
                                             const HvpArgs& a, const int row0) {
     constexpr int LD = HvpCoSmem<H>::LD;
@@ -100,11 +97,10 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
     float* dout = sm.xd; float* rdout = sm.xd + 32 * FSRL_DOW;
 
     // ---- h1 of this theta -> slot 0 ; observations (transposed) ; the head threads' mean_old / std_old (registers)
-    if constexpr (CACHED)
-        for (int e = tid; e < R * H4; e += NT) {
-            const int i = e / H4, c4 = e - i * H4;
-            *reinterpret_cast<f32x4*>(&h1[i * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(a.A1 + base + (size_t)i * H + 4 * c4);
-        }
+    for (int e = tid; e < R * H4; e += NT) {
+        const int i = e / H4, c4 = e - i * H4;
+        *reinterpret_cast<f32x4*>(&h1[i * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(a.A1 + base + (size_t)i * H + 4 * c4);
+    }
     for (int e = tid; e < R * Do; e += NT) {
         const int i = e / Do, k = e - i * Do;
         sm.xd[k * 32 + i] = (i < n_valid) ? a.obs[(size_t)row0 * Do + e] : 0.0f;
@@ -119,23 +115,19 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
     }
     __syncthreads();
 
-    // ---- layer 1 (first product only) and its tangent on MFMA, the wave's two column groups:  R{h1} = relu'(z1) (V1 x + vb1).
-    //      relu'(z1) of the lane's own outputs is kept as bits (the first product reads it back for R{dz1}: its h1 slot is gone by then)
-    unsigned m1bits = 0u;
+    // ---- layer-1 tangent on MFMA, the wave's two column groups:  R{h1} = relu'(z1) (V1 x + vb1)
 #pragma unroll 1
     for (int g = 0; g < 2; ++g) {
         const int cg = wave + g * WAVES;
-        f32x4 acc[NH], racc[NH];
+        f32x4 racc[NH];
 #pragma unroll
-        for (int hf = 0; hf < NH; ++hf) acc[hf] = racc[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* __restrict__ wrow = P + no.W1 + (size_t)(cg * 16 + li) * Do;
+        for (int hf = 0; hf < NH; ++hf) racc[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* __restrict__ vrow = V + no.W1 + (size_t)(cg * 16 + li) * Do;
         for (int k0 = 0; k0 < Do; k0 += 64) {
-            float b_[16], vb_[16];
+            float vb_[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int k = k0 + 4 * s + q;
-                if constexpr (!CACHED) b_[s] = (k < Do) ? wrow[k] : 0.0f;
                 vb_[s] = (k < Do) ? vrow[k] : 0.0f;
             }
 #pragma unroll
@@ -145,39 +137,24 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
 #pragma unroll
                     for (int hf = 0; hf < NH; ++hf) {
                         const float a_ = (k < Do) ? sm.xd[k * 32 + 16 * hf + li] : 0.0f;
-                        if constexpr (!CACHED) acc[hf] = mfma_16x16x4(a_, b_[s], acc[hf]);
                         racc[hf] = mfma_16x16x4(a_, vb_[s], racc[hf]);
                     }
                 }
             }
         }
         const int j = cg * 16 + li;
-        const float b1 = CACHED ? 0.0f : P[no.b1 + j];
         const float vb1 = V[no.b1 + j];
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int l = (16 * hf + 4 * q + r) * LD + j;
-                bool on;
-                if constexpr (CACHED) on = h1[l] > 0.0f;
-                else {
-                    const float z = acc[hf][r] + b1;
-                    on = z > 0.0f;
-                    h1[l] = on ? z : 0.0f;
-                    m1bits |= (on ? 1u : 0u) << (8 * g + 4 * hf + r);
-                }
-                rh1[l] = on ? racc[hf][r] + vb1 : 0.0f;
+                rh1[l] = (h1[l] > 0.0f) ? racc[hf][r] + vb1 : 0.0f;
             }
         }
     }
     __syncthreads();                                  // R{h1} complete; the observation tile is dead
     for (int e = tid; e < R * FSRL_DOW; e += NT) { dout[e] = 0.0f; rdout[e] = 0.0f; }
-    if constexpr (!CACHED)                            // h1 of this theta for the later products (and the weight side)
-        for (int e = tid; e < R * H4; e += NT) {
-            const int i = e / H4, c4 = e - i * H4;
-            store4_fb(a.A1 + base + (size_t)i * H + 4 * c4, *reinterpret_cast<const f32x4*>(&h1[i * LD + 4 * c4]));
-        }
     // R{h1} leaves for the weight-side kernel (dz2^T R{h1}: not in the Gauss-Newton form, where dz2 = 0)
     if constexpr (!GN)
         for (int e = tid; e < R * H4; e += NT) {
@@ -185,7 +162,7 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
             store4_fb(a.RA1 + base + (size_t)i * H + 4 * c4, *reinterpret_cast<const f32x4*>(&rh1[i * LD + 4 * c4]));
         }
     // ---- layer 2 tangent:  R{z2} = W2 R{h1} + V2 h1   (per column group: W2 fragments, then V2 fragments, same registers)
-    f32x4 rz[2][NH], zz[CACHED ? 1 : 2][NH];
+    f32x4 rz[2][NH];
     CO_PRIO(2);
 #pragma unroll 1
     for (int g = 0; g < 2; ++g) {
@@ -194,11 +171,6 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
         for (int hf = 0; hf < NH; ++hf) rz[g][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
         FwdW2Frag<H> wf;
         wf.load(P + no.W2f, cg, lane);
-        if constexpr (!CACHED) {                      // z2 = W2 h1 (first product)
-#pragma unroll
-            for (int hf = 0; hf < NH; ++hf) zz[g][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
-            mma_rows_n<H, NH>(h1, wf, li, q, zz[g]);
-        }
         mma_rows_n<H, NH>(rh1, wf, li, q, rz[g]);
         __builtin_amdgcn_sched_barrier(0);            // one fragment set (64 VGPRs) in flight at a time: the partner workgroup fills the gap
         wf.load(V + no.W2f, cg, lane);
@@ -207,32 +179,22 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
     }
     CO_PRIO(0);
     __syncthreads();                                  // both slots have been read by every wave; the R{h1} spill is out
-    // ---- h2 of this theta -> slot 0 (read back, or computed by the first product), R{h2} = relu'(z2) (R{z2} + vb2) -> slot 1
-    if constexpr (CACHED) {
-        for (int e = tid; e < R * H4; e += NT) {
-            const int i = e / H4, c4 = e - i * H4;
-            *reinterpret_cast<f32x4*>(&h2[i * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(a.A2 + base + (size_t)i * H + 4 * c4);
-        }
-        __syncthreads();
+    // ---- h2 of this theta -> slot 0
+    for (int e = tid; e < R * H4; e += NT) {
+        const int i = e / H4, c4 = e - i * H4;
+        *reinterpret_cast<f32x4*>(&h2[i * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(a.A2 + base + (size_t)i * H + 4 * c4);
     }
-#pragma unroll
+    __syncthreads();
+#pragma unroll 1
     for (int g = 0; g < 2; ++g) {
         const int j = (wave + g * WAVES) * 16 + li;
-        const float bias = CACHED ? 0.0f : P[no.b2 + j];
         const float vbias = V[no.b2 + j];
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int l = (16 * hf + 4 * q + r) * LD + j;
-                bool on;
-                if constexpr (CACHED) on = h2[l] > 0.0f;
-                else {
-                    const float z = zz[g][hf][r] + bias;
-                    on = z > 0.0f;
-                    h2[l] = on ? z : 0.0f;
-                }
-                rh2[l] = on ? rz[g][hf][r] + vbias : 0.0f;
+                rh2[l] = (h2[l] > 0.0f) ? rz[g][hf][r] + vbias : 0.0f;
             }
         }
     }
@@ -258,11 +220,6 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
             }
         }
     }
-    if constexpr (!CACHED)
-        for (int e = tid; e < R * H4; e += NT) {
-            const int i = e / H4, c4 = e - i * H4;
-            store4_fb(a.A2 + base + (size_t)i * H + 4 * c4, *reinterpret_cast<const f32x4*>(&h2[i * LD + 4 * c4]));
-        }
     // R{h2} leaves (dout^T R{h2}: not in the Gauss-Newton form); slot 1 is free after the barrier
     if constexpr (!GN)
         for (int e = tid; e < R * H4; e += NT) {
@@ -330,10 +287,7 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if constexpr (CACHED) m1[hf][r] = a.A1[base + (size_t)(16 * hf + 4 * q + r) * H + col];
-                else m1[hf][r] = ((m1bits >> (8 * g + 4 * hf + r)) & 1u) ? 1.0f : 0.0f;
-            }
+            for (int r = 0; r < 4; ++r) m1[hf][r] = a.A1[base + (size_t)(16 * hf + 4 * q + r) * H + col];
         }
         f32x4 acc[NH];
 #pragma unroll
@@ -359,35 +313,28 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
         store4_fb(a.RD2 + base + (size_t)i * H + 4 * c4, *reinterpret_cast<const f32x4*>(&rd2[i * LD + 4 * c4]));
     }
     for (int e = tid; e < R * FSRL_DOW; e += NT) a.RDO[(size_t)row0 * FSRL_DOW + e] = rdout[e];
-    if constexpr (!CACHED && !GN) {                   // dz2 / dout of this theta for the later products' weight side
-        for (int e = tid; e < R * H4; e += NT) {
-            const int i = e / H4, c4 = e - i * H4;
-            store4_fb(a.D2 + base + (size_t)i * H + 4 * c4, *reinterpret_cast<const f32x4*>(&d2[i * LD + 4 * c4]));
-        }
-        for (int e = tid; e < R * FSRL_DOW; e += NT) a.DO[(size_t)row0 * FSRL_DOW + e] = dout[e];
-    }
 }
 
 // Mixed-height grid like fb_hvp_mixed_kernel: blocks [0, n32) take 32-row tiles, the rest 16-row tiles behind them.
 // 2 H threads, <= 128 VGPRs (4 waves per SIMD) and 78.8 KB of LDS: two workgroups per CU.
 // PERSIST = false: one workgroup per tile (straight-line: 116 VGPRs, no scratch); true: persistent workgroups (A/B)
-template <int H, bool PERSIST, bool GN, bool CACHED = true>
+template <int H, bool PERSIST, bool GN>
 __global__ __launch_bounds__(2 * H, 4) void fb_hvp_co_kernel(const float* __restrict__ P, const ModelDesc md, const HvpArgs a,
                                                             const int n32, const CoSched cs) {
     __shared__ HvpCoSmem<H> sm;
     co_desync(cs);
     if constexpr (!PERSIST) {
         const int b = blockIdx.x;
-        if (b < n32) hvp_co_body<H, 2, GN, CACHED>(sm, P, md, a, 32 * b);
-        else hvp_co_body<H, 1, GN, CACHED>(sm, P, md, a, 32 * n32 + 16 * (b - n32));
+        if (b < n32) hvp_co_body<H, 2, GN>(sm, P, md, a, 32 * b);
+        else hvp_co_body<H, 1, GN>(sm, P, md, a, 32 * n32 + 16 * (b - n32));
     } else {
         __shared__ int s_next;
         int b = co_first_tile(cs, &s_next);
         while (b < cs.total) {
             unsigned nxt = 0u;
             if (threadIdx.x == 0) nxt = atomicAdd(cs.counter, 1u) - cs.base;   // in flight under this tile
-            if (b < n32) hvp_co_body<H, 2, GN, CACHED>(sm, P, md, a, 32 * b);
-            else hvp_co_body<H, 1, GN, CACHED>(sm, P, md, a, 32 * n32 + 16 * (b - n32));
+            if (b < n32) hvp_co_body<H, 2, GN>(sm, P, md, a, 32 * b);
+            else hvp_co_body<H, 1, GN>(sm, P, md, a, 32 * n32 + 16 * (b - n32));
             __syncthreads();                               // the slots and s_next are free
             if (threadIdx.x == 0) s_next = (int)nxt;
             __syncthreads();
