@@ -687,6 +687,14 @@ def main():
                                        "mfma_at_peak": floor_us - floors_us}
         r["step_us"] = step_us
         r["frac_of_latency_floor"] = floor_us / step_us if step_us > 0 else None
+        # what the state restore at the head of every timed update costs (three device-to-device copies, 2.4 MB, on the compute
+        # stream): 50 of them back to back, one synchronisation
+        eng.sync()
+        t_r = time.perf_counter()
+        for _ in range(50):
+            eng.state_restore()
+        eng.sync()
+        r["state_restore_us_inside_every_timed_update"] = (time.perf_counter() - t_r) / 50 * 1e6
         pmc = pmc_traffic()
         if pmc is not None:
             r["traffic"], r["traffic_source"], r["traffic_profile_head"], r["traffic_profile_csrc_sha16"] = pmc
