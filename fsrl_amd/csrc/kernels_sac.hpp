@@ -187,6 +187,12 @@ struct SacActorArgs {
     // actor P2 on obs2 / eps2 into X2 / lp2.  One launch then serves both a' ~ pi(s_{t+n}) for the targets and a ~ pi(s_t)
     // for the actor step -- neither depends on the critic update in between.
     const float* P2; const float* obs2; const float* eps2; float* X2; float* lp2; int tiles_half;
+    // r5, FWD of an update with the library's RNG: every workgroup first DRAWS its rows (sac_sample_row: the Philox counters of
+    // sac_sample_gather_kernel, so the same sample) and gathers them -- the first half obs_next at the chain's end into XN / OBSN,
+    // the second half obs (+ the stored action) into XQ / XP / OBS -- then reads them back as its tile.  One launch less per update.
+    int sg_on;
+    SacSampleArgs sa;
+    SacGatherArgs ga;
 };
 
 template <int H, int R>
@@ -208,6 +214,41 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
     const int n_valid = max(0, min(R, a.B - row0));
     const float invB = 1.0f / (float)a.B;
 
+    if (a.sg_on) {
+        constexpr int BOOK_LDS = 512;
+        __shared__ SacBook book_s[BOOK_LDS];
+        __shared__ int idx_s[16], term_s[16];
+        const bool in_lds = a.sa.env_num <= BOOK_LDS;
+        if (in_lds) {
+            for (int e = tid; e < a.sa.env_num; e += NT) book_s[e] = a.sa.book[e];
+            __syncthreads();
+        }
+        const SacBook* __restrict__ book = in_lds ? book_s : a.sa.book;
+        if (tid < R && row0 + tid < a.B)       // both halves draw their rows: the same counters, the same values, written twice
+            sac_sample_row(a.sa, book, row0 + tid, (uint32_t)a.sa.key, (uint32_t)(a.sa.key >> 32), &idx_s[tid], &term_s[tid]);
+        __syncthreads();
+        const SacGatherArgs& g = a.ga;
+        const int Din = Do + Da;
+        if (second) {
+            for (int e = tid; e < n_valid * Din; e += NT) {
+                const int rl = e / Din, f = e - rl * Din, r = row0 + rl;
+                const size_t s_ = (size_t)idx_s[rl], o = (size_t)r * Din + f;
+                if (f < Do) {
+                    const float ob = g.st.obs[s_ * Do + f];
+                    g.XQ[o] = ob; g.XP[o] = ob; g.OBS[(size_t)r * Do + f] = ob;
+                } else {
+                    g.XQ[o] = g.st.act[s_ * Da + (f - Do)];
+                }
+            }
+        } else {
+            for (int e = tid; e < n_valid * Do; e += NT) {
+                const int rl = e / Do, f = e - rl * Do, r = row0 + rl;
+                const float on = g.st.obs_next[(size_t)term_s[rl] * Do + f];
+                g.XN[(size_t)r * Din + f] = on; g.OBSN[(size_t)r * Do + f] = on;
+            }
+        }
+        __syncthreads();                       // s_waitcnt vmcnt(0) + barrier: the rows read below are this workgroup's own stores
+    }
     TileStage<H> stg;
     stg.issue(Pn, no, Do, 0, obs_ + (size_t)row0 * Do, nullptr, n_valid, tid);
     FwdW2Frag<H> wf;
