@@ -84,7 +84,9 @@ def main(argv=None, emit=True):
            "ms_per_update": dev * 1e3, "samples_per_s": B / dev,
            "config": {"workload": f"SAC-Lag SafetyAntRun shape obs {Do} act {Da} {H}x{H}, store {T * E} rows in HBM, "
                                   f"batch {B}, n_step 2", "updates": a.updates, "blocks_us_per_update": [round(b * 1e6, 1) for b in blocks]},
-           "store_fill_rows_per_s": T * E / fill_s, "dtype": "fp32"}
+           "store_fill_rows_per_s": T * E / fill_s, "dtype": "fp32",
+           # r5 default: sample + gather inside the actors' forward launch; FSRL_SAC_PLAN bits 4 / 1 / 2 add launches back
+           "launches_per_update": 9 + sum(1 for bit in (16, 2, 4) if int(os.environ.get("FSRL_SAC_PLAN", "0")) & bit)}
     # roofline of the whole update (12 launches): algorithmic FLOPs per sample (~4.9 MFLOP at 256x256)
     Fq = 2 * ((Do + Da) * H + H * H + H); Fa = 2 * (Do * H + H * H + H * 2 * Da)
     per_sample = (2 * Fa            # actor forwards at s_{t+n} and s_t
@@ -93,7 +95,7 @@ def main(argv=None, emit=True):
                   + 4 * 2 * Fq      # Q(s, a_pi) forward + input gradient of four Q-nets
                   + 2 * Fa)         # actor backward
     flops = per_sample * B
-    out["roofline"] = {"bound": "mfma", "scope": "whole update (12 launches)", "achieved": flops / dev / 1e12, "peak": 157.3,
+    out["roofline"] = {"bound": "mfma", "scope": "whole update (9 launches)", "achieved": flops / dev / 1e12, "peak": 157.3,
                        "unit": "TFLOP/s", "frac": flops / dev / 1e12 / 157.3, "flops_per_update": flops,
                        "algorithmic_gather_bytes": B * ((2 * Do + Da) * 4 + 17), "traffic": None}
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
