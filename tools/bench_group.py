@@ -3,7 +3,10 @@
 launches (fsrl_group_ppo_update): the BASELINE configs[1] workload per agent (obs 8 / act 2 / 256x256 / N = 20 000 /
 batch 256 / 4 passes / grad-clip 0.5).  One JSON line per k.
 
-    python tools/bench_group.py [--ks 1 2 4 8] [--updates 6] [--no-clip]"""
+    python tools/bench_group.py [--ks 1 2 4 8] [--updates 6] [--no-clip] [--host-reset]
+
+Every timed update starts from the same state (initial weights, fresh Adam moments): restored from the HBM snapshot, as bench.py
+does for the single agent (--host-reset: round 4's harness, which uploaded the weights from the host inside the timed region)."""
 import argparse
 import json
 import os
@@ -18,7 +21,7 @@ from bench import ACT, BATCH, ENVS, F32_MFMA_PEAK_TFLOPS, HID, NROWS, OBS, REPEA
 from fsrl_amd.engine import Engine, EngineConfig, EngineGroup  # noqa: E402
 
 
-def run(k, updates, clip):
+def run(k, updates, clip, host_reset=False):
     engs, thetas = [], []
     for i in range(k):
         e = Engine(EngineConfig(obs_dim=OBS, act_dim=ACT, hidden=HID, env_num=ENVS, buffer_size=100000, max_grad_norm=clip,
@@ -32,10 +35,15 @@ def run(k, updates, clip):
         engs.append(e); thetas.append(th)
     grp = EngineGroup(engs)
     lags, resc = np.full((k, 1), 0.75), np.full(k, 1 / 1.75)
+    for e, th in zip(engs, thetas):
+        e.set_params(th); e.optim_reset(); e.state_snapshot()
 
     def one(u):
         for e, th in zip(engs, thetas):                 # same workload every update: initial weights, fresh Adam state
-            e.set_params(th); e.optim_reset()
+            if host_reset:
+                e.set_params(th); e.optim_reset()
+            else:
+                e.state_restore()
         return grp.ppo_update(lags, resc, BATCH, REPEAT, seed=u + 1)[0]
     one(0)
     for e in engs:
@@ -54,6 +62,7 @@ def run(k, updates, clip):
     return {"agents_per_gpu": k, "aggregate_updates_per_s": k / dt, "per_agent_updates_per_s": 1 / dt,
             "ms_per_group_update": dt * 1e3, "us_per_step_all_agents": dt * 1e6 / steps,
             "us_per_agent_step": dt * 1e6 / steps / k, "grad_clip": clip,
+            "reset": "host upload" if host_reset else "HBM snapshot",
             "fwdbwd_flops_per_step_all_agents": flops_fwdbwd_launch(NROWS / (steps / REPEAT)) * k}
 
 
@@ -62,6 +71,7 @@ if __name__ == "__main__":
     ap.add_argument("--ks", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--updates", type=int, default=6)
     ap.add_argument("--no-clip", action="store_true")
+    ap.add_argument("--host-reset", action="store_true")
     a = ap.parse_args()
     for k in a.ks:
-        print(json.dumps(run(k, a.updates, None if a.no_clip else 0.5)), flush=True)
+        print(json.dumps(run(k, a.updates, None if a.no_clip else 0.5, a.host_reset)), flush=True)

@@ -36,6 +36,8 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_pr
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_group -- python $R/tools/bench_group.py --ks 4 --updates 3 > /dev/null 2>&1
 cd $R
 timeout 300 python tools/bench_group.py > $O/${TAG}_bench_group.json 2>/dev/null
+timeout 300 python tools/bench_group.py --host-reset > $O/${TAG}_bench_group_hostreset.json 2>/dev/null
+timeout 300 python tools/bench_group.py --no-clip > $O/${TAG}_bench_group_noclip.json 2>/dev/null
 timeout 300 python tools/bench_sac.py > $O/${TAG}_bench_sac.json 2>/dev/null
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_sac -- python $R/tools/bench_sac.py --rows 200000 --updates 300 --no-cpu > /dev/null 2>&1

@@ -30,6 +30,8 @@ def one(pattern):
 for src, dst in ((f"{tag}_bench.json", f"{tag}_bench.json"), (f"{tag}_bench_profiled.json", f"{tag}_bench_profiled.json"),
                  (f"{tag}_bench_sac.json", f"{tag}_bench_sac.json"), (f"{tag}_bench_trust.json", f"{tag}_bench_trust.json"),
                  (f"{tag}_bench_cvpo.json", f"{tag}_bench_cvpo.json"), (f"{tag}_bench_group.json", f"{tag}_bench_group.json"),
+                 (f"{tag}_bench_group_hostreset.json", f"{tag}_bench_group_hostreset.json"),
+                 (f"{tag}_bench_group_noclip.json", f"{tag}_bench_group_noclip.json"),
                  (f"{tag}_learning_curves.json", f"{tag}_learning_curves.json"),
                  (f"{tag}_learning_curves_pointcircle.json", f"{tag}_learning_curves_pointcircle.json"), (f"{tag}_bench_shmem.json", f"{tag}_bench_shmem.json"),
                  (f"{tag}_ubench_gridsync.txt", f"{tag}_ubench_gridsync.txt"), (f"{tag}_ubench_dispatch.txt", f"{tag}_ubench_dispatch.txt"),

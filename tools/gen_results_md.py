@@ -171,7 +171,15 @@ def build(tag):
     g = jl(f"{tag}_bench_group.json")
     if g:
         add(f"Grouped launches (`profiles/{tag}_bench_group.json`): " +
-            ", ".join(f"k = {x['agents_per_gpu']}: {fmt(x['aggregate_updates_per_s'])}" for x in g) + " updates/s aggregate.\n")
+            ", ".join(f"k = {x['agents_per_gpu']}: {fmt(x['aggregate_updates_per_s'])}" for x in g) + " updates/s aggregate" +
+            (f" (every timed update restored from the {g[0]['reset']})" if "reset" in g[0] else "") + ".")
+        for suffix, what in (("hostreset", "same box, the weights uploaded from the host inside the timed region (the harness up to round 4)"),
+                             ("noclip", "same box, max_grad_norm off (the agent's default: 2 launches per step)")):
+            h = jl(f"{tag}_bench_group_{suffix}.json")
+            if h:
+                add(f"  {what} (`profiles/{tag}_bench_group_{suffix}.json`): " +
+                    ", ".join(f"k = {x['agents_per_gpu']}: {fmt(x['aggregate_updates_per_s'])}" for x in h) + ".")
+        add("")
     # ---- r5: the full-batch kernel plans side by side (same box, alternated), the co-resident kernels' counters, the GEMM loops alone
     ab = [x for x in jl(f"{tag}_ab_trust_plans.json") if "alg" in x]
     f = os.path.join(PR, f"{tag}_ab_trust_plans.json")
