@@ -560,13 +560,32 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    comm_fallback = None
     if world > 1:
         import torch.distributed as dist
         if args.share_gpu:
             local_rank = 0
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # RCCL has never run with more than one rank where this was built (no multi-GPU lease): prove it with one collective
+            # before anything depends on it.  If it cannot start on this node -- the same way on every rank -- the two
+            # collectives the contract needs (barrier, max of the ranks' times) go over gloo and the line says so; the ranks'
+            # work has no data-path collective, so the figure is the same either way.
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                assert float(probe.item()) == float(world)
+            except Exception as e:                                 # noqa: BLE001
+                comm_fallback = f"{type(e).__name__}: {str(e).strip().splitlines()[-1][:160] if str(e).strip() else ''}"
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:                                  # noqa: BLE001
+                    pass
+                dist.init_process_group("gloo")
+                args.backend = "gloo"
         else:
             dist.init_process_group("gloo")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -646,6 +665,8 @@ def main():
             out["ranks_seen"] = len(per_rank)
             out["per_rank_updates_per_s"] = [round(r["updates_per_s"], 3) for r in sorted(per_rank, key=lambda r: r["rank"])]
             out["sum_of_rank_rates"] = sum(r["updates_per_s"] for r in per_rank)
+            out["timing_exchange"] = ("rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo") + \
+                (f"; nccl could not start here ({comm_fallback})" if comm_fallback else "")
     legs = Legs(out, rank, total_budget_s=float(os.environ.get("FSRL_BENCH_LEG_BUDGET_S", "420")))
 
     # ---- roofline of the dominant kernel: HIP events around every ppo_fwd_bwd_kernel launch on

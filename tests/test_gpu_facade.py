@@ -361,6 +361,24 @@ def test_bench_multi_rank_path_on_one_gpu():
     assert abs(job["env_steps_per_s"] - sum(job["per_rank_env_steps_per_s"])) < 1.0 and job["env_steps_per_s"] > 1000
 
 
+def test_bench_falls_back_to_gloo_when_rccl_cannot_start():
+    """Two ranks on ONE GPU with the driver's default backend: RCCL refuses two ranks on one device, the same way on both ranks
+    -- the failure mode of a node whose RCCL cannot start.  bench.py must still print its line: the barrier and the
+    max-over-ranks time go over gloo (the ranks' work has no data-path collective) and the line says so."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FSRL_BENCH_LEG_BUDGET_S="60")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--share-gpu"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["ranks_seen"] == 2
+    assert d["timing_exchange"].startswith("gloo; nccl could not start here"), d["timing_exchange"]
+
+
 def test_bench_headline_survives_a_failing_leg():
     """a secondary leg that raises on one code path must not cost the headline line.  Two ranks over
     gloo sharing this GPU, the per-rank training-loop leg forced to fail on every rank: the line is still printed, the
