@@ -22,6 +22,7 @@
 #include "kernels_fb.hpp"
 #include "kernels_fbco.hpp"
 #include "kernels_wgrad2.hpp"
+#include "kernels_wgrad3.hpp"
 #include "kernels_layered.hpp"
 
 // ------------------------------------------------------------------------------ errors
@@ -164,6 +165,8 @@ struct fsrl_ctx {
     int n_cus = 256;                // compute units of the device (tile-shape heuristic)
     bool wgrad_xcd = false;         // fb_wgrad_kernel: XCD-aware placement of the splits (fsrl_tr_set_plan)
     bool wgrad_stream = false;      // fsrl_tr_set_plan(wgrad = 3): fb_wgrad2_kernel (one streaming pass per workgroup) where it applies
+    int wgrad_tiles = 1;            // r6: fb_wgrad3_kernel (every workgroup a 64 x 64 tile job, two per CU) where it applies: 1 = default
+                                    // (XCD-aware order), 0 = off (fsrl_tr_set_plan wgrad 1 / 2 / 3), bit 1 = plain block order, bit 2 = half the splits
     struct FocState* foc = nullptr; // FOCOPS working set, owned
     float* mu_old = nullptr;        // [maxsize][Da] actor means at process time (FOCOPS)
     float* sigma_old = nullptr;     // [FSRL_MAX_ACT] sigma_param at process time (FOCOPS)
@@ -270,6 +273,28 @@ static int ensure_parts(fsrl_ctx* c, int stride, int nsplit) {
 template <bool PAIR2>
 static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int ny, int stride, int* nsplit) {
     const int H_ = c->cfg.hidden;
+    // r6 default at 256 wide over a few thousand rows or more, for the callers that hand over the re-laid observations: every
+    // workgroup a 64 x 64 tile job (kernels_wgrad3.hpp), 512 threads, two per CU, ONE round of at most 2 x CUs workgroups
+    if (H_ == 256 && wa.rows >= 4096 && wa.obs_pad && c->wgrad_tiles) {
+        for (int y = 0; y < ny; ++y)
+            CHECK_ARG(wa.nets[y].b1_src == wa.nets[y].w1_y && wa.nets[y].b2_src == wa.nets[y].w2_ya && wa.nets[y].do_src == wa.nets[y].w3_ya,
+                      "fb_wgrad3_kernel takes the bias sums off the operands of the matrix products");
+        constexpr int NP = PAIR2 ? 2 : 1;
+        const int NB = 16 * NP + 4 * wa.obs_ko + 2 * NP, KS = wa.rows >> 2;
+        int ns = std::max(1, std::min(24 / NP, 2 * c->n_cus / (NB * ny)));
+        if (c->wgrad_tiles & 4) ns = std::max(1, ns / 2);
+        const int per = round_up((KS + ns - 1) / ns, 8);
+        ns = (KS + per - 1) / per;
+        int rc = ensure_parts(c, stride, NP * ns);
+        if (rc) return rc;
+        wa.out = c->wg_parts; wa.split_stride = stride; wa.ks_per_split = per;
+        wa.remap_total = NB * ny * ns; wa.remap_ny = ny; wa.wg3_flags = (c->wgrad_tiles & 2) ? 0 : 1;
+        *nsplit = NP * ns;                                  // the consumers add NP x ns partials (pair b's slots behind pair a's)
+        wa.dbg_skip = c->probe_wgrad_skip;                  // 0 outside probe builds
+        hipLaunchKernelGGL((fb_wgrad3_kernel<256>), dim3(round_up(wa.remap_total, 8)), dim3(512), 0, c->compute, md, wa, NP, ns);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     // fsrl_tr_set_plan(wgrad = 3), 256-wide layers over a few thousand rows or more: the one-pass streaming form
     // (kernels_wgrad2.hpp) -- a workgroup per (network, output quarter, row slice), ONE round of workgroups, slices of a multiple
     // of 32 rows.  It moves 2.6x fewer bytes (160 vs 413-430 MB per launch at N = 20 000) in the same time (80 vs 82 us for the

@@ -1074,6 +1074,9 @@ struct FbWgradArgs {
     // blocks -- the blocks of one split, which stream the same rows -- behind one L2.
     int remap_total, remap_ny;
     int aux_passes;     // passes over the rows an aux column block needs (1 + the dW1 chunks beyond the first pass): one BLOCK per pass
+    // fb_wgrad3_kernel (kernels_wgrad3.hpp) only: the observations re-laid for float4 operand loads ([rows][64 * obs_ko], zero-filled;
+    // null = the caller has none and the launch keeps fb_wgrad_kernel), and bit 0 of wg3_flags = XCD-aware block order
+    const float* obs_pad; int obs_ko; int wg3_flags;
 };
 
 // one pass of an aux block of fb_wgrad_kernel over its rows: NCH 16-column chunks of dW1 (columns k0 ..), and with FIRST the

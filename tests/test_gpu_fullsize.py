@@ -308,15 +308,16 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
         out["theta_trpo"] = eng.get_params().copy()
         return out
 
-    # the tile / HVP plans are bit-identical under EITHER weight-gradient kernel (wgrad 0: the split-K kernel, the default;
-    # wgrad 3: the one-pass streaming kernel where it applies -- 256-wide layers, >= 4096 rows)
+    # the tile / HVP plans are bit-identical under EVERY weight-gradient kernel (wgrad 0: r6's tile jobs, two workgroups per CU,
+    # the default where it applies -- 256-wide layers, >= 4096 rows; wgrad 2: round 5's split-K kernel; wgrad 3: the one-pass
+    # streaming kernel)
     refs = {}
-    for wg in (3, 0):
+    for wg in (3, 2, 0):
         ref = refs[wg] = run(16, 1, wg)
         assert np.isfinite(ref["cpo"]).all() and np.isfinite(ref["trpo"]).all() and np.abs(ref["hvp"]).max() > 0
         # (32, 3): round 4's one-workgroup-per-CU kernels; (0, 0): round 5's co-resident pairs where they apply (256 wide)
         # tile_rows + 64: the critics' steps on the compute stream, behind each other, instead of beside the actor's step (r5)
-        for plan in ((0, 2, wg), (0, 0, wg), (16, 0, wg), (32, 3, wg), (32, 0, wg), (0, 3, wg), (64, 0, wg), (96, 3, wg)) + (((0, 0, 1), ) if wg == 0 else ()):
+        for plan in ((0, 2, wg), (0, 0, wg), (16, 0, wg), (32, 3, wg), (32, 0, wg), (0, 3, wg), (64, 0, wg), (96, 3, wg)) + (((0, 0, 1), ) if wg == 2 else ((0, 0, 4), ) if wg == 0 else ()):
             got = run(*plan)
             for k in ref:
                 assert np.array_equal(ref[k], got[k]), (plan, k, np.abs(np.asarray(ref[k], np.float64) - got[k]).max())
@@ -324,8 +325,8 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
     # classes, 32-64 vs <= 24 partials in float64): the building blocks agree to 2e-5 of the vector's largest entry (the
     # tolerance of the autograd comparison in test_gpu_trust.py); whole updates -- conjugate gradients amplify summation
     # order, DESIGN "conditioning note" -- at the fixture tolerances of test_gpu_trust.py (2e-2 on what is downstream of CG)
-    a, b = refs[3], refs[0]
-    if hid == 256 and envs * T >= 4096:
+    for a, b in ((refs[3], refs[2]), (refs[0], refs[2])):
+      if hid == 256 and envs * T >= 4096:
         for k in ("grad0", "grad1", "grad2", "hvp"):
             scale = max(float(np.abs(b[k]).max()), 1e-12)
             assert float(np.abs(a[k] - b[k]).max()) <= 2e-5 * scale, (k, float(np.abs(a[k] - b[k]).max()), scale)
@@ -344,9 +345,9 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
         for k in ("theta_cpo", "theta_trpo"):
             d = np.abs(a[k] - b[k])
             assert d.max() <= 5e-3 and d.mean() <= 5e-5, (k, d.max(), d.mean())
-    else:
+      else:
         for k in a:
-            assert np.array_equal(a[k], b[k]), k                         # below the new kernel's range nothing changes
+            assert np.array_equal(a[k], b[k]), k                         # below the new kernels' range nothing changes
     eng.tr_set_plan(0, 0, 0)
     eng.close()
 
@@ -397,7 +398,7 @@ def test_co_resident_kernels_match_one_workgroup_per_cu(obs_dim, T, at_theta_old
     ref = run(32, 3)
     assert np.array_equal(ref["hvp"], ref["hvp_cached"]) and np.abs(ref["hvp"]).max() > 0 and np.isfinite(ref["cpo"]).all()
     bad = []
-    # (-1, -1): persistent workgroups drawing tiles from the device counter, automatic tile mix; (-2, -2): one workgroup per tile
+    # (-1, -1): one workgroup per tile (the default), automatic tile mix; (-2, -2): PERSISTENT workgroups drawing tiles from the device counter
     for split in ((-1, -1), (-2, -2), (N // 32, N // 32), (0, 0), (1, 1), (300, 100)):
         got = run(0, 0, split)
         for k in ref:
@@ -419,7 +420,7 @@ def test_co_resident_kernels_match_one_workgroup_per_cu(obs_dim, T, at_theta_old
 
 
 def test_streaming_weight_gradients_vs_autograd_at_full_size():
-    """fb_wgrad2_kernel (256-wide layers, N = 20 000, obs 60: four 16-column chunks of dW1 with a ragged last one) against torch
+    """The weight-gradient kernels (256-wide layers, N = 20 000, obs 60: four 16-column chunks of dW1 with a ragged last one) against torch
     autograd of the oracle's losses on the same batch: the two surrogate gradients, the KL gradient away from theta_old, and
     three Hessian-vector products of the mean KL (cpo.py:177-182, 206-220), for both weight-gradient kernels.  2e-5 / 5e-5 of
     the vector's largest entry, the bars of the small-fixture test (tests/test_gpu_trust.py).  The critics' gradients take the
@@ -453,7 +454,7 @@ def test_streaming_weight_gradients_vs_autograd_at_full_size():
         scale = max(float(np.abs(b).max()), 1e-12)
         err = float(np.abs(np.asarray(a) - np.asarray(b)).max())
         assert err <= rel * scale, (err, scale)
-    for plan in (3, 0):
+    for plan in (3, 2, 5, 0):          # streaming | round 5's split-K | r6's tile jobs with half the row splits | r6 default
         eng.tr_set_plan(0, 0, plan)
         close(eng.tr_grad(0), og, 2e-5)
         close(eng.tr_grad(1), ob, 2e-5)

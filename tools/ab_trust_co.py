@@ -24,11 +24,21 @@ def main():
     ap.add_argument("--splits", action="store_true", help="also sweep forced 32-row tile counts of the co-resident launches")
     ap.add_argument("--only", default="cpo,trpo")
     ap.add_argument("--delays", action="store_true", help="sweep the start offset of every CU's second resident workgroup")
+    ap.add_argument("--plan", default=None, help="run ONE plan 'tile_rows,hvp,wgrad' only (profiling runs)")
+    ap.add_argument("--wgrad", action="store_true", help="r6: the weight-gradient kernels against each other on the default tile plan")
     a = ap.parse_args()
     plans = {"r4: one workgroup per CU, full R-op, one stream (96,7)": ("96,7,0", None),
              "co + Gauss-Newton, one stream (64,0)": ("64,0,0", None),
              "r4 kernels, critics beside the actor (32,7)": ("32,7,0", None),
              "co + Gauss-Newton + critics beside the actor (0,0) = default": ("0,0,0", None)}
+    if a.wgrad:
+        plans = {"r5 split-K weight gradients (0,0,2)": ("0,0,2", None),
+                 "streaming weight gradients (0,0,3)": ("0,0,3", None),
+                 "r6 tile jobs, two per CU, XCD-aware order (0,0,0) = default": ("0,0,0", None),
+                 "r6 tile jobs, plain block order (0,0,4)": ("0,0,4", None),
+                 "r6 tile jobs, half the row splits (0,0,5)": ("0,0,5", None)}
+    if a.plan:
+        plans = {f"plan ({a.plan})": (a.plan, None)}
     res = {}
     for rnd in range(a.rounds):
         for kind, od, ep in (("cpo", 60, 1000), ("trpo", 8, 250)):
