@@ -275,12 +275,18 @@ static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int n
     const int H_ = c->cfg.hidden;
     // r6 default at 256 wide over a few thousand rows or more, for the callers that hand over the re-laid observations: every
     // workgroup a 64 x 64 tile job (kernels_wgrad3.hpp), 512 threads, two per CU, ONE round of at most 2 x CUs workgroups
-    if (H_ == 256 && wa.rows >= 4096 && wa.obs_pad && c->wgrad_tiles) {
+    // Narrow observations (<= 32 columns) keep round 5's kernel unless the plan forces the tile jobs (wgrad 4 / 5 / 6): its aux role is
+    // one pass there and the launch is balanced as it is (TRPO-Lag at obs 8, same box: 23.4 vs 23.7 ms); at obs 60 (CPO configs[2])
+    // the aux role is 16 of 50 workgroups per split and the tile jobs win: 32.3 -> 31.1 ms, 362 -> 163 MB per launch.
+    const bool wg3_auto = c->wgrad_tiles == 1 ? md.Do > 32 : c->wgrad_tiles != 0;
+    if (H_ == 256 && wa.rows >= 4096 && wa.obs_pad && wg3_auto) {
         for (int y = 0; y < ny; ++y)
             CHECK_ARG(wa.nets[y].b1_src == wa.nets[y].w1_y && wa.nets[y].b2_src == wa.nets[y].w2_ya && wa.nets[y].do_src == wa.nets[y].w3_ya,
                       "fb_wgrad3_kernel takes the bias sums off the operands of the matrix products");
         constexpr int NP = PAIR2 ? 2 : 1;
-        const int NB = 16 * NP + 4 * wa.obs_ko + 2 * NP, KS = wa.rows >> 2;
+        int NB = 16 * NP + 2 * NP;                          // dW2 tile jobs + dW3 jobs, + the dW1 jobs of every observation group
+        for (int ko = 0; ko < wa.obs_ko; ++ko) NB += wg3_ujobs(md.Do, ko);
+        const int KS = wa.rows >> 2;
         int ns = std::max(1, std::min(24 / NP, 2 * c->n_cus / (NB * ny)));
         if (c->wgrad_tiles & 4) ns = std::max(1, ns / 2);
         const int per = round_up((KS + ns - 1) / ns, 8);
@@ -291,7 +297,7 @@ static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int n
         wa.remap_total = NB * ny * ns; wa.remap_ny = ny; wa.wg3_flags = (c->wgrad_tiles & 2) ? 0 : 1;
         *nsplit = NP * ns;                                  // the consumers add NP x ns partials (pair b's slots behind pair a's)
         wa.dbg_skip = c->probe_wgrad_skip;                  // 0 outside probe builds
-        hipLaunchKernelGGL((fb_wgrad3_kernel<256>), dim3(round_up(wa.remap_total, 8)), dim3(512), 0, c->compute, md, wa, NP, ns);
+        hipLaunchKernelGGL((fb_wgrad3_kernel<256>), dim3(round_up(wa.remap_total, 8)), dim3(512), 0, c->compute, md, wa, NP, ns, NB);
         HIPCHK(hipGetLastError());
         return 0;
     }

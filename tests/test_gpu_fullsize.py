@@ -308,16 +308,16 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
         out["theta_trpo"] = eng.get_params().copy()
         return out
 
-    # the tile / HVP plans are bit-identical under EVERY weight-gradient kernel (wgrad 0: r6's tile jobs, two workgroups per CU,
-    # the default where it applies -- 256-wide layers, >= 4096 rows; wgrad 2: round 5's split-K kernel; wgrad 3: the one-pass
-    # streaming kernel)
+    # the tile / HVP plans are bit-identical under EVERY weight-gradient kernel (wgrad 4: r6's tile jobs, two workgroups per CU,
+    # wherever they apply -- 256-wide layers, >= 4096 rows; wgrad 2: round 5's split-K kernel; wgrad 3: the one-pass streaming
+    # kernel); wgrad 0 = automatic: the tile jobs (in XCD-aware block order: same sums) above 32 observation columns, else split-K
     refs = {}
-    for wg in (3, 2, 0):
+    for wg in (3, 2, 4):
         ref = refs[wg] = run(16, 1, wg)
         assert np.isfinite(ref["cpo"]).all() and np.isfinite(ref["trpo"]).all() and np.abs(ref["hvp"]).max() > 0
         # (32, 3): round 4's one-workgroup-per-CU kernels; (0, 0): round 5's co-resident pairs where they apply (256 wide)
         # tile_rows + 64: the critics' steps on the compute stream, behind each other, instead of beside the actor's step (r5)
-        for plan in ((0, 2, wg), (0, 0, wg), (16, 0, wg), (32, 3, wg), (32, 0, wg), (0, 3, wg), (64, 0, wg), (96, 3, wg)) + (((0, 0, 1), ) if wg == 2 else ((0, 0, 4), ) if wg == 0 else ()):
+        for plan in ((0, 2, wg), (0, 0, wg), (16, 0, wg), (32, 3, wg), (32, 0, wg), (0, 3, wg), (64, 0, wg), (96, 3, wg)) + (((0, 0, 1), ) if wg == 2 else ()):
             got = run(*plan)
             for k in ref:
                 assert np.array_equal(ref[k], got[k]), (plan, k, np.abs(np.asarray(ref[k], np.float64) - got[k]).max())
@@ -325,7 +325,11 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
     # classes, 32-64 vs <= 24 partials in float64): the building blocks agree to 2e-5 of the vector's largest entry (the
     # tolerance of the autograd comparison in test_gpu_trust.py); whole updates -- conjugate gradients amplify summation
     # order, DESIGN "conditioning note" -- at the fixture tolerances of test_gpu_trust.py (2e-2 on what is downstream of CG)
-    for a, b in ((refs[3], refs[2]), (refs[0], refs[2])):
+    auto = run(0, 0, 0)
+    same_as = refs[4] if obs_dim > 32 else refs[2]
+    for k in auto:
+        assert np.array_equal(auto[k], same_as[k]), ("automatic weight-gradient plan", k)
+    for a, b in ((refs[3], refs[2]), (refs[4], refs[2])):
       if hid == 256 and envs * T >= 4096:
         for k in ("grad0", "grad1", "grad2", "hvp"):
             scale = max(float(np.abs(b[k]).max()), 1e-12)
