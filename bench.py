@@ -130,6 +130,105 @@ def cpu_baseline(theta, inputs, seconds=12.0, threads=4, hid=None):
                       f"{_usable_cpus():g} usable (affinity / cgroup quota)"}
 
 
+def torch_rocm_baseline(inputs, updates=2, seconds=20.0):
+    """Context, never a target and never on the product path: the reference's ONLY GPU path is stock PyTorch with
+    `device="cuda"` (fsrl/agent/ppo_lag_agent.py:136-145 puts the Tianshou nets on the device; ppo_lag.py:214-257 then runs
+    312 autograd steps with ~12 `.item()` read-backs each).  This leg runs that update -- same workload, same structure: per-
+    critic value passes + a host GAE scan (base_policy.py:427-446), then repeat x Batch.split minibatches of forward, losses,
+    backward, clip_grad_norm_, one Adam over all nets, the logged scalars read back per step -- with torch.nn / torch.optim
+    on THIS GPU through ROCm PyTorch, so the hand-written path is shown against the same chip, not only against 4 CPU threads.
+    Written here from the reference's call structure with stock modules (it is a comparator, not the oracle, and checks
+    nothing)."""
+    import torch
+    from scipy.signal import lfilter
+    from torch import nn
+    from torch.distributions import Independent, Normal
+    dev = torch.device("cuda", torch.cuda.current_device())
+    torch.manual_seed(0)
+
+    def mlp(out):
+        m = nn.Sequential(nn.Linear(OBS, HID), nn.ReLU(), nn.Linear(HID, HID), nn.ReLU(), nn.Linear(HID, out))
+        for l in m:
+            if isinstance(l, nn.Linear):
+                nn.init.orthogonal_(l.weight); nn.init.zeros_(l.bias)
+        return m.to(dev)
+    actor, critics = mlp(ACT), [mlp(1), mlp(1)]
+    sigma = nn.Parameter(torch.full((ACT, 1), -0.5, device=dev))
+    params = [sigma] + list(actor.parameters()) + [p for c in critics for p in c.parameters()]
+    optim = torch.optim.Adam(params, lr=5e-4)
+    obs, act, rew, cost, term, trunc = inputs
+    em = lambda a: np.concatenate([a[:, e] for e in range(ENVS)])
+    h_obs, h_next, h_act = em(obs[:-1]), em(obs[1:]), em(act)
+    metrics = [em(rew).astype(np.float64), em(cost).astype(np.float64)]
+    end = em(term | trunc); mask = ~em(term)
+    gamma, lam_gae, eps_clip, lag, resc = 0.99, 0.95, 0.2, 0.75, 1.0 / 1.75
+    bounds = np.flatnonzero(end) + 1
+    starts = np.concatenate([[0], bounds[:-1]]) if len(bounds) else np.array([0])
+    if len(bounds) == 0 or bounds[-1] != NROWS:
+        starts, bounds = np.append(starts, bounds[-1] if len(bounds) else 0), np.append(bounds, NROWS)
+
+    def dist_of(o):
+        mu = torch.tanh(actor(o))
+        return Independent(Normal(mu, (sigma.view(1, -1) + torch.zeros_like(mu)).exp()), 1)
+
+    def one_update(rng):
+        # process_fn: values on the device, the scan on the host (the reference's numba gae_return), back to the device
+        t_obs = torch.as_tensor(h_obs, device=dev); t_next = torch.as_tensor(h_next, device=dev); t_act = torch.as_tensor(h_act, device=dev)
+        advs, rets = [], []
+        with torch.no_grad():
+            for i, c in enumerate(critics):
+                v = c(t_obs).flatten().cpu().numpy(); vn = c(t_next).flatten().cpu().numpy() * mask
+                delta = metrics[i] + gamma * vn - v
+                adv = np.empty(NROWS)
+                for a, b in zip(starts, bounds):          # discounted reverse cumulative sum per episode segment
+                    adv[a:b] = lfilter([1.0], [1.0, -gamma * lam_gae], delta[a:b][::-1])[::-1]
+                advs.append(torch.as_tensor(adv, dtype=torch.float32, device=dev))
+                rets.append(torch.as_tensor(adv + v, dtype=torch.float32, device=dev))
+            logp_old = dist_of(t_obs).log_prob(t_act)
+        advs, rets = torch.stack(advs, -1), torch.stack(rets, -1)
+        steps = 0
+        for _ in range(REPEAT):
+            perm = rng.permutation(NROWS)
+            chunks = [perm[i:i + BATCH] for i in range(0, NROWS, BATCH)]
+            if len(chunks) > 1 and len(chunks[-1]) < BATCH:        # merge_last
+                chunks[-2] = np.concatenate([chunks[-2], chunks[-1]]); chunks.pop()
+            for idx in chunks:
+                ix = torch.as_tensor(idx, device=dev)
+                o, a, adv, ret, lo = t_obs[ix], t_act[ix], advs[ix].clone(), rets[ix], logp_old[ix]
+                d = dist_of(o)
+                logp = d.log_prob(a)
+                ratio = (logp - lo).exp().reshape(1, -1)
+                for i in range(2):
+                    adv[..., i] = (adv[..., i] - adv[..., i].mean()) / adv[..., i].std()
+                s1, s2 = ratio * adv[..., 0], ratio.clamp(1 - eps_clip, 1 + eps_clip) * adv[..., 0]
+                l_rew = -torch.min(s1, s2).mean()
+                l_safe = torch.mean(ratio * adv[..., 1] * lag)
+                l_actor = resc * (l_rew + l_safe)
+                vfs = [(ret[..., i] - critics[i](o).flatten()).pow(2).mean() for i in range(2)]
+                loss = l_actor + 0.25 * (vfs[0] + vfs[1])
+                optim.zero_grad()
+                loss.backward()
+                nn.utils.clip_grad_norm_(params, max_norm=0.5)
+                optim.step()
+                # the reference's logger.store(...) read-backs (ppo_lag.py:196-211, 166-170, 242-247)
+                _ = (l_safe.item(), l_rew.item(), l_actor.item(), (lo - logp).mean().item(), vfs[0].item(), vfs[1].item(),
+                     (vfs[0] + vfs[1]).item(), loss.item(), d.entropy().mean().item())
+                steps += 1
+        return steps
+    rng = np.random.default_rng(0)
+    one_update(rng)                                   # warm-up (allocator, kernel selection)
+    torch.cuda.synchronize()
+    n, steps, t0 = 0, 0, time.perf_counter()
+    while n < updates and time.perf_counter() - t0 < seconds:
+        steps = one_update(rng); n += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "updates/s", "kind": "port on ROCm torch", "device": torch.cuda.get_device_name(dev),
+            "grad_steps_per_update": steps, "us_per_grad_step": dt / max(n * steps, 1) * 1e6,
+            "sample": f"{n} full updates of the same 20k-row workload with stock torch.nn / torch.optim on the GPU (torch {torch.__version__}), "
+                      "one warm-up update before; host GAE scan and per-step .item() read-backs as in the reference"}
+
+
 def gpu_config0(inputs, seed, steps=8):
     """BASELINE configs[0]'s shape (128x128 MLPs, otherwise the headline workload) through the HIP path, beside
     `cpu_baseline_c0`: the reference's CPU-runnable configuration on both sides of this box."""
@@ -466,6 +565,22 @@ def configs_summary(out):
     if isinstance(d, dict) and "ms_per_update" in d:
         c["kl_on"] = {"ms": r(d["ms_per_update"]), "steps": r(d.get("grad_steps_per_update_mean"), 1),
                       "stopped": d.get("updates_stopped_early"), "of": d.get("updates")}
+    # r6: BOTH halves of the headline metric (BASELINE.json: "env-steps/sec + policy-updates/sec") where the record keeps them:
+    # the training loop's env-steps/s (in-process zero-cost env, device actor), the update rate, and how close the worker-process
+    # env at 32 workers x 100 us per step comes to its own bound; at N > 1 the whole job's sum over the ranks
+    d = out.get("end_to_end")
+    if isinstance(d, dict) and "env_steps_per_s" in d:
+        e = {"env_steps_s": r(d["env_steps_per_s"], 0), "updates_s": r(out.get("value"), 1)}
+        for w in out.get("end_to_end_shmem") or []:
+            if isinstance(w, dict) and w.get("workers") == 32 and w.get("busy_us") == 100.0 and "frac_of_env_bound" in w:
+                e["w32_b100_frac_of_bound"] = r(w["frac_of_env_bound"], 2)
+        c["e2e"] = e
+    d = out.get("end_to_end_job")
+    if isinstance(d, dict) and "env_steps_per_s" in d:
+        c["job"] = {"env_steps_s": r(d["env_steps_per_s"], 0), "updates_s": r(out.get("value"), 1), "ranks_ok": d.get("ranks_ok")}
+    d = out.get("torch_rocm_baseline")
+    if isinstance(d, dict) and "value" in d:
+        c["c1_ppo"]["torch_gpu_updates_s"] = r(d["value"], 2)
     return c
 
 
@@ -561,33 +676,41 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     comm_fallback = None
+    nccl_pg = None                   # the RCCL group of the timing exchange (N > 1, when it started on every rank)
     if world > 1:
         import torch.distributed as dist
         if args.share_gpu:
             local_rank = 0
         torch.cuda.set_device(local_rank)
+        # The control plane is ALWAYS a gloo group (barrier, rank agreement, the id broadcast of the library's communicator): it is
+        # created once, first, with an explicit timeout -- no second init_process_group on the same MASTER_PORT whatever RCCL does.
+        from datetime import timedelta
+        dist.init_process_group("gloo", timeout=timedelta(seconds=180))
         if args.backend == "nccl":
-            # RCCL has never run with more than one rank where this was built (no multi-GPU lease): prove it with one collective
-            # before anything depends on it.  If it cannot start on this node -- the same way on every rank -- the two
-            # collectives the contract needs (barrier, max of the ranks' times) go over gloo and the line says so; the ranks'
-            # work has no data-path collective, so the figure is the same either way.
+            # RCCL (a SECOND group) carries the timing exchange when it starts on every rank.  It has never run with more than one
+            # rank where this was built (no multi-GPU lease), so it is proven with one collective before anything depends on it, and
+            # the ranks AGREE on the outcome over gloo: one rank raising while another succeeds cannot leave them in different
+            # groups.  A rank that hangs inside RCCL instead of raising is ended by the group's own timeout (90 s).  The ranks' work
+            # has no data-path collective, so the figure is the same either way; the line says which exchange ran.
+            ok, why = 1, None
             try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                try:
+                    nccl_pg = dist.new_group(backend="nccl", timeout=timedelta(seconds=90), device_id=torch.device("cuda", local_rank))
+                except TypeError:                                   # older torch: no device_id on new_group
+                    nccl_pg = dist.new_group(backend="nccl", timeout=timedelta(seconds=90))
                 probe = torch.ones(1, device="cuda")
-                dist.all_reduce(probe)
+                dist.all_reduce(probe, group=nccl_pg)
                 torch.cuda.synchronize()
                 assert float(probe.item()) == float(world)
             except Exception as e:                                 # noqa: BLE001
-                comm_fallback = f"{type(e).__name__}: {str(e).strip().splitlines()[-1][:160] if str(e).strip() else ''}"
-                try:
-                    if dist.is_initialized():
-                        dist.destroy_process_group()
-                except Exception:                                  # noqa: BLE001
-                    pass
-                dist.init_process_group("gloo")
+                ok = 0
+                why = f"{type(e).__name__}: {str(e).strip().splitlines()[-1][:160] if str(e).strip() else ''}"
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # over gloo: every rank takes the same branch
+            if int(flag.item()) != 1:
+                comm_fallback = why or "another rank could not start RCCL"
+                nccl_pg = None
                 args.backend = "gloo"
-        else:
-            dist.init_process_group("gloo")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from fsrl_amd.engine import Engine, EngineConfig
@@ -637,8 +760,8 @@ def main():
     if dist is not None:
         # the contract's max-over-ranks time, and the SURVEY 8(e) exchange: every rank's figures gathered once
         from fsrl_amd import parallel
-        tt = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tt = torch.tensor([dt], device="cuda" if nccl_pg is not None else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=nccl_pg)     # group None = the gloo control plane
         dt = float(tt.item())
         per_rank = parallel.allgather_metrics({"rank": float(rank), "seed": float(seed), "updates": float(args.steps),
                                                "grad_steps": float(grad_steps * args.steps), "seconds": dt_local,
@@ -761,21 +884,21 @@ def main():
         #      communicator (fsrl_comm_init + fsrl_metrics_allreduce), checked against torch.distributed's sum.  Every rank
         #      first proves it can reach RCCL, so a rank that cannot does not leave the others inside ncclCommInitRank; a
         #      rank that still hangs there trips the watchdog (30 s), which prints the line and ends every rank.
-        if args.backend == "nccl" and os.environ.get("FSRL_BENCH_LIB_COMM", "1") != "0":
+        if nccl_pg is not None and os.environ.get("FSRL_BENCH_LIB_COMM", "1") != "0":
             def lib_comm_leg():
                 try:
                     eng.comm_unique_id(); ok, why = 1.0, None
                 except Exception as e:                          # noqa: BLE001
                     ok, why = 0.0, f"unavailable: {e}"
                 flag = torch.tensor([ok], device="cuda", dtype=torch.float64)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=nccl_pg)
                 if float(flag.item()) != 1.0:
                     return why or "skipped: another rank cannot reach RCCL"
                 eng.comm_init_from_torch()
                 v = np.array([1.0, float(rank), args.steps / dt_local, float(seed)])
                 got = eng.metrics_allreduce(v)
                 want = torch.from_numpy(v).cuda()
-                dist.all_reduce(want, op=dist.ReduceOp.SUM)
+                dist.all_reduce(want, op=dist.ReduceOp.SUM, group=nccl_pg)
                 res = "ok" if np.array_equal(got, want.cpu().numpy()) and eng.comm_info() == (rank, world) else "mismatch"
                 eng.comm_destroy()
                 return res
@@ -786,6 +909,8 @@ def main():
             legs.run("cpu_baseline", lambda: cpu_baseline(theta, inputs), 90.0)
             if isinstance(out.get("cpu_baseline"), dict) and "value" in out["cpu_baseline"]:
                 out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+            # the reference's own GPU path (stock PyTorch on the device) on THIS chip, beside the CPU figure: context only
+            legs.run("torch_rocm_baseline", lambda: torch_rocm_baseline(inputs), 60.0)
             # BASELINE configs[0]: the reference's own CPU-runnable case (128x128, 4 threads: fsrl/config/ppol_cfg.py:11,15)
             legs.run("cpu_baseline_c0", lambda: cpu_baseline(orthogonal_theta(seed, hid=128), inputs, seconds=8.0, threads=4,
                                                              hid=128), 60.0)

@@ -180,8 +180,13 @@ class FastCollector:
                 try:
                     k_steps, csum, obs, act, rew, cost, terminated, truncated, obs_next = eng.collect_run(
                         self.env.native_desc(), ready, obs, act, env_act, det, bound, low, high)
-                finally:
+                except BaseException:
+                    # as in _collect_native: a failed native run may have left a command half-handled on a lane (dead worker,
+                    # HIP error after a posted command) -- the env refuses every later command instead of answering with stale data
                     self.env.sync_native()
+                    self.env.mark_broken("a native collect run failed while env commands were in flight")
+                    raise
+                self.env.sync_native()
                 done = terminated | truncated
                 total_cost += csum
                 step_count += len(ready) * k_steps

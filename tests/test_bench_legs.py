@@ -78,6 +78,20 @@ def test_configs_summary_is_the_last_key_and_compact(capsys):
     assert abs(c["c2_cpo"]["ms"] - rec["cpo_c2"]["hip_ms_per_update"]) < 0.01 and c["c2_cpo"]["frac"] > 0 and c["c2_cpo"]["cpu_updates_s"] > 0
     assert abs(c["c3_sac"]["us"] - rec["sac_c3"]["ms_per_update"] * 1e3) < 0.06 and c["c3_sac"]["cpu_updates_s"] > 0
     assert c["c1_trpo"]["traffic_gb"] > 1 and c["c1_ppo"]["frac"] > 0
+    # r6: both halves of the headline metric in the kept tail: env-steps/s of the training loop beside updates/s
+    assert c["e2e"]["env_steps_s"] == round(rec["end_to_end"]["env_steps_per_s"]) and c["e2e"]["updates_s"] == round(rec["value"], 1)
+    assert 0 < c["e2e"]["w32_b100_frac_of_bound"] <= 1.0
+
+
+def test_configs_summary_carries_the_job_figures_at_n_gt_1():
+    import bench
+    out = {"value": 900.0, "ms_per_step": 8.9, "roofline": {"frac": 0.1, "step_us": 26.0},
+           "end_to_end_job": {"env_steps_per_s": 2.5e6, "policy_updates_per_s": 400.0, "ranks": 8, "ranks_ok": 8},
+           "torch_rocm_baseline": {"value": 1.23456}}
+    c = bench.configs_summary(out)
+    assert c["job"] == {"env_steps_s": 2500000.0, "updates_s": 900.0, "ranks_ok": 8}
+    assert c["c1_ppo"]["torch_gpu_updates_s"] == 1.23 and "e2e" not in c
+    assert len(json.dumps(c)) <= 600
 
 
 def test_headline_workload_string_survives_the_records_cut():

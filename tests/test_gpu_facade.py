@@ -379,6 +379,40 @@ def test_bench_falls_back_to_gloo_when_rccl_cannot_start():
     assert d["timing_exchange"].startswith("gloo; nccl could not start here"), d["timing_exchange"]
 
 
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_bench_eight_ranks_dry_run_on_one_gpu(backend):
+    """The driver's SCALE run is one shot at 8 ranks: this is its dry run on ONE device (--share-gpu) -- eight processes, eight
+    engines and stores in this GPU's HBM, eight training loops on their core slices (the box may have fewer usable CPUs than
+    ranks), the watchdog budgets, the gloo control plane.  `gloo`: the exchange over gloo as asked.  `nccl`: the driver's default
+    -- RCCL refuses eight ranks on one device, every rank agrees on the fallback over the control plane (no second rendezvous on
+    the same port) and the line says so.  Exactly ONE JSON line either way, with the whole job's env-steps/s in the tail key."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FSRL_BENCH_LEG_BUDGET_S="150")
+    port = {"gloo": "29551", "nccl": "29553"}[backend]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--share-gpu"]
+    if backend == "gloo":
+        cmd += ["--backend", "gloo"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 8 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]      # whole-job = ranks / max-over-ranks step time
+    assert d["ranks_seen"] == 8 and len(d["per_rank_updates_per_s"]) == 8
+    assert d["timing_exchange"].startswith("gloo"), d["timing_exchange"]
+    if backend == "nccl":
+        assert "nccl could not start here" in d["timing_exchange"], d["timing_exchange"]
+    job = d["end_to_end_job"]
+    assert job["ranks"] == 8 and job["ranks_ok"] == 8 and len(job["per_rank_env_steps_per_s"]) == 8, job
+    assert job["host_cores_per_rank"] >= 1 and job["env_steps_per_s"] > 1000
+    assert list(d)[-1] == "configs" and len(json.dumps(d["configs"])) <= 600
+    tail = d["configs"]["job"]
+    assert tail["ranks_ok"] == 8 and abs(tail["env_steps_s"] - job["env_steps_per_s"]) <= 1.0 and tail["updates_s"] > 0
+
+
 def test_bench_headline_survives_a_failing_leg():
     """a secondary leg that raises on one code path must not cost the headline line.  Two ranks over
     gloo sharing this GPU, the per-rank training-loop leg forced to fail on every rank: the line is still printed, the
