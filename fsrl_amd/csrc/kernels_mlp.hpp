@@ -826,9 +826,11 @@ __device__ __forceinline__ void ppo_wgrad_extra_block(const ModelDesc& md, const
             float t = 0.0f;
             for (int ch = 0; ch < CH; ++ch) {
                 float v[16];
+                int rbase = 512 * ch;
+                if constexpr (BIG) asm volatile("" : "+s"(rbase));
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
-                    const int r = 512 * ch + php + 32 * u;
+                    const int r = rbase + php + 32 * u;
                     v[u] = (r < mbp) ? DOn[(size_t)r * FSRL_DOW + col] : 0.0f;
                 }
 #pragma unroll
@@ -904,7 +906,11 @@ __device__ __forceinline__ void ppo_wgrad_body(const ModelDesc& md, const WgradP
         const int KS = mbp >> 2;
         f32x4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
         for (int ch = 0; ch < CH; ++ch) {
-            const int s0 = 16 * WG_MAXU * ch;
+            int s0 = 16 * WG_MAXU * ch;
+            // BIG: the chunk base is made opaque to the optimiser.  Left visible, it hoists the 64-bit address of every load of the
+            // burst out of the chunk loop (2 x 8 address pairs here, 5 x 4 in the aux role) and spills them: 167-223 VGPRs, 472-544
+            // bytes of scratch per lane in every BIG instantiation (round 5's code-object notes).  One add per load instead.
+            if constexpr (BIG) asm volatile("" : "+s"(s0));
             f32x2 a[WG_MAXU], b[WG_MAXU];
 #pragma unroll
             for (int u = 0; u < WG_MAXU; ++u) {
@@ -981,12 +987,14 @@ __device__ __forceinline__ void ppo_wgrad_body(const ModelDesc& md, const WgradP
             f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
             for (int ch = 0; ch < CH; ++ch)
             for (int ub = 0; ub < WG_MAXU; ub += 4) {       // 4 k-steps per burst (64 rows / wave set)
-                if (16 * WG_MAXU * ch + wave + 16 * ub >= KS) break;            // wave-uniform
+                int sbase = 16 * WG_MAXU * ch + 16 * ub;
+                if constexpr (BIG) asm volatile("" : "+s"(sbase));             // see the tile role: nothing of a burst is hoisted
+                if (sbase + wave >= KS) break;                                  // wave-uniform
                 f32x2 a1[4], a2[4], a3[4];
                 float bx[4], bd[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {               // one burst of independent loads
-                    const int sidx = 16 * WG_MAXU * ch + wave + 16 * (ub + u);
+                    const int sidx = sbase + wave + 16 * u;
                     a1[u] = f32x2{0.f, 0.f}; a2[u] = f32x2{0.f, 0.f}; a3[u] = f32x2{0.f, 0.f};
                     bx[u] = 0.f; bd[u] = 0.f;
                     if (sidx < KS) {

@@ -24,11 +24,24 @@ class Box:
         self._rng = np.random.default_rng(seed)
 
 
+def stable_coupling(obs_dim):
+    """the `coupling` that keeps the synthetic dynamics as contractive at obs_dim columns as the default is at 8"""
+    return 0.02 * float(np.sqrt(8.0 / max(int(obs_dim), 8)))
+
+
 class SyntheticSafetyVectorEnv:
     """Vector env with the tianshou BaseVectorEnv calling convention the collector uses:
     `len(env)`, `reset(ids=None) -> (obs, info)`, `step(act, ids) -> (obs, rew, term, trunc, info)`."""
 
-    def __init__(self, env_num=20, obs_dim=8, act_dim=2, episode_len=300, seed=0, busy_us=0.0):
+    def __init__(self, env_num=20, obs_dim=8, act_dim=2, episode_len=300, seed=0, busy_us=0.0, coupling=0.02, cost_threshold=1.0):
+        # coupling: scale of the random part of A = 0.95 I + coupling N(0, 1).  The default keeps every existing fixture; WIDE
+        # observations need coupling = 0.02 sqrt(8 / obs_dim) (`stable_coupling`): the random part's spectral radius grows like
+        # coupling sqrt(obs_dim), and at obs 33 / 60 the default dynamics have eigenvalues of modulus 1.05 / 1.08 -- a 1000-step
+        # episode overflows
+        # cost_threshold: cost = 1 where |state[1]| exceeds it.  The default (1.0) makes a 1000-step episode of an untrained policy cost
+        # several hundred -- against the reference's PID gains (tuned for limits of 10 - 25) the multiplier then swings between 0 and
+        # 100 from one collect to the next; the multi-seed fixtures use a higher threshold so that episode costs sit near the limit
+        self.cost_threshold = float(cost_threshold)
         self.env_num, self.obs_dim, self.act_dim = env_num, obs_dim, act_dim
         self.episode_len, self.busy_us = episode_len, busy_us
         self.observation_space = Box(-np.inf, np.inf, (obs_dim, ))
@@ -37,7 +50,7 @@ class SyntheticSafetyVectorEnv:
         self.spec = SimpleNamespace(id="SyntheticSafety-v0", max_episode_steps=episode_len)   # gym's env.spec (CVPO reads it)
         self.rng = np.random.default_rng(seed)
         k = np.random.default_rng(1234)
-        self.A = (0.95 * np.eye(obs_dim) + 0.02 * k.standard_normal((obs_dim, obs_dim))).astype(np.float32)
+        self.A = (0.95 * np.eye(obs_dim) + coupling * k.standard_normal((obs_dim, obs_dim))).astype(np.float32)
         self.B = (0.3 * k.standard_normal((act_dim, obs_dim))).astype(np.float32)
         self.state = np.zeros((env_num, obs_dim), np.float32)
         self.t = np.zeros(env_num, int)
@@ -66,7 +79,7 @@ class SyntheticSafetyVectorEnv:
         self.state[ids] = s
         self.t[ids] += 1
         rew = (s[:, 0] * act[:, 0] - 0.1 * (act**2).sum(1)).astype(np.float64) + 0.5
-        cost = (np.abs(s[:, 1]) > 1.0).astype(np.float64)
+        cost = (np.abs(s[:, 1]) > self.cost_threshold).astype(np.float64)
         truncated = self.t[ids] >= self.episode_len
         terminated = np.zeros(len(ids), bool)
         while end and time.perf_counter() < end:

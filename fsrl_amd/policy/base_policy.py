@@ -16,6 +16,30 @@ from fsrl_amd.utils.logger import BaseLogger, DummyLogger
 from fsrl_amd.utils.net import ActorCritic
 
 
+class DeviceBatch:
+    """What `process_fn` returns on the HIP path: a HANDLE to the processed batch, which lives in HBM (buffer.sample(0) order:
+    env-major, chronological) -- the reference's process_fn returns the Batch with `values / rets / advs / logp_old` attached
+    (fsrl/policy/base_policy.py:384-451, ppo_lag.py:134-150); here those columns are fetched from the device on first access.
+    `learn(batch, ...)` takes exactly this object back."""
+
+    def __init__(self, engine, n: int, batch_size: int):
+        self.engine, self.n, self.batch_size = engine, int(n), int(batch_size)
+        self._cache = {}
+
+    def __len__(self) -> int:
+        return self.n
+
+    def _get(self, which: str):
+        if which not in self._cache:
+            self._cache[which] = torch.from_numpy(np.ascontiguousarray(self.engine.batch_get(which)))
+        return self._cache[which]
+
+    values = property(lambda self: self._get("values"))          # [N, critics] V(obs) at process time
+    rets = property(lambda self: self._get("rets"))              # [N, critics] GAE returns
+    advs = property(lambda self: self._get("advs"))              # [N, critics] advantages (CPO / TRPO-Lag: normalised over the batch)
+    logp_old = property(lambda self: self._get("logp_old"))      # [N]
+
+
 class BasePolicy(ABC, nn.Module):
     def __init__(self, actor: nn.Module, critics: Union[nn.Module, List[nn.Module]], dist_fn=None,
                  logger: BaseLogger = None, gamma: float = 0.99, max_batchsize: Optional[int] = 99999,
@@ -201,8 +225,10 @@ class BasePolicy(ABC, nn.Module):
     # ------------------------------------------------------------------ update
     @abstractmethod
     def learn(self, batch, **kwargs: Any):
-        """Concrete policies run the whole update on the device in `update()`; `learn` is kept
-        for interface parity and is not called by the trainers here."""
+        """The on-policy agents (PPO-Lag, FOCOPS, CPO, TRPO-Lag): `process_fn(batch, buffer, indices)` returns a DeviceBatch (the
+        library's begin call), `learn(that batch, batch_size, repeat)` runs the passes (the library's pass / learn / end calls);
+        `update()` is the two in a row, as fsrl/policy/base_policy.py:332-355.  The replay agents' update() is ONE library call
+        (sampling, n-step targets and the three optimiser steps are fused on the device): their `learn` says so."""
 
     @abstractmethod
     def update(self, sample_size: int, buffer, **kwargs: Any):

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from fsrl_amd.policy.base_policy import BasePolicy
+from fsrl_amd.policy.base_policy import BasePolicy, DeviceBatch
 from fsrl_amd.policy.trpo_lag import _split_sizes
 
 CPO_ACTOR_KEYS = ("loss/kl", "loss/entropy", "loss/rew_loss", "loss/cost_loss", "loss/optim_A",
@@ -60,20 +60,25 @@ class CPO(BasePolicy):
             for _ in range(forwards):
                 torch.normal(torch.zeros(n_rows, da), torch.ones(n_rows, da))
 
-    def learn(self, batch, **kwargs: Any):
-        raise NotImplementedError("the HIP path runs process_fn + learn inside update()")
-
-    def update(self, sample_size: int, buffer, batch_size: int = 99999, repeat: int = 4, **kwargs: Any):
-        if buffer is None:
-            return {}
-        assert sample_size == 0 and getattr(buffer, "engine", None) is self.engine
+    def process_fn(self, batch=None, buffer=None, indices=None, **kwargs: Any):
+        """cpo.py:123-145 on the device = `fsrl_tr_begin`: sample(0), V / GAE per critic, full-batch advantage normalisation,
+        logp_old / mean_old / std_old.  -> DeviceBatch; `batch` / `indices` ignored (the on-policy batch is the whole store)."""
+        assert getattr(buffer, "engine", None) is self.engine
         self.updating = True
-        eng = self.engine
         g = self.optim.param_groups[0]
-        n = eng.tr_begin(target_kl=self._delta, backtrack_coeff=self._backtrack_coeff,
-                         damping=self._damping_coeff, l2_reg=self._l2_reg, critic_lr=g["lr"],
-                         max_backtracks=self._max_backtracks, optim_critic_iters=self._optim_critic_iters,
-                         cg_iters=10, norm_adv=self._norm_adv, cost_limit=float(self._cost_limit))
+        n = self.engine.tr_begin(target_kl=self._delta, backtrack_coeff=self._backtrack_coeff,
+                                 damping=self._damping_coeff, l2_reg=self._l2_reg, critic_lr=g["lr"],
+                                 max_backtracks=self._max_backtracks, optim_critic_iters=self._optim_critic_iters,
+                                 cg_iters=10, norm_adv=self._norm_adv, cost_limit=float(self._cost_limit))
+        self._pending = DeviceBatch(self.engine, n, 0)
+        return self._pending
+
+    def learn(self, batch, batch_size: int = 99999, repeat: int = 4, **kwargs: Any):
+        """cpo.py:353-370 on the device = `fsrl_cpo_learn[_mb]`; `batch` is what process_fn returned."""
+        assert isinstance(batch, DeviceBatch) and batch is getattr(self, "_pending", None), \
+            "learn() takes the DeviceBatch the last process_fn() returned (the processed batch lives in HBM)"
+        self._pending = None
+        eng, n = self.engine, batch.n
         # Batch.split(batch_size, merge_last=True) inside learn (cpo.py:357-358) draws one np.random.permutation per repeat
         # from numpy's global stream -- also when one minibatch covers the batch (then the order only moves sums and the
         # device keeps store order)
@@ -91,6 +96,17 @@ class CPO(BasePolicy):
             for rows, ev in zip(sizes * repeat, eng.tr_linesearch_evals(cap=len(stats) + 1)):
                 self._burn(rows, 1 + int(ev))
         self._mark_stale()                                       # host mirror refreshed on demand
-        self._step_lr_scheduler()
-        self.updating = False
         return {"gradient_steps": len(stats)}
+
+    def update(self, sample_size: int, buffer, batch_size: int = 99999, repeat: int = 4, **kwargs: Any):
+        """base_policy.py:332-355: sample(0) -> process_fn -> learn -> lr scheduler"""
+        if buffer is None:
+            return {}
+        assert sample_size == 0
+        try:
+            batch = self.process_fn(None, buffer, None)
+            result = self.learn(batch, batch_size=batch_size, repeat=repeat)
+        finally:
+            self.updating = False
+        self._step_lr_scheduler()
+        return result

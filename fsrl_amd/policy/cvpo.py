@@ -128,7 +128,8 @@ class CVPO(BasePolicy):
         return Batch(logits=logits, act=act, state=hidden, dist=dist)
 
     def learn(self, batch, **kwargs: Any):
-        raise NotImplementedError("the HIP path runs process_fn + learn inside update()")
+        raise NotImplementedError("replay agents: update(batch_size, buffer) is ONE library call on the HIP path -- the sample, the n-step "
+                                  "targets (process_fn) and the optimiser steps (learn) are fused on the device; see INTEGRATION.md section 3")
 
     # ------------------------------------------------------------------ update
     def pre_update_fn(self, **kwarg: Any) -> None:

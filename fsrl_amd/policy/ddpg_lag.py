@@ -98,7 +98,8 @@ class DDPGLagrangian(LagrangianPolicy):
         return act + self._noise(act.shape) if isinstance(act, np.ndarray) else act
 
     def learn(self, batch, **kwargs: Any):
-        raise NotImplementedError("the HIP path runs process_fn + learn inside update()")
+        raise NotImplementedError("replay agents: update(batch_size, buffer) is ONE library call on the HIP path -- the sample, the n-step "
+                                  "targets (process_fn) and the optimiser steps (learn) are fused on the device; see INTEGRATION.md section 3")
 
     def _log_rows(self, rows) -> None:
         table = getattr(self.logger, "store_rows", None)         # fsrl_amd loggers take the drained rows at once

@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from fsrl_amd import _lib
-from fsrl_amd.policy.base_policy import BasePolicy
+from fsrl_amd.policy.base_policy import BasePolicy, DeviceBatch
 from fsrl_amd.policy.ppo_lag import _chunk_sizes
 
 FOCOPS_KEYS = ("loss/nu_loss", "loss/nu_value", "loss/actor_loss", "loss/kl", "loss/entropy", "loss/vf0", "loss/vf1",
@@ -47,13 +47,10 @@ class FOCOPS(BasePolicy):
     def update_cost_limit(self, cost_limit: float) -> None:
         self.cost_limit = cost_limit
 
-    def learn(self, batch, **kwargs: Any):
-        raise NotImplementedError("the HIP path runs process_fn + learn inside update()")
-
-    def update(self, sample_size: int, buffer, batch_size: int = 256, repeat: int = 4, **kwargs: Any):
-        if buffer is None:
-            return {}
-        assert sample_size == 0 and getattr(buffer, "engine", None) is self.engine
+    def process_fn(self, batch=None, buffer=None, indices=None, batch_size: int = 256):
+        """focops.py:126-153 on the device: the nu step (:155-158, host float32) + `fsrl_ppo_begin` (sample(0), V / GAE per critic,
+        logp_old, mean_old / std_old).  -> DeviceBatch; `batch` / `indices` ignored (the on-policy batch is the whole store)."""
+        assert getattr(buffer, "engine", None) is self.engine
         self.updating = True
         loss_nu = self.cost_limit - self._ave_cost_return            # focops.py:155-158, float32 tensor arithmetic
         self._nu = self._nu + (-self._nu_lr * loss_nu)
@@ -62,11 +59,28 @@ class FOCOPS(BasePolicy):
         _lib.check(eng.lib.fsrl_focops_set_nu(eng._ctx, float(self._nu), float(loss_nu)))
         n = eng.ppo_begin([0.0], 1.0, batch_size)
         try:
+            if self._reference_rng and (self.training or not self._deterministic_eval):
+                da = eng.cfg.act_dim
+                for m in _chunk_sizes(n, self._max_batchsize):          # process_fn: forward per chunk of max_batchsize
+                    torch.normal(torch.zeros(m, da), torch.ones(m, da))
+        except BaseException:
+            eng.ppo_abort(); self.updating = False
+            raise
+        self._pending = DeviceBatch(eng, n, batch_size)
+        return self._pending
+
+    def learn(self, batch, batch_size: int = 256, repeat: int = 4, **kwargs: Any):
+        """focops.py:205-251 on the device: `fsrl_ppo_pass` x repeat + `fsrl_ppo_end`; `batch` is what process_fn returned."""
+        assert isinstance(batch, DeviceBatch) and batch is getattr(self, "_pending", None), \
+            "learn() takes the DeviceBatch the last process_fn() returned (the processed batch lives in HBM)"
+        self._pending = None
+        eng, n = self.engine, batch.n
+        try:
+            if batch.batch_size != batch_size:                       # another minibatch size than planned: begin again
+                eng.ppo_abort()
+                n = eng.ppo_begin([0.0], 1.0, batch_size)
             burn = self._reference_rng and (self.training or not self._deterministic_eval)
             da = eng.cfg.act_dim
-            if burn:                                                     # process_fn: forward per chunk of max_batchsize
-                for m in _chunk_sizes(n, self._max_batchsize):
-                    torch.normal(torch.zeros(m, da), torch.ones(m, da))
             stopped_at = -1
             perm = np.random.permutation(n) if n > 0 else None           # Batch.split(shuffle=True) of the first pass
             for step in range(repeat):
@@ -100,6 +114,15 @@ class FOCOPS(BasePolicy):
         self.gradient_steps += len(stats)
         self.logger.store(gradient_steps=self.gradient_steps, tab="update")
         self._mark_stale()                                       # host mirror refreshed on demand
+        return {"gradient_steps": len(stats), "early_stop_pass": stopped_at}
+
+    def update(self, sample_size: int, buffer, batch_size: int = 256, repeat: int = 4, **kwargs: Any):
+        """base_policy.py:332-355: sample(0) -> process_fn -> learn -> lr scheduler"""
+        if buffer is None:
+            return {}
+        assert sample_size == 0
+        batch = self.process_fn(None, buffer, None, batch_size=batch_size)
+        result = self.learn(batch, batch_size=batch_size, repeat=repeat)
         self._step_lr_scheduler()
         self.updating = False
-        return {"gradient_steps": len(stats), "early_stop_pass": stopped_at}
+        return result

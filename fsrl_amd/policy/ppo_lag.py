@@ -7,6 +7,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from fsrl_amd.policy.base_policy import DeviceBatch
 from fsrl_amd.policy.lagrangian_base import LagrangianPolicy
 
 PPO_STAT_KEYS = ("loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss/actor_rew",
@@ -68,28 +69,42 @@ class PPOLagrangian(LagrangianPolicy):
                           use_lagrangian=use_lagrangian, recompute_adv=bool(recompute_advantage),
                           value_clip=bool(value_clip))
 
-    def learn(self, batch, **kwargs: Any):
-        raise NotImplementedError("the HIP path runs process_fn + learn inside update()")
-
     def _burn_samples(self, sizes) -> None:
         da = self.engine.cfg.act_dim
         for m in sizes:                                          # Independent(Normal).sample() of an [m, Da] batch
             torch.normal(torch.zeros(m, da), torch.ones(m, da))
 
-    def update(self, sample_size: int, buffer, batch_size: int = 256, repeat: int = 4, **kwargs: Any):
-        if buffer is None:
-            return {}
-        assert sample_size == 0, "on-policy update consumes the whole buffer (sample_size=0)"
+    def process_fn(self, batch=None, buffer=None, indices=None, batch_size: int = 256):
+        """ppo_lag.py:134-150 on the device = `fsrl_ppo_begin`: buffer.sample(0), V(obs) / V(obs_next) of every critic, the float64
+        GAE scan, logp_old.  -> DeviceBatch (the processed batch stays in HBM).  `batch` / `indices` are accepted for signature
+        parity and ignored: the on-policy batch is always the whole store.  batch_size: the minibatch size `learn` will use (the
+        library plans its working set at begin; learn() re-begins if it is given another one)."""
         assert getattr(buffer, "engine", None) is self.engine, \
-            "PPOLagrangian.update needs the HipVectorReplayBuffer bound to this policy's engine"
+            "PPOLagrangian.process_fn needs the HipVectorReplayBuffer bound to this policy's engine"
         self.updating = True
         lags, rescaling = self.lagrangians_and_rescaling() if self.use_lagrangian else ([], 1.0)
-        eng = self.engine
-        n = eng.ppo_begin(lags, rescaling, batch_size)          # buffer.sample(0) + process_fn
+        self._begin_args = (lags, rescaling)
+        n = self.engine.ppo_begin(lags, rescaling, batch_size)      # buffer.sample(0) + process_fn
+        try:
+            if self._reference_rng and (self.training or not self._deterministic_eval):
+                self._burn_samples(_chunk_sizes(n, self._max_batchsize))   # process_fn's forward over chunks of max_batchsize
+        except BaseException:
+            self.engine.ppo_abort(); self.updating = False
+            raise
+        self._pending = DeviceBatch(self.engine, n, batch_size)
+        return self._pending
+
+    def learn(self, batch, batch_size: int = 256, repeat: int = 4, **kwargs: Any):
+        """ppo_lag.py:214-257 on the device = `fsrl_ppo_pass` x repeat + `fsrl_ppo_end`; `batch` is what process_fn returned."""
+        assert isinstance(batch, DeviceBatch) and batch is getattr(self, "_pending", None), \
+            "learn() takes the DeviceBatch the last process_fn() returned (the processed batch lives in HBM)"
+        self._pending = None
+        eng, n = self.engine, batch.n
         try:                                                     # begin ... end is a state machine in the library:
+            if batch.batch_size != batch_size:                   # another minibatch size than planned: begin again (no RNG is consumed)
+                eng.ppo_abort()
+                n = eng.ppo_begin(*self._begin_args, batch_size)
             burn = self._reference_rng and (self.training or not self._deterministic_eval)
-            if burn:                                                 # process_fn's forward over chunks of max_batchsize
-                self._burn_samples(_chunk_sizes(n, self._max_batchsize))
             stopped_at = -1
             perm = np.random.permutation(n) if n > 0 else None       # Batch.split(shuffle=True) of the first pass
             for step in range(repeat):                               # ppo_lag.py:217
@@ -132,6 +147,15 @@ class PPOLagrangian(LagrangianPolicy):
         self.gradient_steps += len(stats)
         self.logger.store(gradient_steps=self.gradient_steps, tab="update")
         self._mark_stale()                                       # host mirror refreshed on demand
+        return {"gradient_steps": len(stats), "early_stop_pass": stopped_at}
+
+    def update(self, sample_size: int, buffer, batch_size: int = 256, repeat: int = 4, **kwargs: Any):
+        """base_policy.py:332-355: sample(0) -> process_fn -> learn -> lr scheduler"""
+        if buffer is None:
+            return {}
+        assert sample_size == 0, "on-policy update consumes the whole buffer (sample_size=0)"
+        batch = self.process_fn(None, buffer, None, batch_size=batch_size)
+        result = self.learn(batch, batch_size=batch_size, repeat=repeat)
         self._step_lr_scheduler()
         self.updating = False
-        return {"gradient_steps": len(stats), "early_stop_pass": stopped_at}
+        return result

@@ -166,7 +166,8 @@ class SACLagrangian(LagrangianPolicy):
         super().post_update_fn(**kwarg)
 
     def learn(self, batch, **kwargs: Any):
-        raise NotImplementedError("the HIP path runs process_fn + learn inside update()")
+        raise NotImplementedError("replay agents: update(batch_size, buffer) is ONE library call on the HIP path -- the sample, the n-step "
+                                  "targets (process_fn) and the optimiser steps (learn) are fused on the device; see INTEGRATION.md section 3")
 
     def update(self, sample_size: int, buffer, **kwargs: Any):
         if buffer is None:

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from fsrl_amd.policy.base_policy import DeviceBatch
 from fsrl_amd.policy.lagrangian_base import LagrangianPolicy
 
 TRPO_KEYS = ("loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss/actor_rew", "loss/actor_total",
@@ -64,19 +65,24 @@ class TRPOLagrangian(LagrangianPolicy):
             for _ in range(forwards):
                 torch.normal(torch.zeros(n_rows, da), torch.ones(n_rows, da))
 
-    def learn(self, batch, **kwargs: Any):
-        raise NotImplementedError("the HIP path runs process_fn + learn inside update()")
-
-    def update(self, sample_size: int, buffer, batch_size: int = 99999, repeat: int = 4, **kwargs: Any):
-        if buffer is None:
-            return {}
-        assert sample_size == 0 and getattr(buffer, "engine", None) is self.engine
+    def process_fn(self, batch=None, buffer=None, indices=None, **kwargs: Any):
+        """trpo_lag.py:132-146 on the device = `fsrl_tr_begin`: sample(0), V / GAE per critic, advantage normalisation, logp_old.
+        -> DeviceBatch; `batch` / `indices` ignored (the on-policy batch is the whole store)."""
+        assert getattr(buffer, "engine", None) is self.engine
         self.updating = True
-        eng = self.engine
         g = self.optim.param_groups[0]
-        n = eng.tr_begin(target_kl=self._delta, backtrack_coeff=self._backtrack_coeff, damping=self._damping,
-                         l2_reg=0.0, critic_lr=g["lr"], max_backtracks=self._max_backtracks,
-                         optim_critic_iters=self._optim_critic_iters, cg_iters=10, norm_adv=self._norm_adv)
+        n = self.engine.tr_begin(target_kl=self._delta, backtrack_coeff=self._backtrack_coeff, damping=self._damping,
+                                 l2_reg=0.0, critic_lr=g["lr"], max_backtracks=self._max_backtracks,
+                                 optim_critic_iters=self._optim_critic_iters, cg_iters=10, norm_adv=self._norm_adv)
+        self._pending = DeviceBatch(self.engine, n, 0)
+        return self._pending
+
+    def learn(self, batch, batch_size: int = 99999, repeat: int = 4, **kwargs: Any):
+        """trpo_lag.py:173-251 on the device = `fsrl_trpo_learn[_mb]`; `batch` is what process_fn returned."""
+        assert isinstance(batch, DeviceBatch) and batch is getattr(self, "_pending", None), \
+            "learn() takes the DeviceBatch the last process_fn() returned (the processed batch lives in HBM)"
+        self._pending = None
+        eng, n = self.engine, batch.n
         lags, rescaling = self.lagrangians_and_rescaling() if self.use_lagrangian else ([], 1.0)
         # Batch.split(batch_size, merge_last=True) inside learn (trpo_lag.py:177-178) draws one np.random.permutation per
         # repeat from numpy's global stream -- also when one minibatch covers the batch (then the order only moves sums and
@@ -97,6 +103,17 @@ class TRPOLagrangian(LagrangianPolicy):
             for rows, ev in zip(sizes * repeat, eng.tr_linesearch_evals(cap=len(stats) + 1)):
                 self._burn(rows, 2 + int(ev))
         self._mark_stale()                                       # host mirror refreshed on demand
-        self._step_lr_scheduler()
-        self.updating = False
         return {"gradient_steps": len(stats)}
+
+    def update(self, sample_size: int, buffer, batch_size: int = 99999, repeat: int = 4, **kwargs: Any):
+        """base_policy.py:332-355: sample(0) -> process_fn -> learn -> lr scheduler"""
+        if buffer is None:
+            return {}
+        assert sample_size == 0
+        try:
+            batch = self.process_fn(None, buffer, None)
+            result = self.learn(batch, batch_size=batch_size, repeat=repeat)
+        finally:
+            self.updating = False
+        self._step_lr_scheduler()
+        return result

@@ -115,10 +115,12 @@ def ppo_full_case(name):
     return cfg, g, steps
 
 
-def synth_theta(seed, shapes, bias_scale=0.05):
+def synth_theta(seed, shapes, bias_scale=0.05, head_scale=1.0):
     """A seeded parameter vector for the full-size fixtures (NOT stored in them: regenerated here, checksum in the fixture):
     `shapes` = the shapes of a module's parameters() in order; matrices ~ N(0, 1 / fan_in), vectors ~ bias_scale * N(0, 1);
-    a (Da, 1) tensor is the on-policy actor's sigma_param (= -0.5, ppo_lag_agent.py:147)."""
+    a (Da, 1) tensor is the on-policy actor's sigma_param (= -0.5, ppo_lag_agent.py:147).  head_scale: factor on the head
+    matrices (<= 16 output rows): the multi-seed learning-curve fixtures start from small mean actions (0.1), like the agents'
+    `last_layer_scale` option (ppo_lag_agent.py:155-161), instead of a saturated tanh."""
     rng = np.random.default_rng(seed)
     parts = []
     for sh in shapes:
@@ -126,7 +128,10 @@ def synth_theta(seed, shapes, bias_scale=0.05):
         if len(sh) == 2 and sh[1] == 1 and sh[0] <= 16:
             parts.append(np.full(sh[0], -0.5, np.float32))
         elif len(sh) == 2:
-            parts.append((rng.standard_normal(sh) / np.sqrt(sh[1])).astype(np.float32).reshape(-1))
+            w = (rng.standard_normal(sh) / np.sqrt(sh[1])).astype(np.float32)
+            if sh[0] <= 16 and head_scale != 1.0:
+                w = (w * np.float32(head_scale)).astype(np.float32)
+            parts.append(w.reshape(-1))
         else:
             parts.append((bias_scale * rng.standard_normal(sh)).astype(np.float32).reshape(-1))
     return np.concatenate(parts)

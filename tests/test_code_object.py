@@ -1,0 +1,66 @@
+"""The built library's gfx950 code object, read on the host (no GPU): register spills of the kernels.
+
+tools/sonotes.py unbundles the device code object from libfsrl_hip.so's .hip_fatbin section and parses the AMDGPU metadata note
+(llvm-readelf --notes): vgpr_count, vgpr_spill_count, private_segment_fixed_size (scratch bytes per lane).  A kernel on a default
+plan must not spill vector registers: round 5 shipped every `ppo_wgrad*<.., BIG = true, ..>` instantiation with 167-223 spilled
+VGPRs (472-544 bytes of scratch per lane) -- the optimiser had hoisted the 64-bit address of every load of a burst out of the chunk
+loop; the chunk base is opaque now (kernels_mlp.hpp)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+LIB = os.path.join(ROOT, "fsrl_amd", "libfsrl_hip.so")
+
+# kernels that are allowed to spill vector registers, with the reason (mangled-name prefix -> max spilled VGPRs)
+KNOWN = {
+    # A/B-only plans (fsrl_tr_set_tile_split(-2, -2): persistent workgroups drawing tiles from a device counter; measured, rejected)
+    "_Z16fb_hvp_co_kernelILi256ELb1E": 64,
+    "_Z17fb_tile_co_kernelILi256ELb1E": 8,
+    # round 4's one-workgroup-per-CU tile kernel (fsrl_tr_set_plan(32, ..): A/B and the bit-identity tests)
+    "_Z20fb_tile_mixed_kernelILi256E": 8,
+    # the FIRST product of a conjugate-gradient solve (4-8 launches per update): 4 registers at the 128-VGPR cap of 1024 threads
+    "_Z19fb_hvp_mixed_kernelILi256ELb0E": 4,
+}
+
+
+@pytest.fixture(scope="module")
+def notes():
+    if not os.path.exists(LIB):
+        pytest.skip("libfsrl_hip.so is not built")
+    import sonotes
+    n = sonotes.kernel_notes(LIB)
+    assert len(n) > 100, "the code object's metadata note was not parsed"
+    return n
+
+
+def test_every_declared_kernel_family_is_in_the_code_object(notes):
+    names = " ".join(notes)
+    for fam in ("ppo_fwd_bwd_kernel", "ppo_wgrad_kernel", "ppo_wgrad_group_kernel", "adam_clip_kernel", "gae_kernel", "mlp_infer_kernel",
+                "fb_tile_co_kernel", "fb_hvp_co_kernel", "fb_wgrad_kernel", "fb_wgrad3_kernel", "sac_actor_tile_kernel", "lin_kernel"):
+        assert fam in names, fam
+
+
+def test_no_vector_register_spills_outside_the_known_list(notes):
+    bad = []
+    for name, k in notes.items():
+        allowed = max([v for p, v in KNOWN.items() if name.startswith(p)] or [0])
+        if k["vgpr_spill_count"] > allowed:
+            bad.append((name, k["vgpr_spill_count"], k["private_segment_fixed_size"]))
+    assert not bad, bad
+
+
+def test_weight_gradient_kernels_use_no_scratch_at_all(notes):
+    """every instantiation of the minibatch step's weight-gradient kernels (incl. the chunked BIG form of the grouped launches) and
+    r6's tile-job kernel: zero spilled VGPRs, zero bytes of scratch, and the register budgets their launch bounds promise"""
+    seen = 0
+    for name, k in notes.items():
+        if "ppo_wgrad" in name or "fb_wgrad3" in name or "fb_wgrad_kernel" in name:
+            seen += 1
+            assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (name, k)
+            assert k["vgpr_count"] <= 128, (name, k)
+    assert seen >= 10
+    w3 = [k for n, k in notes.items() if "fb_wgrad3_kernel" in n]
+    assert len(w3) == 1 and w3[0]["max_flat_workgroup_size"] == 512 and 2 * w3[0]["group_segment_fixed_size"] <= 160 * 1024   # two per CU

@@ -642,3 +642,56 @@ def test_agents_with_two_hidden_layers_of_any_width(kind, tmp_path):
         a2 = cls(env, None, cost_limit=10, device="cuda:0", seed=3, hidden_sizes=other, training_num=4, **kw)
         if kind in ("ppol", "focops", "cpo"):
             assert a2.policy.engine.n_params == sum(p.numel() for p in a2.policy._actor_critic.parameters())
+
+
+@pytest.mark.parametrize("kind", ["ppo", "cpo"])
+def test_process_fn_then_learn_is_update(kind):
+    """fsrl/policy/base_policy.py:332-355: update() = process_fn -> learn.  On the HIP path process_fn returns a DeviceBatch (the
+    processed batch stays in HBM: values / rets / advs / logp_old on demand) and learn takes it back; the two calls in a row leave
+    exactly the parameters one update() call leaves, and learn refuses anything that is not the pending batch."""
+    from torch.distributions import Independent, Normal
+    from fsrl_amd.data import Batch, HipVectorReplayBuffer
+    from fsrl_amd.env import Box, SyntheticSafetyVectorEnv
+    from fsrl_amd.policy import CPO, PPOLagrangian
+    from fsrl_amd.policy.base_policy import DeviceBatch
+    from fsrl_amd.utils.net import ActorCritic, ActorProb, Critic, Net
+    from test_gpu_loop import _Cap, _rollout
+    Do, Da, E, T = 8, 2, 4, 60
+
+    def make():
+        torch.manual_seed(3)
+        actor = ActorProb(Net((Do, ), hidden_sizes=(64, 64)), (Da, ), max_action=1.0)
+        critics = [Critic(Net((Do, ), hidden_sizes=(64, 64))) for _ in range(2)]
+        common = dict(logger=_Cap(), cost_limit=10.0, observation_space=Box(-np.inf, np.inf, (Do, )), action_space=Box(-1, 1, (Da, )),
+                      device=0, env_num=E, buffer_size=E * T * 2)
+        if kind == "ppo":
+            pol = PPOLagrangian(actor, critics, torch.optim.Adam(ActorCritic(actor, critics).parameters(), lr=5e-4),
+                                lambda *l: Independent(Normal(*l), 1), target_kl=None, max_grad_norm=0.5, **common)
+        else:
+            pol = CPO(actor, critics, torch.optim.Adam(torch.nn.ModuleList(critics).parameters(), lr=1e-3),
+                      lambda *l: Independent(Normal(*l), 1), optim_critic_iters=3, **common)
+        pol.train()
+        env = SyntheticSafetyVectorEnv(env_num=E, obs_dim=Do, act_dim=Da, episode_len=T, seed=5)
+        buf = HipVectorReplayBuffer(pol.engine, E * T * 2, E)
+        torch.manual_seed(11); np.random.seed(11)
+        st = _rollout(pol, env, buf)
+        pol.pre_update_fn(stats_train={"cost": st["cost"]})
+        np.random.seed(12)
+        return pol, buf
+    kw = dict(batch_size=64, repeat=2) if kind == "ppo" else dict(batch_size=99999, repeat=2)
+    a, buf_a = make()
+    res_a = a.update(0, buf_a, **kw)
+    theta_a = a.engine.get_params().copy()
+    b, buf_b = make()
+    batch = b.process_fn(None, buf_b, None, **({"batch_size": 64} if kind == "ppo" else {}))
+    assert isinstance(batch, DeviceBatch) and len(batch) == E * T and b.updating
+    assert tuple(batch.advs.shape) == (E * T, 2) and tuple(batch.rets.shape) == (E * T, 2) and tuple(batch.logp_old.shape) == (E * T, )
+    assert torch.isfinite(batch.advs).all() and torch.isfinite(batch.values).all()
+    with pytest.raises(AssertionError):
+        b.learn(Batch(obs=np.zeros((1, Do), np.float32)), **kw)          # not the pending device batch
+    res_b = b.learn(batch, **kw)
+    assert res_b["gradient_steps"] == res_a["gradient_steps"] > 0
+    assert np.array_equal(b.engine.get_params(), theta_a)
+    with pytest.raises(AssertionError):
+        b.learn(batch, **kw)                                              # consumed: a second learn needs a new process_fn
+    a.engine.close(); b.engine.close()
