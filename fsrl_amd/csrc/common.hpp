@@ -79,6 +79,7 @@ struct PpoStepArgs {
     float bc2_sqrt;    // sqrt(1 - beta2^t)
     int value_clip;    // ppo_lag.py:158-164 (only with reward_normalization, as the reference asserts)
     int fuse_adam;     // max_grad_norm off (the agent default): the weight-gradient kernel applies Adam itself, 2 launches per step
+    int xcd_pair;      // fused forward/backward launch: 1 = one network per XCD pair (single-agent step, <= 4 networks), 0 = tile-major blocks
     int dbg_phase;     // probe builds only (-DFSRL_PROBES, env FSRL_DBG_PHASE): early-exit timing experiments, results invalid
 };
 // Early-exit timing probes of the step kernels (tools/phase_probe.sh).  They exist only in a build with -DFSRL_PROBES

@@ -180,6 +180,7 @@ struct fsrl_ctx {
     unsigned long long* probe_ts = nullptr;   // probe builds: [1024][16] phase stamps of the last fused-kernel launch
     bool probe_tile16 = false;
     bool no_fuse_adam = false;      // probe builds: FSRL_NO_FUSE_ADAM keeps the separate Adam launch without a clip (A/B, bit-compare)
+    bool no_xcd_pair = false;       // probe builds: FSRL_NO_XCD_PAIR keeps the tile-major block order of the fused forward/backward launch (A/B)
     bool no_spin = false;           // wait for the collector's actor with hipStreamSynchronize instead of the completion words
     std::vector<float> act_mu, act_sg;                   // mean / std of the last actor evaluation (host)
     std::vector<int> perm_tmp;      // this pass's permutation before it goes to the pinned buffer
@@ -502,6 +503,7 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
     { const char* e = getenv("FSRL_WGRAD_SKIP"); c->probe_wgrad_skip = e ? atoi(e) : 0; }
     c->probe_tile16 = getenv("FSRL_TILE16") != nullptr;
     c->no_spin = getenv("FSRL_NO_SPIN") != nullptr;
+    c->no_xcd_pair = getenv("FSRL_NO_XCD_PAIR") != nullptr;
     c->no_fuse_adam = getenv("FSRL_NO_FUSE_ADAM") != nullptr;
     if (getenv("FSRL_TSTAMP")) {
         (void)hipMalloc(&c->probe_ts, 1024 * 16 * sizeof(unsigned long long));
@@ -1225,7 +1227,8 @@ extern "C" int fsrl_launch_floors(fsrl_ctx* c, int32_t mb_rows, int32_t iters, d
     const int H = c->cfg.hidden, nn = c->md.n_nets;
     const int tiles = (mb_rows + 15) / 16;
     const bool rows4 = tiles * 4 * nn <= c->n_cus, rows8 = !rows4 && tiles * 2 * nn <= c->n_cus;
-    const int g_fb = rows4 ? tiles * 4 * nn : rows8 ? tiles * 2 * nn : tiles * nn;
+    const int nt_ = rows4 ? tiles * 4 : rows8 ? tiles * 2 : tiles;
+    const int g_fb = (nn <= 4 && !c->no_xcd_pair) ? 8 * ((nt_ + 1) / 2) : nt_ * nn;      // the step's own grid (one network per XCD pair)
     const int g_wg = nn * ((H / 32) * (H / 32) + H / 32) + 1;
     const int g_ad = (c->n_dev + 4 * ADAM_NT - 1) / (4 * ADAM_NT);
     size_t lds_fb = 0, lds_wg = 0;
