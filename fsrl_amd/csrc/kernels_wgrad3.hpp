@@ -127,6 +127,27 @@ __device__ __forceinline__ void wg3_pipeline2(const int KS0, const int KS, const
     if (i < n) fma(A);
 }
 
+// Operand loads as BUFFER loads: one SGPR resource per array + a 32-bit byte offset per lane (`buffer_load_dwordx4 v, v_off, s[rsrc], 0
+// offen`) instead of a 64-bit address pair per lane and load.
+#ifndef WG3_NO_BUFFER
+typedef unsigned wg3_u32x4 __attribute__((ext_vector_type(4)));
+struct Wg3Buf { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ Wg3Buf wg3_buf(const float* base) {        // base: workgroup-uniform
+    Wg3Buf b; b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7FFFFFFF, 0x00020000); return b;
+}
+__device__ __forceinline__ f32x4 wg3_ld4(const Wg3Buf& b, const unsigned off_floats) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, off_floats * 4u, 0, 0));
+}
+__device__ __forceinline__ float wg3_ld1(const Wg3Buf& b, const unsigned off_floats) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, off_floats * 4u, 0, 0));
+}
+#else
+struct Wg3Buf { const float* p; };
+__device__ __forceinline__ Wg3Buf wg3_buf(const float* base) { Wg3Buf b; b.p = base; return b; }
+__device__ __forceinline__ f32x4 wg3_ld4(const Wg3Buf& b, const unsigned off_floats) { return *reinterpret_cast<const f32x4*>(b.p + off_floats); }
+__device__ __forceinline__ float wg3_ld1(const Wg3Buf& b, const unsigned off_floats) { return b.p[off_floats]; }
+#endif
+
 // sum of the four LDS slots of element e (fixed order)
 __device__ __forceinline__ float wg3_sum4(const float* red, const int e) {
     return (red[e] + red[WG3_SLOT + e]) + (red[2 * WG3_SLOT + e] + red[3 * WG3_SLOT + e]);
@@ -155,8 +176,7 @@ __device__ __forceinline__ void wg3_job_T(const Wg3Ctx& k, const int pr, const i
     const int c = k.c, q = k.q, wave = k.wave, tid = k.tid;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // lane (c, q) holds four columns of row 4 s + q of each operand; acc[t][u][r] = output (j = 4 (4 q + r) + t, k = 4 c + u)
-    const float* py = (pr ? wn.w2_yb : wn.w2_ya) + tj * 64 + 4 * c;
-    const float* px = (pr ? wn.w2_xb : wn.w2_xa) + tk * 64 + 4 * c;
+    const Wg3Buf by = wg3_buf((pr ? wn.w2_yb : wn.w2_ya) + tj * 64), bx = wg3_buf((pr ? wn.w2_xb : wn.w2_xa) + tk * 64);
     f32x4 acc[4][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -165,9 +185,9 @@ __device__ __forceinline__ void wg3_job_T(const Wg3Ctx& k, const int pr, const i
     f32x4 sy = zero4;                                        // column sums of Y: db2 (pair a, tile column 0: b2_src == w2_ya)
     struct Set { f32x4 y, x; };
     auto fetch = [&](const int s, Set& o) {
-        const unsigned r = (unsigned)(4 * s + q) * (unsigned)H;          // 32-bit offsets: rows * 256 floats stays far below 2^32
-        o.y = *reinterpret_cast<const f32x4*>(py + r);
-        o.x = *reinterpret_cast<const f32x4*>(px + r);
+        const unsigned r = (unsigned)(4 * s + q) * (unsigned)H + 4u * (unsigned)c;   // 32-bit offsets: rows * 256 floats stays far below 2^32
+        o.y = wg3_ld4(by, r);
+        o.x = wg3_ld4(bx, r);
     };
     auto fma = [&](const Set& o) {
 #ifdef FSRL_PROBES
@@ -219,8 +239,7 @@ __device__ __forceinline__ void wg3_job_U(const Wg3Ctx& k, const int tj0, const 
     const FbWgradNet& wn = *k.wn; const NetOff& no = *k.no;
     const int c = k.c, q = k.q, wave = k.wave, tid = k.tid, Do = k.Do;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const float* py = wn.w1_y + tj0 * 64 + 4 * c;
-    const float* px = k.wa->obs_pad + (size_t)64 * ko + 4 * c;
+    const Wg3Buf by = wg3_buf(wn.w1_y + tj0 * 64), bx = wg3_buf(k.wa->obs_pad + (size_t)64 * ko);
     const unsigned ldx = 64u * (unsigned)k.wa->obs_ko;
     f32x4 acc[4][4];
 #pragma unroll
@@ -231,8 +250,8 @@ __device__ __forceinline__ void wg3_job_U(const Wg3Ctx& k, const int tj0, const 
     auto fetch = [&](const int s, Set& o) {
         const unsigned r = (unsigned)(4 * s + q);
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) o.y[j] = *reinterpret_cast<const f32x4*>(py + r * (unsigned)H + 64 * j);
-        o.x = *reinterpret_cast<const f32x4*>(px + r * ldx);
+        for (int j = 0; j < TJ; ++j) o.y[j] = wg3_ld4(by, r * (unsigned)H + 64u * j + 4u * (unsigned)c);
+        o.x = wg3_ld4(bx, r * ldx + 4u * (unsigned)c);
     };
     auto fma = [&](const Set& o) {
 #ifdef FSRL_PROBES
@@ -288,19 +307,18 @@ __device__ __forceinline__ void wg3_job_V(const Wg3Ctx& k, const int pr, const i
         for (int t = 0; t < 4; ++t) ad[g][t] = zero4;
     float s3a = 0.0f, s3b = 0.0f;
     f32x4 s1[2] = {zero4, zero4};                            // db1: column sums of the dW1 operand (b1_src == w1_y in every caller)
-    const float* px3 = (pr ? wn.w3_xb : wn.w3_xa) + 128 * half + 4 * c;
-    const float* pd3 = (pr ? wn.w3_yb : wn.w3_ya) + c;
-    const float* py1 = wn.w1_y + 128 * half + 4 * c;
+    const Wg3Buf bx3 = wg3_buf((pr ? wn.w3_xb : wn.w3_xa) + 128 * half), bd3 = wg3_buf(pr ? wn.w3_yb : wn.w3_ya),
+                 by1 = wg3_buf(wn.w1_y + 128 * half);
     struct VSet { f32x4 x[2], y1[2]; float d, d2; };
     auto vfetch = [&](const int s, VSet& o) {
         const unsigned r = (unsigned)(4 * s + q);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            o.x[g] = *reinterpret_cast<const f32x4*>(px3 + r * (unsigned)H + 64 * g);
-            o.y1[g] = *reinterpret_cast<const f32x4*>(py1 + r * (unsigned)H + 64 * g);
+            o.x[g] = wg3_ld4(bx3, r * (unsigned)H + 64u * g + 4u * (unsigned)c);
+            o.y1[g] = wg3_ld4(by1, r * (unsigned)H + 64u * g + 4u * (unsigned)c);
         }
-        o.d = pd3[r * (unsigned)FSRL_DOW];
-        o.d2 = pd3[r * (unsigned)FSRL_DOW + 16];
+        o.d = wg3_ld1(bd3, r * (unsigned)FSRL_DOW + (unsigned)c);
+        o.d2 = wg3_ld1(bd3, r * (unsigned)FSRL_DOW + 16u + (unsigned)c);
     };
     auto vfma = [&](const VSet& o) {
 #pragma unroll
