@@ -142,6 +142,45 @@ __device__ __forceinline__ void store4_fb(float* p, const f32x4 v) { *reinterpre
 __device__ __forceinline__ void store4_fb(float* p, const f32x4 v) { store4_next(p, v); }
 #endif
 
+// Global loads of the hot paths as BUFFER loads (r6): one SGPR resource per array + a 32-bit byte offset per lane
+// (`buffer_load_dwordx4 v, v_off, s[rsrc], 0 offen`) instead of a 64-bit address pair per lane and load.  fb_wgrad3_kernel, same box:
+// 60.4 -> 52.5 us per launch (the load side alone, MFMAs taken out: 28.4 -> 25.0 us), and the loads overlap the matrix work better.
+#ifndef WG3_NO_BUFFER
+typedef unsigned wg3_u32x4 __attribute__((ext_vector_type(4)));
+struct Wg3Buf { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ Wg3Buf wg3_buf(const float* base) {        // base: workgroup-uniform
+    Wg3Buf b; b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7FFFFFFF, 0x00020000); return b;
+}
+// the same, built where it is used: the base goes through an opaque SGPR pair, so the four descriptor registers are not hoisted out of
+// an enclosing loop and kept alive next to the other resources of a register-bound kernel (SGPR spills land in VGPR lanes)
+__device__ __forceinline__ Wg3Buf wg3_buf_here(const float* base) {
+    unsigned long long p = (unsigned long long)base;
+    asm volatile("" : "+s"(p));
+    return wg3_buf(reinterpret_cast<const float*>(p));
+}
+__device__ __forceinline__ f32x4 wg3_ld4(const Wg3Buf& b, const unsigned off_floats) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, off_floats * 4u, 0, 0));
+}
+__device__ __forceinline__ float wg3_ld1(const Wg3Buf& b, const unsigned off_floats) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, off_floats * 4u, 0, 0));
+}
+// the same with a wave-uniform part of the offset in an SGPR (`soffset`): bursts that walk a matrix in fixed strides
+__device__ __forceinline__ float wg3_ld1s(const Wg3Buf& b, const unsigned lane_off_floats, const unsigned uni_off_floats) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, lane_off_floats * 4u, uni_off_floats * 4u, 0));
+}
+__device__ __forceinline__ f32x4 wg3_ld4s(const Wg3Buf& b, const unsigned lane_off_floats, const unsigned uni_off_floats) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, lane_off_floats * 4u, uni_off_floats * 4u, 0));
+}
+#else
+struct Wg3Buf { const float* p; };
+__device__ __forceinline__ Wg3Buf wg3_buf(const float* base) { Wg3Buf b; b.p = base; return b; }
+__device__ __forceinline__ Wg3Buf wg3_buf_here(const float* base) { return wg3_buf(base); }
+__device__ __forceinline__ f32x4 wg3_ld4(const Wg3Buf& b, const unsigned off_floats) { return *reinterpret_cast<const f32x4*>(b.p + off_floats); }
+__device__ __forceinline__ float wg3_ld1(const Wg3Buf& b, const unsigned off_floats) { return b.p[off_floats]; }
+__device__ __forceinline__ float wg3_ld1s(const Wg3Buf& b, const unsigned l, const unsigned u) { return b.p[l + u]; }
+__device__ __forceinline__ f32x4 wg3_ld4s(const Wg3Buf& b, const unsigned l, const unsigned u) { return *reinterpret_cast<const f32x4*>(b.p + l + u); }
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -762,17 +762,30 @@ __device__ __forceinline__ void mma_rows_n(const float* A, const FwdW2Frag<H>& w
         }
     }
 }
-template <int H, int NH>
+// BUF (r6, the co-resident kernels): the 64 dword loads of the column burst as buffer loads -- one resource, one lane offset, the row
+// offset in an SGPR -- instead of 64 address pairs (see FwdW2Frag::load_buf for the measurements)
+template <int H, int NH, bool BUF = false>
 __device__ __forceinline__ void mma_cols_n(const float* A, const float* __restrict__ W, int wave, int li, int q,
                                            f32x4 (&acc)[NH]) {
     constexpr int LD = H + 4;
-    const float* __restrict__ Wc = W + wave * 16 + li;
     float wb[H / 16][4];
+    if constexpr (BUF) {
+        const Wg3Buf bw = wg3_buf_here(W);
+        const unsigned lane_off = (unsigned)(wave * 16 + li) + (unsigned)(4 * q) * (unsigned)H;
 #pragma unroll
-    for (int jc = 0; jc < H / 16; ++jc) {
+        for (int jc = 0; jc < H / 16; ++jc) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wb[jc][s] = Wc[(size_t)(16 * jc + 4 * q + s) * H];
+            for (int s = 0; s < 4; ++s) wb[jc][s] = wg3_ld1s(bw, lane_off, (unsigned)(16 * jc + s) * (unsigned)H);
+        }
+    } else {
+        const float* __restrict__ Wc = W + wave * 16 + li;
+#pragma unroll
+        for (int jc = 0; jc < H / 16; ++jc) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wb[jc][s] = Wc[(size_t)(16 * jc + 4 * q + s) * H];
+        }
     }
+
     const float* arow = A + li * LD + 4 * q;
 #pragma unroll
     for (int jc = 0; jc < H / 16; ++jc) {
@@ -1112,6 +1125,9 @@ __device__ __forceinline__ void wgrad_aux_pass(const FbWgradArgs& wa, const FbWg
     // a head with ONE output (every critic / Q-net): dW3 = A2^T dout is a matrix-vector product -- four FMAs per lane and
     // k-step instead of four 16-wide MFMAs that would carry one useful column (a third of this pass's matrix-pipe time)
     const bool vec3 = first && !PAIR2 && out == 1;
+    // r6: buffer loads (see wg3_ld4); a null second pair gets pair a's array (never loaded from)
+    const Wg3Buf b_y1 = wg3_buf(wn.w1_y), b_obs = wg3_buf(wa.obs), b_xa3 = wg3_buf(wn.w3_xa), b_ya3 = wg3_buf(wn.w3_ya),
+                 b_xb3 = wg3_buf(PAIR2 ? wn.w3_xb : wn.w3_xa), b_yb3 = wg3_buf(PAIR2 ? wn.w3_yb : wn.w3_ya), b_b2 = wg3_buf(wn.b2_src);
     for (int sb = KS0 + wave; sb < KS; sb += 16 * AUXU) {
         f32x4 y1[AUXU], xa3[AUXU], xb3[AUXU], b2v[AUXU];
         float bx[AUXU][NCH], bda[AUXU], bdb[AUXU];
@@ -1123,19 +1139,20 @@ __device__ __forceinline__ void wgrad_aux_pass(const FbWgradArgs& wa, const FbWg
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) bx[u][ch] = 0.f;
             if (s < KS) {
-                const size_t r = (size_t)(4 * s + q);
-                y1[u] = *reinterpret_cast<const f32x4*>(wn.w1_y + r * H + j0 + T * c);
+                const unsigned r = (unsigned)(4 * s + q);
+                const unsigned rh = r * (unsigned)H + (unsigned)(j0 + T * c);
+                y1[u] = wg3_ld4(b_y1, rh);
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch)
-                    if (k0 + 16 * ch + c < Do && r < (size_t)wa.N) bx[u][ch] = wa.obs[r * Do + k0 + 16 * ch + c];
+                    if (k0 + 16 * ch + c < Do && r < (unsigned)wa.N) bx[u][ch] = wg3_ld1(b_obs, r * (unsigned)Do + (unsigned)(k0 + 16 * ch + c));
                 if (first) {
-                    xa3[u] = *reinterpret_cast<const f32x4*>(wn.w3_xa + r * H + j0 + T * c);
-                    bda[u] = wn.w3_ya[r * FSRL_DOW + (vec3 ? 0 : c)];
+                    xa3[u] = wg3_ld4(b_xa3, rh);
+                    bda[u] = wg3_ld1(b_ya3, r * (unsigned)FSRL_DOW + (unsigned)(vec3 ? 0 : c));
                     if constexpr (PAIR2) {
-                        xb3[u] = *reinterpret_cast<const f32x4*>(wn.w3_xb + r * H + j0 + T * c);
-                        bdb[u] = wn.w3_yb[r * FSRL_DOW + c];
+                        xb3[u] = wg3_ld4(b_xb3, rh);
+                        bdb[u] = wg3_ld1(b_yb3, r * (unsigned)FSRL_DOW + (unsigned)c);
                     }
-                    b2v[u] = *reinterpret_cast<const f32x4*>(wn.b2_src + r * H + j0 + T * c);
+                    b2v[u] = wg3_ld4(b_b2, rh);
                 }
             }
         }
@@ -1286,13 +1303,15 @@ __global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, cons
         // Software-pipelined: the operands of the wave's NEXT k-step are requested before the 16 (32) MFMAs of the current one
         // issue, so a wave's own MFMA time hides part of its load latency too (load -> wait -> MFMAs left that to the other
         // three waves of the SIMD).  Same k order per wave, same accumulation order: bit-identical to the loop it replaces.
+        const Wg3Buf bya = wg3_buf(wn.w2_ya + tj * 64), bxa = wg3_buf(wn.w2_xa + tk * 64);
+        const Wg3Buf byb = wg3_buf(PAIR2 ? wn.w2_yb + tj * 64 : wn.w2_ya), bxb = wg3_buf(PAIR2 ? wn.w2_xb + tk * 64 : wn.w2_xa);
         auto fetch = [&](const int s, f32x4& ya, f32x4& xa, f32x4& yb, f32x4& xb) {
-            const size_t r = (size_t)(4 * s + q) * H;
-            ya = *reinterpret_cast<const f32x4*>(wn.w2_ya + r + tj * 64 + 4 * c);
-            xa = *reinterpret_cast<const f32x4*>(wn.w2_xa + r + tk * 64 + 4 * c);
+            const unsigned r = (unsigned)(4 * s + q) * (unsigned)H + 4u * (unsigned)c;      // r6: buffer loads (see wg3_ld4)
+            ya = wg3_ld4(bya, r);
+            xa = wg3_ld4(bxa, r);
             if constexpr (PAIR2) {
-                yb = *reinterpret_cast<const f32x4*>(wn.w2_yb + r + tj * 64 + 4 * c);
-                xb = *reinterpret_cast<const f32x4*>(wn.w2_xb + r + tk * 64 + 4 * c);
+                yb = wg3_ld4(byb, r);
+                xb = wg3_ld4(bxb, r);
             }
         };
         auto fma16 = [&](const f32x4& ya, const f32x4& xa, const f32x4& yb, const f32x4& xb) {

@@ -170,10 +170,10 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) rz[g][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
         FwdW2Frag<H> wf;
-        wf.load(P + no.W2f, cg, lane);
+        wf.load_buf(P + no.W2f, cg, lane);
         mma_rows_n<H, NH>(rh1, wf, li, q, rz[g]);
         __builtin_amdgcn_sched_barrier(0);            // one fragment set (64 VGPRs) in flight at a time: the partner workgroup fills the gap
-        wf.load(V + no.W2f, cg, lane);
+        wf.load_buf(V + no.W2f, cg, lane);
         mma_rows_n<H, NH>(h1, wf, li, q, rz[g]);
         __builtin_amdgcn_sched_barrier(0);            // the next group's fragment loads stay behind this group's MFMAs (64 VGPRs each)
     }
@@ -292,9 +292,9 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
         f32x4 acc[NH];
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) acc[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mma_cols_n<H, NH>(rd2, P + no.W2, cg, li, q, acc);
+        mma_cols_n<H, NH, true>(rd2, P + no.W2, cg, li, q, acc);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!GN) mma_cols_n<H, NH>(d2, V + no.W2, cg, li, q, acc);         // dz2 V2: dz2 = 0 in the Gauss-Newton form
+        if constexpr (!GN) mma_cols_n<H, NH, true>(d2, V + no.W2, cg, li, q, acc);         // dz2 V2: dz2 = 0 in the Gauss-Newton form
         float* __restrict__ RD1 = a.RD1 + base;
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
@@ -460,7 +460,7 @@ __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __r
     for (int g = 0; g < 2; ++g) {
         const int cg = wave + g * WAVES;
         FwdW2Frag<H> wf;
-        wf.load(P + no.W2f, cg, lane);
+        wf.load_buf(P + no.W2f, cg, lane);
         f32x4 acc[NH];
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) acc[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -570,7 +570,7 @@ __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __r
         f32x4 acc[NH];
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) acc[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mma_cols_n<H, NH>(d2, P + no.W2, cg, li, q, acc);
+        mma_cols_n<H, NH, true>(d2, P + no.W2, cg, li, q, acc);
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
 #pragma unroll

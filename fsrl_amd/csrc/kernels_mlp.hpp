@@ -61,6 +61,17 @@ struct FwdW2Frag {
 #pragma unroll
         for (int kc = 0; kc < H / 16; ++kc) b[kc] = *reinterpret_cast<const f32x4*>(base + kc * 256);
     }
+    // r6, the co-resident full-batch kernels: the same burst as buffer loads (common.hpp wg3_ld4s) -- one resource for the mirror, the
+    // lane's 16 bytes as the VGPR offset, the fragment (wave, kc) as an SGPR offset: no 64-bit address arithmetic per load.  Same-box
+    // A/B: fb_hvp_co_kernel 138.9 -> 128.5 us, fb_tile_co_kernel 101.3 -> 97.7 us (what a backward-ORDER mirror of W2 would have
+    // given, measured with a probe build, without keeping one); the fused PPO kernel LOSES with them (12.9 -> 13.85 us per launch,
+    // 121.6 -> 114 updates/s) and keeps the global loads.
+    __device__ __forceinline__ void load_buf(const float* __restrict__ W2f, int wave, int lane) {
+        const Wg3Buf bw = wg3_buf_here(W2f);
+        const unsigned frag0 = (unsigned)wave * (unsigned)(H / 16) * 256u;
+#pragma unroll
+        for (int kc = 0; kc < H / 16; ++kc) b[kc] = wg3_ld4s(bw, 4u * (unsigned)lane, frag0 + 256u * (unsigned)kc);
+    }
 };
 
 // Prologue: the small parameters and this tile's inputs are loaded into registers first

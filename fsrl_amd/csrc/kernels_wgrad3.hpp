@@ -127,27 +127,6 @@ __device__ __forceinline__ void wg3_pipeline2(const int KS0, const int KS, const
     if (i < n) fma(A);
 }
 
-// Operand loads as BUFFER loads: one SGPR resource per array + a 32-bit byte offset per lane (`buffer_load_dwordx4 v, v_off, s[rsrc], 0
-// offen`) instead of a 64-bit address pair per lane and load.
-#ifndef WG3_NO_BUFFER
-typedef unsigned wg3_u32x4 __attribute__((ext_vector_type(4)));
-struct Wg3Buf { __amdgpu_buffer_rsrc_t r; };
-__device__ __forceinline__ Wg3Buf wg3_buf(const float* base) {        // base: workgroup-uniform
-    Wg3Buf b; b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7FFFFFFF, 0x00020000); return b;
-}
-__device__ __forceinline__ f32x4 wg3_ld4(const Wg3Buf& b, const unsigned off_floats) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, off_floats * 4u, 0, 0));
-}
-__device__ __forceinline__ float wg3_ld1(const Wg3Buf& b, const unsigned off_floats) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, off_floats * 4u, 0, 0));
-}
-#else
-struct Wg3Buf { const float* p; };
-__device__ __forceinline__ Wg3Buf wg3_buf(const float* base) { Wg3Buf b; b.p = base; return b; }
-__device__ __forceinline__ f32x4 wg3_ld4(const Wg3Buf& b, const unsigned off_floats) { return *reinterpret_cast<const f32x4*>(b.p + off_floats); }
-__device__ __forceinline__ float wg3_ld1(const Wg3Buf& b, const unsigned off_floats) { return b.p[off_floats]; }
-#endif
-
 // sum of the four LDS slots of element e (fixed order)
 __device__ __forceinline__ float wg3_sum4(const float* red, const int e) {
     return (red[e] + red[WG3_SLOT + e]) + (red[2 * WG3_SLOT + e] + red[3 * WG3_SLOT + e]);

@@ -16,9 +16,13 @@ LIB = os.path.join(ROOT, "fsrl_amd", "libfsrl_hip.so")
 
 # kernels that are allowed to spill vector registers, with the reason (mangled-name prefix -> max spilled VGPRs)
 KNOWN = {
+    # the cached Hessian-vector product's co-resident kernel at the 128-VGPR cap of two workgroups per CU: 9-11 registers spilled and
+    # reloaded ONCE per tile, outside every loop (r6: its weight bursts became buffer loads, four descriptors live: 138.9 -> 128.5 us
+    # per launch with the spills in)
+    "_Z16fb_hvp_co_kernelILi256ELb0E": 12,
     # A/B-only plans (fsrl_tr_set_tile_split(-2, -2): persistent workgroups drawing tiles from a device counter; measured, rejected)
     "_Z16fb_hvp_co_kernelILi256ELb1E": 64,
-    "_Z17fb_tile_co_kernelILi256ELb1E": 8,
+    "_Z17fb_tile_co_kernelILi256ELb1E": 40,
     # round 4's one-workgroup-per-CU tile kernel (fsrl_tr_set_plan(32, ..): A/B and the bit-identity tests)
     "_Z20fb_tile_mixed_kernelILi256E": 8,
     # the FIRST product of a conjugate-gradient solve (4-8 launches per update): 4 registers at the 128-VGPR cap of 1024 threads
