@@ -460,7 +460,7 @@ def pmc_traffic():
     the guide's KiB unit and gfx950 x2 FETCH correction).  Counters cannot be read inside this process,
     so the figure is the one measured when the profile was captured; None when there is none."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         f = os.path.join(here, "profiles", f"{tag}_pmc_traffic.json")
         if os.path.exists(f):
             j = json.load(open(f))

@@ -21,7 +21,7 @@ def pmc_update_traffic(alg):
     """HBM-side bytes per update from the committed PMC passes (profiles/rNN_pmc_traffic_updates.json: FETCH_SIZE x 2 +
     WRITE_SIZE over a whole traced run / its updates); counters cannot be read inside this process.  None without a capture."""
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for tag in ("r05", "r04", "r03"):
+    for tag in ("r06", "r05", "r04", "r03"):
         f = os.path.join(here, "profiles", f"{tag}_pmc_traffic_updates.json")
         if os.path.exists(f):
             j = json.load(open(f))

@@ -25,6 +25,10 @@ for ALG in cpo trpo; do
     timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/${TAG}_pmc_${C}_${ALG} -- env FSRL_NO_CPU=1 FSRL_ONLY=$ALG python $R/tools/bench_trust.py > /dev/null 2>&1
   done
 done
+# the same for CPO with round 5's split-K weight-gradient kernel (fsrl_tr_set_plan(wgrad = 2): the default up to r5)
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/${TAG}_pmc_${C}_cpo_splitk -- env FSRL_NO_CPU=1 FSRL_ONLY=cpo FSRL_TR_PLAN=0,0,2 python $R/tools/bench_trust.py > /dev/null 2>&1
+done
 # the same for CPO with the one-pass streaming weight-gradient kernel (fsrl_tr_set_plan(wgrad = 3): not the default)
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/${TAG}_pmc_${C}_cpo_stream -- env FSRL_NO_CPU=1 FSRL_ONLY=cpo FSRL_TR_PLAN=0,0,3 python $R/tools/bench_trust.py > /dev/null 2>&1
@@ -60,6 +64,8 @@ fi
 [ -x tools/ubench/mfma_pat.bin ] && timeout 60 tools/ubench/mfma_pat.bin > $O/${TAG}_ubench_mfma_pat.txt 2>&1
 [ -x tools/ubench/hwid.bin ] && timeout 60 tools/ubench/hwid.bin > $O/${TAG}_ubench_hwid.txt 2>&1
 timeout 600 python tools/ab_trust_co.py --rounds 2 > $O/${TAG}_ab_trust_plans.json 2>/dev/null
+# r6: the weight-gradient kernels against each other on the default tile plan (split-K | streaming | tile jobs: XCD-aware / plain / half the splits)
+timeout 600 python tools/ab_trust_co.py --wgrad --rounds 2 > $O/${TAG}_ab_wgrad_plans.json 2>/dev/null
 # per-kernel counter means of the trust-region run (co-resident kernels beside round 4's): summarised here, the raw files are large
 cd /tmp
 for SET in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum"; do

@@ -36,7 +36,7 @@ for src, dst in ((f"{tag}_bench.json", f"{tag}_bench.json"), (f"{tag}_bench_prof
                  (f"{tag}_learning_curves_pointcircle.json", f"{tag}_learning_curves_pointcircle.json"), (f"{tag}_bench_shmem.json", f"{tag}_bench_shmem.json"),
                  (f"{tag}_ubench_gridsync.txt", f"{tag}_ubench_gridsync.txt"), (f"{tag}_ubench_dispatch.txt", f"{tag}_ubench_dispatch.txt"),
                  (f"{tag}_ubench_chain.txt", f"{tag}_ubench_chain.txt"), (f"{tag}_ubench_mfma_pat.txt", f"{tag}_ubench_mfma_pat.txt"),
-                 (f"{tag}_ubench_hwid.txt", f"{tag}_ubench_hwid.txt"), (f"{tag}_ab_trust_plans.json", f"{tag}_ab_trust_plans.json"),
+                 (f"{tag}_ubench_hwid.txt", f"{tag}_ubench_hwid.txt"), (f"{tag}_ab_trust_plans.json", f"{tag}_ab_trust_plans.json"), (f"{tag}_ab_wgrad_plans.json", f"{tag}_ab_wgrad_plans.json"),
                  (f"{tag}_pmc_trust_plans.json", f"{tag}_pmc_trust_plans.json")):
     if os.path.exists(os.path.join(go, src)):
         shutil.copy(os.path.join(go, src), os.path.join(pr, dst))
@@ -91,7 +91,7 @@ if out:
 #      the run, divided by the updates the traced command made (bench_trust.py: 1 warm-up + 5 timed; bench_sac.py: 200 + 3 x 200;
 #      cpo_stream = CPO with the one-pass streaming weight-gradient kernel, fsrl_tr_set_plan(wgrad = 3))
 upd = {}
-for alg, n_upd in (("cpo", 6), ("trpo", 6), ("sac", 800), ("cpo_stream", 6)):     # bench_sac.py: 200 warm-up + 3 blocks of --updates 200
+for alg, n_upd in (("cpo", 6), ("trpo", 6), ("sac", 800), ("cpo_stream", 6), ("cpo_splitk", 6)):     # bench_sac.py: 200 warm-up + 3 blocks of --updates 200
     by = defaultdict(lambda: {"launches": 0, "fetch_kib": 0.0, "write_kib": 0.0})
     ok = False
     for cname, key in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib")):
