@@ -68,6 +68,10 @@ def build(tag):
             c = b.get(key)
             if isinstance(c, dict) and "value" in c:
                 add(f"| {label} | {fmt(c['value'], 3)} updates/s on {c['cores']} threads |")
+        tb_ = b.get("torch_rocm_baseline")
+        if isinstance(tb_, dict) and "value" in tb_:
+            add(f"| stock PyTorch on THIS GPU (the reference's only GPU path: torch.nn / torch.optim with device=\"cuda\", ROCm torch; context, not a target) | "
+                f"{fmt(tb_['value'], 2)} updates/s ({fmt(tb_.get('us_per_grad_step'), 0)} us per optimiser step); the HIP path: {fmt(b['value'] / tb_['value'], 0)}x |")
         if isinstance(b.get("gpu_c0"), dict) and "value" in b["gpu_c0"]:
             add(f"| HIP path at the configs[0] shape (128x128) | {fmt(b['gpu_c0']['value'])} updates/s ({fmt(b['gpu_c0']['us_per_step'], 1)} us per step) |")
         if "speedup_vs_cpu_port" in b:
@@ -137,6 +141,9 @@ def build(tag):
             cpu = t.get("cpu_oracle_ms_per_update_4thr")
             add(f"| {kind.upper()} ({'obs 60, ' if kind == 'cpo' else ''}256x256, N = 20 000) | {fmt(t['hip_ms_per_update'], 1)} ms | {fmt(rf.get('frac'), 3)} | "
                 f"{(fmt(tb / 1e9, 2) + ' GB') if tb else 'n/a'} | {(fmt(cpu / 1e3, 1) + ' s = ' + fmt(t.get('speedup'), 0) + 'x') if cpu else 'n/a'} |")
+        ck = (upd.get("cpo_splitk") or {}).get("hbm_bytes_per_update")
+        if ck:
+            add(f"| CPO with round 5's split-K weight-gradient kernel (`fsrl_tr_set_plan(wgrad = 2)`: the default up to r5) | see the plan table below | | {fmt(ck / 1e9, 2)} GB | |")
         cs = (upd.get("cpo_stream") or {}).get("hbm_bytes_per_update")
         if cs:
             add(f"| CPO with the one-pass streaming weight-gradient kernel (`fsrl_tr_set_plan(wgrad = 3)`, not the default) | same time within 1-2 % "
@@ -197,10 +204,25 @@ def build(tag):
             c_ = sorted(med.get(("cpo", plan), [float("nan")])); t_ = sorted(med.get(("trpo", plan), [float("nan")]))
             add(f"| {plan} | {fmt(c_[len(c_) // 2], 2)} | {fmt(t_[len(t_) // 2], 2)} |")
         add("")
+    abw = [x for x in jl(f"{tag}_ab_wgrad_plans.json") if "alg" in x]
+    if abw:
+        med = {}
+        for x in abw:
+            med.setdefault((x["alg"], x["plan"]), []).append(x["ms"])
+        add(f"Weight-gradient kernels on one box, alternated, default tile plan (`tools/ab_trust_co.py --wgrad`, `profiles/{tag}_ab_wgrad_plans.json`; ms per update, median):\n")
+        plans = []
+        for (alg, plan) in med:
+            if plan not in plans:
+                plans.append(plan)
+        add("| weight-gradient plan (fsrl_tr_set_plan wgrad) | CPO configs[2] (obs 60) | TRPO-Lag (obs 8) |\n|---|---|---|")
+        for plan in plans:
+            c_ = sorted(med.get(("cpo", plan), [float("nan")])); t_ = sorted(med.get(("trpo", plan), [float("nan")]))
+            add(f"| {plan} | {fmt(c_[len(c_) // 2], 2)} | {fmt(t_[len(t_) // 2], 2)} |")
+        add("")
     f = os.path.join(PR, f"{tag}_pmc_trust_plans.json")
     if os.path.exists(f):
         pj = json.load(open(f))
-        names = [n for n in pj if any(k in n for k in ("fb_hvp_co", "fb_hvp_mixed_kernel<256, true", "fb_tile_co", "fb_tile_mixed", "fb_wgrad_kernel"))]
+        names = [n for n in pj if any(k in n for k in ("fb_hvp_co", "fb_hvp_mixed_kernel<256, true", "fb_tile_co", "fb_tile_mixed", "fb_wgrad_kernel", "fb_wgrad3_kernel"))]
         if names:
             add(f"Counter means per launch of the full-batch kernels (own PMC passes over `tools/ab_trust_co.py --only cpo`; `profiles/{tag}_pmc_trust_plans.json`; "
                 "cycles per SIMD = SQ_VALU_MFMA_BUSY_CYCLES / 1024, GPU cycles = GRBM_GUI_ACTIVE / 8 XCDs, LDS cycles per CU = SQ_LDS_IDX_ACTIVE / 256):\n")
