@@ -374,12 +374,15 @@ int fsrl_tr_eval(fsrl_ctx* ctx, double* stats8);
  * Gauss-Newton form of the product off (A/B): by default, whenever mean_old / std_old of the batch were computed at the present
  * theta -- every TRPO-Lag product (trpo_lag.py:189-190), CPO's products until its first line-search step -- the KL gradient
  * is identically zero and the heads use mu - mean_old = 0, std_old = sigma exactly (as the reference's autograd does on its
- * detached copy of the same forward), so the dz2 / dout terms vanish and are not computed.  wgrad: 0 = the split-K weight-gradient
- * kernel (default), 1 = the same with XCD-aware placement of its blocks, 3 = the one-pass streaming kernel for 256-wide layers
- * over >= 4096 rows (one workgroup per network, output quarter and row slice; operands by LDS-DMA; 2.6x less memory traffic,
- * the same time: not the default).  The tile_rows / hvp / wgrad 0-1 plans give bit-identical results; the streaming kernel adds
- * the rows up in another order (fp32 MFMA chains of different lengths, partials in float64): its results agree to rounding
- * (tests/test_gpu_fullsize.py states the tolerance).                                                                   */
+ * detached copy of the same forward), so the dz2 / dout terms vanish and are not computed.  wgrad (the weight-side products):
+ * 0 = automatic -- round 6's tile jobs (fb_wgrad3_kernel: every workgroup a 64 x 64 MFMA tile job, 512 threads, two per CU,
+ * XCD-aware block order) at 256-wide layers over >= 4096 rows with more than 32 observation columns, else round 5's split-K kernel;
+ * 1 = the split-K kernel with XCD-aware placement of its blocks, 2 = the split-K kernel; 3 = the one-pass streaming kernel
+ * (one workgroup per network, output quarter and row slice; operands by LDS-DMA); 4 = tile jobs wherever 256 wide / >= 4096 rows, in
+ * plain block order; 5 = the same in XCD-aware order with half the row splits; 6 = both.  The tile_rows / hvp plans give
+ * bit-identical results under EVERY wgrad plan; wgrad 1 and 2 agree to the bit, 0 and 4 where the tile jobs run; the kernel
+ * families add the rows up in different orders (fp32 MFMA chains of different lengths, partials in float64): their results
+ * agree to rounding (tests/test_gpu_fullsize.py states the tolerance).                                                  */
 int fsrl_tr_set_plan(fsrl_ctx* ctx, int32_t tile_rows, int32_t hvp, int32_t wgrad);
 /* A/B only: force how many 32-row tiles (per network) the co-resident launches of the tile kernel / of the cached Hessian
  * product start with, the remaining rows going to 16-row tiles behind them; -1 = automatic.  A PERSISTENT form exists:
