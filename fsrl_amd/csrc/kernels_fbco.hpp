@@ -366,6 +366,14 @@ struct TileCoSmem {
 static_assert(sizeof(TileCoSmem<256>) <= 80 * 1024, "two workgroups per CU");
 static_assert(64 * 32 + 256 * FSRL_W1_LDS <= 32 * (256 + 4), "x^T and the staged W1 share slot 1 during layer 1");
 
+// timing probes of the co-resident tile kernel (probe builds only: FSRL_TILE_PROBE=n ends every tile after phase n; results invalid).
+// The phase number travels in FbArgs::eta, which only the FOCOPS mode reads.
+#ifdef FSRL_PROBES
+#define TC_PROBE(a, n) ((a).mode != FB_MODE_FOCOPS && (int)(a).eta == (n))
+#else
+#define TC_PROBE(a, n) false
+#endif
+
 template <int H, int NH>
 __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __restrict__ P, const ModelDesc& md, const FbArgs& a,
                                              const int row0, const int stat_tile, const int y, const int ny) {
@@ -401,6 +409,7 @@ __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __r
     }
     for (int e = tid; e < R * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
     __syncthreads();
+    if (TC_PROBE(a, 1)) return;
 
     // ---- layer 1 -> h1 (slot 0): tile_forward's two paths, the wave's two column groups on the MFMA one
     if (Do <= FSRL_W1_LDS) {
@@ -453,6 +462,7 @@ __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __r
         }
     }
     __syncthreads();                                  // h1 complete; x^T / W1 in slot 1 are dead
+    if (TC_PROBE(a, 2)) return;
 
     // ---- layer 2 -> h2 (slot 1)
     CO_PRIO(2);
@@ -476,6 +486,7 @@ __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __r
     }
     CO_PRIO(0);
     __syncthreads();
+    if (TC_PROBE(a, 3)) return;
 
     // ---- head pre-activations: one wave per (row, output)
     for (int idx = wave; idx < R * no.out; idx += WAVES) {
@@ -529,6 +540,7 @@ __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __r
         a.statp[((size_t)(stat_tile + half) * ny + y) * FB_NSTAT + f] = t;
     }
     if (!backward) return;
+    if (TC_PROBE(a, 4)) return;
 
     // ---- activation backward (tile_backward): spills for the weight-gradient kernel
     const size_t nb = ((size_t)y * a.rows_pad + row0);
@@ -561,6 +573,7 @@ __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __r
         store4_fb(&D2[(size_t)i * H + 4 * c4], *reinterpret_cast<const f32x4*>(&d2[i * LD + 4 * c4]));
     }
     for (int e = tid; e < R * FSRL_DOW; e += NT) DOb[e] = sm.dout[e];
+    if (TC_PROBE(a, 5)) return;
     // ---- dz1 = (dz2 @ W2) * relu'(z1), the wave's two column groups
     CO_PRIO(2);
 #pragma unroll 1
