@@ -694,10 +694,9 @@ def main():
             # has no data-path collective, so the figure is the same either way; the line says which exchange ran.
             ok, why = 1, None
             try:
-                try:
-                    nccl_pg = dist.new_group(backend="nccl", timeout=timedelta(seconds=90), device_id=torch.device("cuda", local_rank))
-                except TypeError:                                   # older torch: no device_id on new_group
-                    nccl_pg = dist.new_group(backend="nccl", timeout=timedelta(seconds=90))
+                # no device_id: the communicator is created lazily by the first collective on the device torch.cuda.set_device chose
+                # (eager initialisation of a SECOND group next to a gloo default group is the less travelled path)
+                nccl_pg = dist.new_group(backend="nccl", timeout=timedelta(seconds=90))
                 probe = torch.ones(1, device="cuda")
                 dist.all_reduce(probe, group=nccl_pg)
                 torch.cuda.synchronize()
