@@ -307,3 +307,96 @@ def test_large_minibatch_without_grad_clip_vs_oracle():
     d = np.abs(eng.get_params() - o.get_params())
     assert np.quantile(d, 0.999) <= 5e-6 and d.max() <= 1e-4, (np.quantile(d, 0.999), d.max())
     eng.close()
+
+
+@pytest.mark.parametrize("Do,Da,rows", [
+    (33, 8, [1500, 1500, 1111]),      # NU = 3 chunks of one observation group, ragged N (4 111 rows: the last tile is 15 rows)
+    (64, 1, [4100]),                  # a full 64-column group, one action column
+    (65, 3, [2500, 2500]),            # second observation group with ONE column
+    (100, 6, [2100, 2000, 13]),       # two groups, 36 columns in the second (NU = 3)
+    (128, 16, [4096]),                # the maximum observation / action widths, the minimum row count of the kernel
+    (17, 2, [3000, 3000]),            # two chunks (NU' = 2): two dW1 jobs of two tile rows each
+    (4, 5, [5000]),                   # one chunk, forced onto the tile jobs (automatic keeps round 5's kernel here)
+])
+def test_tile_job_weight_gradients_shape_sweep_vs_autograd(Do, Da, rows):
+    """kernels_wgrad3.hpp over the shapes its job table branches on (chunks per observation group 1 / 2 / 3 / 4, one and two groups,
+    a ragged last group, 1 .. 16 action columns, N not a multiple of 16) against torch autograd of the oracle's losses
+    (cpo.py:177-182, 206-220): the surrogate gradient, the KL gradient away from theta_old and a Hessian-vector product, at
+    2e-5 / 5e-5 of the vector's largest entry (1e-4 for the surrogate, see below).  Plans:
+    4 = the tile jobs forced, 6 = with half the row splits, 2 = round 5's split-K kernel on the same inputs, 0 = automatic.
+    Then one whole CPO update (two critics per weight-gradient launch) under plan 4 against plan 2: same branch of the dual
+    solve, statistics within 2e-2 of their scale (downstream of conjugate gradients)."""
+    from fsrl_amd.engine import Engine, EngineConfig
+    from oracle.ppo_lag import OnPolicyData
+    from oracle.trust_region import CPOConfig, CPOOracle
+    from torch.distributions import Independent, Normal, kl_divergence
+    torch.set_num_threads(4)
+    H = 256
+    rng = np.random.default_rng(Do * 31 + Da)
+    cols = _synthetic(rng, rows, Do, Da, 250)
+    eng = Engine(EngineConfig(obs_dim=Do, act_dim=Da, hidden=H, env_num=len(rows), buffer_size=len(rows) * 5120,
+                              target_kl=None, max_action=1.0, lr=1e-3))
+    o = CPOOracle(CPOConfig(obs_dim=Do, act_dim=Da, hidden=(H, H)))
+    torch.manual_seed(Do)
+    theta = (0.08 * torch.randn(o.n_params)).numpy()
+    o.set_params(theta); eng.set_params(theta); eng.optim_reset()
+    for t in range(max(rows)):
+        ids = [e for e in range(len(rows)) if t < rows[e]]
+        eng.push(ids, *[np.stack([cols[k][e][t] for e in ids]) for k in ("obs", "act", "rew", "cost", "term", "trunc",
+                                                                         "obs_next")])
+    cat = {k: np.concatenate(v) for k, v in cols.items()}
+    end = (cat["term"] | cat["trunc"]).copy(); end[np.cumsum(rows) - 1] = True
+    data = OnPolicyData(obs=cat["obs"], act=cat["act"], rew=cat["rew"], cost=cat["cost"], terminated=cat["term"],
+                        truncated=cat["trunc"], obs_next=cat["obs_next"], end_flag=end)
+    pb = o.process(data)
+    assert eng.tr_begin(target_kl=0.01, norm_adv=True, cost_limit=10.0) == sum(rows)
+    na = eng.n_actor_params
+    moved = theta.copy()
+    moved[:na] += (0.01 * rng.standard_normal(na)).astype(np.float32)                # theta != theta_old: exact Hessian
+    o.set_params(moved); eng.set_params(moved)
+    dist = o.actor_dist(pb["obs"])
+    ratio = torch.exp(dist.log_prob(pb["act"]) - pb["logp_old"])
+    obj = torch.mean(ratio * pb["advs"][..., 0])
+    kl = kl_divergence(Independent(Normal(pb["mean_old"], pb["std_old"]), 1), dist).mean()
+    og = o.flat_grad(obj, retain_graph=True).numpy()
+    klg = o.flat_grad(kl, create_graph=True)
+    v = np.random.default_rng(1).standard_normal(og.size).astype(np.float32)
+    hv = o.flat_grad(torch.dot(klg, torch.from_numpy(v)), retain_graph=True).numpy()
+
+    errs = {}
+
+    def close(a, b, rel, what):
+        scale = max(float(np.abs(b).max()), 1e-12)
+        errs[what] = (float(np.abs(np.asarray(a) - np.asarray(b)).max()) / scale, rel)
+    got = {}
+    for plan in (4, 6, 2, 0):
+        eng.tr_set_plan(0, 0, plan)
+        got[plan] = (eng.tr_grad(0), eng.tr_grad(2), eng.tr_hvp(v))
+        # the surrogate gradient is a sum over mean-zero normalised advantages: it cancels to ~1e-2 of its terms, and the fp32
+        # advantage pipelines of the two sides (oracle: numpy, HIP: scan kernels) differ at 1e-7 -- 1e-4 of the result, the
+        # same under every plan; the plans among themselves agree to 2e-5 (below)
+        close(got[plan][0], og, 1e-4, (plan, "surrogate"))
+        close(got[plan][1], klg.detach().numpy(), 2e-5, (plan, "kl"))
+        close(got[plan][2], hv, 5e-5, (plan, "hvp"))
+        for j, what in enumerate(("surrogate", "kl", "hvp")):
+            close(got[plan][j], got[4][j], 2e-5, (plan, what, "vs plan 4"))
+    assert all(e <= rel for e, rel in errs.values()), errs
+    assert not np.array_equal(got[4][2], got[2][2])                                  # the tile jobs did run
+    auto = 4 if Do > 32 else 2
+    for a, b in zip(got[0], got[auto]):
+        assert np.array_equal(a, b)
+
+    def whole(plan):
+        eng.tr_set_plan(0, 0, plan)
+        eng.set_params(theta); eng.optim_reset()
+        eng.tr_begin(target_kl=0.01, l2_reg=0.001, critic_lr=1e-3, max_backtracks=10, optim_critic_iters=3, cost_limit=10.0)
+        return eng.cpo_learn(25.0, 1).copy(), eng.get_params().copy()
+    (sa, ta), (sb, tb) = whole(4), whole(2)
+    assert np.isfinite(sa).all() and sa[0, 12] == sb[0, 12]                          # loss/optim_case
+    sc = np.maximum(np.abs(sb[0]), 1e-3 * np.abs(sb[0]).max())
+    bad = np.abs(sa[0] - sb[0]) > 2e-2 * sc
+    assert not bad.any(), (np.flatnonzero(bad), sa[0], sb[0])
+    d = np.abs(ta - tb)
+    assert d.max() <= 5e-3 and d.mean() <= 5e-5, (d.max(), d.mean())
+    eng.tr_set_plan(0, 0, 0)
+    eng.close()
