@@ -275,11 +275,11 @@ template <bool PAIR2>
 static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int ny, int stride, int* nsplit) {
     const int H_ = c->cfg.hidden;
     // r6 default at 256 wide over a few thousand rows or more, for the callers that hand over the re-laid observations: every
-    // workgroup a 64 x 64 tile job (kernels_wgrad3.hpp), 512 threads, two per CU, ONE round of at most 2 x CUs workgroups
-    // Narrow observations (<= 32 columns) keep round 5's kernel unless the plan forces the tile jobs (wgrad 4 / 5 / 6): its aux role is
-    // one pass there and the launch is balanced as it is (TRPO-Lag at obs 8, same box: 23.4 vs 23.7 ms); at obs 60 (CPO configs[2])
-    // the aux role is 16 of 50 workgroups per split and the tile jobs win: 32.3 -> 31.1 ms, 362 -> 163 MB per launch.
-    const bool wg3_auto = c->wgrad_tiles == 1 ? md.Do > 32 : c->wgrad_tiles != 0;
+    // workgroup a 64 x 64 tile job (kernels_wgrad3.hpp), 512 threads, two per CU, ONE round of at most 2 x CUs workgroups, in
+    // XCD-aware block order.  Same box, against round 5's kernel: obs 60 (CPO configs[2]) 32.3 -> 28.9 ms, 362 -> 163 MB per launch;
+    // obs 8 (TRPO-Lag, one dW1 job per split) 21.93 -> 21.69 ms -- in plain block order it lost there (22.3), which is why narrow
+    // observations kept round 5's kernel until the XCD-aware order existed.
+    const bool wg3_auto = c->wgrad_tiles != 0;
     if (H_ == 256 && wa.rows >= 4096 && wa.obs_pad && wg3_auto) {
         for (int y = 0; y < ny; ++y)
             CHECK_ARG(wa.nets[y].b1_src == wa.nets[y].w1_y && wa.nets[y].b2_src == wa.nets[y].w2_ya && wa.nets[y].do_src == wa.nets[y].w3_ya,

@@ -376,9 +376,9 @@ int fsrl_tr_eval(fsrl_ctx* ctx, double* stats8);
  * is identically zero and the heads use mu - mean_old = 0, std_old = sigma exactly (as the reference's autograd does on its
  * detached copy of the same forward), so the dz2 / dout terms vanish and are not computed.  wgrad (the weight-side products):
  * 0 = automatic -- round 6's tile jobs (fb_wgrad3_kernel: every workgroup a 64 x 64 MFMA tile job, 512 threads, two per CU,
- * XCD-aware block order) at 256-wide layers over >= 4096 rows with more than 32 observation columns, else round 5's split-K kernel;
+ * XCD-aware block order) at 256-wide layers over >= 4096 rows, else round 5's split-K kernel;
  * 1 = the split-K kernel with XCD-aware placement of its blocks, 2 = the split-K kernel; 3 = the one-pass streaming kernel
- * (one workgroup per network, output quarter and row slice; operands by LDS-DMA); 4 = tile jobs wherever 256 wide / >= 4096 rows, in
+ * (one workgroup per network, output quarter and row slice; operands by LDS-DMA); 4 = the tile jobs in
  * plain block order; 5 = the same in XCD-aware order with half the row splits; 6 = both.  The tile_rows / hvp plans give
  * bit-identical results under EVERY wgrad plan; wgrad 1 and 2 agree to the bit, 0 and 4 where the tile jobs run; the kernel
  * families add the rows up in different orders (fp32 MFMA chains of different lengths, partials in float64): their results

@@ -310,7 +310,7 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
 
     # the tile / HVP plans are bit-identical under EVERY weight-gradient kernel (wgrad 4: r6's tile jobs, two workgroups per CU,
     # wherever they apply -- 256-wide layers, >= 4096 rows; wgrad 2: round 5's split-K kernel; wgrad 3: the one-pass streaming
-    # kernel); wgrad 0 = automatic: the tile jobs (in XCD-aware block order: same sums) above 32 observation columns, else split-K
+    # kernel); wgrad 0 = automatic: the tile jobs in XCD-aware block order (same sums as the plain order of wgrad 4)
     refs = {}
     for wg in (3, 2, 4):
         ref = refs[wg] = run(16, 1, wg)
@@ -326,7 +326,7 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
     # tolerance of the autograd comparison in test_gpu_trust.py); whole updates -- conjugate gradients amplify summation
     # order, DESIGN "conditioning note" -- at the fixture tolerances of test_gpu_trust.py (2e-2 on what is downstream of CG)
     auto = run(0, 0, 0)
-    same_as = refs[4] if obs_dim > 32 else refs[2]
+    same_as = refs[4]                # below 256 wide / 4096 rows every plan is round 5's kernel and refs[4] == refs[2] (checked below)
     for k in auto:
         assert np.array_equal(auto[k], same_as[k]), ("automatic weight-gradient plan", k)
     for a, b in ((refs[3], refs[2]), (refs[4], refs[2])):

@@ -316,7 +316,7 @@ def test_large_minibatch_without_grad_clip_vs_oracle():
     (100, 6, [2100, 2000, 13]),       # two groups, 36 columns in the second (NU = 3)
     (128, 16, [4096]),                # the maximum observation / action widths, the minimum row count of the kernel
     (17, 2, [3000, 3000]),            # two chunks (NU' = 2): two dW1 jobs of two tile rows each
-    (4, 5, [5000]),                   # one chunk, forced onto the tile jobs (automatic keeps round 5's kernel here)
+    (4, 5, [5000]),                   # one chunk: all four tile rows of hidden units in ONE dW1 job
 ])
 def test_tile_job_weight_gradients_shape_sweep_vs_autograd(Do, Da, rows):
     """kernels_wgrad3.hpp over the shapes its job table branches on (chunks per observation group 1 / 2 / 3 / 4, one and two groups,
@@ -382,8 +382,7 @@ def test_tile_job_weight_gradients_shape_sweep_vs_autograd(Do, Da, rows):
             close(got[plan][j], got[4][j], 2e-5, (plan, what, "vs plan 4"))
     assert all(e <= rel for e, rel in errs.values()), errs
     assert not np.array_equal(got[4][2], got[2][2])                                  # the tile jobs did run
-    auto = 4 if Do > 32 else 2
-    for a, b in zip(got[0], got[auto]):
+    for a, b in zip(got[0], got[4]):                                                 # automatic = the tile jobs (XCD-aware order: same sums)
         assert np.array_equal(a, b)
 
     def whole(plan):
