@@ -142,6 +142,10 @@ __device__ __forceinline__ void store4_fb(float* p, const f32x4 v) { *reinterpre
 __device__ __forceinline__ void store4_fb(float* p, const f32x4 v) { store4_next(p, v); }
 #endif
 
+// e / d for e < 2^16 as a multiply-high with ceil(2^32 / d) (exact there); d == 1 would need 2^32 itself: magic 0 stands for it
+__host__ __device__ __forceinline__ unsigned div_magic(const int d) { return d > 1 ? 0xFFFFFFFFu / (unsigned)d + 1u : 0u; }
+__device__ __forceinline__ int div_by_magic(const unsigned e, const unsigned magic) { return magic ? (int)__umulhi(e, magic) : (int)e; }
+
 // Global loads of the hot paths as BUFFER loads (r6): one SGPR resource per array + a 32-bit byte offset per lane
 // (`buffer_load_dwordx4 v, v_off, s[rsrc], 0 offen`) instead of a 64-bit address pair per lane and load.  fb_wgrad3_kernel, same box:
 // 60.4 -> 52.5 us per launch (the load side alone, MFMAs taken out: 28.4 -> 25.0 us), and the loads overlap the matrix work better.

@@ -148,21 +148,24 @@ __device__ __forceinline__ void fb_tr_actor_head(const float x, const float sigm
 
 // Activation backward of one tile given sm.dout: spills relu(z1), relu(z2), dz2, dout, dz1 for the
 // weight-gradient kernel.  wb = this wave's column slice of W2 (lane (li,q): W2[16jc+4q+s][16w+li]).
-// keep_dz1: also leave dz1 in sm.d2 (used for input gradients).  Always leaves dz1 in sm.d2 when
-// `FB_MODE_Q_DIN` callers ask for it via the trailing flag == true or read it after a barrier.
+// din (kernel-uniform; FB_MODE_Q_DIN, whose launch has no weight-gradient launch behind it): nothing is spilled -- 16 MB of
+// stores per SAC update that nobody reads -- and dz1 is left in sm.d2 for the input gradient instead; the other callers skip that
+// LDS pass and its barrier.
 template <int H, int R = 16>
 __device__ __forceinline__ void tile_backward(TileSmem<H, tile_rows(R)>& sm, const NetOff no, const float (&wb)[H / 16][4],
                                               float* __restrict__ A1, float* __restrict__ A2,
                                               float* __restrict__ D1, float* __restrict__ D2,
-                                              float* __restrict__ DOb, const int tid, const bool) {
+                                              float* __restrict__ DOb, const int tid, const bool din) {
     constexpr int LD = TileSmem<H>::LD;
     constexpr int NT = TileGeom<H>::NT;
     constexpr int H4 = H / 4;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
-    for (int e = tid; e < R * H4; e += NT) {
-        const int i = e / H4, c4 = e - i * H4;
-        store4_fb(&A1[(size_t)i * H + 4 * c4], *reinterpret_cast<const f32x4*>(&sm.h1[i * LD + 4 * c4]));
-        store4_fb(&A2[(size_t)i * H + 4 * c4], *reinterpret_cast<const f32x4*>(&sm.h2[i * LD + 4 * c4]));
+    if (!din) {
+        for (int e = tid; e < R * H4; e += NT) {
+            const int i = e / H4, c4 = e - i * H4;
+            store4_fb(&A1[(size_t)i * H + 4 * c4], *reinterpret_cast<const f32x4*>(&sm.h1[i * LD + 4 * c4]));
+            store4_fb(&A2[(size_t)i * H + 4 * c4], *reinterpret_cast<const f32x4*>(&sm.h2[i * LD + 4 * c4]));
+        }
     }
     for (int t = tid; t < (R / 4) * H; t += NT) {   // dz2 = (dout @ W3) * relu'(z2); one trip up to 16 rows, two for 32
         const int k = t % H, rg = t / H;
@@ -179,11 +182,13 @@ __device__ __forceinline__ void tile_backward(TileSmem<H, tile_rows(R)>& sm, con
         }
     }
     __syncthreads();
-    for (int e = tid; e < R * H4; e += NT) {
-        const int i = e / H4, c4 = e - i * H4;
-        store4_fb(&D2[(size_t)i * H + 4 * c4], *reinterpret_cast<const f32x4*>(&sm.d2[i * LD + 4 * c4]));
+    if (!din) {
+        for (int e = tid; e < R * H4; e += NT) {
+            const int i = e / H4, c4 = e - i * H4;
+            store4_fb(&D2[(size_t)i * H + 4 * c4], *reinterpret_cast<const f32x4*>(&sm.d2[i * LD + 4 * c4]));
+        }
+        for (int e = tid; e < R * FSRL_DOW; e += NT) DOb[e] = sm.dout[e];
     }
-    for (int e = tid; e < R * FSRL_DOW; e += NT) DOb[e] = sm.dout[e];
     // dz1 = (dz2 @ W2) * relu'(z1)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int col = wave * 16 + li;
@@ -204,12 +209,14 @@ __device__ __forceinline__ void tile_backward(TileSmem<H, tile_rows(R)>& sm, con
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             v[r] = (sm.h1[r * LD + col] > 0.0f) ? acc[r] : 0.0f;
-            if (q == 0) D1[(size_t)r * H + col] = v[r];
+            if (q == 0 && !din) D1[(size_t)r * H + col] = v[r];
         }
-        __syncthreads();          // every wave is done reading dz2 from sm.d2
-        if (q == 0) {
+        if (din) {
+            __syncthreads();          // every wave is done reading dz2 from sm.d2
+            if (q == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sm.d2[r * LD + col] = v[r];   // dz1, for input gradients
+                for (int r = 0; r < 4; ++r) sm.d2[r * LD + col] = v[r];   // dz1, for input gradients
+            }
         }
     } else {
         f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};                  // rows 16..31 of a 32-row tile: same fragment, second pass
@@ -230,17 +237,19 @@ __device__ __forceinline__ void tile_backward(TileSmem<H, tile_rows(R)>& sm, con
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * q + r;
             v[r] = (sm.h1[i * LD + col] > 0.0f) ? acc[r] : 0.0f;
-            D1[(size_t)i * H + col] = v[r];
+            if (!din) D1[(size_t)i * H + col] = v[r];
             if constexpr (R == 32) {
                 v2[r] = (sm.h1[(16 + i) * LD + col] > 0.0f) ? acc2[r] : 0.0f;
-                D1[(size_t)(16 + i) * H + col] = v2[r];
+                if (!din) D1[(size_t)(16 + i) * H + col] = v2[r];
             }
         }
-        __syncthreads();          // every wave is done reading dz2 from sm.d2
+        if (din) {
+            __syncthreads();          // every wave is done reading dz2 from sm.d2
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sm.d2[(4 * q + r) * LD + col] = v[r];   // dz1, for input gradients
-            if constexpr (R == 32) sm.d2[(16 + 4 * q + r) * LD + col] = v2[r];
+            for (int r = 0; r < 4; ++r) {
+                sm.d2[(4 * q + r) * LD + col] = v[r];   // dz1, for input gradients
+                if constexpr (R == 32) sm.d2[(16 + 4 * q + r) * LD + col] = v2[r];
+            }
         }
     }
 }
@@ -415,19 +424,41 @@ __device__ __forceinline__ void fb_tile_body(TileSmem<H, tile_rows(R)>& sm, cons
     if (!backward) return;
 
     const size_t nb = (size_t)y * a.rows_pad;
+    const bool din = a.mode == FB_MODE_Q_DIN;
+    // Q_DIN: the action columns of W1 ([H][Dact], 2 .. 16 floats per thread) start their trip now, underneath the backward pass
+    // (16-row tiles: the 4-row kernel at 256 wide sits at its 128-register cap and fetches them behind the backward pass as before)
+    constexpr bool PRE = (R == 16);
+    constexpr int NWA = (H * FSRL_MAX_ACT + NT - 1) / NT;
+    float wav[NWA];
+    const int Dact = a.act_cols, Dobs = Do - Dact;
+    if (din && PRE) {
+        const unsigned magic = div_magic(Dact);        // e / Dact by multiply-high: exact for e < 2^16
+#pragma unroll
+        for (int u = 0; u < NWA; ++u) {
+            const int e = min(tid + u * NT, H * Dact - 1);
+            const int j = div_by_magic((unsigned)e, magic), kk = e - j * Dact;
+            wav[u] = P[no.W1 + (size_t)j * Do + Dobs + kk];
+        }
+    }
     tile_backward<H, R>(sm, no, wb, a.A1 + (nb + row0) * H, a.A2 + (nb + row0) * H, a.D1 + (nb + row0) * H,
-                     a.D2 + (nb + row0) * H, a.DO + (nb + row0) * FSRL_DOW, tid, false);
-    if (a.mode == FB_MODE_Q_DIN) {
+                     a.D2 + (nb + row0) * H, a.DO + (nb + row0) * FSRL_DOW, tid, din);
+    if (din) {
         // input gradient w.r.t. the action columns of x = concat(obs, act):
         //   da[i][k] = sum_j dz1[i][j] * W1[j][Do_obs + k]       (dz1 left in sm.d2 by tile_backward)
-        __syncthreads();
-        const int Dact = a.act_cols, Dobs = Do - Dact;
-        // stage the action columns of W1 ([H][Dact]) into LDS with one coalesced burst (sm.h2 is
-        // free now), then thread (row i, column kk, j-phase jp) sums 1/8 of the j range
+        // the action columns of W1 go to LDS (sm.h2 is free: its last readers sit before tile_backward's first barrier), then
+        // thread (row i, column kk, j-phase jp) sums 1/8 of the j range
         float* __restrict__ wact = sm.h2;
-        for (int e = tid; e < H * Dact; e += NT) {
-            const int j = e / Dact, kk = e - j * Dact;
-            wact[e] = P[no.W1 + (size_t)j * Do + Dobs + kk];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int u = 0; u < NWA; ++u) {
+                const int e = tid + u * NT;
+                if (e < H * Dact) wact[e] = wav[u];
+            }
+        } else {
+            for (int e = tid; e < H * Dact; e += NT) {
+                const int j = e / Dact, kk = e - j * Dact;
+                wact[e] = P[no.W1 + (size_t)j * Do + Dobs + kk];
+            }
         }
         __syncthreads();
         for (int e0 = 0; e0 < R * Dact * 8; e0 += NT) {

@@ -125,16 +125,37 @@ struct TileStage {
         b3v = (tid < no.out) ? t3 : 0.0f;
         sgv = (no.sigma >= 0 && tid < Da) ? t4 : 0.0f;
     }
+    // the small parameters alone, for a caller that fills xv / rdv itself (the SAC actors' forward launch gathers its rows
+    // straight into the stage registers)
+    __device__ __forceinline__ void issue_params(const float* __restrict__ P, const NetOff no, const int Do, const int Da,
+                                                 const int tid) {
+        const int n3 = no.out * H, n1 = (Do <= FSRL_W1_LDS) ? H * Do : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + u * NT;
+            const float a = P[no.W3 + min(e, n3 - 1)];
+            const float b = P[no.W1 + min(e, max(n1 - 1, 0))];
+            w3v[u] = (e < n3) ? a : 0.0f;
+            w1v[u] = (e < n1) ? b : 0.0f;
+        }
+        const float t1 = P[no.b1 + min(tid, H - 1)], t2 = P[no.b2 + min(tid, H - 1)];
+        const float t3 = P[no.b3 + min(tid, no.out - 1)];
+        const float t4 = P[max(no.sigma, 0) + min(tid, Da - 1)];
+        b1v = (tid < H) ? t1 : 0.0f;
+        b2v = (tid < H) ? t2 : 0.0f;
+        b3v = (tid < no.out) ? t3 : 0.0f;
+        sgv = (no.sigma >= 0 && tid < Da) ? t4 : 0.0f;
+    }
 
     __device__ __forceinline__ void commit(TileSmem<H, ROWS>& sm, const NetOff no, const int Do,
                                            const int tid) const {
         // e -> (row i, column k) = (e / Do, e % Do) by a multiply-high with ceil(2^32 / Do): exact for e < 2^16
-        const unsigned magic = 0xFFFFFFFFu / (unsigned)Do + 1u;
+        const unsigned magic = div_magic(Do);
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
             const int e = tid + u * NT;
             if (e < ROWS * Do) {
-                const int i = (int)__umulhi((unsigned)e, magic), k = e - i * Do;
+                const int i = div_by_magic((unsigned)e, magic), k = e - i * Do;
                 sm.xT[k * ROWS + i] = xv[u];
             }
         }
@@ -354,7 +375,7 @@ __global__ __launch_bounds__(4 * H) void mlp_infer_kernel(const float* __restric
     const NetOff no = md.net[net];
     const int Do = md.Do;
     const int n_tiles = (a.N + 15) >> 4;
-    const unsigned magic = 0xFFFFFFFFu / (unsigned)Do + 1u;      // e / Do as a multiply-high (exact for e < 2^16)
+    const unsigned magic = div_magic(Do);      // e / Do as a multiply-high (exact for e < 2^16)
     const float* __restrict__ X = use_next ? a.obs_next : a.obs;
     int tile = blockIdx.x;
     int row0 = tile * 16;
@@ -415,7 +436,7 @@ __global__ __launch_bounds__(4 * H) void mlp_infer_kernel(const float* __restric
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
             const int e = tid + u * NT;
-            if (e < 16 * Do) { const int i = (int)__umulhi((unsigned)e, magic), k = e - i * Do; sm.xT[k * 16 + i] = xn[u]; }
+            if (e < 16 * Do) { const int i = div_by_magic((unsigned)e, magic), k = e - i * Do; sm.xT[k * 16 + i] = xn[u]; }
         }
         tile = ntile; row0 = nrow0; n_valid = nn_valid;
     }

@@ -64,9 +64,21 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
     sincospif(2.0f * u2, &sn, &cs);
     n0 = rad * cs; n1 = rad * sn;
 }
-// one sampled row: the uniform index, its n-step chain with the end flags, the two rsample noise rows.  -> (index, terminal index)
-__device__ __forceinline__ void sac_sample_row(const SacSampleArgs& a, const SacBook* __restrict__ book, const int b,
-                                               const uint32_t k0, const uint32_t k1, int* idx_out = nullptr, int* term_out = nullptr) {
+// the two rsample noise values of row b, dimensions d0 and d0 + 1: 4 normals per Philox block, 2 for each stream
+__device__ __forceinline__ void sac_sample_noise(const SacSampleArgs& a, const int b, const int d0, const uint32_t k0, const uint32_t k1) {
+    uint32_t r[4] = {(uint32_t)b, 1u + (uint32_t)(d0 >> 1), (uint32_t)a.counter, (uint32_t)(a.counter >> 32)};
+    philox4x32_10(r, k0, k1);
+    float t0, t1, p0, p1;
+    box_muller(r[0], r[1], t0, t1);
+    box_muller(r[2], r[3], p0, p1);
+    a.eps_t[(size_t)b * a.Da + d0] = t0; a.eps_p[(size_t)b * a.Da + d0] = p0;
+    if (d0 + 1 < a.Da) { a.eps_t[(size_t)b * a.Da + d0 + 1] = t1; a.eps_p[(size_t)b * a.Da + d0 + 1] = p1; }
+}
+// index and n-step chain of sampled row b -> (index, terminal index); the chain's LAST end bit is left to the caller as (flag byte,
+// at-the-write-head) so that the load behind it need not have landed when the caller moves on (sac_sample_end_last)
+__device__ __forceinline__ void sac_sample_index(const SacSampleArgs& a, const SacBook* __restrict__ book, const int b,
+                                                 const uint32_t k0, const uint32_t k1, int& idx, int& term,
+                                                 unsigned char& f_last, bool& head_last) {
     uint32_t c[4] = {(uint32_t)b, 0u, (uint32_t)a.counter, (uint32_t)(a.counter >> 32)};
     philox4x32_10(c, k0, k1);
     unsigned long long k = ((unsigned long long)c[0] * a.stored) >> 32;    // uniform over the stored rows
@@ -74,29 +86,38 @@ __device__ __forceinline__ void sac_sample_row(const SacSampleArgs& a, const Sac
     while (e < a.env_num - 1 && k >= (unsigned long long)book[e].size) { k -= book[e].size; ++e; }
     int cur = e * a.sub_size + (int)k;
     a.idx[b] = cur;
-    if (idx_out) *idx_out = cur;
+    idx = cur;
+    unsigned char f = a.flags[cur];
+    bool head = false;
     for (int n = 0; n < a.n_step; ++n) {
         const int env = cur / a.sub_size, local = cur - env * a.sub_size;
         const SacBook bk = book[env];
         if (n > 0) {                                   // indices[n] = buffer.next(indices[n-1])
-            const bool end = a.flags[cur] != 0 || local == bk.last_index;
-            if (!end && bk.size > 0) cur = env * a.sub_size + (local + 1) % bk.size;
+            const bool end = f != 0 || local == bk.last_index;
+            if (!end && bk.size > 0) { cur = env * a.sub_size + (local + 1) % bk.size; f = a.flags[cur]; }
         }
         const int loc2 = cur - env * a.sub_size;
         a.chain[(size_t)n * a.B + b] = cur;
-        a.endbits[(size_t)n * a.B + b] =
-            (a.flags[cur] != 0 || (bk.size > 0 && loc2 == (bk.index - 1 + bk.size) % bk.size)) ? 1 : 0;
+        head = bk.size > 0 && loc2 == (bk.index - 1 + bk.size) % bk.size;
+        if (n + 1 < a.n_step) a.endbits[(size_t)n * a.B + b] = (f != 0 || head) ? 1 : 0;
     }
-    if (term_out) *term_out = cur;                     // the chain's last element
-    for (int d0 = 0; d0 < a.Da; d0 += 2) {             // 4 normals per Philox block: 2 for each stream
-        uint32_t r[4] = {(uint32_t)b, 1u + (uint32_t)(d0 >> 1), (uint32_t)a.counter, (uint32_t)(a.counter >> 32)};
-        philox4x32_10(r, k0, k1);
-        float t0, t1, p0, p1;
-        box_muller(r[0], r[1], t0, t1);
-        box_muller(r[2], r[3], p0, p1);
-        a.eps_t[(size_t)b * a.Da + d0] = t0; a.eps_p[(size_t)b * a.Da + d0] = p0;
-        if (d0 + 1 < a.Da) { a.eps_t[(size_t)b * a.Da + d0 + 1] = t1; a.eps_p[(size_t)b * a.Da + d0 + 1] = p1; }
-    }
+    term = cur;                                        // the chain's last element
+    f_last = f; head_last = head;
+}
+__device__ __forceinline__ void sac_sample_end_last(const SacSampleArgs& a, const int b, const unsigned char f_last, const bool head_last) {
+    a.endbits[(size_t)(a.n_step - 1) * a.B + b] = (f_last != 0 || head_last) ? 1 : 0;
+}
+// one sampled row: the uniform index, its n-step chain with the end flags, the two rsample noise rows.  -> (index, terminal index)
+__device__ __forceinline__ void sac_sample_row(const SacSampleArgs& a, const SacBook* __restrict__ book, const int b,
+                                               const uint32_t k0, const uint32_t k1, int* idx_out = nullptr, int* term_out = nullptr) {
+    int idx, term;
+    unsigned char f;
+    bool head;
+    sac_sample_index(a, book, b, k0, k1, idx, term, f, head);
+    sac_sample_end_last(a, b, f, head);
+    if (idx_out) *idx_out = idx;
+    if (term_out) *term_out = term;
+    for (int d0 = 0; d0 < a.Da; d0 += 2) sac_sample_noise(a, b, d0, k0, k1);
 }
 
 __global__ __launch_bounds__(256) void sac_sample_kernel(const SacSampleArgs a) {
@@ -214,6 +235,7 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
     const int n_valid = max(0, min(R, a.B - row0));
     const float invB = 1.0f / (float)a.B;
 
+    TileStage<H> stg;
     if (a.sg_on) {
         constexpr int BOOK_LDS = 512;
         __shared__ SacBook book_s[BOOK_LDS];
@@ -224,33 +246,54 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
             __syncthreads();
         }
         const SacBook* __restrict__ book = in_lds ? book_s : a.sa.book;
-        if (tid < R && row0 + tid < a.B)       // both halves draw their rows: the same counters, the same values, written twice
-            sac_sample_row(a.sa, book, row0 + tid, (uint32_t)a.sa.key, (uint32_t)(a.sa.key >> 32), &idx_s[tid], &term_s[tid]);
+        if (tid < 16) { idx_s[tid] = 0; term_s[tid] = 0; }
+        // both halves draw their rows: the same counters, the same values, written twice.  Index + chain: one thread per row in wave 0;
+        // the noise: one thread per (row, pair of action dimensions) from wave 1 on
+        const int npair = (Da + 1) >> 1;
+        const bool sampler = tid < R && row0 + tid < a.B;
+        unsigned char f_last = 0;
+        bool head_last = false;
+        if (sampler) {
+            int idx, term;
+            sac_sample_index(a.sa, book, row0 + tid, (uint32_t)a.sa.key, (uint32_t)(a.sa.key >> 32), idx, term, f_last, head_last);
+            idx_s[tid] = idx; term_s[tid] = term;
+        } else if (tid >= 64 && tid < 64 + R * npair) {
+            const int t = tid - 64, rl = t / npair, pp = t - rl * npair;
+            if (row0 + rl < a.B) sac_sample_noise(a.sa, row0 + rl, 2 * pp, (uint32_t)a.sa.key, (uint32_t)(a.sa.key >> 32));
+        }
         __syncthreads();
+        if (sampler) sac_sample_end_last(a.sa, row0 + tid, f_last, head_last);     // its flag byte may still be in flight at the barrier
+        // r6: the gathered rows go STRAIGHT into the stage registers (element e = row * Do + k: the stage's own mapping) and to the
+        // batch arrays the later launches read; until r5 they were stored, waited for and read back (two more round trips)
         const SacGatherArgs& g = a.ga;
-        const int Din = Do + Da;
-        if (second) {
-            for (int e = tid; e < n_valid * Din; e += NT) {
-                const int rl = e / Din, f = e - rl * Din, r = row0 + rl;
-                const size_t s_ = (size_t)idx_s[rl], o = (size_t)r * Din + f;
-                if (f < Do) {
-                    const float ob = g.st.obs[s_ * Do + f];
-                    g.XQ[o] = ob; g.XP[o] = ob; g.OBS[(size_t)r * Do + f] = ob;
-                } else {
-                    g.XQ[o] = g.st.act[s_ * Da + (f - Do)];
-                }
-            }
-        } else {
-            for (int e = tid; e < n_valid * Do; e += NT) {
-                const int rl = e / Do, f = e - rl * Do, r = row0 + rl;
-                const float on = g.st.obs_next[(size_t)term_s[rl] * Do + f];
-                g.XN[(size_t)r * Din + f] = on; g.OBSN[(size_t)r * Do + f] = on;
+        const int Din = Do + Da, nx = n_valid * Do;
+        const unsigned magic = div_magic(Do);
+        const float* __restrict__ src = second ? g.st.obs : g.st.obs_next;
+        const int* __restrict__ row_s = second ? idx_s : term_s;
+#pragma unroll
+        for (int u = 0; u < TileStage<H>::NX; ++u) {
+            const int e = tid + u * NT, ec = min(e, max(nx - 1, 0));
+            const int i = div_by_magic((unsigned)ec, magic), k = ec - i * Do;
+            const float v = src[(size_t)row_s[i] * Do + k];
+            stg.xv[u] = (e < nx) ? v : 0.0f;
+            if (e < nx) {
+                const size_t r = (size_t)(row0 + i);
+                if (second) { g.XQ[r * Din + k] = v; g.XP[r * Din + k] = v; g.OBS[r * Do + k] = v; }
+                else { g.XN[r * Din + k] = v; g.OBSN[r * Do + k] = v; }
             }
         }
-        __syncthreads();                       // s_waitcnt vmcnt(0) + barrier: the rows read below are this workgroup's own stores
+        if (second) {
+            for (int e = tid; e < n_valid * Da; e += NT) {
+                const int rl = e / Da, f = e - rl * Da;
+                g.XQ[(size_t)(row0 + rl) * Din + Do + f] = g.st.act[(size_t)idx_s[rl] * Da + f];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TileStage<H>::NR; ++u) stg.rdv[u] = 0.0f;
+        stg.issue_params(Pn, no, Do, 0, tid);
+    } else {
+        stg.issue(Pn, no, Do, 0, obs_ + (size_t)row0 * Do, nullptr, n_valid, tid);
     }
-    TileStage<H> stg;
-    stg.issue(Pn, no, Do, 0, obs_ + (size_t)row0 * Do, nullptr, n_valid, tid);
     FwdW2Frag<H> wf;
     wf.load(Pn + no.W2f, wave, lane);
     for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;

@@ -34,6 +34,7 @@ SHAPES = [  # obs, act, hidden, rows per env, episode length, batch, repeat
     (60, 2, 256, [520], 520, 512, 1),                  # one env, unfinished episode only, two 16-row steps
     (8, 2, 256, [700, 600], 100, 1024, 2),             # one merged minibatch of 1 300 rows: the split-K weight-gradient path
     (12, 3, 128, [900, 900, 500], 150, 1024, 2),       # 1 024 + 1 276 rows per pass at 128 wide
+    (1, 1, 64, [100, 60], 25, 64, 2),                  # ONE observation column (r6: the stage's divide-by-multiply needs its d = 1 case)
 ]
 
 
