@@ -271,8 +271,12 @@ static int ensure_parts(fsrl_ctx* c, int stride, int nsplit) {
     c->wg_parts = slot->p;
     return 0;
 }
+// rider (replay agents, the actor's launch): blocks appended along x draw + gather the next update's batch (kernels_sample.hpp);
+// *rider_done tells the caller whether this launch carried them (only the 3-D grid of round 5's split-K kernel does)
 template <bool PAIR2>
-static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int ny, int stride, int* nsplit) {
+static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int ny, int stride, int* nsplit,
+                        SgRider* rider = nullptr, bool* rider_done = nullptr) {
+    if (rider_done) *rider_done = false;
     const int H_ = c->cfg.hidden;
     // r6 default at 256 wide over a few thousand rows or more, for the callers that hand over the re-laid observations: every
     // workgroup a 64 x 64 tile job (kernels_wgrad3.hpp), 512 threads, two per CU, ONE round of at most 2 x CUs workgroups, in
@@ -339,9 +343,14 @@ static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int n
         constexpr int HH = decltype(hc)::value;
         if (c->wgrad_xcd) {
             wa.remap_total = NB * ny * pl.nsplit; wa.remap_ny = ny;
-            hipLaunchKernelGGL((fb_wgrad_kernel<HH, PAIR2>), dim3(round_up(wa.remap_total, 8)), dim3(1024), 0, c->compute, md, wa);
+            hipLaunchKernelGGL((fb_wgrad_kernel<HH, PAIR2>), dim3(round_up(wa.remap_total, 8)), dim3(1024), 0, c->compute, md, wa, NoRider{});
+        } else if (rider && !PAIR2) {
+            const int blocks = (rider->sa.B + SG_ROWS - 1) / SG_ROWS;
+            rider->x0 = NB; rider->nx = (blocks + ny * pl.nsplit - 1) / (ny * pl.nsplit);
+            hipLaunchKernelGGL((fb_wgrad_kernel<HH, false, SgRider>), dim3(NB + rider->nx, ny, pl.nsplit), dim3(1024), 0, c->compute, md, wa, *rider);
+            if (rider_done) *rider_done = true;
         } else
-        hipLaunchKernelGGL((fb_wgrad_kernel<HH, PAIR2>), dim3(NB, ny, pl.nsplit), dim3(1024), 0, c->compute, md, wa);
+        hipLaunchKernelGGL((fb_wgrad_kernel<HH, PAIR2>), dim3(NB, ny, pl.nsplit), dim3(1024), 0, c->compute, md, wa, NoRider{});
         HIPCHK(hipGetLastError());
         return 0;
     });

@@ -11,6 +11,7 @@
 // grid is ceil(N/16) tiles, and the weight-gradient kernel loops over all N rows.
 #pragma once
 #include "kernels_mlp.hpp"
+#include "kernels_sample.hpp"
 
 #define FB_MODE_VF 0     // critics: d/dtheta mean((ret - V)^2)
 #define FB_MODE_SUR 1    // actor: d/dtheta mean((cr*A_r + cc*A_c) * ratio)
@@ -1288,8 +1289,16 @@ __device__ __forceinline__ void wgrad_aux_pass(const FbWgradArgs& wa, const FbWg
 // [4*z*ks_per_split, 4*(z+1)*ks_per_split) and writes a PARTIAL gradient; the consumer
 // (fb_sum_parts_kernel or adam_range_kernel's nparts) adds the partials in z order, so the result
 // does not depend on scheduling.  PAIR2: second operand pair (R-op products of the HVP).
-template <int H, bool PAIR2>
-__global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, const FbWgradArgs wa) {
+// Rider (kernels_sample.hpp): SgRider appends blocks along x that draw + gather the replay agents' next batch on the CUs this launch
+// leaves idle; NoRider (every other caller) compiles to the kernel as it was.
+template <int H, bool PAIR2, class Rider = NoRider>
+__global__ __launch_bounds__(1024) void fb_wgrad_kernel(const ModelDesc md, const FbWgradArgs wa, const Rider rider = Rider{}) {
+    if constexpr (Rider::on) {
+        if ((int)blockIdx.x >= rider.x0) {
+            sac_sample_gather_block(rider.sa, rider.ga, (int)((blockIdx.z * gridDim.y + blockIdx.y) * rider.nx + blockIdx.x - rider.x0));
+            return;
+        }
+    }
     constexpr int TPD = H / 64;             // dW2 tiles of 64 x 64 outputs
     constexpr int NT2 = TPD * TPD;
     constexpr int NA = H / FB_AUX_COLS;

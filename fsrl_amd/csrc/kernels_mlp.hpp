@@ -184,7 +184,10 @@ struct TileStage {
 // column quads), each q-class accumulates its quarter of K and the classes are added at the end.
 // R = 32: two 16-row MFMA passes per weight fragment (the fragment registers are the same; the per-element K order is
 // the 16-row tile's, so a row's result does not depend on the tile height).
-template <int H, int R = 16>
+// WIDE_HEAD (the replay agents' actors: 2 * act_dim outputs, 16 at act_dim 8): the head Linear of a 16-row tile on MFMA, split-K
+// over the waves, partial 16 x 16 tiles through sm.d2 (free until the backward pass) -- the wave-per-(row, output) loop below takes
+// R * out / WAVES dependent LDS -> FMA -> wave_sum trips (16 at out = 16: 5 us of the actors' forward launch, phase probes r6).
+template <int H, int R = 16, bool WIDE_HEAD = false>
 __device__ __forceinline__ void tile_forward(TileSmem<H, tile_rows(R)>& sm, const float* __restrict__ P,
                                              const NetOff no, const int Do, const int tid,
                                              const FwdW2Frag<H>& wf, unsigned long long* ts = nullptr) {
@@ -319,6 +322,30 @@ __device__ __forceinline__ void tile_forward(TileSmem<H, tile_rows(R)>& sm, cons
     __syncthreads();
     FSRL_TS(ts, 5);
 
+    if constexpr (WIDE_HEAD && R == 16) {
+        if (no.out > 4) {
+            // wave w: k in [16 w, 16 w + 16), lane (li, q) holds h2[li][16 w + 4 q + s] and W3[li][16 w + 4 q + s], s = 0 .. 3
+            const f32x4 av = *reinterpret_cast<const f32x4*>(&sm.h2[li * LD + 16 * wave + 4 * q]);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(&sm.w3[li * H + 16 * wave + 4 * q]);     // rows >= out: whatever LDS holds, masked
+            const bool on = li < no.out;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) acc = mfma_16x16x4(av[s2], on ? wv[s2] : 0.0f, acc);
+            float* __restrict__ part = sm.d2;                 // [WAVES][16 rows][16 outputs]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(wave * 16 + 4 * q + r) * 16 + li] = acc[r];
+            __syncthreads();
+            if (tid < 256) {
+                const int i = tid >> 4, o = tid & 15;
+                float t = 0.0f;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) t += part[(w * 16 + i) * 16 + o];      // fixed order: deterministic
+                if (o < no.out) sm.out[i * FSRL_MAX_ACT + o] = t + sm.b3[o];
+            }
+            __syncthreads();
+            return;
+        }
+    }
     // ---- head (out <= 16): one wave per row, 64-lane shuffle reduce
     for (int idx = wave; idx < R * no.out; idx += WAVES) {      // one wave per (row, output): a 4-row actor tile keeps 8 waves busy
         const int i = idx / no.out, o = idx - i * no.out;

@@ -4,23 +4,14 @@
 // float64 n-step target, the scalar bookkeeping (alpha, logged stats) and the Polyak update.
 #pragma once
 #include "kernels_fb.hpp"
+#include "kernels_sample.hpp"
 
 #define SAC_LOG_SIG_MIN (-20.0f)
 #define SAC_LOG_SIG_MAX (2.0f)
 #define SAC_F32_EPS 1.1920928955078125e-07f   // np.finfo(np.float32).eps  (sac_lag.py:118)
 #define FSRL_SAC_NSTATS_K 10
 
-// ---- replay gather: rows `idx` (sampled) and `term` (n-step terminal) of the store
-struct SacGatherArgs {
-    StorePtrs st;
-    const int* idx; const int* term;
-    float* XQ;      // [B][Do+Da] concat(obs, act)               (critic update)
-    float* OBS;     // [B][Do]
-    float* OBSN;    // [B][Do]   obs_next at the terminal index
-    float* XN;      // [B][Do+Da] obs part of concat(obs_next_T, a')
-    float* XP;      // [B][Do+Da] obs part of concat(obs, a_pi)
-    int B, Do, Da;
-};
+// (SacGatherArgs, the sampler's structs and device functions: kernels_sample.hpp)
 __global__ void sac_gather_kernel(const SacGatherArgs a) {
     const int Din = a.Do + a.Da;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < a.B * Din; e += gridDim.x * blockDim.x) {
@@ -34,90 +25,6 @@ __global__ void sac_gather_kernel(const SacGatherArgs a) {
             a.XQ[e] = a.st.act[s * a.Da + (f - a.Do)];
         }
     }
-}
-
-// ---- device-side sampling (library RNG mode): uniform rows of the store, their n-step chains
-//      (tianshou ReplayBuffer.next / unfinished_index) and the two rsample N(0,1) blocks.
-//      Philox4x32-10 counter RNG: counter = (row, draw, update lo, update hi), key = seed.
-struct SacBook { int size, index, last_index, pad; };     // one sub-buffer's bookkeeping
-struct SacSampleArgs {
-    const SacBook* book; const uint8_t* flags;
-    int* idx; int* chain; uint8_t* endbits; float* eps_t; float* eps_p;
-    int env_num, sub_size, B, n_step, Da;
-    unsigned long long stored, key, counter;
-    float* eps_k; int K;      // CVPO: the K particles' N(0,1) block [K][B][Da] (NULL otherwise)
-};
-__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-        c[0] = hi1 ^ c[1] ^ k0; c[1] = lo1; c[2] = hi0 ^ c[3] ^ k1; c[3] = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-}
-__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
-    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
-    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);              // [0, 1)
-    const float rad = sqrtf(-2.0f * logf(u1));
-    float sn, cs;
-    sincospif(2.0f * u2, &sn, &cs);
-    n0 = rad * cs; n1 = rad * sn;
-}
-// the two rsample noise values of row b, dimensions d0 and d0 + 1: 4 normals per Philox block, 2 for each stream
-__device__ __forceinline__ void sac_sample_noise(const SacSampleArgs& a, const int b, const int d0, const uint32_t k0, const uint32_t k1) {
-    uint32_t r[4] = {(uint32_t)b, 1u + (uint32_t)(d0 >> 1), (uint32_t)a.counter, (uint32_t)(a.counter >> 32)};
-    philox4x32_10(r, k0, k1);
-    float t0, t1, p0, p1;
-    box_muller(r[0], r[1], t0, t1);
-    box_muller(r[2], r[3], p0, p1);
-    a.eps_t[(size_t)b * a.Da + d0] = t0; a.eps_p[(size_t)b * a.Da + d0] = p0;
-    if (d0 + 1 < a.Da) { a.eps_t[(size_t)b * a.Da + d0 + 1] = t1; a.eps_p[(size_t)b * a.Da + d0 + 1] = p1; }
-}
-// index and n-step chain of sampled row b -> (index, terminal index); the chain's LAST end bit is left to the caller as (flag byte,
-// at-the-write-head) so that the load behind it need not have landed when the caller moves on (sac_sample_end_last)
-__device__ __forceinline__ void sac_sample_index(const SacSampleArgs& a, const SacBook* __restrict__ book, const int b,
-                                                 const uint32_t k0, const uint32_t k1, int& idx, int& term,
-                                                 unsigned char& f_last, bool& head_last) {
-    uint32_t c[4] = {(uint32_t)b, 0u, (uint32_t)a.counter, (uint32_t)(a.counter >> 32)};
-    philox4x32_10(c, k0, k1);
-    unsigned long long k = ((unsigned long long)c[0] * a.stored) >> 32;    // uniform over the stored rows
-    int e = 0;
-    while (e < a.env_num - 1 && k >= (unsigned long long)book[e].size) { k -= book[e].size; ++e; }
-    int cur = e * a.sub_size + (int)k;
-    a.idx[b] = cur;
-    idx = cur;
-    unsigned char f = a.flags[cur];
-    bool head = false;
-    for (int n = 0; n < a.n_step; ++n) {
-        const int env = cur / a.sub_size, local = cur - env * a.sub_size;
-        const SacBook bk = book[env];
-        if (n > 0) {                                   // indices[n] = buffer.next(indices[n-1])
-            const bool end = f != 0 || local == bk.last_index;
-            if (!end && bk.size > 0) { cur = env * a.sub_size + (local + 1) % bk.size; f = a.flags[cur]; }
-        }
-        const int loc2 = cur - env * a.sub_size;
-        a.chain[(size_t)n * a.B + b] = cur;
-        head = bk.size > 0 && loc2 == (bk.index - 1 + bk.size) % bk.size;
-        if (n + 1 < a.n_step) a.endbits[(size_t)n * a.B + b] = (f != 0 || head) ? 1 : 0;
-    }
-    term = cur;                                        // the chain's last element
-    f_last = f; head_last = head;
-}
-__device__ __forceinline__ void sac_sample_end_last(const SacSampleArgs& a, const int b, const unsigned char f_last, const bool head_last) {
-    a.endbits[(size_t)(a.n_step - 1) * a.B + b] = (f_last != 0 || head_last) ? 1 : 0;
-}
-// one sampled row: the uniform index, its n-step chain with the end flags, the two rsample noise rows.  -> (index, terminal index)
-__device__ __forceinline__ void sac_sample_row(const SacSampleArgs& a, const SacBook* __restrict__ book, const int b,
-                                               const uint32_t k0, const uint32_t k1, int* idx_out = nullptr, int* term_out = nullptr) {
-    int idx, term;
-    unsigned char f;
-    bool head;
-    sac_sample_index(a, book, b, k0, k1, idx, term, f, head);
-    sac_sample_end_last(a, b, f, head);
-    if (idx_out) *idx_out = idx;
-    if (term_out) *term_out = term;
-    for (int d0 = 0; d0 < a.Da; d0 += 2) sac_sample_noise(a, b, d0, k0, k1);
 }
 
 __global__ __launch_bounds__(256) void sac_sample_kernel(const SacSampleArgs a) {
@@ -152,37 +59,10 @@ __global__ __launch_bounds__(256) void sac_sample_kernel(const SacSampleArgs a) 
     sac_sample_row(a, book, b, k0, k1);
 }
 
-// ---- sample + gather in ONE launch (SAC / DDPG-Lag, library RNG): a workgroup draws SG_ROWS rows (one thread each: index,
-//      chain, noise -- the same Philox counters as sac_sample_kernel, so the same sample) and then gathers exactly those rows with
-//      all its threads.  Two dependent ~5-7 us launches at their floors become one.
-#define SG_ROWS 16
+// ---- sample + gather in ONE launch (SAC / DDPG-Lag, library RNG): sac_sample_gather_block (kernels_sample.hpp) per workgroup.
+//      Two dependent ~5-7 us launches at their floors become one.
 __global__ __launch_bounds__(256) void sac_sample_gather_kernel(const SacSampleArgs a, const SacGatherArgs g) {
-    constexpr int BOOK_LDS = 512;
-    __shared__ SacBook book_s[BOOK_LDS];
-    __shared__ int idx_s[SG_ROWS], term_s[SG_ROWS];
-    const bool in_lds = a.env_num <= BOOK_LDS;
-    if (in_lds) {
-        for (int e = threadIdx.x; e < a.env_num; e += blockDim.x) book_s[e] = a.book[e];
-        __syncthreads();
-    }
-    const SacBook* __restrict__ book = in_lds ? book_s : a.book;
-    const int b0 = blockIdx.x * SG_ROWS;
-    if (threadIdx.x < SG_ROWS && b0 + threadIdx.x < a.B)
-        sac_sample_row(a, book, b0 + threadIdx.x, (uint32_t)a.key, (uint32_t)(a.key >> 32), &idx_s[threadIdx.x], &term_s[threadIdx.x]);
-    __syncthreads();
-    const int Din = g.Do + g.Da, nrow = min(SG_ROWS, a.B - b0);
-    for (int e = threadIdx.x; e < nrow * Din; e += blockDim.x) {
-        const int rl = e / Din, f = e - rl * Din, r = b0 + rl;
-        const size_t s_ = (size_t)idx_s[rl], t_ = (size_t)term_s[rl];
-        const size_t o = (size_t)r * Din + f;
-        if (f < g.Do) {
-            const float ob = g.st.obs[s_ * g.Do + f], on = g.st.obs_next[t_ * g.Do + f];
-            g.XQ[o] = ob; g.XP[o] = ob; g.XN[o] = on;
-            g.OBS[(size_t)r * g.Do + f] = ob; g.OBSN[(size_t)r * g.Do + f] = on;
-        } else {
-            g.XQ[o] = g.st.act[s_ * g.Da + (f - g.Do)];
-        }
-    }
+    sac_sample_gather_block(a, g, blockIdx.x);
 }
 
 // ---- actor tile: a = tanh(mu + sigma*eps), log pi with the tanh correction; optional backward
@@ -214,6 +94,7 @@ struct SacActorArgs {
     int sg_on;
     SacSampleArgs sa;
     SacGatherArgs ga;
+    int probe;           // -DFSRL_PROBES builds: FWD launches return early -- 1 at entry, 2 behind the prologue, 3 behind the forward pass
 };
 
 template <int H, int R>
@@ -234,6 +115,9 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
     const int Do = md.Do, Da = md.Da;
     const int n_valid = max(0, min(R, a.B - row0));
     const float invB = 1.0f / (float)a.B;
+#ifdef FSRL_PROBES
+    if (a.probe == 1 && a.mode == SAC_A_FWD) return;
+#endif
 
     TileStage<H> stg;
     if (a.sg_on) {
@@ -299,7 +183,13 @@ __global__ __launch_bounds__(4 * H) void sac_actor_tile_kernel(const float* __re
     for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
     stg.commit(sm, no, Do, tid);
     __syncthreads();
-    tile_forward<H, R>(sm, Pn, no, Do, tid, wf);     // sm.out[i][0..Da) = mu, [Da..2Da) = raw log sigma
+#ifdef FSRL_PROBES
+    if (a.probe == 2 && a.mode == SAC_A_FWD) return;
+#endif
+    tile_forward<H, R, true>(sm, Pn, no, Do, tid, wf);     // sm.out[i][0..Da) = mu, [Da..2Da) = raw log sigma
+#ifdef FSRL_PROBES
+    if (a.probe == 3 && a.mode == SAC_A_FWD) return;
+#endif
 
     float wb[H / 16][4];
     if (a.mode == SAC_A_BWD) {

@@ -446,7 +446,7 @@ typedef struct fsrl_sac_config {
 #define FSRL_SAC_NSTATS 10  /* rescaling, lagrangian, actor_safety, alpha_loss, alpha_value, actor_rew,
                                actor_total (sac_lag.py:231-257) then q0, q1, q_total (:203-208) */
 int fsrl_sac_init(fsrl_ctx* ctx, const fsrl_sac_config* cfg);
-/* A/B and tests only; plan is a 5-bit mask, 0..31 (default 0):
+/* A/B and tests only; plan is a 6-bit mask, 0..63 (default 0):
  *   bit 0 (1): split-K weight gradients (fb_wgrad_kernel) at every batch size (default: batches of up to 512 rows use the
  *              PPO step's one-workgroup-per-tile kernel; same products, different summation order);
  *   bit 1 (2): the sampler and the row gather as two launches (default: one launch);
@@ -455,8 +455,14 @@ int fsrl_sac_init(fsrl_ctx* ctx, const fsrl_sac_config* cfg);
  *              stand-alone n-step launch, whatever the caller set;
  *   bit 3 (8): prefetch the next update's sample + gather on the side stream (double-buffered batch);
  *   bit 4 (16): sample + gather as ONE launch of their own (round 4: 10 launches per update).  Default (r5): the forward launch of
- *              both actors draws and gathers its own rows first (9 launches per update; fused two-layer networks only).
- * Bits 1 .. 4 keep the same Philox counters and the same float64 operations: bit-identical results. */
+ *              both actors draws and gathers its own rows first (9 launches per update; fused two-layer networks only);
+ *   bit 5 (32): no rider blocks.  Default (r6) where the actor's weight-gradient launch is fb_wgrad_kernel (batches above 512 rows):
+ *              that launch leaves 150 CUs idle, and extra blocks of it draw + gather the NEXT update's batch into a second set of
+ *              batch arrays, in stream order; the next update uses them if nothing that determines the sample changed (store
+ *              contents, batch size, key, update count) and draws its own otherwise.  The reference's trainer runs its updates
+ *              back to back between collects (offpolicy trainer: round(update_per_step * steps) calls of policy.update), so
+ *              every update but the first after a collect finds its rows in place.
+ * Bits 1 .. 5 keep the same Philox counters and the same float64 operations: bit-identical results. */
 int fsrl_sac_set_plan(fsrl_ctx* ctx, int32_t plan);
 int64_t fsrl_sac_param_count(const fsrl_ctx* ctx, int32_t which);    /* 0 actor, 1 critics         */
 int fsrl_sac_params_set(fsrl_ctx* ctx, const float* actor, int64_t na, const float* critics, int64_t nc,
