@@ -69,7 +69,7 @@ __global__ __launch_bounds__(4 * H) void cvpo_actor_tile_kernel(const float* __r
     for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
     stg.commit(sm, no, Do, tid);
     __syncthreads();
-    tile_forward<H, R>(sm, P, no, Do, tid, wf);     // sm.out[i][0..Da) = mean head, [Da..2Da) = raw log sigma
+    tile_forward<H, R, true>(sm, P, no, Do, tid, wf);     // sm.out[i][0..Da) = mean head, [Da..2Da) = raw log sigma
 
     float wb[H / 16][4];
     if (mode == CVPO_A_MBWD) {

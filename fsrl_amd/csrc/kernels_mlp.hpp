@@ -184,7 +184,7 @@ struct TileStage {
 // column quads), each q-class accumulates its quarter of K and the classes are added at the end.
 // R = 32: two 16-row MFMA passes per weight fragment (the fragment registers are the same; the per-element K order is
 // the 16-row tile's, so a row's result does not depend on the tile height).
-// WIDE_HEAD (the replay agents' actors: 2 * act_dim outputs, 16 at act_dim 8): the head Linear of a 16-row tile on MFMA, split-K
+// WIDE_HEAD (the replay agents' actors: 2 * act_dim outputs, 16 at act_dim 8): the head Linear of a tile of up to 16 rows on MFMA, split-K
 // over the waves, partial 16 x 16 tiles through sm.d2 (free until the backward pass) -- the wave-per-(row, output) loop below takes
 // R * out / WAVES dependent LDS -> FMA -> wave_sum trips (16 at out = 16: 5 us of the actors' forward launch, phase probes r6).
 template <int H, int R = 16, bool WIDE_HEAD = false>
@@ -322,7 +322,7 @@ __device__ __forceinline__ void tile_forward(TileSmem<H, tile_rows(R)>& sm, cons
     __syncthreads();
     FSRL_TS(ts, 5);
 
-    if constexpr (WIDE_HEAD && R == 16) {
+    if constexpr (WIDE_HEAD && R <= 16) {        // a 4- or 8-row tile runs the same 16-row MFMAs: the rows beyond R are never read back
         if (no.out > 4) {
             // wave w: k in [16 w, 16 w + 16), lane (li, q) holds h2[li][16 w + 4 q + s] and W3[li][16 w + 4 q + s], s = 0 .. 3
             const f32x4 av = *reinterpret_cast<const f32x4*>(&sm.h2[li * LD + 16 * wave + 4 * q]);
@@ -335,7 +335,7 @@ __device__ __forceinline__ void tile_forward(TileSmem<H, tile_rows(R)>& sm, cons
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[(wave * 16 + 4 * q + r) * 16 + li] = acc[r];
             __syncthreads();
-            if (tid < 256) {
+            if (tid < 16 * R) {
                 const int i = tid >> 4, o = tid & 15;
                 float t = 0.0f;
 #pragma unroll
