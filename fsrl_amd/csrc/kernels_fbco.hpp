@@ -200,23 +200,32 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
     }
     __syncthreads();
     // ---- head pre-activations: out = W3 h2 + b3 ; R{out} = W3 R{h2} + V3 h2 + vb3
-    for (int i = wave; i < R; i += WAVES) {
-        for (int o = 0; o < Da; ++o) {
-            const float* __restrict__ w3 = P + no.W3 + (size_t)o * H;
-            const float* __restrict__ v3 = V + no.W3 + (size_t)o * H;
+    // r6: output-major -- the head rows of W3 / V3 are fetched ONCE per output (they sat inside the row loop: R / WAVES x Da dependent L2
+    // round trips per tile) and the wave's R / WAVES rows unroll into independent LDS -> FMA -> wave_sum chains.  Every (row, output)
+    // sees the same lanes and the same order of operations: bit-identical.
+    for (int o = 0; o < Da; ++o) {
+        float w3r[H / 64], v3r[H / 64];
+#pragma unroll
+        for (int t = 0; t < H / 64; ++t) {
+            w3r[t] = P[no.W3 + (size_t)o * H + lane + 64 * t];
+            v3r[t] = V[no.W3 + (size_t)o * H + lane + 64 * t];
+        }
+        const float b3o = P[no.b3 + o], vb3o = V[no.b3 + o];
+#pragma unroll
+        for (int i = wave; i < R; i += WAVES) {
             float s = 0.0f, rs = 0.0f;
 #pragma unroll
-            for (int k = lane; k < H; k += 64) {
-                const float h = h2[i * LD + k];
-                s = fmaf(h, w3[k], s);
-                rs = fmaf(rh2[i * LD + k], w3[k], rs);
-                rs = fmaf(h, v3[k], rs);
+            for (int t = 0; t < H / 64; ++t) {
+                const float h = h2[i * LD + lane + 64 * t];
+                s = fmaf(h, w3r[t], s);
+                rs = fmaf(rh2[i * LD + lane + 64 * t], w3r[t], rs);
+                rs = fmaf(h, v3r[t], rs);
             }
             s = wave_sum(s);
             rs = wave_sum(rs);
             if (lane == 0) {
-                sm.out[i * FSRL_MAX_ACT + o] = s + P[no.b3 + o];
-                sm.rout[i * FSRL_MAX_ACT + o] = rs + V[no.b3 + o];
+                sm.out[i * FSRL_MAX_ACT + o] = s + b3o;
+                sm.rout[i * FSRL_MAX_ACT + o] = rs + vb3o;
             }
         }
     }
@@ -489,14 +498,20 @@ __device__ __forceinline__ void tile_co_body(TileCoSmem<H>& sm, const float* __r
     if (TC_PROBE(a, 3)) return;
 
     // ---- head pre-activations: one wave per (row, output)
-    for (int idx = wave; idx < R * no.out; idx += WAVES) {
-        const int i = idx / no.out, o = idx - i * no.out;
-        const float* __restrict__ w3 = P + no.W3 + (size_t)o * H;
-        float s = 0.0f;
+    // r6: output-major, the head row of W3 fetched once per output, the wave's R / WAVES rows as independent chains (see fb_hvp_co_kernel)
+    for (int o = 0; o < no.out; ++o) {
+        float w3r[H / 64];
 #pragma unroll
-        for (int k = lane; k < H; k += 64) s = fmaf(h2[i * LD + k], w3[k], s);
-        s = wave_sum(s);
-        if (lane == 0) sm.out[i * FSRL_MAX_ACT + o] = s + P[no.b3 + o];
+        for (int t = 0; t < H / 64; ++t) w3r[t] = P[no.W3 + (size_t)o * H + lane + 64 * t];
+        const float b3o = P[no.b3 + o];
+#pragma unroll
+        for (int i = wave; i < R; i += WAVES) {
+            float s = 0.0f;
+#pragma unroll
+            for (int t = 0; t < H / 64; ++t) s = fmaf(h2[i * LD + lane + 64 * t], w3r[t], s);
+            s = wave_sum(s);
+            if (lane == 0) sm.out[i * FSRL_MAX_ACT + o] = s + b3o;
+        }
     }
     __syncthreads();
 

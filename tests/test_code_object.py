@@ -16,10 +16,10 @@ LIB = os.path.join(ROOT, "fsrl_amd", "libfsrl_hip.so")
 
 # kernels that are allowed to spill vector registers, with the reason (mangled-name prefix -> max spilled VGPRs)
 KNOWN = {
-    # the cached Hessian-vector product's co-resident kernel at the 128-VGPR cap of two workgroups per CU: 9-11 registers spilled and
+    # the cached Hessian-vector product's co-resident kernel at the 128-VGPR cap of two workgroups per CU: 10-13 registers spilled and
     # reloaded ONCE per tile, outside every loop (r6: its weight bursts became buffer loads, four descriptors live: 138.9 -> 128.5 us
     # per launch with the spills in)
-    "_Z16fb_hvp_co_kernelILi256ELb0E": 12,
+    "_Z16fb_hvp_co_kernelILi256ELb0E": 14,
     # A/B-only plans (fsrl_tr_set_tile_split(-2, -2): persistent workgroups drawing tiles from a device counter; measured, rejected)
     "_Z16fb_hvp_co_kernelILi256ELb1E": 64,
     "_Z17fb_tile_co_kernelILi256ELb1E": 40,
