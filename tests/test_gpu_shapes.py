@@ -373,6 +373,9 @@ def test_tile_job_weight_gradients_shape_sweep_vs_autograd(Do, Da, rows):
     for plan in (4, 6, 2, 0):
         eng.tr_set_plan(0, 0, plan)
         got[plan] = (eng.tr_grad(0), eng.tr_grad(2), eng.tr_hvp(v))
+        # the cached-activation product (co-resident kernel at 256 wide: its dz2 phase holds four action dimensions' columns of W3 / V3 in
+        # registers and fetches the rest inside the loop -- act_dim 5 .. 16 here)
+        close(eng.tr_hvp_cached(v), hv, 5e-5, (plan, "hvp cached"))
         # the surrogate gradient is a sum over mean-zero normalised advantages: it cancels to ~1e-2 of its terms, and the fp32
         # advantage pipelines of the two sides (oracle: numpy, HIP: scan kernels) differ at 1e-7 -- 1e-4 of the result, the
         # same under every plan; the plans among themselves agree to 2e-5 (below)
