@@ -242,19 +242,20 @@ def test_update_is_deterministic_and_idempotent_setup():
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("hid,env_num", [(256, 20), (128, 4)])      # configs[1] | configs[0]: 128x128, 4 envs (the reference's CPU case)
 @pytest.mark.parametrize("repeat", [1, 4])
-def test_full_size_update_vs_oracle(repeat):
-    """BASELINE configs[1] shape (obs 8, act 2, 256x256, 20 100 rows = 67 episodes x 300, B 256): stats and parameters vs the
-    oracle.  repeat 1: one pass (78 steps), tight early + envelope.  repeat 4: the headline workload's 312 dependent steps,
+def test_full_size_update_vs_oracle(repeat, hid, env_num):
+    """BASELINE configs[1] shape (obs 8, act 2, 256x256, 20 100 rows = 67 episodes x 300, B 256) and configs[0]'s (128x128, the
+    same rows from 4 envs): stats and parameters vs the oracle.  repeat 1: one pass (78 steps), tight early + envelope.  repeat 4: the headline workload's 312 dependent steps,
     judged against the float64 run of the same algorithm -- the device must stay as close to it as the reference-equivalent
     fp32 oracle does (both are fp32 trajectories of a chaotic map; neither can track the other step by step that long)."""
     from oracle.ppo_lag import OnPolicyData, PPOLagConfig, PPOLagOracle
     from fsrl_amd.engine import Engine, EngineConfig
     rng = np.random.default_rng(11)
-    env_num, ep, n_ep = 20, 300, 67
-    eng = Engine(EngineConfig(obs_dim=8, act_dim=2, hidden=256, env_num=env_num, max_grad_norm=0.5,
+    ep, n_ep = 300, 67
+    eng = Engine(EngineConfig(obs_dim=8, act_dim=2, hidden=hid, env_num=env_num, max_grad_norm=0.5,
                               target_kl=None))
-    ocfg = PPOLagConfig(obs_dim=8, act_dim=2, hidden=(256, 256), max_grad_norm=0.5, target_kl=1e9)
+    ocfg = PPOLagConfig(obs_dim=8, act_dim=2, hidden=(hid, hid), max_grad_norm=0.5, target_kl=1e9)
     o = PPOLagOracle(ocfg)
     torch.manual_seed(5)
     theta = (0.1 * torch.randn(o.n_params)).numpy()
