@@ -74,7 +74,11 @@ static_assert(sizeof(HvpCoSmem<256>) <= 80 * 1024, "two workgroups per CU");
 // the other, keeping 2-4 fragment sets alive through scratch (400-1000 spilled dwords per lane, measured); as runtime loops the
 // kernel needs 116 VGPRs and no scratch, and the fragment loads travel a chunk or two ahead of the MFMAs that consume them.
 // One tile of 16 NH rows starting at row0 of the CACHED product (h1 / h2 / dout / dz2 of this theta are in A1 / A2 / DO / D2).
-template <int H, int NH, bool GN>
+// FIRST (r6): the first product of a solve -- nothing is cached yet: z1 rides the layer-1 tangent's MFMA pass (the W1 burst beside the
+// V1 burst), z2 = W2 h1 the layer-2 pass (same fragments, one more accumulator set), and h1 / h2 / dout / dz2 leave for A1 / A2 /
+// DO / D2 on the way.  fb_hvp_mixed_kernel<.., false>'s arithmetic, element by element (bit-identical plans); it took 262-357 us per
+// launch alone on its CU, four times per update.
+template <int H, int NH, bool GN, bool FIRST = false>
 __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __restrict__ P, const ModelDesc& md,
                                             const HvpArgs& a, const int row0) {
     constexpr int LD = HvpCoSmem<H>::LD;
@@ -97,10 +101,11 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
     float* dout = sm.xd; float* rdout = sm.xd + 32 * FSRL_DOW;
 
     // ---- h1 of this theta -> slot 0 ; observations (transposed) ; the head threads' mean_old / std_old (registers)
-    for (int e = tid; e < R * H4; e += NT) {
-        const int i = e / H4, c4 = e - i * H4;
-        *reinterpret_cast<f32x4*>(&h1[i * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(a.A1 + base + (size_t)i * H + 4 * c4);
-    }
+    if constexpr (!FIRST)
+        for (int e = tid; e < R * H4; e += NT) {
+            const int i = e / H4, c4 = e - i * H4;
+            *reinterpret_cast<f32x4*>(&h1[i * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(a.A1 + base + (size_t)i * H + 4 * c4);
+        }
     for (int e = tid; e < R * Do; e += NT) {
         const int i = e / Do, k = e - i * Do;
         sm.xd[k * 32 + i] = (i < n_valid) ? a.obs[(size_t)row0 * Do + e] : 0.0f;
@@ -119,15 +124,17 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
 #pragma unroll 1
     for (int g = 0; g < 2; ++g) {
         const int cg = wave + g * WAVES;
-        f32x4 racc[NH];
+        f32x4 racc[NH], zacc[NH];
 #pragma unroll
-        for (int hf = 0; hf < NH; ++hf) racc[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int hf = 0; hf < NH; ++hf) racc[hf] = zacc[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* __restrict__ vrow = V + no.W1 + (size_t)(cg * 16 + li) * Do;
+        const float* __restrict__ wrow = P + no.W1 + (size_t)(cg * 16 + li) * Do;
         for (int k0 = 0; k0 < Do; k0 += 64) {
-            float vb_[16];
+            float vb_[16], wb_[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int k = k0 + 4 * s + q;
+                if constexpr (FIRST) wb_[s] = (k < Do) ? wrow[k] : 0.0f;
                 vb_[s] = (k < Do) ? vrow[k] : 0.0f;
             }
 #pragma unroll
@@ -137,6 +144,7 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
 #pragma unroll
                     for (int hf = 0; hf < NH; ++hf) {
                         const float a_ = (k < Do) ? sm.xd[k * 32 + 16 * hf + li] : 0.0f;
+                        if constexpr (FIRST) zacc[hf] = mfma_16x16x4(a_, wb_[s], zacc[hf]);
                         racc[hf] = mfma_16x16x4(a_, vb_[s], racc[hf]);
                     }
                 }
@@ -144,12 +152,19 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
         }
         const int j = cg * 16 + li;
         const float vb1 = V[no.b1 + j];
+        const float b1 = FIRST ? P[no.b1 + j] : 0.0f;
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int l = (16 * hf + 4 * q + r) * LD + j;
-                rh1[l] = (h1[l] > 0.0f) ? racc[hf][r] + vb1 : 0.0f;
+                bool on;
+                if constexpr (FIRST) {
+                    const float z = zacc[hf][r] + b1;
+                    on = z > 0.0f;
+                    h1[l] = on ? z : 0.0f;
+                } else on = h1[l] > 0.0f;
+                rh1[l] = on ? racc[hf][r] + vb1 : 0.0f;
             }
         }
     }
@@ -161,8 +176,13 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
             const int i = e / H4, c4 = e - i * H4;
             store4_fb(a.RA1 + base + (size_t)i * H + 4 * c4, *reinterpret_cast<const f32x4*>(&rh1[i * LD + 4 * c4]));
         }
+    if constexpr (FIRST)                               // h1 into the cache (later products load it; the relu'(z1) mask below reads it back)
+        for (int e = tid; e < R * H4; e += NT) {
+            const int i = e / H4, c4 = e - i * H4;
+            store4_fb(a.A1 + base + (size_t)i * H + 4 * c4, *reinterpret_cast<const f32x4*>(&h1[i * LD + 4 * c4]));
+        }
     // ---- layer 2 tangent:  R{z2} = W2 R{h1} + V2 h1   (per column group: W2 fragments, then V2 fragments, same registers)
-    f32x4 rz[2][NH];
+    f32x4 rz[2][NH], z2[2][FIRST ? NH : 1];
     CO_PRIO(2);
 #pragma unroll 1
     for (int g = 0; g < 2; ++g) {
@@ -171,6 +191,11 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
         for (int hf = 0; hf < NH; ++hf) rz[g][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
         FwdW2Frag<H> wf;
         wf.load_buf(P + no.W2f, cg, lane);
+        if constexpr (FIRST) {
+#pragma unroll
+            for (int hf = 0; hf < NH; ++hf) z2[g][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma_rows_n<H, NH>(h1, wf, li, q, z2[g]);
+        }
         mma_rows_n<H, NH>(rh1, wf, li, q, rz[g]);
         __builtin_amdgcn_sched_barrier(0);            // one fragment set (64 VGPRs) in flight at a time: the partner workgroup fills the gap
         wf.load_buf(V + no.W2f, cg, lane);
@@ -180,21 +205,30 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
     CO_PRIO(0);
     __syncthreads();                                  // both slots have been read by every wave; the R{h1} spill is out
     // ---- h2 of this theta -> slot 0
-    for (int e = tid; e < R * H4; e += NT) {
-        const int i = e / H4, c4 = e - i * H4;
-        *reinterpret_cast<f32x4*>(&h2[i * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(a.A2 + base + (size_t)i * H + 4 * c4);
+    if constexpr (!FIRST) {
+        for (int e = tid; e < R * H4; e += NT) {
+            const int i = e / H4, c4 = e - i * H4;
+            *reinterpret_cast<f32x4*>(&h2[i * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(a.A2 + base + (size_t)i * H + 4 * c4);
+        }
+        __syncthreads();
     }
-    __syncthreads();
 #pragma unroll 1
     for (int g = 0; g < 2; ++g) {
         const int j = (wave + g * WAVES) * 16 + li;
         const float vbias = V[no.b2 + j];
+        const float bias = FIRST ? P[no.b2 + j] : 0.0f;
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int l = (16 * hf + 4 * q + r) * LD + j;
-                rh2[l] = (h2[l] > 0.0f) ? rz[g][hf][r] + vbias : 0.0f;
+                bool on;
+                if constexpr (FIRST) {
+                    const float zz = z2[g][hf][r] + bias;
+                    on = zz > 0.0f;
+                    h2[l] = on ? zz : 0.0f;
+                } else on = h2[l] > 0.0f;
+                rh2[l] = on ? rz[g][hf][r] + vbias : 0.0f;
             }
         }
     }
@@ -234,6 +268,11 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
         for (int e = tid; e < R * H4; e += NT) {
             const int i = e / H4, c4 = e - i * H4;
             store4_fb(a.RA2 + base + (size_t)i * H + 4 * c4, *reinterpret_cast<const f32x4*>(&rh2[i * LD + 4 * c4]));
+        }
+    if constexpr (FIRST)                               // h2 into the cache
+        for (int e = tid; e < R * H4; e += NT) {
+            const int i = e / H4, c4 = e - i * H4;
+            store4_fb(a.A2 + base + (size_t)i * H + 4 * c4, *reinterpret_cast<const f32x4*>(&h2[i * LD + 4 * c4]));
         }
     __syncthreads();
     // ---- KL head (per row, per action dim): dout, R{dout}, and the sigma_param rows   (hvp_tile_body's arithmetic)
@@ -286,6 +325,13 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
         }
     }
     __syncthreads();
+    if constexpr (FIRST && !GN) {                      // dz2 / dout of the KL head into the cache (exact zeros, unread, in the Gauss-Newton form)
+        for (int e = tid; e < R * H4; e += NT) {
+            const int i = e / H4, c4 = e - i * H4;
+            store4_fb(a.D2 + base + (size_t)i * H + 4 * c4, *reinterpret_cast<const f32x4*>(&d2[i * LD + 4 * c4]));
+        }
+        for (int e = tid; e < R * FSRL_DOW; e += NT) a.DO[(size_t)row0 * FSRL_DOW + e] = dout[e];
+    }
     // ---- R{dz1} = relu'(z1) (R{dz2} W2 + dz2 V2), the wave's two column groups; relu'(z1) off the cached h1 (the lane's own elements)
     CO_PRIO(2);
 #pragma unroll 1
@@ -327,15 +373,16 @@ __device__ __forceinline__ void hvp_co_body(HvpCoSmem<H>& sm, const float* __res
 // Mixed-height grid like fb_hvp_mixed_kernel: blocks [0, n32) take 32-row tiles, the rest 16-row tiles behind them.
 // 2 H threads, <= 128 VGPRs (4 waves per SIMD) and 78.8 KB of LDS: two workgroups per CU.
 // PERSIST = false: one workgroup per tile (straight-line: 116 VGPRs, no scratch); true: persistent workgroups (A/B)
-template <int H, bool PERSIST, bool GN>
+template <int H, bool PERSIST, bool GN, bool FIRST = false>
 __global__ __launch_bounds__(2 * H, 4) void fb_hvp_co_kernel(const float* __restrict__ P, const ModelDesc md, const HvpArgs a,
                                                             const int n32, const CoSched cs) {
     __shared__ HvpCoSmem<H> sm;
     co_desync(cs);
+    static_assert(!(PERSIST && FIRST), "the first product has no persistent form");
     if constexpr (!PERSIST) {
         const int b = blockIdx.x;
-        if (b < n32) hvp_co_body<H, 2, GN>(sm, P, md, a, 32 * b);
-        else hvp_co_body<H, 1, GN>(sm, P, md, a, 32 * n32 + 16 * (b - n32));
+        if (b < n32) hvp_co_body<H, 2, GN, FIRST>(sm, P, md, a, 32 * b);
+        else hvp_co_body<H, 1, GN, FIRST>(sm, P, md, a, 32 * n32 + 16 * (b - n32));
     } else {
         __shared__ int s_next;
         int b = co_first_tile(cs, &s_next);
