@@ -281,7 +281,14 @@ __device__ __forceinline__ void fb_tile_body(TileSmem<H, tile_rows(R)>& sm, cons
     for (int e = tid; e < ROWS * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
     stg.commit(sm, no, Do, tid);
     __syncthreads();
+#ifdef FSRL_PROBES
+#define FBT_PROBE(k) (a.mode >= FB_MODE_Q_TRAIN && a.eta == (float)(k))      /* Q launches of the replay agents: FbArgs::eta is free there */
+#else
+#define FBT_PROBE(k) false
+#endif
+    if (FBT_PROBE(1)) return;                                        // behind the prologue
     tile_forward<H, R>(sm, P, no, Do, tid, wf);
+    if (FBT_PROBE(2)) return;                                        // behind the forward pass
     const bool backward = (a.mode != FB_MODE_EVAL && a.mode != FB_MODE_Q_FWD);
     const bool qmode = a.mode >= FB_MODE_Q_TRAIN && a.mode <= FB_MODE_Q_DIN;
 
@@ -423,6 +430,7 @@ __device__ __forceinline__ void fb_tile_body(TileSmem<H, tile_rows(R)>& sm, cons
         }
     }
     if (!backward) return;
+    if (FBT_PROBE(3)) return;                                        // behind the loss head and the statistics
 
     const size_t nb = (size_t)y * a.rows_pad;
     const bool din = a.mode == FB_MODE_Q_DIN;
@@ -443,6 +451,7 @@ __device__ __forceinline__ void fb_tile_body(TileSmem<H, tile_rows(R)>& sm, cons
     }
     tile_backward<H, R>(sm, no, wb, a.A1 + (nb + row0) * H, a.A2 + (nb + row0) * H, a.D1 + (nb + row0) * H,
                      a.D2 + (nb + row0) * H, a.DO + (nb + row0) * FSRL_DOW, tid, din);
+    if (FBT_PROBE(4)) return;                                        // behind the activation backward
     if (din) {
         // input gradient w.r.t. the action columns of x = concat(obs, act):
         //   da[i][k] = sum_j dz1[i][j] * W1[j][Do_obs + k]       (dz1 left in sm.d2 by tile_backward)
