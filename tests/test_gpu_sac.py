@@ -153,3 +153,38 @@ def test_device_sampling_replays_through_caller_rng_and_is_well_distributed():
     assert np.array_equal(i2, first[0]) and np.array_equal(e2, first[1])
     for e in (dev, twin, again):
         e.close()
+
+
+def test_more_sub_buffers_than_the_samplers_lds_table_holds():
+    """600 envs (the samplers keep up to 512 sub-buffers' bookkeeping in LDS and read it from global memory beyond): the launch plans must
+    still agree bit for bit at batch 1024 -- rider blocks + folded sample (default) | no riders | sample + gather as one launch of their
+    own | sampler and gather as two launches -- and every sampled row must be a stored one.  n_step 3 walks the chains across the
+    sub-buffers' write heads (ragged fill: 1 .. 40 rows per env)."""
+    from fsrl_amd import _lib
+    from fsrl_amd.engine import Engine, EngineConfig
+    E, sub, Do, Da, B = 600, 64, 11, 3, 1024
+    rng = np.random.default_rng(3)
+    rows = rng.integers(1, 41, E)
+    outs = []
+    for plan in (0, 32, 48, 2):
+        eng = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=Do, act_dim=Da, hidden_sizes=(64, 64), n_critics=2, env_num=E,
+                                  buffer_size=E * sub, gamma=0.99, target_kl=None))
+        eng.sac_init(n_step=3)
+        r2 = np.random.default_rng(4)
+        for t in range(int(rows.max())):
+            ids = np.flatnonzero(rows > t)
+            k = ids.size
+            eng.push(ids, r2.standard_normal((k, Do)).astype(np.float32), np.tanh(r2.standard_normal((k, Da))).astype(np.float32),
+                     r2.standard_normal(k), (r2.random(k) < 0.2).astype(np.float64), r2.random(k) < 0.05, r2.random(k) < 0.05,
+                     r2.standard_normal((k, Do)).astype(np.float32))
+        eng.sac_set_plan(plan)
+        st = [eng.sac_update(B, [0.3], 1 / 1.3, seed=5 if u == 0 else 0).copy() for u in range(6)]
+        idx = eng.sac_last_sample(B)[0].copy()
+        valid = np.concatenate([e * sub + np.arange(rows[e]) for e in range(E)])
+        assert np.isin(idx, valid).all()
+        outs.append((np.stack(st), idx, eng.sac_get_params(0)[0], eng.sac_get_params(1)[0]))
+        eng.close()
+    assert np.isfinite(outs[0][0]).all()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
