@@ -275,7 +275,7 @@ static int ensure_parts(fsrl_ctx* c, int stride, int nsplit) {
 // *rider_done tells the caller whether this launch carried them (only the 3-D grid of round 5's split-K kernel does)
 template <bool PAIR2>
 static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int ny, int stride, int* nsplit,
-                        SgRider* rider = nullptr, bool* rider_done = nullptr) {
+                        SgRider* rider = nullptr, bool* rider_done = nullptr, int xcd_order = -1) {
     if (rider_done) *rider_done = false;
     const int H_ = c->cfg.hidden;
     // r6 default at 256 wide over a few thousand rows or more, for the callers that hand over the re-laid observations: every
@@ -341,7 +341,7 @@ static int wgrad_launch(fsrl_ctx* c, const ModelDesc& md, FbWgradArgs& wa, int n
     *nsplit = pl.nsplit;
     return dispatch_H(c->cfg.hidden, [&](auto hc) {
         constexpr int HH = decltype(hc)::value;
-        if (c->wgrad_xcd) {
+        if (xcd_order < 0 ? c->wgrad_xcd : xcd_order != 0) {      // xcd_order: a caller's own choice (the replay agents' critics)
             wa.remap_total = NB * ny * pl.nsplit; wa.remap_ny = ny;
             hipLaunchKernelGGL((fb_wgrad_kernel<HH, PAIR2>), dim3(round_up(wa.remap_total, 8)), dim3(1024), 0, c->compute, md, wa, NoRider{});
         } else if (rider && !PAIR2) {

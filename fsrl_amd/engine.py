@@ -539,7 +539,8 @@ class Engine:
         512 rows); bit 1 = sample and gather as two launches, bit 2 = the n-step targets as a launch of their own (default: 10
         launches per update, not 12), bit 3 = prefetch the next update's sample on the side stream (measured slower: off by default),
         bit 4 = sample + gather as a launch of their own (round 4: 10 launches; r5 default: inside the actors' forward launch, 9),
-        bit 5 = no rider blocks (r6 default above 512 rows: the actor's weight-gradient launch also draws the NEXT update's batch)"""
+        bit 5 = no rider blocks (r6 default above 512 rows: the actor's weight-gradient launch also draws the NEXT update's batch),
+        bit 6 = the critics' split-K weight-gradient launch in plain block order (r6 default: XCD-aware, 2.3x less memory-side traffic)"""
         _lib.check(self.lib.fsrl_sac_set_plan(self._ctx, int(plan)))
 
     def sac_set_params(self, actor_flat, critics_flat, log_alpha=0.0):

@@ -446,7 +446,7 @@ typedef struct fsrl_sac_config {
 #define FSRL_SAC_NSTATS 10  /* rescaling, lagrangian, actor_safety, alpha_loss, alpha_value, actor_rew,
                                actor_total (sac_lag.py:231-257) then q0, q1, q_total (:203-208) */
 int fsrl_sac_init(fsrl_ctx* ctx, const fsrl_sac_config* cfg);
-/* A/B and tests only; plan is a 6-bit mask, 0..63 (default 0):
+/* A/B and tests only; plan is a 7-bit mask, 0..127 (default 0):
  *   bit 0 (1): split-K weight gradients (fb_wgrad_kernel) at every batch size (default: batches of up to 512 rows use the
  *              PPO step's one-workgroup-per-tile kernel; same products, different summation order);
  *   bit 1 (2): the sampler and the row gather as two launches (default: one launch);
@@ -462,7 +462,9 @@ int fsrl_sac_init(fsrl_ctx* ctx, const fsrl_sac_config* cfg);
  *              contents, batch size, key, update count) and draws its own otherwise.  The reference's trainer runs its updates
  *              back to back between collects (offpolicy trainer: round(update_per_step * steps) calls of policy.update), so
  *              every update but the first after a collect finds its rows in place.
- * Bits 1 .. 5 keep the same Philox counters and the same float64 operations: bit-identical results. */
+ *   bit 6 (64): the critics' split-K weight-gradient launch in plain block order.  Default (r6): XCD-aware order -- the blocks of one
+ *              (network, split), which stream the same rows, behind one L2: 46 -> 20 MB of memory-side traffic per launch, same time.
+ * Bits 1 .. 6 keep the same Philox counters, the same float64 operations and the same sums: bit-identical results. */
 int fsrl_sac_set_plan(fsrl_ctx* ctx, int32_t plan);
 int64_t fsrl_sac_param_count(const fsrl_ctx* ctx, int32_t which);    /* 0 actor, 1 critics         */
 int fsrl_sac_params_set(fsrl_ctx* ctx, const float* actor, int64_t na, const float* critics, int64_t nc,

@@ -71,12 +71,13 @@ def test_fused_launch_plan_is_bit_identical_to_the_separate_launches(batch):
     launches per update) against the default (sample + gather in one launch, the critics' tile launch computing its targets itself: 10);
     bit 3: the next update's sample drawn on the side stream while this update runs (rows pushed in between invalidate it);
     bit 4 (r5): sample + gather as ONE launch of their own instead of inside the forward launch of both actors (the default: 9);
-    bit 5 (r6): no rider blocks -- by default, at batch 1024, the actor's weight-gradient launch also draws the NEXT update's batch.
+    bit 5 (r6): no rider blocks -- by default, at batch 1024, the actor's weight-gradient launch also draws the NEXT update's batch;
+    bit 6 (r6): the critics' split-K weight-gradient launch in plain instead of XCD-aware block order.
     The same Philox counters, the same rows, the same float64 operations: statistics and parameters must agree BIT FOR BIT over
     a run of library-RNG updates; with the caller's indices (parity mode) only the n-step fold differs, also bit for bit."""
     g, cfg, ocfg, store, index = sac_setup("c4")
     outs = []
-    for plan in (0, 32, 16, 6, 2, 8, 40, 14, 22):        # 0 (r5 default): sample + gather inside the actors' forward launch (9 launches); 16: round 4's 10
+    for plan in (0, 32, 64, 16, 6, 2, 8, 40, 14, 22):        # 0 (r5 default): sample + gather inside the actors' forward launch (9 launches); 16: round 4's 10
         eng = _engine(cfg, g)
         eng.sac_set_plan(plan)
         rows = [eng.sac_update(batch, [0.5], 1 / 1.5, seed=7 if u == 0 else 0).copy() for u in range(12)]
