@@ -274,8 +274,12 @@ __device__ __forceinline__ void fb_tile_body(TileSmem<H, tile_rows(R)>& sm, cons
 
     TileStage<H, ROWS> stg;
     stg.issue(P, no, Do, Da, a.obs + (size_t)row0 * Do, a.rd ? a.rd + (size_t)row0 * FSRL_RD : nullptr, n_valid, tid);
-    if (a.mode == FB_MODE_Q_TRAIN && a.ns_on && tid < n_valid)       // its loads travel underneath the forward pass; read by the head
-        sm.st[tid] = sac_nstep_target(a.ns, row0 + tid, net >> a.pair_shift);
+    if (a.mode == FB_MODE_Q_TRAIN && a.ns_on && tid < n_valid) {     // its loads travel underneath the forward pass; read by the head
+        const float yv = sac_nstep_target(a.ns, row0 + tid, net >> a.pair_shift);
+        sm.st[tid] = yv;
+        // the first network of every target group also leaves the target where the stand-alone launch would (CVPO logs its mean)
+        if ((net & ((1 << a.pair_shift) - 1)) == 0) a.ns.Y[(size_t)(net >> a.pair_shift) * a.N + row0 + tid] = yv;
+    }
     FwdW2Frag<H> wf;
     wf.load(P + no.W2f, wave, lane);
     for (int e = tid; e < ROWS * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;

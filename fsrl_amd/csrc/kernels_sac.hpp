@@ -59,6 +59,27 @@ __global__ __launch_bounds__(256) void sac_sample_kernel(const SacSampleArgs a) 
     sac_sample_row(a, book, b, k0, k1);
 }
 
+// ---- CVPO, library RNG: sample + gather + the K particles' noise in ONE launch (r6; sac_sample_kernel + sac_gather_kernel before).
+//      Blocks [0, ceil(B / SG_ROWS)): sac_sample_gather_block; the blocks behind them: thread (b, kp) draws particle kp's noise for
+//      row b -- the Philox counters of sac_sample_kernel's CVPO branch, so the same values.
+__global__ __launch_bounds__(256) void cvpo_sample_gather_kernel(const SacSampleArgs a, const SacGatherArgs g) {
+    const int nb = (a.B + SG_ROWS - 1) / SG_ROWS;
+    if ((int)blockIdx.x < nb) { sac_sample_gather_block(a, g, blockIdx.x); return; }
+    const int t = ((int)blockIdx.x - nb) * 256 + threadIdx.x;
+    const int b = t % a.B, kp = t / a.B;
+    if (kp >= a.K) return;
+    const uint32_t k0 = (uint32_t)a.key, k1 = (uint32_t)(a.key >> 32);
+    for (int d0 = 0; d0 < a.Da; d0 += 4) {             // draws 0x100.. : four normals per Philox block
+        uint32_t r[4] = {(uint32_t)b, 0x100u + (uint32_t)(kp * 4 + (d0 >> 2)), (uint32_t)a.counter, (uint32_t)(a.counter >> 32)};
+        philox4x32_10(r, k0, k1);
+        float v[4];
+        box_muller(r[0], r[1], v[0], v[1]);
+        box_muller(r[2], r[3], v[2], v[3]);
+        float* o = a.eps_k + ((size_t)kp * a.B + b) * a.Da + d0;
+        for (int j = 0; j < 4 && d0 + j < a.Da; ++j) o[j] = v[j];
+    }
+}
+
 // ---- sample + gather in ONE launch (SAC / DDPG-Lag, library RNG): sac_sample_gather_block (kernels_sample.hpp) per workgroup.
 //      Two dependent ~5-7 us launches at their floors become one.
 __global__ __launch_bounds__(256) void sac_sample_gather_kernel(const SacSampleArgs a, const SacGatherArgs g) {

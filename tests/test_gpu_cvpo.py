@@ -315,3 +315,27 @@ def test_cvpo_cost_limit_update_and_call_order_errors():
     sizes = sac.store_sizes()
     assert sizes.tolist() == [0]
     sac.close()
+
+
+@pytest.mark.parametrize("name", ["default", "double"])
+def test_cvpo_launch_plans_are_bit_identical(name):
+    """r6: sample + gather + the K particles' noise in one launch and the float64 n-step targets inside the critics' tile launch (13
+    launches per update) against the stand-alone launches (fsrl_sac_set_plan bits 1 and 2: sampler, gather and n-step kernel on their
+    own, 15 launches): same Philox counters, same float64 operations -- statistics, parameters, duals and the drawn sample must agree
+    bit for bit over a run of library-RNG updates."""
+    g, cfg, ocfg, store, index = cvpo_setup(name)
+    B = cfg["batch_size"]
+    outs = []
+    for plan in (0, 2, 4, 6):
+        eng = _engine(cfg, g, ocfg)
+        eng.sac_set_plan(plan)
+        eng.cvpo_pre_update()
+        rows = [eng.cvpo_update(B, seed=9 if u == 0 else 0).copy() for u in range(5)]
+        idx, et, _ = eng.sac_last_sample(B)
+        outs.append((np.stack(rows), idx.copy(), et.copy(), eng.cvpo_last_particles(B).copy(), np.asarray(eng.cvpo_duals()),
+                     eng.sac_get_params(0)[0], eng.sac_get_params(1)[0], eng.sac_get_params(2)[0]))
+        eng.close()
+    assert np.isfinite(outs[0][0]).all()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)

@@ -80,13 +80,13 @@ def main():
            "config": {"workload": f"CVPO defaults: obs {Do} act {Da} {H}x{H}, SingleCritic pair, store {T * E} rows in HBM, "
                                   f"batch {B}, K {K}, n_step 2", "updates": a.updates}, "dtype": "fp32",
            "last_stats": [float(x) for x in st[-1]]}
-    # roofline of the whole update (15 launches), algorithmic FLOPs: forward F per row and network, gradient = 3 F
+    # roofline of the whole update (13 launches), algorithmic FLOPs: forward F per row and network, gradient = 3 F
     Fq = 2 * ((Do + Da) * H + H * H + H); Fa = 2 * (Do * H + H * H + H * 2 * Da)
     flops = B * (Fa + 2 * Fq            # target action at s_{t+n} and the two target critics
                  + 2 * 3 * Fq           # critic step (SingleCritic pair)
                  + Fa + K * 2 * Fq      # actor_old at s_t and the K particles through both updated critics
                  + 3 * Fa)              # M-step: forward + backward of the actor
-    out["roofline"] = {"bound": "mfma", "scope": "whole update (15 launches)", "achieved": flops / dev / 1e12, "peak": 157.3,
+    out["roofline"] = {"bound": "mfma", "scope": "whole update (13 launches)", "achieved": flops / dev / 1e12, "peak": 157.3,
                        "unit": "TFLOP/s", "frac": flops / dev / 1e12 / 157.3, "flops_per_update": flops, "traffic": None}
     if not a.no_cpu:
         torch.set_num_threads(4)
