@@ -939,10 +939,12 @@ __device__ __forceinline__ void ppo_wgrad_extra_block(const ModelDesc& md, const
 // BIG = true: the same code inside a loop over 512-row chunks (merged last minibatch of batch 512: 1023).
 // FUSE: apply Adam to every gradient element as soon as it is reduced (max_grad_norm off); a separate instantiation so
 // that the clipped path keeps its register budget (one kernel with a runtime switch spilled 42 VGPRs).
-template <int H, bool BIG, bool FUSE>
+// U: k-steps per wave and load burst in the tile role (a chunk = 64 U rows).  8 for the single-agent launches; the grouped launches
+// take 4 -- a 256-row minibatch needs no more -- to fit 64 VGPRs, so that TWO workgroups share a CU (r6).
+template <int H, bool BIG, bool FUSE, int U = WG_MAXU>
 __device__ __forceinline__ void ppo_wgrad_body(const ModelDesc& md, const WgradPtrs& wp, const int mbp,
                                                const PpoStepArgs& sa, const int n_stat_tiles) {
-    const int CH = BIG ? (mbp + 511) / 512 : 1;      // row chunks
+    const int CH = BIG ? (mbp + 64 * U - 1) / (64 * U) : 1;      // row chunks
     constexpr int TPD = H / 32;          // tiles per dimension
     constexpr int NT2 = TPD * TPD;
     constexpr int NA = H / 32;
@@ -977,14 +979,14 @@ __device__ __forceinline__ void ppo_wgrad_body(const ModelDesc& md, const WgradP
         const int KS = mbp >> 2;
         f32x4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
         for (int ch = 0; ch < CH; ++ch) {
-            int s0 = 16 * WG_MAXU * ch;
+            int s0 = 16 * U * ch;
             // BIG: the chunk base is made opaque to the optimiser.  Left visible, it hoists the 64-bit address of every load of the
             // burst out of the chunk loop (2 x 8 address pairs here, 5 x 4 in the aux role) and spills them: 167-223 VGPRs, 472-544
             // bytes of scratch per lane in every BIG instantiation (round 5's code-object notes).  One add per load instead.
             if constexpr (BIG) asm volatile("" : "+s"(s0));
-            f32x2 a[WG_MAXU], b[WG_MAXU];
+            f32x2 a[U], b[U];
 #pragma unroll
-            for (int u = 0; u < WG_MAXU; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int s = s0 + wave + 16 * u;
                 if (s < KS) {
                     const size_t r = (size_t)(4 * s + q) * H;
@@ -996,7 +998,7 @@ __device__ __forceinline__ void ppo_wgrad_body(const ModelDesc& md, const WgradP
                 }
             }
 #pragma unroll
-            for (int u = 0; u < WG_MAXU; ++u) {
+            for (int u = 0; u < U; ++u) {
                 if (s0 + wave + 16 * u < KS) {   // wave-uniform
                     acc00 = mfma_16x16x4(a[u][0], b[u][0], acc00);
                     acc01 = mfma_16x16x4(a[u][0], b[u][1], acc01);
@@ -1057,8 +1059,8 @@ __device__ __forceinline__ void ppo_wgrad_body(const ModelDesc& md, const WgradP
             f32x4 ax0 = {0, 0, 0, 0}, ax1 = {0, 0, 0, 0}, ad0 = {0, 0, 0, 0}, ad1 = {0, 0, 0, 0};
             f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
             for (int ch = 0; ch < CH; ++ch)
-            for (int ub = 0; ub < WG_MAXU; ub += 4) {       // 4 k-steps per burst (64 rows / wave set)
-                int sbase = 16 * WG_MAXU * ch + 16 * ub;
+            for (int ub = 0; ub < U; ub += 4) {       // 4 k-steps per burst (64 rows / wave set)
+                int sbase = 16 * U * ch + 16 * ub;
                 if constexpr (BIG) asm volatile("" : "+s"(sbase));             // see the tile role: nothing of a burst is hoisted
                 if (sbase + wave >= KS) break;                                  // wave-uniform
                 f32x2 a1[4], a2[4], a3[4];
@@ -1240,8 +1242,12 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_group_kernel(const ModelDes
     ppo_fwd_bwd_body<H, R>(sm, a.P, md, a.bp, sa);
 }
 
+// r6: minibatches of up to 256 rows (BIG = false) take bursts of 4 k-steps per wave and a 64-VGPR budget, so that TWO workgroups share a
+// CU: a group of 8 is 1 736 workgroups per launch (6.8 rounds of one per CU: 33.0 us; 3.4 rounds of two: 24.4 us; k = 8 232.9 -> 253.1
+// updates/s aggregate, k = 4 212.6 -> 224.8, same box).  1-2 registers spill at that cap, outside the loops.  Larger (merged last)
+// minibatches keep the chunked 512-row form, one workgroup per CU, nothing spilled.
 template <int H, bool BIG, bool FUSE, int R>
-__global__ __launch_bounds__(1024) void ppo_wgrad_group_kernel(const ModelDesc md, const GroupAgent* __restrict__ tab,
+__global__ __launch_bounds__(1024, BIG ? 4 : 8) void ppo_wgrad_group_kernel(const ModelDesc md, const GroupAgent* __restrict__ tab,
                                                               const GroupStep* __restrict__ steps,
                                                               const PpoStepArgs base) {
     const GroupStep st = steps[blockIdx.y];
@@ -1251,7 +1257,7 @@ __global__ __launch_bounds__(1024) void ppo_wgrad_group_kernel(const ModelDesc m
     WgradPtrs wp = a.wp;
     wp.X = a.bp.obs_p + (size_t)st.mb_start * md.Do;
     const int tiles = (st.mb_size + 15) >> 4;
-    ppo_wgrad_body<H, BIG, FUSE>(md, wp, tiles * 16, sa, tiles * (16 / R));
+    ppo_wgrad_body<H, BIG, FUSE, BIG ? WG_MAXU : 4>(md, wp, tiles * 16, sa, tiles * (16 / R));
 }
 
 __global__ __launch_bounds__(ADAM_NT) void adam_clip_group_kernel(const ModelDesc md, const GroupAgent* __restrict__ tab,
