@@ -106,6 +106,7 @@ SIGNATURES = {
     "fsrl_batch_get": (C.c_int, [_ctx, C.c_char_p, _f, C.c_int64]),
     "fsrl_group_create": (C.c_int, [_P(_ctx), C.c_int32, _P(_ctx)]),
     "fsrl_group_destroy": (C.c_int, [_ctx]),
+    "fsrl_group_set_plan": (C.c_int, [_ctx, C.c_int32]),
     "fsrl_group_ppo_update": (C.c_int, [_ctx, _d, _d, C.c_int32, C.c_int32, _P(_i64), C.c_uint64, _P(_f), C.c_int64, _i64,
                                         _i32]),
     "fsrl_gae_return": (C.c_int, [_ctx, _f, _f, _d, _u8, C.c_int64, C.c_double, C.c_double, _d]),

@@ -494,13 +494,18 @@ struct PpoBatchPtrs {
     unsigned long long* ts;  // probe builds: [blocks][16] shader-clock stamps of the phase boundaries (else null)
 };
 
+// R = 32 (r6, grouped launches): two 16-row MFMA passes per weight fragment; a row's arithmetic does not depend on its tile's height and
+// the per-tile statistics keep their 16-row slots (stat_tile, stat_tile + 1), so 32- and 16-row tiles mix bit-identically.
 template <int H, int R>
-__device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* __restrict__ P, const ModelDesc& md,
-                                                 const PpoBatchPtrs& bp, const PpoStepArgs& sa) {
+__device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H, tile_rows(R)>& sm, const float* __restrict__ P, const ModelDesc& md,
+                                                 const PpoBatchPtrs& bp, const PpoStepArgs& sa, int tile = -1, int net = -1,
+                                                 int stat_tile = -1) {
     constexpr int LD = TileSmem<H>::LD;
     constexpr int NT = TileGeom<H>::NT;
+    constexpr int ROWS = tile_rows(R);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+    const bool placed = tile >= 0;          // the caller chose (tile, net, stat_tile): the grouped launch's mixed tile heights
     // block id = tile + n_tiles*net: consecutive tiles of one network land on different XCDs
     // (grouping a network's tiles on few XCDs was measured 25% slower: same-line contention)
     // tiles cover round_up(mb_size, 16) rows: the weight-gradient kernel reads whole 16-row groups,
@@ -512,15 +517,17 @@ __device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* _
     // same arithmetic.  DESIGN_HISTORY 3 (i-e) measured + 3 % on a probe build and left it out; re-tested on the product build, six
     // alternations on one box: 119.7 vs 116.5 updates/s mean, 120.7 vs 117.9 median (step 25.7 vs 26.4 us; the fused kernel itself
     // 13.05 vs 13.0 us -- the gain is what the next two launches no longer wait for).  Grouped launches keep the tile-major order.
-    int tile, net;
-    if (sa.xcd_pair) {
+    if (placed) {
+        // nothing to decode
+    } else if (sa.xcd_pair) {
         net = (int)(blockIdx.x & 7) >> 1; tile = 2 * (int)(blockIdx.x >> 3) + (int)(blockIdx.x & 1);
         if (net >= md.n_nets || tile >= n_tiles) return;
     } else {
         tile = blockIdx.x % n_tiles; net = blockIdx.x / n_tiles;
         if (net >= md.n_nets) return;       // grouped launches size grid.x for the largest member's minibatch
     }
-    const int row0 = tile * R;
+    if (!placed) stat_tile = tile;
+    const int row0 = placed ? tile : tile * R;      // placed: `tile` IS the first row
     const NetOff no = md.net[net];
     const int Do = md.Do, Da = md.Da, C = md.n_nets - 1;
     const int n_valid = max(0, min(R, sa.mb_size - row0));
@@ -530,7 +537,7 @@ __device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* _
     //      parameters); nothing below waits on a second cold round trip.
     if (FSRL_PROBE(sa, 10)) return;                     // pure launch floor of this kernel
     FSRL_TS(bp.ts, 0);
-    TileStage<H> stg;
+    TileStage<H, ROWS> stg;
     stg.issue(P, no, Do, Da, bp.obs_p + grow0 * Do, bp.rd_p + grow0 * FSRL_RD, n_valid, tid);
     if (FSRL_PROBE(sa, 13)) { asm volatile("" ::"v"(stg.b1v), "v"(stg.xv[0])); return; }
     FwdW2Frag<H> wf;
@@ -542,7 +549,7 @@ __device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* _
         return;
     }
     wf.load(P + no.W2f, wave, lane);
-    for (int e = tid; e < 16 * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
+    for (int e = tid; e < ROWS * FSRL_DOW; e += NT) sm.dout[e] = 0.0f;
     if (FSRL_PROBE(sa, 11)) {                           // loads issued, nobody waits for them
         asm volatile("" ::"v"(stg.b1v), "v"(wf.b[0]));
         return;
@@ -677,27 +684,41 @@ __device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* _
     FSRL_TS(bp.ts, 8);
     __syncthreads();
     FSRL_TS(bp.ts, 9);
-    if (tid < 4) {   // rows summed in ascending order (fixed => deterministic)
-        float t = 0.0f;
-        if (tid < 3)
-            for (int i = 0; i < R; ++i) t += sm.st[i * 4 + tid];
-        bp.statp[((size_t)tile * md.n_nets + net) * 4 + tid] = t;
+    if constexpr (R <= 16) {
+        if (tid < 4) {   // rows summed in ascending order (fixed => deterministic)
+            float t = 0.0f;
+            if (tid < 3)
+                for (int i = 0; i < R; ++i) t += sm.st[i * 4 + tid];
+            bp.statp[((size_t)stat_tile * md.n_nets + net) * 4 + tid] = t;
+        }
+    } else {
+        if (tid < 8) {   // the two 16-row halves in the slots the 16-row tiles would write
+            const int half = tid >> 2, f = tid & 3;
+            float t = 0.0f;
+            if (f < 3)
+                for (int i = 0; i < 16; ++i) t += sm.st[(16 * half + i) * 4 + f];
+            bp.statp[((size_t)(stat_tile + half) * md.n_nets + net) * 4 + f] = t;
+        }
     }
 
     if (FSRL_PROBE(sa, 6)) { if (wb[0][0] == 123.f) bp.statp[1] = 1.f; return; }
     // ---- dL/dz2 = (dout @ W3) * relu'(z2); thread = (column k, group of 4 rows)
-    if (tid < (R / 4) * H) {
-        const int k = tid % H, rg = tid / H;
-        float g[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int o = 0; o < no.out; ++o) {
-            const float w = sm.w3[o * H + k];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = fmaf(sm.dout[(4 * rg + e) * FSRL_DOW + o], w, g[e]);
-        }
+    for (int t0 = 0; t0 < (R / 4) * H; t0 += NT) {     // one trip up to 16 rows, two for 32
+        const int t = t0 + tid;
+        if (t < (R / 4) * H) {
+            const int k = t % H, rg = t / H;
+            float g[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int o = 0; o < no.out; ++o) {
+                const float w = sm.w3[o * H + k];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = 4 * rg + e;
-            sm.d2[i * LD + k] = (sm.h2[i * LD + k] > 0.0f) ? g[e] : 0.0f;
+                for (int e = 0; e < 4; ++e) g[e] = fmaf(sm.dout[(4 * rg + e) * FSRL_DOW + o], w, g[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * rg + e;
+                sm.d2[i * LD + k] = (sm.h2[i * LD + k] > 0.0f) ? g[e] : 0.0f;
+            }
         }
     }
     __syncthreads();
@@ -715,7 +736,7 @@ __device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* _
     }
     FSRL_TS(bp.ts, 11);
     // ---- dL/dz1 = (dz2 @ W2) * relu'(z1) on MFMA; result goes straight to L2/HBM
-    if constexpr (R != 16) {
+    if constexpr (R < 16) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc8 = {0.f, 0.f, 0.f, 0.f};
         const float* arow = &sm.d2[(lane & 3) * LD + 4 * q];
 #pragma unroll
@@ -747,13 +768,18 @@ __device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* _
             }
         }
     } else {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};     // acc2: rows 16..31 of a 32-row tile, same fragment
         const float* arow = &sm.d2[li * LD + 4 * q];
 #pragma unroll
         for (int jc = 0; jc < H / 16; ++jc) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * jc);
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = mfma_16x16x4(a[s], wb[jc][s], acc);
+            if constexpr (R == 32) {
+                const f32x4 a2 = *reinterpret_cast<const f32x4*>(arow + 16 * LD + 16 * jc);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc2 = mfma_16x16x4(a2[s], wb[jc][s], acc2);
+            }
         }
         if (FSRL_PROBE(sa, 7)) { if (acc[0] == 123.f) bp.statp[1] = 1.f; return; }
         float* __restrict__ D1 = bp.D1 + (nb + row0) * H;
@@ -762,6 +788,7 @@ __device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H>& sm, const float* _
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * q + r;
             D1[(size_t)i * H + col] = (sm.h1[i * LD + col] > 0.0f) ? acc[r] : 0.0f;
+            if constexpr (R == 32) D1[(size_t)(16 + i) * H + col] = (sm.h1[(16 + i) * LD + col] > 0.0f) ? acc2[r] : 0.0f;
         }
     }
     FSRL_TS(bp.ts, 13);
@@ -1240,6 +1267,28 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_group_kernel(const ModelDes
     const GroupAgent& a = tab[blockIdx.y];
     const PpoStepArgs sa = group_step_args(base, a, st);
     ppo_fwd_bwd_body<H, R>(sm, a.P, md, a.bp, sa);
+}
+
+// r6 (late): tall tiles.  When a group's 16-row tiles need a second round of workgroups (8 members x 3 networks x 16 tiles = 384 on
+// 256 CUs), the first `n32` tiles of every (member, network) are 32 rows tall (two MFMA passes per weight fragment: half the L2 -> register
+// weight ingest per row) and the rest stay 16 rows: per_net = n32 + the largest member's remaining 16-row tiles, grid.x = n_nets * per_net.
+// The host's automatic plan makes ALL of them tall (host_group.inc: k = 8 245 -> 283 updates/s aggregate).  A row's arithmetic and the
+// 16-row statistic slots do not depend on the tile height (ppo_fwd_bwd_body), so every plan gives the same bits.
+template <int H>
+__global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_group_mix_kernel(const ModelDesc md, const GroupAgent* __restrict__ tab,
+                                                                     const GroupStep* __restrict__ steps, const PpoStepArgs base,
+                                                                     const int n32, const int per_net) {
+    __shared__ __align__(16) unsigned char raw[sizeof(TileSmem<H, 32>)];
+    static_assert(sizeof(TileSmem<H, 32>) >= sizeof(TileSmem<H, 16>), "the 16-row layout lives inside the 32-row one");
+    const GroupStep st = steps[blockIdx.y];
+    if (!st.active) return;
+    const GroupAgent& a = tab[blockIdx.y];
+    const PpoStepArgs sa = group_step_args(base, a, st);
+    const int net = (int)blockIdx.x / per_net, b = (int)blockIdx.x - net * per_net;
+    const int row0 = b < n32 ? 32 * b : 32 * n32 + 16 * (b - n32);
+    if (net >= md.n_nets || row0 >= ((st.mb_size + 15) & ~15)) return;        // a smaller member has fewer tiles
+    if (b < n32) ppo_fwd_bwd_body<H, 32>(*reinterpret_cast<TileSmem<H, 32>*>(raw), a.P, md, a.bp, sa, row0, net, row0 >> 4);
+    else ppo_fwd_bwd_body<H, 16>(*reinterpret_cast<TileSmem<H, 16>*>(raw), a.P, md, a.bp, sa, row0, net, row0 >> 4);
 }
 
 // r6: minibatches of up to 256 rows (BIG = false) take bursts of 4 k-steps per wave and a 64-VGPR budget, so that TWO workgroups share a

@@ -716,6 +716,10 @@ class EngineGroup:
         except Exception:
             pass
 
+    def set_plan(self, tall_tiles=-1):
+        """32-row tiles per (member, network) in the forward / backward launch: -1 automatic, 0 none, n > 0 a count (A/B; same bits)."""
+        _lib.check(self.lib.fsrl_group_set_plan(self._g, int(tall_tiles)))
+
     def ppo_update(self, lagrangians, rescalings, batch_size, repeat, perms=None, seed=0):
         """k x Engine.ppo_update.  lagrangians: [k][n_critics - 1]; rescalings: [k]; perms: None or per member a list /
         array [repeat][N_i].  -> (list of stats arrays [steps_i, 11], list of stopped passes (-1 = none))."""

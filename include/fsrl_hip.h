@@ -277,6 +277,11 @@ int fsrl_ppo_update(fsrl_ctx* ctx, const double* lagrangians, double rescaling,
 typedef struct fsrl_group fsrl_group;
 int fsrl_group_create(fsrl_ctx** ctxs, int32_t k, fsrl_group** out);       /* 1 <= k <= 16; members are not owned   */
 int fsrl_group_destroy(fsrl_group* group);
+/* Launch plan of the group's forward / backward launch (A/B and tests; every plan gives the same bits): how many leading tiles of a
+ * (member, network) are 32 rows tall.  -1 automatic (default: all of them once the 16-row tiles of the group exceed the CU count, e.g.
+ * 8 members x 3 networks x 256 rows: 192 workgroups of 32 rows instead of 384 of 16), 0 none, n > 0 min(n, tiles / 2).
+ * Needs hidden >= 128 and obs_dim <= 64 (else 16-row tiles whatever the plan).                                                      */
+int fsrl_group_set_plan(fsrl_group* group, int32_t tall_tiles);
 /* k x BasePolicy.update (base_policy.py:332-355).  lagrangians [k][n_critics - 1], rescaling [k]; perms: NULL (library
  * shuffle, member i seeded by seed + 1000003 i + pass) or k pointers to [repeat][N_i]; stats_out: NULL or k pointers to
  * [cap_steps][FSRL_PPO_NSTATS]; n_steps_out [k]; stopped_pass_out [k] (-1 = ran every pass).                          */

@@ -227,3 +227,35 @@ def test_large_groups_match_member_by_member(H, k):
     grp.close()
     for e in engs + solo:
         e.close()
+
+
+@pytest.mark.parametrize("H,k,Do", [(256, 8, 8), (128, 7, 40), (256, 9, 60)])
+def test_tall_tile_plans_are_bit_identical(H, k, Do):
+    """fsrl_group_set_plan: the forward / backward launch with 32-row tiles for the first n tiles of every (member, network) -- automatic
+    (all of them once the 16-row tiles exceed the CU count), none (16-row tiles only), one (a mix), all -- gives the same logged rows and the same parameters to the bit: a
+    row's arithmetic and the 16-row statistic slots do not depend on the tile height.  Members have different lengths (ragged last
+    minibatches: 256 + merged 280 / 296 / ..., and one member with a single short minibatch whose tail tile is half empty)."""
+    from fsrl_amd.engine import EngineGroup
+    Ts = [268 + 8 * i for i in range(k - 1)] + [77]            # rows per member = 2 T: 536, 552, ... and 154 (< one minibatch of 256)
+    rng = np.random.default_rng(3)
+    perms = [[rng.permutation(2 * T) for _ in range(2)] for T in Ts]
+    lags = np.linspace(0.1, 0.9, k).reshape(k, 1)
+    resc = [1.0 / (1.0 + float(l)) for l in lags[:, 0]]
+    got = {}
+    for plan in (0, -1, 1, 64):
+        engs = [_filled(T, 40 + i, None, H=H, Do=Do) for i, T in enumerate(Ts)]
+        grp = EngineGroup(engs)
+        grp.set_plan(plan)
+        st, _ = grp.ppo_update(lags, resc, 256, 2, perms=perms)
+        st2, _ = grp.ppo_update(lags, resc, 256, 2, perms=perms)
+        got[plan] = (st, st2, [e.get_params() for e in engs])
+        grp.close()
+        for e in engs:
+            e.close()
+    base = got[0]
+    assert all(np.isfinite(s).all() for s in base[0])
+    for plan in (-1, 1, 64):
+        for i in range(k):
+            assert np.array_equal(got[plan][0][i], base[0][i]), (plan, i)
+            assert np.array_equal(got[plan][1][i], base[1][i]), (plan, i)
+            assert np.array_equal(got[plan][2][i], base[2][i]), (plan, i)

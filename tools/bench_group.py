@@ -3,7 +3,7 @@
 launches (fsrl_group_ppo_update): the BASELINE configs[1] workload per agent (obs 8 / act 2 / 256x256 / N = 20 000 /
 batch 256 / 4 passes / grad-clip 0.5).  One JSON line per k.
 
-    python tools/bench_group.py [--ks 1 2 4 8] [--updates 6] [--no-clip] [--host-reset]
+    python tools/bench_group.py [--ks 1 2 4 8] [--updates 6] [--no-clip] [--host-reset] [--tall -1 0 8]
 
 Every timed update starts from the same state (initial weights, fresh Adam moments): restored from the HBM snapshot, as bench.py
 does for the single agent (--host-reset: round 4's harness, which uploaded the weights from the host inside the timed region)."""
@@ -21,7 +21,7 @@ from bench import ACT, BATCH, ENVS, F32_MFMA_PEAK_TFLOPS, HID, NROWS, OBS, REPEA
 from fsrl_amd.engine import Engine, EngineConfig, EngineGroup  # noqa: E402
 
 
-def run(k, updates, clip, host_reset=False):
+def run(k, updates, clip, host_reset=False, tall=-1):
     engs, thetas = [], []
     for i in range(k):
         e = Engine(EngineConfig(obs_dim=OBS, act_dim=ACT, hidden=HID, env_num=ENVS, buffer_size=100000, max_grad_norm=clip,
@@ -34,6 +34,7 @@ def run(k, updates, clip, host_reset=False):
         e.sync()
         engs.append(e); thetas.append(th)
     grp = EngineGroup(engs)
+    grp.set_plan(tall)
     lags, resc = np.full((k, 1), 0.75), np.full(k, 1 / 1.75)
     for e, th in zip(engs, thetas):
         e.set_params(th); e.optim_reset(); e.state_snapshot()
@@ -62,7 +63,7 @@ def run(k, updates, clip, host_reset=False):
     return {"agents_per_gpu": k, "aggregate_updates_per_s": k / dt, "per_agent_updates_per_s": 1 / dt,
             "ms_per_group_update": dt * 1e3, "us_per_step_all_agents": dt * 1e6 / steps,
             "us_per_agent_step": dt * 1e6 / steps / k, "grad_clip": clip,
-            "reset": "host upload" if host_reset else "HBM snapshot",
+            "reset": "host upload" if host_reset else "HBM snapshot", "tall_tiles_plan": tall,
             "fwdbwd_flops_per_step_all_agents": flops_fwdbwd_launch(NROWS / (steps / REPEAT)) * k}
 
 
@@ -72,6 +73,9 @@ if __name__ == "__main__":
     ap.add_argument("--updates", type=int, default=6)
     ap.add_argument("--no-clip", action="store_true")
     ap.add_argument("--host-reset", action="store_true")
+    ap.add_argument("--tall", type=int, nargs="+", default=[-1],
+                    help="fsrl_group_set_plan values to run (each k once per value): -1 automatic, 0 = 16-row tiles only, n = count")
     a = ap.parse_args()
     for k in a.ks:
-        print(json.dumps(run(k, a.updates, None if a.no_clip else 0.5, a.host_reset)), flush=True)
+        for tall in a.tall:
+            print(json.dumps(run(k, a.updates, None if a.no_clip else 0.5, a.host_reset, tall)), flush=True)
