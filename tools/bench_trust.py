@@ -170,6 +170,8 @@ def run_focops(obs_dim=8, act_dim=2, hid=256, envs=20, T=1000, ep=250, batch=256
     obs, act, rew, cost, term, trunc = inputs(rng, envs, T, obs_dim, act_dim, ep)
     eng = Engine(EngineConfig(algo=_lib.ALGO_FOCOPS, obs_dim=obs_dim, act_dim=act_dim, hidden=hid, env_num=envs, target_kl=None))
     eng.focops_init(delta=1e9)                      # KL early stop off: every update runs all 312 steps
+    if os.environ.get("FSRL_FOC_PLAN"):               # A/B: fsrl_focops_set_plan (1 four launches, 2 the narrow step kernel)
+        eng.focops_set_plan(int(os.environ["FSRL_FOC_PLAN"]))
     o = FOCOPSOracle(FOCOPSConfig(obs_dim=obs_dim, act_dim=act_dim, hidden=(hid, hid), delta=1e9))
     theta = orth_theta(o, 0)
     ids = np.arange(envs)

@@ -37,7 +37,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/${TAG}_pmc_${C}_sac -- python $R/tools/bench_sac.py --rows 200000 --updates 200 --no-cpu > /dev/null 2>&1
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_trust -- env FSRL_NO_CPU=1 python $R/tools/bench_trust.py > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_group -- python $R/tools/bench_group.py --ks 4 --updates 3 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_group -- python $R/tools/bench_group.py --ks 8 --updates 3 > /dev/null 2>&1
 cd $R
 timeout 300 python tools/bench_group.py > $O/${TAG}_bench_group.json 2>/dev/null
 timeout 300 python tools/bench_group.py --host-reset > $O/${TAG}_bench_group_hostreset.json 2>/dev/null
