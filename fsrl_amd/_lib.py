@@ -103,6 +103,7 @@ SIGNATURES = {
     "fsrl_ppo_end": (C.c_int, [_ctx, _f, C.c_int64, _i64]),
     "fsrl_ppo_update": (C.c_int, [_ctx, _d, C.c_double, C.c_int32, C.c_int32, _i64, C.c_uint64, _f,
                                   C.c_int64, _i64, _i32]),
+    "fsrl_ppo_set_plan": (C.c_int, [_ctx, C.c_int32]),
     "fsrl_batch_get": (C.c_int, [_ctx, C.c_char_p, _f, C.c_int64]),
     "fsrl_group_create": (C.c_int, [_P(_ctx), C.c_int32, _P(_ctx)]),
     "fsrl_group_destroy": (C.c_int, [_ctx]),

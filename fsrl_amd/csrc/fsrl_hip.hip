@@ -179,6 +179,7 @@ struct fsrl_ctx {
     int probe_phase = 0, probe_wgrad_skip = 0;
     unsigned long long* probe_ts = nullptr;   // probe builds: [1024][16] phase stamps of the last fused-kernel launch
     bool probe_tile16 = false;
+    int tall_tiles = -1;               // fsrl_ppo_set_plan: 32-row tiles of the minibatch step's forward / backward launch (-1 automatic)
     bool no_fuse_adam = false;      // probe builds: FSRL_NO_FUSE_ADAM keeps the separate Adam launch without a clip (A/B, bit-compare)
     bool no_xcd_pair = false;       // probe builds: FSRL_NO_XCD_PAIR keeps the tile-major block order of the fused forward/backward launch (A/B)
     bool no_spin = false;           // wait for the collector's actor with hipStreamSynchronize instead of the completion words

@@ -803,6 +803,28 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_kernel(const float* __restr
     ppo_fwd_bwd_body<H, R>(sm, P, md, bp, sa);
 }
 
+// r6 (late): tall tiles.  Once a launch's 16-row tiles exceed the CU count (a group of 8 members x 3 networks x 16 tiles = 384 workgroups on
+// 256 CUs; one agent at minibatches above ~1 360 rows), the first `n32` tiles of every network are 32 rows tall (two MFMA passes per weight
+// fragment: half the L2 -> register weight ingest per row) and the rest stay 16 rows: block b of a network covers rows [32 b, 32 b + 32) for
+// b < n32 and 16 rows behind them otherwise; per_net = n32 + the remaining 16-row tiles, grid.x = n_nets * per_net.  A row's arithmetic and
+// the 16-row statistic slots do not depend on the tile height (ppo_fwd_bwd_body), so every plan gives the same bits.
+template <int H>
+__device__ __forceinline__ void ppo_fwd_bwd_mixed(unsigned char* raw, const float* __restrict__ P, const ModelDesc& md,
+                                                  const PpoBatchPtrs& bp, const PpoStepArgs& sa, const int n32, const int per_net) {
+    static_assert(sizeof(TileSmem<H, 32>) >= sizeof(TileSmem<H, 16>), "the 16-row layout lives inside the 32-row one");
+    const int net = (int)blockIdx.x / per_net, b = (int)blockIdx.x - net * per_net;
+    const int row0 = b < n32 ? 32 * b : 32 * n32 + 16 * (b - n32);
+    if (net >= md.n_nets || row0 >= ((sa.mb_size + 15) & ~15)) return;        // a smaller member of a group has fewer tiles
+    if (b < n32) ppo_fwd_bwd_body<H, 32>(*reinterpret_cast<TileSmem<H, 32>*>(raw), P, md, bp, sa, row0, net, row0 >> 4);
+    else ppo_fwd_bwd_body<H, 16>(*reinterpret_cast<TileSmem<H, 16>*>(raw), P, md, bp, sa, row0, net, row0 >> 4);
+}
+template <int H>
+__global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_tall_kernel(const float* __restrict__ P, const ModelDesc md, const PpoBatchPtrs bp,
+                                                                const PpoStepArgs sa, const int n32, const int per_net) {
+    __shared__ __align__(16) unsigned char raw[sizeof(TileSmem<H, 32>)];
+    ppo_fwd_bwd_mixed<H>(raw, P, md, bp, sa, n32, per_net);
+}
+
 // ---------------------------------------------------------------- weight gradients
 // block = 1024 threads (16 waves).  grid.x = n_nets * (NT2 + NA) + 1:
 //   NT2 = (H/32)^2 MFMA tile blocks (dW2, 32x32 outputs, 16-way split-K over the waves)
@@ -1269,26 +1291,18 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_group_kernel(const ModelDes
     ppo_fwd_bwd_body<H, R>(sm, a.P, md, a.bp, sa);
 }
 
-// r6 (late): tall tiles.  When a group's 16-row tiles need a second round of workgroups (8 members x 3 networks x 16 tiles = 384 on
-// 256 CUs), the first `n32` tiles of every (member, network) are 32 rows tall (two MFMA passes per weight fragment: half the L2 -> register
-// weight ingest per row) and the rest stay 16 rows: per_net = n32 + the largest member's remaining 16-row tiles, grid.x = n_nets * per_net.
-// The host's automatic plan makes ALL of them tall (host_group.inc: k = 8 245 -> 283 updates/s aggregate).  A row's arithmetic and the
-// 16-row statistic slots do not depend on the tile height (ppo_fwd_bwd_body), so every plan gives the same bits.
+// the grouped form of ppo_fwd_bwd_tall_kernel (grid.y = member); the host's automatic plan makes ALL tiles tall once the group's 16-row
+// tiles exceed the CU count (host_group.inc: k = 8 245 -> 283 updates/s aggregate)
 template <int H>
 __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_group_mix_kernel(const ModelDesc md, const GroupAgent* __restrict__ tab,
                                                                      const GroupStep* __restrict__ steps, const PpoStepArgs base,
                                                                      const int n32, const int per_net) {
     __shared__ __align__(16) unsigned char raw[sizeof(TileSmem<H, 32>)];
-    static_assert(sizeof(TileSmem<H, 32>) >= sizeof(TileSmem<H, 16>), "the 16-row layout lives inside the 32-row one");
     const GroupStep st = steps[blockIdx.y];
     if (!st.active) return;
     const GroupAgent& a = tab[blockIdx.y];
     const PpoStepArgs sa = group_step_args(base, a, st);
-    const int net = (int)blockIdx.x / per_net, b = (int)blockIdx.x - net * per_net;
-    const int row0 = b < n32 ? 32 * b : 32 * n32 + 16 * (b - n32);
-    if (net >= md.n_nets || row0 >= ((st.mb_size + 15) & ~15)) return;        // a smaller member has fewer tiles
-    if (b < n32) ppo_fwd_bwd_body<H, 32>(*reinterpret_cast<TileSmem<H, 32>*>(raw), a.P, md, a.bp, sa, row0, net, row0 >> 4);
-    else ppo_fwd_bwd_body<H, 16>(*reinterpret_cast<TileSmem<H, 16>*>(raw), a.P, md, a.bp, sa, row0, net, row0 >> 4);
+    ppo_fwd_bwd_mixed<H>(raw, a.P, md, a.bp, sa, n32, per_net);
 }
 
 // r6: minibatches of up to 256 rows (BIG = false) take bursts of 4 k-steps per wave and a 64-VGPR budget, so that TWO workgroups share a

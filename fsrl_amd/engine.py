@@ -381,6 +381,10 @@ class Engine:
         _lib.check(self.lib.fsrl_ppo_end(self._ctx, _ptr(out, _f32p), out.shape[0], C.byref(n)))
         return out[:n.value]
 
+    def ppo_set_plan(self, tall_tiles: int = -1):
+        """32-row tiles in the forward / backward launch of a minibatch step: -1 automatic, 0 none, n > 0 a count (A/B; same bits)"""
+        _lib.check(self.lib.fsrl_ppo_set_plan(self._ctx, int(tall_tiles)))
+
     def ppo_update(self, lagrangians, rescaling, batch_size, repeat, perms=None, seed=0):
         """-> (stats [steps, 11] float32, stopped_pass or -1)."""
         n = self.ppo_begin(lagrangians, rescaling, batch_size)

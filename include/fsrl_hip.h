@@ -265,6 +265,11 @@ int fsrl_ppo_update(fsrl_ctx* ctx, const double* lagrangians, double rescaling,
                     float* stats_out, int64_t cap_steps, int64_t* n_steps_out,
                     int32_t* stopped_pass_out);
 
+/* Launch plan of the minibatch step's forward / backward launch (A/B and tests; every plan gives the same bits): how many leading tiles of a
+ * network are 32 rows tall.  -1 automatic (default: all of them once the 16-row tiles exceed the CU count, i.e. minibatches above
+ * ~1 360 rows with three networks), 0 none, n > 0 min(n, tiles / 2).  Needs hidden >= 128 and obs_dim <= 64.                        */
+int fsrl_ppo_set_plan(fsrl_ctx* ctx, int32_t tall_tiles);
+
 /* ---- grouped updates: k independent PPO-Lagrangian agents of ONE network shape on one GPU, stepped in lock step
  *      (multi-seed runs; SURVEY 8e "within-GPU batching of k seeds").  The reference runs seeds as separate jobs; one
  *      agent's update is a chain of small dependent launches that leaves most of an MI355X idle, so k agents share every

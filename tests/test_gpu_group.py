@@ -259,3 +259,24 @@ def test_tall_tile_plans_are_bit_identical(H, k, Do):
             assert np.array_equal(got[plan][0][i], base[0][i]), (plan, i)
             assert np.array_equal(got[plan][1][i], base[1][i]), (plan, i)
             assert np.array_equal(got[plan][2][i], base[2][i]), (plan, i)
+
+
+@pytest.mark.parametrize("H,Do,B", [(256, 8, 2048), (128, 40, 1536)])
+def test_single_agent_tall_tile_plans_are_bit_identical(H, Do, B):
+    """fsrl_ppo_set_plan: minibatches whose 16-row tiles exceed the CU count (2 048 rows x 3 networks = 384 tiles) run 32-row tiles by
+    default; none / automatic / a mix of 3 tall tiles give the same logged rows and parameters to the bit (merged last minibatch ragged)."""
+    T = 2300                                                    # 4 600 rows: minibatches of B and the merged rest
+    rng = np.random.default_rng(4)
+    perms = [rng.permutation(2 * T) for _ in range(2)]
+    got = {}
+    for plan in (0, -1, 3):
+        e = _filled(T, 77, None, H=H, Do=Do)
+        e.ppo_set_plan(plan)
+        s1, _ = e.ppo_update([0.4], 1 / 1.4, B, 2, perms=perms)
+        s2, _ = e.ppo_update([0.4], 1 / 1.4, B, 2, perms=perms)
+        got[plan] = (s1, s2, e.get_params())
+        e.close()
+    assert np.isfinite(got[0][0]).all() and got[0][0].shape[0] == 2 * len(range(0, 2 * T - B + 1, B))
+    for plan in (-1, 3):
+        for a, b in zip(got[plan], got[0]):
+            assert np.array_equal(a, b), plan

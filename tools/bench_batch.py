@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """PPO-Lag update time against the minibatch size (configs[1] shape, N = 20 000, 4 passes): one line per batch size.
-    python tools/bench_batch.py [64 128 ...]"""
+    python tools/bench_batch.py [64 128 ...]          FSRL_TALL=0 : 16-row tiles only (fsrl_ppo_set_plan; default automatic)"""
 import os
 import sys
 import time
@@ -21,6 +21,8 @@ if __name__ == "__main__":
     for t in range(bench.NROWS // bench.ENVS):
         eng.push(ids, obs[t], act[t], rew[t], cost[t], term[t], trunc[t], obs[t + 1])
     eng.sync()
+    if os.environ.get("FSRL_TALL"):
+        eng.ppo_set_plan(int(os.environ["FSRL_TALL"]))
     lag, resc = np.array([0.75]), 1 / 1.75
     for B in sizes:
         for k in range(2):
