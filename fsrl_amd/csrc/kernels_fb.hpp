@@ -1506,8 +1506,18 @@ __global__ __launch_bounds__(256) void fb_sum_parts_kernel(float* __restrict__ o
 
 // ------------------------------------------------------------------------------------------
 // sum the per-tile statistics: statp[n_tiles][ny][FB_NSTAT] -> out[ny][FB_NSTAT] (float64)
+// r6 (late): `hout` / `done` (pinned host memory) -- every block also writes its sum straight to the host and then its completion word
+// `seq` (system-scope release): the host polls the words instead of paying a device-to-host copy launch and a stream synchronisation per
+// read-back (tr_stats / tr_dots: ~40 per CPO update, ~25 us each).
+__device__ __forceinline__ void rb_publish(double* __restrict__ hout, unsigned* __restrict__ done, const int slot, const double v,
+                                           const unsigned seq) {
+    hout[slot] = v;
+    __threadfence_system();
+    __hip_atomic_store(done + slot, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ __launch_bounds__(256) void fb_reduce_stats_kernel(const float* __restrict__ statp, int n_tiles,
-                                                             int ny, double* __restrict__ out) {
+                                                             int ny, double* __restrict__ out, double* __restrict__ hout = nullptr,
+                                                             unsigned* __restrict__ done = nullptr, unsigned seq = 0u) {
     __shared__ double sh[4];
     const int slot = blockIdx.x;          // (y, field)
     const int tid = threadIdx.x;
@@ -1516,7 +1526,11 @@ __global__ __launch_bounds__(256) void fb_reduce_stats_kernel(const float* __res
     s = wave_sum_d(s);
     if ((tid & 63) == 0) sh[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) out[slot] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (tid == 0) {
+        const double v = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        out[slot] = v;
+        if (hout) rb_publish(hout, done, slot, v, seq);
+    }
 }
 
 // ---- conjugate gradients on the device (cpo.py:184-204, trpo_lag.py:261-283).  Vectors live in the
@@ -1667,7 +1681,9 @@ __global__ __launch_bounds__(256) void cg_p_kernel(const float* __restrict__ r, 
 // accumulation of the dot products, rounded once), so results move only by the order of the float64 sums.
 struct TrDotArgs { const float* a[4]; const float* b[4]; int n_pairs; };
 // partial sums of up to four dot products: part[pair * CG_NB + block]
-__global__ __launch_bounds__(256) void tr_dots_kernel(const TrDotArgs da, double* __restrict__ part, int n) {
+__global__ __launch_bounds__(256) void tr_dots_kernel(const TrDotArgs da, double* __restrict__ part, int n,
+                                                     double* __restrict__ hpart = nullptr, unsigned* __restrict__ done = nullptr,
+                                                     unsigned seq = 0u) {
     __shared__ double sh[4];
     const int tid = threadIdx.x;
     for (int k = 0; k < da.n_pairs; ++k) {
@@ -1680,8 +1696,15 @@ __global__ __launch_bounds__(256) void tr_dots_kernel(const TrDotArgs da, double
             for (int e = 0; e < 4; ++e) acc += (double)x[e] * (double)y[e];
         }
         const double t = cg_block_sum256(acc, sh, tid);
-        if (tid == 0) part[k * CG_NB + blockIdx.x] = t;
+        if (tid == 0) {
+            part[k * CG_NB + blockIdx.x] = t;
+            if (hpart) hpart[k * CG_NB + blockIdx.x] = t;
+        }
         __syncthreads();
+    }
+    if (hpart && tid == 0) {              // the block's partials of every pair are on their way: its completion word behind them
+        __threadfence_system();
+        __hip_atomic_store(done + blockIdx.x, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 // dst = src (+ the W2 mirror when `mirror`): a gradient / solution vector becomes the tangent the HVP kernels read

@@ -392,7 +392,10 @@ int fsrl_tr_eval(fsrl_ctx* ctx, double* stats8);
  * plain block order; 5 = the same in XCD-aware order with half the row splits; 6 = both.  The tile_rows / hvp plans give
  * bit-identical results under EVERY wgrad plan; wgrad 1 and 2 agree to the bit, 0 and 4 where the tile jobs run; the kernel
  * families add the rows up in different orders (fp32 MFMA chains of different lengths, partials in float64): their results
- * agree to rounding (tests/test_gpu_fullsize.py states the tolerance).                                                  */
+ * agree to rounding (tests/test_gpu_fullsize.py states the tolerance).  tile_rows + 64: the critics' steps on the compute
+ * stream instead of beside the actor's step; tile_rows + 128: the host-side read-backs of an update (line-search statistics,
+ * dot products of the dual solve) by hipMemcpyAsync + hipStreamSynchronize instead of completion words the reducing kernels
+ * write to pinned memory (r6: CPO configs[2] 28.3 -> 27.65 ms per update); same results.                                   */
 int fsrl_tr_set_plan(fsrl_ctx* ctx, int32_t tile_rows, int32_t hvp, int32_t wgrad);
 /* A/B only: force how many 32-row tiles (per network) the co-resident launches of the tile kernel / of the cached Hessian
  * product start with, the remaining rows going to 16-row tiles behind them; -1 = automatic.  A PERSISTENT form exists:

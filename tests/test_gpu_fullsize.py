@@ -317,7 +317,8 @@ def test_full_batch_kernel_plans_are_bit_identical(obs_dim, hid, T):
         assert np.isfinite(ref["cpo"]).all() and np.isfinite(ref["trpo"]).all() and np.abs(ref["hvp"]).max() > 0
         # (32, 3): round 4's one-workgroup-per-CU kernels; (0, 0): round 5's co-resident pairs where they apply (256 wide)
         # tile_rows + 64: the critics' steps on the compute stream, behind each other, instead of beside the actor's step (r5)
-        for plan in ((0, 2, wg), (0, 0, wg), (16, 0, wg), (32, 3, wg), (32, 0, wg), (0, 3, wg), (64, 0, wg), (96, 3, wg)) + (((0, 0, 1), ) if wg == 2 else ()):
+        # tile_rows + 128: read-backs by hipMemcpyAsync + hipStreamSynchronize instead of the polled completion words (r6)
+        for plan in ((0, 2, wg), (0, 0, wg), (16, 0, wg), (32, 3, wg), (32, 0, wg), (0, 3, wg), (64, 0, wg), (96, 3, wg), (128, 0, wg)) + (((0, 0, 1), ) if wg == 2 else ()):
             got = run(*plan)
             for k in ref:
                 assert np.array_equal(ref[k], got[k]), (plan, k, np.abs(np.asarray(ref[k], np.float64) - got[k]).max())
