@@ -479,7 +479,8 @@ class Engine:
         return out
 
     def tr_set_plan(self, tile_rows: int = 0, hvp: int = 0, wgrad: int = 0):
-        """Kernel plan of the full-batch path (A/B timing, bit-identity tests); 0 / 0 = automatic."""
+        """Kernel plan of the full-batch path (A/B timing, bit-identity tests); 0 / 0 = automatic.  tile_rows + 64: critic steps on the
+        compute stream; + 128: read-backs by copy + stream synchronisation instead of polled completion words."""
         _lib.check(self.lib.fsrl_tr_set_plan(self._ctx, int(tile_rows), int(hvp), int(wgrad)))
 
     def tr_set_tile_split(self, n32_tile: int = -1, n32_hvp: int = -1):
