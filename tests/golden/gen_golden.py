@@ -329,6 +329,14 @@ def gen_ppo():
                  advantage_normalization=False)
 
 
+def gen_ppo_bigbatch():
+    # a minibatch whose 16-row tiles exceed the CU count of an MI355X (2 048 rows x 3 networks = 384 tiles > 256): the HIP path runs
+    # 32-row tiles there (r6, ppo_fwd_bwd_tall_kernel); 4 600 rows = one minibatch of 2 048 + the merged rest of 2 552 per pass
+    gen_ppo_case("bigbatch", obs_dim=8, act_dim=2, hidden=(256, 256), env_num=4,
+                 ep_lens=[[600, 550], [600, 550], [600, 550], [600, 550]], batch_size=2048,
+                 repeat=2, seed=6, max_grad_norm=0.5, target_kl=1e9)
+
+
 def gen_ppo_recompute():
     # recompute_advantage (ppo_lag.py:218-221): GAE from the CURRENT critics before passes 2 and 3
     gen_ppo_case("recompute", obs_dim=6, act_dim=2, hidden=(64, 64), env_num=3,
@@ -502,5 +510,5 @@ if __name__ == "__main__":
     torch.set_num_threads(4)
     which = sys.argv[1:] or ["gae", "nstep", "pid", "ppo", "manifest"]
     for w in which:
-        {"gae": gen_gae, "nstep": gen_nstep, "pid": gen_pid, "ppo": gen_ppo, "recompute": gen_ppo_recompute, "options": gen_ppo_options,
+        {"gae": gen_gae, "nstep": gen_nstep, "pid": gen_pid, "ppo": gen_ppo, "recompute": gen_ppo_recompute, "bigbatch": gen_ppo_bigbatch, "options": gen_ppo_options,
          "widths": gen_ppo_widths, "depths": gen_ppo_depths, "full": gen_ppo_full, "full_klstop": gen_ppo_full_klstop, "manifest": gen_manifest}[w]()

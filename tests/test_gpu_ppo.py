@@ -13,7 +13,7 @@ from helpers import load_npz, oracle_cfg_and_data, ppo_case, ppo_full_case, roll
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["tiny", "dualclip", "earlystop", "c1", "c2", "recompute", "rewnorm", "rewnorm_first", "rewnorm_recompute", "unbounded",
+CASES = ["tiny", "dualclip", "earlystop", "c1", "c2", "bigbatch", "recompute", "rewnorm", "rewnorm_first", "rewnorm_recompute", "unbounded",
          "widths", "widths_wide",      # two hidden layers of different widths, none of them 64 / 128 / 256 (zero-padded on the device)
          "deep3", "wide", "one_layer", "deep4_options"]     # other depths / widths above 256: layered contexts (host_layered.inc)
 

@@ -10,7 +10,7 @@ from helpers import oracle_cfg_and_data, ppo_case, ppo_full_case, rollout_env_ma
 from oracle.pid import rescaling_factor
 from oracle.ppo_lag import PPOLagOracle, split_chunks
 
-CASES = ["tiny", "c1", "c2", "earlystop", "dualclip", "recompute", "rewnorm", "rewnorm_first", "rewnorm_recompute",
+CASES = ["tiny", "c1", "c2", "bigbatch", "earlystop", "dualclip", "recompute", "rewnorm", "rewnorm_first", "rewnorm_recompute",
          "unbounded", "widths", "widths_wide",
          "deep3", "wide", "one_layer", "deep4_options"]     # hidden_sizes of other depths / widths above 256
 
