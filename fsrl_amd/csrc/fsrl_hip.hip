@@ -1239,7 +1239,7 @@ extern "C" int fsrl_launch_floors(fsrl_ctx* c, int32_t mb_rows, int32_t iters, d
     const bool rows4 = tiles * 4 * nn <= c->n_cus, rows8 = !rows4 && tiles * 2 * nn <= c->n_cus;
     const int nt_ = rows4 ? tiles * 4 : rows8 ? tiles * 2 : tiles;
     const int g_fb = (nn <= 4 && !c->no_xcd_pair) ? 8 * ((nt_ + 1) / 2) : nt_ * nn;      // the step's own grid (one network per XCD pair)
-    const int g_wg = nn * ((H / 32) * (H / 32) + H / 32) + 1;
+    const int g_wg = wg_grid(H, nn);
     const int g_ad = (c->n_dev + 4 * ADAM_NT - 1) / (4 * ADAM_NT);
     size_t lds_fb = 0, lds_wg = 0;
     int rc = dispatch_H(H, [&](auto hc) {

@@ -826,11 +826,11 @@ __global__ __launch_bounds__(4 * H) void ppo_fwd_bwd_tall_kernel(const float* __
 }
 
 // ---------------------------------------------------------------- weight gradients
-// block = 1024 threads (16 waves).  grid.x = n_nets * (NT2 + NA) + 1:
-//   NT2 = (H/32)^2 MFMA tile blocks (dW2, 32x32 outputs, 16-way split-K over the waves)
-//   NA  = H/32 aux blocks (dW1, dW3, db1, db2 of 32 columns; also MFMA, 16-way split-K)
-//   +1  = the block that finalises the logged statistics of this step and reduces the
-//         column sums of the dout side buffer (db3, dsigma) of every network.
+// block = 1024 threads (16 waves).  grid.x = wg_grid(H, n_nets) = n_nets * (NT2 + 2 NA) + n_nets + 1:
+//   NT2  = (H/32)^2 MFMA tile blocks (dW2, 32x32 outputs, 16-way split-K over the waves)
+//   2 NA = H/32 aux blocks for dW1 + db1 and H/32 for dW3 + db2 (32 columns each; also MFMA, 16-way split-K)
+//   + n_nets blocks reducing the column sums of the dout side buffer (db3, dsigma) of one network each
+//   + 1 block that finalises the logged statistics of this step.
 // Every block emits the sum of squares of the gradient entries it produced
 // (clip_grad_norm_, ppo_lag.py:237-240).
 struct WgradPtrs {
@@ -860,6 +860,11 @@ __device__ __forceinline__ void ppo_adam_elem(const WgradPtrs& wp, const PpoStep
     wp.M[i] = m; wp.V[i] = v; wp.Pw[i] = p;
     if (mi >= 0) wp.Pw[mi] = p;
 }
+
+// grid of a weight-gradient launch (host and device): per network (H/32)^2 dW2 tiles + 2 x H/32 aux parts, then one extra block per
+// network and the logged-row block; every block leaves one squared-norm partial in gsq_part
+__host__ __device__ constexpr int wg_blocks_per_net(int H) { return (H / 32) * (H / 32) + 2 * (H / 32); }
+__host__ __device__ constexpr int wg_grid(int H, int n_nets) { return n_nets * wg_blocks_per_net(H) + n_nets + 1; }
 
 #define WG_MAXU 8      // k-steps per wave and load burst in the tile role (512 rows per burst)
 #define AUX_MAXU 32    // rows per thread in the aux role:   mbp/16   <= 32
@@ -920,68 +925,233 @@ __device__ __forceinline__ void ppo_stats_finalize(const ModelDesc& md, const Wg
     }
 }
 
-// The extra block of a weight-gradient launch: the step's logged row, and db3 / dsigma (column sums of the dout side buffer)
-// of every network with their share of the squared gradient norm.  `red`: at least 32 x 33 floats of LDS.
+// The extra blocks of a weight-gradient launch (r6 late: one per role; up to r6 early ONE block walked all of it -- the logged row's
+// chain of dependent cold loads, then the networks one after the other: 2.6 us over the launch floor where a dW2 tile takes 1.0):
+//   e < n_nets : db3 / dsigma of network e (column sums of its dout side buffer) and their share of the squared gradient norm
+//   e == n_nets: the step's logged row (FUSE: the block of network 0 writes it first -- it reads the sigma_param its own Adam step
+//                is about to change -- and this block only leaves a zero behind)
+// `red`: at least 32 x 33 floats of LDS.
 template <bool BIG, bool FUSE>
 __device__ __forceinline__ void ppo_wgrad_extra_block(const ModelDesc& md, const WgradPtrs& wp, const int mbp, const PpoStepArgs& sa,
-                                                      const int n_stat_tiles, float* red) {
+                                                      const int n_stat_tiles, float* red, const int e) {
     const int CH = BIG ? (mbp + 511) / 512 : 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-        if (FSRL_PROBE(sa, 21) || FSRL_PROBE(sa, 22)) return;
-        if (wave == 0 && wp.stats) {
-            ppo_stats_finalize(md, wp, sa, n_stat_tiles, lane);
-            // fused mode: the pass-level KL stop that adam_clip_kernel's first block decides otherwise (ppo_lag.py:251-255)
-            if (FUSE && lane == 0 && sa.last_in_pass && sa.target_kl > 0.0f) {
-                const double mean_kl = wp.ctrl->kl_sum / ((double)sa.iters_in_pass + 1e-7);
-                if (mean_kl > sa.kl_thresh) wp.ctrl->stopped_after = sa.pass;
+    if (FSRL_PROBE(sa, 21)) return;
+    const bool stats_here = FUSE ? (e == 0) : (e == md.n_nets);
+    if (stats_here && wave == 0 && wp.stats) {
+        ppo_stats_finalize(md, wp, sa, n_stat_tiles, lane);
+        // fused mode: the pass-level KL stop that adam_clip_kernel's first block decides otherwise (ppo_lag.py:251-255)
+        if (FUSE && lane == 0 && sa.last_in_pass && sa.target_kl > 0.0f) {
+            const double mean_kl = wp.ctrl->kl_sum / ((double)sa.iters_in_pass + 1e-7);
+            if (mean_kl > sa.kl_thresh) wp.ctrl->stopped_after = sa.pass;
+        }
+    }
+    if (e == md.n_nets) {                     // nothing of the gradient is produced here
+        if (tid == 0) wp.gsq_part[blockIdx.x] = 0.0f;
+        return;
+    }
+    // db3[o] / dsigma[d] = column sums of DO over the minibatch rows:
+    // thread (col = tid & 31, row phase = tid >> 5); all loads of a thread in one burst
+    float sqs = 0.0f;
+    {
+        const int net = e;
+        const NetOff no = md.net[net];
+        const float* __restrict__ DOn = wp.DO + (size_t)net * wp.mbp_max * FSRL_DOW;
+        const int col = tid & 31, php = tid >> 5;
+        float t = 0.0f;
+        for (int ch = 0; ch < CH; ++ch) {
+            float v[16];
+            int rbase = 512 * ch;
+            if constexpr (BIG) asm volatile("" : "+s"(rbase));
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = rbase + php + 32 * u;
+                v[u] = (r < mbp) ? DOn[(size_t)r * FSRL_DOW + col] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t += v[u];
+        }
+        __syncthreads();
+        red[php * 33 + col] = t;
+        __syncthreads();
+        if (tid < 32) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int p2 = 0; p2 < 32; ++p2) tot += red[p2 * 33 + tid];
+            if (tid < no.out) {
+                wp.grad[no.b3 + tid] = tot; sqs = fmaf(tot, tot, sqs);
+                if constexpr (FUSE) ppo_adam_elem(wp, sa, no.b3 + tid, tot);
+            }
+            if (no.sigma >= 0 && tid >= 16 && tid < 16 + md.Da) {
+                wp.grad[no.sigma + tid - 16] = tot; sqs = fmaf(tot, tot, sqs);
+                if constexpr (FUSE) ppo_adam_elem(wp, sa, no.sigma + tid - 16, tot);   // wave 0 logged the entropy first
             }
         }
-        // db3[o] / dsigma[d] = column sums of DO over the minibatch rows, for every network:
-        // thread (col = tid & 31, row phase = tid >> 5); all loads of a thread in one burst
-        float sqs = 0.0f, sqs_prev = 0.0f;
-        for (int net = 0; net < md.n_nets; ++net) {
-            const NetOff no = md.net[net];
-            const float* __restrict__ DOn = wp.DO + (size_t)net * wp.mbp_max * FSRL_DOW;
-            const int col = tid & 31, php = tid >> 5;
-            float t = 0.0f;
-            for (int ch = 0; ch < CH; ++ch) {
-                float v[16];
-                int rbase = 512 * ch;
-                if constexpr (BIG) asm volatile("" : "+s"(rbase));
+    }
+    if (wave == 0) {
+        sqs = wave_sum(sqs);                  // lanes >= 32 hold 0
+        if (lane == 0) {
+            wp.gsq_part[blockIdx.x] = sqs;
+            if (wp.gsq_net) wp.gsq_net[e] = sqs;          // this network's share on its own (FOCOPS clips the actor alone)
+        }
+    }
+}
+
+// ---- aux roles of the weight-gradient launch: 32 columns j0..j0+31 of one network, the 16-way split-K MFMA structure of the dW2 tiles.
+//        PA: dW1[j][k] = sum_r D1[r][j] * X[r][k]  (A = D1, B = x row)  and  db1[j] = column sums of D1
+//        PB: dW3[o][j] = sum_r A2[r][j] * DO[r][o] (A = A2, B = dout row) and  db2[j] = column sums of D2
+//      r6 (late): one workgroup per PART (up to r6 early one workgroup did both: 5 operand streams, 128 KB through one CU's L1 at 256 rows
+//      where a dW2 tile moves 64 KB -- the role timing of a probe build: launch floor 4.4 us, tiles alone 5.4, aux blocks alone 7.2, with
+//      D1 / X only 6.2).  Per element the loads, MFMA order and the two-round LDS reduction are unchanged: same bits.
+//      (v1 did this with VALU + LDS broadcasts on 12 blocks and took 16 us.)
+template <int H, bool BIG, bool FUSE, int U, bool PA, bool PB>
+__device__ __forceinline__ void ppo_wgrad_aux(const ModelDesc& md, const WgradPtrs& wp, const int mbp, const PpoStepArgs& sa,
+                                              const NetOff& no, const float* __restrict__ A2, const float* __restrict__ D1,
+                                              const float* __restrict__ D2, const float* __restrict__ DOb, const int j0,
+                                              float* red, float& sq) {
+    const int CH = BIG ? (mbp + 64 * U - 1) / (64 * U) : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int Do = md.Do, out = no.out;
+    const int KS = mbp >> 2;
+    const float* __restrict__ X = wp.X;
+    for (int k0 = 0; k0 < (PA ? Do : 1); k0 += 16) {
+        const bool first = (k0 == 0);
+        f32x4 ax0 = {0, 0, 0, 0}, ax1 = {0, 0, 0, 0}, ad0 = {0, 0, 0, 0}, ad1 = {0, 0, 0, 0};
+        f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+        for (int ch = 0; ch < CH; ++ch)
+        for (int ub = 0; ub < U; ub += 4) {       // 4 k-steps per burst (64 rows / wave set)
+            int sbase = 16 * U * ch + 16 * ub;
+            if constexpr (BIG) asm volatile("" : "+s"(sbase));             // see the tile role: nothing of a burst is hoisted
+            if (sbase + wave >= KS) break;                                  // wave-uniform
+            f32x2 a1[4], a2[4], a3[4];
+            float bx[4], bd[4];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int r = rbase + php + 32 * u;
-                    v[u] = (r < mbp) ? DOn[(size_t)r * FSRL_DOW + col] : 0.0f;
+            for (int u = 0; u < 4; ++u) {               // one burst of independent loads
+                const int sidx = sbase + wave + 16 * u;
+                a1[u] = f32x2{0.f, 0.f}; a2[u] = f32x2{0.f, 0.f}; a3[u] = f32x2{0.f, 0.f};
+                bx[u] = 0.f; bd[u] = 0.f;
+                if (sidx < KS) {
+                    const size_t r = (size_t)(4 * sidx + q);
+                    if constexpr (PA) {
+                        a1[u] = *reinterpret_cast<const f32x2*>(D1 + r * H + j0 + 2 * c);
+                        if (k0 + c < Do) bx[u] = X[r * Do + k0 + c];
+                    }
+                    if constexpr (PB) {
+                        if (first) {
+                            a2[u] = *reinterpret_cast<const f32x2*>(A2 + r * H + j0 + 2 * c);
+                            a3[u] = *reinterpret_cast<const f32x2*>(D2 + r * H + j0 + 2 * c);
+                            bd[u] = DOb[r * FSRL_DOW + c];
+                        }
+                    }
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) t += v[u];
+            for (int u = 0; u < 4; ++u) {               // zero operands beyond KS add nothing
+                if constexpr (PA) {
+                    ax0 = mfma_16x16x4(a1[u][0], bx[u], ax0);
+                    ax1 = mfma_16x16x4(a1[u][1], bx[u], ax1);
+                    if (first) s1 += a1[u];
+                }
+                if constexpr (PB) {
+                    if (first) {
+                        ad0 = mfma_16x16x4(a2[u][0], bd[u], ad0);
+                        ad1 = mfma_16x16x4(a2[u][1], bd[u], ad1);
+                        s2 += a3[u];
+                    }
+                }
+            }
+        }
+        // bias sums: add the 4 k-slots (q) of the wave; lanes q==0 then hold columns 2c, 2c+1
+        if (first) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if constexpr (PA) { s1[t] += __shfl_xor(s1[t], 16, 64); s1[t] += __shfl_xor(s1[t], 32, 64); }
+                if constexpr (PB) { s2[t] += __shfl_xor(s2[t], 16, 64); s2[t] += __shfl_xor(s2[t], 32, 64); }
+            }
+        }
+        // slot layout (1088 floats): [0,512) dW1 tile [32 j][16 k], [512,1024) dW3^T tile
+        // [32 j][16 o], [1024,1056) db1[32], [1056,1088) db2[32].  Two rounds over 8 slots.
+        float* slot = red + (wave & 7) * 1088;
+        __syncthreads();
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            if ((wave >> 3) == round) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jl = 2 * (4 * q + r);
+                    if (round == 0) {
+                        if constexpr (PA) {
+                            slot[(jl + 0) * 16 + c] = ax0[r];
+                            slot[(jl + 1) * 16 + c] = ax1[r];
+                        }
+                        if constexpr (PB) {
+                            if (first) {
+                                slot[512 + (jl + 0) * 16 + c] = ad0[r];
+                                slot[512 + (jl + 1) * 16 + c] = ad1[r];
+                            }
+                        }
+                    } else {
+                        if constexpr (PA) {
+                            slot[(jl + 0) * 16 + c] += ax0[r];
+                            slot[(jl + 1) * 16 + c] += ax1[r];
+                        }
+                        if constexpr (PB) {
+                            if (first) {
+                                slot[512 + (jl + 0) * 16 + c] += ad0[r];
+                                slot[512 + (jl + 1) * 16 + c] += ad1[r];
+                            }
+                        }
+                    }
+                }
+                if (first && q == 0) {
+                    if (round == 0) {
+                        if constexpr (PA) { slot[1024 + 2 * c] = s1[0]; slot[1024 + 2 * c + 1] = s1[1]; }
+                        if constexpr (PB) { slot[1056 + 2 * c] = s2[0]; slot[1056 + 2 * c + 1] = s2[1]; }
+                    } else {
+                        if constexpr (PA) { slot[1024 + 2 * c] += s1[0]; slot[1024 + 2 * c + 1] += s1[1]; }
+                        if constexpr (PB) { slot[1056 + 2 * c] += s2[0]; slot[1056 + 2 * c + 1] += s2[1]; }
+                    }
+                }
             }
             __syncthreads();
-            red[php * 33 + col] = t;
-            __syncthreads();
-            if (tid < 32) {
-                float tot = 0.0f;
+        }
+        // final: threads [0,512) dW1, [512,1024) dW3^T (+ the first 64 of them the biases)
+        {
+            const int e = tid & 511;
+            float v = 0.0f;
+            const int off = (tid < 512) ? e : 512 + e;
+            if ((PA && tid < 512) || (PB && tid >= 512)) {
 #pragma unroll
-                for (int p2 = 0; p2 < 32; ++p2) tot += red[p2 * 33 + tid];
-                if (tid < no.out) {
-                    wp.grad[no.b3 + tid] = tot; sqs = fmaf(tot, tot, sqs);
-                    if constexpr (FUSE) ppo_adam_elem(wp, sa, no.b3 + tid, tot);
-                }
-                if (no.sigma >= 0 && tid >= 16 && tid < 16 + md.Da) {
-                    wp.grad[no.sigma + tid - 16] = tot; sqs = fmaf(tot, tot, sqs);
-                    if constexpr (FUSE) ppo_adam_elem(wp, sa, no.sigma + tid - 16, tot);   // wave 0 logged the entropy first
-                }
+                for (int w = 0; w < 8; ++w) v += red[w * 1088 + off];
             }
-            if (wp.gsq_net && wave == 0) {           // this network's share on its own (lanes >= 32 of wave 0 hold 0)
-                const float d = wave_sum(sqs - sqs_prev);
-                if (lane == 0) wp.gsq_net[net] = d;
-                sqs_prev = sqs;
+            const int jl = e >> 4, kk = e & 15;
+            if (tid < 512) {
+                if constexpr (PA) {
+                    if (k0 + kk < Do) {
+                        const int gi = no.W1 + (j0 + jl) * Do + k0 + kk;
+                        wp.grad[gi] = v;
+                        sq = fmaf(v, v, sq);
+                        if constexpr (FUSE) ppo_adam_elem(wp, sa, gi, v);
+                    }
+                }
+            } else if (PB && first && kk < out) {
+                const int gi = no.W3 + kk * H + j0 + jl;
+                wp.grad[gi] = v;
+                sq = fmaf(v, v, sq);
+                if constexpr (FUSE) ppo_adam_elem(wp, sa, gi, v);
+            }
+            if (first && ((PA && tid < 32) || (PB && tid >= 32 && tid < 64))) {
+                float bsum = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) bsum += red[w * 1088 + 1024 + tid];
+                const int gi = (tid < 32) ? no.b1 + j0 + tid : no.b2 + j0 + tid - 32;
+                wp.grad[gi] = bsum;
+                sq = fmaf(bsum, bsum, sq);
+                if constexpr (FUSE) ppo_adam_elem(wp, sa, gi, bsum);
             }
         }
-        if (wave == 0) {
-            sqs = wave_sum(sqs);
-            if (lane == 0) wp.gsq_part[blockIdx.x] = sqs;
-        }
+    }
 }
 
 // BIG = false: mbp <= 512, every role is one straight-line load burst (the common case: batch <= 256).
@@ -997,13 +1167,14 @@ __device__ __forceinline__ void ppo_wgrad_body(const ModelDesc& md, const WgradP
     constexpr int TPD = H / 32;          // tiles per dimension
     constexpr int NT2 = TPD * TPD;
     constexpr int NA = H / 32;
-    constexpr int PB = NT2 + NA;
+    constexpr int PB = NT2 + 2 * NA;     // per network: the dW2 tiles, then the two aux parts (dW1 + db1 | dW3 + db2) of every 32 columns
+    static_assert(PB == wg_blocks_per_net(H), "host and device agree on the grid");
     __shared__ float red[1024 * 9];      // 8 split-K partial slots of a 32x32 tile / aux reduce scratch
     __shared__ float wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (FSRL_PROBE(sa, 20)) return;
-    if ((int)blockIdx.x == md.n_nets * PB) {  // the stats block
-        ppo_wgrad_extra_block<BIG, FUSE>(md, wp, mbp, sa, n_stat_tiles, red);
+    if ((int)blockIdx.x >= md.n_nets * PB) {  // the extra blocks: one per network + the logged row
+        ppo_wgrad_extra_block<BIG, FUSE>(md, wp, mbp, sa, n_stat_tiles, red, (int)blockIdx.x - md.n_nets * PB);
         return;
     }
     const int net = blockIdx.x / PB, rb = blockIdx.x % PB;
@@ -1092,134 +1263,10 @@ __device__ __forceinline__ void ppo_wgrad_body(const ModelDesc& md, const WgradP
             if constexpr (FUSE)
                 ppo_adam_elem(wp, sa, gi, v, no.W2f + w2f_index(H, tj * 32 + jl, tk * 32 + kl));
         }
+    } else if (rb < NT2 + NA) {
+        ppo_wgrad_aux<H, BIG, FUSE, U, true, false>(md, wp, mbp, sa, no, A2, D1, D2, DOb, (rb - NT2) * 32, red, sq);
     } else {
-        // ---- aux: 32 columns j0..j0+31 of this network; same 16-way split-K MFMA structure as
-        // the dW2 tiles:   dW1[j][k]  = sum_r D1[r][j] * X[r][k]      (A = D1, B = x row)
-        //                  dW3[o][j]  = sum_r A2[r][j] * DO[r][o]     (A = A2, B = dout row)
-        //                  db1[j], db2[j] = column sums of D1, D2     (register sums of A)
-        // (v1 did this with VALU + LDS broadcasts on 12 blocks and took 16 us.)
-        const int j0 = (rb - NT2) * 32;
-        const int c = lane & 15, q = lane >> 4;
-        const int Do = md.Do, out = no.out;
-        const int KS = mbp >> 2;
-        const float* __restrict__ X = wp.X;
-        for (int k0 = 0; k0 < Do; k0 += 16) {
-            const bool first = (k0 == 0);
-            f32x4 ax0 = {0, 0, 0, 0}, ax1 = {0, 0, 0, 0}, ad0 = {0, 0, 0, 0}, ad1 = {0, 0, 0, 0};
-            f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
-            for (int ch = 0; ch < CH; ++ch)
-            for (int ub = 0; ub < U; ub += 4) {       // 4 k-steps per burst (64 rows / wave set)
-                int sbase = 16 * U * ch + 16 * ub;
-                if constexpr (BIG) asm volatile("" : "+s"(sbase));             // see the tile role: nothing of a burst is hoisted
-                if (sbase + wave >= KS) break;                                  // wave-uniform
-                f32x2 a1[4], a2[4], a3[4];
-                float bx[4], bd[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {               // one burst of independent loads
-                    const int sidx = sbase + wave + 16 * u;
-                    a1[u] = f32x2{0.f, 0.f}; a2[u] = f32x2{0.f, 0.f}; a3[u] = f32x2{0.f, 0.f};
-                    bx[u] = 0.f; bd[u] = 0.f;
-                    if (sidx < KS) {
-                        const size_t r = (size_t)(4 * sidx + q);
-                        a1[u] = *reinterpret_cast<const f32x2*>(D1 + r * H + j0 + 2 * c);
-                        if (k0 + c < Do) bx[u] = X[r * Do + k0 + c];
-                        if (first) {
-                            a2[u] = *reinterpret_cast<const f32x2*>(A2 + r * H + j0 + 2 * c);
-                            a3[u] = *reinterpret_cast<const f32x2*>(D2 + r * H + j0 + 2 * c);
-                            bd[u] = DOb[r * FSRL_DOW + c];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {               // zero operands beyond KS add nothing
-                    ax0 = mfma_16x16x4(a1[u][0], bx[u], ax0);
-                    ax1 = mfma_16x16x4(a1[u][1], bx[u], ax1);
-                    if (first) {
-                        ad0 = mfma_16x16x4(a2[u][0], bd[u], ad0);
-                        ad1 = mfma_16x16x4(a2[u][1], bd[u], ad1);
-                        s1 += a1[u];
-                        s2 += a3[u];
-                    }
-                }
-            }
-            // bias sums: add the 4 k-slots (q) of the wave; lanes q==0 then hold columns 2c, 2c+1
-            if (first) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    s1[t] += __shfl_xor(s1[t], 16, 64); s1[t] += __shfl_xor(s1[t], 32, 64);
-                    s2[t] += __shfl_xor(s2[t], 16, 64); s2[t] += __shfl_xor(s2[t], 32, 64);
-                }
-            }
-            // slot layout (1088 floats): [0,512) dW1 tile [32 j][16 k], [512,1024) dW3^T tile
-            // [32 j][16 o], [1024,1056) db1[32], [1056,1088) db2[32].  Two rounds over 8 slots.
-            float* slot = red + (wave & 7) * 1088;
-            __syncthreads();
-#pragma unroll
-            for (int round = 0; round < 2; ++round) {
-                if ((wave >> 3) == round) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int jl = 2 * (4 * q + r);
-                        if (round == 0) {
-                            slot[(jl + 0) * 16 + c] = ax0[r];
-                            slot[(jl + 1) * 16 + c] = ax1[r];
-                            if (first) {
-                                slot[512 + (jl + 0) * 16 + c] = ad0[r];
-                                slot[512 + (jl + 1) * 16 + c] = ad1[r];
-                            }
-                        } else {
-                            slot[(jl + 0) * 16 + c] += ax0[r];
-                            slot[(jl + 1) * 16 + c] += ax1[r];
-                            if (first) {
-                                slot[512 + (jl + 0) * 16 + c] += ad0[r];
-                                slot[512 + (jl + 1) * 16 + c] += ad1[r];
-                            }
-                        }
-                    }
-                    if (first && q == 0) {
-                        if (round == 0) {
-                            slot[1024 + 2 * c] = s1[0]; slot[1024 + 2 * c + 1] = s1[1];
-                            slot[1056 + 2 * c] = s2[0]; slot[1056 + 2 * c + 1] = s2[1];
-                        } else {
-                            slot[1024 + 2 * c] += s1[0]; slot[1024 + 2 * c + 1] += s1[1];
-                            slot[1056 + 2 * c] += s2[0]; slot[1056 + 2 * c + 1] += s2[1];
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-            // final: threads [0,512) dW1, [512,1024) dW3^T (+ the first 64 of them the biases)
-            {
-                const int e = tid & 511;
-                float v = 0.0f;
-                const int off = (tid < 512) ? e : 512 + e;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) v += red[w * 1088 + off];
-                const int jl = e >> 4, kk = e & 15;
-                if (tid < 512) {
-                    if (k0 + kk < Do) {
-                        const int gi = no.W1 + (j0 + jl) * Do + k0 + kk;
-                        wp.grad[gi] = v;
-                        sq = fmaf(v, v, sq);
-                        if constexpr (FUSE) ppo_adam_elem(wp, sa, gi, v);
-                    }
-                } else if (first && kk < out) {
-                    const int gi = no.W3 + kk * H + j0 + jl;
-                    wp.grad[gi] = v;
-                    sq = fmaf(v, v, sq);
-                    if constexpr (FUSE) ppo_adam_elem(wp, sa, gi, v);
-                }
-                if (first && tid < 64) {
-                    float bsum = 0.0f;
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) bsum += red[w * 1088 + 1024 + tid];
-                    const int gi = (tid < 32) ? no.b1 + j0 + tid : no.b2 + j0 + tid - 32;
-                    wp.grad[gi] = bsum;
-                    sq = fmaf(bsum, bsum, sq);
-                    if constexpr (FUSE) ppo_adam_elem(wp, sa, gi, bsum);
-                }
-            }
-        }
+        ppo_wgrad_aux<H, BIG, FUSE, U, false, true>(md, wp, mbp, sa, no, A2, D1, D2, DOb, (rb - NT2 - NA) * 32, red, sq);
     }
     // ---- block sum of squares (fixed order => deterministic)
     sq = wave_sum(sq);

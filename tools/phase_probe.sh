@@ -4,7 +4,7 @@
 R=$PWD; cd /tmp; export TMPDIR=/tmp
 export FSRL_HIP_LIB=$R/fsrl_amd/libfsrl_hip_probe.so
 for ph in ${PHASES:-0 9 1 4 5 6 7 20 21 22 23}; do
-  rm -rf /tmp/pp; FSRL_DBG_PHASE=$ph rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rm -rf /tmp/pp; FSRL_DBG_PHASE=$ph rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp -o p -- python $R/bench.py --steps 2 --warmup 1 ${BENCH_FLAGS:---no-cpu-baseline} > /dev/null 2>&1
   python - "$ph" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open('/tmp/pp/p_kernel_stats.csv')))
