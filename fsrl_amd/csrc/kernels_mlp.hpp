@@ -536,6 +536,7 @@ __device__ __forceinline__ void ppo_fwd_bwd_body(TileSmem<H, tile_rows(R)>& sm, 
     // ---- prologue: ONE burst of independent loads (W2 slice, obs tile, row data, small
     //      parameters); nothing below waits on a second cold round trip.
     if (FSRL_PROBE(sa, 10)) return;                     // pure launch floor of this kernel
+    if ((FSRL_PROBE(sa, 15) && net != 0) || (FSRL_PROBE(sa, 16) && net == 0)) return;      // the actor's tiles alone | the critics' alone
     FSRL_TS(bp.ts, 0);
     TileStage<H, ROWS> stg;
     stg.issue(P, no, Do, Da, bp.obs_p + grow0 * Do, bp.rd_p + grow0 * FSRL_RD, n_valid, tid);
