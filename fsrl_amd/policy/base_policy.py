@@ -40,6 +40,24 @@ class DeviceBatch:
     logp_old = property(lambda self: self._get("logp_old"))      # [N]
 
 
+class ReplayDeviceBatch:
+    """What the replay agents' `process_fn` returns (SAC-Lag, DDPG-Lag, CVPO): the SAMPLE of the update -- the indices into the
+    HBM-resident store and the noise the reference's process_fn consumed (its `_target_q` forward at s_{t+n}:
+    fsrl/policy/sac_lag.py:136-150, cvpo.py:204-218).  The reference's process_fn also attaches the n-step returns
+    (base_policy.py:453-567); here the float64 n-step targets are formed inside the critics' launch of `learn`, from exactly these
+    indices, so the handle carries no tensor.  `indices is None` = the library's own Philox sample (drawn on the device in learn).
+    `learn(batch)` takes this object."""
+
+    def __init__(self, engine, n: int, indices=None, eps_target=None):
+        self.engine, self.n = engine, int(n)
+        self.indices = None if indices is None else np.ascontiguousarray(indices, np.int64).reshape(-1)
+        self.eps_target = eps_target
+        assert self.indices is None or self.indices.size == self.n
+
+    def __len__(self) -> int:
+        return self.n
+
+
 class BasePolicy(ABC, nn.Module):
     def __init__(self, actor: nn.Module, critics: Union[nn.Module, List[nn.Module]], dist_fn=None,
                  logger: BaseLogger = None, gamma: float = 0.99, max_batchsize: Optional[int] = 99999,
@@ -227,8 +245,10 @@ class BasePolicy(ABC, nn.Module):
     def learn(self, batch, **kwargs: Any):
         """The on-policy agents (PPO-Lag, FOCOPS, CPO, TRPO-Lag): `process_fn(batch, buffer, indices)` returns a DeviceBatch (the
         library's begin call), `learn(that batch, batch_size, repeat)` runs the passes (the library's pass / learn / end calls);
-        `update()` is the two in a row, as fsrl/policy/base_policy.py:332-355.  The replay agents' update() is ONE library call
-        (sampling, n-step targets and the three optimiser steps are fused on the device): their `learn` says so."""
+        `update()` is the two in a row, as fsrl/policy/base_policy.py:332-355.  The replay agents (SAC-Lag, DDPG-Lag, CVPO):
+        `process_fn(batch, buffer, indices)` returns a ReplayDeviceBatch (the sample: indices + the noise process_fn consumed),
+        `learn(that batch)` is the ONE fused library call (n-step targets and the optimiser steps on the device); `update()` is
+        buffer.sample_indices -> process_fn -> learn."""
 
     @abstractmethod
     def update(self, sample_size: int, buffer, **kwargs: Any):

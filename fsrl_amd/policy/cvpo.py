@@ -14,7 +14,7 @@ from torch import nn
 from fsrl_amd import _lib
 from fsrl_amd.data.batch import Batch
 from fsrl_amd.engine import Engine, EngineConfig
-from fsrl_amd.policy.base_policy import BasePolicy
+from fsrl_amd.policy.base_policy import BasePolicy, ReplayDeviceBatch
 from fsrl_amd.policy.sac_lag import SACLagrangian
 
 # row of FSRL_CVPO_NSTATS floats -> the reference's logger keys (tab, key)
@@ -127,10 +127,6 @@ class CVPO(BasePolicy):
         act = logits[0] if (self._deterministic_eval and not self.training) else dist.sample()
         return Batch(logits=logits, act=act, state=hidden, dist=dist)
 
-    def learn(self, batch, **kwargs: Any):
-        raise NotImplementedError("replay agents: update(batch_size, buffer) is ONE library call on the HIP path -- the sample, the n-step "
-                                  "targets (process_fn) and the optimiser steps (learn) are fused on the device; see INTEGRATION.md section 3")
-
     # ------------------------------------------------------------------ update
     def pre_update_fn(self, **kwarg: Any) -> None:
         self.engine.cvpo_pre_update()
@@ -158,20 +154,31 @@ class CVPO(BasePolicy):
             self._log_rows(self.engine.sac_drain())
             self._pending = 0
 
-    def update(self, sample_size: int, buffer, **kwargs: Any):
-        if buffer is None:
-            return {}
-        assert getattr(buffer, "engine", None) is self.engine
+    def process_fn(self, batch=None, buffer=None, indices=None, sample_size: int = 0):
+        """cvpo.py:204-222 (`compute_nstep_returns` over `_target_q`): the sample's indices and ONE actor sample at s_{t+n}; the
+        n-step targets are formed on the device inside learn's critic launch.  -> ReplayDeviceBatch.  indices=None: the library
+        draws `sample_size` rows itself (Philox, in learn); `batch` is ignored (the rows live in the HBM store)."""
+        assert getattr(buffer, "engine", None) is self.engine, \
+            "CVPO.process_fn needs the HipVectorReplayBuffer bound to this policy's engine"
         self.updating = True
-        B, Da, K = int(sample_size), self.engine.cfg.act_dim, self._sample_act_num
-        if self._reference_rng:
-            indices = buffer.sample_indices(B)          # numpy RNG, tianshou rule
-            eps_t = torch.randn(B, Da).numpy()          # _target_q: forward(actor, obs_next).act          (cvpo.py:208)
+        if indices is None:
+            return ReplayDeviceBatch(self.engine, int(sample_size))
+        B, Da = len(indices), self.engine.cfg.act_dim
+        eps_t = torch.randn(B, Da).numpy()              # _target_q: forward(actor, obs_next).act          (cvpo.py:208)
+        return ReplayDeviceBatch(self.engine, B, indices, eps_t)
+
+    def learn(self, batch, **kwargs: Any):
+        """cvpo.py:319-420 on the device = `fsrl_cvpo_update` (critics' step, E-step dual, M-step iterations); `batch` is what
+        process_fn returned."""
+        assert isinstance(batch, ReplayDeviceBatch) and batch.engine is self.engine and len(batch) >= 1, \
+            "learn() takes the ReplayDeviceBatch process_fn() returned (the sampled rows live in HBM)"
+        B, Da, K = len(batch), self.engine.cfg.act_dim, self._sample_act_num
+        if batch.indices is not None:
             torch.randn(B, Da)                          # policy_loss: forward(actor_old).act, unused      (cvpo.py:331)
             eps_k = torch.randn(K, B, Da).numpy()       # old_dist.sample((K, ))                            (cvpo.py:334)
             for _ in range(self._mstep_iter_num):
                 torch.randn(B, Da)                      # M-step: forward(actor).act, unused                (cvpo.py:382)
-            st = self.engine.cvpo_update(B, indices=indices, eps_target=eps_t, eps_particles=eps_k)
+            st = self.engine.cvpo_update(B, indices=batch.indices, eps_target=batch.eps_target, eps_particles=eps_k)
             self._log_rows(st[None])
         else:
             self.engine.cvpo_update(B, seed=self._seed + 1 if self.gradient_steps == 0 else 0, sync=False)
@@ -180,6 +187,16 @@ class CVPO(BasePolicy):
                 self._drain()
         self.gradient_steps += 1
         self._dirty = self._rest_dirty = True      # actor mirror AND critics / targets are behind the device now
+        return {}
+
+    def update(self, sample_size: int, buffer, **kwargs: Any):
+        """base_policy.py:332-355: buffer.sample -> process_fn -> learn -> lr scheduler"""
+        if buffer is None:
+            return {}
+        assert getattr(buffer, "engine", None) is self.engine
+        B = int(sample_size)
+        indices = buffer.sample_indices(B) if self._reference_rng else None      # numpy RNG, tianshou rule | device RNG
+        result = self.learn(self.process_fn(None, buffer, indices, sample_size=B))
         self._step_lr_scheduler()
         self.updating = False
-        return {}
+        return result

@@ -12,6 +12,7 @@ from torch import nn
 from fsrl_amd import _lib
 from fsrl_amd.data.batch import Batch
 from fsrl_amd.engine import Engine, EngineConfig
+from fsrl_amd.policy.base_policy import ReplayDeviceBatch
 from fsrl_amd.policy.lagrangian_base import LagrangianPolicy
 from fsrl_amd.policy.sac_lag import SAC_KEYS, SACLagrangian
 
@@ -97,10 +98,6 @@ class DDPGLagrangian(LagrangianPolicy):
             return act
         return act + self._noise(act.shape) if isinstance(act, np.ndarray) else act
 
-    def learn(self, batch, **kwargs: Any):
-        raise NotImplementedError("replay agents: update(batch_size, buffer) is ONE library call on the HIP path -- the sample, the n-step "
-                                  "targets (process_fn) and the optimiser steps (learn) are fused on the device; see INTEGRATION.md section 3")
-
     def _log_rows(self, rows) -> None:
         table = getattr(self.logger, "store_rows", None)         # fsrl_amd loggers take the drained rows at once
         if table is not None and len(rows):
@@ -125,16 +122,27 @@ class DDPGLagrangian(LagrangianPolicy):
         self._drain()
         super().post_update_fn(**kwarg)
 
-    def update(self, sample_size: int, buffer, **kwargs: Any):
-        if buffer is None:
-            return {}
-        assert getattr(buffer, "engine", None) is self.engine
+    def process_fn(self, batch=None, buffer=None, indices=None, sample_size: int = 0):
+        """ddpg_lag.py:125-140 (`compute_nstep_returns` over `_target_q`: the target actor is deterministic, no noise is drawn):
+        the sample's indices; the n-step targets are formed on the device inside learn's critic launch.  -> ReplayDeviceBatch.
+        indices=None: the library draws `sample_size` rows itself (Philox, in learn); `batch` is ignored (the rows live in HBM)."""
+        assert getattr(buffer, "engine", None) is self.engine, \
+            "DDPGLagrangian.process_fn needs the HipVectorReplayBuffer bound to this policy's engine"
         self.updating = True
-        B = int(sample_size)
+        if indices is None:
+            return ReplayDeviceBatch(self.engine, int(sample_size))
+        return ReplayDeviceBatch(self.engine, len(indices), indices)
+
+    def learn(self, batch, **kwargs: Any):
+        """ddpg_lag.py:178-223 on the device = `fsrl_sac_update` of a deterministic-actor context; `batch` is what process_fn
+        returned."""
+        assert isinstance(batch, ReplayDeviceBatch) and batch.engine is self.engine and len(batch) >= 1, \
+            "learn() takes the ReplayDeviceBatch process_fn() returned (the sampled rows live in HBM)"
+        B = len(batch)
         lags, rescaling = self.lagrangians_and_rescaling() if self.use_lagrangian else ([], 1.0)
-        if self._reference_rng:                       # buffer.sample through numpy's RNG, like the reference
+        if batch.indices is not None:
             zero = np.zeros((B, self.engine.cfg.act_dim), np.float32)
-            st = self.engine.sac_update(B, lags, rescaling, indices=buffer.sample_indices(B), eps_target=zero, eps_pi=zero)
+            st = self.engine.sac_update(B, lags, rescaling, indices=batch.indices, eps_target=zero, eps_pi=zero)
             self._log_rows(st[None])
         else:
             self.engine.sac_update(B, lags, rescaling, seed=self._seed + 1 if self.gradient_steps == 0 else 0, sync=False)
@@ -143,6 +151,16 @@ class DDPGLagrangian(LagrangianPolicy):
                 self._drain()
         self.gradient_steps += 1
         self._dirty = self._rest_dirty = True      # actor mirror AND critics / targets are behind the device now
+        return {}
+
+    def update(self, sample_size: int, buffer, **kwargs: Any):
+        """base_policy.py:332-355: buffer.sample -> process_fn -> learn -> lr scheduler"""
+        if buffer is None:
+            return {}
+        assert getattr(buffer, "engine", None) is self.engine
+        B = int(sample_size)
+        indices = buffer.sample_indices(B) if self._reference_rng else None      # numpy RNG, like the reference | device RNG
+        result = self.learn(self.process_fn(None, buffer, indices, sample_size=B))
         self._step_lr_scheduler()
         self.updating = False
-        return {}
+        return result

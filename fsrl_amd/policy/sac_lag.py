@@ -14,6 +14,7 @@ from torch.distributions import Independent, Normal
 from fsrl_amd import _lib
 from fsrl_amd.data.batch import Batch
 from fsrl_amd.engine import Engine, EngineConfig
+from fsrl_amd.policy.base_policy import ReplayDeviceBatch
 from fsrl_amd.policy.lagrangian_base import LagrangianPolicy
 
 SAC_KEYS = ("loss/rescaling", "loss/lagrangian", "loss/actor_safety", "loss/alpha_loss", "loss/alpha_value",
@@ -165,22 +166,30 @@ class SACLagrangian(LagrangianPolicy):
         self._drain()
         super().post_update_fn(**kwarg)
 
-    def learn(self, batch, **kwargs: Any):
-        raise NotImplementedError("replay agents: update(batch_size, buffer) is ONE library call on the HIP path -- the sample, the n-step "
-                                  "targets (process_fn) and the optimiser steps (learn) are fused on the device; see INTEGRATION.md section 3")
-
-    def update(self, sample_size: int, buffer, **kwargs: Any):
-        if buffer is None:
-            return {}
-        assert getattr(buffer, "engine", None) is self.engine
+    def process_fn(self, batch=None, buffer=None, indices=None, sample_size: int = 0):
+        """sac_lag.py:136-150 (`compute_nstep_returns` over `_target_q`): what the reference's process_fn consumes is the sample's
+        indices and ONE rsample at s_{t+n}; the n-step targets themselves are formed on the device inside learn's critic launch.
+        -> ReplayDeviceBatch.  indices=None: the library draws `sample_size` rows itself (Philox, in learn); `batch` is accepted
+        for signature parity and ignored (the rows live in the HBM store)."""
+        assert getattr(buffer, "engine", None) is self.engine, \
+            "SACLagrangian.process_fn needs the HipVectorReplayBuffer bound to this policy's engine"
         self.updating = True
-        B, Da = int(sample_size), self.engine.cfg.act_dim
+        if indices is None:
+            return ReplayDeviceBatch(self.engine, int(sample_size))
+        B, Da = len(indices), self.engine.cfg.act_dim
+        eps_t = torch.normal(torch.zeros(B, Da), torch.ones(B, Da)).numpy()       # rsample at s_{t+n}
+        return ReplayDeviceBatch(self.engine, B, indices, eps_t)
+
+    def learn(self, batch, **kwargs: Any):
+        """sac_lag.py:185-269 on the device = `fsrl_sac_update` (critics' step, Polyak targets, actor step, alpha step);
+        `batch` is what process_fn returned."""
+        assert isinstance(batch, ReplayDeviceBatch) and batch.engine is self.engine and len(batch) >= 1, \
+            "learn() takes the ReplayDeviceBatch process_fn() returned (the sampled rows live in HBM)"
+        B, Da = len(batch), self.engine.cfg.act_dim
         lags, rescaling = self.lagrangians_and_rescaling() if self.use_lagrangian else ([], 1.0)
-        if self._reference_rng:
-            indices = buffer.sample_indices(B)                               # numpy RNG, tianshou rule
-            eps_t = torch.normal(torch.zeros(B, Da), torch.ones(B, Da)).numpy()   # rsample at s_{t+n}
+        if batch.indices is not None:
             eps_p = torch.normal(torch.zeros(B, Da), torch.ones(B, Da)).numpy()   # rsample at s_t
-            st = self.engine.sac_update(B, lags, rescaling, indices=indices, eps_target=eps_t, eps_pi=eps_p)
+            st = self.engine.sac_update(B, lags, rescaling, indices=batch.indices, eps_target=batch.eps_target, eps_pi=eps_p)
             self._log_rows(st[None])
         else:
             seed = self._seed + 1 if self.gradient_steps == 0 else 0     # key the Philox stream once
@@ -190,6 +199,16 @@ class SACLagrangian(LagrangianPolicy):
                 self._drain()
         self.gradient_steps += 1
         self._dirty = self._rest_dirty = True      # actor mirror AND critics / targets are behind the device now
+        return {}
+
+    def update(self, sample_size: int, buffer, **kwargs: Any):
+        """base_policy.py:332-355: buffer.sample -> process_fn -> learn -> lr scheduler"""
+        if buffer is None:
+            return {}
+        assert getattr(buffer, "engine", None) is self.engine
+        B = int(sample_size)
+        indices = buffer.sample_indices(B) if self._reference_rng else None      # numpy RNG, tianshou rule | device RNG
+        result = self.learn(self.process_fn(None, buffer, indices, sample_size=B))
         self._step_lr_scheduler()
         self.updating = False
-        return {}
+        return result

@@ -695,3 +695,73 @@ def test_process_fn_then_learn_is_update(kind):
     with pytest.raises(AssertionError):
         b.learn(batch, **kw)                                              # consumed: a second learn needs a new process_fn
     a.engine.close(); b.engine.close()
+
+
+@pytest.mark.parametrize("ref_rng", [True, False])
+@pytest.mark.parametrize("kind", ["sac", "ddpg", "cvpo"])
+def test_replay_process_fn_then_learn_is_update(kind, ref_rng):
+    """fsrl/policy/base_policy.py:332-355 for the replay agents: update() = buffer.sample -> process_fn -> learn.  process_fn
+    returns a ReplayDeviceBatch (the sample: indices + the noise the reference's `_target_q` forward drew; the rows stay in the HBM
+    store), learn takes it back and runs the fused update; the calls made by hand leave exactly the parameters update() leaves."""
+    from torch.distributions import Independent, Normal
+    from fsrl_amd.data import Batch, HipVectorReplayBuffer
+    from fsrl_amd.env import Box, SyntheticSafetyVectorEnv
+    from fsrl_amd.policy import CVPO, DDPGLagrangian, SACLagrangian
+    from fsrl_amd.policy.base_policy import ReplayDeviceBatch
+    from fsrl_amd.utils.net import Actor, ActorProb, Critic, DoubleCritic, Net, SingleCritic
+    from test_gpu_loop import _Cap, _rollout
+    Do, Da, h, E, T, B = 6, 3, (64, 64), 4, 50, 64
+
+    def make():
+        torch.manual_seed(3)
+        sp = dict(observation_space=Box(-np.inf, np.inf, (Do, )), action_space=Box(-1, 1, (Da, )), device=0, env_num=E,
+                  cost_limit=10.0, buffer_size=E * T * 2, reference_rng=ref_rng, logger=_Cap())
+        if kind == "sac":
+            actor = ActorProb(Net((Do, ), hidden_sizes=h), (Da, ), conditioned_sigma=True, unbounded=True)
+            critics = [DoubleCritic(Net((Do, ), (Da, ), hidden_sizes=h, concat=True), Net((Do, ), (Da, ), hidden_sizes=h, concat=True))
+                       for _ in range(2)]
+            la = torch.zeros(1, requires_grad=True)
+            pol = SACLagrangian(actor, critics, torch.optim.Adam(actor.parameters(), lr=1e-3),
+                                torch.optim.Adam(torch.nn.ModuleList(critics).parameters(), lr=1e-3),
+                                alpha=(-3.0, la, torch.optim.Adam([la], lr=1e-3)), n_step=2, **sp)
+        elif kind == "ddpg":
+            actor = Actor(Net((Do, ), hidden_sizes=h), (Da, ))
+            critics = [Critic(Net((Do, ), (Da, ), hidden_sizes=h, concat=True)) for _ in range(2)]
+            pol = DDPGLagrangian(actor, critics, torch.optim.Adam(actor.parameters(), lr=1e-3),
+                                 torch.optim.Adam(torch.nn.ModuleList(critics).parameters(), lr=1e-3), n_step=2, **sp)
+        else:
+            actor = ActorProb(Net((Do, ), hidden_sizes=h), (Da, ), conditioned_sigma=True, unbounded=False)
+            critics = [SingleCritic(Net((Do, ), (Da, ), hidden_sizes=h, concat=True)) for _ in range(2)]
+            pol = CVPO(actor, critics, torch.optim.Adam(actor.parameters(), lr=1e-3),
+                       torch.optim.Adam(torch.nn.ModuleList(critics).parameters(), lr=1e-3),
+                       dist_fn=lambda *l: Independent(Normal(*l), 1), max_episode_steps=T, **sp)
+        pol.train()
+        env = SyntheticSafetyVectorEnv(env_num=E, obs_dim=Do, act_dim=Da, episode_len=T, seed=5)
+        buf = HipVectorReplayBuffer(pol.engine, E * T * 2, E)
+        torch.manual_seed(11); np.random.seed(11)
+        st = _rollout(pol, env, buf, noise=(kind == "ddpg"))
+        pol.pre_update_fn(stats_train={"cost": st["cost"]})
+        torch.manual_seed(12); np.random.seed(12)
+        return pol, buf
+    a, buf_a = make()
+    for _ in range(3):
+        a.update(B, buf_a)
+    a.post_update_fn(stats_train={"cost": 0.0})
+    want = [a.engine.sac_get_params(w)[0].copy() for w in (0, 1, 2)]
+    b, buf_b = make()
+    for _ in range(3):
+        indices = buf_b.sample_indices(B) if ref_rng else None                 # BasePolicy.update's buffer.sample
+        batch = b.process_fn(None, buf_b, indices, sample_size=B)
+        assert isinstance(batch, ReplayDeviceBatch) and len(batch) == B and b.updating
+        assert (batch.indices is None) == (not ref_rng)
+        b.learn(batch)
+        b._step_lr_scheduler(); b.updating = False
+    b.post_update_fn(stats_train={"cost": 0.0})
+    assert b.gradient_steps == a.gradient_steps == 3
+    for w, t in zip((0, 1, 2), want):
+        got = b.engine.sac_get_params(w)[0]
+        assert np.isfinite(got).all() and np.array_equal(got, t), (kind, ref_rng, w)
+    assert not np.array_equal(want[0], make()[0].engine.sac_get_params(0)[0])  # the updates moved the actor
+    with pytest.raises(AssertionError):
+        b.learn(Batch(obs=np.zeros((1, Do), np.float32)))                      # not a ReplayDeviceBatch
+    a.engine.close(); b.engine.close()
