@@ -490,6 +490,11 @@ def gen_ppo_full():
     gen_ppo_full_case("c5rank", 32, [[250, 250, -125]] * 32, theta0_from="ppo_c2full.npz")
 
 
+def gen_ppo_full_c0():
+    # configs[0] at its full size: 4 envs x 5000 rows (twenty episodes of 250 each), 128x128 -- the reference's own CPU-runnable case
+    gen_ppo_full_case("c0full", 4, [[250] * 20] * 4, hidden=(128, 128))
+
+
 def gen_ppo_full_klstop():
     # configs[1] with the reference's default target_kl = 0.02 (ppo_lag_agent.py:95) and a learning rate at which the pass-mean
     # KL crosses 1.5 x target_kl: the early stop (ppo_lag.py:251-255) fires at full size
@@ -511,4 +516,4 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["gae", "nstep", "pid", "ppo", "manifest"]
     for w in which:
         {"gae": gen_gae, "nstep": gen_nstep, "pid": gen_pid, "ppo": gen_ppo, "recompute": gen_ppo_recompute, "bigbatch": gen_ppo_bigbatch, "options": gen_ppo_options,
-         "widths": gen_ppo_widths, "depths": gen_ppo_depths, "full": gen_ppo_full, "full_klstop": gen_ppo_full_klstop, "manifest": gen_manifest}[w]()
+         "widths": gen_ppo_widths, "depths": gen_ppo_depths, "full": gen_ppo_full, "full_c0": gen_ppo_full_c0, "full_klstop": gen_ppo_full_klstop, "manifest": gen_manifest}[w]()

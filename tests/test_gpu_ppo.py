@@ -326,13 +326,15 @@ def test_full_size_update_vs_oracle(repeat, hid, env_num):
 
 # observed on MI355X (deterministic kernels; three boxes, profiles/r05_fullsize_bars.txt) -> asserted at 3x
 FULL_BARS = {"c2full": dict(tight_steps=50, pass1_stat=1.6e-2, theta_max=8.4e-3, theta_mean=6.8e-5),       # 53 steps / 5.32e-3 / 2.80e-3 / 2.24e-5
+             "c0full": dict(tight_steps=78, pass1_stat=5.7e-5, theta_max=2.9e-4, theta_mean=2.0e-7),       # all 78 / 1.88e-5 / 9.51e-5 / 6.56e-8 (r6)
              "c5rank": dict(tight_steps=78, pass1_stat=4.3e-5, theta_max=1.1e-6, theta_mean=1.6e-8)}       # all 78 / 1.42e-5 / 3.35e-7 / 5.33e-9
 
 
-@pytest.mark.parametrize("name", ["c2full", "c5rank"])
+@pytest.mark.parametrize("name", ["c2full", "c5rank", "c0full"])
 def test_full_size_update_vs_reference(name):
-    """The headline workload pinned to the reference ITSELF (not only to the oracle): BASELINE configs[1] (20 envs x 1000 rows)
-    and one rank of configs[4] (32 envs x 625 rows, unfinished tails), obs 8 / act 2 / 256x256 / batch 256 / 4 passes / grad
+    """The headline workload pinned to the reference ITSELF (not only to the oracle): BASELINE configs[1] (20 envs x 1000 rows),
+    one rank of configs[4] (32 envs x 625 rows, unfinished tails) and configs[0] at its full size (c0full: 4 envs x 5000 rows,
+    128x128 -- the reference's CPU-runnable case), obs 8 / act 2 / 256x256 / batch 256 / 4 passes / grad
     clip 0.5 (ppol_cfg.py:21), recorded from the unmodified PPOLagrangian.update (ppo_lag.py:214-257) by
     tests/golden/gen_golden.py full.  process_fn at 5e-6 of scale; the leading optimiser steps at the fixture tolerance
     (2e-5; FULL_BARS: how many); the whole FIRST pass and theta after it at 3x the device's measured distance; passes 2-4 under the float64-yardstick rule of
@@ -375,7 +377,7 @@ def test_full_size_update_vs_reference(name):
     assert np.array_equal(outs[4][0][:78], s1)         # the first pass of the 4-pass update is the 1-pass update
     # passes 2-4: the float64 run of the same algorithm is the yardstick for both fp32 trajectories
     torch.set_num_threads(4)
-    o64 = PPOLagOracle(PPOLagConfig(obs_dim=8, act_dim=2, hidden=(256, 256), max_grad_norm=0.5, target_kl=1e9), dtype=torch.float64)
+    o64 = PPOLagOracle(PPOLagConfig(obs_dim=8, act_dim=2, hidden=tuple(cfg["hidden"]), max_grad_norm=0.5, target_kl=1e9), dtype=torch.float64)
     o64.set_params(g["theta0"])
     _, xstats, _ = o64.update(OnPolicyData(**rollout_env_major(steps, cfg["env_num"])), lag, _rescale(lag), 256, 4, perms=g["perms"])
     pm = lambda a: a.reshape(4, 78, 11).mean(1)  # noqa: E731

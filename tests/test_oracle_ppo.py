@@ -75,17 +75,18 @@ def test_two_updates_under_an_lr_schedule():
     assert g["lrs"][1] == 0.5 * g["lrs"][0] and g["lrs"][2] == 0.25 * g["lrs"][0]
 
 
-@pytest.mark.parametrize("name", ["c2full", "c5rank"])
+@pytest.mark.parametrize("name", ["c2full", "c5rank", "c0full"])
 def test_full_size_update_vs_reference(name):
     """The headline workload itself (BASELINE configs[1] / one rank of configs[4]: obs 8, act 2, 256x256, N = 20 000, batch 256,
-    4 passes = 312 steps, max_grad_norm 0.5 as in ppol_cfg.py:21) recorded from the unmodified reference (ppo_lag.py:214-257):
+    4 passes = 312 steps, max_grad_norm 0.5 as in ppol_cfg.py:21; c0full: configs[0] at its full size, 4 envs x 5000 rows, 128x128)
+    recorded from the unmodified reference (ppo_lag.py:214-257):
     process_fn, every logged statistic of the first pass at the fixture tolerances, theta after pass 1 and after pass 4."""
     from oracle.ppo_lag import OnPolicyData, PPOLagConfig
     torch.set_num_threads(4)
     cfg, g, steps = ppo_full_case(name)
     d = rollout_env_major(steps, cfg["env_num"])
     assert len(d["obs"]) == int(g["n_rows"]) == 20000
-    ocfg = PPOLagConfig(obs_dim=8, act_dim=2, hidden=(256, 256), max_grad_norm=0.5, target_kl=1e9)
+    ocfg = PPOLagConfig(obs_dim=8, act_dim=2, hidden=tuple(cfg["hidden"]), max_grad_norm=0.5, target_kl=1e9)
     o = PPOLagOracle(ocfg)
     o.set_params(g["theta0"])
     lag = g["lagrangian"]
