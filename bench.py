@@ -322,13 +322,17 @@ def end_to_end(local_rank, seed, seconds=6.0, device_actor=False, workers=0, bus
                                   and (col.native_loop is True or not col.split_phase))
                               else "interpreted, one library call per vector step" if device_actor else "interpreted, host actor"),
            "env_bound_env_steps_per_s": env_bound(envs, procs, busy_us, usable_cpus()),
-           "actor": "device (fsrl_collect_step: one call per vector step, library RNG)" if device_actor else "host mirror (torch CPU, torch RNG)",
+           "actor": "device (fsrl_collect_step: one call per vector step, library RNG; served by a resident workgroup through a doorbell in pinned memory: one kernel launch per collect)" if device_actor else "host mirror (torch CPU, torch RNG)",
            "collects": collects, "env_steps_per_s": col.collect_step / dt,
            "frac_of_env_bound": (col.collect_step / dt / env_bound(envs, procs, busy_us, usable_cpus())
                                  if busy_us > 0 else None),
            "collector_only_env_steps_per_s": col.collect_step / col.collect_time,
            "update_ms_per_collect": update_s / collects * 1e3,
            "policy_updates_per_s": collects / dt}
+    if device_actor:        # r6: the actor as a resident workgroup (fsrl_actor_set_resident): launches vs calls served through the doorbell
+        st = agent.policy.engine.actor_resident_stats()
+        out["actor_resident"] = {"kernel_launches": st["launches"], "calls_served": st["requests"],
+                                 "per_collect": round(st["launches"] / max(collects, 1), 2)}
     agent.policy.engine.close()
     if hasattr(env, "close"):
         env.close()

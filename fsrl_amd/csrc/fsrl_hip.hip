@@ -174,6 +174,13 @@ struct fsrl_ctx {
     int actor_k = 0; size_t actor_ob = 0, actor_mb = 0;  // geometry of the actor evaluation in flight
     unsigned* h_done = nullptr; int done_cap = 0;        // pinned per-block completion words of that evaluation
     unsigned actor_seq = 0; int actor_blocks = 0;
+    // r6: the collector's actor as a RESIDENT workgroup (actor_resident_kernel: one launch per collect instead of one per vector step)
+    bool pa_on = true;              // fsrl_actor_set_resident
+    bool pa_live = false;           // a kernel of generation pa_gen was launched and not told to end
+    bool pa_req = false;            // the evaluation in flight went to the resident kernel (actor_eval_finish)
+    unsigned pa_gen = 0, pa_seq = 0; int pa_cap = 0, pa_blocks = 1; double pa_idle_us = 2000.0;
+    void* h_pa = nullptr;           // pinned: [bell 8 B | pad | done[4] at 16 | state[4] at 32 | pad to 64 B | obs cap x Do | mu cap x Da | sigma_param]
+    long long pa_launches = 0, pa_requests = 0;          // fsrl_actor_resident_stats
     // timing-probe switches: always 0 / false in the shipped library; a -DFSRL_PROBES build reads them ONCE, at
     // fsrl_ctx_create, from FSRL_DBG_PHASE / FSRL_TILE16 / FSRL_WGRAD_SKIP / FSRL_NO_SPIN (tools/phase_probe.sh)
     int probe_phase = 0, probe_wgrad_skip = 0;
@@ -222,6 +229,12 @@ static int pass_verdict(fsrl_ctx* c, int32_t* stopped_out);
 // copies before whatever the compute stream runs next.  Off-policy trainers call update() many times between collects;
 // the join (an event record + wait, ~6 us of GPU idle per update) is skipped while the store has not changed.
 static int flush_stage(fsrl_ctx* c);
+// Every entry point that may enqueue work on the compute stream tells the resident actor (if one is live) to end first: the work is
+// then behind a kernel that is on its way out, and the next actor call launches a new one BEHIND that work -- stream order as with
+// one launch per call.  The actor / collector entry points themselves keep it (plain hipSetDevice).
+static void pactor_release(fsrl_ctx* c);
+#define ENTER_DEV(c) do { HIPCHK(hipSetDevice((c)->device)); pactor_release(c); } while (0)
+
 static int join_store(fsrl_ctx* c) {
     if (c->joined_version == c->store_version) return 0;
     int rc = flush_stage(c);
@@ -414,6 +427,7 @@ static void fill_mirrors(const ModelDesc& md, std::vector<float>& v) {
 extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
+    pactor_release(c);
     (void)hipDeviceSynchronize();
     if (c->group) group_detach(c);          // a member destroyed before its group: take its own stream back
     comm_free(c);
@@ -423,6 +437,7 @@ extern "C" int fsrl_ctx_destroy(fsrl_ctx* c) {
     lay_free(c);
     if (c->h_actor) (void)hipHostFree(c->h_actor);
     if (c->h_done) (void)hipHostFree(c->h_done);
+    if (c->h_pa) (void)hipHostFree(c->h_pa);
     if (c->mbstat) (void)hipFree(c->mbstat);
     if (c->d_rms) (void)hipFree(c->d_rms);
     if (c->ret64) (void)hipFree(c->ret64);
@@ -580,7 +595,7 @@ extern "C" int fsrl_ctx_create(int device_id, const fsrl_config* cfg, fsrl_ctx**
 
 extern "C" int fsrl_sync(fsrl_ctx* c) {
     CHECK_ARG(c, "null ctx");
-    HIPCHK(hipSetDevice(c->device));
+    ENTER_DEV(c);
     HIPCHK(hipStreamSynchronize(c->side));
     HIPCHK(hipStreamSynchronize(c->compute));
     return 0;
@@ -591,7 +606,7 @@ extern "C" int64_t fsrl_param_count(const fsrl_ctx* c) { return c ? c->n_api : 0
 
 static int copy_flat(fsrl_ctx* c, float* dev, float* host_out, const float* host_in, int64_t n) {
     CHECK_ARG(n == c->n_api, "expected %lld parameters, got %lld", (long long)c->n_api, (long long)n);
-    HIPCHK(hipSetDevice(c->device));
+    ENTER_DEV(c);
     std::vector<float> tmp((size_t)c->n_dev, 0.0f);
     if (host_in) {                              // only P is ever written from the host
         for (const TensorMap& t : c->tmap) t.to_dev(tmp.data(), host_in);
@@ -622,7 +637,7 @@ extern "C" int fsrl_grads_get(fsrl_ctx* c, float* flat, int64_t n) {
 }
 extern "C" int fsrl_optim_reset(fsrl_ctx* c) {
     CHECK_ARG(c, "null ctx");
-    HIPCHK(hipSetDevice(c->device));
+    ENTER_DEV(c);
     HIPCHK(hipStreamSynchronize(c->compute));
     HIPCHK(hipMemsetAsync(c->M, 0, (size_t)c->n_dev * 4, c->compute));
     HIPCHK(hipMemsetAsync(c->V, 0, (size_t)c->n_dev * 4, c->compute));
@@ -644,7 +659,7 @@ extern "C" int fsrl_state_snapshot(fsrl_ctx* c) {
     // replay agents keep their training state elsewhere (SacState: actor / Q / target stores, log alpha, three Adam states): a
     // snapshot of c->P / M / V would restore nothing of it
     CHECK_ARG(!ctx_is_replay(c), "fsrl_state_snapshot covers on-policy contexts (PPO-Lag, FOCOPS, CPO, TRPO-Lag) only");
-    HIPCHK(hipSetDevice(c->device));
+    ENTER_DEV(c);
     if (!c->snap) {
         HIPCHK(hipMalloc(&c->snap, ((size_t)c->n_alloc + 2 * (size_t)c->n_dev) * 4 + 3 * FSRL_MAX_CRITICS * sizeof(double)));
     }
@@ -665,7 +680,7 @@ extern "C" int fsrl_state_restore(fsrl_ctx* c) {
     CHECK_ARG(c, "null ctx");
     CHECK_ARG(!c->in_update, "fsrl_state_restore inside an update");
     if (!c->snap_valid) return fail(FSRL_ESTATE, "fsrl_state_restore before fsrl_state_snapshot");
-    HIPCHK(hipSetDevice(c->device));
+    ENTER_DEV(c);
     hipStream_t st = c->compute;
     c->theta_version += 1;
     HIPCHK(hipMemcpyAsync(c->P, c->snap, (size_t)c->n_alloc * 4, hipMemcpyDeviceToDevice, st));
@@ -711,7 +726,7 @@ extern "C" int fsrl_store_push(fsrl_ctx* c, const int32_t* env_ids, int32_t k, c
                                int32_t* ep_len_out, int64_t* ep_idx_out) {
     CHECK_ARG(c && env_ids && obs && act && rew && terminated && truncated && obs_next, "null argument");
     CHECK_ARG(k >= 0 && k <= c->active_envs, "k=%d rows but %d sub-buffers", k, c->active_envs);
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipSetDevice(c->device));      // keeps a resident actor alive (ENTER_DEV would end it)
     c->store_version += 1;
     const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim;
     const size_t rec = stage_rec_bytes(Do, Da);
@@ -766,7 +781,7 @@ extern "C" int fsrl_store_push(fsrl_ctx* c, const int32_t* env_ids, int32_t k, c
 
 extern "C" int fsrl_store_reset(fsrl_ctx* c, int keep_statistics) {
     CHECK_ARG(c, "null ctx");
-    HIPCHK(hipSetDevice(c->device));
+    ENTER_DEV(c);
     int rc = flush_stage(c);   // rows already staged still land (then become unreachable)
     if (rc) return rc;
     // tianshou-0.5 ReplayBuffer.reset(keep_statistics): index / size / last_index go back to zero; the running episode's
@@ -854,7 +869,7 @@ extern "C" int fsrl_store_read(fsrl_ctx* c, const int64_t* indices, int64_t n, f
     CHECK_ARG(c && (indices || n == 0), "null argument");
     CHECK_ARG(n >= 0 && n <= c->maxsize, "bad row count");
     if (n == 0) return 0;
-    HIPCHK(hipSetDevice(c->device));
+    ENTER_DEV(c);
     int rc = join_store(c);
     if (rc) return rc;
     const size_t N = (size_t)n, Do = (size_t)c->cfg.obs_dim, Da = (size_t)c->cfg.act_dim;
@@ -933,8 +948,131 @@ static int sac_actor_launch(fsrl_ctx* c, const float* h_obs, float* h_raw, int k
 static void sac_actor_finish(fsrl_ctx* c, const float* h_raw, int k, float* mu_out, float* sigma_out);
 static bool sac_squashes(fsrl_ctx* c);
 
+// ---- the resident actor (actor_resident_kernel, kernels_mlp.hpp).  Protocol, host side:
+//   post:    [wait until every workgroup of every earlier generation has reported its end] -> launch generation g if none is live ->
+//            write the k observations -> ring the doorbell (k << 32 | seq, one release store);
+//   finish:  spin on `done[b] == seq` of the request's tiles; if a `state[b] == g` shows up instead (a workgroup ended by its idle
+//            timeout just before the doorbell), tell the rest to end, wait for them, launch generation g + 1 and ring again;
+//   release: doorbell = EXIT; nothing is waited for (the stream orders what follows behind the kernel).
+// A doorbell is only ever rung when generation pa_gen is the one kernel that can hear it.
+struct PaLayout { unsigned long long* bell; unsigned* done; unsigned* state; float* obs; float* mu; float* sp; };
+static PaLayout pa_layout(const fsrl_ctx* c) {
+    char* b = (char*)c->h_pa;
+    PaLayout l;
+    l.bell = (unsigned long long*)b; l.done = (unsigned*)(b + 16); l.state = (unsigned*)(b + 32);
+    l.obs = (float*)(b + 64);
+    l.mu = l.obs + (size_t)c->pa_cap * c->cfg.obs_dim;
+    l.sp = l.mu + (size_t)c->pa_cap * c->cfg.act_dim;
+    return l;
+}
+
+static bool pactor_ok(const fsrl_ctx* c, int k) {
+    const int blocks = std::min(PACTOR_BLOCKS, std::max(1, (c->cfg.env_num + 15) / 16));
+    return c->pa_on && !c->no_spin && !c->lay && !c->group && c->cfg.algo != FSRL_ALGO_SAC_LAG && k >= 1 && k <= 16 * blocks;
+}
+
+static void pactor_release(fsrl_ctx* c) {
+    if (!c->pa_live) return;
+    const PaLayout l = pa_layout(c);
+    c->pa_seq += 1;
+    __atomic_store_n(l.bell, ((unsigned long long)PACTOR_EXIT << 32) | c->pa_seq, __ATOMIC_RELEASE);
+    c->pa_live = false;
+}
+
+// how many workgroups of generation pa_gen have ended
+static int pactor_ended_count(const fsrl_ctx* c) {
+    const PaLayout l = pa_layout(c);
+    int n = 0;
+    for (int b = 0; b < c->pa_blocks; ++b) n += __atomic_load_n(l.state + b, __ATOMIC_ACQUIRE) == c->pa_gen;
+    return n;
+}
+
+// generation pa_gen has ended (true at once if none was ever launched); waits for a kernel that was told to end, never for a live one
+static bool pactor_ended(fsrl_ctx* c, bool wait) {
+    if (c->pa_gen == 0) return true;
+    for (long spins = 0;; ++spins) {
+        if (pactor_ended_count(c) == c->pa_blocks) return true;
+        if (!wait) return false;
+        if (spins > 4000000) { (void)hipStreamSynchronize(c->compute); return pactor_ended_count(c) == c->pa_blocks; }
+        __builtin_ia32_pause();
+    }
+}
+
+static int pactor_launch(fsrl_ctx* c, unsigned last_seq) {
+    const PaLayout l = pa_layout(c);
+    PActorArgs a{};
+    a.obs = l.obs; a.mu_out = l.mu; a.sigma_param_out = l.sp; a.bell = l.bell; a.done = l.done; a.state = l.state;
+    c->pa_gen += 1;
+    if (c->pa_gen == 0) c->pa_gen = 1;
+    a.gen = c->pa_gen; a.last_seq = last_seq; a.max_action = c->cfg.max_action;
+    a.timeout_ticks = (unsigned long long)(c->pa_idle_us * 100.0);            // wall_clock64: 100 MHz
+    c->pa_blocks = std::min(PACTOR_BLOCKS, std::max(1, (c->cfg.env_num + 15) / 16));
+    const int rc = dispatch_H(c->cfg.hidden, [&](auto hc) {
+        constexpr int H = decltype(hc)::value;
+        hipLaunchKernelGGL(actor_resident_kernel<H>, dim3(c->pa_blocks), dim3(4 * H), 0, c->compute, c->P, c->md, a);
+        HIPCHK(hipGetLastError());
+        return 0;
+    });
+    if (rc) return rc;
+    c->pa_live = true; c->pa_launches += 1;
+    return 0;
+}
+
+// ring the doorbell for the k rows already in place (launching a kernel first if none can hear it)
+static int pactor_ring(fsrl_ctx* c, int k) {
+    const PaLayout l = pa_layout(c);
+    if (c->pa_live && pactor_ended_count(c) > 0) pactor_release(c);          // (some of) it ended by its idle timeout: the rest follows
+    c->pa_seq += 1;
+    if (!c->pa_live) {
+        if (!pactor_ended(c, true)) return fail(FSRL_EHIP, "the resident actor did not end");
+        const int rc = pactor_launch(c, c->pa_seq - 1);
+        if (rc) return rc;
+    }
+    __atomic_store_n(l.bell, ((unsigned long long)(unsigned)k << 32) | c->pa_seq, __ATOMIC_RELEASE);
+    return 0;
+}
+
+static int pactor_post(fsrl_ctx* c, const float* obs, int k) {
+    const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim;
+    if (!c->h_pa) {
+        c->pa_cap = 16 * PACTOR_BLOCKS;
+        const size_t bytes = 64 + ((size_t)c->pa_cap * (Do + Da) + FSRL_MAX_ACT) * 4;
+        HIPCHK(hipHostMalloc(&c->h_pa, bytes));
+        memset(c->h_pa, 0, bytes);
+    }
+    memcpy(pa_layout(c).obs, obs, (size_t)k * Do * 4);
+    const int rc = pactor_ring(c, k);
+    if (rc) return rc;
+    c->actor_k = k; c->pa_req = true; c->pa_requests += 1;
+    return 0;
+}
+
+static int pactor_wait(fsrl_ctx* c) {
+    const PaLayout l = pa_layout(c);
+    const int tiles = (c->actor_k + 15) / 16;
+    auto served = [&]() {
+        for (int b = 0; b < tiles; ++b)
+            if (__atomic_load_n(l.done + b, __ATOMIC_ACQUIRE) != c->pa_seq) return false;
+        return true;
+    };
+    for (long spins = 0;; ++spins) {
+        if (served()) return 0;
+        if ((spins & 255) == 255 && pactor_ended_count(c) > 0) {
+            // a workgroup is gone (idle timeout just before the doorbell) -- unless it served the request first
+            if (served()) return 0;
+            const int rc = pactor_ring(c, c->actor_k);
+            if (rc) return rc;
+        }
+        if (spins > 500000000L) return fail(FSRL_EHIP, "the resident actor does not answer");
+        __builtin_ia32_pause();
+    }
+}
+
 static int actor_eval_launch(fsrl_ctx* c, const float* obs, int32_t k, bool want_sigma) {
     const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim;
+    c->pa_req = false;
+    if (want_sigma && pactor_ok(c, k)) return pactor_post(c, obs, k);
+    pactor_release(c);                       // a launch behind a live resident kernel would wait for its idle timeout
     // pinned staging [obs | head outputs (2*Da per row) | sigma_param]
     const size_t ob = (size_t)k * Do * 4, mb = (size_t)k * 2 * Da * 4;
     const size_t need = ob + mb + FSRL_MAX_ACT * 4;
@@ -978,6 +1116,17 @@ static int actor_eval_launch(fsrl_ctx* c, const float* obs, int32_t k, bool want
 
 static int actor_eval_finish(fsrl_ctx* c, float* mu_out, float* sigma_out) {
     const int Da = c->cfg.act_dim, k = c->actor_k;
+    if (c->pa_req) {                                    // served by the resident kernel
+        c->pa_req = false;
+        const int rc = pactor_wait(c);
+        if (rc) return rc;
+        const PaLayout l = pa_layout(c);
+        memcpy(mu_out, l.mu, (size_t)k * Da * 4);
+        if (sigma_out)
+            for (int r = 0; r < k; ++r)
+                for (int d = 0; d < Da; ++d) sigma_out[(size_t)r * Da + d] = expf(l.sp[d]);
+        return 0;
+    }
     bool landed = false;
     if (k > 0 && !c->no_spin) {                        // spin on the kernel's completion words (bounded), else synchronise
         landed = true;
@@ -1006,7 +1155,7 @@ extern "C" int fsrl_actor_forward(fsrl_ctx* c, const float* obs, int32_t k, floa
     CHECK_ARG(c && obs && mu_out, "null argument");
     CHECK_ARG(k >= 0, "negative row count");
     CHECK_ARG(!ctx_is_replay(c), "replay contexts: fsrl_sac_actor_forward");
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipSetDevice(c->device));      // keeps a resident actor alive (ENTER_DEV would end it)
     int rc = actor_eval_launch(c, obs, k, sigma_out != nullptr);
     if (rc) return rc;
     return actor_eval_finish(c, mu_out, sigma_out);
@@ -1051,7 +1200,7 @@ extern "C" int fsrl_actor_sample(fsrl_ctx* c, const float* obs, int32_t k, int32
     CHECK_ARG(c && obs && act_out, "null argument");
     CHECK_ARG(k >= 0, "negative row count");
     if (k == 0) return 0;
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipSetDevice(c->device));      // keeps a resident actor alive (ENTER_DEV would end it)
     if (seed) { c->rng[2] ^= seed; c->rng[3] += seed * 0x9E3779B97F4A7C15ull; }
     int rc = actor_eval_launch(c, obs, k, true);
     if (rc) return rc;
@@ -1074,7 +1223,7 @@ extern "C" int fsrl_collect_step(fsrl_ctx* c, const int32_t* env_ids, int32_t k,
     CHECK_ARG(k_act == 0 || (obs_act && act_out), "obs_act / act_out missing");
     CHECK_ARG(bound_method >= 0 && bound_method <= 2, "bound_method: 0 none, 1 clip, 2 tanh");
     CHECK_ARG((act_low == nullptr) == (act_high == nullptr), "act_low and act_high are given together");
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipSetDevice(c->device));      // keeps a resident actor alive (ENTER_DEV would end it)
     int rc = 0;
     if (k_act > 0) {
         rc = actor_eval_launch(c, obs_act, k_act, true);
@@ -1117,7 +1266,7 @@ extern "C" int fsrl_gae_return(fsrl_ctx* c, const float* v, const float* v_next,
     CHECK_ARG(gae_lambda >= 0.0 && gae_lambda <= 1.0, "GAE lambda should be in [0, 1].");
     if (n == 0) return 0;
     CHECK_ARG(v && v_next && rew && end_flag, "null argument");
-    HIPCHK(hipSetDevice(c->device));
+    ENTER_DEV(c);
     // segments: cut after every end_flag (disc = 0 there, so the scan restarts)
     std::vector<int> seg{0};
     std::vector<uint8_t> fl((size_t)n);
@@ -1165,7 +1314,7 @@ extern "C" int fsrl_nstep_return(fsrl_ctx* c, const double* metric, const uint8_
     CHECK_ARG(metric && end_flag && target_q && indices && len > 0, "null argument");
     for (int64_t i = 0; i < (int64_t)n_step * bsz; ++i)
         CHECK_ARG(indices[i] >= 0 && indices[i] < len, "index out of range");
-    HIPCHK(hipSetDevice(c->device));
+    ENTER_DEV(c);
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
     const size_t L = (size_t)len, B = (size_t)bsz, Q = (size_t)q;
     const size_t o_m = 0, o_e = o_m + al(L * 8), o_t = o_e + al(L), o_i = o_t + al(B * Q * 4),
@@ -1201,7 +1350,7 @@ extern "C" int fsrl_nstep_return(fsrl_ctx* c, const double* metric, const uint8_
 // caller's side): drain the stream, clear the state machine.  No-op outside an update.
 extern "C" int fsrl_ppo_abort(fsrl_ctx* c) {
     CHECK_ARG(c, "null ctx");
-    HIPCHK(hipSetDevice(c->device));
+    ENTER_DEV(c);
     if (c->in_update) (void)hipStreamSynchronize(c->compute);
     c->in_update = false; c->verdict_pending = false;
     return 0;
@@ -1233,7 +1382,7 @@ __global__ __launch_bounds__(NT) void floor_kernel(int* sink) {
 extern "C" int fsrl_launch_floors(fsrl_ctx* c, int32_t mb_rows, int32_t iters, double* out_us) {
     CHECK_ARG(c && out_us && mb_rows >= 1 && iters >= 1 && iters <= 100000, "bad argument");
     CHECK_ARG(!c->lay, "launch floors describe the fused three-launch step, not a layered context");
-    HIPCHK(hipSetDevice(c->device));
+    ENTER_DEV(c);
     const int H = c->cfg.hidden, nn = c->md.n_nets;
     const int tiles = (mb_rows + 15) / 16;
     const bool rows4 = tiles * 4 * nn <= c->n_cus, rows8 = !rows4 && tiles * 2 * nn <= c->n_cus;
@@ -1314,7 +1463,7 @@ extern "C" int fsrl_ret_rms_get(fsrl_ctx* c, double* out, int32_t n) {
     CHECK_ARG(c && out, "null argument");
     CHECK_ARG(n == 3 * c->cfg.n_critics, "expected 3 * n_critics = %d doubles", 3 * c->cfg.n_critics);
     if (!c->d_rms) return fail(FSRL_ESTATE, "reward_normalization is off in this context");
-    HIPCHK(hipSetDevice(c->device));
+    ENTER_DEV(c);
     HIPCHK(hipStreamSynchronize(c->compute));
     HIPCHK(hipMemcpy(out, c->d_rms, (size_t)n * 8, hipMemcpyDeviceToHost));
     return 0;
@@ -1325,7 +1474,7 @@ extern "C" int fsrl_ret_rms_set(fsrl_ctx* c, const double* in, int32_t n) {
     if (!c->d_rms) return fail(FSRL_ESTATE, "reward_normalization is off in this context");
     for (int i = 0; i < c->cfg.n_critics; ++i)
         CHECK_ARG(std::isfinite(in[3 * i]) && in[3 * i + 1] >= 0.0 && in[3 * i + 2] >= 0.0, "row %d: var and count must be >= 0", i);
-    HIPCHK(hipSetDevice(c->device));
+    ENTER_DEV(c);
     HIPCHK(hipStreamSynchronize(c->compute));
     HIPCHK(hipMemcpy(c->d_rms, in, (size_t)n * 8, hipMemcpyHostToDevice));
     return 0;

@@ -474,6 +474,98 @@ __global__ __launch_bounds__(4 * H) void mlp_infer_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------- the collector's actor, resident for the length of a collect (r6)
+// Up to PACTOR_BLOCKS workgroups (one per 16-row tile of the vector env) that stay on their CUs between the vector steps of a collect
+// instead of one launch per step: the host rings a DOORBELL in pinned memory ({k rows, sequence number} in one 8-byte word, after
+// writing the k observations next to it), thread 0 of every workgroup polls it with system-scope loads, workgroup b runs the actor
+// over rows 16 b .. of the request (if it has any) and writes the head outputs and its completion word back to pinned memory, where
+// the host spins on them.  The W2 fragment (registers) and the small parameters (LDS) are loaded ONCE per launch -- parameters only
+// change in launches that are behind this kernel in stream order.  The arithmetic is mlp_infer_kernel's (same staging, same
+// tile_forward, same head): bit-identical actions.
+// A workgroup ends on the EXIT command (k = ~0: the host rings it before it enqueues anything else on the stream) and BY ITSELF
+// after `timeout_ticks` of the 100 MHz wall clock without a doorbell (or 2^26 polls), so that a host that went away never leaves it
+// behind; it then stores its generation number in state[b], which the host checks before it trusts a doorbell to be heard.
+#define PACTOR_BLOCKS 4
+struct PActorArgs {
+    const float* obs;                 // pinned [16 * blocks rows][Do]
+    float* mu_out;                    // pinned [16 * blocks rows][Da]
+    float* sigma_param_out;           // pinned [Da]
+    const unsigned long long* bell;   // pinned: (k << 32) | seq
+    unsigned* done;                   // pinned [blocks]: seq of the last request workgroup b served
+    unsigned* state;                  // pinned [blocks]: generation of the last kernel whose workgroup b ended
+    unsigned gen, last_seq;
+    unsigned long long timeout_ticks;
+    float max_action;
+};
+#define PACTOR_EXIT 0xFFFFFFFFu
+
+template <int H>
+__global__ __launch_bounds__(4 * H) void actor_resident_kernel(const float* __restrict__ P, const ModelDesc md, const PActorArgs a) {
+    __shared__ TileSmem<H> sm;
+    __shared__ unsigned k_s, seq_s;
+    __shared__ unsigned last_s;                                  // the last sequence number seen (thread 0's; in LDS: the kernel sits at its register cap)
+    constexpr int NT = TileGeom<H>::NT;
+    constexpr int NX = TileStage<H>::NX;
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    const NetOff no = md.net[0];
+    const int Do = md.Do;
+    const unsigned magic = div_magic(Do);
+    TileStage<H> stg;
+    stg.issue(P, no, Do, md.Da, P, nullptr, 0, tid);          // the small parameters; no rows yet (n_valid = 0: the x loads are masked)
+    FwdW2Frag<H> wf;
+    wf.load(P + no.W2f, tid >> 6, tid & 63);
+    stg.commit(sm, no, Do, tid);
+    if (tid == 0) last_s = a.last_seq;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long t0 = wall_clock64();
+            const unsigned last = last_s;
+            unsigned long long v;
+            unsigned polls = 0;
+            for (;;) {
+                v = __hip_atomic_load(a.bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((unsigned)v != last) break;
+                if (wall_clock64() - t0 > a.timeout_ticks || ++polls > (1u << 26)) { v = (unsigned long long)PACTOR_EXIT << 32; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);             // system scope: the observations were written before the doorbell
+            k_s = (unsigned)(v >> 32); seq_s = (unsigned)v;
+            last_s = (unsigned)v;
+        }
+        __syncthreads();
+        const unsigned k = k_s;
+        if (k == PACTOR_EXIT) break;
+        const int row0 = blk * 16, n_valid = min(16, (int)k - row0);
+        if (n_valid <= 0) continue;                              // this request has no rows for this workgroup (block-uniform)
+        const float* xrow = a.obs + row0 * Do;                   // block-uniform (scalar registers)
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int e = tid + u * NT;
+            if (e < 16 * Do) {
+                const float x = (e < n_valid * Do)              // rows are contiguous; past the caches (host memory, rewritten between requests)
+                    ? __hip_atomic_load(xrow + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0f;
+                const int i = div_by_magic((unsigned)e, magic), kk = e - i * Do;
+                sm.xT[kk * 16 + i] = x;
+            }
+        }
+        __syncthreads();
+        tile_forward<H>(sm, P, no, Do, tid, wf);
+        if (blk == 0 && tid < md.Da && no.sigma >= 0) a.sigma_param_out[tid] = sm.sig[tid];
+        if (tid < n_valid) {
+            const int r = row0 + tid;
+            for (int d = 0; d < md.Da; ++d) {
+                const float x = sm.out[tid * FSRL_MAX_ACT + d];
+                a.mu_out[r * md.Da + d] = md.unbounded ? x : a.max_action * tanhf(x);
+            }
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.done + blk, seq_s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (tid == 0) __hip_atomic_store(a.state + blk, a.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---------------------------------------------------------------- fused fwd + loss + bwd
 // One PPO minibatch step, activation side.  1-D grid of 8*slots blocks mapped to
 // (network, 16-row tile) by xcd_assign(); block = 4*H threads.

@@ -324,6 +324,15 @@ class Engine:
         return dict(steps=int(steps.value), total_cost=float(cost.value), terminated=int(nt.value), truncated=int(ntr.value),
                     ep_rews=ep_rew[:k], ep_lens=ep_len[:k], t_env=float(tm[0]), t_act=float(tm[1]))
 
+    def actor_set_resident(self, on=True, idle_timeout_us=0.0):
+        """The collector's actor as a resident workgroup (include/fsrl_hip.h: fsrl_actor_set_resident); on by default."""
+        _lib.check(self.lib.fsrl_actor_set_resident(self._ctx, int(bool(on)), float(idle_timeout_us)))
+
+    def actor_resident_stats(self):
+        out = np.zeros(3, np.int64)
+        _lib.check(self.lib.fsrl_actor_resident_stats(self._ctx, _ptr(out, _i64p)))
+        return dict(launches=int(out[0]), requests=int(out[1]), live=bool(out[2]))
+
     def store_sizes(self, n=None):
         n = self.cfg.env_num if n is None else int(n)
         out = np.empty(n, np.int64)

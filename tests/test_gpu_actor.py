@@ -261,3 +261,77 @@ def test_native_collect_fails_fast_on_a_dead_worker_and_leaves_the_env_object_co
         eng.close()
     finally:
         env.close()
+
+
+def _mk_engine(resident, hidden=256, obs_dim=8, act_dim=2, unbounded=False):
+    from fsrl_amd.engine import Engine, EngineConfig
+    eng = Engine(EngineConfig(obs_dim=obs_dim, act_dim=act_dim, hidden=hidden, env_num=64, max_grad_norm=0.5, target_kl=None,
+                              unbounded=unbounded))
+    eng.actor_set_resident(resident, idle_timeout_us=2.0e5)      # 0.2 s: the launch counts below do not depend on first-launch code loading
+    rng = np.random.default_rng(3)
+    eng.set_params((0.2 * rng.standard_normal(eng.n_params)).astype(np.float32))
+    return eng
+
+
+@pytest.mark.parametrize("hidden,obs_dim,act_dim,unbounded", [(256, 8, 2, False), (128, 27, 8, False), (64, 60, 2, True)])
+def test_resident_actor_gives_the_launched_actors_actions_bit_for_bit(hidden, obs_dim, act_dim, unbounded):
+    """fsrl_actor_set_resident: the collector's actor as one workgroup that stays on its CU between calls (doorbell in pinned
+    memory) against one kernel launch per call -- same library RNG stream, same mean / sigma: identical actions for every row count
+    (one tile, ragged second tile, the cap of four tiles, beyond it: the launch path), across a parameter upload (the resident kernel
+    holds the weights in registers: the upload must end it) and across its idle timeout (it ends by itself, the next call
+    launches another)."""
+    import time
+    a, b = _mk_engine(True, hidden, obs_dim, act_dim, unbounded), _mk_engine(False, hidden, obs_dim, act_dim, unbounded)
+    rng = np.random.default_rng(5)
+    ks = [1, 16, 20, 33, 64, 7, 65, 20, 20]
+    for i, k in enumerate(ks):
+        obs = rng.standard_normal((k, obs_dim)).astype(np.float32)
+        xa, xb = a.actor_sample(obs, seed=9 if i == 0 else 0), b.actor_sample(obs, seed=9 if i == 0 else 0)
+        assert np.isfinite(xa).all() and np.array_equal(xa, xb), (i, k)
+        ma, mb = a.actor_forward(obs), b.actor_forward(obs)
+        assert np.array_equal(ma[0], mb[0]) and np.array_equal(ma[1], mb[1]), (i, k)
+    st = a.actor_resident_stats()
+    assert st["requests"] == 2 * (len(ks) - 1) and st["live"], st           # k = 65 went down the launch path (and ended the resident kernel)
+    assert 2 <= st["launches"] <= 6, st      # one before it, one after (+ idle timeouts while the other engine's first launches load code)
+    assert b.actor_resident_stats() == dict(launches=0, requests=0, live=False)
+    # a parameter upload between two calls: the next call sees the new weights
+    th = (0.2 * np.random.default_rng(8).standard_normal(a.n_params)).astype(np.float32)
+    a.set_params(th); b.set_params(th)
+    assert not a.actor_resident_stats()["live"]
+    obs = rng.standard_normal((20, obs_dim)).astype(np.float32)
+    ma, mb = a.actor_forward(obs), b.actor_forward(obs)
+    assert np.array_equal(ma[0], mb[0]) and a.actor_resident_stats()["launches"] == st["launches"] + 1
+    # idle timeout: the kernel ends by itself, the host finds out at the next call
+    a.actor_set_resident(True, idle_timeout_us=300.0)
+    for rep in range(3):
+        ma = a.actor_forward(obs)
+        assert np.array_equal(ma[0], mb[0])
+        time.sleep(0.02)
+    assert a.actor_resident_stats()["launches"] == st["launches"] + 4, a.actor_resident_stats()
+    a.sync()                                                                  # nothing is left running on the stream
+    a.close(); b.close()
+
+
+def test_resident_actor_survives_updates_between_collects():
+    """collect (resident actor) -> PPO update -> collect: the update's launches are ordered behind the resident kernel's end, the
+    second collect's actor runs the updated weights; identical to the one-launch-per-call actor throughout."""
+    outs = []
+    for resident in (True, False):
+        eng = _mk_engine(resident, 64)
+        rng = np.random.default_rng(1)
+        acts = []
+        for cyc in range(3):
+            obs = rng.standard_normal((8, 8)).astype(np.float32)
+            for t in range(40):
+                act = eng.actor_sample(obs, seed=4 if (cyc == 0 and t == 0) else 0)
+                nxt = (0.9 * obs + 0.1 * rng.standard_normal((8, 8))).astype(np.float32)
+                done = np.full(8, t == 39)
+                eng.push(np.arange(8), obs, act, rng.normal(0.5, 0.5, 8), (rng.random(8) < 0.1).astype(np.float64),
+                         np.zeros(8, bool), done, nxt)
+                acts.append(act.copy()); obs = nxt
+            eng.ppo_update(np.array([0.5]), 1.0 / 1.5, 64, 2, perms=[rng.permutation(320) for _ in range(2)])
+            eng.reset_store()
+        outs.append((np.stack(acts), eng.get_params(), eng.actor_resident_stats()))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert 3 <= outs[0][2]["launches"] <= 6 and outs[0][2]["requests"] == 120, outs[0][2]
