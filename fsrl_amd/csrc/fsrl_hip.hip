@@ -947,6 +947,7 @@ static bool ctx_is_replay(const fsrl_ctx* c) { return c->cfg.algo == FSRL_ALGO_S
 static int sac_actor_launch(fsrl_ctx* c, const float* h_obs, float* h_raw, int k);                 // defined with the SAC code
 static void sac_actor_finish(fsrl_ctx* c, const float* h_raw, int k, float* mu_out, float* sigma_out);
 static bool sac_squashes(fsrl_ctx* c);
+static bool sac_actor_resident_args(fsrl_ctx* c, const float** P, const ModelDesc** md);   // false: no fused actor (layered / not initialised)
 
 // ---- the resident actor (actor_resident_kernel, kernels_mlp.hpp).  Protocol, host side:
 //   post:    [wait until every workgroup of every earlier generation has reported its end] -> launch generation g if none is live ->
@@ -962,13 +963,16 @@ static PaLayout pa_layout(const fsrl_ctx* c) {
     l.bell = (unsigned long long*)b; l.done = (unsigned*)(b + 16); l.state = (unsigned*)(b + 32);
     l.obs = (float*)(b + 64);
     l.mu = l.obs + (size_t)c->pa_cap * c->cfg.obs_dim;
-    l.sp = l.mu + (size_t)c->pa_cap * c->cfg.act_dim;
+    l.sp = l.mu + (size_t)c->pa_cap * 2 * c->cfg.act_dim;        // replay contexts: [mu | log sigma] per row
     return l;
 }
 
 static bool pactor_ok(const fsrl_ctx* c, int k) {
     const int blocks = std::min(PACTOR_BLOCKS, std::max(1, (c->cfg.env_num + 15) / 16));
-    return c->pa_on && !c->no_spin && !c->lay && !c->group && c->cfg.algo != FSRL_ALGO_SAC_LAG && k >= 1 && k <= 16 * blocks;
+    if (!(c->pa_on && !c->no_spin && !c->lay && !c->group && k >= 1 && k <= 16 * blocks)) return false;
+    if (c->cfg.algo != FSRL_ALGO_SAC_LAG) return true;
+    const float* P; const ModelDesc* md;
+    return sac_actor_resident_args(const_cast<fsrl_ctx*>(c), &P, &md);      // replay contexts: their fused actor network
 }
 
 static void pactor_release(fsrl_ctx* c) {
@@ -1007,9 +1011,16 @@ static int pactor_launch(fsrl_ctx* c, unsigned last_seq) {
     a.gen = c->pa_gen; a.last_seq = last_seq; a.max_action = c->cfg.max_action;
     a.timeout_ticks = (unsigned long long)(c->pa_idle_us * 100.0);            // wall_clock64: 100 MHz
     c->pa_blocks = std::min(PACTOR_BLOCKS, std::max(1, (c->cfg.env_num + 15) / 16));
+    const float* P = c->P; const ModelDesc* md = &c->md;
+    if (c->cfg.algo == FSRL_ALGO_SAC_LAG) {                                    // the replay agents' actor: raw head outputs, as sac_actor_launch
+        if (!sac_actor_resident_args(c, &P, &md)) return fail(FSRL_ESTATE, "no fused actor network");
+        a.raw_cols = 2 * c->cfg.act_dim; a.max_action = 1.0f;
+    }
+    const ModelDesc mdv = *md;
     const int rc = dispatch_H(c->cfg.hidden, [&](auto hc) {
         constexpr int H = decltype(hc)::value;
-        hipLaunchKernelGGL(actor_resident_kernel<H>, dim3(c->pa_blocks), dim3(4 * H), 0, c->compute, c->P, c->md, a);
+        if (a.raw_cols > 0) hipLaunchKernelGGL((actor_resident_kernel<H, true>), dim3(c->pa_blocks), dim3(4 * H), 0, c->compute, P, mdv, a);
+        else hipLaunchKernelGGL((actor_resident_kernel<H, false>), dim3(c->pa_blocks), dim3(4 * H), 0, c->compute, P, mdv, a);
         HIPCHK(hipGetLastError());
         return 0;
     });
@@ -1036,7 +1047,7 @@ static int pactor_post(fsrl_ctx* c, const float* obs, int k) {
     const int Do = c->cfg.obs_dim, Da = c->cfg.act_dim;
     if (!c->h_pa) {
         c->pa_cap = 16 * PACTOR_BLOCKS;
-        const size_t bytes = 64 + ((size_t)c->pa_cap * (Do + Da) + FSRL_MAX_ACT) * 4;
+        const size_t bytes = 64 + ((size_t)c->pa_cap * (Do + 2 * Da) + FSRL_MAX_ACT) * 4;
         HIPCHK(hipHostMalloc(&c->h_pa, bytes));
         memset(c->h_pa, 0, bytes);
     }
@@ -1121,6 +1132,7 @@ static int actor_eval_finish(fsrl_ctx* c, float* mu_out, float* sigma_out) {
         const int rc = pactor_wait(c);
         if (rc) return rc;
         const PaLayout l = pa_layout(c);
+        if (ctx_is_replay(c)) { sac_actor_finish(c, l.mu, k, mu_out, sigma_out); return 0; }
         memcpy(mu_out, l.mu, (size_t)k * Da * 4);
         if (sigma_out)
             for (int r = 0; r < k; ++r)

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(4 * H) void mlp_infer_kernel(const float* __restric
 #define PACTOR_BLOCKS 4
 struct PActorArgs {
     const float* obs;                 // pinned [16 * blocks rows][Do]
-    float* mu_out;                    // pinned [16 * blocks rows][Da]
+    float* mu_out;                    // pinned [16 * blocks rows][Da]; raw_cols > 0 (replay contexts' actors): [rows][raw_cols] raw head outputs
     float* sigma_param_out;           // pinned [Da]
     const unsigned long long* bell;   // pinned: (k << 32) | seq
     unsigned* done;                   // pinned [blocks]: seq of the last request workgroup b served
@@ -496,10 +496,11 @@ struct PActorArgs {
     unsigned gen, last_seq;
     unsigned long long timeout_ticks;
     float max_action;
+    int raw_cols;
 };
 #define PACTOR_EXIT 0xFFFFFFFFu
 
-template <int H>
+template <int H, bool RAW>
 __global__ __launch_bounds__(4 * H) void actor_resident_kernel(const float* __restrict__ P, const ModelDesc md, const PActorArgs a) {
     __shared__ TileSmem<H> sm;
     __shared__ unsigned k_s, seq_s;
@@ -551,12 +552,19 @@ __global__ __launch_bounds__(4 * H) void actor_resident_kernel(const float* __re
         }
         __syncthreads();
         tile_forward<H>(sm, P, no, Do, tid, wf);
-        if (blk == 0 && tid < md.Da && no.sigma >= 0) a.sigma_param_out[tid] = sm.sig[tid];
-        if (tid < n_valid) {
-            const int r = row0 + tid;
-            for (int d = 0; d < md.Da; ++d) {
-                const float x = sm.out[tid * FSRL_MAX_ACT + d];
-                a.mu_out[r * md.Da + d] = md.unbounded ? x : a.max_action * tanhf(x);
+        if constexpr (RAW) {                                     // SAC-Lag / DDPG-Lag / CVPO: [mu | log sigma] as the head left them
+            for (int e = tid; e < n_valid * a.raw_cols; e += NT) {
+                const int i = e / a.raw_cols, o = e - i * a.raw_cols;
+                a.mu_out[(row0 + i) * a.raw_cols + o] = sm.out[i * FSRL_MAX_ACT + o];
+            }
+        } else {
+            if (blk == 0 && tid < md.Da && no.sigma >= 0) a.sigma_param_out[tid] = sm.sig[tid];
+            if (tid < n_valid) {
+                const int r = row0 + tid;
+                for (int d = 0; d < md.Da; ++d) {
+                    const float x = sm.out[tid * FSRL_MAX_ACT + d];
+                    a.mu_out[r * md.Da + d] = md.unbounded ? x : a.max_action * tanhf(x);
+                }
             }
         }
         __threadfence_system();

@@ -234,7 +234,7 @@ int fsrl_collect_episodes_split(fsrl_ctx* ctx, fsrl_shm_env* env, const int32_t*
                                 double* ep_rew_out, int32_t* ep_len_out, int32_t* episodes_out);
 /* out2[0] = seconds the last fsrl_collect_episodes[_split] waited for the env workers, out2[1] = seconds in its store + actor calls */
 int fsrl_collect_timing(fsrl_ctx* ctx, double* out2);
-/* The collector's actor as a RESIDENT workgroup (on-policy contexts with the fused two-layer networks, up to 64 rows per call):
+/* The collector's actor as a RESIDENT workgroup (contexts with the fused two-layer networks, up to 64 rows per call):
  * instead of one kernel launch per vector step (fast_collector.py:283-300: `self.policy(self.data, last_state)` per step) one
  * workgroup stays on its CU for the length of a collect; the host rings a doorbell in pinned memory with the observations next to
  * it and spins on a completion word.  The kernel ends on the next library call that enqueues other work on the context's stream

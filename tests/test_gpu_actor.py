@@ -335,3 +335,48 @@ def test_resident_actor_survives_updates_between_collects():
         eng.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert 3 <= outs[0][2]["launches"] <= 6 and outs[0][2]["requests"] == 120, outs[0][2]
+
+
+@pytest.mark.parametrize("kind", ["sac", "ddpg", "cvpo"])
+def test_resident_actor_of_the_replay_agents_is_the_launched_one_bit_for_bit(kind):
+    """The replay agents' collector actor (raw head outputs [mu | log sigma], sac_lag.py:155-183) through the resident kernel against
+    one launch per call: identical (mu, sigma) and identical sampled actions for every row count, before and after updates (the
+    update's launches end the resident kernel; the next call runs the updated actor)."""
+    from fsrl_amd import _lib
+    from fsrl_amd.engine import Engine, EngineConfig
+    E, sub, Do, Da, B = 24, 64, 11, 3, 64
+    outs = []
+    for resident in (True, False):
+        eng = Engine(EngineConfig(algo=_lib.ALGO_SAC_LAG, obs_dim=Do, act_dim=Da, hidden_sizes=(128, 128), n_critics=2, env_num=E,
+                                  buffer_size=E * sub, gamma=0.99, target_kl=None))
+        if kind == "cvpo":
+            eng.cvpo_init(10.0, n_step=2)
+        else:
+            eng.sac_init(n_step=2, deterministic=(kind == "ddpg"))
+        eng.actor_set_resident(resident, idle_timeout_us=2.0e5)
+        rng = np.random.default_rng(4)
+        got = []
+        for cyc in range(2):
+            for t in range(30):
+                k = E if t % 3 else int(rng.integers(1, E + 1))
+                obs = rng.standard_normal((k, Do)).astype(np.float32)
+                mu, sg = eng.sac_actor_forward(obs)
+                act = eng.actor_sample(obs, seed=6 if (cyc == 0 and t == 0) else 0)
+                assert np.isfinite(mu).all() and np.isfinite(sg).all() and np.isfinite(act).all()
+                got += [mu.copy(), sg.copy(), act.copy()]
+                eng.push(np.arange(k), obs, np.clip(act, -1, 1), rng.standard_normal(k), (rng.random(k) < 0.2).astype(np.float64),
+                         rng.random(k) < 0.05, rng.random(k) < 0.05, rng.standard_normal((k, Do)).astype(np.float32))
+            for u in range(3):
+                if kind == "cvpo":
+                    eng.cvpo_update(B, seed=5 if (cyc == 0 and u == 0) else 0)
+                else:
+                    eng.sac_update(B, [0.3], 1 / 1.3, seed=5 if (cyc == 0 and u == 0) else 0)
+        st = eng.actor_resident_stats()
+        outs.append((got, eng.sac_get_params(0)[0].copy(), st))
+        eng.close()
+    assert len(outs[0][0]) == len(outs[1][0])
+    for x, y in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2]["requests"] == 120 and 2 <= outs[0][2]["launches"] <= 6, outs[0][2]
+    assert outs[1][2] == dict(launches=0, requests=0, live=False)

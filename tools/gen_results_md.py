@@ -111,7 +111,10 @@ def build(tag):
                            ("end_to_end_host_actor", "the same with the host torch actor")):
             e = b.get(key)
             if isinstance(e, dict) and "env_steps_per_s" in e:
-                add(f"| {label} | {fmt(e['env_steps_per_s'], 0)} env-steps/s ({fmt(e['update_ms_per_collect'], 2)} ms update per collect) |")
+                ar = e.get("actor_resident")
+                res = (f"; resident actor: {ar['per_collect']:g} kernel launch(es) per collect, {ar['calls_served']} calls through the doorbell"
+                       if isinstance(ar, dict) else "")
+                add(f"| {label} | {fmt(e['env_steps_per_s'], 0)} env-steps/s ({fmt(e['update_ms_per_collect'], 2)} ms update per collect{res}) |")
         for e in b.get("end_to_end_shmem", []) or []:
             if isinstance(e, dict) and "env_steps_per_s" in e:
                 bound = e.get("env_bound_env_steps_per_s")
