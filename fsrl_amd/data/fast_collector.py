@@ -16,11 +16,17 @@ from fsrl_amd.data.batch import Batch
 
 class FastCollector:
     def __init__(self, policy, env, buffer=None, preprocess_fn=None, exploration_noise: bool = False,
-                 device_actor: bool = False, fused_step: bool = True, split_phase=False, native_loop: bool = True):
+                 device_actor: bool = False, fused_step: bool = True, split_phase=False, native_loop: bool = True,
+                 resident_actor: Optional[bool] = None):
         # device_actor=True: actions come from fsrl_actor_sample (actor on the MI355X, library RNG) and rows go
         # straight to fsrl_store_push -- no torch call and no Batch objects per vector step.  False keeps the
         # host mirror of the actor with torch's random stream (what the reference consumes).
         self.device_actor = device_actor and getattr(policy, "engine", None) is not None
+        # resident_actor (device_actor only; None = the library's default, on): the actor kernel stays on the device for the length of a
+        # collect and is rung through a doorbell in pinned memory instead of being launched once per vector step
+        # (fsrl_actor_set_resident, include/fsrl_hip.h).  Same actions either way.
+        if self.device_actor and resident_actor is not None:
+            policy.engine.actor_set_resident(bool(resident_actor))
         # fused_step (device_actor only): one fsrl_collect_step per vector step instead of fsrl_actor_sample + fsrl_store_push
         self.fused_step = fused_step
         # native_loop (device_actor + fused_step over the worker-process env).  True: a collect(n_episode) is ONE library call
