@@ -380,3 +380,35 @@ def test_resident_actor_of_the_replay_agents_is_the_launched_one_bit_for_bit(kin
     assert np.array_equal(outs[0][1], outs[1][1])
     assert outs[0][2]["requests"] == 120 and 2 <= outs[0][2]["launches"] <= 6, outs[0][2]
     assert outs[1][2] == dict(launches=0, requests=0, live=False)
+
+
+def test_resident_actor_calls_spaced_around_its_idle_timeout():
+    """The end / relaunch protocol under its race: calls 0.6 .. 1.4 idle timeouts apart, so that workgroups give up while a doorbell is
+    being rung (the host then ends the rest, launches the next generation and rings again), 1 .. 64 rows (one to four workgroups have
+    rows), a parameter upload in the middle.  Every answer equals the one-launch-per-call actor's; tools/diag/resident_soak.py is the long
+    form (150 000 calls: profiles/r06_resident_actor_ab.txt)."""
+    import time
+    a, b = _mk_engine(True), _mk_engine(False)
+    a.actor_set_resident(True, idle_timeout_us=120.0)
+    rng = np.random.default_rng(2)
+    pool = [rng.standard_normal((64, 8)).astype(np.float32) for _ in range(4)]
+    thetas = [(0.2 * rng.standard_normal(a.n_params)).astype(np.float32) for _ in range(2)]
+    want = {}
+    for ti, th in enumerate(thetas):
+        b.set_params(th)
+        for pi, o in enumerate(pool):
+            want[(ti, pi)] = b.actor_forward(o)[0].copy()
+    n = 6000
+    for i in range(n):
+        ti = int(i >= n // 2)
+        if i in (0, n // 2):
+            a.set_params(thetas[ti])
+        gap = rng.uniform(0.6, 1.4) * 120e-6 if i % 3 else 0.0
+        t = time.perf_counter()
+        while time.perf_counter() - t < gap:
+            pass
+        pi, k = int(rng.integers(0, 4)), int(rng.integers(1, 65))
+        assert np.array_equal(a.actor_forward(pool[pi][:k])[0], want[(ti, pi)][:k]), (i, k)
+    st = a.actor_resident_stats()
+    assert st["requests"] == n and 100 < st["launches"] < n, st          # the timeouts did fire, and not before every call
+    a.close(); b.close()
