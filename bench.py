@@ -270,6 +270,10 @@ def env_bound(envs, workers, busy_us, cpus):
     return envs / (-(-envs // lanes) * busy_us * 1e-6)
 
 
+def eng_cfg_obs(agent):
+    return int(agent.policy.engine.cfg.obs_dim)
+
+
 def end_to_end(local_rank, seed, seconds=6.0, device_actor=False, workers=0, busy_us=0.0, envs=ENVS, cap_workers=False):
     """Secondary figure (outside the timed region): the whole training loop of
     OnpolicyAgent.learn -- host collector over a SYNTHETIC SafetyCarCircle-shaped vector env
@@ -333,6 +337,19 @@ def end_to_end(local_rank, seed, seconds=6.0, device_actor=False, workers=0, bus
         st = agent.policy.engine.actor_resident_stats()
         out["actor_resident"] = {"kernel_launches": st["launches"], "calls_served": st["requests"],
                                  "per_collect": round(st["launches"] / max(collects, 1), 2)}
+        if workers == 0:    # ... and what one actor call of this vector env costs, resident against one launch per call (2 x 2000 calls)
+            eng_, obs_ = agent.policy.engine, np.zeros((envs, eng_cfg_obs(agent)), np.float32)
+            us = {}
+            for name, on in (("resident", True), ("launched", False)):
+                eng_.actor_set_resident(on)
+                for _ in range(200):
+                    eng_.actor_sample(obs_)
+                t0 = time.perf_counter()
+                for _ in range(2000):
+                    eng_.actor_sample(obs_)
+                us[name] = round((time.perf_counter() - t0) / 2000 * 1e6, 2)
+            eng_.actor_set_resident(True)
+            out["actor_call_us"] = us
     agent.policy.engine.close()
     if hasattr(env, "close"):
         env.close()

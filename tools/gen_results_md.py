@@ -115,6 +115,9 @@ def build(tag):
                 res = (f"; resident actor: {ar['per_collect']:g} kernel launch(es) per collect, {ar['calls_served']} calls through the doorbell"
                        if isinstance(ar, dict) else "")
                 add(f"| {label} | {fmt(e['env_steps_per_s'], 0)} env-steps/s ({fmt(e['update_ms_per_collect'], 2)} ms update per collect{res}) |")
+                ac = e.get("actor_call_us")
+                if isinstance(ac, dict) and "resident" in ac:
+                    add(f"| one device-actor call of that vector env (`fsrl_actor_sample`, {e.get('envs', 20)} rows, through ctypes) | {fmt(ac['resident'], 1)} us resident, {fmt(ac['launched'], 1)} us with one kernel launch per call |")
         for e in b.get("end_to_end_shmem", []) or []:
             if isinstance(e, dict) and "env_steps_per_s" in e:
                 bound = e.get("env_bound_env_steps_per_s")
