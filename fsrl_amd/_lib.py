@@ -147,6 +147,7 @@ SIGNATURES = {
     "fsrl_collect_timing": (C.c_int, [_ctx, _d]),
     "fsrl_actor_set_resident": (C.c_int, [_ctx, C.c_int32, C.c_double]),
     "fsrl_actor_resident_stats": (C.c_int, [_ctx, _i64]),
+    "fsrl_actor_release": (C.c_int, [_ctx]),
     "fsrl_collect_run": (C.c_int, [_ctx, _P(ShmEnv), _i32, C.c_int32, _f, _f, _f, C.c_int32, C.c_int32, _f, _f, C.c_int32, _i32, _d, _d, _d,
                                   _u8, _u8, _f]),
     "fsrl_store_sizes": (C.c_int, [_ctx, _i64, C.c_int32]),

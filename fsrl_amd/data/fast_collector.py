@@ -80,6 +80,16 @@ class FastCollector:
     # ------------------------------------------------------------------ collect
     def collect(self, n_episode: int = 1, random: bool = False, render: bool = False,
                 no_grad: bool = True, gym_reset_kwargs: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
+        """fsrl/data/fast_collector.py:252-368.  With the actor on the device the resident actor kernel (fsrl_actor_set_resident) lives
+        for the length of this call: the native loops end it themselves, the interpreted ones through fsrl_actor_release here."""
+        try:
+            return self._collect(n_episode, random, render, no_grad, gym_reset_kwargs)
+        finally:
+            if self.device_actor:
+                self.policy.engine.actor_release()
+
+    def _collect(self, n_episode: int = 1, random: bool = False, render: bool = False,
+                 no_grad: bool = True, gym_reset_kwargs: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
         if n_episode is None:
             raise TypeError("Please specify n_episode in FastCollector.collect().")
         assert n_episode > 0

@@ -328,6 +328,10 @@ class Engine:
         """The collector's actor as a resident workgroup (include/fsrl_hip.h: fsrl_actor_set_resident); on by default."""
         _lib.check(self.lib.fsrl_actor_set_resident(self._ctx, int(bool(on)), float(idle_timeout_us)))
 
+    def actor_release(self):
+        """End the resident actor kernel now (a collect is over) instead of at the next stream work / its idle timeout."""
+        self.lib.fsrl_actor_release(self._ctx)
+
     def actor_resident_stats(self):
         out = np.zeros(3, np.int64)
         _lib.check(self.lib.fsrl_actor_resident_stats(self._ctx, _ptr(out, _i64p)))

@@ -243,6 +243,8 @@ int fsrl_collect_timing(fsrl_ctx* ctx, double* out2);
 int fsrl_actor_set_resident(fsrl_ctx* ctx, int32_t on, double idle_timeout_us);
 /* out3 = {resident kernels launched, actor calls served through the doorbell, 1 if a resident kernel is live}                  */
 int fsrl_actor_resident_stats(fsrl_ctx* ctx, int64_t* out3);
+/* end the resident kernel now (the caller's collect is over); a no-op when none is live.  Never needed for correctness.           */
+int fsrl_actor_release(fsrl_ctx* ctx);
 
 /* Fill level of the first n sub-buffers (len(buffer.buffers[e]); ReplayBufferManager.sample_indices weighs by it). */
 int fsrl_store_sizes(const fsrl_ctx* ctx, int64_t* sizes_out, int32_t n);
